@@ -1,0 +1,123 @@
+/* tmdnet_amd.h -- C ABI of the MI355X-native TensorNet energy+force engine (libtmdnet_amd.so).
+ *
+ * Drop-in boundary.  The reference has no C FFI of its own on this path:
+ * its "native" seam is a set of torch custom ops written in NVIDIA Warp
+ * (torchmdnet/extensions/ops.py:14-106, the files under torchmdnet/extensions/warp_ops/) below the Python
+ * surface create_model / load_model / TorchMD_Net.forward (torchmdnet/models/model.py:21,208,530).
+ * This header is what a binding for that path binds instead: plain pointers and sizes, no torch
+ * types.  The host side in torchmd-net_amd/torchmdnet_amd/ calls it through ctypes (see
+ * INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every `const float*` / `const int64_t*` data pointer is a DEVICE pointer (HIP, gfx950) unless
+ *     the parameter name ends in `_host`; all tensors are dense row-major fp32 / int64.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  Calls enqueue work and return;
+ *     only tmdnet_build_graph synchronises the stream (it reads back three integers, the analogue
+ *     of the reference's `resize_to_fit` host sync, torchmdnet/models/utils.py:303-307).
+ *   - no hidden device allocation happens inside build_graph / energy_forces: the caller owns both
+ *     workspaces (size them with the *_workspace_bytes queries).
+ *   - a handle is re-entrant across handles but not thread-safe on one handle.
+ *   - return value: 0 on success, a TMDNET_ERR_* code otherwise; tmdnet_last_error() gives text.
+ */
+#ifndef TMDNET_AMD_H
+#define TMDNET_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMDNET_OK 0
+#define TMDNET_ERR_INVALID 1   /* bad argument / unknown parameter / wrong size */
+#define TMDNET_ERR_HIP 2       /* a HIP runtime call failed */
+#define TMDNET_ERR_OVERFLOW 3  /* more neighbour pairs than max_num_neighbors * n_atoms:
+                                  the reference raises RuntimeError here (models/utils.py:297-300) */
+#define TMDNET_ERR_WORKSPACE 4 /* caller workspace too small */
+#define TMDNET_ERR_STATE 5     /* call order violated (e.g. parameters not finalised) */
+
+typedef struct tmdnet_model tmdnet_model; /* opaque */
+
+/* Hyper-parameters of TensorNet + Scalar head: the subset of the reference's create_model argument
+ * dict that the path depends on (torchmdnet/models/model.py:35-60,96-105,134-152). */
+typedef struct tmdnet_hparams {
+  int32_t hidden_channels;   /* embedding_dimension (F) */
+  int32_t num_layers;        /* interaction layers (L) */
+  int32_t num_rbf;           /* ExpNormal radial basis size (K) */
+  int32_t max_z;             /* rows of the atom-type embedding */
+  int32_t max_num_neighbors; /* pair capacity = max_num_neighbors * n_atoms (tensornet.py:281-290) */
+  int32_t group_o3;          /* 1: O(3) (Y M + M Y), 0: SO(3) (2 Y M)   (tensornet.py:788-793) */
+  int32_t head_hidden;       /* Scalar head hidden width (F/2, output_modules.py:96-103) */
+  int32_t has_atomref;       /* 1: an "atomref" table [max_z] is added per atom (priors/atomref.py:93-96) */
+  float cutoff_lower;
+  float cutoff_upper;
+} tmdnet_hparams;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out);
+int tmdnet_destroy(tmdnet_model* m);
+const char* tmdnet_last_error(const tmdnet_model* m);
+const char* tmdnet_version(void);
+
+/* Parameters are addressed by the reference's state-dict keys without the "model." prefix
+ * (SURVEY.md Appendix A), e.g. "representation_model.layers.0.linears_scalar.2.weight", plus
+ * "mean", "std" and "atomref".  `data_host` is HOST memory, row-major, `numel` floats; it is copied.
+ * tmdnet_finalize_params checks that every tensor is present with the expected size, builds the
+ * transposed copies used by the reverse pass and uploads one packed device buffer. */
+int tmdnet_set_param(tmdnet_model* m, const char* name, const float* data_host, int64_t numel);
+int tmdnet_finalize_params(tmdnet_model* m);
+/* number of parameter tensors the model expects; name of the idx-th one and its element count */
+int tmdnet_num_params(const tmdnet_model* m);
+const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel);
+
+/* ---- phase A: neighbour graph ------------------------------------------------------------------
+ * Replaces OptimizedDistance.forward + get_neighbor_pairs_kernel + graph_transform
+ * (torchmdnet/models/utils.py:233-313, extensions/ops.py:14, warp_ops/graph_transform.py:160-179).
+ * Brute-force pair search restricted to each molecule, self loops included, both directions,
+ * optional triclinic minimum image (box_mode 1: one [3,3] box, 2: one box per molecule [B,3,3]).
+ * Produces a deterministic pair list + symmetric CSR inside `graph_ws`.
+ * counts_host[0] = number of undirected pairs P, [1] = number of directed edges incl. self loops E,
+ * [2] = overflow flag, [3] = 1 if `batch` was not sorted (slow path).
+ * Returns TMDNET_ERR_OVERFLOW when E > max_num_neighbors * n_atoms. */
+int tmdnet_graph_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, size_t* bytes);
+int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms, int64_t n_mol,
+                       const float* pos, const int64_t* batch, const float* box, int32_t box_mode, int64_t counts_host[4]);
+
+/* ---- phase B: energies and forces ---------------------------------------------------------------
+ * Replaces TorchMD_Net.forward for TensorNet + Scalar (torchmdnet/models/model.py:530-631):
+ * energy[n_mol] = sum over atoms of the per-atom scalar (* std, + atomref[z]) + mean, and
+ * forces[n_atoms,3] = -d(sum_m energy[m])/d(pos) from the hand-written reverse pass
+ * (want_forces = 0 skips it).  `q` = total charge per molecule [n_mol] or NULL (tensornet.py:341-344).
+ * Must be called after tmdnet_build_graph on the same graph_ws (which holds the pair geometry);
+ * n_pairs = counts_host[0] of that call.  Enqueues only: no synchronisation, no allocation. */
+int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int64_t n_edges,
+                                   int32_t want_forces, size_t* bytes);
+int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms,
+                         int64_t n_mol, int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q,
+                         int32_t want_forces, float* energy, float* forces);
+
+/* ---- fine-grained operator: the reference's neighbour op --------------------------------------
+ * Same outputs as torch.ops.torchmdnet.warp_neighbor_brute_fwd (warp_ops/neighbors.py:34-148):
+ * neighbors int64 [2,max_num_pairs] padded with -1, deltas [max_num_pairs,3], distances
+ * [max_num_pairs], num_pairs int32[1] (the true count, may exceed max_num_pairs).  Pair order is
+ * deterministic: lower pairs (i>j) sorted by (i,j), then their transposes, then self loops.
+ * `ws` must hold tmdnet_neighbor_workspace_bytes(n_atoms, n_mol, max_num_pairs). */
+int tmdnet_neighbor_workspace_bytes(int64_t n_atoms, int64_t n_mol, int64_t max_num_pairs, size_t* bytes);
+int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol, const float* pos,
+                          const int64_t* batch, const float* box, int32_t box_mode, float cutoff_lower, float cutoff_upper,
+                          int64_t max_num_pairs, int32_t loop, int32_t include_transpose, int64_t* neighbors, float* deltas,
+                          float* distances, int32_t* num_pairs);
+
+/* ---- diagnostics ---------------------------------------------------------------------------------
+ * Copy an intermediate of the last tmdnet_energy_forces call out of the workspace (device -> device).
+ * Names: "X_embed", "X_layer<l>", "x", "phi", "Q", "u0", "G_embed".  Used by the parity tests. */
+int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* out, int64_t numel);
+/* plain dense contraction through the path's MFMA GEMM: C[M,N] = A[M,K] @ W[N,K]^T (+bias); for unit tests */
+int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float* bias, float* C, int64_t M, int64_t N,
+                      int64_t K, int32_t silu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMDNET_AMD_H */

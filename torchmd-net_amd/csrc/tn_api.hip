@@ -1,0 +1,683 @@
+// C-ABI entry points of libtmdnet_amd.so (include/tmdnet_amd.h): parameter packing, workspace
+// carving and the kernel schedule of the TensorNet energy+force path on one MI355X.
+//
+// Schedule = reference call stack TorchMD_Net.forward -> TensorNet.forward -> TensorEmbedding /
+// Interaction x L -> readout -> Scalar head -> reduce (torchmdnet/models/model.py:530-631,
+// tensornet.py:308-402, 543-619, 729-814, output_modules.py:43-117), followed by the hand-written
+// reverse pass that replaces torch.autograd.grad (model.py:618-628).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tmdnet_amd.h"
+#include "tn_gemm.h"
+#include "tn_kernels.h"
+
+using namespace tn;
+
+namespace {
+
+struct LayerP {
+  const float *M1, *b1, *M1T, *M2, *b2, *M2T, *M3, *b3, *M3T;
+  const float* V[6];
+  const float* VT[6];
+};
+
+struct DevParams {
+  const float *means, *betas;
+  const float *Wdp, *bdp, *WdpT;
+  const float *emb, *emb2_w, *emb2_b;
+  const float* Ue[3];
+  const float* UeT[3];
+  const float *L1, *bL1, *L1T, *L2, *bL2, *L2T;
+  const float *ln0_w, *ln0_b;
+  std::vector<LayerP> layer;
+  const float *lnr_w, *lnr_b, *Lin, *bLin, *LinT;
+  const float *O1, *bO1, *O1T, *O2, *bO2;
+  const float* atomref;
+  float mean, std;
+};
+
+struct ParamSpec {
+  std::string name;
+  int64_t rows, cols;  // cols = 1 for vectors
+};
+
+// carve helper: 256-byte aligned sub-buffers of one caller-owned allocation
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(reinterpret_cast<char*>(p)) {}
+  template <typename T>
+  T* take(int64_t n) {
+    size_t bytes = (size_t)(n > 0 ? n : 0) * sizeof(T);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (bytes + 255) & ~size_t(255);
+    return p;
+  }
+};
+
+struct FwdBuffers {
+  float *phi, *dphi, *C, *dC;
+  float *Utab, *Vtab, *Q, *u0, *s0n, *ln0, *xh0, *rstd0, *a1, *h1, *a2, *gates, *UX;
+  std::vector<float*> X;                               // L+1
+  std::vector<float*> e1, e2, e3, w, Pn, Mi, D;        // per layer
+  float *he1, *he2, *Xh, *Ch;
+  float *feat, *lnr, *xhr, *rstdr, *al, *x, *ao, *ea;
+  // reverse
+  float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *g_e3, *g_e2, *g_e1, *g_phi, *gC;
+  float *gUX, *g_a2, *g_a1, *g_ln0, *g_s0n, *g_u0l, *gA, *g_rhat, *g_delta;
+};
+
+}  // namespace
+
+struct tmdnet_model {
+  tmdnet_hparams hp;
+  std::vector<ParamSpec> specs;
+  std::map<std::string, std::vector<float>> host;
+  float* dev = nullptr;  // packed parameters
+  DevParams P;
+  bool finalized = false;
+  std::string err;
+  // last-call bookkeeping for tmdnet_debug_tensor
+  FwdBuffers last{};
+  int64_t lastN = 0, lastP = 0;
+  bool has_last = false;
+};
+
+namespace {
+
+int fail(tmdnet_model* m, int code, const std::string& msg) {
+  if (m) m->err = msg;
+  return code;
+}
+#define HIP_TRY(m, expr)                                                                    \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(m, TMDNET_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+void build_specs(tmdnet_model* m) {
+  const int F = m->hp.hidden_channels, K = m->hp.num_rbf, L = m->hp.num_layers, Z = m->hp.max_z, H = m->hp.head_hidden;
+  auto& s = m->specs;
+  const std::string R = "representation_model.", T = R + "tensor_embedding.";
+  s.push_back({R + "distance_expansion.means", K, 1});
+  s.push_back({R + "distance_expansion.betas", K, 1});
+  for (int k = 1; k <= 3; ++k) {
+    s.push_back({T + "distance_proj" + std::to_string(k) + ".weight", F, K});
+    s.push_back({T + "distance_proj" + std::to_string(k) + ".bias", F, 1});
+  }
+  s.push_back({T + "emb.weight", Z, F});
+  s.push_back({T + "emb2.weight", F, 2 * F});
+  s.push_back({T + "emb2.bias", F, 1});
+  for (int k = 0; k < 3; ++k) s.push_back({T + "linears_tensor." + std::to_string(k) + ".weight", F, F});
+  s.push_back({T + "linears_scalar.0.weight", 2 * F, F});
+  s.push_back({T + "linears_scalar.0.bias", 2 * F, 1});
+  s.push_back({T + "linears_scalar.1.weight", 3 * F, 2 * F});
+  s.push_back({T + "linears_scalar.1.bias", 3 * F, 1});
+  s.push_back({T + "init_norm.weight", F, 1});
+  s.push_back({T + "init_norm.bias", F, 1});
+  for (int l = 0; l < L; ++l) {
+    const std::string Lp = R + "layers." + std::to_string(l) + ".";
+    const int64_t dims[3][2] = {{F, K}, {2 * F, F}, {3 * F, 2 * F}};
+    for (int k = 0; k < 3; ++k) {
+      s.push_back({Lp + "linears_scalar." + std::to_string(k) + ".weight", dims[k][0], dims[k][1]});
+      s.push_back({Lp + "linears_scalar." + std::to_string(k) + ".bias", dims[k][0], 1});
+    }
+    for (int k = 0; k < 6; ++k) s.push_back({Lp + "linears_tensor." + std::to_string(k) + ".weight", F, F});
+  }
+  s.push_back({R + "linear.weight", F, 3 * F});
+  s.push_back({R + "linear.bias", F, 1});
+  s.push_back({R + "out_norm.weight", 3 * F, 1});
+  s.push_back({R + "out_norm.bias", 3 * F, 1});
+  const std::string O = "output_model.output_network.layers.";
+  s.push_back({O + "0.weight", H, F});
+  s.push_back({O + "0.bias", H, 1});
+  s.push_back({O + "2.weight", 1, H});
+  s.push_back({O + "2.bias", 1, 1});
+  s.push_back({"mean", 1, 1});
+  s.push_back({"std", 1, 1});
+  if (m->hp.has_atomref) s.push_back({"atomref", Z, 1});
+}
+
+// host-side packer: appends a tensor (optionally transposed) to the staging buffer, 64-float aligned
+struct Packer {
+  std::vector<float> buf;
+  size_t add(const std::vector<float>& v) {
+    size_t off = (buf.size() + 63) & ~size_t(63);
+    buf.resize(off + v.size());
+    std::memcpy(buf.data() + off, v.data(), v.size() * sizeof(float));
+    return off;
+  }
+  size_t add_T(const std::vector<float>& v, int64_t rows, int64_t cols) {
+    std::vector<float> t(v.size());
+    for (int64_t r = 0; r < rows; ++r)
+      for (int64_t c = 0; c < cols; ++c) t[c * rows + r] = v[r * cols + c];
+    return add(t);
+  }
+};
+
+void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc, int M,
+          int N, int K, int flags = 0, float* pre = nullptr, int64_t ldpre = 0, const float* aux = nullptr, int64_t ldaux = 0,
+          const float* rowscale = nullptr) {
+  GemmArgs a{};
+  a.A = A;
+  a.W[0] = W;
+  a.C = C;
+  a.bias[0] = bias;
+  a.pre = pre;
+  a.aux = aux;
+  a.rowscale = rowscale;
+  a.lda = lda;
+  a.ldw = ldw;
+  a.ldc = ldc;
+  a.ldpre = ldpre;
+  a.ldaux = ldaux;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.groups = 1;
+  a.flags = flags;
+  launch_gemm(a, s);
+}
+
+// the three weight matrices act on the channel axis of the 1 + 3 + 5 irreducible components
+// (reference tensornet.py:595-617, 752-754, 808-810): one grouped launch, 9 groups
+void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], float* C, int N, int F, int flags = 0,
+                   float* pre = nullptr, const float* gates = nullptr) {
+  GemmArgs a{};
+  a.A = A;
+  a.C = C;
+  a.pre = pre;
+  a.aux = gates;
+  a.lda = a.ldc = a.ldpre = 9 * (int64_t)F;
+  a.ldaux = 3 * (int64_t)F;
+  a.ldw = F;
+  for (int c = 0; c < 9; ++c) {
+    const int t = c == 0 ? 0 : (c < 4 ? 1 : 2);
+    a.W[c] = W3[t];
+    a.bias[c] = nullptr;
+    a.a_off[c] = a.c_off[c] = a.pre_off[c] = c * F;
+    a.aux_off[c] = t * F;
+  }
+  a.M = N;
+  a.N = F;
+  a.K = F;
+  a.groups = 9;
+  a.flags = flags;
+  launch_gemm(a, s);
+}
+
+Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
+  Carver c(ws);
+  Graph g{};
+  const int64_t pcap = ecap / 2 + 1;
+  g.counts = c.take<int>(8);
+  g.mstart = c.take<int>(B);
+  g.mend = c.take<int>(B);
+  g.nlow = c.take<int>(N);
+  g.ntot = c.take<int>(N);
+  g.rowptr = c.take<int>(N + 1);
+  g.pairptr = c.take<int>(N + 1);
+  g.col = c.take<int>(ecap);
+  g.epair = c.take<int>(ecap);
+  g.esign = c.take<float>(ecap);
+  g.pair_i = c.take<int>(pcap);
+  g.pair_j = c.take<int>(pcap);
+  g.pd = c.take<float>(pcap + 1);
+  g.pdelta = c.take<float>(pcap * 3);
+  g.prhat = c.take<float>(pcap * 3);
+  g.ecap = ecap;
+  g.pcap = pcap;
+  if (total) *total = c.off;
+  return g;
+}
+
+FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, int64_t P, bool bwd, size_t* total) {
+  Carver c(ws);
+  FwdBuffers b{};
+  const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden;
+  const int64_t P1 = P + 1, N9 = N * 9 * F;
+  b.phi = c.take<float>(P1 * K);
+  b.dphi = c.take<float>(P1 * K);
+  b.C = c.take<float>(P1);
+  b.dC = c.take<float>(P1);
+  b.Utab = c.take<float>(Z * F);
+  b.Vtab = c.take<float>(Z * F);
+  b.Q = c.take<float>(P1 * 3 * F);
+  b.u0 = c.take<float>(N9);
+  b.s0n = c.take<float>(N * F);
+  b.ln0 = c.take<float>(N * F);
+  b.xh0 = c.take<float>(N * F);
+  b.rstd0 = c.take<float>(N);
+  b.a1 = c.take<float>(N * 2 * F);
+  b.h1 = c.take<float>(N * 2 * F);
+  b.a2 = c.take<float>(N * 3 * F);
+  b.gates = c.take<float>(N * 3 * F);
+  b.UX = c.take<float>(N9);
+  for (int l = 0; l <= L; ++l) b.X.push_back(c.take<float>(N9));
+  for (int l = 0; l < L; ++l) {
+    b.e1.push_back(c.take<float>(P1 * F));
+    b.e2.push_back(c.take<float>(P1 * 2 * F));
+    b.e3.push_back(c.take<float>(P1 * 3 * F));
+    b.w.push_back(c.take<float>(P1 * 3 * F));
+    b.Pn.push_back(c.take<float>(N9));
+    b.Mi.push_back(c.take<float>(N9));
+    b.D.push_back(c.take<float>(N9));
+  }
+  b.he1 = c.take<float>(P1 * F);
+  b.he2 = c.take<float>(P1 * 2 * F);
+  b.Xh = c.take<float>(N9);
+  b.Ch = c.take<float>(N9);
+  b.feat = c.take<float>(N * 3 * F);
+  b.lnr = c.take<float>(N * 3 * F);
+  b.xhr = c.take<float>(N * 3 * F);
+  b.rstdr = c.take<float>(N);
+  b.al = c.take<float>(N * F);
+  b.x = c.take<float>(N * F);
+  b.ao = c.take<float>(N * H);
+  b.ea = c.take<float>(N);
+  if (bwd) {
+    b.g_ao = c.take<float>(N * H);
+    b.g_al = c.take<float>(N * F);
+    b.g_ln = c.take<float>(N * 3 * F);
+    b.g_feat = c.take<float>(N * 3 * F);
+    b.G = c.take<float>(N9);
+    b.gD = c.take<float>(N9);
+    b.gCh = c.take<float>(N9);
+    b.gMi = c.take<float>(N9);
+    b.gPn = c.take<float>(N9);
+    b.gXl = c.take<float>(N9);
+    b.g_e3 = c.take<float>(P1 * 3 * F);
+    b.g_e2 = c.take<float>(P1 * 2 * F);
+    b.g_e1 = c.take<float>(P1 * F);
+    b.g_phi = c.take<float>(P1 * K);
+    b.gC = c.take<float>(P1);
+    b.gUX = c.take<float>(N9);
+    b.g_a2 = c.take<float>(N * 3 * F);
+    b.g_a1 = c.take<float>(N * 2 * F);
+    b.g_ln0 = c.take<float>(N * F);
+    b.g_s0n = c.take<float>(N * F);
+    b.g_u0l = c.take<float>(N9);
+    b.gA = c.take<float>(N * 10 * F);
+    b.g_rhat = c.take<float>(P1 * 3);
+    b.g_delta = c.take<float>(P1 * 3);
+  }
+  if (total) *total = c.off;
+  return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tmdnet_version(void) { return "tmdnet_amd 0.1 (gfx950)"; }
+
+int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out) {
+  if (!hp || !out) return TMDNET_ERR_INVALID;
+  if (hp->hidden_channels <= 0 || hp->num_layers < 0 || hp->num_rbf <= 0 || hp->max_z <= 0 || hp->head_hidden <= 0 ||
+      hp->max_num_neighbors <= 0 || !(hp->cutoff_upper > hp->cutoff_lower))
+    return TMDNET_ERR_INVALID;
+  tmdnet_model* m = new tmdnet_model();
+  m->hp = *hp;
+  build_specs(m);
+  *out = m;
+  return TMDNET_OK;
+}
+
+int tmdnet_destroy(tmdnet_model* m) {
+  if (!m) return TMDNET_OK;
+  if (m->dev) (void)hipFree(m->dev);
+  delete m;
+  return TMDNET_OK;
+}
+
+const char* tmdnet_last_error(const tmdnet_model* m) { return m ? m->err.c_str() : "null model"; }
+
+int tmdnet_num_params(const tmdnet_model* m) { return m ? (int)m->specs.size() : 0; }
+
+const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel) {
+  if (!m || idx < 0 || idx >= (int)m->specs.size()) return nullptr;
+  if (numel) *numel = m->specs[idx].rows * m->specs[idx].cols;
+  return m->specs[idx].name.c_str();
+}
+
+int tmdnet_set_param(tmdnet_model* m, const char* name, const float* data_host, int64_t numel) {
+  if (!m || !name || !data_host) return TMDNET_ERR_INVALID;
+  for (const auto& sp : m->specs) {
+    if (sp.name == name) {
+      if (numel != sp.rows * sp.cols)
+        return fail(m, TMDNET_ERR_INVALID, std::string("parameter ") + name + ": expected " + std::to_string(sp.rows * sp.cols) +
+                                               " elements, got " + std::to_string(numel));
+      m->host[name].assign(data_host, data_host + numel);
+      m->finalized = false;
+      return TMDNET_OK;
+    }
+  }
+  return fail(m, TMDNET_ERR_INVALID, std::string("unknown parameter: ") + name);
+}
+
+int tmdnet_finalize_params(tmdnet_model* m) {
+  if (!m) return TMDNET_ERR_INVALID;
+  for (const auto& sp : m->specs)
+    if (!m->host.count(sp.name)) return fail(m, TMDNET_ERR_STATE, "missing parameter: " + sp.name);
+  const int F = m->hp.hidden_channels, K = m->hp.num_rbf, L = m->hp.num_layers, H = m->hp.head_hidden;
+  const std::string R = "representation_model.", T = R + "tensor_embedding.", O = "output_model.output_network.layers.";
+  auto& h = m->host;
+  Packer pk;
+  std::map<std::string, size_t> off;
+  auto put = [&](const std::string& key, const std::vector<float>& v) { off[key] = pk.add(v); };
+  auto putT = [&](const std::string& key, const std::vector<float>& v, int64_t r, int64_t c) { off[key] = pk.add_T(v, r, c); };
+  put("means", h[R + "distance_expansion.means"]);
+  put("betas", h[R + "distance_expansion.betas"]);
+  std::vector<float> Wdp, bdp;
+  for (int k = 1; k <= 3; ++k) {
+    auto& w = h[T + "distance_proj" + std::to_string(k) + ".weight"];
+    auto& b = h[T + "distance_proj" + std::to_string(k) + ".bias"];
+    Wdp.insert(Wdp.end(), w.begin(), w.end());
+    bdp.insert(bdp.end(), b.begin(), b.end());
+  }
+  put("Wdp", Wdp);
+  put("bdp", bdp);
+  putT("WdpT", Wdp, 3 * F, K);
+  put("emb", h[T + "emb.weight"]);
+  put("emb2_w", h[T + "emb2.weight"]);
+  put("emb2_b", h[T + "emb2.bias"]);
+  for (int k = 0; k < 3; ++k) {
+    put("Ue" + std::to_string(k), h[T + "linears_tensor." + std::to_string(k) + ".weight"]);
+    putT("UeT" + std::to_string(k), h[T + "linears_tensor." + std::to_string(k) + ".weight"], F, F);
+  }
+  put("L1", h[T + "linears_scalar.0.weight"]);
+  put("bL1", h[T + "linears_scalar.0.bias"]);
+  putT("L1T", h[T + "linears_scalar.0.weight"], 2 * F, F);
+  put("L2", h[T + "linears_scalar.1.weight"]);
+  put("bL2", h[T + "linears_scalar.1.bias"]);
+  putT("L2T", h[T + "linears_scalar.1.weight"], 3 * F, 2 * F);
+  put("ln0_w", h[T + "init_norm.weight"]);
+  put("ln0_b", h[T + "init_norm.bias"]);
+  for (int l = 0; l < L; ++l) {
+    const std::string Lp = R + "layers." + std::to_string(l) + ".", t = "l" + std::to_string(l) + ".";
+    const int64_t dims[3][2] = {{F, K}, {2 * F, F}, {3 * F, 2 * F}};
+    for (int k = 0; k < 3; ++k) {
+      put(t + "M" + std::to_string(k), h[Lp + "linears_scalar." + std::to_string(k) + ".weight"]);
+      put(t + "b" + std::to_string(k), h[Lp + "linears_scalar." + std::to_string(k) + ".bias"]);
+      putT(t + "MT" + std::to_string(k), h[Lp + "linears_scalar." + std::to_string(k) + ".weight"], dims[k][0], dims[k][1]);
+    }
+    for (int k = 0; k < 6; ++k) {
+      put(t + "V" + std::to_string(k), h[Lp + "linears_tensor." + std::to_string(k) + ".weight"]);
+      putT(t + "VT" + std::to_string(k), h[Lp + "linears_tensor." + std::to_string(k) + ".weight"], F, F);
+    }
+  }
+  put("lnr_w", h[R + "out_norm.weight"]);
+  put("lnr_b", h[R + "out_norm.bias"]);
+  put("Lin", h[R + "linear.weight"]);
+  put("bLin", h[R + "linear.bias"]);
+  putT("LinT", h[R + "linear.weight"], F, 3 * F);
+  put("O1", h[O + "0.weight"]);
+  put("bO1", h[O + "0.bias"]);
+  putT("O1T", h[O + "0.weight"], H, F);
+  put("O2", h[O + "2.weight"]);
+  put("bO2", h[O + "2.bias"]);
+  if (m->hp.has_atomref) put("atomref", h["atomref"]);
+
+  if (m->dev) {
+    HIP_TRY(m, hipFree(m->dev));
+    m->dev = nullptr;
+  }
+  HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev), pk.buf.size() * sizeof(float)));
+  HIP_TRY(m, hipMemcpy(m->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice));
+  auto D = [&](const std::string& key) -> const float* { return m->dev + off.at(key); };
+  DevParams& P = m->P;
+  P = DevParams{};
+  P.means = D("means");
+  P.betas = D("betas");
+  P.Wdp = D("Wdp");
+  P.bdp = D("bdp");
+  P.WdpT = D("WdpT");
+  P.emb = D("emb");
+  P.emb2_w = D("emb2_w");
+  P.emb2_b = D("emb2_b");
+  for (int k = 0; k < 3; ++k) {
+    P.Ue[k] = D("Ue" + std::to_string(k));
+    P.UeT[k] = D("UeT" + std::to_string(k));
+  }
+  P.L1 = D("L1");
+  P.bL1 = D("bL1");
+  P.L1T = D("L1T");
+  P.L2 = D("L2");
+  P.bL2 = D("bL2");
+  P.L2T = D("L2T");
+  P.ln0_w = D("ln0_w");
+  P.ln0_b = D("ln0_b");
+  P.layer.resize(L);
+  for (int l = 0; l < L; ++l) {
+    const std::string t = "l" + std::to_string(l) + ".";
+    LayerP& q = P.layer[l];
+    q.M1 = D(t + "M0");
+    q.b1 = D(t + "b0");
+    q.M1T = D(t + "MT0");
+    q.M2 = D(t + "M1");
+    q.b2 = D(t + "b1");
+    q.M2T = D(t + "MT1");
+    q.M3 = D(t + "M2");
+    q.b3 = D(t + "b2");
+    q.M3T = D(t + "MT2");
+    for (int k = 0; k < 6; ++k) {
+      q.V[k] = D(t + "V" + std::to_string(k));
+      q.VT[k] = D(t + "VT" + std::to_string(k));
+    }
+  }
+  P.lnr_w = D("lnr_w");
+  P.lnr_b = D("lnr_b");
+  P.Lin = D("Lin");
+  P.bLin = D("bLin");
+  P.LinT = D("LinT");
+  P.O1 = D("O1");
+  P.bO1 = D("bO1");
+  P.O1T = D("O1T");
+  P.O2 = D("O2");
+  P.bO2 = D("bO2");
+  P.atomref = m->hp.has_atomref ? D("atomref") : nullptr;
+  P.mean = h["mean"][0];
+  P.std = h["std"][0];
+  m->finalized = true;
+  return TMDNET_OK;
+}
+
+// ------------------------------------------------------------------------------------ graph
+int tmdnet_graph_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, size_t* bytes) {
+  if (!m || !bytes || n_atoms < 0 || n_mol < 0) return TMDNET_ERR_INVALID;
+  const int64_t ecap = (int64_t)m->hp.max_num_neighbors * n_atoms;
+  carve_graph(nullptr, n_atoms, n_mol, ecap, bytes);
+  return TMDNET_OK;
+}
+
+int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms, int64_t n_mol,
+                       const float* pos, const int64_t* batch, const float* box, int32_t box_mode, int64_t counts_host[4]) {
+  if (!m || !graph_ws || !counts_host || n_atoms < 0 || n_mol < 0) return TMDNET_ERR_INVALID;
+  if (n_atoms >= (int64_t)1 << 30) return fail(m, TMDNET_ERR_INVALID, "n_atoms too large for 32-bit indices");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t ecap = (int64_t)m->hp.max_num_neighbors * n_atoms;
+  size_t need = 0;
+  Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, &need);
+  if (need > graph_ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "graph workspace too small");
+  if (box_mode != 0 && !box) return fail(m, TMDNET_ERR_INVALID, "box_mode != 0 needs a box");
+  launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper, true,
+                            s);
+  int counts[4] = {0, 0, 0, 0};
+  HIP_TRY(m, hipMemcpyAsync(counts, g.counts, sizeof(counts), hipMemcpyDeviceToHost, s));
+  HIP_TRY(m, hipStreamSynchronize(s));
+  for (int k = 0; k < 4; ++k) counts_host[k] = counts[k];
+  if (counts[2])
+    return fail(m, TMDNET_ERR_OVERFLOW, "Found num_pairs > max_num_pairs, please increase max_num_pairs (found " +
+                                            std::to_string(counts[1]) + " edges, capacity " + std::to_string(ecap) + ")");
+  launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+  HIP_TRY(m, hipGetLastError());
+  return TMDNET_OK;
+}
+
+// ------------------------------------------------------------------------------------ forward + reverse
+int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int64_t n_edges,
+                                   int32_t want_forces, size_t* bytes) {
+  if (!m || !bytes) return TMDNET_ERR_INVALID;
+  (void)n_edges;
+  carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes);
+  return TMDNET_OK;
+}
+
+int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms,
+                         int64_t n_mol, int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q,
+                         int32_t want_forces, float* energy, float* forces) {
+  if (!m || !graph_ws || !ws || !energy) return TMDNET_ERR_INVALID;
+  if (!m->finalized) return fail(m, TMDNET_ERR_STATE, "parameters not finalised");
+  if (want_forces && !forces) return TMDNET_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const tmdnet_hparams& hp = m->hp;
+  const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden;
+  const int N = (int)n_atoms, B = (int)n_mol;
+  const int64_t ecap = (int64_t)hp.max_num_neighbors * n_atoms;
+  Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, nullptr);
+  if (n_pairs < 0 || n_pairs > g.pcap) return fail(m, TMDNET_ERR_INVALID, "n_pairs out of range");
+  const int P = (int)n_pairs, P1 = P + 1;  // read back by tmdnet_build_graph
+  size_t need = 0;
+  FwdBuffers b = carve_fwd(ws, hp, n_atoms, n_mol, P, want_forces != 0, &need);
+  if (need > ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "forward workspace too small: need " + std::to_string(need));
+  const DevParams& W = m->P;
+  const int o3 = hp.group_o3;
+
+  // ---- radial functions per pair
+  RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
+  launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s);
+  // ---- embedding
+  gemm(s, W.emb, F, W.emb2_w, 2 * F, W.emb2_b, b.Utab, F, Z, F, F);          // U[z] = emb2_w[:, :F] emb[z] + b
+  gemm(s, W.emb, F, W.emb2_w + F, 2 * F, nullptr, b.Vtab, F, Z, F, F);       // V[z] = emb2_w[:, F:] emb[z]
+  gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);              // distance projections
+  launch_embed_scatter(g, N, F, z, b.Utab, b.Vtab, b.Q, b.C, b.u0, b.s0n, s);
+  launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s);
+  gemm(s, b.ln0, F, W.L1, F, W.bL1, b.h1, 2 * F, N, 2 * F, F, GEMM_ACT_SILU, b.a1, 2 * F);
+  gemm(s, b.h1, 2 * F, W.L2, 2 * F, W.bL2, b.gates, 3 * F, N, 3 * F, 2 * F, GEMM_ACT_SILU, b.a2, 3 * F);
+  tensor_linear(s, b.u0, W.Ue, b.X[0], N, F, GEMM_MUL_AUX, b.UX, b.gates);
+  // ---- interaction layers
+  for (int l = 0; l < L; ++l) {
+    const LayerP& q_ = W.layer[l];
+    gemm(s, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU, b.e1[l], F);
+    gemm(s, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU, b.e2[l], 2 * F);
+    gemm(s, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, b.e3[l], 3 * F,
+         nullptr, 0, b.C);
+    launch_norm_x(b.X[l], b.Xh, N, F, s);
+    tensor_linear(s, b.Xh, q_.V, b.Pn[l], N, F);
+    launch_message(g, N, F, b.w[l], b.Pn[l], q, batch, o3, b.Mi[l], b.Ch, s);
+    tensor_linear(s, b.Ch, q_.V + 3, b.D[l], N, F);
+    launch_layer_update(b.Xh, b.D[l], q, batch, N, F, b.X[l + 1], s);
+  }
+  // ---- readout + head + per-molecule sum
+  launch_readout_feat(b.X[L], N, F, b.feat, s);
+  launch_layernorm_fwd(b.feat, W.lnr_w, W.lnr_b, N, 3 * F, b.lnr, b.xhr, b.rstdr, s);
+  gemm(s, b.lnr, 3 * F, W.Lin, 3 * F, W.bLin, b.x, F, N, F, 3 * F, GEMM_ACT_SILU, b.al, F);
+  gemm(s, b.x, F, W.O1, F, W.bO1, b.ao, H, N, H, F);
+  launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s);
+  launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s);
+
+  if (want_forces) {
+    launch_head_bwd(b.ao, W.O2, N, H, W.std, b.g_ao, s);
+    gemm(s, b.g_ao, H, W.O1T, H, nullptr, b.g_al, F, N, F, H, GEMM_MUL_DSILU_AUX, nullptr, 0, b.al, F);
+    gemm(s, b.g_al, F, W.LinT, F, nullptr, b.g_ln, 3 * F, N, 3 * F, F);
+    launch_layernorm_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, 3 * F, b.g_feat, s);
+    launch_readout_bwd(b.X[L], b.g_feat, N, F, b.G, s);
+    HIP_TRY(m, hipMemsetAsync(b.gC, 0, sizeof(float) * P1, s));
+    HIP_TRY(m, hipMemsetAsync(b.g_phi, 0, sizeof(float) * (size_t)P1 * K, s));
+    for (int l = L - 1; l >= 0; --l) {
+      const LayerP& q_ = W.layer[l];
+      launch_update_bwd(b.G, b.D[l], q, batch, N, F, b.gD, s);
+      tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
+      launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch, o3, N, F, b.gMi, b.gPn, s);
+      launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s);
+      launch_pair_bwd(g, P, F, b.gMi, b.Pn[l], b.e3[l], b.C, b.g_e3, b.gC, s);
+      gemm(s, b.g_e3, 3 * F, q_.M3T, 3 * F, nullptr, b.g_e2, 2 * F, P, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.e2[l], 2 * F);
+      gemm(s, b.g_e2, 2 * F, q_.M2T, 2 * F, nullptr, b.g_e1, F, P, F, 2 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.e1[l], F);
+      gemm(s, b.g_e1, F, q_.M1T, F, nullptr, b.g_phi, K, P, K, F, GEMM_ACCUM);
+      tensor_linear(s, b.gPn, q_.VT, b.gXl, N, F);
+      launch_norm_bwd(b.X[l], b.gXl, N, F, b.G, s);
+    }
+    launch_embed_gate_bwd(b.G, b.UX, b.gates, b.a2, N, F, b.gUX, b.g_a2, s);
+    gemm(s, b.g_a2, 3 * F, W.L2T, 3 * F, nullptr, b.g_a1, 2 * F, N, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.a1, 2 * F);
+    gemm(s, b.g_a1, 2 * F, W.L1T, 2 * F, nullptr, b.g_ln0, F, N, F, 2 * F);
+    launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s);
+    tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
+    launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s);
+    launch_embed_bwd_pair(g, P, F, z, b.Utab, b.Vtab, b.Q, b.C, b.gA, b.g_e3 /* gQ reuses g_e3 */, b.gC, b.g_rhat, s);
+    gemm(s, b.g_e3, 3 * F, W.WdpT, 3 * F, nullptr, b.g_phi, K, P, K, 3 * F, GEMM_ACCUM);
+    launch_geom(g, P, K, b.gC, b.dC, b.g_phi, b.dphi, b.g_rhat, b.g_delta, s);
+    launch_force_gather(g, N, b.g_delta, forces, s);
+  }
+  HIP_TRY(m, hipGetLastError());
+  m->last = b;
+  m->lastN = N;
+  m->lastP = P;
+  m->has_last = true;
+  return TMDNET_OK;
+}
+
+// ------------------------------------------------------------------------------------ neighbour operator
+int tmdnet_neighbor_workspace_bytes(int64_t n_atoms, int64_t n_mol, int64_t max_num_pairs, size_t* bytes) {
+  if (!bytes || n_atoms < 0 || n_mol < 0 || max_num_pairs < 0) return TMDNET_ERR_INVALID;
+  // directed capacity: both directions + self loops of the requested undirected/directed list
+  const int64_t ecap = 2 * max_num_pairs + n_atoms + 2;
+  carve_graph(nullptr, n_atoms, n_mol, ecap, bytes);
+  return TMDNET_OK;
+}
+
+int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol, const float* pos,
+                          const int64_t* batch, const float* box, int32_t box_mode, float cutoff_lower, float cutoff_upper,
+                          int64_t max_num_pairs, int32_t loop, int32_t include_transpose, int64_t* neighbors, float* deltas,
+                          float* distances, int32_t* num_pairs) {
+  if (!ws || !neighbors || !deltas || !distances || !num_pairs) return TMDNET_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t ecap = 2 * max_num_pairs + n_atoms + 2;
+  size_t need = 0;
+  Graph g = carve_graph(ws, n_atoms, n_mol, ecap, &need);
+  if (need > ws_bytes) return TMDNET_ERR_WORKSPACE;
+  // internal CSR always carries self loops + both directions; the export selects what the caller asked for
+  launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, cutoff_lower, cutoff_upper, true, s);
+  launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, cutoff_lower, cutoff_upper, true, s);
+  launch_export_pairs(g, (int)n_atoms, include_transpose != 0, loop != 0, max_num_pairs, neighbors, deltas, distances, num_pairs, s);
+  return hipGetLastError() == hipSuccess ? TMDNET_OK : TMDNET_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------ diagnostics
+int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* out, int64_t numel) {
+  if (!m || !name || !out || !m->has_last) return TMDNET_ERR_STATE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t F = m->hp.hidden_channels, K = m->hp.num_rbf, N = m->lastN, P1 = m->lastP + 1;
+  const FwdBuffers& b = m->last;
+  const float* src = nullptr;
+  int64_t n = 0;
+  std::string nm(name);
+  if (nm == "X_embed") { src = b.X[0]; n = N * 9 * F; }
+  else if (nm.rfind("X_layer", 0) == 0) {
+    int l = std::atoi(nm.c_str() + 7);
+    if (l < 0 || l >= m->hp.num_layers) return TMDNET_ERR_INVALID;
+    src = b.X[l + 1]; n = N * 9 * F;
+  }
+  else if (nm == "x") { src = b.x; n = N * F; }
+  else if (nm == "phi") { src = b.phi; n = P1 * K; }
+  else if (nm == "Q") { src = b.Q; n = P1 * 3 * F; }
+  else if (nm == "u0") { src = b.u0; n = N * 9 * F; }
+  else if (nm == "G_embed") { src = b.G; n = N * 9 * F; }
+  else return fail(m, TMDNET_ERR_INVALID, "unknown debug tensor");
+  if (!src || numel != n) return fail(m, TMDNET_ERR_INVALID, "debug tensor size mismatch: expected " + std::to_string(n));
+  HIP_TRY(m, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+  return TMDNET_OK;
+}
+
+int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float* bias, float* C, int64_t M, int64_t N,
+                      int64_t K, int32_t silu_) {
+  gemm(reinterpret_cast<hipStream_t>(stream), A, K, W, K, bias, C, N, (int)M, (int)N, (int)K, silu_ ? GEMM_ACT_SILU : 0);
+  return hipGetLastError() == hipSuccess ? TMDNET_OK : TMDNET_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// fp32 MFMA GEMM with fused epilogues for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain).
+//
+//   C[g][m, n] = epilogue( sum_k A[g][m, k] * W[g][n, k] )          "NT": W is [N_out, K] row-major
+//
+// Used for every dense contraction on the path: edge MLPs (reference tensornet.py:738-743),
+// distance projections (:558-560), scalar MLPs (:590-593), the 9-component tensor linears
+// (:595-617, :752-754, :808-810; grouped launch, one group per irreducible component), readout
+// linear (:398) and output MLP (models/utils.py:552-580), plus all of their input-gradient
+// (transposed-weight) counterparts in the hand-written reverse pass.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tn {
+
+enum GemmFlags : int {
+  GEMM_ACT_SILU = 1,       // out = silu(pre)
+  GEMM_MUL_AUX = 2,        // out *= aux[m, n]
+  GEMM_MUL_DSILU_AUX = 4,  // out *= silu'(aux[m, n])
+  GEMM_ACCUM = 8,          // out += C_old[m, n]
+  GEMM_ROWSCALE = 16,      // out *= rowscale[m]
+};
+
+constexpr int GEMM_MAX_GROUPS = 9;
+
+struct GemmArgs {
+  const float* A;
+  const float* W[GEMM_MAX_GROUPS];
+  float* C;
+  const float* bias[GEMM_MAX_GROUPS];  // [N] or null
+  float* pre;                          // optional: pre-activation (after bias) saved here
+  const float* aux;                    // optional operand of MUL_AUX / MUL_DSILU_AUX
+  const float* rowscale;               // [M]
+  int64_t lda, ldw, ldc, ldpre, ldaux;
+  int a_off[GEMM_MAX_GROUPS], c_off[GEMM_MAX_GROUPS], pre_off[GEMM_MAX_GROUPS], aux_off[GEMM_MAX_GROUPS];
+  int M, N, K, groups, flags;
+};
+
+// launches on `stream`; returns hipError_t as int
+int launch_gemm(const GemmArgs& args, hipStream_t stream);
+
+}  // namespace tn

@@ -1,0 +1,90 @@
+// Launch wrappers of the non-GEMM HIP kernels of the TensorNet energy+force path (gfx950).
+// Every wrapper enqueues on `s` and returns immediately.  Layouts: see tn_common.h / DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tn {
+
+struct Graph {  // device pointers into the graph workspace
+  int* mstart;   // [B]   first atom of each molecule (valid when batch is sorted)
+  int* mend;     // [B]
+  int* nlow;     // [N]   number of neighbours j < i
+  int* ntot;     // [N]   row length (lower + self + upper)
+  int* rowptr;   // [N+1]
+  int* pairptr;  // [N+1]
+  int* col;      // [Ecap] neighbour index, ascending within a row
+  int* epair;    // [Ecap] pair id of the edge (P = self pair)
+  float* esign;  // [Ecap] +1: row atom is the pair's i, -1: it is the pair's j, 0: self edge
+  int* pair_i;   // [Pcap]
+  int* pair_j;   // [Pcap]
+  float* pd;     // [Pcap+1] distance (self pair: 0)
+  float* pdelta; // [Pcap,3] pos_i - pos_j (+ minimum image)
+  float* prhat;  // [Pcap,3] unit vector
+  int* counts;   // [8]: 0 = P, 1 = E, 2 = overflow, 3 = batch unsorted
+  int64_t ecap, pcap;
+};
+
+struct RadialParams {
+  const float* means;
+  const float* betas;
+  int K;
+  float lo, up;
+};
+
+// ---- graph construction (reference models/utils.py:233-313, warp_kernels/neighbors_brute.py:40-205,
+//      warp_ops/graph_transform.py:160-179)
+void launch_graph_build_phase1(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
+                               int B, float lo, float up, bool loop, hipStream_t s);
+void launch_graph_build_phase2(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
+                               float lo, float up, bool loop, hipStream_t s);
+// COO export in the reference operator's format (warp_ops/neighbors.py:34-148)
+void launch_export_pairs(const Graph& g, int N, bool include_transpose, bool loop, int64_t max_pairs, int64_t* neighbors,
+                         float* deltas, float* distances, int* num_pairs, hipStream_t s);
+
+// ---- radial basis + cutoff per pair (reference models/utils.py:402-407, 506-528)
+void launch_radial(const Graph& g, int P, RadialParams rp, float* phi, float* dphi, float* C, float* dC, hipStream_t s);
+
+// ---- embedding (reference tensornet.py:543-619, 405-445)
+void launch_embed_scatter(const Graph& g, int N, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                          const float* C, float* u0, float* s0n, hipStream_t s);
+// ---- LayerNorm over rows of length R (torch.nn.LayerNorm semantics, eps 1e-5, biased variance)
+void launch_layernorm_fwd(const float* x, const float* w, const float* b, int rows, int R, float* y, float* xhat, float* rstd,
+                          hipStream_t s);
+void launch_layernorm_bwd(const float* g, const float* xhat, const float* rstd, const float* w, int rows, int R, float* gx,
+                          hipStream_t s);
+// ---- interaction layer (reference tensornet.py:729-814, 622-679)
+void launch_norm_x(const float* X, float* Xh, int N, int F, hipStream_t s);
+// mode 0: forward message + O(3)/SO(3) product + normalisation -> Mi, Ch ; mode 1: dst[i] += sum_e w * src[j] (adjoint)
+void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
+                    float* Mi, float* Ch, hipStream_t s);
+void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);
+void launch_layer_update(const float* Xh, const float* D, const float* q, const int64_t* batch, int N, int F, float* Xn,
+                         hipStream_t s);
+// ---- readout (reference tensornet.py:384-398, output_modules.py:43-117, model.py:591-607)
+void launch_readout_feat(const float* X, int N, int F, float* feat, hipStream_t s);
+void launch_head_energy(const float* ao, const float* O2, const float* bO2, int N, int H, float std, const float* atomref,
+                        const int64_t* z, float* ea, hipStream_t s);
+void launch_mol_sum(const Graph& g, const float* ea, const int64_t* batch, int N, int B, float mean, float* energy, hipStream_t s);
+
+// ---- reverse pass
+void launch_head_bwd(const float* ao, const float* O2, int N, int H, float std, float* g_ao, hipStream_t s);
+void launch_readout_bwd(const float* X, const float* g_feat, int N, int F, float* G, hipStream_t s);
+void launch_update_bwd(const float* G, const float* D, const float* q, const int64_t* batch, int N, int F, float* gD,
+                       hipStream_t s);
+void launch_message_bwd_node(const float* gCh, const float* Pn, const float* Mi, const float* q, const int64_t* batch, int o3, int N,
+                             int F, float* gMi, float* gPn, hipStream_t s);
+void launch_pair_bwd(const Graph& g, int P, int F, const float* gMi, const float* Pn, const float* e3, const float* C, float* g_e3,
+                     float* gC, hipStream_t s);
+void launch_norm_bwd(const float* X, const float* gXh_lin, int N, int F, float* G, hipStream_t s);
+void launch_embed_gate_bwd(const float* G, const float* UX, const float* gates, const float* a2, int N, int F, float* gUX, float* g_a2,
+                           hipStream_t s);
+void launch_embed_bwd_atom(const float* g_u0_lin, const float* u0, const float* g_s0n, int N, int F, float* gA, hipStream_t s);
+void launch_embed_bwd_pair(const Graph& g, int P, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                           const float* C, const float* gA, float* gQ, float* gC, float* g_rhat, hipStream_t s);
+void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC, const float* g_phi, const float* dphi,
+                 const float* g_rhat, float* g_delta, hipStream_t s);
+void launch_force_gather(const Graph& g, int N, const float* g_delta, float* forces, hipStream_t s);
+void launch_fill(float* p, float v, int64_t n, hipStream_t s);
+
+}  // namespace tn

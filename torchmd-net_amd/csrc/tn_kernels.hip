@@ -1,0 +1,961 @@
+// Non-GEMM HIP kernels of the TensorNet energy+force path for gfx950 (CDNA4, wave64).
+// Thread mapping used by all per-atom kernels: the feature channel f is the fastest-varying thread
+// index, so every global access is a contiguous 4*F-byte run (coalesced), and per-edge / per-atom
+// scalars are wave-uniform (scalar loads).  Segmented sums over CSR rows are done in registers by
+// the thread that owns (atom, channel): no atomics, deterministic results.
+#include "tn_kernels.h"
+
+#include "tn_common.h"
+
+namespace tn {
+
+static inline int fthreads(int F) {
+  int t = ((F + 63) / 64) * 64;
+  return t > 256 ? 256 : t;
+}
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// =====================================================================================
+//                                   graph construction
+// =====================================================================================
+__global__ void k_mol_ranges(const int64_t* __restrict__ batch, int N, int B, int* mstart, int* mend, int* counts) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int64_t b = batch[i];
+  if (b < 0 || b >= B) {
+    counts[3] = 1;  // unusable for the range trick: fall back to the full scan
+    return;
+  }
+  if (i > 0) {
+    int64_t bp = batch[i - 1];
+    if (bp > b) counts[3] = 1;
+    if (bp != b) mstart[b] = i;
+  } else {
+    mstart[b] = 0;
+  }
+  if (i == N - 1 || batch[i + 1] != b) mend[b] = i + 1;
+}
+
+// canonical pair geometry: delta = pos[hi] - pos[lo] (+ triclinic minimum image, z -> y -> x;
+// reference neighbors_brute.py:112-135).  Both atoms of a pair evaluate the identical expression.
+__device__ __forceinline__ float pair_delta(const float* __restrict__ pos, int hi, int lo, const float* __restrict__ box,
+                                            float& dx, float& dy, float& dz) {
+  dx = pos[hi * 3 + 0] - pos[lo * 3 + 0];
+  dy = pos[hi * 3 + 1] - pos[lo * 3 + 1];
+  dz = pos[hi * 3 + 2] - pos[lo * 3 + 2];
+  if (box) {
+    float s3 = roundf(dz / box[8]);
+    dx -= s3 * box[6];
+    dy -= s3 * box[7];
+    dz -= s3 * box[8];
+    float s2 = roundf(dy / box[4]);
+    dx -= s2 * box[3];
+    dy -= s2 * box[4];
+    float s1 = roundf(dx / box[0]);
+    dx -= s1 * box[0];
+  }
+  return dx * dx + dy * dy + dz * dz;
+}
+
+__device__ __forceinline__ void cand_range(const int* mstart, const int* mend, const int* counts, int64_t b, int N, int& j0,
+                                           int& j1) {
+  if (counts[3]) {
+    j0 = 0;
+    j1 = N;
+  } else {
+    j0 = mstart[b];
+    j1 = mend[b];
+  }
+}
+
+__global__ void k_nbr_count(Graph g, const float* __restrict__ pos, const int64_t* __restrict__ batch, const float* __restrict__ box,
+                            int box_mode, int N, float lo2, float up2, int loop) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int64_t b = batch[i];
+  int j0, j1;
+  cand_range(g.mstart, g.mend, g.counts, b, N, j0, j1);
+  const float* bx = box_mode == 0 ? nullptr : (box_mode == 1 ? box : box + b * 9);
+  int nl = 0, nt = 0;
+  for (int j = j0; j < j1; ++j) {
+    if (j == i) {
+      nt += loop ? 1 : 0;
+      continue;
+    }
+    if (batch[j] != b) continue;
+    float dx, dy, dz;
+    float d2 = (j < i) ? pair_delta(pos, i, j, bx, dx, dy, dz) : pair_delta(pos, j, i, bx, dx, dy, dz);
+    if (d2 < up2 && d2 >= lo2) {
+      ++nt;
+      if (j < i) ++nl;
+    }
+  }
+  g.nlow[i] = nl;
+  g.ntot[i] = nt;
+}
+
+// single-block exclusive scan of nlow -> pairptr and ntot -> rowptr; publishes P, E and the overflow flag
+__global__ __launch_bounds__(1024) void k_scan_counts(Graph g, int N) {
+  __shared__ int wsum[2][16];
+  __shared__ int carry[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry[0] = carry[1] = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    int i = base + tid;
+    int a = i < N ? g.nlow[i] : 0;
+    int b = i < N ? g.ntot[i] : 0;
+    int ia = a, ib = b;  // inclusive wave scans
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int ta = __shfl_up(ia, off, 64), tb = __shfl_up(ib, off, 64);
+      if (lane >= off) {
+        ia += ta;
+        ib += tb;
+      }
+    }
+    if (lane == 63) {
+      wsum[0][wave] = ia;
+      wsum[1][wave] = ib;
+    }
+    __syncthreads();
+    int oa = carry[0], ob = carry[1];
+    for (int w = 0; w < wave; ++w) {
+      oa += wsum[0][w];
+      ob += wsum[1][w];
+    }
+    if (i < N) {
+      g.pairptr[i] = oa + ia - a;
+      g.rowptr[i] = ob + ib - b;
+    }
+    __syncthreads();
+    if (tid == 1023) {
+      carry[0] = oa + ia;
+      carry[1] = ob + ib;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int P = carry[0], E = carry[1];
+    g.pairptr[N] = P;
+    g.rowptr[N] = E;
+    g.counts[0] = P;
+    g.counts[1] = E;
+    g.counts[2] = (E > g.ecap || P > g.pcap) ? 1 : 0;
+  }
+}
+
+__global__ void k_nbr_fill(Graph g, const float* __restrict__ pos, const int64_t* __restrict__ batch, const float* __restrict__ box,
+                           int box_mode, int N, float lo2, float up2, int loop) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (g.counts[2]) return;  // overflow: the host raises (reference models/utils.py:297-300)
+  const int P = g.counts[0];
+  int64_t b = batch[i];
+  int j0, j1;
+  cand_range(g.mstart, g.mend, g.counts, b, N, j0, j1);
+  const float* bx = box_mode == 0 ? nullptr : (box_mode == 1 ? box : box + b * 9);
+  int e = g.rowptr[i];
+  int p = g.pairptr[i];
+  for (int j = j0; j < j1; ++j) {
+    if (j == i) {
+      if (loop) {
+        g.col[e] = i;
+        g.epair[e] = P;
+        g.esign[e] = 0.f;
+        ++e;
+      }
+      continue;
+    }
+    if (batch[j] != b) continue;
+    float dx, dy, dz;
+    float d2 = (j < i) ? pair_delta(pos, i, j, bx, dx, dy, dz) : pair_delta(pos, j, i, bx, dx, dy, dz);
+    if (d2 < up2 && d2 >= lo2) {
+      g.col[e] = j;
+      if (j < i) {
+        float d = sqrtf(d2);
+        float inv = d > 0.f ? 1.0f / d : 0.f;
+        g.pair_i[p] = i;
+        g.pair_j[p] = j;
+        g.pd[p] = d;
+        g.pdelta[p * 3 + 0] = dx;
+        g.pdelta[p * 3 + 1] = dy;
+        g.pdelta[p * 3 + 2] = dz;
+        g.prhat[p * 3 + 0] = dx * inv;
+        g.prhat[p * 3 + 1] = dy * inv;
+        g.prhat[p * 3 + 2] = dz * inv;
+        g.epair[e] = p;
+        g.esign[e] = 1.f;
+        ++p;
+      } else {
+        g.epair[e] = -1;  // linked by k_nbr_link
+        g.esign[e] = -1.f;
+      }
+      ++e;
+    }
+  }
+  if (i == 0) g.pd[P] = 0.f;  // the self pair
+}
+
+// upper edges (i <- j, j > i) take the pair id of the lower edge (j <- i): binary search of i among the
+// sorted lower neighbours of j
+__global__ void k_nbr_link(Graph g, int N) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (g.counts[2]) return;
+  int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  for (int e = e0; e < e1; ++e) {
+    int j = g.col[e];
+    if (j <= i) continue;
+    int lo = g.rowptr[j], hi = lo + g.nlow[j] - 1, base = lo;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (g.col[mid] < i) lo = mid + 1; else hi = mid;
+    }
+    g.epair[e] = g.pairptr[j] + (lo - base);
+  }
+}
+
+void launch_graph_build_phase1(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
+                               int B, float lo, float up, bool loop, hipStream_t s) {
+  hipMemsetAsync(g.mstart, 0, sizeof(int) * B, s);
+  hipMemsetAsync(g.mend, 0, sizeof(int) * B, s);
+  hipMemsetAsync(g.counts, 0, sizeof(int) * 8, s);
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_mol_ranges, dim3(cdiv(N, 256)), dim3(256), 0, s, batch, N, B, g.mstart, g.mend, g.counts);
+  hipLaunchKernelGGL(k_nbr_count, dim3(cdiv(N, 64)), dim3(64), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up, (int)loop);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, g, N);
+}
+
+void launch_graph_build_phase2(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
+                               float lo, float up, bool loop, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_nbr_fill, dim3(cdiv(N, 64)), dim3(64), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up, (int)loop);
+  hipLaunchKernelGGL(k_nbr_link, dim3(cdiv(N, 64)), dim3(64), 0, s, g, N);
+}
+
+// COO list in the reference operator's format: lower pairs (i>j) [+ transposes] [+ self loops], padded with -1/0
+__global__ void k_export_pairs(Graph g, int N, int include_transpose, int loop, int64_t max_pairs, int64_t* neighbors,
+                               float* deltas, float* distances, int* num_pairs) {
+  const int P = g.counts[0];
+  const int64_t total = (int64_t)P * (include_transpose ? 2 : 1) + (loop ? N : 0);
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx == 0) num_pairs[0] = (int)total;
+  if (idx >= max_pairs) return;
+  int64_t a = -1, b = -1;
+  float dx = 0.f, dy = 0.f, dz = 0.f, d = 0.f;
+  if (idx < total && !g.counts[2]) {
+    int64_t k = idx;
+    if (k < P) {
+      a = g.pair_i[k]; b = g.pair_j[k];
+      dx = g.pdelta[k * 3]; dy = g.pdelta[k * 3 + 1]; dz = g.pdelta[k * 3 + 2]; d = g.pd[k];
+    } else if (include_transpose && k < 2 * (int64_t)P) {
+      k -= P;
+      a = g.pair_j[k]; b = g.pair_i[k];
+      dx = -g.pdelta[k * 3]; dy = -g.pdelta[k * 3 + 1]; dz = -g.pdelta[k * 3 + 2]; d = g.pd[k];
+    } else {
+      a = b = k - (int64_t)P * (include_transpose ? 2 : 1);
+    }
+  }
+  neighbors[idx] = a;
+  neighbors[max_pairs + idx] = b;
+  deltas[idx * 3] = dx; deltas[idx * 3 + 1] = dy; deltas[idx * 3 + 2] = dz;
+  distances[idx] = d;
+}
+
+void launch_export_pairs(const Graph& g, int N, bool include_transpose, bool loop, int64_t max_pairs, int64_t* neighbors,
+                         float* deltas, float* distances, int* num_pairs, hipStream_t s) {
+  int64_t n = max_pairs > 0 ? max_pairs : 1;
+  hipLaunchKernelGGL(k_export_pairs, dim3(cdiv(n, 256)), dim3(256), 0, s, g, N, (int)include_transpose, (int)loop, max_pairs,
+                     neighbors, deltas, distances, num_pairs);
+}
+
+// =====================================================================================
+//                         radial basis + cutoff (one thread per (pair, k))
+// =====================================================================================
+__global__ void k_radial(Graph g, int P, RadialParams rp, float* __restrict__ phi, float* __restrict__ dphi, float* __restrict__ C,
+                         float* __restrict__ dC) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)(P + 1) * rp.K;
+  if (idx >= total) return;
+  int p = (int)(idx / rp.K), k = (int)(idx - (int64_t)p * rp.K);
+  float d = p < P ? g.pd[p] : 0.f;
+  float c0, dc0;
+  cosine_cutoff(d, 0.f, rp.up, c0, dc0);  // ExpNormalSmearing uses CosineCutoff(0, upper): utils.py:371
+  float alpha = 5.0f / (rp.up - rp.lo);
+  float u = expf(-alpha * (d - rp.lo));
+  float mu = rp.means[k], beta = rp.betas[k];
+  float gk = expf(-beta * (u - mu) * (u - mu));
+  phi[idx] = c0 * gk;
+  dphi[idx] = dc0 * gk + c0 * gk * (-2.0f * beta * (u - mu)) * (-alpha * u);
+  if (k == 0) {
+    float c, dc;
+    cosine_cutoff(d, rp.lo, rp.up, c, dc);
+    C[p] = c;
+    dC[p] = dc;
+  }
+}
+void launch_radial(const Graph& g, int P, RadialParams rp, float* phi, float* dphi, float* C, float* dC, hipStream_t s) {
+  int64_t total = (int64_t)(P + 1) * rp.K;
+  hipLaunchKernelGGL(k_radial, dim3(cdiv(total, 256)), dim3(256), 0, s, g, P, rp, phi, dphi, C, dC);
+}
+
+// =====================================================================================
+//                                     embedding scatter
+// =====================================================================================
+// block = one atom, thread = channel.  I0 = sum W0 ; v = sum W1 r ; T = sum W2 r r^T ; u0 = (I0, v, T - tr(T)/3)
+__global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict__ z, const float* __restrict__ Utab,
+                                const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ C,
+                                float* __restrict__ u0, float* __restrict__ s0n) {
+  const int i = blockIdx.x;
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  const int64_t zi = z[i];
+  const int F3 = 3 * F;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    const float Ui = Utab[zi * F + f];
+    float I0 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f, t00 = 0.f, t01 = 0.f, t02 = 0.f, t11 = 0.f, t12 = 0.f, t22 = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int j = g.col[e], p = g.epair[e];
+      const float sg = g.esign[e];
+      float rx = 0.f, ry = 0.f, rz = 0.f;
+      if (sg != 0.f) {
+        rx = sg * g.prhat[p * 3];
+        ry = sg * g.prhat[p * 3 + 1];
+        rz = sg * g.prhat[p * 3 + 2];
+      }
+      const float cz = C[p] * (Ui + Vtab[z[j] * F + f]);
+      const float* q = Q + (int64_t)p * F3 + f;
+      const float W0 = cz * q[0], W1 = cz * q[F], W2 = cz * q[2 * F];
+      I0 += W0;
+      v0 += W1 * rx; v1 += W1 * ry; v2 += W1 * rz;
+      t00 += W2 * rx * rx; t01 += W2 * rx * ry; t02 += W2 * rx * rz;
+      t11 += W2 * ry * ry; t12 += W2 * ry * rz; t22 += W2 * rz * rz;
+    }
+    const float tr3 = (t00 + t11 + t22) * (1.0f / 3.0f);
+    float u[9] = {I0, v0, v1, v2, t00 - tr3, t01, t02, t11 - tr3, t12};
+    float* o = u0 + (int64_t)i * 9 * F + f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c * F] = u[c];
+    s0n[(int64_t)i * F + f] = quad(u);
+  }
+}
+void launch_embed_scatter(const Graph& g, int N, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                          const float* C, float* u0, float* s0n, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_embed_scatter, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
+}
+
+// =====================================================================================
+//                                        LayerNorm
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_layernorm_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int rows, int R, float* __restrict__ y,
+                                                       float* __restrict__ xhat, float* __restrict__ rstd) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * R;
+  float sum = 0.f;
+  for (int k = lane; k < R; k += 64) sum += xr[k];
+  const float mean = wave_sum(sum) / R;
+  float var = 0.f;
+  for (int k = lane; k < R; k += 64) {
+    float d = xr[k] - mean;
+    var += d * d;
+  }
+  var = wave_sum(var) / R;
+  const float rs = 1.0f / sqrtf(var + 1e-5f);
+  for (int k = lane; k < R; k += 64) {
+    float xh = (xr[k] - mean) * rs;
+    xhat[(int64_t)row * R + k] = xh;
+    y[(int64_t)row * R + k] = xh * w[k] + b[k];
+  }
+  if (lane == 0) rstd[row] = rs;
+}
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ g, const float* __restrict__ xhat,
+                                                       const float* __restrict__ rstd, const float* __restrict__ w, int rows, int R,
+                                                       float* __restrict__ gx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* gr = g + (int64_t)row * R;
+  const float* xh = xhat + (int64_t)row * R;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = lane; k < R; k += 64) {
+    float gw = gr[k] * w[k];
+    s1 += gw;
+    s2 += gw * xh[k];
+  }
+  s1 = wave_sum(s1) / R;
+  s2 = wave_sum(s2) / R;
+  const float rs = rstd[row];
+  for (int k = lane; k < R; k += 64) gx[(int64_t)row * R + k] = (gr[k] * w[k] - s1 - xh[k] * s2) * rs;
+}
+void launch_layernorm_fwd(const float* x, const float* w, const float* b, int rows, int R, float* y, float* xhat, float* rstd,
+                          hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(k_layernorm_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, w, b, rows, R, y, xhat, rstd);
+}
+void launch_layernorm_bwd(const float* g, const float* xhat, const float* rstd, const float* w, int rows, int R, float* gx,
+                          hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, s, g, xhat, rstd, w, rows, R, gx);
+}
+
+// =====================================================================================
+//                               interaction layer, node side
+// =====================================================================================
+__device__ __forceinline__ void load9(const float* __restrict__ p, int F, float u[9]) {
+#pragma unroll
+  for (int c = 0; c < 9; ++c) u[c] = p[c * F];
+}
+__device__ __forceinline__ void store9(float* __restrict__ p, int F, const float u[9]) {
+#pragma unroll
+  for (int c = 0; c < 9; ++c) p[c * F] = u[c];
+}
+__device__ __forceinline__ float kappa_of(const float* __restrict__ q, const int64_t* __restrict__ batch, int n) {
+  return q ? 1.0f + 0.1f * q[batch[n]] : 1.0f;
+}
+
+// X_hat = X / (||X||^2 + 1)   (reference tensornet.py:745)
+__global__ void k_norm_x(const float* __restrict__ X, float* __restrict__ Xh, int N, int F) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
+  float u[9];
+  load9(X + (int64_t)n * 9 * F + f, F, u);
+  const float inv = 1.0f / (quad(u) + 1.0f);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) u[c] *= inv;
+  store9(Xh + (int64_t)n * 9 * F + f, F, u);
+}
+void launch_norm_x(const float* X, float* Xh, int N, int F, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_norm_x, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, X, Xh, N, F);
+}
+
+// CSR segmented gather-sum: acc[c] = sum_{e in row(i)} w[pair(e), type(c), f] * src[col(e), c, f]
+__device__ __forceinline__ void csr_gather(const Graph& g, int i, int F, int f, const float* __restrict__ w,
+                                           const float* __restrict__ src, float acc[9]) {
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  const int F3 = 3 * F, F9 = 9 * F;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+#pragma unroll 2
+  for (int e = e0; e < e1; ++e) {
+    const int j = g.col[e], p = g.epair[e];
+    const float* wp = w + (int64_t)p * F3 + f;
+    const float* sp = src + (int64_t)j * F9 + f;
+    const float w0 = wp[0], w1 = wp[F], w2 = wp[2 * F];
+    acc[0] += w0 * sp[0];
+    acc[1] += w1 * sp[F];
+    acc[2] += w1 * sp[2 * F];
+    acc[3] += w1 * sp[3 * F];
+    acc[4] += w2 * sp[4 * F];
+    acc[5] += w2 * sp[5 * F];
+    acc[6] += w2 * sp[6 * F];
+    acc[7] += w2 * sp[7 * F];
+    acc[8] += w2 * sp[8 * F];
+  }
+}
+
+// message passing + group product + normalisation (reference tensornet.py:757-806)
+__global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ Pn,
+                          const float* __restrict__ q, const int64_t* __restrict__ batch, int o3, float* __restrict__ Mi,
+                          float* __restrict__ Ch) {
+  const int i = blockIdx.x;
+  const float kap = kappa_of(q, batch, i);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float m[9], y[9];
+    csr_gather(g, i, F, f, w, Pn, m);
+    load9(Pn + (int64_t)i * 9 * F + f, F, y);
+    store9(Mi + (int64_t)i * 9 * F + f, F, m);
+    const M3 Y = compose(y), M = compose(m);
+    M3 Cm = o3 ? scale(add(matmul(Y, M), matmul(M, Y)), kap) : scale(matmul(Y, M), 2.0f);
+    float uc[9];
+    decompose(Cm, uc);
+    const float inv = 1.0f / (frob2(Cm) + 1.0f);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) uc[c] *= inv;
+    store9(Ch + (int64_t)i * 9 * F + f, F, uc);
+  }
+}
+void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
+                    float* Mi, float* Ch, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
+}
+
+// adjoint of the message sum: the graph and the edge weights are symmetric, so the transpose sweep is the
+// same CSR sweep with the message gradient as source:  gPn[i] += sum_e w * gMi[col(e)]
+__global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ gMi,
+                                  float* __restrict__ gPn) {
+  const int i = blockIdx.x;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float a[9];
+    csr_gather(g, i, F, f, w, gMi, a);
+    float* o = gPn + (int64_t)i * 9 * F + f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c * F] += a[c];
+  }
+}
+void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_message_adjoint, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, gMi, gPn);
+}
+
+// X_new = X_hat + dX + kappa * dX.dX    (reference tensornet.py:811-812; residual on the normalised X)
+__global__ void k_layer_update(const float* __restrict__ Xh, const float* __restrict__ D, const float* __restrict__ q,
+                               const int64_t* __restrict__ batch, int N, int F, float* __restrict__ Xn) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
+  float xh[9], d[9];
+  load9(Xh + (int64_t)n * 9 * F + f, F, xh);
+  load9(D + (int64_t)n * 9 * F + f, F, d);
+  const float kap = kappa_of(q, batch, n);
+  const M3 dX = compose(d);
+  const M3 Xf = add(add(compose(xh), dX), scale(matmul(dX, dX), kap));
+  float o[9];
+  decompose(Xf, o);
+  store9(Xn + (int64_t)n * 9 * F + f, F, o);
+}
+void launch_layer_update(const float* Xh, const float* D, const float* q, const int64_t* batch, int N, int F, float* Xn,
+                         hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_layer_update, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, Xh, D, q, batch, N, F, Xn);
+}
+
+// =====================================================================================
+//                                         readout
+// =====================================================================================
+// feat = [3 I^2 ; ||A||^2 ; ||S||^2]   (reference tensornet.py:385-386)
+__global__ void k_readout_feat(const float* __restrict__ X, int N, int F, float* __restrict__ feat) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
+  float u[9];
+  load9(X + (int64_t)n * 9 * F + f, F, u);
+  float* o = feat + (int64_t)n * 3 * F + f;
+  const float t = u[4] + u[7];
+  o[0] = 3.0f * u[0] * u[0];
+  o[F] = 2.0f * (u[1] * u[1] + u[2] * u[2] + u[3] * u[3]);
+  o[2 * F] = u[4] * u[4] + u[7] * u[7] + t * t + 2.0f * (u[5] * u[5] + u[6] * u[6] + u[8] * u[8]);
+}
+void launch_readout_feat(const float* X, int N, int F, float* feat, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_readout_feat, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, X, N, F, feat);
+}
+
+// per-atom energy: e = silu(ao) . O2 + b ; e*std + atomref[z]   (one wave per atom)
+__global__ __launch_bounds__(256) void k_head_energy(const float* __restrict__ ao, const float* __restrict__ O2,
+                                                     const float* __restrict__ bO2, int N, int H, float std,
+                                                     const float* __restrict__ atomref, const int64_t* __restrict__ z,
+                                                     float* __restrict__ ea) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < H; k += 64) s += silu(ao[(int64_t)n * H + k]) * O2[k];
+  s = wave_sum(s);
+  if (lane == 0) {
+    float e = (s + bO2[0]) * std;
+    if (atomref) e += atomref[z[n]];
+    ea[n] = e;
+  }
+}
+void launch_head_energy(const float* ao, const float* O2, const float* bO2, int N, int H, float std, const float* atomref,
+                        const int64_t* z, float* ea, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_head_energy, dim3(cdiv(N, 4)), dim3(256), 0, s, ao, O2, bO2, N, H, std, atomref, z, ea);
+}
+
+// per-molecule sum (reference output_modules.py:43-73).  Sorted batch: one block per molecule, fixed order.
+__global__ __launch_bounds__(256) void k_mol_sum_sorted(Graph g, const float* __restrict__ ea, int B, float mean,
+                                                        float* __restrict__ energy) {
+  if (g.counts[3]) return;
+  __shared__ float part[4];
+  const int m = blockIdx.x;
+  const int i0 = g.mstart[m], i1 = g.mend[m];
+  float s = 0.f;
+  for (int i = i0 + threadIdx.x; i < i1; i += 256) s += ea[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) energy[m] = part[0] + part[1] + part[2] + part[3] + mean;
+}
+__global__ void k_mol_sum_unsorted(Graph g, const float* __restrict__ ea, const int64_t* __restrict__ batch, int N, int B,
+                                   float mean, float* __restrict__ energy, int phase) {
+  if (!g.counts[3]) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (phase == 0) {
+    if (i < B) energy[i] = mean;
+  } else if (i < N) {
+    int64_t b = batch[i];
+    if (b >= 0 && b < B) atomicAdd(&energy[b], ea[i]);
+  }
+}
+void launch_mol_sum(const Graph& g, const float* ea, const int64_t* batch, int N, int B, float mean, float* energy, hipStream_t s) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_mol_sum_sorted, dim3(B), dim3(256), 0, s, g, ea, B, mean, energy);
+  hipLaunchKernelGGL(k_mol_sum_unsorted, dim3(cdiv(B, 256)), dim3(256), 0, s, g, ea, batch, N, B, mean, energy, 0);
+  if (N > 0) hipLaunchKernelGGL(k_mol_sum_unsorted, dim3(cdiv(N, 256)), dim3(256), 0, s, g, ea, batch, N, B, mean, energy, 1);
+}
+
+// =====================================================================================
+//                                       reverse pass
+// =====================================================================================
+__global__ void k_head_bwd(const float* __restrict__ ao, const float* __restrict__ O2, int N, int H, float std,
+                           float* __restrict__ g_ao) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * H) return;
+  int k = (int)(idx % H);
+  g_ao[idx] = std * O2[k] * silu_grad(ao[idx]);
+}
+void launch_head_bwd(const float* ao, const float* O2, int N, int H, float std, float* g_ao, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_head_bwd, dim3(cdiv((int64_t)N * H, 256)), dim3(256), 0, s, ao, O2, N, H, std, g_ao);
+}
+
+__global__ void k_readout_bwd(const float* __restrict__ X, const float* __restrict__ g_feat, int N, int F, float* __restrict__ G) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
+  float u[9], dq[9];
+  load9(X + (int64_t)n * 9 * F + f, F, u);
+  dquad(u, dq);
+  const float* gf = g_feat + (int64_t)n * 3 * F + f;
+  const float gI = gf[0], gA = gf[F], gS = gf[2 * F];
+  // feat_I = 3 I^2 = quad restricted to I, feat_A = 2|v|^2, feat_S = ||S||^2: same partials as dquad
+  float o[9] = {dq[0] * gI, dq[1] * gA, dq[2] * gA, dq[3] * gA, dq[4] * gS, dq[5] * gS, dq[6] * gS, dq[7] * gS, dq[8] * gS};
+  store9(G + (int64_t)n * 9 * F + f, F, o);
+}
+void launch_readout_bwd(const float* X, const float* g_feat, int N, int F, float* G, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_readout_bwd, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, X, g_feat, N, F, G);
+}
+
+// g_D = compose^T( Gf + kappa (Gf dX^T + dX^T Gf) ),  Gf = dec^T(G)
+__global__ void k_update_bwd(const float* __restrict__ G, const float* __restrict__ D, const float* __restrict__ q,
+                             const int64_t* __restrict__ batch, int N, int F, float* __restrict__ gD) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
+  float gg[9], d[9];
+  load9(G + (int64_t)n * 9 * F + f, F, gg);
+  load9(D + (int64_t)n * 9 * F + f, F, d);
+  const float kap = kappa_of(q, batch, n);
+  const M3 Gf = decompose_T(gg);
+  const M3 dXt = transpose(compose(d));
+  const M3 gdx = add(Gf, scale(add(matmul(Gf, dXt), matmul(dXt, Gf)), kap));
+  float o[9];
+  compose_T(gdx, o);
+  store9(gD + (int64_t)n * 9 * F + f, F, o);
+}
+void launch_update_bwd(const float* G, const float* D, const float* q, const int64_t* batch, int N, int F, float* gD, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_update_bwd, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, G, D, q, batch, N, F, gD);
+}
+
+// adjoint of (Y, M) -> C_hat ; writes gMi (wrt the message components) and the direct part of gPn
+__global__ void k_message_bwd_node(const float* __restrict__ gCh, const float* __restrict__ Pn, const float* __restrict__ Mi,
+                                   const float* __restrict__ q, const int64_t* __restrict__ batch, int o3, int N, int F,
+                                   float* __restrict__ gMi, float* __restrict__ gPn) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
+  float gc[9], y[9], m[9];
+  load9(gCh + (int64_t)n * 9 * F + f, F, gc);
+  load9(Pn + (int64_t)n * 9 * F + f, F, y);
+  load9(Mi + (int64_t)n * 9 * F + f, F, m);
+  const float kap = kappa_of(q, batch, n);
+  const M3 Y = compose(y), M = compose(m);
+  const M3 Cm = o3 ? scale(add(matmul(Y, M), matmul(M, Y)), kap) : scale(matmul(Y, M), 2.0f);
+  float uc[9];
+  decompose(Cm, uc);
+  const float inv = 1.0f / (frob2(Cm) + 1.0f);
+  float dot = 0.f, guc[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    dot += gc[c] * uc[c];
+    guc[c] = gc[c] * inv;
+  }
+  const float g_t = -dot * inv * inv;
+  const M3 gCm = add(decompose_T(guc), scale(Cm, 2.0f * g_t));
+  const M3 Yt = transpose(Y), Mt = transpose(M);
+  M3 gY, gM;
+  if (o3) {
+    gY = scale(add(matmul(gCm, Mt), matmul(Mt, gCm)), kap);
+    gM = scale(add(matmul(Yt, gCm), matmul(gCm, Yt)), kap);
+  } else {
+    gY = scale(matmul(gCm, Mt), 2.0f);
+    gM = scale(matmul(Yt, gCm), 2.0f);
+  }
+  float o[9];
+  compose_T(gM, o);
+  store9(gMi + (int64_t)n * 9 * F + f, F, o);
+  compose_T(gY, o);
+  store9(gPn + (int64_t)n * 9 * F + f, F, o);
+}
+void launch_message_bwd_node(const float* gCh, const float* Pn, const float* Mi, const float* q, const int64_t* batch, int o3, int N,
+                             int F, float* gMi, float* gPn, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_message_bwd_node, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, gCh, Pn, Mi, q, batch, o3, N, F, gMi,
+                     gPn);
+}
+
+// block-level sum of up to 4 values over blockDim threads (blockDim multiple of 64, <= 256)
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red /* [4*NV] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+  if (nw == 1) return;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[wave * NV + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += red[w * NV + k];
+    v[k] = s;
+  }
+}
+
+// per-pair weight gradient of one interaction layer + the first step of the edge-MLP reverse chain
+//   g_w[p,k,f] = sum_{c in k} gMi[i,c,f] Pn[j,c,f] + gMi[j,c,f] Pn[i,c,f]
+//   g_e3 = g_w * C(d) * silu'(e3) ;  gC[p] += sum_{k,f} g_w * silu(e3)
+__global__ void k_pair_bwd(Graph g, int P, int F, const float* __restrict__ gMi, const float* __restrict__ Pn,
+                           const float* __restrict__ e3, const float* __restrict__ C, float* __restrict__ g_e3,
+                           float* __restrict__ gC) {
+  __shared__ float red[4];
+  const int p = blockIdx.x;
+  const int i = g.pair_i[p], j = g.pair_j[p];
+  const float cp = C[p];
+  const int F9 = 9 * F, F3 = 3 * F;
+  float part[1] = {0.f};
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    const float* gi = gMi + (int64_t)i * F9 + f;
+    const float* gj = gMi + (int64_t)j * F9 + f;
+    const float* pi = Pn + (int64_t)i * F9 + f;
+    const float* pj = Pn + (int64_t)j * F9 + f;
+    float gw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gw[type_of(c)] += gi[c * F] * pj[c * F] + gj[c * F] * pi[c * F];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float e = e3[(int64_t)p * F3 + k * F + f];
+      g_e3[(int64_t)p * F3 + k * F + f] = gw[k] * cp * silu_grad(e);
+      part[0] += gw[k] * silu(e);
+    }
+  }
+  block_sum<1>(part, red);
+  if (threadIdx.x == 0) gC[p] += part[0];
+}
+void launch_pair_bwd(const Graph& g, int P, int F, const float* gMi, const float* Pn, const float* e3, const float* C, float* g_e3,
+                     float* gC, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(k_pair_bwd, dim3(P), dim3(fthreads(F)), 0, s, g, P, F, gMi, Pn, e3, C, g_e3, gC);
+}
+
+// G <- (G + gXh_lin)/(s+1) + dquad(X) * g_s ,  g_s = -sum (G + gXh_lin).X / (s+1)^2
+__global__ void k_norm_bwd(const float* __restrict__ X, const float* __restrict__ gl, int N, int F, float* __restrict__ G) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
+  float u[9], gx[9], l[9], dq[9];
+  load9(X + (int64_t)n * 9 * F + f, F, u);
+  load9(G + (int64_t)n * 9 * F + f, F, gx);
+  load9(gl + (int64_t)n * 9 * F + f, F, l);
+  dquad(u, dq);
+  const float inv = 1.0f / (quad(u) + 1.0f);
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    gx[c] += l[c];
+    dot += gx[c] * u[c];
+  }
+  const float g_s = -dot * inv * inv;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) gx[c] = gx[c] * inv + dq[c] * g_s;
+  store9(G + (int64_t)n * 9 * F + f, F, gx);
+}
+void launch_norm_bwd(const float* X, const float* gXh_lin, int N, int F, float* G, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_norm_bwd, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, X, gXh_lin, N, F, G);
+}
+
+// X1[c] = UX[c] * gate[type(c)]: gUX = G * gate ; g_gate = sum_c G*UX ; g_a2 = g_gate * silu'(a2)
+__global__ void k_embed_gate_bwd(const float* __restrict__ G, const float* __restrict__ UX, const float* __restrict__ gates,
+                                 const float* __restrict__ a2, int N, int F, float* __restrict__ gUX, float* __restrict__ g_a2) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
+  float gg[9], ux[9], o[9];
+  load9(G + (int64_t)n * 9 * F + f, F, gg);
+  load9(UX + (int64_t)n * 9 * F + f, F, ux);
+  const float* gt = gates + (int64_t)n * 3 * F + f;
+  const float g3[3] = {gt[0], gt[F], gt[2 * F]};
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    o[c] = gg[c] * g3[type_of(c)];
+    acc[type_of(c)] += gg[c] * ux[c];
+  }
+  store9(gUX + (int64_t)n * 9 * F + f, F, o);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g_a2[(int64_t)n * 3 * F + k * F + f] = acc[k] * silu_grad(a2[(int64_t)n * 3 * F + k * F + f]);
+}
+void launch_embed_gate_bwd(const float* G, const float* UX, const float* gates, const float* a2, int N, int F, float* gUX, float* g_a2,
+                           hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_embed_gate_bwd, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, G, UX, gates, a2, N, F, gUX, g_a2);
+}
+
+// g_u0 = g_u0_lin + dquad(u0) g_s0n  ->  gradients wrt (I0, v[3], T00,T01,T02,T11,T12,T22)   [N,10,F]
+__global__ void k_embed_bwd_atom(const float* __restrict__ gl, const float* __restrict__ u0, const float* __restrict__ g_s0n, int N,
+                                 int F, float* __restrict__ gA) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
+  float g[9], u[9], dq[9];
+  load9(gl + (int64_t)n * 9 * F + f, F, g);
+  load9(u0 + (int64_t)n * 9 * F + f, F, u);
+  dquad(u, dq);
+  const float gs = g_s0n[(int64_t)n * F + f];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) g[c] += dq[c] * gs;
+  const float third = (g[4] + g[7]) * (1.0f / 3.0f);
+  float* o = gA + (int64_t)n * 10 * F + f;
+  o[0] = g[0];
+  o[F] = g[1];
+  o[2 * F] = g[2];
+  o[3 * F] = g[3];
+  o[4 * F] = g[4] - third;  // T00
+  o[5 * F] = g[5];          // T01
+  o[6 * F] = g[6];          // T02
+  o[7 * F] = g[7] - third;  // T11
+  o[8 * F] = g[8];          // T12
+  o[9 * F] = -third;        // T22
+}
+void launch_embed_bwd_atom(const float* g_u0_lin, const float* u0, const float* g_s0n, int N, int F, float* gA, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_embed_bwd_atom, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, g_u0_lin, u0, g_s0n, N, F, gA);
+}
+
+// embedding adjoint per pair (both directions at once): gQ[p,3,F], gC[p] +=, g_rhat[p,3]
+__global__ void k_embed_bwd_pair(Graph g, int P, int F, const int64_t* __restrict__ z, const float* __restrict__ Utab,
+                                 const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ C,
+                                 const float* __restrict__ gA, float* __restrict__ gQ, float* __restrict__ gC,
+                                 float* __restrict__ g_rhat) {
+  __shared__ float red[16];
+  const int p = blockIdx.x;
+  const int i = g.pair_i[p], j = g.pair_j[p];
+  const int64_t zi = z[i], zj = z[j];
+  const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
+  const float cp = C[p];
+  const int F3 = 3 * F, F10 = 10 * F;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // gC, g_r0, g_r1, g_r2
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    const float Z1 = Utab[zi * F + f] + Vtab[zj * F + f];  // edge i <- j
+    const float Z2 = Utab[zj * F + f] + Vtab[zi * F + f];  // edge j <- i
+    const float* qp = Q + (int64_t)p * F3 + f;
+    const float q0 = qp[0], q1 = qp[F], q2 = qp[2 * F];
+    float ai[10], aj[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      ai[c] = gA[(int64_t)i * F10 + c * F + f];
+      aj[c] = gA[(int64_t)j * F10 + c * F + f];
+    }
+    const float gW0_1 = ai[0], gW0_2 = aj[0];
+    const float gW1_1 = ai[1] * r0 + ai[2] * r1 + ai[3] * r2;
+    const float gW1_2 = -(aj[1] * r0 + aj[2] * r1 + aj[3] * r2);
+    const float gW2_1 = ai[4] * r0 * r0 + ai[5] * r0 * r1 + ai[6] * r0 * r2 + ai[7] * r1 * r1 + ai[8] * r1 * r2 + ai[9] * r2 * r2;
+    const float gW2_2 = aj[4] * r0 * r0 + aj[5] * r0 * r1 + aj[6] * r0 * r2 + aj[7] * r1 * r1 + aj[8] * r1 * r2 + aj[9] * r2 * r2;
+    const float s0 = Z1 * gW0_1 + Z2 * gW0_2, s1 = Z1 * gW1_1 + Z2 * gW1_2, s2 = Z1 * gW2_1 + Z2 * gW2_2;
+    float* go = gQ + (int64_t)p * F3 + f;
+    go[0] = cp * s0;
+    go[F] = cp * s1;
+    go[2 * F] = cp * s2;
+    acc[0] += q0 * s0 + q1 * s1 + q2 * s2;
+    const float W1_1 = cp * Z1 * q1, W2_1 = cp * Z1 * q2, W1_2 = cp * Z2 * q1, W2_2 = cp * Z2 * q2;
+    // d(quadratic form)/dr for both atoms
+    const float di0 = 2.f * ai[4] * r0 + ai[5] * r1 + ai[6] * r2, dj0 = 2.f * aj[4] * r0 + aj[5] * r1 + aj[6] * r2;
+    const float di1 = ai[5] * r0 + 2.f * ai[7] * r1 + ai[8] * r2, dj1 = aj[5] * r0 + 2.f * aj[7] * r1 + aj[8] * r2;
+    const float di2 = ai[6] * r0 + ai[8] * r1 + 2.f * ai[9] * r2, dj2 = aj[6] * r0 + aj[8] * r1 + 2.f * aj[9] * r2;
+    acc[1] += ai[1] * W1_1 - aj[1] * W1_2 + di0 * W2_1 + dj0 * W2_2;
+    acc[2] += ai[2] * W1_1 - aj[2] * W1_2 + di1 * W2_1 + dj1 * W2_2;
+    acc[3] += ai[3] * W1_1 - aj[3] * W1_2 + di2 * W2_1 + dj2 * W2_2;
+  }
+  block_sum<4>(acc, red);
+  if (threadIdx.x == 0) {
+    gC[p] += acc[0];
+    g_rhat[p * 3] = acc[1];
+    g_rhat[p * 3 + 1] = acc[2];
+    g_rhat[p * 3 + 2] = acc[3];
+  }
+}
+void launch_embed_bwd_pair(const Graph& g, int P, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                           const float* C, const float* gA, float* gQ, float* gC, float* g_rhat, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(k_embed_bwd_pair, dim3(P), dim3(fthreads(F)), 0, s, g, P, F, z, Utab, Vtab, Q, C, gA, gQ, gC, g_rhat);
+}
+
+// g_d = gC C'(d) + sum_k g_phi phi_k'(d) ;  g_delta = (g_r - (g_r.r) r)/d + g_d r   (reference neighbor_utils.py:11-46)
+__global__ void k_geom(Graph g, int P, int K, const float* __restrict__ gC, const float* __restrict__ dC,
+                       const float* __restrict__ g_phi, const float* __restrict__ dphi, const float* __restrict__ g_rhat,
+                       float* __restrict__ g_delta) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float gd = gC[p] * dC[p];
+  for (int k = 0; k < K; ++k) gd += g_phi[(int64_t)p * K + k] * dphi[(int64_t)p * K + k];
+  const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
+  const float d = g.pd[p];
+  const float inv = d > 0.f ? 1.0f / d : 0.f;
+  const float a0 = g_rhat[p * 3], a1 = g_rhat[p * 3 + 1], a2 = g_rhat[p * 3 + 2];
+  const float dot = a0 * r0 + a1 * r1 + a2 * r2;
+  g_delta[p * 3] = (a0 - dot * r0) * inv + gd * r0;
+  g_delta[p * 3 + 1] = (a1 - dot * r1) * inv + gd * r1;
+  g_delta[p * 3 + 2] = (a2 - dot * r2) * inv + gd * r2;
+}
+void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC, const float* g_phi, const float* dphi,
+                 const float* g_rhat, float* g_delta, hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(k_geom, dim3(cdiv(P, 256)), dim3(256), 0, s, g, P, K, gC, dC, g_phi, dphi, g_rhat, g_delta);
+}
+
+// F_i = - sum_{e in row(i)} sign(e) * g_delta[pair(e)]     (no atomics: CSR gather)
+__global__ void k_force_gather(Graph g, int N, const float* __restrict__ g_delta, float* __restrict__ forces) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  for (int e = g.rowptr[i]; e < g.rowptr[i + 1]; ++e) {
+    const float sg = g.esign[e];
+    if (sg == 0.f) continue;
+    const int p = g.epair[e];
+    fx -= sg * g_delta[p * 3];
+    fy -= sg * g_delta[p * 3 + 1];
+    fz -= sg * g_delta[p * 3 + 2];
+  }
+  forces[i * 3] = fx;
+  forces[i * 3 + 1] = fy;
+  forces[i * 3 + 2] = fz;
+}
+void launch_force_gather(const Graph& g, int N, const float* g_delta, float* forces, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_force_gather, dim3(cdiv(N, 128)), dim3(128), 0, s, g, N, g_delta, forces);
+}
+
+__global__ void k_fill(float* p, float v, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void launch_fill(float* p, float v, int64_t n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, s, p, v, n);
+}
+
+}  // namespace tn

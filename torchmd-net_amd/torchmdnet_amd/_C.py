@@ -1,0 +1,87 @@
+"""ctypes binding of libtmdnet_amd.so (include/tmdnet_amd.h).
+
+There is NO CPU fallback: if the shared library is missing or a symbol is absent the import of the
+compute path fails loudly.  The library itself needs a gfx950 device only when a compute entry
+point is called; dlopen + symbol lookup work on a CPU-only host (used by the "not gpu" tests).
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtmdnet_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "tmdnet_amd.h")
+
+OK, ERR_INVALID, ERR_HIP, ERR_OVERFLOW, ERR_WORKSPACE, ERR_STATE = 0, 1, 2, 3, 4, 5
+
+
+class HParams(C.Structure):
+    _fields_ = [
+        ("hidden_channels", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("num_rbf", C.c_int32),
+        ("max_z", C.c_int32),
+        ("max_num_neighbors", C.c_int32),
+        ("group_o3", C.c_int32),
+        ("head_hidden", C.c_int32),
+        ("has_atomref", C.c_int32),
+        ("cutoff_lower", C.c_float),
+        ("cutoff_upper", C.c_float),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (built in-tree by __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python __graft_entry__.py). "
+            "torchmdnet_amd has no CPU or eager-PyTorch fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+    L.tmdnet_create.argtypes = [C.POINTER(HParams), C.POINTER(vp)]
+    L.tmdnet_destroy.argtypes = [vp]
+    L.tmdnet_last_error.argtypes = [vp]
+    L.tmdnet_last_error.restype = C.c_char_p
+    L.tmdnet_version.restype = C.c_char_p
+    L.tmdnet_set_param.argtypes = [vp, C.c_char_p, vp, i64]
+    L.tmdnet_finalize_params.argtypes = [vp]
+    L.tmdnet_num_params.argtypes = [vp]
+    L.tmdnet_param_name.argtypes = [vp, C.c_int, C.POINTER(i64)]
+    L.tmdnet_param_name.restype = C.c_char_p
+    L.tmdnet_graph_workspace_bytes.argtypes = [vp, i64, i64, C.POINTER(sz)]
+    L.tmdnet_build_graph.argtypes = [vp, vp, vp, sz, i64, i64, vp, vp, vp, i32, C.POINTER(i64)]
+    L.tmdnet_forward_workspace_bytes.argtypes = [vp, i64, i64, i64, i64, i32, C.POINTER(sz)]
+    L.tmdnet_energy_forces.argtypes = [vp, vp, vp, vp, sz, i64, i64, i64, vp, vp, vp, i32, vp, vp]
+    L.tmdnet_neighbor_workspace_bytes.argtypes = [i64, i64, i64, C.POINTER(sz)]
+    L.tmdnet_neighbor_pairs.argtypes = [vp, vp, sz, i64, i64, vp, vp, vp, i32, f32, f32, i64, i32, i32, vp, vp, vp, vp]
+    L.tmdnet_debug_tensor.argtypes = [vp, vp, C.c_char_p, vp, i64]
+    L.tmdnet_debug_gemm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32]
+    for name in declared_symbols():
+        fn = getattr(L, name)
+        if fn.restype is C.c_int:
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def declared_symbols():
+    """Every function declared in include/tmdnet_amd.h."""
+    with open(HEADER_PATH) as fh:
+        txt = fh.read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tmdnet_[a-z_]+)\s*\(", txt)))
+
+
+def check_symbols():
+    L = lib()
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    if missing:
+        raise ImportError(f"libtmdnet_amd.so does not export: {missing}")
+    return declared_symbols()

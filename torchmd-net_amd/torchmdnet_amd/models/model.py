@@ -1,0 +1,452 @@
+"""Model assembly with the reference's public surface (torchmdnet/models/model.py):
+``create_model(args, prior_model=None, mean=None, std=None)``, ``load_model(filepath, args=None, device="cpu",
+return_std=False, **kwargs)``, ``load_ensemble``, ``create_prior_models`` and the ``TorchMD_Net`` /
+``Ensemble`` modules whose ``forward(z, pos, batch, box, q, s, extra_args, num_systems) -> (y, neg_dy)``
+keeps the reference's conventions (model.py:530-631).
+
+Everything numerical happens behind the C ABI of libtmdnet_amd.so (include/tmdnet_amd.h): this file
+only owns parameters (state-dict compatible with the reference), marshals
+pointers, and maps status codes to the reference's exceptions.  There is no CPU path.
+"""
+import copy
+import ctypes as C
+import os
+import re
+import tempfile
+import warnings
+import zipfile
+from glob import glob
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from torchmdnet_amd import _C, priors
+from torchmdnet_amd.models import output_modules
+from torchmdnet_amd.models.utils import _ptr, _require_cuda, _stream_ptr, dtype_mapping
+
+
+# --------------------------------------------------------------------------------------------------
+def create_model(args, prior_model=None, mean=None, std=None):
+    """Same argument dict as the reference (model.py:21-164).  Supported on the HIP path:
+    model == "tensornet", output_model == "Scalar", precision 32, prior_model in {None, Atomref}."""
+    dtype = dtype_mapping[args["precision"]]
+    if "box_vecs" not in args:
+        args["box_vecs"] = None
+    if "static_shapes" not in args:
+        args["static_shapes"] = False
+    if "vector_cutoff" not in args:
+        args["vector_cutoff"] = False
+    if dtype != torch.float32:
+        raise NotImplementedError("torchmdnet_amd computes in fp32 (BASELINE north_star); precision="
+                                  f"{args['precision']} has no HIP path")
+    shared_args = dict(
+        hidden_channels=args["embedding_dimension"],
+        num_layers=args["num_layers"],
+        num_rbf=args["num_rbf"],
+        rbf_type=args["rbf_type"],
+        trainable_rbf=args["trainable_rbf"],
+        activation=args["activation"],
+        cutoff_lower=float(args["cutoff_lower"]),
+        cutoff_upper=float(args["cutoff_upper"]),
+        max_z=args["max_z"],
+        max_num_neighbors=args["max_num_neighbors"],
+        box_vecs=(torch.tensor(args["box_vecs"], dtype=dtype) if args["box_vecs"] is not None else None),
+        dtype=dtype,
+    )
+    if args["model"] == "tensornet":
+        from torchmdnet_amd.models.tensornet import TensorNet
+
+        representation_model = TensorNet(
+            equivariance_invariance_group=args["equivariance_invariance_group"],
+            static_shapes=args["static_shapes"],
+            **shared_args,
+        )
+    elif args["model"] in ("graph-network", "transformer", "equivariant-transformer", "tensornet2"):
+        raise NotImplementedError(f'architecture {args["model"]} has no MI355X-native path in this build (SURVEY.md 8(f))')
+    else:
+        raise ValueError(f'Unknown architecture: {args["model"]}')
+
+    if args.get("atom_filter", -1) > -1:
+        if args["derivative"]:
+            raise ValueError("Derivative and atom filter can't be used together")
+        raise NotImplementedError("AtomFilter wrapper is out of scope of the energy+force path")
+
+    if args["prior_model"] and prior_model is None:
+        prior_model = create_prior_models(args)
+
+    if args["output_model"] != "Scalar":
+        raise NotImplementedError(f'output_model {args["output_model"]} has no HIP path (Scalar only)')
+    output_model = output_modules.Scalar(
+        args["embedding_dimension"],
+        activation=args["activation"],
+        reduce_op=args["reduce_op"],
+        dtype=dtype,
+        static_shapes=args.get("static_shapes", False),
+        num_hidden_layers=args.get("output_mlp_num_layers", 0),
+        num_layers=0,
+    )
+    return TorchMD_Net(representation_model, output_model, prior_model=prior_model, mean=mean, std=std,
+                       derivative=args["derivative"], dtype=dtype)
+
+
+def load_ensemble(filepath, args=None, device="cpu", return_std=False, **kwargs):
+    """List of checkpoints or a zip of ``*.ckpt`` files -> Ensemble (reference model.py:167-205)."""
+    if isinstance(filepath, (list, tuple)):
+        assert all(isinstance(f, str) for f in filepath), "Invalid filepath list."
+        model_list = [load_model(f, args=args, device=device, **kwargs) for f in filepath]
+    elif filepath.endswith(".zip"):
+        with tempfile.TemporaryDirectory() as tmpdir:
+            with zipfile.ZipFile(filepath, "r") as zf:
+                zf.extractall(tmpdir)
+            ckpt_list = glob(os.path.join(tmpdir, "*.ckpt"))
+            assert len(ckpt_list) > 0, "No checkpoint files found in zip file."
+            model_list = [load_model(f, args=args, device=device, **kwargs) for f in ckpt_list]
+    else:
+        raise ValueError("Invalid filepath. Must be a list of paths or a path to a zip file.")
+    return Ensemble(model_list, return_std=return_std)
+
+
+def _remix_rows(weight, bias):
+    """Old checkpoints stored per-atom tensors as [N,F,3,3]; the gate/edge-weight linears then emit
+    F*3 interleaved rows.  Reorder to the current 3*F blocks (reference model.py:296-331)."""
+    a, b = weight.shape
+    weight = weight.view(a // 3, 3, b).transpose(0, 1).reshape(a, b)
+    bias = bias.view(a // 3, 3).transpose(0, 1).reshape(a)
+    return weight.contiguous(), bias.contiguous()
+
+
+def load_model(filepath, args=None, device="cpu", return_std=False, **kwargs):
+    """Consume a Lightning checkpoint written by the reference (model.py:208-374): hyper_parameters
+    (overridable through kwargs), ``model.`` key prefix, legacy key renames, missing ``distance.box``
+    buffer, old-layout remix (auto-detected through ``check_errors`` or forced with
+    ``compatibility_load``), Atomref enable toggle for ``remove_ref_energy=False``."""
+    if isinstance(filepath, (list, tuple)) or filepath.endswith(".zip"):
+        return load_ensemble(filepath, args=args, device=device, return_std=return_std, **kwargs)
+    assert isinstance(filepath, str)
+    ckpt = torch.load(filepath, map_location="cpu", weights_only=False)
+    if args is None:
+        args = ckpt["hyper_parameters"]
+    delta_learning = args["remove_ref_energy"] if "remove_ref_energy" in args else False
+    for key, value in kwargs.items():
+        if key not in args:
+            warnings.warn(f"Unknown hyperparameter: {key}={value}")
+        args[key] = value
+    if args["model"] in ("tensornetv2_alt", "tensornet-nqe"):
+        args["model"] = "tensornet2"
+
+    model = create_model(args)
+    if delta_learning and "remove_ref_energy" in kwargs and not kwargs["remove_ref_energy"]:
+        assert model.prior_model is not None and len(model.prior_model) > 0, (
+            "Atomref prior must be added during training (with enable=False) for total energy prediction.")
+        assert isinstance(model.prior_model[-1], priors.Atomref), "I expected the last prior to be Atomref."
+        model.prior_model[-1].enable = True
+
+    state_dict = {re.sub(r"^model\.", "", k): v for k, v in ckpt["state_dict"].items()}
+    renames = [
+        (r"output_model.output_network.(\d+).update_net.(\d+).", r"output_model.output_network.\1.update_net.layers.\2."),
+        (r"output_model.output_network.([02]).(weight|bias)", r"output_model.output_network.layers.\1.\2"),
+    ]
+    for pat, rep in renames:
+        state_dict = {re.sub(pat, rep, k): v for k, v in state_dict.items()}
+    if "representation_model.distance.box" not in state_dict:
+        state_dict["representation_model.distance.box"] = torch.zeros((3, 3), device="cpu")
+
+    is_old = "check_errors" in ckpt.get("hyper_parameters", {})
+    if kwargs.get("compatibility_load", is_old):
+        if is_old and "compatibility_load" not in kwargs:
+            warnings.warn("Old-format checkpoint detected ('check_errors' found in hyper_parameters). Automatically "
+                          "applying compatibility_load to remap linear-layer weights. Pass compatibility_load=False "
+                          "to suppress this.")
+        keys = ["representation_model.tensor_embedding.linears_scalar.1"]
+        keys += [f"representation_model.layers.{l}.linears_scalar.2" for l in range(args["num_layers"])]
+        for k in keys:
+            state_dict[k + ".weight"], state_dict[k + ".bias"] = _remix_rows(state_dict[k + ".weight"], state_dict[k + ".bias"])
+
+    model.load_state_dict(state_dict)
+    return model.to(device)
+
+
+def create_prior_models(args, dataset=None):
+    """Parse ``prior_model`` / ``prior_args`` exactly like the reference (model.py:377-448); only priors
+    that exist in torchmdnet_amd.priors can be instantiated (Atomref)."""
+    prior_models = []
+    if args["prior_model"]:
+        prior_model = args["prior_model"]
+        names, pargs = [], []
+        if not isinstance(prior_model, list):
+            prior_model = [prior_model]
+        for prior in prior_model:
+            if isinstance(prior, dict):
+                for key, value in prior.items():
+                    names.append(key)
+                    pargs.append({} if value is None else value)
+            else:
+                names.append(prior)
+                pargs.append({})
+        if "prior_args" in args and args["prior_args"] is not None:
+            pargs = args["prior_args"]
+            if not isinstance(pargs, list):
+                pargs = [pargs]
+        for name, arg in zip(names, pargs):
+            if not hasattr(priors, name):
+                raise NotImplementedError(f"prior model {name} has no MI355X-native path (available: {priors.__all__})")
+            prior_models.append(getattr(priors, name)(dataset=dataset, **arg))
+    return prior_models
+
+
+# --------------------------------------------------------------------------------------------------
+class _EngineState:
+    """Per-module handle of the HIP library + caller-owned workspaces.  Never copied or pickled."""
+
+    def __init__(self):
+        self.handle = None
+        self.fingerprint = None
+        self.graph_ws = None
+        self.fwd_ws = None
+        self.counts = None
+
+    def release(self):
+        if self.handle is not None:
+            _C.lib().tmdnet_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def __deepcopy__(self, memo):
+        return _EngineState()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
+
+class _AttachPosGrad(torch.autograd.Function):
+    """Makes the energy differentiable wrt ``pos`` when ``derivative=False`` (ASE calculator and OpenMM
+    wrapper call ``energy.backward()``, reference calculators.py:311-316).  Molecules are independent,
+    so d(sum_m g_m E_m)/d pos_i = g_{batch_i} * dE/dpos_i = -g_{batch_i} * F_i."""
+
+    @staticmethod
+    def forward(ctx, pos, y, forces, batch):
+        ctx.save_for_backward(forces, batch)
+        return y.clone()
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        forces, batch = ctx.saved_tensors
+        return -forces * grad_y.reshape(-1)[batch].unsqueeze(-1), None, None, None
+
+
+class TorchMD_Net(nn.Module):
+    """Representation + output head + priors (reference model.py:451-631), evaluated by one fused HIP schedule."""
+
+    def __init__(self, representation_model, output_model, prior_model=None, mean=None, std=None, derivative=False,
+                 dtype=torch.float32):
+        super().__init__()
+        self.representation_model = representation_model.to(dtype=dtype)
+        self.output_model = output_model.to(dtype=dtype)
+        if not output_model.allow_prior_model and prior_model is not None:
+            prior_model = None
+            warnings.warn("Prior model was given but the output model does not allow prior models. Dropping the prior model.")
+        if isinstance(prior_model, priors.BasePrior):
+            prior_model = [prior_model]
+        if prior_model is not None:
+            for p in prior_model:
+                if not isinstance(p, priors.Atomref):
+                    raise NotImplementedError(f"prior {type(p).__name__} has no MI355X-native path")
+        self.prior_model = None if prior_model is None else nn.ModuleList(prior_model).to(dtype=dtype)
+        self.derivative = derivative
+        mean = torch.scalar_tensor(0) if mean is None else mean
+        self.register_buffer("mean", mean.to(dtype=dtype))
+        std = torch.scalar_tensor(1) if std is None else std
+        self.register_buffer("std", std.to(dtype=dtype))
+        self._engine = _EngineState()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.representation_model.reset_parameters()
+        self.output_model.reset_parameters()
+        if self.prior_model is not None:
+            for prior in self.prior_model:
+                prior.reset_parameters()
+
+    # ---------------------------------------------------------------- engine plumbing
+    def _hparams(self) -> _C.HParams:
+        rm = self.representation_model
+        hp = _C.HParams()
+        hp.hidden_channels = rm.hidden_channels
+        hp.num_layers = rm.num_layers
+        hp.num_rbf = rm.num_rbf
+        hp.max_z = rm.max_z
+        hp.max_num_neighbors = rm.max_num_neighbors
+        hp.group_o3 = 1 if rm.equivariance_invariance_group == "O(3)" else 0
+        hp.head_hidden = self.output_model.output_network.layers[0].out_features
+        hp.has_atomref = 1 if self._atomref_table() is not None else 0
+        hp.cutoff_lower = float(rm.cutoff_lower)
+        hp.cutoff_upper = float(rm.cutoff_upper)
+        return hp
+
+    def _atomref_table(self) -> Optional[Tensor]:
+        if self.prior_model is None:
+            return None
+        tables = [p.atomref.weight.detach().reshape(-1) for p in self.prior_model if p.enable]
+        if not tables:
+            return None
+        max_z = self.representation_model.max_z
+        out = torch.zeros(max_z, dtype=torch.float32)
+        for t in tables:
+            n = min(max_z, t.numel())
+            out[:n] += t[:n].float().cpu()
+        return out
+
+    def _fingerprint(self):
+        fp = [(k, v._version, v.data_ptr()) for k, v in self.state_dict(keep_vars=True).items()]
+        if self.prior_model is not None:
+            fp.append(tuple(p.enable for p in self.prior_model))
+        return tuple(fp)
+
+    def _sync_engine(self):
+        """(Re)create the library handle and upload the parameters when they changed."""
+        st = self._engine
+        fp = self._fingerprint()
+        if st.handle is not None and st.fingerprint == fp:
+            return st
+        L = _C.lib()
+        st.release()
+        hp = self._hparams()
+        handle = C.c_void_p()
+        rc = L.tmdnet_create(C.byref(hp), C.byref(handle))
+        if rc != _C.OK:
+            raise RuntimeError(f"tmdnet_create failed with code {rc}")
+        st.handle = handle
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        table = self._atomref_table()
+        if table is not None:
+            sd["atomref"] = table
+        n = L.tmdnet_num_params(handle)
+        for i in range(n):
+            numel = C.c_int64()
+            name = L.tmdnet_param_name(handle, i, C.byref(numel)).decode()
+            if name not in sd:
+                raise RuntimeError(f"state dict lacks parameter {name}")
+            t = sd[name].to(device="cpu", dtype=torch.float32).contiguous().reshape(-1)
+            rc = L.tmdnet_set_param(handle, name.encode(), C.c_void_p(t.data_ptr()), t.numel())
+            if rc != _C.OK:
+                raise RuntimeError(L.tmdnet_last_error(handle).decode())
+        rc = L.tmdnet_finalize_params(handle)
+        if rc != _C.OK:
+            raise RuntimeError(L.tmdnet_last_error(handle).decode())
+        st.fingerprint = fp
+        return st
+
+    @staticmethod
+    def _grow(buf, nbytes, device):
+        if buf is None or buf.numel() < nbytes or buf.device != device:
+            return torch.empty(max(int(nbytes * 1.1), 256), dtype=torch.uint8, device=device)
+        return buf
+
+    def energy_and_forces(self, z, pos, batch, box, q, n_mol, want_forces=True) -> Tuple[Tensor, Optional[Tensor]]:
+        """Raw engine call: returns (E [n_mol], F [N,3] or None), both fp32 on ``pos.device``."""
+        _require_cuda(pos, "TorchMD_Net.forward")
+        L = _C.lib()
+        dev = pos.device
+        if next(self.parameters()).device != dev:
+            raise RuntimeError("model and inputs are on different devices")
+        with torch.cuda.device(dev):
+            st = self._sync_engine()
+            stream = _stream_ptr(dev)
+            n = int(z.shape[0])
+            p32 = pos.detach().to(torch.float32).contiguous()
+            z = z.contiguous()
+            batch = batch.to(torch.long).contiguous()
+            box_mode = 0
+            if box is not None:
+                box = box.detach().to(device=dev, dtype=torch.float32).contiguous()
+                box_mode = 1 if box.dim() == 2 else 2
+            if q is not None:
+                q = q.detach().to(device=dev, dtype=torch.float32).contiguous()
+                if q.numel() != n_mol:
+                    raise ValueError(f"q must have one entry per molecule ({n_mol}), got {q.numel()}")
+            nbytes = C.c_size_t(0)
+            L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
+            st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
+            counts = (C.c_int64 * 4)()
+            rc = L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32), _ptr(batch),
+                                      _ptr(box), box_mode, counts)
+            if rc == _C.ERR_OVERFLOW:
+                # same exception type and message as the reference (models/utils.py:297-300)
+                raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
+            if rc != _C.OK:
+                raise RuntimeError(f"tmdnet_build_graph: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
+            n_pairs, n_edges = int(counts[0]), int(counts[1])
+            st.counts = (n_pairs, n_edges, int(counts[3]))
+            L.tmdnet_forward_workspace_bytes(st.handle, n, n_mol, n_pairs, n_edges, int(want_forces), C.byref(nbytes))
+            st.fwd_ws = self._grow(st.fwd_ws, nbytes.value, dev)
+            energy = torch.empty(n_mol, dtype=torch.float32, device=dev)
+            forces = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_forces else None
+            rc = L.tmdnet_energy_forces(st.handle, stream, _ptr(st.graph_ws), _ptr(st.fwd_ws), st.fwd_ws.numel(), n, n_mol,
+                                        n_pairs, _ptr(z), _ptr(batch), _ptr(q), int(want_forces), _ptr(energy), _ptr(forces))
+            if rc != _C.OK:
+                raise RuntimeError(f"tmdnet_energy_forces: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
+        return energy, forces
+
+    def debug_tensor(self, name: str, shape) -> Tensor:
+        L = _C.lib()
+        st = self._engine
+        dev = st.fwd_ws.device
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+        rc = L.tmdnet_debug_tensor(st.handle, _stream_ptr(dev), name.encode(), _ptr(out), out.numel())
+        if rc != _C.OK:
+            raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
+        return out
+
+    # ---------------------------------------------------------------- reference-compatible forward
+    def forward(self, z: Tensor, pos: Tensor, batch: Optional[Tensor] = None, box: Optional[Tensor] = None,
+                q: Optional[Tensor] = None, s: Optional[Tensor] = None, extra_args: Optional[Dict[str, Tensor]] = None,
+                num_systems: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+        assert z.dim() == 1 and z.dtype == torch.long
+        batch = torch.zeros_like(z) if batch is None else batch
+        if pos.dtype != torch.float32:
+            raise NotImplementedError("torchmdnet_amd computes in fp32; cast positions to float32")
+        if self.derivative:
+            pos.requires_grad_(True)  # reference side effect (model.py:584-585)
+        n_mol = int(num_systems) if num_systems is not None else (int(batch.max().item()) + 1 if z.numel() else 0)
+        rm = self.representation_model
+        if box is None and rm.distance.use_periodic:
+            box = rm.distance.box
+        want_forces = self.derivative or (pos.requires_grad and torch.is_grad_enabled())
+        energy, forces = self.energy_and_forces(z, pos, batch, box, q, n_mol, want_forces=want_forces)
+        y = energy.view(-1, 1)
+        if self.derivative:
+            return y, forces
+        if want_forces:
+            y = _AttachPosGrad.apply(pos, y, forces, batch.to(torch.long))
+        # an empty tensor keeps the reference's "always two tensors" contract (model.py:629-631)
+        return y, torch.empty(0, device=y.device)
+
+
+class Ensemble(torch.nn.ModuleList):
+    """Average (and optionally std) of several models' predictions (reference model.py:634-680)."""
+
+    def __init__(self, modules: List[nn.Module], return_std: bool = False):
+        for module in modules:
+            assert isinstance(module, TorchMD_Net)
+        super().__init__(modules)
+        self.return_std = return_std
+
+    def forward(self, *args, **kwargs):
+        ys, fs = [], []
+        for model in self:
+            y, f = model(*args, **kwargs)
+            ys.append(y)
+            fs.append(f)
+        y, f = torch.stack(ys), torch.stack(fs)
+        if self.return_std:
+            return torch.mean(y, axis=0), torch.mean(f, axis=0), torch.std(y, axis=0), torch.std(f, axis=0)
+        return torch.mean(y, axis=0), torch.mean(f, axis=0)

@@ -1,0 +1,194 @@
+"""Host-side mirrors of the reference's torchmdnet/models/utils.py classes that sit on the hot path.
+
+These modules own parameters/buffers under the reference's state-dict names so that existing
+checkpoints load unchanged; the arithmetic itself runs in the HIP library (torchmdnet_amd._C).
+Standalone callables (OptimizedDistance) go through the library's fine-grained operator.
+"""
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from torchmdnet_amd import _C
+
+
+def _require_cuda(t: Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"torchmdnet_amd: {what} runs only on an AMD GPU through the HIP extension; got a {t.device} tensor. "
+            "There is no CPU / eager fallback by design."
+        )
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class CosineCutoff(nn.Module):
+    """Parameter-free; evaluated inside the radial kernel (reference models/utils.py:500-528)."""
+
+    def __init__(self, cutoff_lower=0.0, cutoff_upper=5.0):
+        super().__init__()
+        self.cutoff_lower = cutoff_lower
+        self.cutoff_upper = cutoff_upper
+
+
+class ExpNormalSmearing(nn.Module):
+    """Owns ``means`` / ``betas`` (reference models/utils.py:356-407); evaluated in the radial kernel."""
+
+    def __init__(self, cutoff_lower=0.0, cutoff_upper=5.0, num_rbf=50, trainable=True, dtype=torch.float32):
+        super().__init__()
+        self.cutoff_lower = cutoff_lower
+        self.cutoff_upper = cutoff_upper
+        self.num_rbf = num_rbf
+        self.trainable = trainable
+        self.dtype = dtype
+        self.alpha = 5.0 / (cutoff_upper - cutoff_lower)
+        means, betas = self._initial_params()
+        if trainable:
+            self.register_parameter("means", nn.Parameter(means))
+            self.register_parameter("betas", nn.Parameter(betas))
+        else:
+            self.register_buffer("means", means)
+            self.register_buffer("betas", betas)
+
+    def _initial_params(self):
+        # PhysNet defaults, same formulas as the reference (models/utils.py:382-395)
+        start = torch.exp(torch.scalar_tensor(-self.cutoff_upper + self.cutoff_lower, dtype=self.dtype))
+        means = torch.linspace(start, 1, self.num_rbf, dtype=self.dtype)
+        betas = torch.tensor([(2 / self.num_rbf * (1 - start)) ** -2] * self.num_rbf, dtype=self.dtype)
+        return means, betas
+
+    def reset_parameters(self):
+        means, betas = self._initial_params()
+        self.means.data.copy_(means)
+        self.betas.data.copy_(betas)
+
+
+rbf_class_mapping = {"expnorm": ExpNormalSmearing}
+act_class_mapping = {"silu": nn.SiLU}
+dtype_mapping = {16: torch.float16, 32: torch.float, 64: torch.float64}
+
+
+class MLP(nn.Module):
+    """Parameter container with the reference's layout ``layers.{0,2,..}`` (models/utils.py:531-580)."""
+
+    def __init__(self, in_channels, out_channels, hidden_channels, activation, num_hidden_layers=0, dtype=torch.float32):
+        super().__init__()
+        self.act = act_class_mapping[activation]()
+        self.layers = nn.Sequential()
+        self.layers.append(nn.Linear(in_channels, hidden_channels, dtype=dtype))
+        self.layers.append(self.act)
+        for _ in range(num_hidden_layers):
+            self.layers.append(nn.Linear(hidden_channels, hidden_channels, dtype=dtype))
+            self.layers.append(self.act)
+        self.layers.append(nn.Linear(hidden_channels, out_channels, dtype=dtype))
+
+    def reset_parameters(self):
+        for layer in self.layers:
+            if isinstance(layer, nn.Linear):
+                nn.init.xavier_uniform_(layer.weight)
+                layer.bias.data.fill_(0)
+
+
+class OptimizedDistance(nn.Module):
+    """Neighbour list with the reference's interface and conventions (models/utils.py:120-313):
+    ``edge_vec = pos[edge_index[0]] - pos[edge_index[1]]`` (+ triclinic minimum image), pairs padded
+    with (-1,-1) unless ``resize_to_fit``, RuntimeError when more than ``max_num_pairs`` are found.
+    Both strategies run the same molecule-restricted HIP pair search (deterministic order)."""
+
+    def __init__(self, cutoff_lower=0.0, cutoff_upper=5.0, max_num_pairs=-32, return_vecs=False, loop=False,
+                 strategy="brute", include_transpose=True, resize_to_fit=True, box=None, long_edge_index=True):
+        super().__init__()
+        if strategy not in ("brute", "cell"):
+            raise ValueError(f"unknown strategy {strategy}")
+        self.cutoff_upper = cutoff_upper
+        self.cutoff_lower = cutoff_lower
+        self.max_num_pairs = max_num_pairs
+        self.strategy = strategy
+        self.loop = loop
+        self.return_vecs = return_vecs
+        self.include_transpose = include_transpose
+        self.resize_to_fit = resize_to_fit
+        self.use_periodic = box is not None
+        self.long_edge_index = long_edge_index
+        if box is None:
+            box = torch.zeros((3, 3), device="cpu")
+        self.register_buffer("box", box, persistent=True)
+        self._ws = None
+
+    def forward(self, pos: Tensor, batch: Optional[Tensor] = None, box: Optional[Tensor] = None
+                ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+        _require_cuda(pos, "OptimizedDistance")
+        if pos.dtype != torch.float32:
+            raise RuntimeError("torchmdnet_amd neighbour kernels are fp32 (BASELINE north_star); got " + str(pos.dtype))
+        use_periodic = self.use_periodic or box is not None
+        if box is None:
+            box = self.box
+        box = box.to(device=pos.device, dtype=pos.dtype).contiguous()
+        n = pos.shape[0]
+        max_pairs = self.max_num_pairs if self.max_num_pairs >= 0 else -self.max_num_pairs * n
+        if batch is None:
+            batch = torch.zeros(n, dtype=torch.long, device=pos.device)
+        batch = batch.to(torch.long).contiguous()
+        n_mol = int(batch.max().item()) + 1 if n > 0 else 0
+        box_mode = 0 if not use_periodic else (1 if box.dim() == 2 else 2)
+        L = _C.lib()
+        nbytes = C.c_size_t(0)
+        L.tmdnet_neighbor_workspace_bytes(n, n_mol, max_pairs, C.byref(nbytes))
+        if self._ws is None or self._ws.numel() < nbytes.value or self._ws.device != pos.device:
+            self._ws = torch.empty(nbytes.value, dtype=torch.uint8, device=pos.device)
+        neighbors = torch.empty((2, max_pairs), dtype=torch.long, device=pos.device)
+        deltas = torch.empty((max_pairs, 3), dtype=pos.dtype, device=pos.device)
+        dist = torch.empty((max_pairs,), dtype=pos.dtype, device=pos.device)
+        num_pairs = torch.zeros(1, dtype=torch.int32, device=pos.device)
+        p = pos.detach().contiguous()
+        rc = L.tmdnet_neighbor_pairs(_stream_ptr(pos.device), _ptr(self._ws), self._ws.numel(), n, n_mol, _ptr(p),
+                                     _ptr(batch), _ptr(box if use_periodic else None), box_mode, float(self.cutoff_lower),
+                                     float(self.cutoff_upper), max_pairs, int(self.loop), int(self.include_transpose),
+                                     _ptr(neighbors), _ptr(deltas), _ptr(dist), _ptr(num_pairs))
+        if rc != _C.OK:
+            raise RuntimeError(f"tmdnet_neighbor_pairs failed with code {rc}")
+        if int(num_pairs.item()) > max_pairs:  # reference: torch._assert_async -> RuntimeError (models/utils.py:297-300)
+            raise RuntimeError("Found num_pairs > max_num_pairs, please increase max_num_pairs")
+        edge_index, edge_vec, edge_weight = neighbors, deltas, dist
+        if pos.requires_grad:
+            edge_vec, edge_weight = _NeighborGrad.apply(pos, neighbors, deltas, dist)
+        if self.resize_to_fit:
+            mask = edge_index[0] != -1
+            edge_index = edge_index[:, mask]
+            edge_weight = edge_weight[mask]
+            edge_vec = edge_vec[mask, :]
+        if not self.long_edge_index:
+            edge_index = edge_index.to(torch.int32)
+        return (edge_index, edge_weight, edge_vec) if self.return_vecs else (edge_index, edge_weight, None)
+
+
+class _NeighborGrad(torch.autograd.Function):
+    """Gradient of (deltas, distances) wrt positions, as extensions/neighbor_utils.py:11-46 defines it
+    (zero for d = 0).  Plain torch index_add on the GPU: this is glue for standalone use of
+    OptimizedDistance, the model's own force path never goes through it."""
+
+    @staticmethod
+    def forward(ctx, pos, neighbors, deltas, dist):
+        ctx.save_for_backward(neighbors, deltas, dist)
+        ctx.n = pos.shape[0]
+        return deltas.clone(), dist.clone()
+
+    @staticmethod
+    def backward(ctx, g_delta, g_dist):
+        neighbors, deltas, dist = ctx.saved_tensors
+        zero = dist.eq(0) | neighbors[0].eq(-1)
+        safe = dist.masked_fill(zero, 1)
+        g = g_delta.masked_fill(zero[:, None], 0) + (deltas / safe[:, None]) * g_dist.masked_fill(zero, 0)[:, None]
+        idx = neighbors.masked_fill(zero[None, :].expand_as(neighbors), 0)
+        out = torch.zeros((ctx.n, 3), dtype=deltas.dtype, device=deltas.device)
+        out.index_add_(0, idx[0], g)
+        out.index_add_(0, idx[1], -g)
+        return out, None, None, None
