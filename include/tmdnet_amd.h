@@ -109,6 +109,16 @@ int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_ato
                           int64_t max_num_pairs, int32_t loop, int32_t include_transpose, int64_t* neighbors, float* deltas,
                           float* distances, int32_t* num_pairs);
 
+/* ---- per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
+ * selected classes; bit c of category_mask selects class c).  tmdnet_profile_end synchronises the
+ * stream and returns, per class: summed milliseconds, algorithmic FLOPs, algorithmic bytes (each distinct
+ * input/output tensor of a launch counted once) and the number of launches.
+ * Arrays must hold tmdnet_profile_num_categories() entries.  Used by bench.py for `roofline`. */
+int tmdnet_profile_begin(tmdnet_model* m, uint32_t category_mask);
+int tmdnet_profile_end(tmdnet_model* m, void* stream, double* ms, double* flops, double* bytes, int64_t* launches);
+int tmdnet_profile_num_categories(void);
+const char* tmdnet_profile_category_name(int idx);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------
  * Copy an intermediate of the last tmdnet_energy_forces call out of the workspace (device -> device).
  * Names: "X_embed", "X_layer<l>", "x", "phi", "Q", "u0", "G_embed".  Used by the parity tests. */

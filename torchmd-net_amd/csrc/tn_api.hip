@@ -75,8 +75,34 @@ struct FwdBuffers {
 
 }  // namespace
 
+enum ProfCat { CAT_GRAPH = 0, CAT_GEMM_EDGE, CAT_GEMM_NODE, CAT_MESSAGE, CAT_PAIR, CAT_SCATTER, CAT_ELEMENTWISE, CAT_COUNT };
+static const char* kCatNames[CAT_COUNT] = {"graph", "gemm_edge", "gemm_node", "message", "pair_bwd", "embed_scatter", "elementwise"};
+
+struct ProfRec {
+  int cat;
+  hipEvent_t a, b;
+  double flops, bytes;
+};
+struct Profiler {
+  bool on = false;
+  unsigned mask = 0;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  hipEvent_t get() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+};
+
 struct tmdnet_model {
   tmdnet_hparams hp;
+  Profiler prof;
+  int64_t lastE = 0;
   std::vector<ParamSpec> specs;
   std::map<std::string, std::vector<float>> host;
   float* dev = nullptr;  // packed parameters
@@ -161,6 +187,30 @@ struct Packer {
   }
 };
 
+// ---- optional per-launch timing with HIP events on the launch stream (tmdnet_profile_begin/end)
+thread_local tmdnet_model* g_cur = nullptr;
+thread_local int g_gemm_cat = CAT_GEMM_NODE;
+struct ProfScope {
+  int idx = -1;
+  hipStream_t s;
+  ProfScope(hipStream_t s_, int cat, double flops, double bytes) : s(s_) {
+    tmdnet_model* m = g_cur;
+    if (!m || !m->prof.on || !((m->prof.mask >> cat) & 1u)) return;
+    ProfRec r{cat, m->prof.get(), m->prof.get(), flops, bytes};
+    (void)hipEventRecord(r.a, s);
+    idx = (int)m->prof.recs.size();
+    m->prof.recs.push_back(r);
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(g_cur->prof.recs[idx].b, s);
+  }
+};
+#define KR(cat, bytes, call)                      \
+  do {                                            \
+    ProfScope ps_(s, cat, 0.0, (double)(bytes));  \
+    call;                                         \
+  } while (0)
+
 void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc, int M,
           int N, int K, int flags = 0, float* pre = nullptr, int64_t ldpre = 0, const float* aux = nullptr, int64_t ldaux = 0,
           const float* rowscale = nullptr) {
@@ -182,6 +232,9 @@ void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ld
   a.K = K;
   a.groups = 1;
   a.flags = flags;
+  // algorithmic traffic: A and W read once, C (and the saved pre-activation / aux operand) once
+  const double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (1 + (pre ? 1 : 0) + (aux ? 1 : 0) + ((flags & GEMM_ACCUM) ? 1 : 0)));
+  ProfScope ps_(s, g_gemm_cat, 2.0 * M * N * K, bytes);
   launch_gemm(a, s);
 }
 
@@ -209,6 +262,8 @@ void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], floa
   a.K = F;
   a.groups = 9;
   a.flags = flags;
+  const double bytes = 4.0 * (9.0 * N * F * (2 + (pre ? 1 : 0)) + (gates ? 3.0 * N * F : 0.0) + 3.0 * F * F);
+  ProfScope ps_(s, CAT_GEMM_NODE, 2.0 * 9 * N * (double)F * F, bytes);
   launch_gemm(a, s);
 }
 
@@ -506,8 +561,12 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, &need);
   if (need > graph_ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "graph workspace too small");
   if (box_mode != 0 && !box) return fail(m, TMDNET_ERR_INVALID, "box_mode != 0 needs a box");
-  launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper, true,
-                            s);
+  g_cur = m;
+  {
+    ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
+    launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
+                              true, s);
+  }
   int counts[4] = {0, 0, 0, 0};
   HIP_TRY(m, hipMemcpyAsync(counts, g.counts, sizeof(counts), hipMemcpyDeviceToHost, s));
   HIP_TRY(m, hipStreamSynchronize(s));
@@ -515,7 +574,12 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   if (counts[2])
     return fail(m, TMDNET_ERR_OVERFLOW, "Found num_pairs > max_num_pairs, please increase max_num_pairs (found " +
                                             std::to_string(counts[1]) + " edges, capacity " + std::to_string(ecap) + ")");
-  launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+  m->lastE = counts[1];
+  {
+    ProfScope ps_(s, CAT_GRAPH, 0.0, (double)counts[1] * 12 + (double)counts[0] * 40);
+    launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+  }
+  g_cur = nullptr;
   HIP_TRY(m, hipGetLastError());
   return TMDNET_OK;
 }
@@ -549,71 +613,90 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   const DevParams& W = m->P;
   const int o3 = hp.group_o3;
 
+  g_cur = m;
+  const double E_ = (double)m->lastE, Nd = N, Pd = P, Fd = F;
+  const double nodeB = Nd * 9 * Fd * 4;             // one [N,9,F] tensor
+  const double msgB = E_ * (12 * Fd + 8);           // per directed edge: 3F weights + indices
+  auto EDGE = [&]() { g_gemm_cat = CAT_GEMM_EDGE; };
+  auto NODE = [&]() { g_gemm_cat = CAT_GEMM_NODE; };
+
   // ---- radial functions per pair
   RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
-  launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s);
+  KR(CAT_ELEMENTWISE, Pd * (2 * K + 3) * 4, launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s));
   // ---- embedding
+  NODE();
   gemm(s, W.emb, F, W.emb2_w, 2 * F, W.emb2_b, b.Utab, F, Z, F, F);          // U[z] = emb2_w[:, :F] emb[z] + b
   gemm(s, W.emb, F, W.emb2_w + F, 2 * F, nullptr, b.Vtab, F, Z, F, F);       // V[z] = emb2_w[:, F:] emb[z]
+  EDGE();
   gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);              // distance projections
-  launch_embed_scatter(g, N, F, z, b.Utab, b.Vtab, b.Q, b.C, b.u0, b.s0n, s);
-  launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s);
+  KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
+     launch_embed_scatter(g, N, F, z, b.Utab, b.Vtab, b.Q, b.C, b.u0, b.s0n, s));
+  KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s));
+  NODE();
   gemm(s, b.ln0, F, W.L1, F, W.bL1, b.h1, 2 * F, N, 2 * F, F, GEMM_ACT_SILU, b.a1, 2 * F);
   gemm(s, b.h1, 2 * F, W.L2, 2 * F, W.bL2, b.gates, 3 * F, N, 3 * F, 2 * F, GEMM_ACT_SILU, b.a2, 3 * F);
   tensor_linear(s, b.u0, W.Ue, b.X[0], N, F, GEMM_MUL_AUX, b.UX, b.gates);
   // ---- interaction layers
   for (int l = 0; l < L; ++l) {
     const LayerP& q_ = W.layer[l];
+    EDGE();
     gemm(s, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU, b.e1[l], F);
     gemm(s, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU, b.e2[l], 2 * F);
     gemm(s, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, b.e3[l], 3 * F,
          nullptr, 0, b.C);
-    launch_norm_x(b.X[l], b.Xh, N, F, s);
+    KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], b.Xh, N, F, s));
     tensor_linear(s, b.Xh, q_.V, b.Pn[l], N, F);
-    launch_message(g, N, F, b.w[l], b.Pn[l], q, batch, o3, b.Mi[l], b.Ch, s);
+    KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch, o3, b.Mi[l], b.Ch, s));
     tensor_linear(s, b.Ch, q_.V + 3, b.D[l], N, F);
-    launch_layer_update(b.Xh, b.D[l], q, batch, N, F, b.X[l + 1], s);
+    KR(CAT_ELEMENTWISE, 3 * nodeB, launch_layer_update(b.Xh, b.D[l], q, batch, N, F, b.X[l + 1], s));
   }
   // ---- readout + head + per-molecule sum
-  launch_readout_feat(b.X[L], N, F, b.feat, s);
-  launch_layernorm_fwd(b.feat, W.lnr_w, W.lnr_b, N, 3 * F, b.lnr, b.xhr, b.rstdr, s);
+  KR(CAT_ELEMENTWISE, nodeB + Nd * 3 * Fd * 4, launch_readout_feat(b.X[L], N, F, b.feat, s));
+  KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_fwd(b.feat, W.lnr_w, W.lnr_b, N, 3 * F, b.lnr, b.xhr, b.rstdr, s));
+  NODE();
   gemm(s, b.lnr, 3 * F, W.Lin, 3 * F, W.bLin, b.x, F, N, F, 3 * F, GEMM_ACT_SILU, b.al, F);
   gemm(s, b.x, F, W.O1, F, W.bO1, b.ao, H, N, H, F);
-  launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s);
-  launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s);
+  KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s));
+  KR(CAT_ELEMENTWISE, Nd * 4, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
 
   if (want_forces) {
-    launch_head_bwd(b.ao, W.O2, N, H, W.std, b.g_ao, s);
+    KR(CAT_ELEMENTWISE, Nd * H * 8, launch_head_bwd(b.ao, W.O2, N, H, W.std, b.g_ao, s));
+    NODE();
     gemm(s, b.g_ao, H, W.O1T, H, nullptr, b.g_al, F, N, F, H, GEMM_MUL_DSILU_AUX, nullptr, 0, b.al, F);
     gemm(s, b.g_al, F, W.LinT, F, nullptr, b.g_ln, 3 * F, N, 3 * F, F);
-    launch_layernorm_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, 3 * F, b.g_feat, s);
-    launch_readout_bwd(b.X[L], b.g_feat, N, F, b.G, s);
+    KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, 3 * F, b.g_feat, s));
+    KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 4, launch_readout_bwd(b.X[L], b.g_feat, N, F, b.G, s));
     HIP_TRY(m, hipMemsetAsync(b.gC, 0, sizeof(float) * P1, s));
     HIP_TRY(m, hipMemsetAsync(b.g_phi, 0, sizeof(float) * (size_t)P1 * K, s));
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];
-      launch_update_bwd(b.G, b.D[l], q, batch, N, F, b.gD, s);
+      KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch, N, F, b.gD, s));
       tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
-      launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch, o3, N, F, b.gMi, b.gPn, s);
-      launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s);
-      launch_pair_bwd(g, P, F, b.gMi, b.Pn[l], b.e3[l], b.C, b.g_e3, b.gC, s);
+      KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch, o3, N, F, b.gMi, b.gPn, s));
+      KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
+      KR(CAT_PAIR, Pd * (24 * Fd + 8) + 2 * nodeB, launch_pair_bwd(g, P, F, b.gMi, b.Pn[l], b.e3[l], b.C, b.g_e3, b.gC, s));
+      EDGE();
       gemm(s, b.g_e3, 3 * F, q_.M3T, 3 * F, nullptr, b.g_e2, 2 * F, P, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.e2[l], 2 * F);
       gemm(s, b.g_e2, 2 * F, q_.M2T, 2 * F, nullptr, b.g_e1, F, P, F, 2 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.e1[l], F);
       gemm(s, b.g_e1, F, q_.M1T, F, nullptr, b.g_phi, K, P, K, F, GEMM_ACCUM);
       tensor_linear(s, b.gPn, q_.VT, b.gXl, N, F);
-      launch_norm_bwd(b.X[l], b.gXl, N, F, b.G, s);
+      KR(CAT_ELEMENTWISE, 4 * nodeB, launch_norm_bwd(b.X[l], b.gXl, N, F, b.G, s));
     }
-    launch_embed_gate_bwd(b.G, b.UX, b.gates, b.a2, N, F, b.gUX, b.g_a2, s);
+    KR(CAT_ELEMENTWISE, 3 * nodeB + Nd * 3 * Fd * 12, launch_embed_gate_bwd(b.G, b.UX, b.gates, b.a2, N, F, b.gUX, b.g_a2, s));
+    NODE();
     gemm(s, b.g_a2, 3 * F, W.L2T, 3 * F, nullptr, b.g_a1, 2 * F, N, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.a1, 2 * F);
     gemm(s, b.g_a1, 2 * F, W.L1T, 2 * F, nullptr, b.g_ln0, F, N, F, 2 * F);
-    launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s);
+    KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s));
     tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
-    launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s);
-    launch_embed_bwd_pair(g, P, F, z, b.Utab, b.Vtab, b.Q, b.C, b.gA, b.g_e3 /* gQ reuses g_e3 */, b.gC, b.g_rhat, s);
+    KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
+    KR(CAT_PAIR, Pd * (24 * Fd + 8) + Nd * 10 * Fd * 4,
+       launch_embed_bwd_pair(g, P, F, z, b.Utab, b.Vtab, b.Q, b.C, b.gA, b.g_e3 /* gQ reuses g_e3 */, b.gC, b.g_rhat, s));
+    EDGE();
     gemm(s, b.g_e3, 3 * F, W.WdpT, 3 * F, nullptr, b.g_phi, K, P, K, 3 * F, GEMM_ACCUM);
-    launch_geom(g, P, K, b.gC, b.dC, b.g_phi, b.dphi, b.g_rhat, b.g_delta, s);
-    launch_force_gather(g, N, b.g_delta, forces, s);
+    KR(CAT_ELEMENTWISE, Pd * (2 * K + 12) * 4, launch_geom(g, P, K, b.gC, b.dC, b.g_phi, b.dphi, b.g_rhat, b.g_delta, s));
+    KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, forces, s));
   }
+  g_cur = nullptr;
   HIP_TRY(m, hipGetLastError());
   m->last = b;
   m->lastN = N;
@@ -647,6 +730,37 @@ int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_ato
   launch_export_pairs(g, (int)n_atoms, include_transpose != 0, loop != 0, max_num_pairs, neighbors, deltas, distances, num_pairs, s);
   return hipGetLastError() == hipSuccess ? TMDNET_OK : TMDNET_ERR_HIP;
 }
+
+// ------------------------------------------------------------------------------------ profiling
+int tmdnet_profile_begin(tmdnet_model* m, uint32_t category_mask) {
+  if (!m) return TMDNET_ERR_INVALID;
+  m->prof.on = true;
+  m->prof.mask = category_mask;
+  m->prof.recs.clear();
+  m->prof.used = 0;
+  return TMDNET_OK;
+}
+
+int tmdnet_profile_end(tmdnet_model* m, void* stream, double* ms, double* flops, double* bytes, int64_t* launches) {
+  if (!m || !ms || !flops || !bytes || !launches) return TMDNET_ERR_INVALID;
+  HIP_TRY(m, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  for (int c = 0; c < CAT_COUNT; ++c) ms[c] = flops[c] = bytes[c] = 0.0, launches[c] = 0;
+  for (const ProfRec& r : m->prof.recs) {
+    float t = 0.f;
+    HIP_TRY(m, hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.cat] += t;
+    flops[r.cat] += r.flops;
+    bytes[r.cat] += r.bytes;
+    launches[r.cat] += 1;
+  }
+  m->prof.on = false;
+  m->prof.recs.clear();
+  m->prof.used = 0;
+  return TMDNET_OK;
+}
+
+int tmdnet_profile_num_categories(void) { return CAT_COUNT; }
+const char* tmdnet_profile_category_name(int idx) { return idx >= 0 && idx < CAT_COUNT ? kCatNames[idx] : nullptr; }
 
 // ------------------------------------------------------------------------------------ diagnostics
 int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* out, int64_t numel) {
