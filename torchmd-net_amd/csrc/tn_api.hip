@@ -30,7 +30,7 @@ struct LayerP {
 struct DevParams {
   const float *means, *betas;
   const float *Wdp, *bdp, *WdpT;
-  const float *emb, *emb2_w, *emb2_b;
+  const float *emb, *emb2_w, *emb2_b, *emb2_waT, *emb2_wbT;
   const float* Ue[3];
   const float* UeT[3];
   const float *L1, *bL1, *L1T, *L2, *bL2, *L2T;
@@ -442,6 +442,17 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   put("emb", h[T + "emb.weight"]);
   put("emb2_w", h[T + "emb2.weight"]);
   put("emb2_b", h[T + "emb2.bias"]);
+  {  // transposed halves of emb2.weight = [Wa | Wb] for the per-type table kernel (coalesced over channels)
+    const auto& w2 = h[T + "emb2.weight"];
+    std::vector<float> wa((size_t)F * F), wb((size_t)F * F);
+    for (int f = 0; f < F; ++f)
+      for (int k = 0; k < F; ++k) {
+        wa[(size_t)k * F + f] = w2[(size_t)f * 2 * F + k];
+        wb[(size_t)k * F + f] = w2[(size_t)f * 2 * F + F + k];
+      }
+    put("emb2_waT", wa);
+    put("emb2_wbT", wb);
+  }
   for (int k = 0; k < 3; ++k) {
     put("Ue" + std::to_string(k), h[T + "linears_tensor." + std::to_string(k) + ".weight"]);
     putT("UeT" + std::to_string(k), h[T + "linears_tensor." + std::to_string(k) + ".weight"], F, F);
@@ -496,6 +507,8 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   P.emb = D("emb");
   P.emb2_w = D("emb2_w");
   P.emb2_b = D("emb2_b");
+  P.emb2_waT = D("emb2_waT");
+  P.emb2_wbT = D("emb2_wbT");
   for (int k = 0; k < 3; ++k) {
     P.Ue[k] = D("Ue" + std::to_string(k));
     P.UeT[k] = D("UeT" + std::to_string(k));
@@ -624,9 +637,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
   KR(CAT_ELEMENTWISE, Pd * (2 * K + 3) * 4, launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s));
   // ---- embedding
-  NODE();
-  gemm(s, W.emb, F, W.emb2_w, 2 * F, W.emb2_b, b.Utab, F, Z, F, F);          // U[z] = emb2_w[:, :F] emb[z] + b
-  gemm(s, W.emb, F, W.emb2_w + F, 2 * F, nullptr, b.Vtab, F, Z, F, F);       // V[z] = emb2_w[:, F:] emb[z]
+  // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
+  KR(CAT_ELEMENTWISE, (double)Z * F * 12 + 8.0 * F * F, launch_ztables(W.emb, W.emb2_waT, W.emb2_wbT, W.emb2_b, Z, F, b.Utab, b.Vtab, s));
   EDGE();
   gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);              // distance projections
   KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,

@@ -1,0 +1,307 @@
+// 16-byte-per-lane variants of the gather / scatter kernels of the TensorNet path (gfx950).
+//
+// These kernels are bound by L2 / HBM gathers (per directed edge 3F edge weights + 9F source
+// features).  Each thread owns 4 consecutive channels so every access is a global_load_dwordx4
+// (1 KiB per wave-instruction); an atom (or pair) is served by TPA = F/4 lanes, a wave by 64/TPA
+// atoms, and the per-pair reductions over channels are xor-shuffles inside the TPA-lane group.
+// Used when F % 4 == 0, F/4 is a power of two and F/4 <= 64; otherwise the scalar kernels in
+// tn_kernels.hip run.  Same arithmetic, same summation order over edges (deterministic).
+#include <cstdlib>
+
+#include "tn_common.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+static inline int cdiv_(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+bool gather_v4_ok(int F) {
+  static const bool off = getenv("TMDNET_NO_V4") != nullptr;  // developer switch: force the scalar kernels
+  if (off || (F & 3)) return false;
+  int f4 = F >> 2;
+  return f4 >= 1 && f4 <= 64 && (f4 & (f4 - 1)) == 0;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void fma4(float4& a, const float4& w, const float4& s) {
+  a.x += w.x * s.x;
+  a.y += w.y * s.y;
+  a.z += w.z * s.z;
+  a.w += w.w * s.w;
+}
+__device__ __forceinline__ float comp(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+__device__ __forceinline__ void setc(float4& v, int k, float x) {
+  if (k == 0) v.x = x; else if (k == 1) v.y = x; else if (k == 2) v.z = x; else v.w = x;
+}
+__device__ __forceinline__ float group_sum(float v, int tpa) {
+  for (int off = tpa >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ void csr_gather4(const Graph& g, int i, int F, int f, const float* __restrict__ w,
+                                            const float* __restrict__ src, float4 acc[9]) {
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  const int F3 = 3 * F, F9 = 9 * F;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = e0; e < e1; ++e) {
+    const int j = g.col[e], p = g.epair[e];
+    const float* wp = w + (int64_t)p * F3 + f;
+    const float* sp = src + (int64_t)j * F9 + f;
+    const float4 w0 = ld4(wp), w1 = ld4(wp + F), w2 = ld4(wp + 2 * F);
+    float4 s[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s[c] = ld4(sp + c * F);
+    fma4(acc[0], w0, s[0]);
+    fma4(acc[1], w1, s[1]);
+    fma4(acc[2], w1, s[2]);
+    fma4(acc[3], w1, s[3]);
+#pragma unroll
+    for (int c = 4; c < 9; ++c) fma4(acc[c], w2, s[c]);
+  }
+}
+
+// message passing + group product + normalisation (reference tensornet.py:757-806); ADJOINT: gPn[i] += sum_e w gMi[j]
+template <bool ADJOINT>
+__global__ __launch_bounds__(256) void k_message_v4(Graph g, int N, int F, const float* __restrict__ w,
+                                                    const float* __restrict__ src, const float* __restrict__ q,
+                                                    const int64_t* __restrict__ batch, int o3, float* __restrict__ out0,
+                                                    float* __restrict__ out1) {
+  const int tpa = F >> 2, apb = 256 / tpa;
+  const int i = blockIdx.x * apb + threadIdx.x / tpa;
+  if (i >= N) return;
+  const int f = (threadIdx.x % tpa) << 2;
+  float4 m[9];
+  csr_gather4(g, i, F, f, w, src, m);
+  const int64_t base = (int64_t)i * 9 * F + f;
+  if (ADJOINT) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      float4 o = ld4(out0 + base + c * F);
+      o.x += m[c].x; o.y += m[c].y; o.z += m[c].z; o.w += m[c].w;
+      st4(out0 + base + c * F, o);
+    }
+    return;
+  }
+  const float kap = q ? 1.0f + 0.1f * q[batch[i]] : 1.0f;
+  float4 y[9], ch[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    y[c] = ld4(src + base + c * F);
+    st4(out0 + base + c * F, m[c]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float yu[9], mu[9], uc[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      yu[c] = comp(y[c], k);
+      mu[c] = comp(m[c], k);
+    }
+    const M3 Y = compose(yu), M = compose(mu);
+    const M3 Cm = o3 ? scale(add(matmul(Y, M), matmul(M, Y)), kap) : scale(matmul(Y, M), 2.0f);
+    decompose(Cm, uc);
+    const float inv = 1.0f / (frob2(Cm) + 1.0f);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) setc(ch[c], k, uc[c] * inv);
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) st4(out1 + base + c * F, ch[c]);
+}
+
+void launch_message_v4(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
+                       int o3, float* Mi, float* Ch, hipStream_t s) {
+  const int apb = 256 / (F >> 2);
+  hipLaunchKernelGGL(k_message_v4<false>, dim3(cdiv_(N, apb)), dim3(256), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
+}
+void launch_message_adjoint_v4(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
+  const int apb = 256 / (F >> 2);
+  hipLaunchKernelGGL(k_message_v4<true>, dim3(cdiv_(N, apb)), dim3(256), 0, s, g, N, F, w, gMi, nullptr, nullptr, 0, gPn,
+                     nullptr);
+}
+
+// per-pair weight gradient + first step of the edge-MLP reverse chain (see k_pair_bwd in tn_kernels.hip)
+__global__ __launch_bounds__(256) void k_pair_bwd_v4(Graph g, int P, int F, const float* __restrict__ gMi,
+                                                     const float* __restrict__ Pn, const float* __restrict__ e3,
+                                                     const float* __restrict__ C, float* __restrict__ g_e3,
+                                                     float* __restrict__ gC) {
+  const int tpa = F >> 2, ppb = 256 / tpa;
+  const int p = blockIdx.x * ppb + threadIdx.x / tpa;
+  if (p >= P) return;
+  const int f = (threadIdx.x % tpa) << 2;
+  const int i = g.pair_i[p], j = g.pair_j[p];
+  const float cp = C[p];
+  const int F9 = 9 * F, F3 = 3 * F;
+  const float* gi = gMi + (int64_t)i * F9 + f;
+  const float* gj = gMi + (int64_t)j * F9 + f;
+  const float* pi = Pn + (int64_t)i * F9 + f;
+  const float* pj = Pn + (int64_t)j * F9 + f;
+  float4 gw[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) gw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const float4 a = ld4(gi + c * F), b = ld4(pj + c * F), cc = ld4(gj + c * F), d = ld4(pi + c * F);
+    float4& o = gw[c == 0 ? 0 : (c < 4 ? 1 : 2)];
+    fma4(o, a, b);
+    fma4(o, cc, d);
+  }
+  float part = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float4 e = ld4(e3 + (int64_t)p * F3 + k * F + f);
+    float4 o;
+    o.x = gw[k].x * cp * silu_grad(e.x);
+    o.y = gw[k].y * cp * silu_grad(e.y);
+    o.z = gw[k].z * cp * silu_grad(e.z);
+    o.w = gw[k].w * cp * silu_grad(e.w);
+    st4(g_e3 + (int64_t)p * F3 + k * F + f, o);
+    part += gw[k].x * silu(e.x) + gw[k].y * silu(e.y) + gw[k].z * silu(e.z) + gw[k].w * silu(e.w);
+  }
+  part = group_sum(part, tpa);
+  if ((threadIdx.x % tpa) == 0) gC[p] += part;
+}
+void launch_pair_bwd_v4(const Graph& g, int P, int F, const float* gMi, const float* Pn, const float* e3, const float* C,
+                        float* g_e3, float* gC, hipStream_t s) {
+  const int ppb = 256 / (F >> 2);
+  hipLaunchKernelGGL(k_pair_bwd_v4, dim3(cdiv_(P, ppb)), dim3(256), 0, s, g, P, F, gMi, Pn, e3, C, g_e3, gC);
+}
+
+// embedding scatter (see k_embed_scatter in tn_kernels.hip)
+__global__ __launch_bounds__(256) void k_embed_scatter_v4(Graph g, int N, int F, const int64_t* __restrict__ z,
+                                                          const float* __restrict__ Utab, const float* __restrict__ Vtab,
+                                                          const float* __restrict__ Q, const float* __restrict__ C,
+                                                          float* __restrict__ u0, float* __restrict__ s0n) {
+  const int tpa = F >> 2, apb = 256 / tpa;
+  const int i = blockIdx.x * apb + threadIdx.x / tpa;
+  if (i >= N) return;
+  const int f = (threadIdx.x % tpa) << 2;
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  const int F3 = 3 * F;
+  const float4 Ui = ld4(Utab + z[i] * F + f);
+  float4 acc[10];
+#pragma unroll
+  for (int c = 0; c < 10; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = e0; e < e1; ++e) {
+    const int j = g.col[e], p = g.epair[e];
+    const float sg = g.esign[e];
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (sg != 0.f) {
+      rx = sg * g.prhat[p * 3];
+      ry = sg * g.prhat[p * 3 + 1];
+      rz = sg * g.prhat[p * 3 + 2];
+    }
+    const float cp = C[p];
+    const float4 Vj = ld4(Vtab + z[j] * F + f);
+    const float* qp = Q + (int64_t)p * F3 + f;
+    const float4 q0 = ld4(qp), q1 = ld4(qp + F), q2 = ld4(qp + 2 * F);
+    const float rr[6] = {rx * rx, rx * ry, rx * rz, ry * ry, ry * rz, rz * rz};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float cz = cp * (comp(Ui, k) + comp(Vj, k));
+      const float W0 = cz * comp(q0, k), W1 = cz * comp(q1, k), W2 = cz * comp(q2, k);
+      setc(acc[0], k, comp(acc[0], k) + W0);
+      setc(acc[1], k, comp(acc[1], k) + W1 * rx);
+      setc(acc[2], k, comp(acc[2], k) + W1 * ry);
+      setc(acc[3], k, comp(acc[3], k) + W1 * rz);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) setc(acc[4 + c], k, comp(acc[4 + c], k) + W2 * rr[c]);
+    }
+  }
+  // acc[4..9] = T00,T01,T02,T11,T12,T22
+  float4 out[9], sn;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t00 = comp(acc[4], k), t11 = comp(acc[7], k), t22 = comp(acc[9], k);
+    const float tr3 = (t00 + t11 + t22) * (1.0f / 3.0f);
+    float u[9] = {comp(acc[0], k), comp(acc[1], k), comp(acc[2], k), comp(acc[3], k), t00 - tr3,
+                  comp(acc[5], k), comp(acc[6], k), t11 - tr3, comp(acc[8], k)};
+#pragma unroll
+    for (int c = 0; c < 9; ++c) setc(out[c], k, u[c]);
+    setc(sn, k, quad(u));
+  }
+  float* o = u0 + (int64_t)i * 9 * F + f;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) st4(o + c * F, out[c]);
+  st4(s0n + (int64_t)i * F + f, sn);
+}
+void launch_embed_scatter_v4(const Graph& g, int N, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                             const float* C, float* u0, float* s0n, hipStream_t s) {
+  const int apb = 256 / (F >> 2);
+  hipLaunchKernelGGL(k_embed_scatter_v4, dim3(cdiv_(N, apb)), dim3(256), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
+}
+
+// embedding adjoint per pair (see k_embed_bwd_pair in tn_kernels.hip)
+__global__ __launch_bounds__(256) void k_embed_bwd_pair_v4(Graph g, int P, int F, const int64_t* __restrict__ z,
+                                                           const float* __restrict__ Utab, const float* __restrict__ Vtab,
+                                                           const float* __restrict__ Q, const float* __restrict__ C,
+                                                           const float* __restrict__ gA, float* __restrict__ gQ,
+                                                           float* __restrict__ gC, float* __restrict__ g_rhat) {
+  const int tpa = F >> 2, ppb = 256 / tpa;
+  const int p = blockIdx.x * ppb + threadIdx.x / tpa;
+  if (p >= P) return;
+  const int f = (threadIdx.x % tpa) << 2;
+  const int i = g.pair_i[p], j = g.pair_j[p];
+  const int64_t zi = z[i], zj = z[j];
+  const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
+  const float cp = C[p];
+  const int F3 = 3 * F, F10 = 10 * F;
+  const float4 Ui = ld4(Utab + zi * F + f), Vi = ld4(Vtab + zi * F + f), Uj = ld4(Utab + zj * F + f), Vj = ld4(Vtab + zj * F + f);
+  const float* qp = Q + (int64_t)p * F3 + f;
+  const float4 q0v = ld4(qp), q1v = ld4(qp + F), q2v = ld4(qp + 2 * F);
+  float4 aiv[10], ajv[10];
+#pragma unroll
+  for (int c = 0; c < 10; ++c) {
+    aiv[c] = ld4(gA + (int64_t)i * F10 + c * F + f);
+    ajv[c] = ld4(gA + (int64_t)j * F10 + c * F + f);
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 o0, o1, o2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float Z1 = comp(Ui, k) + comp(Vj, k), Z2 = comp(Uj, k) + comp(Vi, k);
+    const float q0 = comp(q0v, k), q1 = comp(q1v, k), q2 = comp(q2v, k);
+    float ai[10], aj[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      ai[c] = comp(aiv[c], k);
+      aj[c] = comp(ajv[c], k);
+    }
+    const float gW1_1 = ai[1] * r0 + ai[2] * r1 + ai[3] * r2;
+    const float gW1_2 = -(aj[1] * r0 + aj[2] * r1 + aj[3] * r2);
+    const float gW2_1 = ai[4] * r0 * r0 + ai[5] * r0 * r1 + ai[6] * r0 * r2 + ai[7] * r1 * r1 + ai[8] * r1 * r2 + ai[9] * r2 * r2;
+    const float gW2_2 = aj[4] * r0 * r0 + aj[5] * r0 * r1 + aj[6] * r0 * r2 + aj[7] * r1 * r1 + aj[8] * r1 * r2 + aj[9] * r2 * r2;
+    const float s0 = Z1 * ai[0] + Z2 * aj[0], s1 = Z1 * gW1_1 + Z2 * gW1_2, s2 = Z1 * gW2_1 + Z2 * gW2_2;
+    setc(o0, k, cp * s0);
+    setc(o1, k, cp * s1);
+    setc(o2, k, cp * s2);
+    acc[0] += q0 * s0 + q1 * s1 + q2 * s2;
+    const float W1_1 = cp * Z1 * q1, W2_1 = cp * Z1 * q2, W1_2 = cp * Z2 * q1, W2_2 = cp * Z2 * q2;
+    const float di0 = 2.f * ai[4] * r0 + ai[5] * r1 + ai[6] * r2, dj0 = 2.f * aj[4] * r0 + aj[5] * r1 + aj[6] * r2;
+    const float di1 = ai[5] * r0 + 2.f * ai[7] * r1 + ai[8] * r2, dj1 = aj[5] * r0 + 2.f * aj[7] * r1 + aj[8] * r2;
+    const float di2 = ai[6] * r0 + ai[8] * r1 + 2.f * ai[9] * r2, dj2 = aj[6] * r0 + aj[8] * r1 + 2.f * aj[9] * r2;
+    acc[1] += ai[1] * W1_1 - aj[1] * W1_2 + di0 * W2_1 + dj0 * W2_2;
+    acc[2] += ai[2] * W1_1 - aj[2] * W1_2 + di1 * W2_1 + dj1 * W2_2;
+    acc[3] += ai[3] * W1_1 - aj[3] * W1_2 + di2 * W2_1 + dj2 * W2_2;
+  }
+  float* go = gQ + (int64_t)p * F3 + f;
+  st4(go, o0);
+  st4(go + F, o1);
+  st4(go + 2 * F, o2);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = group_sum(acc[k], tpa);
+  if ((threadIdx.x % tpa) == 0) {
+    gC[p] += acc[0];
+    g_rhat[p * 3] = acc[1];
+    g_rhat[p * 3 + 1] = acc[2];
+    g_rhat[p * 3 + 2] = acc[3];
+  }
+}
+void launch_embed_bwd_pair_v4(const Graph& g, int P, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                              const float* C, const float* gA, float* gQ, float* gC, float* g_rhat, hipStream_t s) {
+  const int ppb = 256 / (F >> 2);
+  hipLaunchKernelGGL(k_embed_bwd_pair_v4, dim3(cdiv_(P, ppb)), dim3(256), 0, s, g, P, F, z, Utab, Vtab, Q, C, gA, gQ, gC, g_rhat);
+}
+
+}  // namespace tn

@@ -1,14 +1,18 @@
 // fp32 MFMA GEMM for gfx950, see tn_gemm.h.  CDNA4-only code: 64-wide waves, v_mfma_f32_32x32x2_f32.
 //
 // Tiling: 256 threads = 4 waves; block tile BM x BN, K step 32; each wave owns a
-// (BM/WAVES_M) x (BN/WAVES_N) sub-tile made of 32x32 MFMA blocks (16 accumulator VGPRs each).
+// (BM/WAVES_M) x (BN/WAVES_N) sub-tile made of 32x32 MFMA blocks (16 accumulator registers each).
 // LDS image: [rows][32 + 4 pad] floats, k contiguous, so that both MFMA operands are fetched with
 // conflict-free ds_read_b128 (row stride 36 dwords spreads a 16-lane group over all 64 banks).
 // A lane with k-half h = lane>>5 reads k = kk*8 + h*4 + {0..3}; MFMA t of that chunk multiplies the
 // k pair {kk*8+t, kk*8+4+t} - any k order is allowed as long as A and B agree.
 // Block -> tile mapping is XCD-aware: the n-tiles of one m-tile (they share the A panel) get
 // consecutive tile ids, and tile ids are dealt to XCDs in contiguous chunks (block b runs on XCD b%8).
+// The epilogue kind is a compile-time parameter (no per-element branching); the tile loader takes an
+// unguarded float4 path whenever the whole tile is in range and 16-byte aligned (block-uniform test).
 #include "tn_gemm.h"
+
+#include <cstdlib>
 
 #include "tn_common.h"
 
@@ -19,45 +23,64 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-template <int ROWS>
-__device__ __forceinline__ void load_panel(float4 (&reg)[ROWS * 8 / 256 > 0 ? ROWS * 8 / 256 : 1], const float* __restrict__ base,
-                                           int64_t ld, int row0, int nrows, int k0, int K, bool vec_ok, int tid) {
+enum EpiKind : int {
+  EPI_PLAIN = 0,          // C = acc (+bias)
+  EPI_SILU_PRE,           // pre = acc+bias ; C = silu(pre)
+  EPI_SILU_PRE_ROWSCALE,  // pre = acc+bias ; C = silu(pre) * rowscale[m]
+  EPI_MULAUX_PRE,         // pre = acc ; C = pre * aux[m,n]
+  EPI_MULDSILU,           // C = acc * silu'(aux[m,n])
+  EPI_ACCUM,              // C += acc
+  EPI_GENERIC             // run-time flags (any other combination)
+};
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_silu(float x) { return x * fast_sigmoid(x); }
+__device__ __forceinline__ float fast_silu_grad(float x) {
+  float s = fast_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+template <int ROWS, bool FAST>
+__device__ __forceinline__ void load_panel(float4 (&reg)[ROWS * 8 / 256], const float* __restrict__ base, int64_t ld, int row0,
+                                           int nrows, int k0, int K, bool vec_ok, int tid) {
   constexpr int NV = ROWS * 8 / 256;
 #pragma unroll
   for (int r = 0; r < NV; ++r) {
-    int idx = tid + r * 256;
-    int row = idx >> 3;
-    int k = k0 + ((idx & 7) << 2);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    int grow = row0 + row;
-    if (grow < nrows) {
-      const float* p = base + (int64_t)grow * ld + k;
-      if (vec_ok) {
-        if (k < K) v = *reinterpret_cast<const float4*>(p);
-      } else {
-        if (k + 0 < K) v.x = p[0];
-        if (k + 1 < K) v.y = p[1];
-        if (k + 2 < K) v.z = p[2];
-        if (k + 3 < K) v.w = p[3];
+    const int idx = tid + r * 256;
+    const int row = idx >> 3;
+    const int k = k0 + ((idx & 7) << 2);
+    const int grow = row0 + row;
+    if (FAST) {
+      reg[r] = *reinterpret_cast<const float4*>(base + (int64_t)grow * ld + k);
+    } else {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (grow < nrows) {
+        const float* p = base + (int64_t)grow * ld + k;
+        if (vec_ok) {
+          if (k < K) v = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (k + 0 < K) v.x = p[0];
+          if (k + 1 < K) v.y = p[1];
+          if (k + 2 < K) v.z = p[2];
+          if (k + 3 < K) v.w = p[3];
+        }
       }
+      reg[r] = v;
     }
-    reg[r] = v;
   }
 }
 
 template <int ROWS>
-__device__ __forceinline__ void store_panel(const float4 (&reg)[ROWS * 8 / 256 > 0 ? ROWS * 8 / 256 : 1], float* lds, int tid) {
+__device__ __forceinline__ void store_panel(const float4 (&reg)[ROWS * 8 / 256], float* lds, int tid) {
   constexpr int NV = ROWS * 8 / 256;
 #pragma unroll
   for (int r = 0; r < NV; ++r) {
-    int idx = tid + r * 256;
-    int row = idx >> 3;
-    int c = (idx & 7) << 2;
-    *reinterpret_cast<float4*>(&lds[row * LDS_LD + c]) = reg[r];
+    const int idx = tid + r * 256;
+    *reinterpret_cast<float4*>(&lds[(idx >> 3) * LDS_LD + ((idx & 7) << 2)]) = reg[r];
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int DBG>
 __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int tiles_n) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -84,6 +107,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
   const int M = a.M, N = a.N, K = a.K;
   const bool a_vec = ((a.lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const bool w_vec = ((a.ldw & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+  const bool a_full = a_vec && (m0 + BM <= M);
+  const bool w_full = w_vec && (n0 + BN <= N);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -97,14 +122,22 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-  constexpr int NVA = BM * 8 / 256, NVB = (BN * 8 / 256 > 0 ? BN * 8 / 256 : 1);
+  constexpr int NVA = BM * 8 / 256, NVB = BN * 8 / 256;
   float4 ra[NVA], rb[NVB];
   const int nk = (K + BK - 1) / BK;
 
-  load_panel<BM>(ra, A, a.lda, m0, M, 0, K, a_vec, tid);
-  if (BN * 8 >= 256 || tid < BN * 8) load_panel<BN>(rb, W, a.ldw, n0, N, 0, K, w_vec, tid);
+  auto fetch = [&](int kt) {
+    const int k0 = kt * BK;
+    const bool kfull = k0 + BK <= K;
+    if (a_full && kfull) load_panel<BM, true>(ra, A, a.lda, m0, M, k0, K, true, tid);
+    else load_panel<BM, false>(ra, A, a.lda, m0, M, k0, K, a_vec, tid);
+    if (w_full && kfull) load_panel<BN, true>(rb, W, a.ldw, n0, N, k0, K, true, tid);
+    else load_panel<BN, false>(rb, W, a.ldw, n0, N, k0, K, w_vec, tid);
+  };
+
+  fetch(0);
   store_panel<BM>(ra, As, tid);
-  if (BN * 8 >= 256 || tid < BN * 8) store_panel<BN>(rb, Bs, tid);
+  store_panel<BN>(rb, Bs, tid);
   __syncthreads();
 
   const int arow = wm * WTM + (lane & 31);
@@ -113,10 +146,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
 
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more) {
-      load_panel<BM>(ra, A, a.lda, m0, M, (kt + 1) * BK, K, a_vec, tid);
-      if (BN * 8 >= 256 || tid < BN * 8) load_panel<BN>(rb, W, a.ldw, n0, N, (kt + 1) * BK, K, w_vec, tid);
-    }
+    if (more && !(DBG & 1)) fetch(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 af[MI], bf[NI];
@@ -131,13 +161,15 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(afp[mi * 4 + tt], bfp[ni * 4 + tt], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NI; ++ni) {
+            if (DBG & 4) acc[mi][ni][tt] += afp[mi * 4 + tt] * bfp[ni * 4 + tt];
+            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(afp[mi * 4 + tt], bfp[ni * 4 + tt], acc[mi][ni], 0, 0, 0);
+          }
     }
     __syncthreads();
     if (more) {
       store_panel<BM>(ra, As, tid);
-      if (BN * 8 >= 256 || tid < BN * 8) store_panel<BN>(rb, Bs, tid);
+      store_panel<BN>(rb, Bs, tid);
       __syncthreads();
     }
   }
@@ -160,30 +192,84 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
         const int row = m0 + wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (row >= M) continue;
         float v = acc[mi][ni][e] + bv;
-        if (pre) pre[(int64_t)row * a.ldpre + col] = v;
-        if (flags & GEMM_ACT_SILU) v = silu(v);
-        if (flags & GEMM_ROWSCALE) v *= a.rowscale[row];
-        if (flags & GEMM_MUL_AUX) v *= aux[(int64_t)row * a.ldaux + col];
-        if (flags & GEMM_MUL_DSILU_AUX) v *= silu_grad(aux[(int64_t)row * a.ldaux + col]);
+        if ((DBG & 2) && v != 12345.678f) continue;
         float* cp = C + (int64_t)row * a.ldc + col;
-        if (flags & GEMM_ACCUM) v += *cp;
-        *cp = v;
+        if (EPI == EPI_PLAIN) {
+          *cp = v;
+        } else if (EPI == EPI_SILU_PRE) {
+          pre[(int64_t)row * a.ldpre + col] = v;
+          *cp = fast_silu(v);
+        } else if (EPI == EPI_SILU_PRE_ROWSCALE) {
+          pre[(int64_t)row * a.ldpre + col] = v;
+          *cp = fast_silu(v) * a.rowscale[row];
+        } else if (EPI == EPI_MULAUX_PRE) {
+          pre[(int64_t)row * a.ldpre + col] = v;
+          *cp = v * aux[(int64_t)row * a.ldaux + col];
+        } else if (EPI == EPI_MULDSILU) {
+          *cp = v * fast_silu_grad(aux[(int64_t)row * a.ldaux + col]);
+        } else if (EPI == EPI_ACCUM) {
+          *cp = v + *cp;
+        } else {
+          if (pre) pre[(int64_t)row * a.ldpre + col] = v;
+          if (flags & GEMM_ACT_SILU) v = fast_silu(v);
+          if (flags & GEMM_ROWSCALE) v *= a.rowscale[row];
+          if (flags & GEMM_MUL_AUX) v *= aux[(int64_t)row * a.ldaux + col];
+          if (flags & GEMM_MUL_DSILU_AUX) v *= fast_silu_grad(aux[(int64_t)row * a.ldaux + col]);
+          if (flags & GEMM_ACCUM) v += *cp;
+          *cp = v;
+        }
       }
     }
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-static int launch_variant(const GemmArgs& a, hipStream_t stream) {
+static int epi_kind(const GemmArgs& a) {
+  const int f = a.flags;
+  if (f == 0 && !a.pre) return EPI_PLAIN;
+  if (f == GEMM_ACT_SILU && a.pre) return EPI_SILU_PRE;
+  if (f == (GEMM_ACT_SILU | GEMM_ROWSCALE) && a.pre) return EPI_SILU_PRE_ROWSCALE;
+  if (f == GEMM_MUL_AUX && a.pre) return EPI_MULAUX_PRE;
+  if (f == GEMM_MUL_DSILU_AUX && !a.pre) return EPI_MULDSILU;
+  if (f == GEMM_ACCUM && !a.pre) return EPI_ACCUM;
+  return EPI_GENERIC;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int DBG = 0>
+static int launch_one(const GemmArgs& a, hipStream_t stream) {
   int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   int total = tiles_m * tiles_n * a.groups;
   if (total <= 0) return 0;
-  hipLaunchKernelGGL((k_gemm_nt<BM, BN, WAVES_M, WAVES_N>), dim3(total), dim3(256), 0, stream, a, tiles_m, tiles_n);
+  hipLaunchKernelGGL((k_gemm_nt<BM, BN, WAVES_M, WAVES_N, EPI, DBG>), dim3(total), dim3(256), 0, stream, a, tiles_m, tiles_n);
   return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_variant(const GemmArgs& a, hipStream_t stream) {
+  switch (epi_kind(a)) {
+    case EPI_PLAIN: return launch_one<BM, BN, WAVES_M, WAVES_N, EPI_PLAIN>(a, stream);
+    case EPI_SILU_PRE: return launch_one<BM, BN, WAVES_M, WAVES_N, EPI_SILU_PRE>(a, stream);
+    case EPI_SILU_PRE_ROWSCALE: return launch_one<BM, BN, WAVES_M, WAVES_N, EPI_SILU_PRE_ROWSCALE>(a, stream);
+    case EPI_MULAUX_PRE: return launch_one<BM, BN, WAVES_M, WAVES_N, EPI_MULAUX_PRE>(a, stream);
+    case EPI_MULDSILU: return launch_one<BM, BN, WAVES_M, WAVES_N, EPI_MULDSILU>(a, stream);
+    case EPI_ACCUM: return launch_one<BM, BN, WAVES_M, WAVES_N, EPI_ACCUM>(a, stream);
+    default: return launch_one<BM, BN, WAVES_M, WAVES_N, EPI_GENERIC>(a, stream);
+  }
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0) return 0;
+  static const int dbg = getenv("TMDNET_GEMM_DBG") ? atoi(getenv("TMDNET_GEMM_DBG")) : 0;
+  if (dbg) {  // developer ablations on the main tile shape only (results are wrong by construction)
+    switch (dbg) {
+      case 1: return launch_one<128, 128, 2, 2, EPI_GENERIC, 1>(a, stream);
+      case 2: return launch_one<128, 128, 2, 2, EPI_GENERIC, 2>(a, stream);
+      case 3: return launch_one<128, 128, 2, 2, EPI_GENERIC, 3>(a, stream);
+      case 4: return launch_one<128, 128, 2, 2, EPI_GENERIC, 4>(a, stream);
+      case 5: return launch_one<128, 128, 2, 2, EPI_GENERIC, 5>(a, stream);
+      case 7: return launch_one<128, 128, 2, 2, EPI_GENERIC, 7>(a, stream);
+      default: return launch_one<128, 128, 2, 2, EPI_GENERIC, 0>(a, stream);
+    }
+  }
   if (a.N % 128 == 0 || a.N > 192) return launch_variant<128, 128, 2, 2>(a, stream);
   if (a.N > 32) return launch_variant<128, 64, 2, 2>(a, stream);
   return launch_variant<128, 32, 4, 1>(a, stream);

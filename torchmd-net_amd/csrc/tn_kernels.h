@@ -46,6 +46,8 @@ void launch_export_pairs(const Graph& g, int N, bool include_transpose, bool loo
 void launch_radial(const Graph& g, int P, RadialParams rp, float* phi, float* dphi, float* C, float* dC, hipStream_t s);
 
 // ---- embedding (reference tensornet.py:543-619, 405-445)
+void launch_ztables(const float* emb, const float* WaT, const float* WbT, const float* b2, int Z, int F, float* Utab, float* Vtab,
+                    hipStream_t s);
 void launch_embed_scatter(const Graph& g, int N, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
                           const float* C, float* u0, float* s0n, hipStream_t s);
 // ---- LayerNorm over rows of length R (torch.nn.LayerNorm semantics, eps 1e-5, biased variance)
@@ -86,5 +88,17 @@ void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC,
                  const float* g_rhat, float* g_delta, hipStream_t s);
 void launch_force_gather(const Graph& g, int N, const float* g_delta, float* forces, hipStream_t s);
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);
+
+// ---- 16-byte-per-lane variants (tn_gather.hip), selected by the launchers above when gather_v4_ok(F)
+bool gather_v4_ok(int F);
+void launch_message_v4(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
+                       int o3, float* Mi, float* Ch, hipStream_t s);
+void launch_message_adjoint_v4(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);
+void launch_pair_bwd_v4(const Graph& g, int P, int F, const float* gMi, const float* Pn, const float* e3, const float* C,
+                        float* g_e3, float* gC, hipStream_t s);
+void launch_embed_scatter_v4(const Graph& g, int N, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                             const float* C, float* u0, float* s0n, hipStream_t s);
+void launch_embed_bwd_pair_v4(const Graph& g, int P, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                              const float* C, const float* gA, float* gQ, float* gC, float* g_rhat, hipStream_t s);
 
 }  // namespace tn

@@ -303,6 +303,26 @@ void launch_radial(const Graph& g, int P, RadialParams rp, float* phi, float* dp
 // =====================================================================================
 //                                     embedding scatter
 // =====================================================================================
+// U[z,f] = b2[f] + sum_k emb[z,k] Wa[f,k] ; V[z,f] = sum_k emb[z,k] Wb[f,k]   (Wa/Wb stored transposed)
+__global__ void k_ztables(const float* __restrict__ emb, const float* __restrict__ WaT, const float* __restrict__ WbT,
+                          const float* __restrict__ b2, int Z, int F, float* __restrict__ Utab, float* __restrict__ Vtab) {
+  const int z = blockIdx.x;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float u = b2[f], v = 0.f;
+    for (int k = 0; k < F; ++k) {
+      const float e = emb[(int64_t)z * F + k];
+      u += e * WaT[(int64_t)k * F + f];
+      v += e * WbT[(int64_t)k * F + f];
+    }
+    Utab[(int64_t)z * F + f] = u;
+    Vtab[(int64_t)z * F + f] = v;
+  }
+}
+void launch_ztables(const float* emb, const float* WaT, const float* WbT, const float* b2, int Z, int F, float* Utab, float* Vtab,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(k_ztables, dim3(Z), dim3(fthreads(F)), 0, s, emb, WaT, WbT, b2, Z, F, Utab, Vtab);
+}
+
 // block = one atom, thread = channel.  I0 = sum W0 ; v = sum W1 r ; T = sum W2 r r^T ; u0 = (I0, v, T - tr(T)/3)
 __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict__ z, const float* __restrict__ Utab,
                                 const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ C,
@@ -342,6 +362,7 @@ __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict
 void launch_embed_scatter(const Graph& g, int N, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
                           const float* C, float* u0, float* s0n, hipStream_t s) {
   if (N <= 0) return;
+  if (gather_v4_ok(F)) return launch_embed_scatter_v4(g, N, F, z, Utab, Vtab, Q, C, u0, s0n, s);
   hipLaunchKernelGGL(k_embed_scatter, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
 }
 
@@ -483,6 +504,7 @@ __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, co
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
                     float* Mi, float* Ch, hipStream_t s) {
   if (N <= 0) return;
+  if (gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
 }
 
@@ -501,6 +523,7 @@ __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict
 }
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
   if (N <= 0) return;
+  if (gather_v4_ok(F)) return launch_message_adjoint_v4(g, N, F, w, gMi, gPn, s);
   hipLaunchKernelGGL(k_message_adjoint, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, gMi, gPn);
 }
 
@@ -758,6 +781,7 @@ __global__ void k_pair_bwd(Graph g, int P, int F, const float* __restrict__ gMi,
 void launch_pair_bwd(const Graph& g, int P, int F, const float* gMi, const float* Pn, const float* e3, const float* C, float* g_e3,
                      float* gC, hipStream_t s) {
   if (P <= 0) return;
+  if (gather_v4_ok(F)) return launch_pair_bwd_v4(g, P, F, gMi, Pn, e3, C, g_e3, gC, s);
   hipLaunchKernelGGL(k_pair_bwd, dim3(P), dim3(fthreads(F)), 0, s, g, P, F, gMi, Pn, e3, C, g_e3, gC);
 }
 
@@ -901,6 +925,7 @@ __global__ void k_embed_bwd_pair(Graph g, int P, int F, const int64_t* __restric
 void launch_embed_bwd_pair(const Graph& g, int P, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
                            const float* C, const float* gA, float* gQ, float* gC, float* g_rhat, hipStream_t s) {
   if (P <= 0) return;
+  if (gather_v4_ok(F)) return launch_embed_bwd_pair_v4(g, P, F, z, Utab, Vtab, Q, C, gA, gQ, gC, g_rhat, s);
   hipLaunchKernelGGL(k_embed_bwd_pair, dim3(P), dim3(fthreads(F)), 0, s, g, P, F, z, Utab, Vtab, Q, C, gA, gQ, gC, g_rhat);
 }
 
@@ -908,10 +933,14 @@ void launch_embed_bwd_pair(const Graph& g, int P, int F, const int64_t* z, const
 __global__ void k_geom(Graph g, int P, int K, const float* __restrict__ gC, const float* __restrict__ dC,
                        const float* __restrict__ g_phi, const float* __restrict__ dphi, const float* __restrict__ g_rhat,
                        float* __restrict__ g_delta) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per pair: lanes stride over k (coalesced rows of g_phi / dphi), wave-level reduction
+  const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= P) return;
-  float gd = gC[p] * dC[p];
-  for (int k = 0; k < K; ++k) gd += g_phi[(int64_t)p * K + k] * dphi[(int64_t)p * K + k];
+  const int lane = threadIdx.x & 63;
+  float part = 0.f;
+  for (int k = lane; k < K; k += 64) part += g_phi[(int64_t)p * K + k] * dphi[(int64_t)p * K + k];
+  float gd = wave_sum(part) + gC[p] * dC[p];
+  if (lane != 0) return;
   const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
   const float d = g.pd[p];
   const float inv = d > 0.f ? 1.0f / d : 0.f;
@@ -924,7 +953,7 @@ __global__ void k_geom(Graph g, int P, int K, const float* __restrict__ gC, cons
 void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC, const float* g_phi, const float* dphi,
                  const float* g_rhat, float* g_delta, hipStream_t s) {
   if (P <= 0) return;
-  hipLaunchKernelGGL(k_geom, dim3(cdiv(P, 256)), dim3(256), 0, s, g, P, K, gC, dC, g_phi, dphi, g_rhat, g_delta);
+  hipLaunchKernelGGL(k_geom, dim3(cdiv(P, 4)), dim3(256), 0, s, g, P, K, gC, dC, g_phi, dphi, g_rhat, g_delta);
 }
 
 // F_i = - sum_{e in row(i)} sign(e) * g_delta[pair(e)]     (no atomics: CSR gather)
