@@ -1,0 +1,183 @@
+"""not-gpu: host-side logic of the drop-in surface (no compute calls: there is no CPU path)."""
+import copy
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+from oracle import ref_shims as R
+from torchmdnet_amd import workloads as W
+from torchmdnet_amd.models.model import Ensemble, TorchMD_Net, create_model, load_model
+
+
+def test_library_loads_and_exports_every_declared_symbol(hip_lib):
+    from torchmdnet_amd import _C
+
+    syms = _C.check_symbols()
+    assert len(syms) >= 20 and "tmdnet_energy_forces" in syms and "tmdnet_build_graph" in syms
+    assert hip_lib.tmdnet_version().decode().startswith("tmdnet_amd")
+    # parameter table of the C side == state-dict keys of the Python side
+    model = create_model(dict(W.TINY_ARGS))
+    hp = model._hparams()
+    handle = C.c_void_p()
+    assert hip_lib.tmdnet_create(C.byref(hp), C.byref(handle)) == 0
+    names = set()
+    sd = model.state_dict()
+    for i in range(hip_lib.tmdnet_num_params(handle)):
+        numel = C.c_int64()
+        name = hip_lib.tmdnet_param_name(handle, i, C.byref(numel)).decode()
+        assert name in sd and sd[name].numel() == numel.value, name
+        names.add(name)
+    skipped = set(sd) - names
+    assert skipped == {"representation_model.distance.box"}, skipped  # geometry input, not a weight
+    # wrong size / unknown name are rejected with a message
+    buf = (C.c_float * 3)()
+    assert hip_lib.tmdnet_set_param(handle, b"mean", buf, 3) != 0
+    assert b"expected 1" in hip_lib.tmdnet_last_error(handle)
+    assert hip_lib.tmdnet_set_param(handle, b"nope", buf, 3) != 0
+    assert hip_lib.tmdnet_finalize_params(handle) != 0  # parameters missing -> state error, no crash
+    hip_lib.tmdnet_destroy(handle)
+
+
+def test_seeded_init_matches_reference_checksums(golden_dir):
+    """torch.manual_seed(s); create_model(args) gives the reference's weights (tests/test_model.py:265-274)."""
+    g = torch.load(os.path.join(golden_dir, "c2_ref.pt"))
+    torch.manual_seed(0)
+    m = create_model(dict(W.C2_ARGS))
+    chk = float(sum(v.double().abs().sum() for v in m.state_dict().values() if v.is_floating_point()))
+    assert abs(chk - g["sd_checksum"]) < 1e-6 * g["sd_checksum"]
+    assert sum(p.numel() for p in m.parameters()) == 766337
+    g2 = torch.load(os.path.join(golden_dir, "expected_tensornet_scalar.pt"))
+    R.seed_everything(1234)
+    m2 = create_model(dict(g2["args"]))
+    chk2 = float(sum(v.double().abs().sum() for v in m2.state_dict().values() if v.is_floating_point()))
+    assert abs(chk2 - g2["sd_checksum"]) < 1e-6 * g2["sd_checksum"]
+
+
+@pytest.mark.skipif(not R.reference_available(), reason="/root/reference not present")
+def test_state_dict_identical_to_live_reference():
+    mm = R.reference_model_module()
+    for args, seed in [(W.TINY_ARGS, 3), (dict(W.TINY_ARGS, prior_model="Atomref", prior_args={"max_z": 20}), 4)]:
+        torch.manual_seed(seed)
+        a = create_model(dict(args))
+        torch.manual_seed(seed)
+        b = mm.create_model(dict(args))
+        sa, sb = a.state_dict(), b.state_dict()
+        assert set(sa) == set(sb)
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+
+
+def _write_ckpt(path, model, args, old_layout=False):
+    sd = {"model." + k: v.clone() for k, v in model.state_dict().items()}
+    hp = dict(args)
+    if old_layout:
+        hp["check_errors"] = True
+        F = args["embedding_dimension"]
+        keys = ["model.representation_model.tensor_embedding.linears_scalar.1"]
+        keys += [f"model.representation_model.layers.{l}.linears_scalar.2" for l in range(args["num_layers"])]
+        for k in keys:  # current row c*F+f  ->  old row f*3+c  (inverse of the reference's remix, model.py:321-331)
+            w, b = sd[k + ".weight"], sd[k + ".bias"]
+            sd[k + ".weight"] = w.view(3, F, -1).transpose(0, 1).reshape(3 * F, -1).contiguous()
+            sd[k + ".bias"] = b.view(3, F).transpose(0, 1).reshape(3 * F).contiguous()
+        # legacy head key names and missing box buffer (model.py:261-294)
+        for old, new in [("model.output_model.output_network.0.", "model.output_model.output_network.layers.0."),
+                         ("model.output_model.output_network.2.", "model.output_model.output_network.layers.2.")]:
+            for suffix in ("weight", "bias"):
+                sd[old + suffix] = sd.pop(new + suffix)
+        sd.pop("model.representation_model.distance.box")
+    torch.save({"state_dict": sd, "hyper_parameters": hp}, path)
+
+
+@pytest.mark.parametrize("old_layout", [False, True])
+def test_load_model_checkpoint_formats(tmp_path, old_layout):
+    torch.manual_seed(5)
+    args = dict(W.TINY_ARGS)
+    model = create_model(dict(args))
+    path = str(tmp_path / "m.ckpt")
+    _write_ckpt(path, model, args, old_layout=old_layout)
+    with pytest.warns(UserWarning) if old_layout else _nullcontext():
+        loaded = load_model(path, derivative=True)
+    for k, v in model.state_dict().items():
+        assert torch.equal(loaded.state_dict()[k], v), k
+    assert loaded.derivative is True
+    if R.reference_available():  # the reference reads the same file to the same tensors
+        mm = R.reference_model_module()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = mm.load_model(path, derivative=True)
+        for k, v in ref.state_dict().items():
+            assert torch.equal(loaded.state_dict()[k], v), k
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def test_load_ensemble_and_atomref_toggle(tmp_path):
+    args = dict(W.TINY_ARGS, prior_model="Atomref", prior_args={"max_z": 20, "enable": False}, remove_ref_energy=True)
+    paths = []
+    for s in (1, 2):
+        torch.manual_seed(s)
+        m = create_model(dict(args))
+        p = str(tmp_path / f"m{s}.ckpt")
+        _write_ckpt(p, m, args)
+        paths.append(p)
+    ens = load_model(paths, return_std=True)
+    assert isinstance(ens, Ensemble) and len(ens) == 2 and ens.return_std
+    one = load_model(paths[0])
+    assert one.prior_model[-1].enable is False and one._atomref_table() is None
+    one = load_model(paths[0], remove_ref_energy=False)  # total energies: Atomref switched on (model.py:250-259)
+    assert one.prior_model[-1].enable is True and one._atomref_table().shape == (20,)
+
+
+def test_no_cpu_fallback_and_argument_checks():
+    model = create_model(dict(W.TINY_ARGS))
+    z, pos, batch = W.synthetic_batch(n_mol=1, n_atoms=5)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        model(z, pos, batch)
+    with pytest.raises(AssertionError):
+        model(z.to(torch.int32), pos, batch)
+    with pytest.raises(ValueError, match="Unknown architecture"):
+        create_model(dict(W.TINY_ARGS, model="nonsense"))
+    with pytest.raises(NotImplementedError):
+        create_model(dict(W.TINY_ARGS, model="graph-network"))
+    with pytest.raises(NotImplementedError):
+        create_model(dict(W.TINY_ARGS, precision=64))
+
+
+def test_module_protocol_deepcopy_and_freezing():
+    model = create_model(dict(W.TINY_ARGS))
+    assert isinstance(model, TorchMD_Net)
+    clone = copy.deepcopy(model)  # tests/test_calculator.py:54 of the reference does this
+    assert clone._engine is not model._engine and clone._engine.handle is None
+    for p in clone.parameters():
+        p.requires_grad = False  # calculators.py:226-227
+    clone.eval()
+    assert clone.representation_model.static_shapes is False and clone.representation_model.distance.resize_to_fit is True
+    assert set(clone.state_dict()) == set(model.state_dict())
+
+
+def test_install_as_torchmdnet_alias():
+    import sys
+
+    import torchmdnet_amd
+
+    saved = {k: v for k, v in sys.modules.items() if k == "torchmdnet" or k.startswith("torchmdnet.")}
+    try:
+        for k in saved:
+            del sys.modules[k]
+        torchmdnet_amd.install_as_torchmdnet()
+        from torchmdnet.models.model import create_model as cm  # noqa: F401
+
+        assert cm is create_model
+    finally:
+        for k in [k for k in sys.modules if k == "torchmdnet" or k.startswith("torchmdnet.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

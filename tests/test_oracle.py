@@ -1,0 +1,153 @@
+"""not-gpu: pin the oracle.  Three independent restatements of the reference's TensorNet E+F path
+   (a) oracle/tensornet_torch.py   full-tensor PyTorch, autograd forces
+   (b) oracle/tensornet_adjoint.py kernel-level layout, HAND-DERIVED reverse pass (torch, vectorised)
+   (c) oracle/tensornet_c.c        scalar C transliteration of (b)
+are checked against the reference's own golden vector (tests/expected.pkl, committed as
+tests/golden/expected_tensornet_scalar.pt) and against fixtures produced by the UNMODIFIED reference
+(oracle/make_golden.py).  When /root/reference is present the live reference is compared as well."""
+import os
+
+import pytest
+import torch
+
+from oracle import ref_shims as R
+from oracle import tensornet_adjoint as A
+from oracle import tensornet_c as CO
+from oracle import tensornet_torch as T
+
+
+def rel_err(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    return torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+
+
+def _seeded_qm9_model(g):
+    """Rebuild the golden test's model from the seed (bit-identical init order, see test_host.py)."""
+    from torchmdnet_amd.models.model import create_model
+
+    R.seed_everything(1234)
+    model = create_model(dict(g["args"]))
+    z, pos, batch = R.create_example_batch(n_atoms=5)
+    return model, z, pos, batch
+
+
+def test_reference_golden_vector_all_oracles(golden_dir):
+    """tests/expected.pkl['tensornet']['Scalar'] at the reference's own tolerance (atol=rtol=1e-5)."""
+    g = torch.load(os.path.join(golden_dir, "expected_tensornet_scalar.pt"))
+    model, z, pos, batch = _seeded_qm9_model(g)
+    assert torch.equal(pos, g["pos"])
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    hp = T.hparams_from_args(g["args"])
+    for name, fn in [("torch", T.energy_and_forces), ("adjoint", A.energy_forces), ("c", CO.energy_forces)]:
+        E, F = fn(sd, hp, z, pos, batch)
+        torch.testing.assert_close(E, g["pred"], atol=1e-5, rtol=1e-5, msg=name)
+        torch.testing.assert_close(F, g["deriv"], atol=1e-5, rtol=1e-5, msg=name)
+
+
+@pytest.mark.parametrize("impl", ["torch", "adjoint", "c"])
+def test_fp64_fixture(tiny, impl):
+    """fp64: the restatements agree with the reference to round-off (1e-12 relative)."""
+    fn = {"torch": T.energy_and_forces, "adjoint": A.energy_forces, "c": CO.energy_forces}[impl]
+    sd64 = T.cast_state_dict(tiny["state_dict"], torch.float64)
+    hp = T.hparams_from_args(tiny["args"])
+    E, F = fn(sd64, hp, tiny["z"], tiny["pos"].double(), tiny["batch"], q=tiny["q"].double())
+    assert rel_err(E, tiny["E64"]) < 1e-12
+    assert rel_err(F, tiny["F64"]) < 1e-12
+
+
+@pytest.mark.parametrize("impl", ["torch", "adjoint", "c"])
+def test_fp32_fixture_and_charges(tiny, impl):
+    fn = {"torch": T.energy_and_forces, "adjoint": A.energy_forces, "c": CO.energy_forces}[impl]
+    hp = T.hparams_from_args(tiny["args"])
+    E, F = fn(tiny["state_dict"], hp, tiny["z"], tiny["pos"], tiny["batch"], q=tiny["q"])
+    assert rel_err(E, tiny["E"]) < 1e-5 and rel_err(F, tiny["F"]) < 1e-5
+    E, F = fn(tiny["state_dict"], hp, tiny["z"], tiny["pos"], tiny["batch"])
+    assert rel_err(E, tiny["E_q0"]) < 1e-5 and rel_err(F, tiny["F_q0"]) < 1e-5
+
+
+def test_intermediates(tiny):
+    hp = T.hparams_from_args(tiny["args"])
+    x, inter = T.tensornet_representation(tiny["state_dict"], hp, tiny["z"], tiny["pos"], tiny["batch"], q=tiny["q"],
+                                          return_intermediates=True)
+    for k in ["X_embed", "X_layer0", "X_layer1"]:
+        assert rel_err(inter[k], tiny["inter"][k]) < 1e-5
+    assert rel_err(x, tiny["inter"]["x"]) < 1e-5
+    _, _, c = A.energy_forces(tiny["state_dict"], hp, tiny["z"], tiny["pos"], tiny["batch"], q=tiny["q"], want_cache=True)
+    assert rel_err(A.compose(c["X_embed"]), tiny["inter"]["X_embed"]) < 1e-5
+    assert rel_err(A.compose(c["X_final"]), tiny["inter"]["X_layer1"]) < 1e-5
+
+
+@pytest.mark.parametrize("impl", ["torch", "adjoint", "c"])
+def test_triclinic_periodic_fixture(tiny, golden_dir, impl):
+    fn = {"torch": T.energy_and_forces, "adjoint": A.energy_forces, "c": CO.energy_forces}[impl]
+    p = torch.load(os.path.join(golden_dir, "tiny_pbc_ref.pt"))
+    hp = T.hparams_from_args(tiny["args"])
+    E, F = fn(tiny["state_dict"], hp, p["z"], p["pos"], p["batch"], box=p["box"])
+    assert rel_err(E, p["E"]) < 1e-5 and rel_err(F, p["F"]) < 1e-5
+
+
+def test_c2_fixture(golden_dir):
+    """BASELINE configs[1] weights (seed 0), 4 molecules of S-mol64, vs the unmodified reference."""
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, "c2_ref.pt"))
+    torch.manual_seed(0)
+    model = create_model(dict(W.C2_ARGS))
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    z, pos, batch = W.synthetic_batch(n_mol=1)
+    hp = T.hparams_from_args(W.C2_ARGS)
+    E, F = CO.energy_forces(sd, hp, z, pos, batch)
+    assert rel_err(E, g["E"][:1]) < 1e-5 and rel_err(F, g["F"][:64]) < 1e-5
+    E, F = T.energy_and_forces(sd, hp, z, pos, batch)
+    assert rel_err(E, g["E"][:1]) < 1e-5 and rel_err(F, g["F"][:64]) < 1e-5
+
+
+def test_hand_adjoint_equals_autograd_so3_and_lower_cutoff(tiny):
+    """configurations the fixtures do not cover: SO(3) group and cutoff_lower > 0 (fp64, round-off)."""
+    sd64 = T.cast_state_dict(tiny["state_dict"], torch.float64)
+    for extra in [dict(equivariance_invariance_group="SO(3)"), dict(cutoff_lower=1.2)]:
+        hp = dict(T.hparams_from_args(tiny["args"]), **extra)
+        Ea, Fa = T.energy_and_forces(sd64, hp, tiny["z"], tiny["pos"].double(), tiny["batch"], q=tiny["q"].double())
+        for fn in (A.energy_forces, CO.energy_forces):
+            E, F = fn(sd64, hp, tiny["z"], tiny["pos"].double(), tiny["batch"], q=tiny["q"].double())
+            assert rel_err(E, Ea) < 1e-11 and rel_err(F, Fa) < 1e-11
+
+
+def test_forces_are_minus_energy_gradient_finite_difference(tiny):
+    sd64 = T.cast_state_dict(tiny["state_dict"], torch.float64)
+    hp = T.hparams_from_args(tiny["args"])
+    z, pos, batch = tiny["z"][:7], tiny["pos"][:7].double(), tiny["batch"][:7]
+    _, F = CO.energy_forces(sd64, hp, z, pos, batch)
+    h = 1e-5
+    for (i, a) in [(0, 0), (3, 2), (6, 1)]:
+        pp, pm = pos.clone(), pos.clone()
+        pp[i, a] += h
+        pm[i, a] -= h
+        Ep, _ = CO.energy_forces(sd64, hp, z, pp, batch, want_forces=False)
+        Em, _ = CO.energy_forces(sd64, hp, z, pm, batch, want_forces=False)
+        fd = -(Ep.sum() - Em.sum()) / (2 * h)
+        assert abs(fd.item() - F[i, a].item()) < 1e-7 * max(1.0, abs(fd.item()))
+
+
+@pytest.mark.skipif(not R.reference_available(), reason="/root/reference not present (GPU box)")
+def test_live_reference_random_system():
+    """The unmodified reference, imported here, on a fresh random system (not a committed fixture)."""
+    from torchmdnet_amd import workloads as W
+
+    mm = R.reference_model_module()
+    torch.manual_seed(11)
+    args = dict(W.TINY_ARGS, num_layers=3)
+    ref = mm.create_model(dict(args))
+    z, pos, batch = W.synthetic_batch(n_mol=2, n_atoms=17, first_seed=900)
+    q = torch.tensor([0.5, -2.0])
+    Er, Fr = ref(z, pos.clone(), batch, q=q)
+    sd = {k: v.detach() for k, v in ref.state_dict().items()}
+    hp = T.hparams_from_args(args)
+    for fn in (T.energy_and_forces, A.energy_forces, CO.energy_forces):
+        E, F = fn(sd, hp, z, pos, batch, q=q)
+        assert rel_err(E, Er.detach()) < 1e-5 and rel_err(F, Fr.detach()) < 1e-5

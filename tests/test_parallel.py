@@ -1,0 +1,72 @@
+"""not-gpu: molecule sharding + energy reduction over torch.distributed (gloo, world_size 2).
+The compute callable is the oracle (allowed in tests): the partition / collective logic is what is tested."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from torchmdnet_amd.parallel import ShardedEvaluator, molecule_ranges
+
+
+def test_molecule_ranges_cover_and_balance():
+    sizes = [5, 64, 64, 3, 40, 17, 64, 9]
+    batch = torch.cat([torch.full((n,), m, dtype=torch.long) for m, n in enumerate(sizes)])
+    for world in (1, 2, 3, 4, 8, 11):
+        r = molecule_ranges(batch, len(sizes), world)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == len(sizes) and r[-1][3] == sum(sizes)
+        for a, b in zip(r[:-1], r[1:]):
+            assert a[1] == b[0] and a[3] == b[2]
+        for (m0, m1, a0, a1) in r:
+            assert a1 - a0 == sum(sizes[m0:m1])
+    r = molecule_ranges(batch, len(sizes), 2)
+    assert abs((r[0][3] - r[0][2]) - (r[1][3] - r[1][2])) <= 64
+
+
+def _worker(rank, world, port, tmpdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "torchmd-net_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import tensornet_c as CO, tensornet_torch as T
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = create_model(dict(W.TINY_ARGS))
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    hp = T.hparams_from_args(W.TINY_ARGS)
+    sizes = [9, 14, 5, 20, 11]
+    zs, ps, bs = [], [], []
+    for m, n in enumerate(sizes):
+        zz, pp = W.synthetic_molecule(40 + m, n_atoms=n)
+        zs.append(torch.from_numpy(zz)); ps.append(torch.from_numpy(pp)); bs.append(torch.full((n,), m, dtype=torch.long))
+    z, pos, batch = torch.cat(zs), torch.cat(ps), torch.cat(bs)
+    q = torch.tensor([0.0, 1.0, -1.0, 0.0, 2.0])
+
+    def compute(zl, pl, bl, boxl, ql, nm):
+        return CO.energy_forces(sd, hp, zl, pl, bl, q=ql)
+
+    ev = ShardedEvaluator(compute, gather_forces=True)
+    E, F, rng = ev.evaluate(z, pos, batch, q=q)
+    Er, Fr = CO.energy_forces(sd, hp, z, pos, batch, q=q)
+    ok = torch.allclose(E.view(-1, 1), Er, atol=1e-6) and torch.allclose(F, Fr, atol=1e-6) and rng == (0, z.shape[0])
+    ev2 = ShardedEvaluator(compute, gather_forces=False)
+    E2, Fl, (a0, a1) = ev2.evaluate(z, pos, batch, q=q)
+    ok = ok and torch.allclose(E2.view(-1, 1), Er, atol=1e-6) and torch.allclose(Fl, Fr[a0:a1], atol=1e-6)
+    with open(os.path.join(tmpdir, f"ok{rank}"), "w") as fh:
+        fh.write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluator_gloo_world2(tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"ok{r}").read() == "1"

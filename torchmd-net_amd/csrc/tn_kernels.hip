@@ -362,7 +362,8 @@ __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict
 void launch_embed_scatter(const Graph& g, int N, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
                           const float* C, float* u0, float* s0n, hipStream_t s) {
   if (N <= 0) return;
-  if (gather_v4_ok(F)) return launch_embed_scatter_v4(g, N, F, z, Utab, Vtab, Q, C, u0, s0n, s);
+  // measured on MI355X (profiles/r01_notes.md): the 16-byte CSR sweep is slower than one-channel-per-lane here (scalar edge loads, 4x the waves)
+  if (false && gather_v4_ok(F)) return launch_embed_scatter_v4(g, N, F, z, Utab, Vtab, Q, C, u0, s0n, s);
   hipLaunchKernelGGL(k_embed_scatter, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
 }
 
@@ -504,7 +505,7 @@ __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, co
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
                     float* Mi, float* Ch, hipStream_t s) {
   if (N <= 0) return;
-  if (gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
+  if (false && gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
 }
 
@@ -523,7 +524,7 @@ __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict
 }
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
   if (N <= 0) return;
-  if (gather_v4_ok(F)) return launch_message_adjoint_v4(g, N, F, w, gMi, gPn, s);
+  if (false && gather_v4_ok(F)) return launch_message_adjoint_v4(g, N, F, w, gMi, gPn, s);
   hipLaunchKernelGGL(k_message_adjoint, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, gMi, gPn);
 }
 
