@@ -84,13 +84,24 @@ int tmdnet_graph_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t
 int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms, int64_t n_mol,
                        const float* pos, const int64_t* batch, const float* box, int32_t box_mode, int64_t counts_host[4]);
 
+/* Static (HIP-graph capturable) variant: same kernels, NO read-back and no synchronisation.  The pair count
+ * stays in device memory; call tmdnet_energy_forces with n_pairs = -1 and workspaces sized for the pair
+ * capacity (tmdnet_forward_workspace_bytes with n_pairs = -1).  On overflow the kernels of both phases skip
+ * their work (outputs undefined) and the flag is left in the graph workspace: poll it with
+ * tmdnet_graph_counts (synchronises; returns TMDNET_ERR_OVERFLOW) whenever convenient -- the analogue of the
+ * reference's torch._assert_async (torchmdnet/models/utils.py:297-300). */
+int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms,
+                              int64_t n_mol, const float* pos, const int64_t* batch, const float* box, int32_t box_mode);
+int tmdnet_graph_counts(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t counts_host[4]);
+
 /* ---- phase B: energies and forces ---------------------------------------------------------------
  * Replaces TorchMD_Net.forward for TensorNet + Scalar (torchmdnet/models/model.py:530-631):
  * energy[n_mol] = sum over atoms of the per-atom scalar (* std, + atomref[z]) + mean, and
  * forces[n_atoms,3] = -d(sum_m energy[m])/d(pos) from the hand-written reverse pass
  * (want_forces = 0 skips it).  `q` = total charge per molecule [n_mol] or NULL (tensornet.py:341-344).
  * Must be called after tmdnet_build_graph on the same graph_ws (which holds the pair geometry);
- * n_pairs = counts_host[0] of that call.  Enqueues only: no synchronisation, no allocation. */
+ * n_pairs = counts_host[0] of that call (or -1 after tmdnet_build_graph_static).  Enqueues only: no
+ * synchronisation, no allocation. */
 int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int64_t n_edges,
                                    int32_t want_forces, size_t* bytes);
 int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms,

@@ -196,3 +196,33 @@ def test_mfma_gemm_unit(hip_lib):
         assert rc == 0
         ref = (A.double() @ Wt.double().t() + b.double()).float()
         assert rel_err(Cc.cpu(), ref.cpu()) < 1e-5, (M, N, K)
+
+
+def test_static_shapes_equals_dynamic_and_graph_replay(hip_lib, golden_dir):
+    """reference tests/test_staticshapes.py:59-87 (static == dynamic to 1e-5) + HIP-graph capture/replay
+    (reference tests/test_model.py:162-262 do this with torch.cuda.graphs)."""
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    dyn = _model_from_sd(g["args"], g["state_dict"])
+    sta = _model_from_sd(dict(g["args"], static_shapes=True), g["state_dict"])
+    z, pos, batch = g["z"].cuda(), g["pos"].cuda(), g["batch"].cuda()
+    Ed, Fd = dyn(z, pos, batch)
+    Es, Fs = sta(z, pos, batch)
+    torch.testing.assert_close(Es, Ed, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(Fs, Fd, atol=1e-5, rtol=1e-5)
+    assert sta._engine.counts[:2] == dyn._engine.counts[:2]
+    replay = sta.capture(z, pos, batch)
+    E1, F1 = replay()
+    assert rel_err(E1.cpu(), g["E_q0"]) < REL and rel_err(F1.cpu(), g["F_q0"]) < REL
+    # new positions through the same graph: the neighbour list is rebuilt inside the replay
+    torch.manual_seed(0)
+    pos2 = pos + 0.05 * torch.randn_like(pos)
+    E2, F2 = replay(pos2)
+    E2, F2 = E2.clone(), F2.clone()
+    Er, Fr = dyn(z, pos2, batch)
+    assert rel_err(E2, Er) < 1e-5 and rel_err(F2, Fr) < 1e-5
+    # overflow in static mode: flag polled outside capture -> same RuntimeError as the reference
+    small = _model_from_sd(dict(g["args"], static_shapes=True, max_num_neighbors=3), g["state_dict"])
+    with pytest.raises(RuntimeError, match="max_num_pairs"):
+        small(z, pos, batch)

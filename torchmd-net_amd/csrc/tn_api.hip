@@ -190,6 +190,8 @@ struct Packer {
 // ---- optional per-launch timing with HIP events on the launch stream (tmdnet_profile_begin/end)
 thread_local tmdnet_model* g_cur = nullptr;
 thread_local int g_gemm_cat = CAT_GEMM_NODE;
+thread_local const int* g_mdev = nullptr;  // device-side row count of pair-row GEMMs (see GemmArgs::m_dev)
+thread_local int g_madd = 0;
 struct ProfScope {
   int idx = -1;
   hipStream_t s;
@@ -232,6 +234,8 @@ void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ld
   a.K = K;
   a.groups = 1;
   a.flags = flags;
+  a.m_dev = g_mdev;
+  a.m_add = g_madd;
   // algorithmic traffic: A and W read once, C (and the saved pre-activation / aux operand) once
   const double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (1 + (pre ? 1 : 0) + (aux ? 1 : 0) + ((flags & GEMM_ACCUM) ? 1 : 0)));
   ProfScope ps_(s, g_gemm_cat, 2.0 * M * N * K, bytes);
@@ -597,11 +601,45 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   return TMDNET_OK;
 }
 
+int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms, int64_t n_mol,
+                              const float* pos, const int64_t* batch, const float* box, int32_t box_mode) {
+  if (!m || !graph_ws || n_atoms < 0 || n_mol < 0) return TMDNET_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t ecap = (int64_t)m->hp.max_num_neighbors * n_atoms;
+  size_t need = 0;
+  Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, &need);
+  if (need > graph_ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "graph workspace too small");
+  if (box_mode != 0 && !box) return fail(m, TMDNET_ERR_INVALID, "box_mode != 0 needs a box");
+  g_cur = m;
+  {
+    ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
+    launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
+                              true, s);
+    launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+  }
+  g_cur = nullptr;
+  m->lastE = ecap;
+  HIP_TRY(m, hipGetLastError());
+  return TMDNET_OK;
+}
+
+int tmdnet_graph_counts(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t counts_host[4]) {
+  if (!m || !graph_ws || !counts_host) return TMDNET_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Graph g = carve_graph(graph_ws, n_atoms, n_mol, (int64_t)m->hp.max_num_neighbors * n_atoms, nullptr);
+  int counts[4] = {0, 0, 0, 0};
+  HIP_TRY(m, hipMemcpyAsync(counts, g.counts, sizeof(counts), hipMemcpyDeviceToHost, s));
+  HIP_TRY(m, hipStreamSynchronize(s));
+  for (int k = 0; k < 4; ++k) counts_host[k] = counts[k];
+  return counts[2] ? TMDNET_ERR_OVERFLOW : TMDNET_OK;
+}
+
 // ------------------------------------------------------------------------------------ forward + reverse
 int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int64_t n_edges,
                                    int32_t want_forces, size_t* bytes) {
   if (!m || !bytes) return TMDNET_ERR_INVALID;
   (void)n_edges;
+  if (n_pairs < 0) n_pairs = ((int64_t)m->hp.max_num_neighbors * n_atoms) / 2 + 1;  // static mode: pair capacity
   carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes);
   return TMDNET_OK;
 }
@@ -618,8 +656,10 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   const int N = (int)n_atoms, B = (int)n_mol;
   const int64_t ecap = (int64_t)hp.max_num_neighbors * n_atoms;
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, nullptr);
-  if (n_pairs < 0 || n_pairs > g.pcap) return fail(m, TMDNET_ERR_INVALID, "n_pairs out of range");
-  const int P = (int)n_pairs, P1 = P + 1;  // read back by tmdnet_build_graph
+  if (n_pairs > g.pcap) return fail(m, TMDNET_ERR_INVALID, "n_pairs out of range");
+  // n_pairs >= 0: exact count read back by tmdnet_build_graph (launch grids sized exactly);
+  // n_pairs <  0: static mode, grids and workspace sized by the pair capacity, true count read on the device
+  const int P = n_pairs >= 0 ? (int)n_pairs : (int)g.pcap, P1 = P + 1;
   size_t need = 0;
   FwdBuffers b = carve_fwd(ws, hp, n_atoms, n_mol, P, want_forces != 0, &need);
   if (need > ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "forward workspace too small: need " + std::to_string(need));
@@ -630,8 +670,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   const double E_ = (double)m->lastE, Nd = N, Pd = P, Fd = F;
   const double nodeB = Nd * 9 * Fd * 4;             // one [N,9,F] tensor
   const double msgB = E_ * (12 * Fd + 8);           // per directed edge: 3F weights + indices
-  auto EDGE = [&]() { g_gemm_cat = CAT_GEMM_EDGE; };
-  auto NODE = [&]() { g_gemm_cat = CAT_GEMM_NODE; };
+  auto EDGE = [&](int add) { g_gemm_cat = CAT_GEMM_EDGE; g_mdev = g.counts; g_madd = add; };
+  auto NODE = [&]() { g_gemm_cat = CAT_GEMM_NODE; g_mdev = nullptr; g_madd = 0; };
 
   // ---- radial functions per pair
   RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
@@ -639,7 +679,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   // ---- embedding
   // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
   KR(CAT_ELEMENTWISE, (double)Z * F * 12 + 8.0 * F * F, launch_ztables(W.emb, W.emb2_waT, W.emb2_wbT, W.emb2_b, Z, F, b.Utab, b.Vtab, s));
-  EDGE();
+  EDGE(1);
   gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);              // distance projections
   KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
      launch_embed_scatter(g, N, F, z, b.Utab, b.Vtab, b.Q, b.C, b.u0, b.s0n, s));
@@ -651,7 +691,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   // ---- interaction layers
   for (int l = 0; l < L; ++l) {
     const LayerP& q_ = W.layer[l];
-    EDGE();
+    EDGE(1);
     gemm(s, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU, b.e1[l], F);
     gemm(s, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU, b.e2[l], 2 * F);
     gemm(s, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, b.e3[l], 3 * F,
@@ -678,8 +718,10 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     gemm(s, b.g_al, F, W.LinT, F, nullptr, b.g_ln, 3 * F, N, 3 * F, F);
     KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, 3 * F, b.g_feat, s));
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 4, launch_readout_bwd(b.X[L], b.g_feat, N, F, b.G, s));
-    HIP_TRY(m, hipMemsetAsync(b.gC, 0, sizeof(float) * P1, s));
-    HIP_TRY(m, hipMemsetAsync(b.g_phi, 0, sizeof(float) * (size_t)P1 * K, s));
+    // zero-fills are kernels, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to
+    // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
+    launch_fill(b.gC, 0.f, P1, s);
+    launch_fill(b.g_phi, 0.f, (int64_t)P1 * K, s);
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];
       KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch, N, F, b.gD, s));
@@ -687,7 +729,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch, o3, N, F, b.gMi, b.gPn, s));
       KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
       KR(CAT_PAIR, Pd * (24 * Fd + 8) + 2 * nodeB, launch_pair_bwd(g, P, F, b.gMi, b.Pn[l], b.e3[l], b.C, b.g_e3, b.gC, s));
-      EDGE();
+      EDGE(0);
       gemm(s, b.g_e3, 3 * F, q_.M3T, 3 * F, nullptr, b.g_e2, 2 * F, P, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.e2[l], 2 * F);
       gemm(s, b.g_e2, 2 * F, q_.M2T, 2 * F, nullptr, b.g_e1, F, P, F, 2 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.e1[l], F);
       gemm(s, b.g_e1, F, q_.M1T, F, nullptr, b.g_phi, K, P, K, F, GEMM_ACCUM);
@@ -703,11 +745,12 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
     KR(CAT_PAIR, Pd * (24 * Fd + 8) + Nd * 10 * Fd * 4,
        launch_embed_bwd_pair(g, P, F, z, b.Utab, b.Vtab, b.Q, b.C, b.gA, b.g_e3 /* gQ reuses g_e3 */, b.gC, b.g_rhat, s));
-    EDGE();
+    EDGE(0);
     gemm(s, b.g_e3, 3 * F, W.WdpT, 3 * F, nullptr, b.g_phi, K, P, K, 3 * F, GEMM_ACCUM);
     KR(CAT_ELEMENTWISE, Pd * (2 * K + 12) * 4, launch_geom(g, P, K, b.gC, b.dC, b.g_phi, b.dphi, b.g_rhat, b.g_delta, s));
     KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, forces, s));
   }
+  NODE();
   g_cur = nullptr;
   HIP_TRY(m, hipGetLastError());
   m->last = b;

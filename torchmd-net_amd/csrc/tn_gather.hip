@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_message_v4(Graph g, int N, int F, const
                                                     float* __restrict__ out1) {
   const int tpa = F >> 2, apb = 256 / tpa;
   const int i = blockIdx.x * apb + threadIdx.x / tpa;
-  if (i >= N) return;
+  if (i >= N || g.counts[2]) return;
   const int f = (threadIdx.x % tpa) << 2;
   float4 m[9];
   csr_gather4(g, i, F, f, w, src, m);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_v4(Graph g, int P, int F, cons
                                                      float* __restrict__ gC) {
   const int tpa = F >> 2, ppb = 256 / tpa;
   const int p = blockIdx.x * ppb + threadIdx.x / tpa;
-  if (p >= P) return;
+  if (p >= g.counts[0] || g.counts[2]) return;  // grid sized by capacity, true count on the device
   const int f = (threadIdx.x % tpa) << 2;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const float cp = C[p];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_embed_scatter_v4(Graph g, int N, int F,
                                                           float* __restrict__ u0, float* __restrict__ s0n) {
   const int tpa = F >> 2, apb = 256 / tpa;
   const int i = blockIdx.x * apb + threadIdx.x / tpa;
-  if (i >= N) return;
+  if (i >= N || g.counts[2]) return;
   const int f = (threadIdx.x % tpa) << 2;
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   const int F3 = 3 * F;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd_pair_v4(Graph g, int P, int F
                                                            float* __restrict__ gC, float* __restrict__ g_rhat) {
   const int tpa = F >> 2, ppb = 256 / tpa;
   const int p = blockIdx.x * ppb + threadIdx.x / tpa;
-  if (p >= P) return;
+  if (p >= g.counts[0] || g.counts[2]) return;  // grid sized by capacity, true count on the device
   const int f = (threadIdx.x % tpa) << 2;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const int64_t zi = z[i], zj = z[j];

@@ -34,6 +34,10 @@ struct GemmArgs {
   int64_t lda, ldw, ldc, ldpre, ldaux;
   int a_off[GEMM_MAX_GROUPS], c_off[GEMM_MAX_GROUPS], pre_off[GEMM_MAX_GROUPS], aux_off[GEMM_MAX_GROUPS];
   int M, N, K, groups, flags;
+  // optional device-side row count: rows = min(M, *m_dev + m_add).  The grid is sized by M (the capacity) and
+  // surplus blocks exit at once, so a schedule with data-dependent pair counts needs no host synchronisation.
+  const int* m_dev;
+  int m_add;
 };
 
 // launches on `stream`; returns hipError_t as int

@@ -104,7 +104,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
 
   const float* __restrict__ A = a.A + a.a_off[g];
   const float* __restrict__ W = a.W[g];
-  const int M = a.M, N = a.N, K = a.K;
+  int M = a.M;
+  if (a.m_dev) {
+    const int md = *a.m_dev + a.m_add;
+    M = md < M ? md : M;
+    if (m0 >= M) return;  // whole block: before any barrier
+  }
+  const int N = a.N, K = a.K;
   const bool a_vec = ((a.lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const bool w_vec = ((a.ldw & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
   const bool a_full = a_vec && (m0 + BM <= M);
@@ -135,6 +141,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
     else load_panel<BN, false>(rb, W, a.ldw, n0, N, k0, K, w_vec, tid);
   };
 
+  if (DBG & 16) {  // experiment: de-synchronise the co-resident blocks of the first round
+    const int grp = (DBG & 32) ? ((DBG & 64) ? (blockIdx.x >> 3) % 3 : blockIdx.x % 3) : (blockIdx.x >> 8) % 3;
+    if (blockIdx.x < 768)
+      for (int i = 0; i < grp * nk / 2; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   fetch(0);
   store_panel<BM>(ra, As, tid);
   store_panel<BN>(rb, Bs, tid);
@@ -267,6 +278,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
       case 4: return launch_one<128, 128, 2, 2, EPI_GENERIC, 4>(a, stream);
       case 5: return launch_one<128, 128, 2, 2, EPI_GENERIC, 5>(a, stream);
       case 7: return launch_one<128, 128, 2, 2, EPI_GENERIC, 7>(a, stream);
+      case 16: return launch_one<128, 128, 2, 2, EPI_GENERIC, 16>(a, stream);
+      case 48: return launch_one<128, 128, 2, 2, EPI_GENERIC, 48>(a, stream);
+      case 112: return launch_one<128, 128, 2, 2, EPI_GENERIC, 112>(a, stream);
       default: return launch_one<128, 128, 2, 2, EPI_GENERIC, 0>(a, stream);
     }
   }

@@ -218,9 +218,10 @@ __global__ void k_nbr_link(Graph g, int N) {
 
 void launch_graph_build_phase1(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
                                int B, float lo, float up, bool loop, hipStream_t s) {
-  hipMemsetAsync(g.mstart, 0, sizeof(int) * B, s);
-  hipMemsetAsync(g.mend, 0, sizeof(int) * B, s);
-  hipMemsetAsync(g.counts, 0, sizeof(int) * 8, s);
+  // kernel fills instead of hipMemsetAsync (memset nodes did not replay reliably from a captured HIP graph)
+  launch_fill(reinterpret_cast<float*>(g.mstart), 0.f, B, s);
+  launch_fill(reinterpret_cast<float*>(g.mend), 0.f, B, s);
+  launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
   if (N <= 0) return;
   hipLaunchKernelGGL(k_mol_ranges, dim3(cdiv(N, 256)), dim3(256), 0, s, batch, N, B, g.mstart, g.mend, g.counts);
   hipLaunchKernelGGL(k_nbr_count, dim3(cdiv(N, 64)), dim3(64), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up, (int)loop);
@@ -273,8 +274,12 @@ void launch_export_pairs(const Graph& g, int N, bool include_transpose, bool loo
 // =====================================================================================
 //                         radial basis + cutoff (one thread per (pair, k))
 // =====================================================================================
-__global__ void k_radial(Graph g, int P, RadialParams rp, float* __restrict__ phi, float* __restrict__ dphi, float* __restrict__ C,
+// NOTE (all per-pair kernels): the launch grid is sized by the host-side pair CAPACITY; the true pair count is
+// read from device memory (g.counts[0]) so that the schedule can be replayed from a HIP graph without a host sync.
+__global__ void k_radial(Graph g, int Pcap, RadialParams rp, float* __restrict__ phi, float* __restrict__ dphi, float* __restrict__ C,
                          float* __restrict__ dC) {
+  const int P = g.counts[0];
+  if (g.counts[2]) return;
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t total = (int64_t)(P + 1) * rp.K;
   if (idx >= total) return;
@@ -328,6 +333,7 @@ __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict
                                 const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ C,
                                 float* __restrict__ u0, float* __restrict__ s0n) {
   const int i = blockIdx.x;
+  if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   const int64_t zi = z[i];
   const int F3 = 3 * F;
@@ -486,6 +492,7 @@ __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, co
                           const float* __restrict__ q, const int64_t* __restrict__ batch, int o3, float* __restrict__ Mi,
                           float* __restrict__ Ch) {
   const int i = blockIdx.x;
+  if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
   const float kap = kappa_of(q, batch, i);
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
     float m[9], y[9];
@@ -514,6 +521,7 @@ void launch_message(const Graph& g, int N, int F, const float* w, const float* s
 __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ gMi,
                                   float* __restrict__ gPn) {
   const int i = blockIdx.x;
+  if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
     float a[9];
     csr_gather(g, i, F, f, w, gMi, a);
@@ -757,6 +765,7 @@ __global__ void k_pair_bwd(Graph g, int P, int F, const float* __restrict__ gMi,
                            float* __restrict__ gC) {
   __shared__ float red[4];
   const int p = blockIdx.x;
+  if (p >= g.counts[0] || g.counts[2]) return;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const float cp = C[p];
   const int F9 = 9 * F, F3 = 3 * F;
@@ -878,6 +887,7 @@ __global__ void k_embed_bwd_pair(Graph g, int P, int F, const int64_t* __restric
                                  float* __restrict__ g_rhat) {
   __shared__ float red[16];
   const int p = blockIdx.x;
+  if (p >= g.counts[0] || g.counts[2]) return;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const int64_t zi = z[i], zj = z[j];
   const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
@@ -936,7 +946,7 @@ __global__ void k_geom(Graph g, int P, int K, const float* __restrict__ gC, cons
                        float* __restrict__ g_delta) {
   // one wave per pair: lanes stride over k (coalesced rows of g_phi / dphi), wave-level reduction
   const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (p >= P) return;
+  if (p >= g.counts[0] || g.counts[2]) return;
   const int lane = threadIdx.x & 63;
   float part = 0.f;
   for (int k = lane; k < K; k += 64) part += g_phi[(int64_t)p * K + k] * dphi[(int64_t)p * K + k];
@@ -960,7 +970,7 @@ void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC,
 // F_i = - sum_{e in row(i)} sign(e) * g_delta[pair(e)]     (no atomics: CSR gather)
 __global__ void k_force_gather(Graph g, int N, const float* __restrict__ g_delta, float* __restrict__ forces) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
+  if (i >= N || g.counts[2]) return;
   float fx = 0.f, fy = 0.f, fz = 0.f;
   for (int e = g.rowptr[i]; e < g.rowptr[i + 1]; ++e) {
     const float sg = g.esign[e];

@@ -267,6 +267,7 @@ class TorchMD_Net(nn.Module):
         std = torch.scalar_tensor(1) if std is None else std
         self.register_buffer("std", std.to(dtype=dtype))
         self._engine = _EngineState()
+        self.static_check = True  # static_shapes mode: poll the overflow flag after every non-captured call
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -377,15 +378,23 @@ class TorchMD_Net(nn.Module):
             L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
             st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
             counts = (C.c_int64 * 4)()
-            rc = L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32), _ptr(batch),
-                                      _ptr(box), box_mode, counts)
+            static = bool(getattr(self.representation_model, "static_shapes", False))
+            if static:
+                # static shapes (reference tensornet.py:277-290): no read-back, no synchronisation -> the whole call
+                # can be captured in a HIP graph; launch grids / workspaces are sized by max_num_neighbors * N
+                rc = L.tmdnet_build_graph_static(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32),
+                                                 _ptr(batch), _ptr(box), box_mode)
+                n_pairs, n_edges = -1, -1
+            else:
+                rc = L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32),
+                                          _ptr(batch), _ptr(box), box_mode, counts)
+                n_pairs, n_edges = int(counts[0]), int(counts[1])
+                st.counts = (n_pairs, n_edges, int(counts[3]))
             if rc == _C.ERR_OVERFLOW:
                 # same exception type and message as the reference (models/utils.py:297-300)
                 raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
             if rc != _C.OK:
                 raise RuntimeError(f"tmdnet_build_graph: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
-            n_pairs, n_edges = int(counts[0]), int(counts[1])
-            st.counts = (n_pairs, n_edges, int(counts[3]))
             L.tmdnet_forward_workspace_bytes(st.handle, n, n_mol, n_pairs, n_edges, int(want_forces), C.byref(nbytes))
             st.fwd_ws = self._grow(st.fwd_ws, nbytes.value, dev)
             energy = torch.empty(n_mol, dtype=torch.float32, device=dev)
@@ -394,7 +403,57 @@ class TorchMD_Net(nn.Module):
                                         n_pairs, _ptr(z), _ptr(batch), _ptr(q), int(want_forces), _ptr(energy), _ptr(forces))
             if rc != _C.OK:
                 raise RuntimeError(f"tmdnet_energy_forces: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
+            if static and self.static_check and not torch.cuda.is_current_stream_capturing():
+                # outside a capture the overflow flag is polled (one sync); replays of a captured graph are unchecked,
+                # like the reference's asynchronous assert (models/utils.py:297-300): call check_overflow() when convenient
+                self.check_overflow(n, n_mol)
         return energy, forces
+
+    def check_overflow(self, n_atoms: int, n_mol: int):
+        """Poll the device-side pair counters of the last static-shape evaluation (synchronises)."""
+        L = _C.lib()
+        st = self._engine
+        counts = (C.c_int64 * 4)()
+        rc = L.tmdnet_graph_counts(st.handle, _stream_ptr(st.graph_ws.device), _ptr(st.graph_ws), n_atoms, n_mol, counts)
+        st.counts = (int(counts[0]), int(counts[1]), int(counts[3]))
+        if rc == _C.ERR_OVERFLOW:
+            raise RuntimeError("Found num_pairs > max_num_pairs, please increase max_num_pairs "
+                               f"(found {int(counts[1])} edges for max_num_neighbors={self.representation_model.max_num_neighbors})")
+        return st.counts
+
+    def capture(self, z: Tensor, pos: Tensor, batch: Optional[Tensor] = None, box: Optional[Tensor] = None,
+                q: Optional[Tensor] = None, num_systems: Optional[int] = None, warmup: int = 3):
+        """Capture one energy+force evaluation into a HIP graph (needs ``static_shapes=True``).
+        Returns ``replay(pos) -> (energy [B,1], forces [N,3])`` writing into static buffers - the reference gets
+        the same effect with torch.cuda.graphs around its model (calculators.py:117-128)."""
+        if not getattr(self.representation_model, "static_shapes", False):
+            raise RuntimeError("capture() needs a model created with static_shapes=True")
+        _require_cuda(pos, "capture")
+        batch = torch.zeros_like(z) if batch is None else batch
+        n_mol = int(num_systems) if num_systems is not None else int(batch.max().item()) + 1
+        s_pos = pos.detach().clone().contiguous()
+        rm = self.representation_model
+        if box is None and rm.distance.use_periodic:
+            box = rm.distance.box
+        side = torch.cuda.Stream(device=pos.device)
+        side.wait_stream(torch.cuda.current_stream(pos.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):  # uploads parameters, sizes the workspaces, checks overflow
+                self.energy_and_forces(z, s_pos, batch, box, q, n_mol, want_forces=True)
+        torch.cuda.current_stream(pos.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            s_e, s_f = self.energy_and_forces(z, s_pos, batch, box, q, n_mol, want_forces=True)
+
+        def replay(new_pos: Optional[Tensor] = None):
+            if new_pos is not None:
+                s_pos.copy_(new_pos)
+            graph.replay()
+            return s_e.view(-1, 1), s_f
+
+        replay.graph = graph
+        replay.n_atoms, replay.n_mol = int(z.shape[0]), n_mol
+        return replay
 
     def debug_tensor(self, name: str, shape) -> Tensor:
         L = _C.lib()
