@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "tn_common.h"
+#include "tn_gemm_epi.h"
 
 namespace tn {
 
@@ -22,23 +23,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
-
-enum EpiKind : int {
-  EPI_PLAIN = 0,          // C = acc (+bias)
-  EPI_SILU_PRE,           // pre = acc+bias ; C = silu(pre)
-  EPI_SILU_PRE_ROWSCALE,  // pre = acc+bias ; C = silu(pre) * rowscale[m]
-  EPI_MULAUX_PRE,         // pre = acc ; C = pre * aux[m,n]
-  EPI_MULDSILU,           // C = acc * silu'(aux[m,n])
-  EPI_ACCUM,              // C += acc
-  EPI_GENERIC             // run-time flags (any other combination)
-};
-
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_silu(float x) { return x * fast_sigmoid(x); }
-__device__ __forceinline__ float fast_silu_grad(float x) {
-  float s = fast_sigmoid(x);
-  return s * (1.0f + x * (1.0f - s));
-}
 
 template <int ROWS, bool FAST>
 __device__ __forceinline__ void load_panel(float4 (&reg)[ROWS * 8 / 256], const float* __restrict__ base, int64_t ld, int row0,
@@ -234,17 +218,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
   }
 }
 
-static int epi_kind(const GemmArgs& a) {
-  const int f = a.flags;
-  if (f == 0 && !a.pre) return EPI_PLAIN;
-  if (f == GEMM_ACT_SILU && a.pre) return EPI_SILU_PRE;
-  if (f == (GEMM_ACT_SILU | GEMM_ROWSCALE) && a.pre) return EPI_SILU_PRE_ROWSCALE;
-  if (f == GEMM_MUL_AUX && a.pre) return EPI_MULAUX_PRE;
-  if (f == GEMM_MUL_DSILU_AUX && !a.pre) return EPI_MULDSILU;
-  if (f == GEMM_ACCUM && !a.pre) return EPI_ACCUM;
-  return EPI_GENERIC;
-}
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int DBG = 0>
 static int launch_one(const GemmArgs& a, hipStream_t stream) {
   int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -283,6 +256,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
       case 112: return launch_one<128, 128, 2, 2, EPI_GENERIC, 112>(a, stream);
       default: return launch_one<128, 128, 2, 2, EPI_GENERIC, 0>(a, stream);
     }
+  }
+  // few tiles: the chip would be mostly idle and every launch would cost K/32 dependent iterations ->
+  // latency-oriented split-K kernel (single molecules, small MD systems)
+  {
+    static const bool no_skinny = getenv("TMDNET_NO_SKINNY") != nullptr;
+    const int bn = (a.N % 128 == 0 || a.N > 192) ? 128 : (a.N > 32 ? 64 : 32);
+    const int64_t tiles = (int64_t)((a.M + 127) / 128) * ((a.N + bn - 1) / bn) * a.groups;
+    if (!no_skinny && tiles < 256) return launch_gemm_skinny(a, stream);
   }
   if (a.N % 128 == 0 || a.N > 192) return launch_variant<128, 128, 2, 2>(a, stream);
   if (a.N > 32) return launch_variant<128, 64, 2, 2>(a, stream);

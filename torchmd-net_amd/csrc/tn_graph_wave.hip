@@ -1,0 +1,134 @@
+// Wave-per-atom neighbour-graph kernels (gfx950, wave64).
+//
+// One 64-lane wave owns one atom; lanes sweep the candidate range 64 atoms at a time (coalesced position
+// loads), `__ballot` + popcount give the counts and the ordered slot of every hit, so rows come out sorted
+// by neighbour index without atomics.  Replaces the thread-per-atom versions of tn_kernels.hip (kept as the
+// readable specification): same pair set, same order, ~10x lower latency for single molecules and coalesced
+// O(N^2/64) wave-passes for one large system.  Semantics: reference warp_kernels/neighbors_brute.py:98-197.
+#include "tn_common.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+static inline int cdivw(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float pair_d2(const float* __restrict__ pos, int hi, int lo, const float* __restrict__ box, float& dx,
+                                         float& dy, float& dz) {
+  dx = pos[hi * 3 + 0] - pos[lo * 3 + 0];
+  dy = pos[hi * 3 + 1] - pos[lo * 3 + 1];
+  dz = pos[hi * 3 + 2] - pos[lo * 3 + 2];
+  if (box) {  // triclinic minimum image, z -> y -> x
+    float s3 = roundf(dz / box[8]);
+    dx -= s3 * box[6]; dy -= s3 * box[7]; dz -= s3 * box[8];
+    float s2 = roundf(dy / box[4]);
+    dx -= s2 * box[3]; dy -= s2 * box[4];
+    float s1 = roundf(dx / box[0]);
+    dx -= s1 * box[0];
+  }
+  return dx * dx + dy * dy + dz * dz;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_nbr_wave(Graph g, const float* __restrict__ pos, const int64_t* __restrict__ batch,
+                                                  const float* __restrict__ box, int box_mode, int N, float lo2, float up2,
+                                                  int loop) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= N) return;
+  if (FILL && g.counts[2]) return;
+  const int64_t b = batch[i];
+  int j0 = 0, j1 = N;
+  if (!g.counts[3]) {
+    j0 = g.mstart[b];
+    j1 = g.mend[b];
+  }
+  const float* bx = box_mode == 0 ? nullptr : (box_mode == 1 ? box : box + b * 9);
+  const int P = FILL ? g.counts[0] : 0;
+  int e = FILL ? g.rowptr[i] : 0, p = FILL ? g.pairptr[i] : 0;
+  int nl = 0, nt = 0;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int base = j0; base < j1; base += 64) {
+    const int j = base + lane;
+    bool hit = false, self = false;
+    float dx = 0.f, dy = 0.f, dz = 0.f, d2 = 0.f;
+    if (j < j1) {
+      if (j == i) {
+        hit = loop != 0;
+        self = true;
+      } else if (batch[j] == b) {
+        d2 = (j < i) ? pair_d2(pos, i, j, bx, dx, dy, dz) : pair_d2(pos, j, i, bx, dx, dy, dz);
+        hit = d2 < up2 && d2 >= lo2;
+      }
+    }
+    const unsigned long long mall = __ballot(hit);
+    const unsigned long long mlow = __ballot(hit && j < i);
+    if (FILL) {
+      if (hit) {
+        const int ee = e + __popcll(mall & lt);
+        g.col[ee] = j;
+        if (self) {
+          g.epair[ee] = P;
+          g.esign[ee] = 0.f;
+        } else if (j < i) {
+          const int pp = p + __popcll(mlow & lt);
+          const float d = sqrtf(d2);
+          const float inv = d > 0.f ? 1.0f / d : 0.f;
+          g.pair_i[pp] = i;
+          g.pair_j[pp] = j;
+          g.pd[pp] = d;
+          g.pdelta[pp * 3 + 0] = dx; g.pdelta[pp * 3 + 1] = dy; g.pdelta[pp * 3 + 2] = dz;
+          g.prhat[pp * 3 + 0] = dx * inv; g.prhat[pp * 3 + 1] = dy * inv; g.prhat[pp * 3 + 2] = dz * inv;
+          g.epair[ee] = pp;
+          g.esign[ee] = 1.f;
+        } else {
+          g.epair[ee] = -1;  // linked by k_nbr_link_wave
+          g.esign[ee] = -1.f;
+        }
+      }
+      e += __popcll(mall);
+      p += __popcll(mlow);
+    } else {
+      nt += __popcll(mall);
+      nl += __popcll(mlow);
+    }
+  }
+  if (!FILL && lane == 0) {
+    g.nlow[i] = nl;
+    g.ntot[i] = nt;
+  }
+  if (FILL && i == 0 && lane == 0) g.pd[P] = 0.f;  // the self pair
+}
+
+// upper edges (i <- j, j > i) take the pair id of the lower edge (j <- i): lanes over the row's edges, binary
+// search of i among the sorted lower neighbours of j
+__global__ __launch_bounds__(256) void k_nbr_link_wave(Graph g, int N) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= N || g.counts[2]) return;
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  for (int e = e0 + lane; e < e1; e += 64) {
+    const int j = g.col[e];
+    if (j <= i) continue;
+    int lo = g.rowptr[j], hi = lo + g.nlow[j] - 1;
+    const int base = lo;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (g.col[mid] < i) lo = mid + 1; else hi = mid;
+    }
+    g.epair[e] = g.pairptr[j] + (lo - base);
+  }
+}
+
+void launch_nbr_count_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, float lo,
+                           float up, bool loop, hipStream_t s) {
+  hipLaunchKernelGGL(k_nbr_wave<false>, dim3(cdivw(N, 4)), dim3(256), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up,
+                     (int)loop);
+}
+void launch_nbr_fill_link_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
+                               float lo, float up, bool loop, hipStream_t s) {
+  hipLaunchKernelGGL(k_nbr_wave<true>, dim3(cdivw(N, 4)), dim3(256), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up,
+                     (int)loop);
+  hipLaunchKernelGGL(k_nbr_link_wave, dim3(cdivw(N, 4)), dim3(256), 0, s, g, N);
+}
+
+}  // namespace tn

@@ -89,6 +89,12 @@ void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC,
 void launch_force_gather(const Graph& g, int N, const float* g_delta, float* forces, hipStream_t s);
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);
 
+// ---- wave-per-atom neighbour kernels (tn_graph_wave.hip)
+void launch_nbr_count_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, float lo,
+                           float up, bool loop, hipStream_t s);
+void launch_nbr_fill_link_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
+                               float lo, float up, bool loop, hipStream_t s);
+
 // ---- 16-byte-per-lane variants (tn_gather.hip), selected by the launchers above when gather_v4_ok(F)
 bool gather_v4_ok(int F);
 void launch_message_v4(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,

@@ -5,6 +5,8 @@
 // the thread that owns (atom, channel): no atomics, deterministic results.
 #include "tn_kernels.h"
 
+#include <cstdlib>
+
 #include "tn_common.h"
 
 namespace tn {
@@ -224,15 +226,22 @@ void launch_graph_build_phase1(const Graph& g, const float* pos, const int64_t* 
   launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
   if (N <= 0) return;
   hipLaunchKernelGGL(k_mol_ranges, dim3(cdiv(N, 256)), dim3(256), 0, s, batch, N, B, g.mstart, g.mend, g.counts);
-  hipLaunchKernelGGL(k_nbr_count, dim3(cdiv(N, 64)), dim3(64), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up, (int)loop);
+  if (getenv("TMDNET_SCALAR_GRAPH"))  // developer switch: thread-per-atom specification kernels
+    hipLaunchKernelGGL(k_nbr_count, dim3(cdiv(N, 64)), dim3(64), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up, (int)loop);
+  else
+    launch_nbr_count_wave(g, pos, batch, box, box_mode, N, lo, up, loop, s);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, g, N);
 }
 
 void launch_graph_build_phase2(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
                                float lo, float up, bool loop, hipStream_t s) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(k_nbr_fill, dim3(cdiv(N, 64)), dim3(64), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up, (int)loop);
-  hipLaunchKernelGGL(k_nbr_link, dim3(cdiv(N, 64)), dim3(64), 0, s, g, N);
+  if (getenv("TMDNET_SCALAR_GRAPH")) {
+    hipLaunchKernelGGL(k_nbr_fill, dim3(cdiv(N, 64)), dim3(64), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up, (int)loop);
+    hipLaunchKernelGGL(k_nbr_link, dim3(cdiv(N, 64)), dim3(64), 0, s, g, N);
+  } else {
+    launch_nbr_fill_link_wave(g, pos, batch, box, box_mode, N, lo, up, loop, s);
+  }
 }
 
 // COO list in the reference operator's format: lower pairs (i>j) [+ transposes] [+ self loops], padded with -1/0
