@@ -81,6 +81,13 @@ const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel);
  * [2] = overflow flag, [3] = 1 if `batch` was not sorted (slow path).
  * Returns TMDNET_ERR_OVERFLOW when E > max_num_neighbors * n_atoms. */
 int tmdnet_graph_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, size_t* bytes);
+/* O(N) cell list (reference "cell" strategy: extensions/neighbor_utils.py:89-150, warp_kernels/neighbors_cell.py:17-153;
+ * orthorhombic boxes, one box for the whole system).  The caller supplies the grid n_axis = floor(L_axis / cutoff_upper)
+ * computed on the host from the box it owns (0,0,0 = always brute force).  The graph builders use the cell list when
+ * n_mol == 1, box_mode == 1, every n_axis >= 3 and n_x*n_y*n_z <= 8*n_atoms; otherwise the brute-force sweep runs.
+ * Same pair set either way; with the cell list atoms are renumbered in cell order internally and forces are
+ * returned in the caller's order. */
+int tmdnet_set_cell_grid(tmdnet_model* m, int32_t ncx, int32_t ncy, int32_t ncz);
 int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms, int64_t n_mol,
                        const float* pos, const int64_t* batch, const float* box, int32_t box_mode, int64_t counts_host[4]);
 

@@ -226,3 +226,34 @@ def test_static_shapes_equals_dynamic_and_graph_replay(hip_lib, golden_dir):
     small = _model_from_sd(dict(g["args"], static_shapes=True, max_num_neighbors=3), g["state_dict"])
     with pytest.raises(RuntimeError, match="max_num_pairs"):
         small(z, pos, batch)
+
+
+def test_cell_list_equals_brute_force_and_oracle(hip_lib):
+    """Large periodic orthorhombic system: the O(N) cell-list graph (atoms renumbered in cell order internally)
+    gives the same energies/forces as the brute-force sweep; sampled forces also checked against the oracle
+    (reference: cell and brute strategies return the same pair set, tests/test_neighbors.py:74-148)."""
+    from oracle import tensornet_c as CO, tensornet_torch as T
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(0)
+    args = dict(W.TINY_ARGS, max_num_neighbors=96)
+    model = create_model(dict(args)).to("cuda")
+    z, pos, box = W.water_box(n_side=8, spacing=3.1)  # 1536 atoms, 24.8 A box -> 4 cells per axis at rc = 5
+    z = z % 19 + 1
+    # shift atoms out of the primary cell: wrapping must not matter
+    pos = pos + torch.tensor([30.0, -55.0, 12.0])
+    batch = torch.zeros_like(z)
+    model.cell_list_min_atoms = 10 ** 9
+    Eb, Fb = model(z.cuda(), pos.cuda(), batch.cuda(), box=box.cuda())
+    cb = model._engine.counts
+    model.cell_list_min_atoms = 1
+    Ec, Fc = model(z.cuda(), pos.cuda(), batch.cuda(), box=box.cuda())
+    cc = model._engine.counts
+    assert cb[:2] == cc[:2], (cb, cc)
+    assert rel_err(Ec, Eb) < 1e-5 and rel_err(Fc, Fb) < 1e-5
+    Ec2, Fc2 = model(z.cuda(), pos.cuda(), batch.cuda(), box=box.cuda())
+    assert torch.equal(Ec, Ec2) and torch.equal(Fc, Fc2)  # deterministic
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    Er, Fr = CO.energy_forces(sd, T.hparams_from_args(args), z, pos, batch, box=box)
+    assert rel_err(Ec.cpu(), Er) < REL and rel_err(Fc.cpu(), Fr) < REL

@@ -103,6 +103,8 @@ struct tmdnet_model {
   tmdnet_hparams hp;
   Profiler prof;
   int64_t lastE = 0;
+  int cell_n[3] = {0, 0, 0};  // cell grid set by tmdnet_set_cell_grid (0 = brute force)
+  bool graph_is_cell = false; // last build used the cell list (atoms internally renumbered)
   std::vector<ParamSpec> specs;
   std::map<std::string, std::vector<float>> host;
   float* dev = nullptr;  // packed parameters
@@ -292,8 +294,33 @@ Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   g.prhat = c.take<float>(pcap * 3);
   g.ecap = ecap;
   g.pcap = pcap;
+  g.perm = c.take<int>(N);
+  g.iota = c.take<int>(N);
+  g.cell_key = c.take<int>(N);
+  g.cell_key_sorted = c.take<int>(N);
+  g.cell_start = c.take<int>(8 * N + 2);
+  g.pos_s = c.take<float>(3 * N);
+  g.z_s = c.take<int64_t>(N);
+  g.boxd = c.take<float>(4);
+  g.sort_tmp_bytes = cell_sort_temp_bytes(N);
+  g.sort_tmp = c.take<char>((int64_t)g.sort_tmp_bytes);
   if (total) *total = c.off;
   return g;
+}
+
+// the cell list applies to ONE periodic orthorhombic system with at least 3 cells per axis (so that the 27
+// neighbour cells are distinct) and a bounded number of cells; everything else takes the brute-force sweep
+bool cell_applicable(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int box_mode) {
+  const int* n = m->cell_n;
+  if (n_mol != 1 || box_mode != 1) return false;
+  if (n[0] < 3 || n[1] < 3 || n[2] < 3) return false;
+  return (int64_t)n[0] * n[1] * n[2] <= 8 * n_atoms;
+}
+void set_cell(Graph& g, const tmdnet_model* m, bool on) {
+  g.use_cell = on ? 1 : 0;
+  g.ncx = m->cell_n[0];
+  g.ncy = m->cell_n[1];
+  g.ncz = m->cell_n[2];
 }
 
 FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, int64_t P, bool bwd, size_t* total) {
@@ -561,6 +588,14 @@ int tmdnet_finalize_params(tmdnet_model* m) {
 }
 
 // ------------------------------------------------------------------------------------ graph
+int tmdnet_set_cell_grid(tmdnet_model* m, int32_t ncx, int32_t ncy, int32_t ncz) {
+  if (!m || ncx < 0 || ncy < 0 || ncz < 0) return TMDNET_ERR_INVALID;
+  m->cell_n[0] = ncx;
+  m->cell_n[1] = ncy;
+  m->cell_n[2] = ncz;
+  return TMDNET_OK;
+}
+
 int tmdnet_graph_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, size_t* bytes) {
   if (!m || !bytes || n_atoms < 0 || n_mol < 0) return TMDNET_ERR_INVALID;
   const int64_t ecap = (int64_t)m->hp.max_num_neighbors * n_atoms;
@@ -578,11 +613,20 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, &need);
   if (need > graph_ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "graph workspace too small");
   if (box_mode != 0 && !box) return fail(m, TMDNET_ERR_INVALID, "box_mode != 0 needs a box");
+  const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
+  set_cell(g, m, cell);
+  m->graph_is_cell = cell;
   g_cur = m;
   {
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
-    launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
-                              true, s);
+    if (cell) {
+      launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
+      launch_cell_phase1(g, pos, box, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, s);
+      launch_scan_counts(g, (int)n_atoms, s);
+    } else {
+      launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
+                                true, s);
+    }
   }
   int counts[4] = {0, 0, 0, 0};
   HIP_TRY(m, hipMemcpyAsync(counts, g.counts, sizeof(counts), hipMemcpyDeviceToHost, s));
@@ -594,7 +638,12 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   m->lastE = counts[1];
   {
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)counts[1] * 12 + (double)counts[0] * 40);
-    launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+    if (cell) {
+      launch_cell_phase2(g, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, s);
+      launch_nbr_link_wave(g, (int)n_atoms, s);
+    } else {
+      launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+    }
   }
   g_cur = nullptr;
   HIP_TRY(m, hipGetLastError());
@@ -610,12 +659,23 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, &need);
   if (need > graph_ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "graph workspace too small");
   if (box_mode != 0 && !box) return fail(m, TMDNET_ERR_INVALID, "box_mode != 0 needs a box");
+  const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
+  set_cell(g, m, cell);
+  m->graph_is_cell = cell;
   g_cur = m;
   {
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
-    launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
-                              true, s);
-    launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+    if (cell) {
+      launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
+      launch_cell_phase1(g, pos, box, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, s);
+      launch_scan_counts(g, (int)n_atoms, s);
+      launch_cell_phase2(g, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, s);
+      launch_nbr_link_wave(g, (int)n_atoms, s);
+    } else {
+      launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
+                                true, s);
+      launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+    }
   }
   g_cur = nullptr;
   m->lastE = ecap;
@@ -667,6 +727,13 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   const int o3 = hp.group_o3;
 
   g_cur = m;
+  const int* perm = nullptr;
+  if (m->graph_is_cell) {  // the graph lives in cell order: renumber z here, scatter the forces back at the end
+    set_cell(g, m, true);
+    launch_permute_z(g, z, N, s);
+    z = g.z_s;
+    perm = g.perm;
+  }
   const double E_ = (double)m->lastE, Nd = N, Pd = P, Fd = F;
   const double nodeB = Nd * 9 * Fd * 4;             // one [N,9,F] tensor
   const double msgB = E_ * (12 * Fd + 8);           // per directed edge: 3F weights + indices
@@ -748,7 +815,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     EDGE(0);
     gemm(s, b.g_e3, 3 * F, W.WdpT, 3 * F, nullptr, b.g_phi, K, P, K, 3 * F, GEMM_ACCUM);
     KR(CAT_ELEMENTWISE, Pd * (2 * K + 12) * 4, launch_geom(g, P, K, b.gC, b.dC, b.g_phi, b.dphi, b.g_rhat, b.g_delta, s));
-    KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, forces, s));
+    KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
   }
   NODE();
   g_cur = nullptr;

@@ -130,5 +130,8 @@ void launch_nbr_fill_link_wave(const Graph& g, const float* pos, const int64_t* 
                      (int)loop);
   hipLaunchKernelGGL(k_nbr_link_wave, dim3(cdivw(N, 4)), dim3(256), 0, s, g, N);
 }
+void launch_nbr_link_wave(const Graph& g, int N, hipStream_t s) {
+  hipLaunchKernelGGL(k_nbr_link_wave, dim3(cdivw(N, 4)), dim3(256), 0, s, g, N);
+}
 
 }  // namespace tn

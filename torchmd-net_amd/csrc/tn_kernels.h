@@ -23,6 +23,18 @@ struct Graph {  // device pointers into the graph workspace
   float* prhat;  // [Pcap,3] unit vector
   int* counts;   // [8]: 0 = P, 1 = E, 2 = overflow, 3 = batch unsorted
   int64_t ecap, pcap;
+  // ---- cell-list path (tn_cell.hip): atoms renumbered in cell order
+  int* perm;             // [N] internal index -> caller's atom index
+  int* iota;             // [N]
+  int* cell_key;         // [N] cell id per caller atom
+  int* cell_key_sorted;  // [N] cell id per internal atom
+  int* cell_start;       // [ncells+1]
+  float* pos_s;          // [N,3] positions in internal order
+  int64_t* z_s;          // [N] atomic numbers in internal order
+  float* boxd;           // [4] box diagonal
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
+  int ncx, ncy, ncz, use_cell;
 };
 
 struct RadialParams {
@@ -86,7 +98,7 @@ void launch_embed_bwd_pair(const Graph& g, int P, int F, const int64_t* z, const
                            const float* C, const float* gA, float* gQ, float* gC, float* g_rhat, hipStream_t s);
 void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC, const float* g_phi, const float* dphi,
                  const float* g_rhat, float* g_delta, hipStream_t s);
-void launch_force_gather(const Graph& g, int N, const float* g_delta, float* forces, hipStream_t s);
+void launch_force_gather(const Graph& g, int N, const float* g_delta, const int* perm, float* forces, hipStream_t s);
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);
 
 // ---- wave-per-atom neighbour kernels (tn_graph_wave.hip)
@@ -94,6 +106,15 @@ void launch_nbr_count_wave(const Graph& g, const float* pos, const int64_t* batc
                            float up, bool loop, hipStream_t s);
 void launch_nbr_fill_link_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
                                float lo, float up, bool loop, hipStream_t s);
+
+void launch_nbr_link_wave(const Graph& g, int N, hipStream_t s);
+void launch_scan_counts(const Graph& g, int N, hipStream_t s);
+
+// ---- O(N) cell list for one periodic orthorhombic system (tn_cell.hip)
+size_t cell_sort_temp_bytes(int64_t n);
+void launch_cell_phase1(const Graph& g, const float* pos, const float* box, int N, float lo, float up, hipStream_t s);
+void launch_cell_phase2(const Graph& g, int N, float lo, float up, hipStream_t s);
+void launch_permute_z(const Graph& g, const int64_t* z, int N, hipStream_t s);
 
 // ---- 16-byte-per-lane variants (tn_gather.hip), selected by the launchers above when gather_v4_ok(F)
 bool gather_v4_ok(int F);

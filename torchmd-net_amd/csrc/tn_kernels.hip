@@ -233,6 +233,10 @@ void launch_graph_build_phase1(const Graph& g, const float* pos, const int64_t* 
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, g, N);
 }
 
+void launch_scan_counts(const Graph& g, int N, hipStream_t s) {
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, g, N);
+}
+
 void launch_graph_build_phase2(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
                                float lo, float up, bool loop, hipStream_t s) {
   if (N <= 0) return;
@@ -977,7 +981,8 @@ void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC,
 }
 
 // F_i = - sum_{e in row(i)} sign(e) * g_delta[pair(e)]     (no atomics: CSR gather)
-__global__ void k_force_gather(Graph g, int N, const float* __restrict__ g_delta, float* __restrict__ forces) {
+__global__ void k_force_gather(Graph g, int N, const float* __restrict__ g_delta, const int* __restrict__ perm,
+                               float* __restrict__ forces) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N || g.counts[2]) return;
   float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -989,13 +994,14 @@ __global__ void k_force_gather(Graph g, int N, const float* __restrict__ g_delta
     fy -= sg * g_delta[p * 3 + 1];
     fz -= sg * g_delta[p * 3 + 2];
   }
-  forces[i * 3] = fx;
-  forces[i * 3 + 1] = fy;
-  forces[i * 3 + 2] = fz;
+  const int o = perm ? perm[i] : i;  // cell-list path: back to the caller's atom order
+  forces[o * 3] = fx;
+  forces[o * 3 + 1] = fy;
+  forces[o * 3 + 2] = fz;
 }
-void launch_force_gather(const Graph& g, int N, const float* g_delta, float* forces, hipStream_t s) {
+void launch_force_gather(const Graph& g, int N, const float* g_delta, const int* perm, float* forces, hipStream_t s) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(k_force_gather, dim3(cdiv(N, 128)), dim3(128), 0, s, g, N, g_delta, forces);
+  hipLaunchKernelGGL(k_force_gather, dim3(cdiv(N, 128)), dim3(128), 0, s, g, N, g_delta, perm, forces);
 }
 
 __global__ void k_fill(float* p, float v, int64_t n) {

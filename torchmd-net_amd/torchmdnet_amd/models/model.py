@@ -268,6 +268,7 @@ class TorchMD_Net(nn.Module):
         self.register_buffer("std", std.to(dtype=dtype))
         self._engine = _EngineState()
         self.static_check = True  # static_shapes mode: poll the overflow flag after every non-captured call
+        self.cell_list_min_atoms = 1024  # single periodic systems at least this large use the O(N) cell list
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -346,6 +347,24 @@ class TorchMD_Net(nn.Module):
         st.fingerprint = fp
         return st
 
+    def _cell_grid(self, box: Tensor):
+        """floor(L/rc) cells per axis (reference get_cell_dimensions, extensions/neighbor_utils.py:76-86) for an
+        orthorhombic box; (0,0,0) = not applicable.  The host copy of the box is cached per tensor version so
+        that replayed / repeated calls do not synchronise."""
+        key = (box.data_ptr(), box._version)
+        cache = self._engine.__dict__.setdefault("box_cache", {})
+        if key not in cache:
+            b = box.detach().to("cpu", torch.float64)
+            off = b - torch.diag(torch.diagonal(b))
+            rc = float(self.representation_model.cutoff_upper)
+            if float(off.abs().max()) != 0.0:
+                cache.clear()
+                cache[key] = (0, 0, 0)  # triclinic: brute force (the reference's cell path has the same limit)
+            else:
+                cache.clear()
+                cache[key] = tuple(int(torch.floor(b[a, a] / rc)) for a in range(3))
+        return cache[key]
+
     @staticmethod
     def _grow(buf, nbytes, device):
         if buf is None or buf.numel() < nbytes or buf.device != device:
@@ -374,6 +393,11 @@ class TorchMD_Net(nn.Module):
                 q = q.detach().to(device=dev, dtype=torch.float32).contiguous()
                 if q.numel() != n_mol:
                     raise ValueError(f"q must have one entry per molecule ({n_mol}), got {q.numel()}")
+            # neighbour strategy: O(N) cell list for one large orthorhombic periodic system, brute force otherwise
+            grid = (0, 0, 0)
+            if box_mode == 1 and n_mol == 1 and n >= self.cell_list_min_atoms:
+                grid = self._cell_grid(box)
+            L.tmdnet_set_cell_grid(st.handle, *grid)
             nbytes = C.c_size_t(0)
             L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
             st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
