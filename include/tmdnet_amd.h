@@ -142,6 +142,9 @@ const char* tmdnet_profile_category_name(int idx);
  * Names: "X_embed", "X_layer<l>", "x", "phi", "Q", "u0", "G_embed".  Used by the parity tests. */
 int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* out, int64_t numel);
 /* plain dense contraction through the path's MFMA GEMM: C[M,N] = A[M,K] @ W[N,K]^T (+bias); for unit tests */
+/* value + tangent GEMM of the edge MLP (kind 0 plain, 1 silu, 2 silu * rs with rs2 = d rs): C = f(A W^T + b), C2 = d/dd */
+int tmdnet_debug_gemm_dual(void* stream, const float* A, const float* A2, const float* W, const float* bias, float* C, float* C2,
+                           int64_t M, int64_t N, int64_t K, int32_t kind, const float* rs, const float* rs2);
 int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float* bias, float* C, int64_t M, int64_t N,
                       int64_t K, int32_t silu);
 

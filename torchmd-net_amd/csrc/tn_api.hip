@@ -65,11 +65,11 @@ struct FwdBuffers {
   float *phi, *dphi, *C, *dC;
   float *Utab, *Vtab, *Q, *u0, *s0n, *ln0, *xh0, *rstd0, *a1, *h1, *a2, *gates, *UX;
   std::vector<float*> X;                               // L+1
-  std::vector<float*> e1, e2, e3, w, Pn, Mi, D;        // per layer
-  float *he1, *he2, *Xh, *Ch;
+  std::vector<float*> w, dw, Pn, Mi, D;                 // per layer (dw = d w / d d, forward tangent)
+  float *he1, *he2, *te1, *te2, *dQ, *Xh, *Ch;
   float *feat, *lnr, *xhr, *rstdr, *al, *x, *ao, *ea;
   // reverse
-  float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *g_e3, *g_e2, *g_e1, *g_phi, *gC;
+  float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *gd;
   float *gUX, *g_a2, *g_a1, *g_ln0, *g_s0n, *g_u0l, *gA, *g_rhat, *g_delta;
 };
 
@@ -244,6 +244,32 @@ void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ld
   launch_gemm(a, s);
 }
 
+// value + tangent through one weight tile (tn_gemm_dual.hip); rows = pairs (device-side count)
+void gemm_dual(hipStream_t s, int kind, const float* A, const float* A2, int64_t lda, const float* W, const float* bias, float* C,
+               float* C2, int64_t ldc, int M, int N, int K, const float* rs = nullptr, const float* rs2 = nullptr) {
+  GemmArgs a{};
+  a.A = A;
+  a.A2 = A2;
+  a.W[0] = W;
+  a.bias[0] = bias;
+  a.C = C;
+  a.C2 = C2;
+  a.rowscale = rs;
+  a.rowscale2 = rs2;
+  a.lda = lda;
+  a.ldw = K;
+  a.ldc = ldc;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.groups = 1;
+  a.m_dev = g_mdev;
+  a.m_add = g_madd;
+  const double bytes = 4.0 * (2.0 * M * K + (double)N * K + 2.0 * M * N);
+  ProfScope ps_(s, CAT_GEMM_EDGE, 4.0 * M * N * K, bytes);
+  launch_gemm_dual(a, kind, s);
+}
+
 // the three weight matrices act on the channel axis of the 1 + 3 + 5 irreducible components
 // (reference tensornet.py:595-617, 752-754, 808-810): one grouped launch, 9 groups
 void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], float* C, int N, int F, int flags = 0,
@@ -347,16 +373,17 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
   b.UX = c.take<float>(N9);
   for (int l = 0; l <= L; ++l) b.X.push_back(c.take<float>(N9));
   for (int l = 0; l < L; ++l) {
-    b.e1.push_back(c.take<float>(P1 * F));
-    b.e2.push_back(c.take<float>(P1 * 2 * F));
-    b.e3.push_back(c.take<float>(P1 * 3 * F));
     b.w.push_back(c.take<float>(P1 * 3 * F));
+    b.dw.push_back(c.take<float>(bwd ? P1 * 3 * F : 0));
     b.Pn.push_back(c.take<float>(N9));
     b.Mi.push_back(c.take<float>(N9));
     b.D.push_back(c.take<float>(N9));
   }
   b.he1 = c.take<float>(P1 * F);
   b.he2 = c.take<float>(P1 * 2 * F);
+  b.te1 = c.take<float>(bwd ? P1 * F : 0);
+  b.te2 = c.take<float>(bwd ? P1 * 2 * F : 0);
+  b.dQ = c.take<float>(bwd ? P1 * 3 * F : 0);
   b.Xh = c.take<float>(N9);
   b.Ch = c.take<float>(N9);
   b.feat = c.take<float>(N * 3 * F);
@@ -378,11 +405,7 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
     b.gMi = c.take<float>(N9);
     b.gPn = c.take<float>(N9);
     b.gXl = c.take<float>(N9);
-    b.g_e3 = c.take<float>(P1 * 3 * F);
-    b.g_e2 = c.take<float>(P1 * 2 * F);
-    b.g_e1 = c.take<float>(P1 * F);
-    b.g_phi = c.take<float>(P1 * K);
-    b.gC = c.take<float>(P1);
+    b.gd = c.take<float>(P1);
     b.gUX = c.take<float>(N9);
     b.g_a2 = c.take<float>(N * 3 * F);
     b.g_a1 = c.take<float>(N * 2 * F);
@@ -747,7 +770,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
   KR(CAT_ELEMENTWISE, (double)Z * F * 12 + 8.0 * F * F, launch_ztables(W.emb, W.emb2_waT, W.emb2_wbT, W.emb2_b, Z, F, b.Utab, b.Vtab, s));
   EDGE(1);
-  gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);              // distance projections
+  if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K);  // distance projections + d/dd
+  else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
   KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
      launch_embed_scatter(g, N, F, z, b.Utab, b.Vtab, b.Q, b.C, b.u0, b.s0n, s));
   KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s));
@@ -759,10 +783,17 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   for (int l = 0; l < L; ++l) {
     const LayerP& q_ = W.layer[l];
     EDGE(1);
-    gemm(s, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU, b.e1[l], F);
-    gemm(s, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU, b.e2[l], 2 * F);
-    gemm(s, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, b.e3[l], 3 * F,
-         nullptr, 0, b.C);
+    if (want_forces) {
+      // edge MLP with its distance tangent carried forward (dw/dd): the reverse pass then needs no edge GEMM
+      gemm_dual(s, 1, b.phi, b.dphi, K, q_.M1, q_.b1, b.he1, b.te1, F, P1, F, K);
+      gemm_dual(s, 1, b.he1, b.te1, F, q_.M2, q_.b2, b.he2, b.te2, 2 * F, P1, 2 * F, F);
+      gemm_dual(s, 2, b.he2, b.te2, 2 * F, q_.M3, q_.b3, b.w[l], b.dw[l], 3 * F, P1, 3 * F, 2 * F, b.C, b.dC);
+    } else {
+      gemm(s, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU);
+      gemm(s, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU);
+      gemm(s, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, nullptr, 0, nullptr, 0,
+           b.C);
+    }
     KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], b.Xh, N, F, s));
     tensor_linear(s, b.Xh, q_.V, b.Pn[l], N, F);
     KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch, o3, b.Mi[l], b.Ch, s));
@@ -787,19 +818,14 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 4, launch_readout_bwd(b.X[L], b.g_feat, N, F, b.G, s));
     // zero-fills are kernels, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to
     // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
-    launch_fill(b.gC, 0.f, P1, s);
-    launch_fill(b.g_phi, 0.f, (int64_t)P1 * K, s);
+    launch_fill(b.gd, 0.f, P1, s);
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];
       KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch, N, F, b.gD, s));
       tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
       KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch, o3, N, F, b.gMi, b.gPn, s));
       KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
-      KR(CAT_PAIR, Pd * (24 * Fd + 8) + 2 * nodeB, launch_pair_bwd(g, P, F, b.gMi, b.Pn[l], b.e3[l], b.C, b.g_e3, b.gC, s));
-      EDGE(0);
-      gemm(s, b.g_e3, 3 * F, q_.M3T, 3 * F, nullptr, b.g_e2, 2 * F, P, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.e2[l], 2 * F);
-      gemm(s, b.g_e2, 2 * F, q_.M2T, 2 * F, nullptr, b.g_e1, F, P, F, 2 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.e1[l], F);
-      gemm(s, b.g_e1, F, q_.M1T, F, nullptr, b.g_phi, K, P, K, F, GEMM_ACCUM);
+      KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));
       tensor_linear(s, b.gPn, q_.VT, b.gXl, N, F);
       KR(CAT_ELEMENTWISE, 4 * nodeB, launch_norm_bwd(b.X[l], b.gXl, N, F, b.G, s));
     }
@@ -810,11 +836,9 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s));
     tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
-    KR(CAT_PAIR, Pd * (24 * Fd + 8) + Nd * 10 * Fd * 4,
-       launch_embed_bwd_pair(g, P, F, z, b.Utab, b.Vtab, b.Q, b.C, b.gA, b.g_e3 /* gQ reuses g_e3 */, b.gC, b.g_rhat, s));
-    EDGE(0);
-    gemm(s, b.g_e3, 3 * F, W.WdpT, 3 * F, nullptr, b.g_phi, K, P, K, 3 * F, GEMM_ACCUM);
-    KR(CAT_ELEMENTWISE, Pd * (2 * K + 12) * 4, launch_geom(g, P, K, b.gC, b.dC, b.g_phi, b.dphi, b.g_rhat, b.g_delta, s));
+    KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
+       launch_embed_pair_gd(g, P, F, z, b.Utab, b.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s));
+    KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s));
     KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
   }
   NODE();
@@ -908,6 +932,13 @@ int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* 
   if (!src || numel != n) return fail(m, TMDNET_ERR_INVALID, "debug tensor size mismatch: expected " + std::to_string(n));
   HIP_TRY(m, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
   return TMDNET_OK;
+}
+
+int tmdnet_debug_gemm_dual(void* stream, const float* A, const float* A2, const float* W, const float* bias, float* C, float* C2,
+                           int64_t M, int64_t N, int64_t K, int32_t kind, const float* rs, const float* rs2) {
+  g_mdev = nullptr;
+  gemm_dual(reinterpret_cast<hipStream_t>(stream), kind, A, A2, K, W, bias, C, C2, N, (int)M, (int)N, (int)K, rs, rs2);
+  return hipGetLastError() == hipSuccess ? TMDNET_OK : TMDNET_ERR_HIP;
 }
 
 int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float* bias, float* C, int64_t M, int64_t N,

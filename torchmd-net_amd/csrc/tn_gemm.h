@@ -38,9 +38,15 @@ struct GemmArgs {
   // surplus blocks exit at once, so a schedule with data-dependent pair counts needs no host synchronisation.
   const int* m_dev;
   int m_add;
+  // dual (value + tangent) launches, tn_gemm_dual.hip: second A operand, second output, second row vector
+  const float* A2;
+  float* C2;
+  const float* rowscale2;
 };
 
 // launches on `stream`; returns hipError_t as int
 int launch_gemm(const GemmArgs& args, hipStream_t stream);
+// value + d/dd tangent through one weight tile; kind 0: plain, 1: silu, 2: silu * C(d) (rowscale/rowscale2 = C, C')
+int launch_gemm_dual(const GemmArgs& args, int kind, hipStream_t stream);
 
 }  // namespace tn

@@ -116,6 +116,12 @@ void launch_cell_phase1(const Graph& g, const float* pos, const float* box, int 
 void launch_cell_phase2(const Graph& g, int N, float lo, float up, hipStream_t s);
 void launch_permute_z(const Graph& g, const int64_t* z, int N, hipStream_t s);
 
+// ---- per-pair reverse kernels of the forward-tangent formulation (tn_pairgrad.hip)
+void launch_pair_gd(const Graph& g, int Pcap, int F, const float* gMi, const float* Pn, const float* dw, float* gd, hipStream_t s);
+void launch_embed_pair_gd(const Graph& g, int Pcap, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                          const float* dQ, const float* C, const float* dC, const float* gA, float* gd, float* g_rhat, hipStream_t s);
+void launch_geom_gd(const Graph& g, int Pcap, const float* gd, const float* g_rhat, float* g_delta, hipStream_t s);
+
 // ---- 16-byte-per-lane variants (tn_gather.hip), selected by the launchers above when gather_v4_ok(F)
 bool gather_v4_ok(int F);
 void launch_message_v4(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,

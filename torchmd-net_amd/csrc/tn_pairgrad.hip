@@ -1,0 +1,232 @@
+// Per-pair reverse kernels for the forward-tangent formulation of the edge MLP (gfx950).
+//
+// With dw/dd (and dQ/dd) propagated forward by the dual GEMM (tn_gemm_dual.hip), the distance gradient of a pair is
+//     g_d[p] = sum_layers sum_{k,f} g_w[p,k,f] * dw[p,k,f]/dd  +  embedding terms ,
+//     g_w[p,k,f] = sum_{c in k} gM[i,c,f] P[j,c,f] + gM[j,c,f] P[i,c,f]                   
+// so the reverse pass of the edge side is pure gather + reduce: no edge GEMM, no g_w array in HBM.  Channel sums
+// are wave-level xor-shuffle reductions inside the lanes that own a pair (16 bytes per lane when F allows it).
+#include "tn_common.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+static inline int cdivp(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int fthreads_p(int F) {
+  int t = ((F + 63) / 64) * 64;
+  return t > 256 ? 256 : t;
+}
+
+__device__ __forceinline__ float4 pld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float pcomp(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float pgroup_sum(float v, int tpa) {
+  for (int off = tpa >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// sum over all threads of a block (blockDim multiple of 64, <= 256); result valid in thread 0
+__device__ __forceinline__ float pblock_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int nw = blockDim.x >> 6;
+  if (nw == 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < nw; ++w) s += red[w];
+  return s;
+}
+
+// ---- interaction layer: gd[p] += sum_{k,f} g_w * dw
+__global__ __launch_bounds__(256) void k_pair_gd_v4(Graph g, int F, const float* __restrict__ gMi, const float* __restrict__ Pn,
+                                                    const float* __restrict__ dw, float* __restrict__ gd) {
+  const int tpa = F >> 2, ppb = 256 / tpa;
+  const int p = blockIdx.x * ppb + threadIdx.x / tpa;
+  if (p >= g.counts[0] || g.counts[2]) return;
+  const int f = (threadIdx.x % tpa) << 2;
+  const int i = g.pair_i[p], j = g.pair_j[p];
+  const int F9 = 9 * F, F3 = 3 * F;
+  const float* gi = gMi + (int64_t)i * F9 + f;
+  const float* gj = gMi + (int64_t)j * F9 + f;
+  const float* pi = Pn + (int64_t)i * F9 + f;
+  const float* pj = Pn + (int64_t)j * F9 + f;
+  float4 gw[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) gw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const float4 a = pld4(gi + c * F), b = pld4(pj + c * F), cc = pld4(gj + c * F), d = pld4(pi + c * F);
+    float4& o = gw[c == 0 ? 0 : (c < 4 ? 1 : 2)];
+    o.x += a.x * b.x + cc.x * d.x;
+    o.y += a.y * b.y + cc.y * d.y;
+    o.z += a.z * b.z + cc.z * d.z;
+    o.w += a.w * b.w + cc.w * d.w;
+  }
+  float part = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) part += dot4(gw[k], pld4(dw + (int64_t)p * F3 + k * F + f));
+  part = pgroup_sum(part, tpa);
+  if ((threadIdx.x % tpa) == 0) gd[p] += part;
+}
+__global__ void k_pair_gd(Graph g, int F, const float* __restrict__ gMi, const float* __restrict__ Pn, const float* __restrict__ dw,
+                          float* __restrict__ gd) {
+  __shared__ float red[4];
+  const int p = blockIdx.x;
+  if (p >= g.counts[0] || g.counts[2]) return;
+  const int i = g.pair_i[p], j = g.pair_j[p];
+  const int F9 = 9 * F, F3 = 3 * F;
+  float part = 0.f;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float gw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+      gw[type_of(c)] += gMi[(int64_t)i * F9 + c * F + f] * Pn[(int64_t)j * F9 + c * F + f] +
+                        gMi[(int64_t)j * F9 + c * F + f] * Pn[(int64_t)i * F9 + c * F + f];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) part += gw[k] * dw[(int64_t)p * F3 + k * F + f];
+  }
+  part = pblock_sum(part, red);
+  if (threadIdx.x == 0) gd[p] += part;
+}
+void launch_pair_gd(const Graph& g, int Pcap, int F, const float* gMi, const float* Pn, const float* dw, float* gd, hipStream_t s) {
+  if (Pcap <= 0) return;
+  if (gather_v4_ok(F)) {
+    const int ppb = 256 / (F >> 2);
+    hipLaunchKernelGGL(k_pair_gd_v4, dim3(cdivp(Pcap, ppb)), dim3(256), 0, s, g, F, gMi, Pn, dw, gd);
+  } else {
+    hipLaunchKernelGGL(k_pair_gd, dim3(Pcap), dim3(fthreads_p(F)), 0, s, g, F, gMi, Pn, dw, gd);
+  }
+}
+
+// ---- embedding: W_c = C(d) Z Q_c(d):  gd[p] += sum_c s_c (C' Q_c + C dQ_c) ;  g_rhat[p] as before
+// s_c = Z1 gW_c(i<-j) + Z2 gW_c(j<-i)  (both directions of the pair), gA = gradients wrt (I0, v[3], T[6]) per atom
+template <bool V4>
+__device__ __forceinline__ void embed_pair_channel(float Z1, float Z2, float q0, float q1, float q2, float dq0, float dq1, float dq2,
+                                                   const float ai[10], const float aj[10], float r0, float r1, float r2, float cp,
+                                                   float dcp, float acc[4]) {
+  const float gW1_1 = ai[1] * r0 + ai[2] * r1 + ai[3] * r2;
+  const float gW1_2 = -(aj[1] * r0 + aj[2] * r1 + aj[3] * r2);
+  const float gW2_1 = ai[4] * r0 * r0 + ai[5] * r0 * r1 + ai[6] * r0 * r2 + ai[7] * r1 * r1 + ai[8] * r1 * r2 + ai[9] * r2 * r2;
+  const float gW2_2 = aj[4] * r0 * r0 + aj[5] * r0 * r1 + aj[6] * r0 * r2 + aj[7] * r1 * r1 + aj[8] * r1 * r2 + aj[9] * r2 * r2;
+  const float s0 = Z1 * ai[0] + Z2 * aj[0], s1 = Z1 * gW1_1 + Z2 * gW1_2, s2 = Z1 * gW2_1 + Z2 * gW2_2;
+  acc[0] += dcp * (q0 * s0 + q1 * s1 + q2 * s2) + cp * (dq0 * s0 + dq1 * s1 + dq2 * s2);
+  const float W1_1 = cp * Z1 * q1, W2_1 = cp * Z1 * q2, W1_2 = cp * Z2 * q1, W2_2 = cp * Z2 * q2;
+  const float di0 = 2.f * ai[4] * r0 + ai[5] * r1 + ai[6] * r2, dj0 = 2.f * aj[4] * r0 + aj[5] * r1 + aj[6] * r2;
+  const float di1 = ai[5] * r0 + 2.f * ai[7] * r1 + ai[8] * r2, dj1 = aj[5] * r0 + 2.f * aj[7] * r1 + aj[8] * r2;
+  const float di2 = ai[6] * r0 + ai[8] * r1 + 2.f * ai[9] * r2, dj2 = aj[6] * r0 + aj[8] * r1 + 2.f * aj[9] * r2;
+  acc[1] += ai[1] * W1_1 - aj[1] * W1_2 + di0 * W2_1 + dj0 * W2_2;
+  acc[2] += ai[2] * W1_1 - aj[2] * W1_2 + di1 * W2_1 + dj1 * W2_2;
+  acc[3] += ai[3] * W1_1 - aj[3] * W1_2 + di2 * W2_1 + dj2 * W2_2;
+}
+
+__global__ __launch_bounds__(256) void k_embed_pair_gd_v4(Graph g, int F, const int64_t* __restrict__ z, const float* __restrict__ Utab,
+                                                          const float* __restrict__ Vtab, const float* __restrict__ Q,
+                                                          const float* __restrict__ dQ, const float* __restrict__ C,
+                                                          const float* __restrict__ dC, const float* __restrict__ gA,
+                                                          float* __restrict__ gd, float* __restrict__ g_rhat) {
+  const int tpa = F >> 2, ppb = 256 / tpa;
+  const int p = blockIdx.x * ppb + threadIdx.x / tpa;
+  if (p >= g.counts[0] || g.counts[2]) return;
+  const int f = (threadIdx.x % tpa) << 2;
+  const int i = g.pair_i[p], j = g.pair_j[p];
+  const int64_t zi = z[i], zj = z[j];
+  const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
+  const float cp = C[p], dcp = dC[p];
+  const int F3 = 3 * F, F10 = 10 * F;
+  const float4 Ui = pld4(Utab + zi * F + f), Vi = pld4(Vtab + zi * F + f), Uj = pld4(Utab + zj * F + f), Vj = pld4(Vtab + zj * F + f);
+  const float* qp = Q + (int64_t)p * F3 + f;
+  const float* dqp = dQ + (int64_t)p * F3 + f;
+  const float4 q0v = pld4(qp), q1v = pld4(qp + F), q2v = pld4(qp + 2 * F);
+  const float4 d0v = pld4(dqp), d1v = pld4(dqp + F), d2v = pld4(dqp + 2 * F);
+  float4 aiv[10], ajv[10];
+#pragma unroll
+  for (int c = 0; c < 10; ++c) {
+    aiv[c] = pld4(gA + (int64_t)i * F10 + c * F + f);
+    ajv[c] = pld4(gA + (int64_t)j * F10 + c * F + f);
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float ai[10], aj[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      ai[c] = pcomp(aiv[c], k);
+      aj[c] = pcomp(ajv[c], k);
+    }
+    embed_pair_channel<true>(pcomp(Ui, k) + pcomp(Vj, k), pcomp(Uj, k) + pcomp(Vi, k), pcomp(q0v, k), pcomp(q1v, k), pcomp(q2v, k),
+                             pcomp(d0v, k), pcomp(d1v, k), pcomp(d2v, k), ai, aj, r0, r1, r2, cp, dcp, acc);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = pgroup_sum(acc[k], tpa);
+  if ((threadIdx.x % tpa) == 0) {
+    gd[p] += acc[0];
+    g_rhat[p * 3] = acc[1];
+    g_rhat[p * 3 + 1] = acc[2];
+    g_rhat[p * 3 + 2] = acc[3];
+  }
+}
+__global__ void k_embed_pair_gd(Graph g, int F, const int64_t* __restrict__ z, const float* __restrict__ Utab,
+                                const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ dQ,
+                                const float* __restrict__ C, const float* __restrict__ dC, const float* __restrict__ gA,
+                                float* __restrict__ gd, float* __restrict__ g_rhat) {
+  __shared__ float red[4];
+  const int p = blockIdx.x;
+  if (p >= g.counts[0] || g.counts[2]) return;
+  const int i = g.pair_i[p], j = g.pair_j[p];
+  const int64_t zi = z[i], zj = z[j];
+  const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
+  const float cp = C[p], dcp = dC[p];
+  const int F3 = 3 * F, F10 = 10 * F;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float ai[10], aj[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      ai[c] = gA[(int64_t)i * F10 + c * F + f];
+      aj[c] = gA[(int64_t)j * F10 + c * F + f];
+    }
+    const float* qp = Q + (int64_t)p * F3 + f;
+    const float* dqp = dQ + (int64_t)p * F3 + f;
+    embed_pair_channel<false>(Utab[zi * F + f] + Vtab[zj * F + f], Utab[zj * F + f] + Vtab[zi * F + f], qp[0], qp[F], qp[2 * F], dqp[0],
+                              dqp[F], dqp[2 * F], ai, aj, r0, r1, r2, cp, dcp, acc);
+  }
+  float tot[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tot[k] = pblock_sum(acc[k], red);
+  if (threadIdx.x == 0) {
+    gd[p] += tot[0];
+    g_rhat[p * 3] = tot[1];
+    g_rhat[p * 3 + 1] = tot[2];
+    g_rhat[p * 3 + 2] = tot[3];
+  }
+}
+void launch_embed_pair_gd(const Graph& g, int Pcap, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                          const float* dQ, const float* C, const float* dC, const float* gA, float* gd, float* g_rhat, hipStream_t s) {
+  if (Pcap <= 0) return;
+  if (gather_v4_ok(F)) {
+    const int ppb = 256 / (F >> 2);
+    hipLaunchKernelGGL(k_embed_pair_gd_v4, dim3(cdivp(Pcap, ppb)), dim3(256), 0, s, g, F, z, Utab, Vtab, Q, dQ, C, dC, gA, gd, g_rhat);
+  } else {
+    hipLaunchKernelGGL(k_embed_pair_gd, dim3(Pcap), dim3(fthreads_p(F)), 0, s, g, F, z, Utab, Vtab, Q, dQ, C, dC, gA, gd, g_rhat);
+  }
+}
+
+// g_delta = (g_r - (g_r . r) r) / d + g_d r     (reference neighbor_utils.py:11-46; zero for d = 0)
+__global__ void k_geom_gd(Graph g, const float* __restrict__ gd, const float* __restrict__ g_rhat, float* __restrict__ g_delta) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= g.counts[0] || g.counts[2]) return;
+  const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
+  const float d = g.pd[p];
+  const float inv = d > 0.f ? 1.0f / d : 0.f;
+  const float a0 = g_rhat[p * 3], a1 = g_rhat[p * 3 + 1], a2 = g_rhat[p * 3 + 2];
+  const float dot = a0 * r0 + a1 * r1 + a2 * r2;
+  const float s = gd[p];
+  g_delta[p * 3] = (a0 - dot * r0) * inv + s * r0;
+  g_delta[p * 3 + 1] = (a1 - dot * r1) * inv + s * r1;
+  g_delta[p * 3 + 2] = (a2 - dot * r2) * inv + s * r2;
+}
+void launch_geom_gd(const Graph& g, int Pcap, const float* gd, const float* g_rhat, float* g_delta, hipStream_t s) {
+  if (Pcap <= 0) return;
+  hipLaunchKernelGGL(k_geom_gd, dim3(cdivp(Pcap, 256)), dim3(256), 0, s, g, gd, g_rhat, g_delta);
+}
+
+}  // namespace tn

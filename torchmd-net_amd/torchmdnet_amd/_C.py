@@ -69,6 +69,7 @@ def lib():
     L.tmdnet_profile_category_name.argtypes = [C.c_int]
     L.tmdnet_profile_category_name.restype = C.c_char_p
     L.tmdnet_debug_tensor.argtypes = [vp, vp, C.c_char_p, vp, i64]
+    L.tmdnet_debug_gemm_dual.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp, vp]
     L.tmdnet_debug_gemm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32]
     for name in declared_symbols():
         fn = getattr(L, name)
