@@ -8,7 +8,7 @@ L = _C.lib()
 P = 193710
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr())
-for (M, N, K, kind) in [(P, 384, 256, 2), (P, 256, 128, 1), (P, 128, 32, 1), (P, 384, 32, 0), (671, 384, 256, 2)]:
+for (M, N, K, kind) in [(P // 4, 384, 1024, 2), (P // 8, 384, 2048, 2), (P, 128, 256, 2), (P, 384, 256, 2), (P, 256, 128, 1), (P, 128, 32, 1), (P, 384, 32, 0), (671, 384, 256, 2)]:
     A = torch.randn(M, K, device="cuda"); A2 = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.05
     b = torch.randn(N, device="cuda"); rs = torch.rand(M, device="cuda"); rs2 = torch.randn(M, device="cuda")
     C1 = torch.empty(M, N, device="cuda"); C2 = torch.empty(M, N, device="cuda")

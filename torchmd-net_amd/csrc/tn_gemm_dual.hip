@@ -13,6 +13,7 @@
 // Kernel shape: block = 4 waves side by side in N (wave tile 128 x 32): LDS rows 0..63 hold the A tile, rows
 // 64..127 the tangent tile of the SAME 64 global rows, so accumulators mi and mi+2 of a lane are e and r of one
 // output element.  A 32x32 split-K variant (4 waves split K, two accumulators) serves small row counts.
+#include <cstdio>
 #include <cstdlib>
 
 #include "tn_common.h"
@@ -22,8 +23,6 @@ namespace tn {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int DBK = 32;
-constexpr int DLD = DBK + 4;
 
 enum DualKind : int {
   DUAL_PLAIN = 0,  // C = e ; C2 = r
@@ -68,9 +67,14 @@ __device__ __forceinline__ float4 dload4(const float* __restrict__ base, int64_t
   return v;
 }
 
-template <int KIND>
-__global__ __launch_bounds__(256) void k_gemm_dual(GemmArgs a, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) float smem[(128 + 128) * DLD];
+template <int KIND, int DBK, int OCC, int PRIO>
+__global__ __launch_bounds__(256, OCC) void k_gemm_dual(GemmArgs a, int tiles_m, int tiles_n) {
+  constexpr int DLD = DBK + 4;          // row stride in floats: 36 / 68 -> conflict-free ds_read_b128
+  constexpr int NV = 128 * DBK / 4 / 256;  // float4 per thread per panel
+  constexpr int CPR = DBK / 4;          // float4 chunks per row
+  constexpr int NBUF = (PRIO & 8) ? 2 : 1;  // PRIO&8: LDS double buffer, one barrier per k-step
+  constexpr int TILE = (128 + 128) * DLD;
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * TILE];
   float* As = smem;               // rows 0..63: A tile, rows 64..127: tangent tile
   float* Bs = smem + 128 * DLD;   // 128 weight rows
   // XCD-aware bijective remap, n-tiles of one row panel consecutive
@@ -102,51 +106,81 @@ __global__ __launch_bounds__(256) void k_gemm_dual(GemmArgs a, int tiles_m, int 
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
 
-  float4 ra[4], rb[4];
+  float4 ra[NV], rb[NV];
   const int nk = (K + DBK - 1) / DBK;
+  // block-uniform fast path: whole tile in range and 16-byte aligned -> unguarded float4 loads with
+  // per-thread base pointers hoisted out of the k loop
+  const bool full = a_vec && w_vec && (m0 + 64 <= M) && (n0 + 128 <= N) && (K % DBK == 0);
+  const float* pa[NV];
+  const float* pb[NV];
+#pragma unroll
+  for (int r = 0; r < NV; ++r) {
+    const int idx = tid + r * 256;
+    const int row = idx / CPR, kc = (idx % CPR) << 2;
+    const int ar = (m0 + (row & 63) < M) ? m0 + (row & 63) : 0, br = (n0 + row < N) ? n0 + row : 0;
+    pa[r] = (row < 64 ? A : A2) + (int64_t)ar * a.lda + kc;
+    pb[r] = W + (int64_t)br * a.ldw + kc;
+  }
   auto fetch = [&](int kt) {
     const int k0 = kt * DBK;
+    if (full) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < NV; ++r) {
+        ra[r] = *reinterpret_cast<const float4*>(pa[r] + k0);
+        rb[r] = *reinterpret_cast<const float4*>(pb[r] + k0);
+      }
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
       const int idx = tid + r * 256;
-      const int row = idx >> 3, k = k0 + ((idx & 7) << 2);
+      const int row = idx / CPR, k = k0 + ((idx % CPR) << 2);
       ra[r] = dload4(row < 64 ? A : A2, a.lda, m0 + (row & 63), M, k, K, a_vec);
       rb[r] = dload4(W, a.ldw, n0 + row, N, k, K, w_vec);
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](int buf) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NV; ++r) {
       const int idx = tid + r * 256;
-      const int off = (idx >> 3) * DLD + ((idx & 7) << 2);
+      const int off = buf * TILE + (idx / CPR) * DLD + ((idx % CPR) << 2);
       *reinterpret_cast<float4*>(&As[off]) = ra[r];
       *reinterpret_cast<float4*>(&Bs[off]) = rb[r];
     }
   };
   fetch(0);
-  stash();
+  stash(0);
   __syncthreads();
   const int arow = lane & 31, brow = wave * 32 + (lane & 31), koff = (lane >> 5) << 2;
+  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
+    const bool more = (PRIO & 2) ? false : (kt + 1 < nk);  // PRIO&2: ablation, no loads / LDS writes in the loop
     if (more) fetch(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < DBK / 8; ++kk) {
       float4 af[4];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const float4*>(&As[(arow + mi * 32) * DLD + kk * 8 + koff]);
-      const float4 bf = *reinterpret_cast<const float4*>(&Bs[brow * DLD + kk * 8 + koff]);
+      for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const float4*>(&As[cur * TILE + (arow + mi * 32) * DLD + kk * 8 + koff]);
+      const float4 bf = *reinterpret_cast<const float4*>(&Bs[cur * TILE + brow * DLD + kk * 8 + koff]);
       const float* afp = reinterpret_cast<const float*>(af);
       const float* bfp = reinterpret_cast<const float*>(&bf);
+      if (PRIO & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(afp[mi * 4 + tt], bfp[tt], acc[mi], 0, 0, 0);
+      if (PRIO & 1) __builtin_amdgcn_s_setprio(0);
     }
-    __syncthreads();
-    if (more) {
-      stash();
+    if (NBUF == 2) {
+      if (more) stash(cur ^ 1);  // the other buffer was last read one k-step ago, before the previous barrier
       __syncthreads();
+      cur ^= 1;
+    } else {
+      if (!(PRIO & 4)) __syncthreads();
+      if (more) {
+        stash(0);
+        __syncthreads();
+      }
     }
   }
   const int col = n0 + wave * 32 + (lane & 31);
@@ -243,7 +277,9 @@ static int launch_dual_kind(const GemmArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((k_gemm_dual_skinny<KIND>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
   } else {
     const int tiles_m = (a.M + 63) / 64, tiles_n = (a.N + 127) / 128;
-    hipLaunchKernelGGL((k_gemm_dual<KIND>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
+    // <BK 32, 3 blocks/CU> measured best on MI355X (profiles/r01_notes.md: BK 64, LDS double buffering, s_setprio and
+    // 2 / 4 blocks per CU were all slower)
+    hipLaunchKernelGGL((k_gemm_dual<KIND, 32, 3, 0>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, a, tiles_m, tiles_n);
   }
   return (int)hipGetLastError();
 }
