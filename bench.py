@@ -114,12 +114,18 @@ def cpu_baseline(args_dict, state_dict, budget_s=20.0):
                       f"(reference PyTorch CPU algorithm, autograd forces), {el:.1f} s"}
 
 
+# HIP kernel behind each profiled class (rocprofv3 names; profiles/r01_kernel_stats.csv)
+KERNEL_OF = {"gemm_edge": "k_gemm_dual", "gemm_node": "k_gemm_nt", "message": "k_message / k_message_adjoint",
+             "pair_bwd": "k_pair_gd_v4 / k_embed_pair_gd_v4"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-md", action="store_true", help="skip the single-system HIP-graph latency leg (profiling runs)")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-class timing table to this file")
     a = ap.parse_args()
 
@@ -196,7 +202,7 @@ def main():
         avg_s = timed["ms"] * 1e-3 / launches
         if timed["flops"] > 0:
             ach = timed["flops"] / launches / avg_s / 1e12
-            roof = {"bound": "mfma", "kernel": f"{dominant} (k_gemm_nt, v_mfma_f32_32x32x2_f32)", "achieved": ach,
+            roof = {"bound": "mfma", "kernel": f"{dominant} ({KERNEL_OF.get(dominant, dominant)}, v_mfma_f32_32x32x2_f32)", "achieved": ach,
                     "peak": PEAK["mfma_f32_tflops"], "unit": "TFLOP/s", "frac": ach / PEAK["mfma_f32_tflops"]}
         else:
             ach = timed["bytes"] / launches / avg_s / 1e9
@@ -229,7 +235,7 @@ def main():
                        "parallelism": f"molecule-sharded x{world}, RCCL all-reduce of energies"},
             "roofline": roof,
         }
-        if world == 1:
+        if world == 1 and not a.no_md:
             out["md_single_system"] = md_latency(model, args_dict, dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args_dict, model.state_dict())

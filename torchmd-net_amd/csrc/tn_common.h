@@ -146,6 +146,14 @@ __device__ __forceinline__ float frob2(const M3& x) {
 __device__ __forceinline__ int type_of(int c) { return c == 0 ? 0 : (c < 4 ? 1 : 2); }
 
 // wave-level sum over 64 lanes (all lanes get the result)
+// Workgroups are dealt to the 8 XCDs round-robin by linear id and each XCD has a private 4 MB L2.  For kernels
+// whose block b works on item b (an atom row, a tile of pairs), neighbouring items share gathered rows (same
+// molecule / cell), so give every XCD one CONTIGUOUS chunk of the items: bijective map block id -> item id.
+__device__ __forceinline__ int xcd_chunk(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

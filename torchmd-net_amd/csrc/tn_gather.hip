@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_message_v4(Graph g, int N, int F, const
                                                     const int64_t* __restrict__ batch, int o3, float* __restrict__ out0,
                                                     float* __restrict__ out1) {
   const int tpa = F >> 2, apb = 256 / tpa;
-  const int i = blockIdx.x * apb + threadIdx.x / tpa;
+  const int i = xcd_chunk(blockIdx.x, gridDim.x) * apb + threadIdx.x / tpa;
   if (i >= N || g.counts[2]) return;
   const int f = (threadIdx.x % tpa) << 2;
   float4 m[9];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_v4(Graph g, int P, int F, cons
                                                      const float* __restrict__ C, float* __restrict__ g_e3,
                                                      float* __restrict__ gC) {
   const int tpa = F >> 2, ppb = 256 / tpa;
-  const int p = blockIdx.x * ppb + threadIdx.x / tpa;
+  const int p = xcd_chunk(blockIdx.x, gridDim.x) * ppb + threadIdx.x / tpa;
   if (p >= g.counts[0] || g.counts[2]) return;  // grid sized by capacity, true count on the device
   const int f = (threadIdx.x % tpa) << 2;
   const int i = g.pair_i[p], j = g.pair_j[p];
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_embed_scatter_v4(Graph g, int N, int F,
                                                           const float* __restrict__ Q, const float* __restrict__ C,
                                                           float* __restrict__ u0, float* __restrict__ s0n) {
   const int tpa = F >> 2, apb = 256 / tpa;
-  const int i = blockIdx.x * apb + threadIdx.x / tpa;
+  const int i = xcd_chunk(blockIdx.x, gridDim.x) * apb + threadIdx.x / tpa;
   if (i >= N || g.counts[2]) return;
   const int f = (threadIdx.x % tpa) << 2;
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd_pair_v4(Graph g, int P, int F
                                                            const float* __restrict__ gA, float* __restrict__ gQ,
                                                            float* __restrict__ gC, float* __restrict__ g_rhat) {
   const int tpa = F >> 2, ppb = 256 / tpa;
-  const int p = blockIdx.x * ppb + threadIdx.x / tpa;
+  const int p = xcd_chunk(blockIdx.x, gridDim.x) * ppb + threadIdx.x / tpa;
   if (p >= g.counts[0] || g.counts[2]) return;  // grid sized by capacity, true count on the device
   const int f = (threadIdx.x % tpa) << 2;
   const int i = g.pair_i[p], j = g.pair_j[p];

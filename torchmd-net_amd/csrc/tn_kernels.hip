@@ -341,11 +341,15 @@ void launch_ztables(const float* emb, const float* WaT, const float* WbT, const 
   hipLaunchKernelGGL(k_ztables, dim3(Z), dim3(fthreads(F)), 0, s, emb, WaT, WbT, b2, Z, F, Utab, Vtab);
 }
 
+static bool sweep_v4() {
+  static const bool on = getenv("TMDNET_V4_SWEEP") != nullptr;  // developer switch (profiles/r01_notes.md)
+  return on;
+}
 // block = one atom, thread = channel.  I0 = sum W0 ; v = sum W1 r ; T = sum W2 r r^T ; u0 = (I0, v, T - tr(T)/3)
 __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict__ z, const float* __restrict__ Utab,
                                 const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ C,
                                 float* __restrict__ u0, float* __restrict__ s0n) {
-  const int i = blockIdx.x;
+  const int i = xcd_chunk(blockIdx.x, gridDim.x);
   if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   const int64_t zi = z[i];
@@ -382,7 +386,7 @@ void launch_embed_scatter(const Graph& g, int N, int F, const int64_t* z, const 
                           const float* C, float* u0, float* s0n, hipStream_t s) {
   if (N <= 0) return;
   // measured on MI355X (profiles/r01_notes.md): the 16-byte CSR sweep is slower than one-channel-per-lane here (scalar edge loads, 4x the waves)
-  if (false && gather_v4_ok(F)) return launch_embed_scatter_v4(g, N, F, z, Utab, Vtab, Q, C, u0, s0n, s);
+  if (sweep_v4() && gather_v4_ok(F)) return launch_embed_scatter_v4(g, N, F, z, Utab, Vtab, Q, C, u0, s0n, s);
   hipLaunchKernelGGL(k_embed_scatter, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
 }
 
@@ -504,7 +508,7 @@ __device__ __forceinline__ void csr_gather(const Graph& g, int i, int F, int f, 
 __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ Pn,
                           const float* __restrict__ q, const int64_t* __restrict__ batch, int o3, float* __restrict__ Mi,
                           float* __restrict__ Ch) {
-  const int i = blockIdx.x;
+  const int i = xcd_chunk(blockIdx.x, gridDim.x);
   if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
   const float kap = kappa_of(q, batch, i);
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
@@ -525,7 +529,7 @@ __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, co
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
                     float* Mi, float* Ch, hipStream_t s) {
   if (N <= 0) return;
-  if (false && gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
+  if (sweep_v4() && gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
 }
 
@@ -533,7 +537,7 @@ void launch_message(const Graph& g, int N, int F, const float* w, const float* s
 // same CSR sweep with the message gradient as source:  gPn[i] += sum_e w * gMi[col(e)]
 __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ gMi,
                                   float* __restrict__ gPn) {
-  const int i = blockIdx.x;
+  const int i = xcd_chunk(blockIdx.x, gridDim.x);
   if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
     float a[9];
@@ -545,7 +549,7 @@ __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict
 }
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
   if (N <= 0) return;
-  if (false && gather_v4_ok(F)) return launch_message_adjoint_v4(g, N, F, w, gMi, gPn, s);
+  if (sweep_v4() && gather_v4_ok(F)) return launch_message_adjoint_v4(g, N, F, w, gMi, gPn, s);
   hipLaunchKernelGGL(k_message_adjoint, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, gMi, gPn);
 }
 

@@ -40,7 +40,7 @@ __device__ __forceinline__ float pblock_sum(float v, float* red) {
 __global__ __launch_bounds__(256) void k_pair_gd_v4(Graph g, int F, const float* __restrict__ gMi, const float* __restrict__ Pn,
                                                     const float* __restrict__ dw, float* __restrict__ gd) {
   const int tpa = F >> 2, ppb = 256 / tpa;
-  const int p = blockIdx.x * ppb + threadIdx.x / tpa;
+  const int p = xcd_chunk(blockIdx.x, gridDim.x) * ppb + threadIdx.x / tpa;
   if (p >= g.counts[0] || g.counts[2]) return;
   const int f = (threadIdx.x % tpa) << 2;
   const int i = g.pair_i[p], j = g.pair_j[p];
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_pair_gd_v4(Graph g, int F, const float*
 __global__ void k_pair_gd(Graph g, int F, const float* __restrict__ gMi, const float* __restrict__ Pn, const float* __restrict__ dw,
                           float* __restrict__ gd) {
   __shared__ float red[4];
-  const int p = blockIdx.x;
+  const int p = xcd_chunk(blockIdx.x, gridDim.x);
   if (p >= g.counts[0] || g.counts[2]) return;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const int F9 = 9 * F, F3 = 3 * F;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_embed_pair_gd_v4(Graph g, int F, const 
                                                           const float* __restrict__ dC, const float* __restrict__ gA,
                                                           float* __restrict__ gd, float* __restrict__ g_rhat) {
   const int tpa = F >> 2, ppb = 256 / tpa;
-  const int p = blockIdx.x * ppb + threadIdx.x / tpa;
+  const int p = xcd_chunk(blockIdx.x, gridDim.x) * ppb + threadIdx.x / tpa;
   if (p >= g.counts[0] || g.counts[2]) return;
   const int f = (threadIdx.x % tpa) << 2;
   const int i = g.pair_i[p], j = g.pair_j[p];
@@ -169,7 +169,7 @@ __global__ void k_embed_pair_gd(Graph g, int F, const int64_t* __restrict__ z, c
                                 const float* __restrict__ C, const float* __restrict__ dC, const float* __restrict__ gA,
                                 float* __restrict__ gd, float* __restrict__ g_rhat) {
   __shared__ float red[4];
-  const int p = blockIdx.x;
+  const int p = xcd_chunk(blockIdx.x, gridDim.x);
   if (p >= g.counts[0] || g.counts[2]) return;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const int64_t zi = z[i], zj = z[j];
