@@ -39,6 +39,7 @@ struct DevParams {
   const float *lnr_w, *lnr_b, *Lin, *bLin, *LinT;
   const float *O1, *bO1, *O1T, *O2, *bO2;
   const float* atomref;
+  const float *Utab, *Vtab;  // per-type pair-embedding tables (k_ztables at finalize)
   float mean, std;
 };
 
@@ -63,7 +64,7 @@ struct Carver {
 
 struct FwdBuffers {
   float *phi, *dphi, *C, *dC;
-  float *Utab, *Vtab, *Q, *u0, *s0n, *ln0, *xh0, *rstd0, *a1, *h1, *a2, *gates, *UX;
+  float *Q, *u0, *s0n, *ln0, *xh0, *rstd0, *a1, *h1, *a2, *gates, *UX;
   std::vector<float*> X;                               // L+1
   std::vector<float*> w, dw, Pn, Mi, D;                 // per layer (dw = d w / d d, forward tangent)
   float *he1, *he2, *te1, *te2, *dQ, *Xh, *Ch;
@@ -358,8 +359,6 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
   b.dphi = c.take<float>(P1 * K);
   b.C = c.take<float>(P1);
   b.dC = c.take<float>(P1);
-  b.Utab = c.take<float>(Z * F);
-  b.Vtab = c.take<float>(Z * F);
   b.Q = c.take<float>(P1 * 3 * F);
   b.u0 = c.take<float>(N9);
   b.s0n = c.take<float>(N * F);
@@ -543,6 +542,9 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   put("O2", h[O + "2.weight"]);
   put("bO2", h[O + "2.bias"]);
   if (m->hp.has_atomref) put("atomref", h["atomref"]);
+  // per-type tables U[z], V[z] of the pair embedding (weights only): filled once below by k_ztables
+  put("Utab", std::vector<float>((size_t)m->hp.max_z * F, 0.f));
+  put("Vtab", std::vector<float>((size_t)m->hp.max_z * F, 0.f));
 
   if (m->dev) {
     HIP_TRY(m, hipFree(m->dev));
@@ -606,6 +608,10 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   P.atomref = m->hp.has_atomref ? D("atomref") : nullptr;
   P.mean = h["mean"][0];
   P.std = h["std"][0];
+  P.Utab = m->dev + off.at("Utab");
+  P.Vtab = m->dev + off.at("Vtab");
+  launch_ztables(P.emb, P.emb2_waT, P.emb2_wbT, P.emb2_b, m->hp.max_z, F, m->dev + off.at("Utab"), m->dev + off.at("Vtab"), nullptr);
+  HIP_TRY(m, hipStreamSynchronize(nullptr));
   m->finalized = true;
   return TMDNET_OK;
 }
@@ -768,12 +774,11 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   KR(CAT_ELEMENTWISE, Pd * (2 * K + 3) * 4, launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s));
   // ---- embedding
   // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
-  KR(CAT_ELEMENTWISE, (double)Z * F * 12 + 8.0 * F * F, launch_ztables(W.emb, W.emb2_waT, W.emb2_wbT, W.emb2_b, Z, F, b.Utab, b.Vtab, s));
   EDGE(1);
   if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K);  // distance projections + d/dd
   else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
   KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
-     launch_embed_scatter(g, N, F, z, b.Utab, b.Vtab, b.Q, b.C, b.u0, b.s0n, s));
+     launch_embed_scatter(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.u0, b.s0n, s));
   KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s));
   NODE();
   gemm(s, b.ln0, F, W.L1, F, W.bL1, b.h1, 2 * F, N, 2 * F, F, GEMM_ACT_SILU, b.a1, 2 * F);
@@ -837,7 +842,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
     KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
-       launch_embed_pair_gd(g, P, F, z, b.Utab, b.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s));
+       launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s));
     KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s));
     KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
   }

@@ -96,49 +96,46 @@ __global__ void k_nbr_count(Graph g, const float* __restrict__ pos, const int64_
   g.ntot[i] = nt;
 }
 
-// single-block exclusive scan of nlow -> pairptr and ntot -> rowptr; publishes P, E and the overflow flag
+// single-block exclusive scan of nlow -> pairptr and ntot -> rowptr; publishes P, E and the overflow flag.
+// Each thread owns one contiguous chunk (all its loads are independent and in flight together), the 1024 chunk
+// sums are scanned through LDS, then the chunk is re-read (cache hit) and its prefixes written.
 __global__ __launch_bounds__(1024) void k_scan_counts(Graph g, int N) {
   __shared__ int wsum[2][16];
-  __shared__ int carry[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry[0] = carry[1] = 0;
-  __syncthreads();
-  for (int base = 0; base < N; base += 1024) {
-    int i = base + tid;
-    int a = i < N ? g.nlow[i] : 0;
-    int b = i < N ? g.ntot[i] : 0;
-    int ia = a, ib = b;  // inclusive wave scans
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      int ta = __shfl_up(ia, off, 64), tb = __shfl_up(ib, off, 64);
-      if (lane >= off) {
-        ia += ta;
-        ib += tb;
-      }
-    }
-    if (lane == 63) {
-      wsum[0][wave] = ia;
-      wsum[1][wave] = ib;
-    }
-    __syncthreads();
-    int oa = carry[0], ob = carry[1];
-    for (int w = 0; w < wave; ++w) {
-      oa += wsum[0][w];
-      ob += wsum[1][w];
-    }
-    if (i < N) {
-      g.pairptr[i] = oa + ia - a;
-      g.rowptr[i] = ob + ib - b;
-    }
-    __syncthreads();
-    if (tid == 1023) {
-      carry[0] = oa + ia;
-      carry[1] = ob + ib;
-    }
-    __syncthreads();
+  const int chunk = (N + 1023) >> 10;
+  const int b0 = min(tid * chunk, N), b1 = min(b0 + chunk, N);
+  int a = 0, b = 0;
+  for (int i = b0; i < b1; ++i) {
+    a += g.nlow[i];
+    b += g.ntot[i];
   }
-  if (tid == 0) {
-    int P = carry[0], E = carry[1];
+  int ia = a, ib = b;  // inclusive wave scans of the chunk sums
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int ta = __shfl_up(ia, off, 64), tb = __shfl_up(ib, off, 64);
+    if (lane >= off) {
+      ia += ta;
+      ib += tb;
+    }
+  }
+  if (lane == 63) {
+    wsum[0][wave] = ia;
+    wsum[1][wave] = ib;
+  }
+  __syncthreads();
+  int oa = ia - a, ob = ib - b;
+  for (int w = 0; w < wave; ++w) {
+    oa += wsum[0][w];
+    ob += wsum[1][w];
+  }
+  for (int i = b0; i < b1; ++i) {
+    g.pairptr[i] = oa;
+    g.rowptr[i] = ob;
+    oa += g.nlow[i];
+    ob += g.ntot[i];
+  }
+  if (tid == 1023) {
+    const int P = oa, E = ob;  // the last thread's running totals are the grand totals
     g.pairptr[N] = P;
     g.rowptr[N] = E;
     g.counts[0] = P;
@@ -985,27 +982,39 @@ void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC,
 }
 
 // F_i = - sum_{e in row(i)} sign(e) * g_delta[pair(e)]     (no atomics: CSR gather)
-__global__ void k_force_gather(Graph g, int N, const float* __restrict__ g_delta, const int* __restrict__ perm,
-                               float* __restrict__ forces) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N || g.counts[2]) return;
+// 16 lanes per atom stride over the row's edges; fixed-order shuffle tree (deterministic)
+__global__ __launch_bounds__(256) void k_force_gather(Graph g, int N, const float* __restrict__ g_delta, const int* __restrict__ perm,
+                                                      float* __restrict__ forces) {
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const bool live = i < N && !g.counts[2];
   float fx = 0.f, fy = 0.f, fz = 0.f;
-  for (int e = g.rowptr[i]; e < g.rowptr[i + 1]; ++e) {
-    const float sg = g.esign[e];
-    if (sg == 0.f) continue;
-    const int p = g.epair[e];
-    fx -= sg * g_delta[p * 3];
-    fy -= sg * g_delta[p * 3 + 1];
-    fz -= sg * g_delta[p * 3 + 2];
+  if (live) {
+    const int e1 = g.rowptr[i + 1];
+    for (int e = g.rowptr[i] + sub; e < e1; e += 16) {
+      const float sg = g.esign[e];
+      if (sg == 0.f) continue;
+      const int p = g.epair[e];
+      fx -= sg * g_delta[p * 3];
+      fy -= sg * g_delta[p * 3 + 1];
+      fz -= sg * g_delta[p * 3 + 2];
+    }
   }
-  const int o = perm ? perm[i] : i;  // cell-list path: back to the caller's atom order
-  forces[o * 3] = fx;
-  forces[o * 3 + 1] = fy;
-  forces[o * 3 + 2] = fz;
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    fx += __shfl_down(fx, off, 16);
+    fy += __shfl_down(fy, off, 16);
+    fz += __shfl_down(fz, off, 16);
+  }
+  if (live && sub == 0) {
+    const int o = perm ? perm[i] : i;  // cell-list path: back to the caller's atom order
+    forces[o * 3] = fx;
+    forces[o * 3 + 1] = fy;
+    forces[o * 3 + 2] = fz;
+  }
 }
 void launch_force_gather(const Graph& g, int N, const float* g_delta, const int* perm, float* forces, hipStream_t s) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(k_force_gather, dim3(cdiv(N, 128)), dim3(128), 0, s, g, N, g_delta, perm, forces);
+  hipLaunchKernelGGL(k_force_gather, dim3(cdiv(N, 16)), dim3(256), 0, s, g, N, g_delta, perm, forces);
 }
 
 __global__ void k_fill(float* p, float v, int64_t n) {
