@@ -28,7 +28,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 N_MOL, N_ATOMS = 256, 64
-PEAK = {"mfma_f32_tflops": 157.3, "hbm_gbs": 8000.0}  # /opt/skills/guides/MI355X_MICROARCH.md
+# /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA 157.3 TF, dense bf16 MFMA 2.5 PF, HBM 8 TB/s.  The pair-row GEMMs
+# (class gemm_edge) compute every fp32 product as 6 bf16 MFMA products (exact 3-way split, fp32 accumulation,
+# tn_gemm_sb.hip), so their fp32-equivalent ceiling is 2500 / 6 TF; the per-atom GEMMs run on the fp32 MFMA pipe.
+PEAK = {"mfma_f32_tflops": 157.3, "mfma_bf16_tflops": 2500.0, "hbm_gbs": 8000.0}
+SPLIT_PRODUCTS = 6
 
 
 def profile_classes(model, L, stream_ptr, mask):
@@ -115,7 +119,7 @@ def cpu_baseline(args_dict, state_dict, budget_s=20.0):
 
 
 # HIP kernel behind each profiled class (rocprofv3 names; profiles/r01_kernel_stats.csv)
-KERNEL_OF = {"gemm_edge": "k_gemm_dual", "gemm_node": "k_gemm_nt", "message": "k_message / k_message_adjoint",
+KERNEL_OF = {"gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_nt", "message": "k_message / k_message_adjoint",
              "pair_bwd": "k_pair_gd_v4 / k_embed_pair_gd_v4"}
 
 
@@ -202,8 +206,13 @@ def main():
         avg_s = timed["ms"] * 1e-3 / launches
         if timed["flops"] > 0:
             ach = timed["flops"] / launches / avg_s / 1e12
-            roof = {"bound": "mfma", "kernel": f"{dominant} ({KERNEL_OF.get(dominant, dominant)}, v_mfma_f32_32x32x2_f32)", "achieved": ach,
-                    "peak": PEAK["mfma_f32_tflops"], "unit": "TFLOP/s", "frac": ach / PEAK["mfma_f32_tflops"]}
+            split = dominant == "gemm_edge" and not os.environ.get("TMDNET_NO_SPLIT_BF16")
+            peak = PEAK["mfma_bf16_tflops"] / SPLIT_PRODUCTS if split else PEAK["mfma_f32_tflops"]
+            inst = "v_mfma_f32_32x32x16_bf16 x6 per fp32 product" if split else "v_mfma_f32_32x32x2_f32"
+            roof = {"bound": "mfma", "kernel": f"{dominant} ({KERNEL_OF.get(dominant, dominant)}, {inst})", "achieved": ach,
+                    "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "peak_note": ("fp32-equivalent: dense bf16 MFMA peak 2500 TF / 6 split products; achieved counts "
+                                  "algorithmic fp32 FLOPs (x6 = executed bf16 FLOPs)") if split else "fp32 MFMA peak"}
         else:
             ach = timed["bytes"] / launches / avg_s / 1e9
             roof = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": PEAK["hbm_gbs"], "unit": "GB/s",

@@ -142,9 +142,14 @@ const char* tmdnet_profile_category_name(int idx);
  * Names: "X_embed", "X_layer<l>", "x", "phi", "Q", "u0", "G_embed".  Used by the parity tests. */
 int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* out, int64_t numel);
 /* plain dense contraction through the path's MFMA GEMM: C[M,N] = A[M,K] @ W[N,K]^T (+bias); for unit tests */
-/* value + tangent GEMM of the edge MLP (kind 0 plain, 1 silu, 2 silu * rs with rs2 = d rs): C = f(A W^T + b), C2 = d/dd */
+/* value + tangent GEMM of the edge MLP (kind 0 plain, 1 silu, 2 silu * rs with rs2 = d rs): C = f(A W^T + b), C2 = d/dd.
+ * Wsb: optional DEVICE copy of the split-bf16 tile image of W (tmdnet_debug_split_weight); when given and the shape
+ * qualifies, the bf16-MFMA kernel runs instead of the fp32-MFMA one. */
 int tmdnet_debug_gemm_dual(void* stream, const float* A, const float* A2, const float* W, const float* bias, float* C, float* C2,
-                           int64_t M, int64_t N, int64_t K, int32_t kind, const float* rs, const float* rs2);
+                           int64_t M, int64_t N, int64_t K, int32_t kind, const float* rs, const float* rs2, const uint16_t* Wsb);
+/* host-side 3 x bf16 split of W[N,K] into the kernel's tile image; returns the number of uint16 elements
+ * (out_host may be NULL to query the size) */
+int64_t tmdnet_debug_split_weight(const float* W_host, int64_t N, int64_t K, uint16_t* out_host);
 int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float* bias, float* C, int64_t M, int64_t N,
                       int64_t K, int32_t silu);
 

@@ -198,6 +198,55 @@ def test_mfma_gemm_unit(hip_lib):
         assert rel_err(Cc.cpu(), ref.cpu()) < 1e-5, (M, N, K)
 
 
+def _dual_reference(A, A2, Wt, b, kind, rs, rs2):
+    e = A.double() @ Wt.double().t() + b.double()
+    r = A2.double() @ Wt.double().t()
+    sg = torch.sigmoid(e)
+    f, df = e * sg, sg * (1 + e * (1 - sg))
+    if kind == 0:
+        return e, r
+    if kind == 1:
+        return f, df * r
+    return f * rs[:, None].double(), df * r * rs[:, None].double() + f * rs2[:, None].double()
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_dual_gemm_unit(hip_lib, split):
+    """value + d/dd tangent GEMM of the edge MLP: fp32-MFMA kernel and the 3 x bf16 split kernel (tn_gemm_sb.hip)
+    against an fp64 contraction; asymmetric operands, ragged row tiles, every epilogue kind.  The split kernel must
+    be as accurate as the fp32 one (it is an exact 3-way split with fp32 accumulation, not a reduced precision)."""
+    import ctypes as C
+
+    torch.manual_seed(1)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (M, N, K): the split kernel engages from 256 tiles of 128 x 128; smaller launches take the split-K fp32 kernel
+    shapes = [(32768 + 77, 128, 32), (16384 + 5, 256, 128), (11000, 384, 256), (300, 128, 32), (70, 52, 24)]
+    for (M, N, K) in shapes:
+        for kind in (0, 1, 2):
+            A = torch.randn(M, K, device="cuda") * (torch.rand(M, 1, device="cuda") * 2)
+            A2 = torch.randn(M, K, device="cuda")
+            Wt = torch.randn(N, K, device="cuda") / K ** 0.5
+            b = torch.randn(N, device="cuda")
+            rs, rs2 = torch.rand(M, device="cuda"), torch.randn(M, device="cuda")
+            C1 = torch.full((M, N), float("nan"), device="cuda")
+            C2 = torch.full((M, N), float("nan"), device="cuda")
+            wsb = None
+            if split:
+                Wh = Wt.cpu().contiguous()
+                n = hip_lib.tmdnet_debug_split_weight(p(Wh), N, K, None)
+                img = torch.empty(n, dtype=torch.int16)
+                hip_lib.tmdnet_debug_split_weight(p(Wh), N, K, p(img))
+                wsb_t = img.cuda()
+                wsb = p(wsb_t)
+            rc = hip_lib.tmdnet_debug_gemm_dual(s, p(A), p(A2), p(Wt), p(b), p(C1), p(C2), M, N, K, kind, p(rs), p(rs2), wsb)
+            assert rc == 0
+            r1, r2 = _dual_reference(A, A2, Wt, b, kind, rs, rs2)
+            assert torch.isfinite(C1).all() and torch.isfinite(C2).all(), (M, N, K, kind)
+            assert rel_err(C1.double().cpu(), r1.cpu()) < 2e-6, (M, N, K, kind, split)
+            assert rel_err(C2.double().cpu(), r2.cpu()) < 2e-6, (M, N, K, kind, split)
+
+
 def test_static_shapes_equals_dynamic_and_graph_replay(hip_lib, golden_dir):
     """reference tests/test_staticshapes.py:59-87 (static == dynamic to 1e-5) + HIP-graph capture/replay
     (reference tests/test_model.py:162-262 do this with torch.cuda.graphs)."""

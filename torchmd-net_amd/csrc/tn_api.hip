@@ -25,6 +25,7 @@ struct LayerP {
   const float *M1, *b1, *M1T, *M2, *b2, *M2T, *M3, *b3, *M3T;
   const float* V[6];
   const float* VT[6];
+  const uint16_t* M_sb[3];  // split-bf16 tile images of M1..M3 (tn_gemm_sb.hip)
 };
 
 struct DevParams {
@@ -39,6 +40,7 @@ struct DevParams {
   const float *lnr_w, *lnr_b, *Lin, *bLin, *LinT;
   const float *O1, *bO1, *O1T, *O2, *bO2;
   const float* atomref;
+  const uint16_t* Wdp_sb;
   const float *Utab, *Vtab;  // per-type pair-embedding tables (k_ztables at finalize)
   float mean, std;
 };
@@ -109,6 +111,7 @@ struct tmdnet_model {
   std::vector<ParamSpec> specs;
   std::map<std::string, std::vector<float>> host;
   float* dev = nullptr;  // packed parameters
+  uint16_t* dev_sb = nullptr;  // split-bf16 weight tile images
   DevParams P;
   bool finalized = false;
   std::string err;
@@ -247,8 +250,10 @@ void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ld
 
 // value + tangent through one weight tile (tn_gemm_dual.hip); rows = pairs (device-side count)
 void gemm_dual(hipStream_t s, int kind, const float* A, const float* A2, int64_t lda, const float* W, const float* bias, float* C,
-               float* C2, int64_t ldc, int M, int N, int K, const float* rs = nullptr, const float* rs2 = nullptr) {
+               float* C2, int64_t ldc, int M, int N, int K, const float* rs = nullptr, const float* rs2 = nullptr,
+               const uint16_t* Wsb = nullptr) {
   GemmArgs a{};
+  a.Wsb = Wsb;
   a.A = A;
   a.A2 = A2;
   a.W[0] = W;
@@ -440,6 +445,7 @@ int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out) {
 int tmdnet_destroy(tmdnet_model* m) {
   if (!m) return TMDNET_OK;
   if (m->dev) (void)hipFree(m->dev);
+  if (m->dev_sb) (void)hipFree(m->dev_sb);
   delete m;
   return TMDNET_OK;
 }
@@ -608,6 +614,32 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   P.atomref = m->hp.has_atomref ? D("atomref") : nullptr;
   P.mean = h["mean"][0];
   P.std = h["std"][0];
+  {  // split-bf16 tile images of the pair-row MLP weights
+    std::vector<uint16_t> sb;
+    std::vector<size_t> offs;
+    auto add_sb = [&](const std::vector<float>& w, int64_t n, int64_t k) {
+      const size_t o = sb.size();
+      sb.resize(o + split_weight_elems(n, k));
+      split_weight_tiles(w.data(), n, k, sb.data() + o);
+      offs.push_back(o);
+    };
+    add_sb(Wdp, 3 * F, K);
+    for (int l = 0; l < L; ++l) {
+      const std::string Lp = R + "layers." + std::to_string(l) + ".linears_scalar.";
+      add_sb(h[Lp + "0.weight"], F, K);
+      add_sb(h[Lp + "1.weight"], 2 * F, F);
+      add_sb(h[Lp + "2.weight"], 3 * F, 2 * F);
+    }
+    if (m->dev_sb) {
+      HIP_TRY(m, hipFree(m->dev_sb));
+      m->dev_sb = nullptr;
+    }
+    HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev_sb), sb.size() * sizeof(uint16_t)));
+    HIP_TRY(m, hipMemcpy(m->dev_sb, sb.data(), sb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    P.Wdp_sb = m->dev_sb + offs[0];
+    for (int l = 0; l < L; ++l)
+      for (int k = 0; k < 3; ++k) P.layer[l].M_sb[k] = m->dev_sb + offs[1 + 3 * l + k];
+  }
   P.Utab = m->dev + off.at("Utab");
   P.Vtab = m->dev + off.at("Vtab");
   launch_ztables(P.emb, P.emb2_waT, P.emb2_wbT, P.emb2_b, m->hp.max_z, F, m->dev + off.at("Utab"), m->dev + off.at("Vtab"), nullptr);
@@ -775,7 +807,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   // ---- embedding
   // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
   EDGE(1);
-  if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K);  // distance projections + d/dd
+  if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);  // distance projections + d/dd
   else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
   KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
      launch_embed_scatter(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.u0, b.s0n, s));
@@ -790,9 +822,9 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     EDGE(1);
     if (want_forces) {
       // edge MLP with its distance tangent carried forward (dw/dd): the reverse pass then needs no edge GEMM
-      gemm_dual(s, 1, b.phi, b.dphi, K, q_.M1, q_.b1, b.he1, b.te1, F, P1, F, K);
-      gemm_dual(s, 1, b.he1, b.te1, F, q_.M2, q_.b2, b.he2, b.te2, 2 * F, P1, 2 * F, F);
-      gemm_dual(s, 2, b.he2, b.te2, 2 * F, q_.M3, q_.b3, b.w[l], b.dw[l], 3 * F, P1, 3 * F, 2 * F, b.C, b.dC);
+      gemm_dual(s, 1, b.phi, b.dphi, K, q_.M1, q_.b1, b.he1, b.te1, F, P1, F, K, nullptr, nullptr, q_.M_sb[0]);
+      gemm_dual(s, 1, b.he1, b.te1, F, q_.M2, q_.b2, b.he2, b.te2, 2 * F, P1, 2 * F, F, nullptr, nullptr, q_.M_sb[1]);
+      gemm_dual(s, 2, b.he2, b.te2, 2 * F, q_.M3, q_.b3, b.w[l], b.dw[l], 3 * F, P1, 3 * F, 2 * F, b.C, b.dC, q_.M_sb[2]);
     } else {
       gemm(s, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU);
       gemm(s, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU);
@@ -940,10 +972,15 @@ int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* 
 }
 
 int tmdnet_debug_gemm_dual(void* stream, const float* A, const float* A2, const float* W, const float* bias, float* C, float* C2,
-                           int64_t M, int64_t N, int64_t K, int32_t kind, const float* rs, const float* rs2) {
+                           int64_t M, int64_t N, int64_t K, int32_t kind, const float* rs, const float* rs2, const uint16_t* Wsb) {
   g_mdev = nullptr;
-  gemm_dual(reinterpret_cast<hipStream_t>(stream), kind, A, A2, K, W, bias, C, C2, N, (int)M, (int)N, (int)K, rs, rs2);
+  gemm_dual(reinterpret_cast<hipStream_t>(stream), kind, A, A2, K, W, bias, C, C2, N, (int)M, (int)N, (int)K, rs, rs2, Wsb);
   return hipGetLastError() == hipSuccess ? TMDNET_OK : TMDNET_ERR_HIP;
+}
+
+int64_t tmdnet_debug_split_weight(const float* W_host, int64_t N, int64_t K, uint16_t* out_host) {
+  if (out_host) split_weight_tiles(W_host, N, K, out_host);
+  return (int64_t)split_weight_elems(N, K);
 }
 
 int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float* bias, float* C, int64_t M, int64_t N,

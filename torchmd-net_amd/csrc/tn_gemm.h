@@ -42,11 +42,18 @@ struct GemmArgs {
   const float* A2;
   float* C2;
   const float* rowscale2;
+  // split-bf16 tile image of W (tn_gemm_sb.hip) or null
+  const uint16_t* Wsb;
 };
 
 // launches on `stream`; returns hipError_t as int
 int launch_gemm(const GemmArgs& args, hipStream_t stream);
 // value + d/dd tangent through one weight tile; kind 0: plain, 1: silu, 2: silu * C(d) (rowscale/rowscale2 = C, C')
 int launch_gemm_dual(const GemmArgs& args, int kind, hipStream_t stream);
+// split-bf16 MFMA variant (tn_gemm_sb.hip): taken by launch_gemm_dual when gemm_dual_sb_ok(args)
+bool gemm_dual_sb_ok(const GemmArgs& args);
+int launch_gemm_dual_sb(const GemmArgs& args, int kind, hipStream_t stream);
+size_t split_weight_elems(int64_t N, int64_t K);                                   // uint16 elements of the tile image
+void split_weight_tiles(const float* W_host, int64_t N, int64_t K, uint16_t* out_host);
 
 }  // namespace tn

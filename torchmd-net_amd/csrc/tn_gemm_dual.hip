@@ -287,6 +287,7 @@ static int launch_dual_kind(const GemmArgs& a, hipStream_t stream) {
 // kind: 0 plain, 1 silu, 2 final (rowscale = C(d), rowscale2 = C'(d))
 int launch_gemm_dual(const GemmArgs& a, int kind, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0) return 0;
+  if (gemm_dual_sb_ok(a)) return launch_gemm_dual_sb(a, kind, stream);
   switch (kind) {
     case DUAL_PLAIN: return launch_dual_kind<DUAL_PLAIN>(a, stream);
     case DUAL_SILU: return launch_dual_kind<DUAL_SILU>(a, stream);

@@ -69,7 +69,9 @@ def lib():
     L.tmdnet_profile_category_name.argtypes = [C.c_int]
     L.tmdnet_profile_category_name.restype = C.c_char_p
     L.tmdnet_debug_tensor.argtypes = [vp, vp, C.c_char_p, vp, i64]
-    L.tmdnet_debug_gemm_dual.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp, vp]
+    L.tmdnet_debug_gemm_dual.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp, vp, vp]
+    L.tmdnet_debug_split_weight.argtypes = [vp, i64, i64, vp]
+    L.tmdnet_debug_split_weight.restype = i64
     L.tmdnet_debug_gemm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32]
     for name in declared_symbols():
         fn = getattr(L, name)
