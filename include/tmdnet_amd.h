@@ -141,7 +141,8 @@ const char* tmdnet_profile_category_name(int idx);
  * Copy an intermediate of the last tmdnet_energy_forces call out of the workspace (device -> device).
  * Names: "X_embed", "X_layer<l>", "x", "phi", "Q", "u0", "G_embed".  Used by the parity tests. */
 int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* out, int64_t numel);
-/* plain dense contraction through the path's MFMA GEMM: C[M,N] = A[M,K] @ W[N,K]^T (+bias); for unit tests */
+/* plain dense contraction through the path's MFMA GEMM: C[M,N] = A[M,K] @ W[N,K]^T (+bias) (silu != 0: silu of it); Wsb as
+ * for tmdnet_debug_gemm_dual (NULL: fp32-MFMA kernels); for unit tests */
 /* value + tangent GEMM of the edge MLP (kind 0 plain, 1 silu, 2 silu * rs with rs2 = d rs): C = f(A W^T + b), C2 = d/dd.
  * Wsb: optional DEVICE copy of the split-bf16 tile image of W (tmdnet_debug_split_weight); when given and the shape
  * qualifies, the bf16-MFMA kernel runs instead of the fp32-MFMA one. */
@@ -151,7 +152,7 @@ int tmdnet_debug_gemm_dual(void* stream, const float* A, const float* A2, const 
  * (out_host may be NULL to query the size) */
 int64_t tmdnet_debug_split_weight(const float* W_host, int64_t N, int64_t K, uint16_t* out_host);
 int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float* bias, float* C, int64_t M, int64_t N,
-                      int64_t K, int32_t silu);
+                      int64_t K, int32_t silu, const uint16_t* Wsb);
 
 #ifdef __cplusplus
 }

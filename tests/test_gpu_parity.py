@@ -181,21 +181,38 @@ def test_neighbor_overflow_raises(hip_lib):
         model(z.cuda(), pos.cuda(), batch.cuda())
 
 
-def test_mfma_gemm_unit(hip_lib):
-    """transpose-detecting check of the fp32 MFMA GEMM (asymmetric operands, ragged sizes)."""
+@pytest.mark.parametrize("split", [False, True])
+def test_mfma_gemm_unit(hip_lib, split):
+    """transpose-detecting check of the MFMA GEMMs (asymmetric operands, ragged sizes): fp32-MFMA tiles / split-K
+    kernel, and the 3 x bf16 split kernel of the per-atom contractions (tn_gemm_sb1.hip, >= 128 tiles)."""
     import ctypes as C
 
     torch.manual_seed(0)
-    for (M, N, K) in [(1, 1, 4), (37, 96, 16), (300, 128, 32), (129, 384, 256), (513, 64, 128), (200, 32, 384), (70, 50, 22)]:
-        A = torch.randn(M, K, device="cuda")
-        Wt = torch.randn(N, K, device="cuda")
-        b = torch.randn(N, device="cuda")
-        Cc = torch.empty(M, N, device="cuda")
-        rc = hip_lib.tmdnet_debug_gemm(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(A.data_ptr()),
-                                       C.c_void_p(Wt.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(Cc.data_ptr()), M, N, K, 0)
-        assert rc == 0
-        ref = (A.double() @ Wt.double().t() + b.double()).float()
-        assert rel_err(Cc.cpu(), ref.cpu()) < 1e-5, (M, N, K)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    shapes = [(1, 1, 4), (37, 96, 16), (300, 128, 32), (129, 384, 256), (513, 64, 128), (200, 32, 384), (70, 50, 22),
+              (16384 + 3, 128, 128), (16384, 384, 256), (9000, 256, 384), (33000, 64, 128)]
+    for (M, N, K) in shapes:
+        for silu in (0, 1):
+            A = torch.randn(M, K, device="cuda") * (torch.rand(M, 1, device="cuda") * 2)
+            Wt = torch.randn(N, K, device="cuda") / K ** 0.5
+            b = torch.randn(N, device="cuda")
+            Cc = torch.full((M, N), float("nan"), device="cuda")
+            wsb = None
+            if split:
+                Wh = Wt.cpu().contiguous()
+                n = hip_lib.tmdnet_debug_split_weight(p(Wh), N, K, None)
+                img = torch.empty(n, dtype=torch.int16)
+                hip_lib.tmdnet_debug_split_weight(p(Wh), N, K, p(img))
+                wsb_t = img.cuda()
+                wsb = p(wsb_t)
+            rc = hip_lib.tmdnet_debug_gemm(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(A), p(Wt), p(b), p(Cc), M, N, K,
+                                           silu, wsb)
+            assert rc == 0
+            ref = A.double() @ Wt.double().t() + b.double()
+            if silu:
+                ref = ref * torch.sigmoid(ref)
+            assert torch.isfinite(Cc).all(), (M, N, K)
+            assert rel_err(Cc.double().cpu(), ref.cpu()) < 2e-6, (M, N, K, silu, split)
 
 
 def _dual_reference(A, A2, Wt, b, kind, rs, rs2):

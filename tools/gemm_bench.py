@@ -12,7 +12,14 @@ s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for (M, N, K, act) in shapes:
     A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.05; b = torch.randn(N, device="cuda")
     Cc = torch.empty(M, N, device="cuda")
-    args = (s, C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(Cc.data_ptr()), M, N, K, act)
+    Wh = W.cpu().contiguous()
+    nsb = L.tmdnet_debug_split_weight(C.c_void_p(Wh.data_ptr()), N, K, None)
+    img = torch.empty(nsb, dtype=torch.int16)
+    L.tmdnet_debug_split_weight(C.c_void_p(Wh.data_ptr()), N, K, C.c_void_p(img.data_ptr()))
+    Wsb = img.cuda()
+    use_sb = os.environ.get("SB", "1") == "1"
+    args = (s, C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(Cc.data_ptr()), M, N, K, act,
+            C.c_void_p(Wsb.data_ptr()) if use_sb else None)
     for _ in range(3): L.tmdnet_debug_gemm(*args)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -112,6 +113,7 @@ struct tmdnet_model {
   std::map<std::string, std::vector<float>> host;
   float* dev = nullptr;  // packed parameters
   uint16_t* dev_sb = nullptr;  // split-bf16 weight tile images
+  std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
   DevParams P;
   bool finalized = false;
   std::string err;
@@ -195,9 +197,14 @@ struct Packer {
 
 // ---- optional per-launch timing with HIP events on the launch stream (tmdnet_profile_begin/end)
 thread_local tmdnet_model* g_cur = nullptr;
+struct CurScope {  // g_cur is valid exactly while an entry point is enqueueing for that model (also on error returns)
+  explicit CurScope(tmdnet_model* m) { g_cur = m; }
+  ~CurScope() { g_cur = nullptr; }
+};
 thread_local int g_gemm_cat = CAT_GEMM_NODE;
 thread_local const int* g_mdev = nullptr;  // device-side row count of pair-row GEMMs (see GemmArgs::m_dev)
 thread_local int g_madd = 0;
+thread_local const uint16_t* g_wsb_debug = nullptr;  // tmdnet_debug_gemm: split image supplied by the caller
 struct ProfScope {
   int idx = -1;
   hipStream_t s;
@@ -242,6 +249,11 @@ void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ld
   a.flags = flags;
   a.m_dev = g_mdev;
   a.m_add = g_madd;
+  if (g_cur && ldw == K) {
+    auto it = g_cur->sb_of.find(W);
+    if (it != g_cur->sb_of.end()) a.Wsbg[0] = it->second;
+  }
+  if (g_wsb_debug) a.Wsbg[0] = g_wsb_debug;
   // algorithmic traffic: A and W read once, C (and the saved pre-activation / aux operand) once
   const double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (1 + (pre ? 1 : 0) + (aux ? 1 : 0) + ((flags & GEMM_ACCUM) ? 1 : 0)));
   ProfScope ps_(s, g_gemm_cat, 2.0 * M * N * K, bytes);
@@ -291,6 +303,10 @@ void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], floa
   for (int c = 0; c < 9; ++c) {
     const int t = c == 0 ? 0 : (c < 4 ? 1 : 2);
     a.W[c] = W3[t];
+    if (g_cur) {
+      auto it = g_cur->sb_of.find(W3[t]);
+      if (it != g_cur->sb_of.end()) a.Wsbg[c] = it->second;
+    }
     a.bias[c] = nullptr;
     a.a_off[c] = a.c_off[c] = a.pre_off[c] = c * F;
     a.aux_off[c] = t * F;
@@ -614,31 +630,53 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   P.atomref = m->hp.has_atomref ? D("atomref") : nullptr;
   P.mean = h["mean"][0];
   P.std = h["std"][0];
-  {  // split-bf16 tile images of the pair-row MLP weights
+  {  // split-bf16 tile images (tn_gemm_sb.hip / tn_gemm_sb1.hip) of every GEMM weight, keyed by its fp32 device copy
+    struct Img { std::string key; int64_t n, k; size_t o; };
+    std::vector<Img> imgs;
     std::vector<uint16_t> sb;
-    std::vector<size_t> offs;
-    auto add_sb = [&](const std::vector<float>& w, int64_t n, int64_t k) {
+    auto add_sb = [&](const std::string& key, int64_t n, int64_t k) {  // packed matrix `key` is [n][k] row-major
       const size_t o = sb.size();
       sb.resize(o + split_weight_elems(n, k));
-      split_weight_tiles(w.data(), n, k, sb.data() + o);
-      offs.push_back(o);
+      split_weight_tiles(pk.buf.data() + off.at(key), n, k, sb.data() + o);
+      imgs.push_back({key, n, k, o});
     };
-    add_sb(Wdp, 3 * F, K);
-    for (int l = 0; l < L; ++l) {
-      const std::string Lp = R + "layers." + std::to_string(l) + ".linears_scalar.";
-      add_sb(h[Lp + "0.weight"], F, K);
-      add_sb(h[Lp + "1.weight"], 2 * F, F);
-      add_sb(h[Lp + "2.weight"], 3 * F, 2 * F);
+    add_sb("Wdp", 3 * F, K);
+    for (int k = 0; k < 3; ++k) {
+      add_sb("Ue" + std::to_string(k), F, F);
+      add_sb("UeT" + std::to_string(k), F, F);
     }
+    add_sb("L1", 2 * F, F);
+    add_sb("L1T", F, 2 * F);
+    add_sb("L2", 3 * F, 2 * F);
+    add_sb("L2T", 2 * F, 3 * F);
+    for (int l = 0; l < L; ++l) {
+      const std::string t = "l" + std::to_string(l) + ".";
+      add_sb(t + "M0", F, K);
+      add_sb(t + "M1", 2 * F, F);
+      add_sb(t + "M2", 3 * F, 2 * F);
+      for (int k = 0; k < 6; ++k) {
+        add_sb(t + "V" + std::to_string(k), F, F);
+        add_sb(t + "VT" + std::to_string(k), F, F);
+      }
+    }
+    add_sb("Lin", F, 3 * F);
+    add_sb("LinT", 3 * F, F);
+    add_sb("O1", H, F);
+    add_sb("O1T", F, H);
     if (m->dev_sb) {
       HIP_TRY(m, hipFree(m->dev_sb));
       m->dev_sb = nullptr;
     }
     HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev_sb), sb.size() * sizeof(uint16_t)));
     HIP_TRY(m, hipMemcpy(m->dev_sb, sb.data(), sb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    P.Wdp_sb = m->dev_sb + offs[0];
-    for (int l = 0; l < L; ++l)
-      for (int k = 0; k < 3; ++k) P.layer[l].M_sb[k] = m->dev_sb + offs[1 + 3 * l + k];
+    m->sb_of.clear();
+    for (const auto& im : imgs) m->sb_of[m->dev + off.at(im.key)] = m->dev_sb + im.o;
+    P.Wdp_sb = m->sb_of.at(P.Wdp);
+    for (int l = 0; l < L; ++l) {
+      P.layer[l].M_sb[0] = m->sb_of.at(P.layer[l].M1);
+      P.layer[l].M_sb[1] = m->sb_of.at(P.layer[l].M2);
+      P.layer[l].M_sb[2] = m->sb_of.at(P.layer[l].M3);
+    }
   }
   P.Utab = m->dev + off.at("Utab");
   P.Vtab = m->dev + off.at("Vtab");
@@ -677,7 +715,7 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
   set_cell(g, m, cell);
   m->graph_is_cell = cell;
-  g_cur = m;
+  CurScope cur_(m);
   {
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
     if (cell) {
@@ -706,7 +744,6 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
       launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
     }
   }
-  g_cur = nullptr;
   HIP_TRY(m, hipGetLastError());
   return TMDNET_OK;
 }
@@ -723,7 +760,7 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
   const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
   set_cell(g, m, cell);
   m->graph_is_cell = cell;
-  g_cur = m;
+  CurScope cur_(m);
   {
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
     if (cell) {
@@ -738,7 +775,6 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
       launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
     }
   }
-  g_cur = nullptr;
   m->lastE = ecap;
   HIP_TRY(m, hipGetLastError());
   return TMDNET_OK;
@@ -787,7 +823,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   const DevParams& W = m->P;
   const int o3 = hp.group_o3;
 
-  g_cur = m;
+  CurScope cur_(m);
   const int* perm = nullptr;
   if (m->graph_is_cell) {  // the graph lives in cell order: renumber z here, scatter the forces back at the end
     set_cell(g, m, true);
@@ -879,7 +915,6 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
   }
   NODE();
-  g_cur = nullptr;
   HIP_TRY(m, hipGetLastError());
   m->last = b;
   m->lastN = N;
@@ -984,8 +1019,11 @@ int64_t tmdnet_debug_split_weight(const float* W_host, int64_t N, int64_t K, uin
 }
 
 int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float* bias, float* C, int64_t M, int64_t N,
-                      int64_t K, int32_t silu_) {
+                      int64_t K, int32_t silu_, const uint16_t* Wsb) {
+  g_mdev = nullptr;
+  g_wsb_debug = Wsb;
   gemm(reinterpret_cast<hipStream_t>(stream), A, K, W, K, bias, C, N, (int)M, (int)N, (int)K, silu_ ? GEMM_ACT_SILU : 0);
+  g_wsb_debug = nullptr;
   return hipGetLastError() == hipSuccess ? TMDNET_OK : TMDNET_ERR_HIP;
 }
 

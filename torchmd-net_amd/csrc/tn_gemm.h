@@ -44,6 +44,8 @@ struct GemmArgs {
   const float* rowscale2;
   // split-bf16 tile image of W (tn_gemm_sb.hip) or null
   const uint16_t* Wsb;
+  // per-group split-bf16 tile images for launch_gemm (tn_gemm_sb1.hip) or null
+  const uint16_t* Wsbg[GEMM_MAX_GROUPS];
 };
 
 // launches on `stream`; returns hipError_t as int
@@ -53,6 +55,9 @@ int launch_gemm_dual(const GemmArgs& args, int kind, hipStream_t stream);
 // split-bf16 MFMA variant (tn_gemm_sb.hip): taken by launch_gemm_dual when gemm_dual_sb_ok(args)
 bool gemm_dual_sb_ok(const GemmArgs& args);
 int launch_gemm_dual_sb(const GemmArgs& args, int kind, hipStream_t stream);
+// single-product split-bf16 variant with the node-side epilogues (tn_gemm_sb1.hip): taken by launch_gemm when ok
+bool gemm_sb1_ok(const GemmArgs& args);
+int launch_gemm_sb1(const GemmArgs& args, hipStream_t stream);
 size_t split_weight_elems(int64_t N, int64_t K);                                   // uint16 elements of the tile image
 void split_weight_tiles(const float* W_host, int64_t N, int64_t K, uint16_t* out_host);
 

@@ -257,6 +257,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
       default: return launch_one<128, 128, 2, 2, EPI_GENERIC, 0>(a, stream);
     }
   }
+  if (gemm_sb1_ok(a)) return launch_gemm_sb1(a, stream);  // bf16 matrix pipe, exact 3-way split (tn_gemm_sb1.hip)
   // few tiles: the chip would be mostly idle and every launch would cost K/32 dependent iterations ->
   // latency-oriented split-K kernel (single molecules, small MD systems)
   {

@@ -21,38 +21,14 @@
 
 #include "tn_common.h"
 #include "tn_gemm_epi.h"
+#include "tn_gemm_sb.h"
 
 namespace tn {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-// two fp32 -> three packed bf16 pairs (round to nearest even at every level; low half = first element)
-__device__ __forceinline__ void split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-  union { bf16x2 v; uint32_t u; } c;
-  c.v = __builtin_convertvector((floatx2){x0, x1}, bf16x2);
-  h = c.u;
-  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-  c.v = __builtin_convertvector((floatx2){r0, r1}, bf16x2);
-  m = c.u;
-  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-  c.v = __builtin_convertvector((floatx2){s0, s1}, bf16x2);
-  l = c.u;
-}
-__device__ __forceinline__ void split8(const float4& u, const float4& v, uint4& h, uint4& m, uint4& l) {
-  split2(u.x, u.y, h.x, m.x, l.x);
-  split2(u.z, u.w, h.y, m.y, l.y);
-  split2(v.x, v.y, h.z, m.z, l.z);
-  split2(v.z, v.w, h.w, m.w, l.w);
-}
 
 // ---- software-pipelined variant: LDS double buffer (unpadded planes, XOR-swizzled 16-byte pieces), ONE barrier per
 // K-step.  Within a step a wave multiplies chunk kt out of buffer kt&1 and, between the MFMAs of the second half,
 // splits chunk kt+1 (loaded during the previous step) into the other buffer, then issues the loads of chunk kt+2
 // into the same registers.  The VALU / LDS-write work rides in the issue slots the 32-cycle MFMAs leave free.
-constexpr int SB2_PLANE = 128 * 32;        // 4096 bytes, no padding
 constexpr int SB2_STAGE = 9 * SB2_PLANE;   // 36864 bytes
 
 template <int KIND>

@@ -72,7 +72,7 @@ def lib():
     L.tmdnet_debug_gemm_dual.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp, vp, vp]
     L.tmdnet_debug_split_weight.argtypes = [vp, i64, i64, vp]
     L.tmdnet_debug_split_weight.restype = i64
-    L.tmdnet_debug_gemm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32]
+    L.tmdnet_debug_gemm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]
     for name in declared_symbols():
         fn = getattr(L, name)
         if fn.restype is C.c_int:
