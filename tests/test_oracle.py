@@ -151,3 +151,29 @@ def test_live_reference_random_system():
     for fn in (T.energy_and_forces, A.energy_forces, CO.energy_forces):
         E, F = fn(sd, hp, z, pos, batch, q=q)
         assert rel_err(E, Er.detach()) < 1e-5 and rel_err(F, Fr.detach()) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------
+# Equivariant Transformer: oracle/et_torch.py against the unmodified reference
+# ----------------------------------------------------------------------------------------------
+from oracle import et_torch as ET  # noqa: E402
+
+
+@pytest.mark.parametrize("fixture", ["et_tiny_ref.pt", "et_tiny_vc_ref.pt"])
+def test_et_oracle_fixtures(golden_dir, fixture):
+    """fp64: round-off agreement with the reference (both branch sets: cutoff on attention vs on values, keys-only
+    distance influence); fp32: the reference's tolerance; per-layer dx / dvec through the residual stream."""
+    g = torch.load(os.path.join(golden_dir, fixture))
+    hp = ET.hparams_from_args(g["args"])
+    sd64 = T.cast_state_dict(g["state_dict"], torch.float64)
+    E, F = ET.energy_and_forces(sd64, hp, g["z"], g["pos"].double(), g["batch"])
+    assert rel_err(E, g["E64"]) < 1e-12 and rel_err(F, g["F64"]) < 1e-12
+    E, F = ET.energy_and_forces(g["state_dict"], hp, g["z"], g["pos"], g["batch"])
+    assert rel_err(E, g["E"]) < 1e-5 and rel_err(F, g["F"]) < 1e-5
+    x, vec, inter = ET.et_representation(g["state_dict"], hp, g["z"], g["pos"], g["batch"], return_intermediates=True)
+    assert rel_err(x, g["inter"]["x_out"]) < 1e-5 and rel_err(vec, g["inter"]["vec_out"]) < 1e-5
+    xprev, vprev = inter["x_embed"], torch.zeros_like(vec)
+    for l in range(hp["num_layers"]):
+        assert rel_err(inter[f"x_layer{l}"] - xprev, g["inter"][f"dx_layer{l}"]) < 1e-4
+        assert rel_err(inter[f"vec_layer{l}"] - vprev, g["inter"][f"dvec_layer{l}"]) < 1e-4
+        xprev, vprev = inter[f"x_layer{l}"], inter[f"vec_layer{l}"]

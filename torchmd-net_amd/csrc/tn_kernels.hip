@@ -526,6 +526,7 @@ __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, co
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
                     float* Mi, float* Ch, hipStream_t s) {
   if (N <= 0) return;
+  if (message_tile_ok(F)) return launch_message_tile(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   if (sweep_v4() && gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
 }
@@ -546,6 +547,10 @@ __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict
 }
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
   if (N <= 0) return;
+  // the LDS-staged tile sweep is slower for the adjoint (read-modify-write of gPn; 231 vs 204 us at C2,
+  // profiles/r01_notes.md), so it is opt-in here
+  static const bool tile_adj = getenv("TMDNET_MSG_TILE_ADJOINT") != nullptr;
+  if (tile_adj && message_tile_ok(F)) return launch_message_adjoint_tile(g, N, F, w, gMi, gPn, s);
   if (sweep_v4() && gather_v4_ok(F)) return launch_message_adjoint_v4(g, N, F, w, gMi, gPn, s);
   hipLaunchKernelGGL(k_message_adjoint, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, gMi, gPn);
 }

@@ -32,6 +32,35 @@ C2_ARGS = dict(
 # a small configuration for fast parity tests (not a BASELINE config)
 TINY_ARGS = dict(C2_ARGS, embedding_dimension=32, num_layers=2, num_rbf=16, max_z=20, max_num_neighbors=64)
 
+# BASELINE.json configs[3] ("C4"): examples/ET-SPICE.yaml (Equivariant Transformer)
+C4_ARGS = dict(
+    model="equivariant-transformer",
+    embedding_dimension=128,
+    num_layers=5,
+    num_heads=8,
+    num_rbf=64,
+    rbf_type="expnorm",
+    trainable_rbf=False,
+    activation="silu",
+    attn_activation="silu",
+    neighbor_embedding=True,
+    distance_influence="both",
+    vector_cutoff=True,
+    cutoff_lower=0.0,
+    cutoff_upper=10.0,
+    max_z=100,
+    max_num_neighbors=128,
+    output_model="Scalar",
+    reduce_op="sum",
+    precision=32,
+    prior_model=None,
+    atom_filter=-1,
+    derivative=True,
+    static_shapes=False,
+)
+ET_TINY_ARGS = dict(C4_ARGS, embedding_dimension=32, num_layers=2, num_heads=4, num_rbf=16, max_z=20, max_num_neighbors=64,
+                    cutoff_upper=5.0, vector_cutoff=False)
+
 _Z_CHOICES = np.array([1, 6, 7, 8], dtype=np.int64)
 _Z_PROBS = np.array([0.5, 0.3, 0.1, 0.1])
 
