@@ -54,8 +54,28 @@ typedef struct tmdnet_hparams {
   float cutoff_upper;
 } tmdnet_hparams;
 
+/* Hyper-parameters of the Equivariant Transformer + EquivariantScalar head (reference
+ * torchmdnet/models/torchmd_et.py:84-103, model.py:62-81,134-135).  Activations are SiLU (activation, attn_activation). */
+typedef struct tmdnet_et_hparams {
+  int32_t hidden_channels;    /* embedding_dimension (F) */
+  int32_t num_layers;         /* attention layers */
+  int32_t num_rbf;            /* ExpNormal radial basis size (K) */
+  int32_t max_z;
+  int32_t max_num_neighbors;  /* pair capacity = max_num_neighbors * n_atoms */
+  int32_t num_heads;          /* F / num_heads must be a power of two <= 64 */
+  int32_t neighbor_embedding; /* 1: NeighborEmbedding (models/utils.py:45-117) */
+  int32_t vector_cutoff;      /* 1: cutoff on the values, 0: on the attention weights (torchmd_et.py:395-401) */
+  int32_t distance_influence; /* bit 0: keys (dk_proj), bit 1: values (dv_proj) */
+  int32_t has_atomref;
+  float cutoff_lower;
+  float cutoff_upper;
+} tmdnet_et_hparams;
+
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out);
+/* Equivariant Transformer handle: every other entry point (parameters by state-dict key, graph, energy_forces with
+ * q = NULL, workspaces, profiling) is shared with the TensorNet handle. */
+int tmdnet_create_et(const tmdnet_et_hparams* hp, tmdnet_model** out);
 int tmdnet_destroy(tmdnet_model* m);
 const char* tmdnet_last_error(const tmdnet_model* m);
 const char* tmdnet_version(void);

@@ -1,0 +1,107 @@
+"""gpu: Equivariant Transformer energy+force path (BASELINE configs[3]) through the C ABI
+(tmdnet_create_et + the shared entry points) against the reference's golden vector, fixtures produced by the
+unmodified reference, and the oracle (oracle/et_torch.py, oracle/et_adjoint.py).  Tolerance: 1e-4 relative (fp32)."""
+import os
+
+import pytest
+import torch
+
+from oracle import ref_shims as R
+from torchmdnet_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def rel_err(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+def _model_from_sd(args, sd):
+    from torchmdnet_amd.models.model import create_model
+
+    m = create_model(dict(args))
+    m.load_state_dict(sd)
+    return m.to("cuda")
+
+
+def test_et_reference_golden_vector(hip_lib, golden_dir):
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, "expected_et_scalar.pt"))
+    R.seed_everything(1234)
+    model = create_model(dict(g["args"])).to("cuda")
+    z, pos, batch = R.create_example_batch(n_atoms=5)
+    E, F = model(z.cuda(), pos.cuda(), batch.cuda())
+    torch.testing.assert_close(E.cpu(), g["pred"], atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(F.cpu(), g["deriv"], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("fixture", ["et_tiny_ref.pt", "et_tiny_vc_ref.pt"])
+def test_et_tiny_vs_reference_fixture(hip_lib, golden_dir, fixture):
+    """ragged molecules, both cutoff placements / distance-influence branches; intermediates of the residual stream
+    and of the reverse pass (hand-derived adjoints of oracle/et_adjoint.py)."""
+    from oracle import et_adjoint as EA
+    from oracle import et_torch as ET
+
+    g = torch.load(os.path.join(golden_dir, fixture))
+    model = _model_from_sd(g["args"], g["state_dict"])
+    z, pos, batch = g["z"].cuda(), g["pos"].cuda(), g["batch"].cuda()
+    E, F = model(z, pos, batch)
+    hp = ET.hparams_from_args(g["args"])
+    N, Fd, L = z.shape[0], hp["hidden_channels"], hp["num_layers"]
+    _, _, cache = EA.energy_forces(g["state_dict"], hp, g["z"], g["pos"], g["batch"], want_cache=True)
+    assert rel_err(model.debug_tensor("x_embed", (N, Fd)).cpu(), cache["x_embed"]) < REL
+    for l in range(L):
+        assert rel_err(model.debug_tensor(f"x_layer{l}", (N, Fd)).cpu(), cache[f"x_layer{l}"]) < REL, l
+        assert rel_err(model.debug_tensor(f"vec_layer{l}", (N, 3, Fd)).cpu(), cache[f"vec_layer{l}"]) < REL, l
+    assert rel_err(model.debug_tensor("x_out", (N, Fd)).cpu(), g["inter"]["x_out"]) < REL
+    assert rel_err(model.debug_tensor("g_x", (N, Fd)).cpu(), cache["g_x_layer0"]) < REL
+    assert rel_err(model.debug_tensor("g_vec", (N, 3, Fd)).cpu(), cache["g_vec_layer0"]) < REL
+    assert rel_err(E.cpu(), g["E"]) < REL
+    assert rel_err(F.cpu(), g["F"]) < REL
+
+
+def test_et_c4_vs_reference_fixture(hip_lib, golden_dir):
+    """BASELINE configs[3]: examples/ET-SPICE.yaml hyper-parameters (F=128, L=5, 8 heads, K=64, rc=10, vector cutoff),
+    weights from seed 0, 3 molecules of S-mol64 evaluated by the unmodified reference."""
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, "et_c4_ref.pt"))
+    torch.manual_seed(0)
+    model = create_model(dict(W.C4_ARGS)).to("cuda")
+    z, pos, batch = W.synthetic_batch(n_mol=g["n_mol"])
+    E, F = model(z.cuda(), pos.cuda(), batch.cuda())
+    assert rel_err(E.cpu(), g["E"]) < REL
+    assert rel_err(F.cpu(), g["F"]) < REL
+
+
+def test_et_batch_properties(hip_lib):
+    """64 molecules x 64 atoms on the C4 model: oracle on two sampled molecules, bit-identical repeat, zero net force
+    per molecule, invariance to permuting molecules and to a rigid translation."""
+    from oracle import et_torch as ET
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(0)
+    model = create_model(dict(W.C4_ARGS)).to("cuda")
+    n_mol = 64
+    z, pos, batch = W.synthetic_batch(n_mol=n_mol)
+    zc, pc, bc = z.cuda(), pos.cuda(), batch.cuda()
+    E, F = model(zc, pc, bc)
+    E2, F2 = model(zc, pc.clone(), bc)
+    assert torch.equal(E, E2) and torch.equal(F, F2)
+    net = torch.zeros(n_mol, 3, device="cuda").index_add(0, bc, F)
+    assert net.abs().max().item() < 1e-3 * F.abs().max().item()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hp = ET.hparams_from_args(W.C4_ARGS)
+    for m in (3, 41):
+        sel = batch == m
+        Eo, Fo = ET.energy_and_forces(sd, hp, z[sel], pos[sel], torch.zeros(int(sel.sum()), dtype=torch.long))
+        assert rel_err(E[m].cpu().reshape(1, 1), Eo) < REL
+        assert rel_err(F[sel.cuda()].cpu(), Fo) < REL
+    perm = torch.randperm(n_mol, generator=torch.Generator().manual_seed(1))
+    order = torch.cat([torch.nonzero(batch == int(m)).flatten() for m in perm])
+    newb = torch.repeat_interleave(torch.arange(n_mol), 64)
+    Ep, Fp = model(z[order].cuda(), (pos[order] + torch.tensor([3.0, -2.0, 1.0])).cuda(), newb.cuda())
+    assert rel_err(Ep.cpu(), E.cpu()[perm]) < 1e-5
+    assert rel_err(Fp.cpu(), F.cpu()[order]) < 1e-4

@@ -53,12 +53,24 @@ def test_seeded_init_matches_reference_checksums(golden_dir):
     m2 = create_model(dict(g2["args"]))
     chk2 = float(sum(v.double().abs().sum() for v in m2.state_dict().values() if v.is_floating_point()))
     assert abs(chk2 - g2["sd_checksum"]) < 1e-6 * g2["sd_checksum"]
+    # Equivariant Transformer: ET-SPICE hyper-parameters (seed 0) and the reference's golden-vector recipe (seed 1234)
+    g3 = torch.load(os.path.join(golden_dir, "et_c4_ref.pt"))
+    torch.manual_seed(0)
+    m3 = create_model(dict(W.C4_ARGS))
+    chk3 = float(sum(v.double().abs().sum() for v in m3.state_dict().values() if v.is_floating_point()))
+    assert abs(chk3 - g3["sd_checksum"]) < 1e-6 * g3["sd_checksum"]
+    g4 = torch.load(os.path.join(golden_dir, "expected_et_scalar.pt"))
+    R.seed_everything(1234)
+    m4 = create_model(dict(g4["args"]))
+    chk4 = float(sum(v.double().abs().sum() for v in m4.state_dict().values() if v.is_floating_point()))
+    assert abs(chk4 - g4["sd_checksum"]) < 1e-6 * g4["sd_checksum"]
 
 
 @pytest.mark.skipif(not R.reference_available(), reason="/root/reference not present")
 def test_state_dict_identical_to_live_reference():
     mm = R.reference_model_module()
-    for args, seed in [(W.TINY_ARGS, 3), (dict(W.TINY_ARGS, prior_model="Atomref", prior_args={"max_z": 20}), 4)]:
+    for args, seed in [(W.TINY_ARGS, 3), (dict(W.TINY_ARGS, prior_model="Atomref", prior_args={"max_z": 20}), 4),
+                       (W.ET_TINY_ARGS, 5), (dict(W.ET_TINY_ARGS, neighbor_embedding=False, distance_influence="values"), 6)]:
         torch.manual_seed(seed)
         a = create_model(dict(args))
         torch.manual_seed(seed)

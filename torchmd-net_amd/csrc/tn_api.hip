@@ -14,126 +14,87 @@
 #include <string>
 #include <vector>
 
-#include "../../include/tmdnet_amd.h"
-#include "tn_gemm.h"
-#include "tn_kernels.h"
+#include "tn_model.h"
 
 using namespace tn;
 
-namespace {
-
-struct LayerP {
-  const float *M1, *b1, *M1T, *M2, *b2, *M2T, *M3, *b3, *M3T;
-  const float* V[6];
-  const float* VT[6];
-  const uint16_t* M_sb[3];  // split-bf16 tile images of M1..M3 (tn_gemm_sb.hip)
-};
-
-struct DevParams {
-  const float *means, *betas;
-  const float *Wdp, *bdp, *WdpT;
-  const float *emb, *emb2_w, *emb2_b, *emb2_waT, *emb2_wbT;
-  const float* Ue[3];
-  const float* UeT[3];
-  const float *L1, *bL1, *L1T, *L2, *bL2, *L2T;
-  const float *ln0_w, *ln0_b;
-  std::vector<LayerP> layer;
-  const float *lnr_w, *lnr_b, *Lin, *bLin, *LinT;
-  const float *O1, *bO1, *O1T, *O2, *bO2;
-  const float* atomref;
-  const uint16_t* Wdp_sb;
-  const float *Utab, *Vtab;  // per-type pair-embedding tables (k_ztables at finalize)
-  float mean, std;
-};
-
-struct ParamSpec {
-  std::string name;
-  int64_t rows, cols;  // cols = 1 for vectors
-};
-
-// carve helper: 256-byte aligned sub-buffers of one caller-owned allocation
-struct Carver {
-  char* base;
-  size_t off = 0;
-  explicit Carver(void* p) : base(reinterpret_cast<char*>(p)) {}
-  template <typename T>
-  T* take(int64_t n) {
-    size_t bytes = (size_t)(n > 0 ? n : 0) * sizeof(T);
-    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-    off += (bytes + 255) & ~size_t(255);
-    return p;
-  }
-};
-
-struct FwdBuffers {
-  float *phi, *dphi, *C, *dC;
-  float *Q, *u0, *s0n, *ln0, *xh0, *rstd0, *a1, *h1, *a2, *gates, *UX;
-  std::vector<float*> X;                               // L+1
-  std::vector<float*> w, dw, Pn, Mi, D;                 // per layer (dw = d w / d d, forward tangent)
-  float *he1, *he2, *te1, *te2, *dQ, *Xh, *Ch;
-  float *feat, *lnr, *xhr, *rstdr, *al, *x, *ao, *ea;
-  // reverse
-  float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *gd;
-  float *gUX, *g_a2, *g_a1, *g_ln0, *g_s0n, *g_u0l, *gA, *g_rhat, *g_delta;
-};
-
-}  // namespace
-
-enum ProfCat { CAT_GRAPH = 0, CAT_GEMM_EDGE, CAT_GEMM_NODE, CAT_MESSAGE, CAT_PAIR, CAT_SCATTER, CAT_ELEMENTWISE, CAT_COUNT };
 static const char* kCatNames[CAT_COUNT] = {"graph", "gemm_edge", "gemm_node", "message", "pair_bwd", "embed_scatter", "elementwise"};
-
-struct ProfRec {
-  int cat;
-  hipEvent_t a, b;
-  double flops, bytes;
-};
-struct Profiler {
-  bool on = false;
-  unsigned mask = 0;
-  std::vector<ProfRec> recs;
-  std::vector<hipEvent_t> pool;
-  size_t used = 0;
-  hipEvent_t get() {
-    if (used == pool.size()) {
-      hipEvent_t e;
-      (void)hipEventCreate(&e);
-      pool.push_back(e);
-    }
-    return pool[used++];
-  }
-};
-
-struct tmdnet_model {
-  tmdnet_hparams hp;
-  Profiler prof;
-  int64_t lastE = 0;
-  int cell_n[3] = {0, 0, 0};  // cell grid set by tmdnet_set_cell_grid (0 = brute force)
-  bool graph_is_cell = false; // last build used the cell list (atoms internally renumbered)
-  std::vector<ParamSpec> specs;
-  std::map<std::string, std::vector<float>> host;
-  float* dev = nullptr;  // packed parameters
-  uint16_t* dev_sb = nullptr;  // split-bf16 weight tile images
-  std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
-  DevParams P;
-  bool finalized = false;
-  std::string err;
-  // last-call bookkeeping for tmdnet_debug_tensor
-  FwdBuffers last{};
-  int64_t lastN = 0, lastP = 0;
-  bool has_last = false;
-};
-
-namespace {
 
 int fail(tmdnet_model* m, int code, const std::string& msg) {
   if (m) m->err = msg;
   return code;
 }
-#define HIP_TRY(m, expr)                                                                    \
-  do {                                                                                      \
-    hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess) return fail(m, TMDNET_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-  } while (0)
+thread_local tmdnet_model* g_cur = nullptr;
+thread_local int g_gemm_cat = CAT_GEMM_NODE;
+thread_local const int* g_mdev = nullptr;
+thread_local int g_madd = 0;
+thread_local const uint16_t* g_wsb_debug = nullptr;  // tmdnet_debug_gemm: split image supplied by the caller
+
+void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc, int M,
+          int N, int K, int flags, float* pre, int64_t ldpre, const float* aux, int64_t ldaux,
+          const float* rowscale) {
+  GemmArgs a{};
+  a.A = A;
+  a.W[0] = W;
+  a.C = C;
+  a.bias[0] = bias;
+  a.pre = pre;
+  a.aux = aux;
+  a.rowscale = rowscale;
+  a.lda = lda;
+  a.ldw = ldw;
+  a.ldc = ldc;
+  a.ldpre = ldpre;
+  a.ldaux = ldaux;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.groups = 1;
+  a.flags = flags;
+  a.m_dev = g_mdev;
+  a.m_add = g_madd;
+  if (g_cur && ldw == K) {
+    auto it = g_cur->sb_of.find(W);
+    if (it != g_cur->sb_of.end()) a.Wsbg[0] = it->second;
+  }
+  if (g_wsb_debug) a.Wsbg[0] = g_wsb_debug;
+  // algorithmic traffic: A and W read once, C (and the saved pre-activation / aux operand) once
+  const double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (1 + (pre ? 1 : 0) + (aux ? 1 : 0) + ((flags & GEMM_ACCUM) ? 1 : 0)));
+  ProfScope ps_(s, g_gemm_cat, 2.0 * M * N * K, bytes);
+  launch_gemm(a, s);
+}
+
+// value + tangent through one weight tile (tn_gemm_dual.hip); rows = pairs (device-side count)
+void gemm_dual(hipStream_t s, int kind, const float* A, const float* A2, int64_t lda, const float* W, const float* bias, float* C,
+               float* C2, int64_t ldc, int M, int N, int K, const float* rs, const float* rs2,
+               const uint16_t* Wsb) {
+  GemmArgs a{};
+  a.Wsb = Wsb;
+  a.A = A;
+  a.A2 = A2;
+  a.W[0] = W;
+  a.bias[0] = bias;
+  a.C = C;
+  a.C2 = C2;
+  a.rowscale = rs;
+  a.rowscale2 = rs2;
+  a.lda = lda;
+  a.ldw = K;
+  a.ldc = ldc;
+  a.M = M;
+  a.N = N;
+  a.K = K;
+  a.groups = 1;
+  a.m_dev = g_mdev;
+  a.m_add = g_madd;
+  const double bytes = 4.0 * (2.0 * M * K + (double)N * K + 2.0 * M * N);
+  ProfScope ps_(s, CAT_GEMM_EDGE, 4.0 * M * N * K, bytes);
+  launch_gemm_dual(a, kind, s);
+}
+
+// the three weight matrices act on the channel axis of the 1 + 3 + 5 irreducible components
+// (reference tensornet.py:595-617, 752-754, 808-810): one grouped launch, 9 groups
+namespace {
 
 void build_specs(tmdnet_model* m) {
   const int F = m->hp.hidden_channels, K = m->hp.num_rbf, L = m->hp.num_layers, Z = m->hp.max_z, H = m->hp.head_hidden;
@@ -178,118 +139,6 @@ void build_specs(tmdnet_model* m) {
   if (m->hp.has_atomref) s.push_back({"atomref", Z, 1});
 }
 
-// host-side packer: appends a tensor (optionally transposed) to the staging buffer, 64-float aligned
-struct Packer {
-  std::vector<float> buf;
-  size_t add(const std::vector<float>& v) {
-    size_t off = (buf.size() + 63) & ~size_t(63);
-    buf.resize(off + v.size());
-    std::memcpy(buf.data() + off, v.data(), v.size() * sizeof(float));
-    return off;
-  }
-  size_t add_T(const std::vector<float>& v, int64_t rows, int64_t cols) {
-    std::vector<float> t(v.size());
-    for (int64_t r = 0; r < rows; ++r)
-      for (int64_t c = 0; c < cols; ++c) t[c * rows + r] = v[r * cols + c];
-    return add(t);
-  }
-};
-
-// ---- optional per-launch timing with HIP events on the launch stream (tmdnet_profile_begin/end)
-thread_local tmdnet_model* g_cur = nullptr;
-struct CurScope {  // g_cur is valid exactly while an entry point is enqueueing for that model (also on error returns)
-  explicit CurScope(tmdnet_model* m) { g_cur = m; }
-  ~CurScope() { g_cur = nullptr; }
-};
-thread_local int g_gemm_cat = CAT_GEMM_NODE;
-thread_local const int* g_mdev = nullptr;  // device-side row count of pair-row GEMMs (see GemmArgs::m_dev)
-thread_local int g_madd = 0;
-thread_local const uint16_t* g_wsb_debug = nullptr;  // tmdnet_debug_gemm: split image supplied by the caller
-struct ProfScope {
-  int idx = -1;
-  hipStream_t s;
-  ProfScope(hipStream_t s_, int cat, double flops, double bytes) : s(s_) {
-    tmdnet_model* m = g_cur;
-    if (!m || !m->prof.on || !((m->prof.mask >> cat) & 1u)) return;
-    ProfRec r{cat, m->prof.get(), m->prof.get(), flops, bytes};
-    (void)hipEventRecord(r.a, s);
-    idx = (int)m->prof.recs.size();
-    m->prof.recs.push_back(r);
-  }
-  ~ProfScope() {
-    if (idx >= 0) (void)hipEventRecord(g_cur->prof.recs[idx].b, s);
-  }
-};
-#define KR(cat, bytes, call)                      \
-  do {                                            \
-    ProfScope ps_(s, cat, 0.0, (double)(bytes));  \
-    call;                                         \
-  } while (0)
-
-void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc, int M,
-          int N, int K, int flags = 0, float* pre = nullptr, int64_t ldpre = 0, const float* aux = nullptr, int64_t ldaux = 0,
-          const float* rowscale = nullptr) {
-  GemmArgs a{};
-  a.A = A;
-  a.W[0] = W;
-  a.C = C;
-  a.bias[0] = bias;
-  a.pre = pre;
-  a.aux = aux;
-  a.rowscale = rowscale;
-  a.lda = lda;
-  a.ldw = ldw;
-  a.ldc = ldc;
-  a.ldpre = ldpre;
-  a.ldaux = ldaux;
-  a.M = M;
-  a.N = N;
-  a.K = K;
-  a.groups = 1;
-  a.flags = flags;
-  a.m_dev = g_mdev;
-  a.m_add = g_madd;
-  if (g_cur && ldw == K) {
-    auto it = g_cur->sb_of.find(W);
-    if (it != g_cur->sb_of.end()) a.Wsbg[0] = it->second;
-  }
-  if (g_wsb_debug) a.Wsbg[0] = g_wsb_debug;
-  // algorithmic traffic: A and W read once, C (and the saved pre-activation / aux operand) once
-  const double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (1 + (pre ? 1 : 0) + (aux ? 1 : 0) + ((flags & GEMM_ACCUM) ? 1 : 0)));
-  ProfScope ps_(s, g_gemm_cat, 2.0 * M * N * K, bytes);
-  launch_gemm(a, s);
-}
-
-// value + tangent through one weight tile (tn_gemm_dual.hip); rows = pairs (device-side count)
-void gemm_dual(hipStream_t s, int kind, const float* A, const float* A2, int64_t lda, const float* W, const float* bias, float* C,
-               float* C2, int64_t ldc, int M, int N, int K, const float* rs = nullptr, const float* rs2 = nullptr,
-               const uint16_t* Wsb = nullptr) {
-  GemmArgs a{};
-  a.Wsb = Wsb;
-  a.A = A;
-  a.A2 = A2;
-  a.W[0] = W;
-  a.bias[0] = bias;
-  a.C = C;
-  a.C2 = C2;
-  a.rowscale = rs;
-  a.rowscale2 = rs2;
-  a.lda = lda;
-  a.ldw = K;
-  a.ldc = ldc;
-  a.M = M;
-  a.N = N;
-  a.K = K;
-  a.groups = 1;
-  a.m_dev = g_mdev;
-  a.m_add = g_madd;
-  const double bytes = 4.0 * (2.0 * M * K + (double)N * K + 2.0 * M * N);
-  ProfScope ps_(s, CAT_GEMM_EDGE, 4.0 * M * N * K, bytes);
-  launch_gemm_dual(a, kind, s);
-}
-
-// the three weight matrices act on the channel axis of the 1 + 3 + 5 irreducible components
-// (reference tensornet.py:595-617, 752-754, 808-810): one grouped launch, 9 groups
 void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], float* C, int N, int F, int flags = 0,
                    float* pre = nullptr, const float* gates = nullptr) {
   GemmArgs a{};
@@ -321,6 +170,7 @@ void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], floa
   launch_gemm(a, s);
 }
 
+}  // namespace
 Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   Carver c(ws);
   Graph g{};
@@ -358,6 +208,7 @@ Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
 
 // the cell list applies to ONE periodic orthorhombic system with at least 3 cells per axis (so that the 27
 // neighbour cells are distinct) and a bounded number of cells; everything else takes the brute-force sweep
+namespace {
 bool cell_applicable(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int box_mode) {
   const int* n = m->cell_n;
   if (n_mol != 1 || box_mode != 1) return false;
@@ -458,8 +309,33 @@ int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out) {
   return TMDNET_OK;
 }
 
+int tmdnet_create_et(const tmdnet_et_hparams* hp, tmdnet_model** out) {
+  if (!hp || !out) return TMDNET_ERR_INVALID;
+  if (hp->hidden_channels <= 0 || hp->num_layers < 0 || hp->num_rbf <= 0 || hp->max_z <= 0 || hp->num_heads <= 0 ||
+      hp->max_num_neighbors <= 0 || !(hp->cutoff_upper > hp->cutoff_lower))
+    return TMDNET_ERR_INVALID;
+  tmdnet_model* m = new tmdnet_model();
+  m->hp = tmdnet_hparams{};  // what the graph phase reads
+  m->hp.hidden_channels = hp->hidden_channels;
+  m->hp.num_layers = hp->num_layers;
+  m->hp.num_rbf = hp->num_rbf;
+  m->hp.max_z = hp->max_z;
+  m->hp.max_num_neighbors = hp->max_num_neighbors;
+  m->hp.has_atomref = hp->has_atomref;
+  m->hp.cutoff_lower = hp->cutoff_lower;
+  m->hp.cutoff_upper = hp->cutoff_upper;
+  const int rc = et_create(m, hp);
+  if (rc != TMDNET_OK) {
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return TMDNET_OK;
+}
+
 int tmdnet_destroy(tmdnet_model* m) {
   if (!m) return TMDNET_OK;
+  et_destroy(m);
   if (m->dev) (void)hipFree(m->dev);
   if (m->dev_sb) (void)hipFree(m->dev_sb);
   delete m;
@@ -493,6 +369,7 @@ int tmdnet_set_param(tmdnet_model* m, const char* name, const float* data_host, 
 
 int tmdnet_finalize_params(tmdnet_model* m) {
   if (!m) return TMDNET_ERR_INVALID;
+  if (m->et) return et_finalize(m);
   for (const auto& sp : m->specs)
     if (!m->host.count(sp.name)) return fail(m, TMDNET_ERR_STATE, "missing parameter: " + sp.name);
   const int F = m->hp.hidden_channels, K = m->hp.num_rbf, L = m->hp.num_layers, H = m->hp.head_hidden;
@@ -797,6 +674,7 @@ int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64
   if (!m || !bytes) return TMDNET_ERR_INVALID;
   (void)n_edges;
   if (n_pairs < 0) n_pairs = ((int64_t)m->hp.max_num_neighbors * n_atoms) / 2 + 1;  // static mode: pair capacity
+  if (m->et) return et_forward_workspace_bytes(m, n_atoms, n_mol, n_pairs, want_forces, bytes);
   carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes);
   return TMDNET_OK;
 }
@@ -814,6 +692,16 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   const int64_t ecap = (int64_t)hp.max_num_neighbors * n_atoms;
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, nullptr);
   if (n_pairs > g.pcap) return fail(m, TMDNET_ERR_INVALID, "n_pairs out of range");
+  if (m->et) {
+    if (q) return fail(m, TMDNET_ERR_INVALID, "the Equivariant Transformer takes no total charge (reference torchmd_et.py:188-196)");
+    CurScope cur_(m);
+    if (m->graph_is_cell) {
+      set_cell(g, m, true);
+      launch_permute_z(g, z, (int)n_atoms, s);
+      z = g.z_s;
+    }
+    return et_energy_forces(m, s, g, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, want_forces, energy, forces);
+  }
   // n_pairs >= 0: exact count read back by tmdnet_build_graph (launch grids sized exactly);
   // n_pairs <  0: static mode, grids and workspace sized by the pair capacity, true count read on the device
   const int P = n_pairs >= 0 ? (int)n_pairs : (int)g.pcap, P1 = P + 1;
@@ -982,6 +870,7 @@ const char* tmdnet_profile_category_name(int idx) { return idx >= 0 && idx < CAT
 
 // ------------------------------------------------------------------------------------ diagnostics
 int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* out, int64_t numel) {
+  if (m && m->et) return et_debug_tensor(m, reinterpret_cast<hipStream_t>(stream), name, out, numel);
   if (!m || !name || !out || !m->has_last) return TMDNET_ERR_STATE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t F = m->hp.hidden_channels, K = m->hp.num_rbf, N = m->lastN, P1 = m->lastP + 1;

@@ -1,0 +1,44 @@
+// Launch wrappers of the Equivariant Transformer kernels (tn_et.hip).  Layouts: see tn_et.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tn_kernels.h"
+
+namespace tn {
+
+struct EtAttnArgs {   // per-layer operands of the attention sweeps
+  const float* qkv;   // [N][5F]  q | k | vx | v1 | v2
+  const float* vec;   // [N][3][F] layer input
+  const float* dkv;   // [P+1][Wd] silu(dk_proj phi) | silu(dv_proj phi) (thirds)
+  const float* tkv;   // [P+1][Wd] d/dd of dkv (reverse pass only)
+  const float* C;     // [P+1] cosine cutoff, dC its derivative
+  const float* dC;
+  int F, hd, Wd, dk_off, dv_off;  // *_off = -1: the model has no such projection (factor 1)
+  int vector_cutoff;
+};
+
+void launch_et_embed(const int64_t* z, const float* emb, int N, int F, float* x, hipStream_t s);
+void launch_et_nbr_embed(const Graph& g, int N, int F, const int64_t* z, const float* emb, const float* embN, const float* Wn,
+                         float* xcat, hipStream_t s);
+void launch_et_nbr_embed_bwd(const Graph& g, int Pcap, int F, const int64_t* z, const float* embN, const float* g_xcat,
+                             const float* dWn, float* gd2, hipStream_t s);
+void launch_et_attn_fwd(const Graph& g, int N, const EtAttnArgs& a, float* xagg, float* vagg, hipStream_t s);
+void launch_et_update(const float* x, const float* vec, const float* vp, const float* o, const float* vagg, int N, int F, float* xn,
+                      float* vecn, float* vdot, hipStream_t s);
+void launch_et_update_bwd(const float* g_x, const float* g_vec, const float* vp, const float* o, const float* vdot, int N, int F,
+                          float* g_o, float* g_vp, hipStream_t s);
+void launch_et_attn_bwd_t(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
+                          float* gd2, float* gr2, hipStream_t s);
+void launch_et_attn_bwd_s(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
+                          float* g_vec, hipStream_t s);
+void launch_et_pair_combine(const Graph& g, int Pcap, const float* gd2, const float* gr2, float* gd, float* g_rhat, hipStream_t s);
+void launch_et_cat_norm(const float* xsrc, int Fx, const float* u, int ldu, int Fn, int N, float* hcat, hipStream_t s);
+void launch_et_norm_bwd(const float* g_n, int ldg, const float* u, int ldu, int Fn, int N, float* g_u, int ldgu, hipStream_t s);
+void launch_et_head_mid(const float* y, const float* u2, int ldu, int F2, int N, float* hcat2, float* vq, hipStream_t s);
+void launch_et_head_mid_bwd(const float* y, const float* u2, int ldu, const float* g_h2, const float* g_vq, int F2, int N, float* g_y,
+                            float* g_u2, int ldgu, hipStream_t s);
+void launch_et_copy2d(const float* src, int lds_, float* dst, int ldd, int rows, int cols, hipStream_t s);
+void launch_et_add(const float* in, float* out, int64_t n, hipStream_t s);
+
+}  // namespace tn

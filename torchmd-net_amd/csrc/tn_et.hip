@@ -1,0 +1,478 @@
+// HIP kernels of the Equivariant Transformer energy+force path (reference
+// torchmdnet/models/torchmd_et.py:188-426, models/utils.py:45-117, 583-655, output_modules.py:120-163) for gfx950.
+//
+// Layouts: x [N][F]; vec [N][3][F] (= [3N][F] row-major for the GEMMs); qkv [N][5F] = q | k | vx | v1 | v2 with the
+// reference's per-head value layout [H][3][hd] permuted to thirds at parameter upload, so channel c = h*hd + c' is the
+// same column in every tensor; per-pair dkv [P+1][Wd] = dk (F) | dvx | dv1 | dv2 (only the parts the model has) and
+// its d/dd tangent tkv; the graph is the symmetric CSR of tn_kernels.h (row atom = message TARGET in the forward sweep).
+// rhat(target <- source) = (pos_s - pos_t)/d = -esign * prhat for the row atom as target, +esign * prhat as source.
+//
+// Edge sweeps are row-per-block, one channel per lane, deterministic (no atomics).  The reverse pass runs two sweeps
+// over the same CSR: "t" (row = target: g_q and the per-edge scalars g_d, g_rhat) and "s" (row = source: g_k, g_v,
+// g_vec); both recompute the attention weights instead of storing per-edge activations.
+#include "tn_common.h"
+#include "tn_et.h"
+
+namespace tn {
+
+static inline int cdiv_(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int bthreads(int F) { return ((F + 63) / 64) * 64; }
+
+__device__ __forceinline__ float head_sum(float v, int hd) {  // sum over the hd lanes of one head (hd = 2^k <= 64)
+  for (int off = hd >> 1; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------- embedding
+__global__ void k_et_embed(const int64_t* __restrict__ z, const float* __restrict__ emb, int N, int F, float* __restrict__ x) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  const int n = (int)(idx / F), c = (int)(idx - (int64_t)n * F);
+  x[idx] = emb[z[n] * F + c];
+}
+void launch_et_embed(const int64_t* z, const float* emb, int N, int F, float* x, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_embed, dim3(cdiv_((int64_t)N * F, 256)), dim3(256), 0, s, z, emb, N, F, x);
+}
+
+// xcat[i] = [ emb[z_i] | sum_{j != i} Wn[pair] * embN[z_j] ]      (models/utils.py:100-116; self loops removed)
+__global__ void k_et_nbr_embed(Graph g, int N, int F, const int64_t* __restrict__ z, const float* __restrict__ emb,
+                               const float* __restrict__ embN, const float* __restrict__ Wn, float* __restrict__ xcat) {
+  const int i = xcd_chunk(blockIdx.x, gridDim.x);
+  if (g.counts[2]) return;
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  for (int c = threadIdx.x; c < F; c += blockDim.x) {
+    float acc = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int j = g.col[e];
+      if (j == i) continue;
+      acc += Wn[(int64_t)g.epair[e] * F + c] * embN[z[j] * F + c];
+    }
+    xcat[(int64_t)i * 2 * F + c] = emb[z[i] * F + c];
+    xcat[(int64_t)i * 2 * F + F + c] = acc;
+  }
+}
+void launch_et_nbr_embed(const Graph& g, int N, int F, const int64_t* z, const float* emb, const float* embN, const float* Wn,
+                         float* xcat, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_nbr_embed, dim3(N), dim3(bthreads(F)), 0, s, g, N, F, z, emb, embN, Wn, xcat);
+}
+
+// g_d[pair] += sum_c (g_xn[i,c] embN[z_j,c] + g_xn[j,c] embN[z_i,c]) dWn[pair,c]   (one wave per pair)
+__global__ __launch_bounds__(256) void k_et_nbr_embed_bwd(Graph g, int F, const int64_t* __restrict__ z, const float* __restrict__ embN,
+                                                           const float* __restrict__ g_xcat, const float* __restrict__ dWn,
+                                                           float* __restrict__ gd2) {
+  const int p = xcd_chunk(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= g.counts[0] || g.counts[2]) return;
+  const int i = g.pair_i[p], j = g.pair_j[p];
+  const float* gi = g_xcat + (int64_t)i * 2 * F + F;
+  const float* gj = g_xcat + (int64_t)j * 2 * F + F;
+  const float* ei = embN + z[i] * F;
+  const float* ej = embN + z[j] * F;
+  float acc = 0.f;
+  for (int c = lane; c < F; c += 64) acc += (gi[c] * ej[c] + gj[c] * ei[c]) * dWn[(int64_t)p * F + c];
+  acc = wave_sum(acc);
+  if (lane == 0) gd2[2 * (int64_t)p] += acc;
+}
+void launch_et_nbr_embed_bwd(const Graph& g, int Pcap, int F, const int64_t* z, const float* embN, const float* g_xcat,
+                             const float* dWn, float* gd2, hipStream_t s) {
+  if (Pcap <= 0) return;
+  hipLaunchKernelGGL(k_et_nbr_embed_bwd, dim3(cdiv_(Pcap, 4)), dim3(256), 0, s, g, F, z, embN, g_xcat, dWn, gd2);
+}
+
+// ---------------------------------------------------------------------------------------------- attention, forward
+struct EtEdge {  // what one lane needs for one edge (channel c of the row atom r and the neighbour j)
+  float A, sx, s1, s2, a, cv, ca;
+};
+
+// xagg[t,c] = sum_e sx * A_h ; vagg[t,a,c] = sum_e vec[s,a,c] * s1 + s2 * rhat_a      (torchmd_et.py:376-426)
+__global__ void k_et_attn_fwd(Graph g, EtAttnArgs a, float* __restrict__ xagg, float* __restrict__ vagg) {
+  const int t = xcd_chunk(blockIdx.x, gridDim.x);
+  if (g.counts[2]) return;
+  const int F = a.F, hd = a.hd, c = threadIdx.x;
+  const bool live = c < F;
+  const int cc = live ? c : 0;
+  const int e0 = g.rowptr[t], e1 = g.rowptr[t + 1];
+  const int64_t F5 = 5 * (int64_t)F;
+  const float qt = a.qkv[(int64_t)t * F5 + cc];
+  float xa = 0.f, va0 = 0.f, va1 = 0.f, va2 = 0.f;
+  for (int e = e0; e < e1; ++e) {
+    const int s = g.col[e], p = g.epair[e];
+    const float sg = g.esign[e];
+    const float* qs = a.qkv + (int64_t)s * F5 + cc;
+    const float* dkv = a.dkv + (int64_t)p * a.Wd;
+    const float C = a.C[p];
+    const float cv = a.vector_cutoff ? C : 1.0f, ca = a.vector_cutoff ? 1.0f : C;
+    const float dk = a.dk_off >= 0 ? dkv[a.dk_off + cc] : 1.0f;
+    float ak = live ? qt * qs[F] * dk : 0.f;
+    ak = head_sum(ak, hd);
+    const float A = silu(ak) * ca;
+    float dvx = 1.f, dv1 = 1.f, dv2 = 1.f;
+    if (a.dv_off >= 0) {
+      dvx = dkv[a.dv_off + cc];
+      dv1 = dkv[a.dv_off + F + cc];
+      dv2 = dkv[a.dv_off + 2 * F + cc];
+    }
+    const float sx = qs[2 * F] * cv * dvx, s1 = qs[3 * F] * cv * dv1, s2 = qs[4 * F] * cv * dv2;
+    const float* vs = a.vec + (int64_t)s * 3 * F + cc;
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;  // self edge: rhat = 0 (the self pair's geometry slot is not written)
+    if (sg != 0.f) {
+      r0 = -sg * g.prhat[(int64_t)p * 3];
+      r1 = -sg * g.prhat[(int64_t)p * 3 + 1];
+      r2 = -sg * g.prhat[(int64_t)p * 3 + 2];
+    }
+    xa += sx * A;
+    va0 += vs[0] * s1 + s2 * r0;
+    va1 += vs[F] * s1 + s2 * r1;
+    va2 += vs[2 * F] * s1 + s2 * r2;
+  }
+  if (live) {
+    xagg[(int64_t)t * F + c] = xa;
+    float* o = vagg + (int64_t)t * 3 * F + c;
+    o[0] = va0;
+    o[F] = va1;
+    o[2 * F] = va2;
+  }
+}
+void launch_et_attn_fwd(const Graph& g, int N, const EtAttnArgs& a, float* xagg, float* vagg, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_attn_fwd, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, xagg, vagg);
+}
+
+// x' = x + vdot o2 + o3 ; vec'[a] = vec[a] + vec3[a] o1 + vagg[a] ; vdot = sum_a vec1[a] vec2[a]   (torchmd_et.py:347-353, 215-217)
+__global__ void k_et_update(const float* __restrict__ x, const float* __restrict__ vec, const float* __restrict__ vp,
+                            const float* __restrict__ o, const float* __restrict__ vagg, int N, int F, float* __restrict__ xn,
+                            float* __restrict__ vecn, float* __restrict__ vdot) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  const int n = (int)(idx / F), c = (int)(idx - (int64_t)n * F);
+  const float* vpn = vp + (int64_t)n * 9 * F + c;  // rows n*3+a of [3N][3F]
+  float vd = 0.f;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) vd += vpn[ax * 3 * F] * vpn[ax * 3 * F + F];
+  const float o1 = o[(int64_t)n * 3 * F + c], o2 = o[(int64_t)n * 3 * F + F + c], o3 = o[(int64_t)n * 3 * F + 2 * F + c];
+  vdot[idx] = vd;
+  xn[idx] = x[idx] + vd * o2 + o3;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const int64_t k = (int64_t)n * 3 * F + ax * F + c;
+    vecn[k] = vec[k] + vpn[ax * 3 * F + 2 * F] * o1 + vagg[k];
+  }
+}
+void launch_et_update(const float* x, const float* vec, const float* vp, const float* o, const float* vagg, int N, int F, float* xn,
+                      float* vecn, float* vdot, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_update, dim3(cdiv_((int64_t)N * F, 256)), dim3(256), 0, s, x, vec, vp, o, vagg, N, F, xn, vecn, vdot);
+}
+
+// g_o = (sum_a g_vec[a] vec3[a] | g_x vdot | g_x) ; g_vp[a] = (g_x o2 vec2[a] | g_x o2 vec1[a] | g_vec[a] o1)
+__global__ void k_et_update_bwd(const float* __restrict__ g_x, const float* __restrict__ g_vec, const float* __restrict__ vp,
+                                const float* __restrict__ o, const float* __restrict__ vdot, int N, int F, float* __restrict__ g_o,
+                                float* __restrict__ g_vp) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F) return;
+  const int n = (int)(idx / F), c = (int)(idx - (int64_t)n * F);
+  const float* vpn = vp + (int64_t)n * 9 * F + c;
+  float* gvp = g_vp + (int64_t)n * 9 * F + c;
+  const float gx = g_x[idx];
+  const float o1 = o[(int64_t)n * 3 * F + c], o2 = o[(int64_t)n * 3 * F + F + c];
+  float go1 = 0.f;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const float gv = g_vec[(int64_t)n * 3 * F + ax * F + c];
+    go1 += gv * vpn[ax * 3 * F + 2 * F];
+    gvp[ax * 3 * F] = gx * o2 * vpn[ax * 3 * F + F];
+    gvp[ax * 3 * F + F] = gx * o2 * vpn[ax * 3 * F];
+    gvp[ax * 3 * F + 2 * F] = gv * o1;
+  }
+  g_o[(int64_t)n * 3 * F + c] = go1;
+  g_o[(int64_t)n * 3 * F + F + c] = gx * vdot[idx];
+  g_o[(int64_t)n * 3 * F + 2 * F + c] = gx;
+}
+void launch_et_update_bwd(const float* g_x, const float* g_vec, const float* vp, const float* o, const float* vdot, int N, int F,
+                          float* g_o, float* g_vp, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_update_bwd, dim3(cdiv_((int64_t)N * F, 256)), dim3(256), 0, s, g_x, g_vec, vp, o, vdot, N, F, g_o, g_vp);
+}
+
+// ---------------------------------------------------------------------------------------------- attention, reverse
+// recompute the forward quantities of one edge for channel cc; `tq` = q of the TARGET, `sq` = qkv row of the SOURCE
+__device__ __forceinline__ EtEdge et_edge(const EtAttnArgs& a, float tq, const float* __restrict__ sq, int p, int cc, bool live,
+                                          float& dk, float& dvx, float& dv1, float& dv2) {
+  const int F = a.F;
+  const float* dkv = a.dkv + (int64_t)p * a.Wd;
+  const float C = a.C[p];
+  EtEdge r;
+  r.cv = a.vector_cutoff ? C : 1.0f;
+  r.ca = a.vector_cutoff ? 1.0f : C;
+  dk = a.dk_off >= 0 ? dkv[a.dk_off + cc] : 1.0f;
+  float ak = live ? tq * sq[F] * dk : 0.f;
+  r.a = head_sum(ak, a.hd);
+  r.A = silu(r.a) * r.ca;
+  dvx = dv1 = dv2 = 1.f;
+  if (a.dv_off >= 0) {
+    dvx = dkv[a.dv_off + cc];
+    dv1 = dkv[a.dv_off + F + cc];
+    dv2 = dkv[a.dv_off + 2 * F + cc];
+  }
+  r.sx = sq[2 * F] * r.cv * dvx;
+  r.s1 = sq[3 * F] * r.cv * dv1;
+  r.s2 = sq[4 * F] * r.cv * dv2;
+  return r;
+}
+
+// row = target t.  g_q[t,c] ; per edge: g_d and g_rhat (reduced over channels), accumulated into the pair's slot
+// (slot 0: the row atom is the pair's i, slot 1: it is the pair's j; one writer per slot -> deterministic).
+__global__ void k_et_attn_bwd_t(Graph g, EtAttnArgs a, const float* __restrict__ g_xagg, const float* __restrict__ g_vagg,
+                                float* __restrict__ g_qkv, float* __restrict__ gd2, float* __restrict__ gr2) {
+  __shared__ float part[16][32][4];  // [wave][edge in chunk][g_d, g_rhat xyz]
+  const int t = xcd_chunk(blockIdx.x, gridDim.x);
+  if (g.counts[2]) return;
+  const int F = a.F, c = threadIdx.x, lane = c & 63, wave = c >> 6, nw = blockDim.x >> 6;
+  const bool live = c < F;
+  const int cc = live ? c : 0;
+  const int e0 = g.rowptr[t], e1 = g.rowptr[t + 1];
+  const int64_t F5 = 5 * (int64_t)F;
+  const float qt = a.qkv[(int64_t)t * F5 + cc];
+  const float gxa = live ? g_xagg[(int64_t)t * F + cc] : 0.f;
+  const float* gvp = g_vagg + (int64_t)t * 3 * F + cc;
+  const float gv0 = live ? gvp[0] : 0.f, gv1 = live ? gvp[F] : 0.f, gv2 = live ? gvp[2 * F] : 0.f;
+  float gq = 0.f;
+  for (int eb = e0; eb < e1; eb += 32) {
+    const int n = min(32, e1 - eb);
+    for (int k = 0; k < n; ++k) {
+      const int e = eb + k;
+      const int s = g.col[e], p = g.epair[e];
+      const float sg = g.esign[e];
+      const float* sq = a.qkv + (int64_t)s * F5 + cc;
+      float dk, dvx, dv1, dv2;
+      const EtEdge ed = et_edge(a, qt, sq, p, cc, live, dk, dvx, dv1, dv2);
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+      if (sg != 0.f) {
+        r0 = -sg * g.prhat[(int64_t)p * 3];
+        r1 = -sg * g.prhat[(int64_t)p * 3 + 1];
+        r2 = -sg * g.prhat[(int64_t)p * 3 + 2];
+      }
+      const float* vs = a.vec + (int64_t)s * 3 * F + cc;
+      const float g_sx = gxa * ed.A;
+      const float g_A = head_sum(gxa * ed.sx, a.hd);
+      const float g_s1 = gv0 * vs[0] + gv1 * vs[F] + gv2 * vs[2 * F];
+      const float g_s2 = gv0 * r0 + gv1 * r1 + gv2 * r2;
+      const float g_a = g_A * silu_grad(ed.a) * ed.ca;
+      gq += g_a * sq[F] * dk;
+      // tangents of dk / dv: d/dd of the pair quantities (forward mode), so g_d needs no per-pair gradient arrays
+      const float* tkv = a.tkv + (int64_t)p * a.Wd;
+      const float vxs = sq[2 * F], v1s = sq[3 * F], v2s = sq[4 * F];
+      float gd = 0.f, gcv = 0.f;
+      if (a.dv_off >= 0) gd = ed.cv * (g_sx * vxs * tkv[a.dv_off + cc] + g_s1 * v1s * tkv[a.dv_off + F + cc] + g_s2 * v2s * tkv[a.dv_off + 2 * F + cc]);
+      if (a.dk_off >= 0) gd += g_a * qt * sq[F] * tkv[a.dk_off + cc];
+      gcv = g_sx * vxs * dvx + g_s1 * v1s * dv1 + g_s2 * v2s * dv2;
+      // cutoff factor: on the values (g_cv) or on the attention weight (g_ca = sum_h g_A silu(a); one lane per head adds it)
+      const float gca = ((cc % a.hd) == 0) ? g_A * silu(ed.a) : 0.f;
+      gd += (a.vector_cutoff ? gcv : gca) * a.dC[p];
+      if (!live) gd = 0.f;
+      const float w0 = wave_sum(gd), w1 = wave_sum(live ? gv0 * ed.s2 : 0.f), w2 = wave_sum(live ? gv1 * ed.s2 : 0.f),
+                  w3 = wave_sum(live ? gv2 * ed.s2 : 0.f);
+      if (lane == 0) {
+        part[wave][k][0] = w0;
+        part[wave][k][1] = w1;
+        part[wave][k][2] = w2;
+        part[wave][k][3] = w3;
+      }
+    }
+    __syncthreads();
+    for (int idx = c; idx < n * 4; idx += blockDim.x) {
+      const int k = idx >> 2, comp = idx & 3, e = eb + k;
+      const float sg = g.esign[e];
+      if (sg != 0.f) {  // self edges: d = 0 and rhat = 0 carry no position dependence
+        float v = 0.f;
+        for (int w = 0; w < nw; ++w) v += part[w][k][comp];
+        const int64_t slot = 2 * (int64_t)g.epair[e] + (sg > 0.f ? 0 : 1);
+        if (comp == 0) gd2[slot] += v;
+        else gr2[slot * 3 + comp - 1] += v;
+      }
+    }
+    __syncthreads();
+  }
+  if (live) g_qkv[(int64_t)t * F5 + c] = gq;
+}
+void launch_et_attn_bwd_t(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
+                          float* gd2, float* gr2, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_attn_bwd_t, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, g_xagg, g_vagg, g_qkv, gd2, gr2);
+}
+
+// row = source s: g_k[s], g_vx/v1/v2[s] and g_vec[s] += sum over the targets t of s
+__global__ void k_et_attn_bwd_s(Graph g, EtAttnArgs a, const float* __restrict__ g_xagg, const float* __restrict__ g_vagg,
+                                float* __restrict__ g_qkv, float* __restrict__ g_vec) {
+  const int s = xcd_chunk(blockIdx.x, gridDim.x);
+  if (g.counts[2]) return;
+  const int F = a.F, c = threadIdx.x;
+  const bool live = c < F;
+  const int cc = live ? c : 0;
+  const int e0 = g.rowptr[s], e1 = g.rowptr[s + 1];
+  const int64_t F5 = 5 * (int64_t)F;
+  const float* sq = a.qkv + (int64_t)s * F5 + cc;
+  const float* vs = a.vec + (int64_t)s * 3 * F + cc;
+  const float vs0 = vs[0], vs1 = vs[F], vs2 = vs[2 * F];
+  float gk = 0.f, gvx = 0.f, gv1s = 0.f, gv2s = 0.f, gvec0 = 0.f, gvec1 = 0.f, gvec2 = 0.f;
+  for (int e = e0; e < e1; ++e) {
+    const int t = g.col[e], p = g.epair[e];
+    const float sg = g.esign[e];
+    const float qt = a.qkv[(int64_t)t * F5 + cc];
+    float dk, dvx, dv1, dv2;
+    const EtEdge ed = et_edge(a, qt, sq, p, cc, live, dk, dvx, dv1, dv2);
+    // rhat(t <- s) = (pos_s - pos_t)/d = +esign * prhat when the ROW atom is the source
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    if (sg != 0.f) {
+      r0 = sg * g.prhat[(int64_t)p * 3];
+      r1 = sg * g.prhat[(int64_t)p * 3 + 1];
+      r2 = sg * g.prhat[(int64_t)p * 3 + 2];
+    }
+    const float gxa = live ? g_xagg[(int64_t)t * F + cc] : 0.f;
+    const float* gvp = g_vagg + (int64_t)t * 3 * F + cc;
+    const float gv0 = gvp[0], gv1 = gvp[F], gv2 = gvp[2 * F];
+    const float g_A = head_sum(gxa * ed.sx, a.hd);
+    const float g_a = g_A * silu_grad(ed.a) * ed.ca;
+    gk += g_a * qt * dk;
+    gvx += gxa * ed.A * ed.cv * dvx;
+    gv1s += (gv0 * vs0 + gv1 * vs1 + gv2 * vs2) * ed.cv * dv1;
+    gv2s += (gv0 * r0 + gv1 * r1 + gv2 * r2) * ed.cv * dv2;
+    gvec0 += gv0 * ed.s1;
+    gvec1 += gv1 * ed.s1;
+    gvec2 += gv2 * ed.s1;
+  }
+  if (live) {
+    float* o = g_qkv + (int64_t)s * F5 + c;
+    o[F] = gk;
+    o[2 * F] = gvx;
+    o[3 * F] = gv1s;
+    o[4 * F] = gv2s;
+    float* gv = g_vec + (int64_t)s * 3 * F + c;
+    gv[0] += gvec0;
+    gv[F] += gvec1;
+    gv[2 * F] += gvec2;
+  }
+}
+void launch_et_attn_bwd_s(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
+                          float* g_vec, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_attn_bwd_s, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec);
+}
+
+// gd[p] = gd2[2p] + gd2[2p+1] ; g_prhat[p] = -gr2[2p] + gr2[2p+1]   (rhat of the target sweep = -esign * prhat)
+__global__ void k_et_pair_combine(Graph g, const float* __restrict__ gd2, const float* __restrict__ gr2, float* __restrict__ gd,
+                                  float* __restrict__ g_rhat) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= g.counts[0] || g.counts[2]) return;
+  gd[p] = gd2[2 * (int64_t)p] + gd2[2 * (int64_t)p + 1];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) g_rhat[(int64_t)p * 3 + ax] = -gr2[(2 * (int64_t)p) * 3 + ax] + gr2[(2 * (int64_t)p + 1) * 3 + ax];
+}
+void launch_et_pair_combine(const Graph& g, int Pcap, const float* gd2, const float* gr2, float* gd, float* g_rhat, hipStream_t s) {
+  if (Pcap <= 0) return;
+  hipLaunchKernelGGL(k_et_pair_combine, dim3(cdiv_(Pcap, 256)), dim3(256), 0, s, g, gd2, gr2, gd, g_rhat);
+}
+
+// ---------------------------------------------------------------------------------------------- head (GatedEquivariantBlock)
+// hcat[n] = [ xsrc[n] (Fx, optional) | norm_a u[3n+a] (Fn) ]      (models/utils.py:626-646)
+__global__ void k_et_cat_norm(const float* __restrict__ xsrc, int Fx, const float* __restrict__ u, int ldu, int Fn, int N,
+                              float* __restrict__ hcat) {
+  const int W = Fx + Fn;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * W) return;
+  const int n = (int)(idx / W), c = (int)(idx - (int64_t)n * W);
+  if (c < Fx) {
+    if (xsrc) hcat[idx] = xsrc[(int64_t)n * Fx + c];
+    return;
+  }
+  const float* up = u + (int64_t)n * 3 * ldu + (c - Fx);
+  const float a0 = up[0], a1 = up[ldu], a2 = up[2 * (int64_t)ldu];
+  hcat[idx] = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+}
+void launch_et_cat_norm(const float* xsrc, int Fx, const float* u, int ldu, int Fn, int N, float* hcat, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_cat_norm, dim3(cdiv_((int64_t)N * (Fx + Fn), 256)), dim3(256), 0, s, xsrc, Fx, u, ldu, Fn, N, hcat);
+}
+// g_u[3n+a, c] = g_n[n, c] u[3n+a, c] / |u[., c]|   (0 where the norm is 0: the reference masks those rows)
+__global__ void k_et_norm_bwd(const float* __restrict__ g_n, int ldg, const float* __restrict__ u, int ldu, int Fn, int N,
+                              float* __restrict__ g_u, int ldgu) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * Fn) return;
+  const int n = (int)(idx / Fn), c = (int)(idx - (int64_t)n * Fn);
+  const float* up = u + (int64_t)n * 3 * ldu + c;
+  const float a0 = up[0], a1 = up[ldu], a2 = up[2 * (int64_t)ldu];
+  const float nn = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  const float k = nn > 0.f ? g_n[(int64_t)n * ldg + c] / nn : 0.f;
+  float* o = g_u + (int64_t)n * 3 * ldgu + c;
+  o[0] = k * a0;
+  o[ldgu] = k * a1;
+  o[2 * (int64_t)ldgu] = k * a2;
+}
+void launch_et_norm_bwd(const float* g_n, int ldg, const float* u, int ldu, int Fn, int N, float* g_u, int ldgu, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_norm_bwd, dim3(cdiv_((int64_t)N * Fn, 256)), dim3(256), 0, s, g_n, ldg, u, ldu, Fn, N, g_u, ldgu);
+}
+// y [N][2 F2] -> hcat2[:, :F2] = silu(y[:, :F2]) ; vq[3n+a, c] = y[n, F2 + c] * u2[3n+a, c]
+__global__ void k_et_head_mid(const float* __restrict__ y, const float* __restrict__ u2, int ldu, int F2, int N,
+                              float* __restrict__ hcat2, float* __restrict__ vq) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F2) return;
+  const int n = (int)(idx / F2), c = (int)(idx - (int64_t)n * F2);
+  hcat2[(int64_t)n * 2 * F2 + c] = silu(y[(int64_t)n * 2 * F2 + c]);
+  const float gate = y[(int64_t)n * 2 * F2 + F2 + c];
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) vq[((int64_t)n * 3 + ax) * F2 + c] = gate * u2[((int64_t)n * 3 + ax) * ldu + c];
+}
+void launch_et_head_mid(const float* y, const float* u2, int ldu, int F2, int N, float* hcat2, float* vq, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_head_mid, dim3(cdiv_((int64_t)N * F2, 256)), dim3(256), 0, s, y, u2, ldu, F2, N, hcat2, vq);
+}
+// g_y = [ g_xs silu'(y[:, :F2]) | sum_a g_vq u2 ] ; g_u2[3n+a, c] = g_vq[3n+a, c] * gate[n, c]
+__global__ void k_et_head_mid_bwd(const float* __restrict__ y, const float* __restrict__ u2, int ldu, const float* __restrict__ g_h2,
+                                  const float* __restrict__ g_vq, int F2, int N, float* __restrict__ g_y, float* __restrict__ g_u2,
+                                  int ldgu) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * F2) return;
+  const int n = (int)(idx / F2), c = (int)(idx - (int64_t)n * F2);
+  const float gate = y[(int64_t)n * 2 * F2 + F2 + c];
+  float gg = 0.f;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const float gv = g_vq[((int64_t)n * 3 + ax) * F2 + c];
+    gg += gv * u2[((int64_t)n * 3 + ax) * ldu + c];
+    g_u2[((int64_t)n * 3 + ax) * ldgu + c] = gv * gate;
+  }
+  g_y[(int64_t)n * 2 * F2 + c] = g_h2[(int64_t)n * 2 * F2 + c] * silu_grad(y[(int64_t)n * 2 * F2 + c]);
+  g_y[(int64_t)n * 2 * F2 + F2 + c] = gg;
+}
+void launch_et_head_mid_bwd(const float* y, const float* u2, int ldu, const float* g_h2, const float* g_vq, int F2, int N, float* g_y,
+                            float* g_u2, int ldgu, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_head_mid_bwd, dim3(cdiv_((int64_t)N * F2, 256)), dim3(256), 0, s, y, u2, ldu, g_h2, g_vq, F2, N, g_y, g_u2,
+                     ldgu);
+}
+
+// dst[r, 0:cols] = src[r, 0:cols] (kernels, not memcpy nodes: HIP-graph replay, see profiles/r01_notes.md)
+__global__ void k_et_copy2d(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int rows, int cols) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)rows * cols) return;
+  const int r = (int)(idx / cols), c = (int)(idx - (int64_t)r * cols);
+  dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds_ + c];
+}
+void launch_et_copy2d(const float* src, int lds_, float* dst, int ldd, int rows, int cols, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return;
+  hipLaunchKernelGGL(k_et_copy2d, dim3(cdiv_((int64_t)rows * cols, 256)), dim3(256), 0, s, src, lds_, dst, ldd, rows, cols);
+}
+
+// out[i] += in[i]
+__global__ void k_et_axpy(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += in[i];
+}
+void launch_et_add(const float* in, float* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_et_axpy, dim3(cdiv_(n, 256)), dim3(256), 0, s, in, out, n);
+}
+
+}  // namespace tn

@@ -1,0 +1,531 @@
+// Equivariant Transformer + EquivariantScalar head behind the same C ABI as TensorNet (include/tmdnet_amd.h,
+// tmdnet_create_et): parameter packing, workspace carving and the kernel schedule of forward + hand-written reverse.
+//
+// Schedule = reference call stack TorchMD_Net.forward -> TorchMD_ET.forward -> NeighborEmbedding ->
+// EquivariantMultiHeadAttention x L -> out_norm -> EquivariantScalar (2 GatedEquivariantBlocks) -> reduce
+// (torchmdnet/models/model.py:530-631, torchmd_et.py:188-426, models/utils.py:45-117, 583-655,
+// output_modules.py:43-73, 120-163), followed by the explicit adjoints specified in oracle/et_adjoint.py.
+// Every dense contraction goes through gemm()/gemm_dual() (bf16 matrix pipe, exact 3-way split); the per-pair
+// quantities (phi, C, dk, dv, the neighbour-embedding filter) are evaluated once per undirected pair together with
+// their d/dd tangents, exactly as in the TensorNet path.
+#include <cstdio>
+#include <cstdlib>
+
+#include "tn_et.h"
+#include "tn_model.h"
+
+namespace {
+
+struct EtLayerP {
+  const float *ln_w, *ln_b;
+  const float *Wqkv, *bqkv;      // [5F][F]: q | k | vx | v1 | v2 (value rows permuted to thirds)
+  const float *WqkvT;            // [F][5F]
+  const float *Wvp, *WvpT;       // [3F][F] (no bias), [F][3F]
+  const float *Wo, *bo, *WoT;    // [3F][F], [F][3F]
+  const float *Wdkv, *bdkv;      // [Wd][K]: dk | dvx | dv1 | dv2 (the parts the model has)
+  const uint16_t* Wdkv_sb;
+};
+
+struct EtParams {
+  const float *means, *betas, *emb;
+  const float *embN, *Wn, *bn, *Wc, *bc, *WcT;  // neighbour embedding (Wc [F][2F])
+  const uint16_t* Wn_sb;
+  std::vector<EtLayerP> layer;
+  const float *lno_w, *lno_b;
+  const float *W1u, *W1uT;            // [F + F/2][F] = vec1_proj | vec2_proj of block 0 ; transposed [F][F + F/2]
+  const float *Wm1, *bm1, *Wm1T;      // [F][2F]
+  const float *Wm2, *bm2, *Wm2T;      // [F][F]
+  const float *W21, *W21T;            // [F/2][F/2]
+  const float *Wn1, *bn1, *Wn1T;      // [F/2][F]
+  const float *Wn2, *bn2;             // row 0 of [2][F/2], bias[0]
+  const float* atomref;
+  float mean, std;
+};
+
+struct EtBuffers {
+  float *phi, *dphi, *C, *dC, *Wn, *dWn, *xcat;
+  std::vector<float*> x, vec;                               // L+1
+  std::vector<float*> xt, xh, rstd, qkv, vp, o, vdot, dkv, tkv;  // per layer
+  float *xagg, *vagg;
+  float *xf, *xfh, *rstdf, *u12, *hcat, *pre1, *m1, *y, *hcat2, *vq, *w1, *pre2, *m2, *ea;
+  // reverse
+  float *g_pre2, *g_h2, *g_w1, *g_vq, *g_y, *g_m1, *g_h1, *g_u12, *g_xf, *g_x, *g_vec, *g_o, *g_vp, *g_xagg, *g_qkv, *g_xt, *g_ln,
+      *g_xcat, *gd2, *gr2, *gd, *g_rhat, *g_delta;
+};
+
+}  // namespace
+
+struct EtModel {
+  tmdnet_et_hparams hp;
+  EtParams P;
+  EtBuffers last{};
+  int64_t lastN = 0;
+  bool has_last = false;
+};
+
+namespace {
+
+int wd_of(const tmdnet_et_hparams& hp) {
+  const int F = hp.hidden_channels;
+  return ((hp.distance_influence & 1) ? F : 0) + ((hp.distance_influence & 2) ? 3 * F : 0);
+}
+
+void et_build_specs(tmdnet_model* m) {
+  const tmdnet_et_hparams& hp = m->et->hp;
+  const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, F2 = F / 2;
+  auto& s = m->specs;
+  const std::string R = "representation_model.";
+  s.push_back({R + "embedding.weight", Z, F});
+  s.push_back({R + "distance_expansion.means", K, 1});
+  s.push_back({R + "distance_expansion.betas", K, 1});
+  if (hp.neighbor_embedding) {
+    const std::string Np = R + "neighbor_embedding.";
+    s.push_back({Np + "embedding.weight", Z, F});
+    s.push_back({Np + "distance_proj.weight", F, K});
+    s.push_back({Np + "distance_proj.bias", F, 1});
+    s.push_back({Np + "combine.weight", F, 2 * F});
+    s.push_back({Np + "combine.bias", F, 1});
+  }
+  for (int l = 0; l < L; ++l) {
+    const std::string Lp = R + "attention_layers." + std::to_string(l) + ".";
+    s.push_back({Lp + "layernorm.weight", F, 1});
+    s.push_back({Lp + "layernorm.bias", F, 1});
+    s.push_back({Lp + "q_proj.weight", F, F});
+    s.push_back({Lp + "q_proj.bias", F, 1});
+    s.push_back({Lp + "k_proj.weight", F, F});
+    s.push_back({Lp + "k_proj.bias", F, 1});
+    s.push_back({Lp + "v_proj.weight", 3 * F, F});
+    s.push_back({Lp + "v_proj.bias", 3 * F, 1});
+    s.push_back({Lp + "o_proj.weight", 3 * F, F});
+    s.push_back({Lp + "o_proj.bias", 3 * F, 1});
+    s.push_back({Lp + "vec_proj.weight", 3 * F, F});
+    if (hp.distance_influence & 1) {
+      s.push_back({Lp + "dk_proj.weight", F, K});
+      s.push_back({Lp + "dk_proj.bias", F, 1});
+    }
+    if (hp.distance_influence & 2) {
+      s.push_back({Lp + "dv_proj.weight", 3 * F, K});
+      s.push_back({Lp + "dv_proj.bias", 3 * F, 1});
+    }
+  }
+  s.push_back({R + "out_norm.weight", F, 1});
+  s.push_back({R + "out_norm.bias", F, 1});
+  const std::string O0 = "output_model.output_network.0.", O1 = "output_model.output_network.1.";
+  s.push_back({O0 + "vec1_proj.weight", F, F});
+  s.push_back({O0 + "vec2_proj.weight", F2, F});
+  s.push_back({O0 + "update_net.layers.0.weight", F, 2 * F});
+  s.push_back({O0 + "update_net.layers.0.bias", F, 1});
+  s.push_back({O0 + "update_net.layers.2.weight", F, F});
+  s.push_back({O0 + "update_net.layers.2.bias", F, 1});
+  s.push_back({O1 + "vec1_proj.weight", F2, F2});
+  s.push_back({O1 + "vec2_proj.weight", 1, F2});
+  s.push_back({O1 + "update_net.layers.0.weight", F2, F});
+  s.push_back({O1 + "update_net.layers.0.bias", F2, 1});
+  s.push_back({O1 + "update_net.layers.2.weight", 2, F2});
+  s.push_back({O1 + "update_net.layers.2.bias", 2, 1});
+  s.push_back({"mean", 1, 1});
+  s.push_back({"std", 1, 1});
+  if (hp.has_atomref) s.push_back({"atomref", Z, 1});
+}
+
+// rows of a [3F][cols] value-type matrix from the reference's per-head layout [H][3][hd] to thirds [3][F]
+std::vector<float> thirds(const std::vector<float>& w, int F, int hd, int64_t cols) {
+  std::vector<float> o(w.size());
+  for (int t = 0; t < 3; ++t)
+    for (int c = 0; c < F; ++c) {
+      const int64_t src = (int64_t)(c / hd) * 3 * hd + t * hd + c % hd, dst = (int64_t)t * F + c;
+      std::memcpy(o.data() + dst * cols, w.data() + src * cols, cols * sizeof(float));
+    }
+  return o;
+}
+std::vector<float> cat(std::initializer_list<const std::vector<float>*> parts) {
+  std::vector<float> o;
+  for (auto* p : parts) o.insert(o.end(), p->begin(), p->end());
+  return o;
+}
+
+EtBuffers et_carve(void* ws, const tmdnet_et_hparams& hp, int64_t N, int64_t B, int64_t P, bool bwd, size_t* total) {
+  Carver c(ws);
+  EtBuffers b{};
+  const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, F2 = F / 2, P1 = P + 1, Wd = wd_of(hp);
+  b.phi = c.take<float>(P1 * K);
+  b.dphi = c.take<float>(P1 * K);
+  b.C = c.take<float>(P1);
+  b.dC = c.take<float>(P1);
+  if (hp.neighbor_embedding) {
+    b.Wn = c.take<float>(P1 * F);
+    b.dWn = c.take<float>(P1 * F);
+    b.xcat = c.take<float>(N * 2 * F);
+  }
+  for (int l = 0; l <= L; ++l) {
+    b.x.push_back(c.take<float>(N * F));
+    b.vec.push_back(c.take<float>(N * 3 * F));
+  }
+  for (int l = 0; l < L; ++l) {
+    b.xt.push_back(c.take<float>(N * F));
+    b.xh.push_back(c.take<float>(N * F));
+    b.rstd.push_back(c.take<float>(N));
+    b.qkv.push_back(c.take<float>(N * 5 * F));
+    b.vp.push_back(c.take<float>(N * 9 * F));
+    b.o.push_back(c.take<float>(N * 3 * F));
+    b.vdot.push_back(c.take<float>(N * F));
+    b.dkv.push_back(c.take<float>(P1 * Wd));
+    b.tkv.push_back(c.take<float>(P1 * Wd));
+  }
+  b.xagg = c.take<float>(N * F);
+  b.vagg = c.take<float>(N * 3 * F);
+  b.xf = c.take<float>(N * F);
+  b.xfh = c.take<float>(N * F);
+  b.rstdf = c.take<float>(N);
+  b.u12 = c.take<float>(N * 3 * (F + F2));
+  b.hcat = c.take<float>(N * 2 * F);
+  b.pre1 = c.take<float>(N * F);
+  b.m1 = c.take<float>(N * F);
+  b.y = c.take<float>(N * F);
+  b.hcat2 = c.take<float>(N * F);
+  b.vq = c.take<float>(N * 3 * F2);
+  b.w1 = c.take<float>(N * 3 * F2);
+  b.pre2 = c.take<float>(N * F2);
+  b.m2 = c.take<float>(N * F2);
+  b.ea = c.take<float>(N);
+  if (bwd) {
+    b.g_pre2 = c.take<float>(N * F2);
+    b.g_h2 = c.take<float>(N * F);
+    b.g_w1 = c.take<float>(N * 3 * F2);
+    b.g_vq = c.take<float>(N * 3 * F2);
+    b.g_y = c.take<float>(N * F);
+    b.g_m1 = c.take<float>(N * F);
+    b.g_h1 = c.take<float>(N * 2 * F);
+    b.g_u12 = c.take<float>(N * 3 * (F + F2));
+    b.g_xf = c.take<float>(N * F);
+    b.g_x = c.take<float>(N * F);
+    b.g_vec = c.take<float>(N * 3 * F);
+    b.g_o = c.take<float>(N * 3 * F);
+    b.g_vp = c.take<float>(N * 9 * F);
+    b.g_xagg = c.take<float>(N * F);
+    b.g_qkv = c.take<float>(N * 5 * F);
+    b.g_xt = c.take<float>(N * F);
+    b.g_ln = c.take<float>(N * F);
+    b.g_xcat = c.take<float>(N * 2 * F);
+    b.gd2 = c.take<float>(2 * P1);
+    b.gr2 = c.take<float>(6 * P1);
+    b.gd = c.take<float>(P1);
+    b.g_rhat = c.take<float>(3 * P1);
+    b.g_delta = c.take<float>(3 * P1);
+  }
+  (void)B;
+  if (total) *total = c.off;
+  return b;
+}
+
+}  // namespace
+
+int et_create(tmdnet_model* m, const tmdnet_et_hparams* hp) {
+  const int F = hp->hidden_channels, H = hp->num_heads;
+  if (F % H) return TMDNET_ERR_INVALID;
+  const int hd = F / H;
+  if (hd > 64 || (hd & (hd - 1)) || (F & 1) || F > 1024) return TMDNET_ERR_INVALID;  // head reductions are wave shuffles
+  if (hp->cutoff_lower != 0.0f) return TMDNET_ERR_INVALID;
+  m->et = new EtModel();
+  m->et->hp = *hp;
+  et_build_specs(m);
+  return TMDNET_OK;
+}
+
+void et_destroy(tmdnet_model* m) {
+  if (m && m->et) {
+    delete m->et;
+    m->et = nullptr;
+  }
+}
+
+int et_finalize(tmdnet_model* m) {
+  for (const auto& sp : m->specs)
+    if (!m->host.count(sp.name)) return fail(m, TMDNET_ERR_STATE, "missing parameter: " + sp.name);
+  const tmdnet_et_hparams& hp = m->et->hp;
+  const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, F2 = F / 2, hd = F / hp.num_heads, Wd = wd_of(hp);
+  const std::string R = "representation_model.", Np = R + "neighbor_embedding.";
+  auto& h = m->host;
+  Packer pk;
+  std::map<std::string, size_t> off;
+  struct Img { std::string key; int64_t n, k; };
+  std::vector<Img> imgs;
+  auto put = [&](const std::string& key, const std::vector<float>& v) { off[key] = pk.add(v); };
+  auto putW = [&](const std::string& key, const std::vector<float>& v, int64_t n, int64_t k) {  // GEMM weight [n][k] + transpose
+    off[key] = pk.add(v);
+    off[key + "T"] = pk.add_T(v, n, k);
+    imgs.push_back({key, n, k});
+    imgs.push_back({key + "T", k, n});
+  };
+  put("means", h[R + "distance_expansion.means"]);
+  put("betas", h[R + "distance_expansion.betas"]);
+  put("emb", h[R + "embedding.weight"]);
+  if (hp.neighbor_embedding) {
+    put("embN", h[Np + "embedding.weight"]);
+    putW("Wn", h[Np + "distance_proj.weight"], F, K);
+    put("bn", h[Np + "distance_proj.bias"]);
+    putW("Wc", h[Np + "combine.weight"], F, 2 * F);
+    put("bc", h[Np + "combine.bias"]);
+  }
+  for (int l = 0; l < L; ++l) {
+    const std::string Lp = R + "attention_layers." + std::to_string(l) + ".", t = "l" + std::to_string(l) + ".";
+    put(t + "ln_w", h[Lp + "layernorm.weight"]);
+    put(t + "ln_b", h[Lp + "layernorm.bias"]);
+    const auto wv = thirds(h[Lp + "v_proj.weight"], F, hd, F), bv = thirds(h[Lp + "v_proj.bias"], F, hd, 1);
+    putW(t + "Wqkv", cat({&h[Lp + "q_proj.weight"], &h[Lp + "k_proj.weight"], &wv}), 5 * F, F);
+    put(t + "bqkv", cat({&h[Lp + "q_proj.bias"], &h[Lp + "k_proj.bias"], &bv}));
+    putW(t + "Wvp", h[Lp + "vec_proj.weight"], 3 * F, F);
+    putW(t + "Wo", h[Lp + "o_proj.weight"], 3 * F, F);
+    put(t + "bo", h[Lp + "o_proj.bias"]);
+    if (Wd > 0) {
+      std::vector<float> w, b;
+      if (hp.distance_influence & 1) {
+        w = h[Lp + "dk_proj.weight"];
+        b = h[Lp + "dk_proj.bias"];
+      }
+      if (hp.distance_influence & 2) {
+        const auto wd = thirds(h[Lp + "dv_proj.weight"], F, hd, K), bd = thirds(h[Lp + "dv_proj.bias"], F, hd, 1);
+        w.insert(w.end(), wd.begin(), wd.end());
+        b.insert(b.end(), bd.begin(), bd.end());
+      }
+      putW(t + "Wdkv", w, Wd, K);
+      put(t + "bdkv", b);
+    }
+  }
+  put("lno_w", h[R + "out_norm.weight"]);
+  put("lno_b", h[R + "out_norm.bias"]);
+  const std::string O0 = "output_model.output_network.0.", O1 = "output_model.output_network.1.";
+  putW("W1u", cat({&h[O0 + "vec1_proj.weight"], &h[O0 + "vec2_proj.weight"]}), F + F2, F);
+  putW("Wm1", h[O0 + "update_net.layers.0.weight"], F, 2 * F);
+  put("bm1", h[O0 + "update_net.layers.0.bias"]);
+  putW("Wm2", h[O0 + "update_net.layers.2.weight"], F, F);
+  put("bm2", h[O0 + "update_net.layers.2.bias"]);
+  putW("W21", h[O1 + "vec1_proj.weight"], F2, F2);
+  putW("Wn1", h[O1 + "update_net.layers.0.weight"], F2, F);
+  put("bn1", h[O1 + "update_net.layers.0.bias"]);
+  put("Wn2", h[O1 + "update_net.layers.2.weight"]);  // row 0 = the scalar output (row 1 gates a vector that is dropped)
+  put("bn2", h[O1 + "update_net.layers.2.bias"]);
+  if (hp.has_atomref) put("atomref", h["atomref"]);
+
+  if (m->dev) {
+    HIP_TRY(m, hipFree(m->dev));
+    m->dev = nullptr;
+  }
+  HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev), pk.buf.size() * sizeof(float)));
+  HIP_TRY(m, hipMemcpy(m->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice));
+  {  // split-bf16 tile images of every GEMM weight
+    std::vector<uint16_t> sb;
+    std::vector<size_t> so;
+    for (const auto& im : imgs) {
+      so.push_back(sb.size());
+      sb.resize(sb.size() + split_weight_elems(im.n, im.k));
+      split_weight_tiles(pk.buf.data() + off.at(im.key), im.n, im.k, sb.data() + so.back());
+    }
+    if (m->dev_sb) {
+      HIP_TRY(m, hipFree(m->dev_sb));
+      m->dev_sb = nullptr;
+    }
+    HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev_sb), sb.size() * sizeof(uint16_t)));
+    HIP_TRY(m, hipMemcpy(m->dev_sb, sb.data(), sb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    m->sb_of.clear();
+    for (size_t i = 0; i < imgs.size(); ++i) m->sb_of[m->dev + off.at(imgs[i].key)] = m->dev_sb + so[i];
+  }
+  auto D = [&](const std::string& key) -> const float* { return m->dev + off.at(key); };
+  EtParams& P = m->et->P;
+  P = EtParams{};
+  P.means = D("means");
+  P.betas = D("betas");
+  P.emb = D("emb");
+  if (hp.neighbor_embedding) {
+    P.embN = D("embN");
+    P.Wn = D("Wn");
+    P.bn = D("bn");
+    P.Wc = D("Wc");
+    P.bc = D("bc");
+    P.WcT = D("WcT");
+    P.Wn_sb = m->sb_of.at(P.Wn);
+  }
+  P.layer.resize(L);
+  for (int l = 0; l < L; ++l) {
+    const std::string t = "l" + std::to_string(l) + ".";
+    EtLayerP& q = P.layer[l];
+    q.ln_w = D(t + "ln_w");
+    q.ln_b = D(t + "ln_b");
+    q.Wqkv = D(t + "Wqkv");
+    q.bqkv = D(t + "bqkv");
+    q.WqkvT = D(t + "WqkvT");
+    q.Wvp = D(t + "Wvp");
+    q.WvpT = D(t + "WvpT");
+    q.Wo = D(t + "Wo");
+    q.bo = D(t + "bo");
+    q.WoT = D(t + "WoT");
+    if (Wd > 0) {
+      q.Wdkv = D(t + "Wdkv");
+      q.bdkv = D(t + "bdkv");
+      q.Wdkv_sb = m->sb_of.at(q.Wdkv);
+    }
+  }
+  P.lno_w = D("lno_w");
+  P.lno_b = D("lno_b");
+  P.W1u = D("W1u");
+  P.W1uT = D("W1uT");
+  P.Wm1 = D("Wm1");
+  P.bm1 = D("bm1");
+  P.Wm1T = D("Wm1T");
+  P.Wm2 = D("Wm2");
+  P.bm2 = D("bm2");
+  P.Wm2T = D("Wm2T");
+  P.W21 = D("W21");
+  P.W21T = D("W21T");
+  P.Wn1 = D("Wn1");
+  P.bn1 = D("bn1");
+  P.Wn1T = D("Wn1T");
+  P.Wn2 = D("Wn2");
+  P.bn2 = D("bn2");
+  P.atomref = hp.has_atomref ? D("atomref") : nullptr;
+  P.mean = h["mean"][0];
+  P.std = h["std"][0];
+  m->finalized = true;
+  return TMDNET_OK;
+}
+
+int et_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int32_t want_forces,
+                               size_t* bytes) {
+  et_carve(nullptr, m->et->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes);
+  return TMDNET_OK;
+}
+
+int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
+                     int64_t n_pairs, const int64_t* z, const int64_t* batch, int32_t want_forces, float* energy, float* forces) {
+  const tmdnet_et_hparams& hp = m->et->hp;
+  const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, F2 = F / 2, hd = F / hp.num_heads, Wd = wd_of(hp);
+  const int N = (int)n_atoms, B = (int)n_mol;
+  const int P = n_pairs >= 0 ? (int)n_pairs : (int)g.pcap, P1 = P + 1;
+  size_t need = 0;
+  EtBuffers b = et_carve(ws, hp, n_atoms, n_mol, P, want_forces != 0, &need);
+  if (need > ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "forward workspace too small: need " + std::to_string(need));
+  const EtParams& W = m->et->P;
+  const int* perm = m->graph_is_cell ? g.perm : nullptr;
+  auto EDGE = [&](int add) { g_gemm_cat = CAT_GEMM_EDGE; g_mdev = n_pairs < 0 ? g.counts : nullptr; g_madd = add; };
+  auto NODE = [&]() { g_gemm_cat = CAT_GEMM_NODE; g_mdev = nullptr; g_madd = 0; };
+  const double Nd = N, Pd = P, Fd = F, Ed = (double)m->lastE;
+
+  // ---------------- forward
+  KR(CAT_ELEMENTWISE, Pd * K * 8, launch_radial(g, P, RadialParams{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper}, b.phi, b.dphi, b.C, b.dC, s));
+  if (hp.neighbor_embedding) {
+    EDGE(1);
+    gemm_dual(s, 3, b.phi, b.dphi, K, W.Wn, W.bn, b.Wn, b.dWn, F, P1, F, K, b.C, b.dC, W.Wn_sb);
+    KR(CAT_SCATTER, Ed * Fd * 8, launch_et_nbr_embed(g, N, F, z, W.emb, W.embN, b.Wn, b.xcat, s));
+    NODE();
+    gemm(s, b.xcat, 2 * F, W.Wc, 2 * F, W.bc, b.x[0], F, N, F, 2 * F);
+  } else {
+    KR(CAT_ELEMENTWISE, Nd * Fd * 4, launch_et_embed(z, W.emb, N, F, b.x[0], s));
+  }
+  KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_fill(b.vec[0], 0.f, (int64_t)N * 3 * F, s));
+  std::vector<EtAttnArgs> aa(L);
+  for (int l = 0; l < L; ++l) {
+    const EtLayerP& q = W.layer[l];
+    NODE();
+    KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.x[l], q.ln_w, q.ln_b, N, F, b.xt[l], b.xh[l], b.rstd[l], s));
+    gemm(s, b.xt[l], F, q.Wqkv, F, q.bqkv, b.qkv[l], 5 * F, N, 5 * F, F);
+    gemm(s, b.vec[l], F, q.Wvp, F, nullptr, b.vp[l], 3 * F, 3 * N, 3 * F, F);
+    if (Wd > 0) {
+      EDGE(1);
+      gemm_dual(s, 1, b.phi, b.dphi, K, q.Wdkv, q.bdkv, b.dkv[l], b.tkv[l], Wd, P1, Wd, K, nullptr, nullptr, q.Wdkv_sb);
+    }
+    EtAttnArgs& a = aa[l];
+    a = EtAttnArgs{b.qkv[l], b.vec[l], b.dkv[l], b.tkv[l], b.C, b.dC, F, hd, Wd,
+                   (hp.distance_influence & 1) ? 0 : -1, (hp.distance_influence & 2) ? ((hp.distance_influence & 1) ? F : 0) : -1,
+                   hp.vector_cutoff};
+    KR(CAT_MESSAGE, Ed * Fd * 4 * 12, launch_et_attn_fwd(g, N, a, b.xagg, b.vagg, s));
+    NODE();
+    gemm(s, b.xagg, F, q.Wo, F, q.bo, b.o[l], 3 * F, N, 3 * F, F);
+    KR(CAT_ELEMENTWISE, Nd * Fd * 4 * 20,
+       launch_et_update(b.x[l], b.vec[l], b.vp[l], b.o[l], b.vagg, N, F, b.x[l + 1], b.vec[l + 1], b.vdot[l], s));
+  }
+  NODE();
+  KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.x[L], W.lno_w, W.lno_b, N, F, b.xf, b.xfh, b.rstdf, s));
+  const int U = F + F2;  // u12 row width: vec1_proj | vec2_proj of head block 0
+  gemm(s, b.vec[L], F, W.W1u, F, nullptr, b.u12, U, 3 * N, U, F);
+  KR(CAT_ELEMENTWISE, Nd * Fd * 24, launch_et_cat_norm(b.xf, F, b.u12, U, F, N, b.hcat, s));
+  gemm(s, b.hcat, 2 * F, W.Wm1, 2 * F, W.bm1, b.m1, F, N, F, 2 * F, GEMM_ACT_SILU, b.pre1, F);
+  gemm(s, b.m1, F, W.Wm2, F, W.bm2, b.y, F, N, F, F);
+  KR(CAT_ELEMENTWISE, Nd * Fd * 16, launch_et_head_mid(b.y, b.u12 + F, U, F2, N, b.hcat2, b.vq, s));
+  gemm(s, b.vq, F2, W.W21, F2, nullptr, b.w1, F2, 3 * N, F2, F2);
+  KR(CAT_ELEMENTWISE, Nd * Fd * 8, launch_et_cat_norm(nullptr, F2, b.w1, F2, F2, N, b.hcat2, s));
+  gemm(s, b.hcat2, F, W.Wn1, F, W.bn1, b.m2, F2, N, F2, F, GEMM_ACT_SILU, b.pre2, F2);
+  KR(CAT_ELEMENTWISE, Nd * F2 * 4, launch_head_energy(b.pre2, W.Wn2, W.bn2, N, F2, W.std, W.atomref, z, b.ea, s));
+  KR(CAT_ELEMENTWISE, Nd * 12, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
+
+  // ---------------- reverse (oracle/et_adjoint.py)
+  if (want_forces) {
+    NODE();
+    KR(CAT_ELEMENTWISE, Nd * F2 * 8, launch_head_bwd(b.pre2, W.Wn2, N, F2, W.std, b.g_pre2, s));
+    gemm(s, b.g_pre2, F2, W.Wn1T, F2, nullptr, b.g_h2, F, N, F, F2);                       // (g_xs | g_n2)
+    KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_et_norm_bwd(b.g_h2 + F2, F, b.w1, F2, F2, N, b.g_w1, F2, s));
+    gemm(s, b.g_w1, F2, W.W21T, F2, nullptr, b.g_vq, F2, 3 * N, F2, F2);
+    KR(CAT_ELEMENTWISE, Nd * Fd * 20,
+       launch_et_head_mid_bwd(b.y, b.u12 + F, U, b.g_h2, b.g_vq, F2, N, b.g_y, b.g_u12 + F, U, s));
+    gemm(s, b.g_y, F, W.Wm2T, F, nullptr, b.g_m1, F, N, F, F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.pre1, F);
+    gemm(s, b.g_m1, F, W.Wm1T, F, nullptr, b.g_h1, 2 * F, N, 2 * F, F);                    // (g_xf | g_n1)
+    KR(CAT_ELEMENTWISE, Nd * Fd * 24, launch_et_norm_bwd(b.g_h1 + F, 2 * F, b.u12, U, F, N, b.g_u12, U, s));
+    gemm(s, b.g_u12, U, W.W1uT, U, nullptr, b.g_vec, F, 3 * N, F, U);
+    // LayerNorm adjoint of out_norm: its input gradient is the first F columns of g_h1 (row stride 2F) -> compact copy
+    KR(CAT_ELEMENTWISE, Nd * Fd * 8, launch_et_copy2d(b.g_h1, 2 * F, b.g_xf, F, N, F, s));
+    KR(CAT_ELEMENTWISE, Nd * Fd * 16, launch_layernorm_bwd(b.g_xf, b.xfh, b.rstdf, W.lno_w, N, F, b.g_x, s));
+    KR(CAT_ELEMENTWISE, Pd * 32, launch_fill(b.gd2, 0.f, 2 * (int64_t)P1, s));
+    KR(CAT_ELEMENTWISE, Pd * 32, launch_fill(b.gr2, 0.f, 6 * (int64_t)P1, s));
+    for (int l = L - 1; l >= 0; --l) {
+      const EtLayerP& q = W.layer[l];
+      NODE();
+      KR(CAT_ELEMENTWISE, Nd * Fd * 4 * 28,
+         launch_et_update_bwd(b.g_x, b.g_vec, b.vp[l], b.o[l], b.vdot[l], N, F, b.g_o, b.g_vp, s));
+      gemm(s, b.g_o, 3 * F, q.WoT, 3 * F, nullptr, b.g_xagg, F, N, F, 3 * F);
+      // g_vagg = g_vec (read by both sweeps before sweep "s" adds the source terms into it: snapshot in vagg)
+      KR(CAT_ELEMENTWISE, Nd * Fd * 24, launch_et_copy2d(b.g_vec, 3 * F, b.vagg, 3 * F, N, 3 * F, s));
+      KR(CAT_PAIR, Ed * Fd * 4 * 16, launch_et_attn_bwd_t(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.gd2, b.gr2, s));
+      KR(CAT_PAIR, Ed * Fd * 4 * 16, launch_et_attn_bwd_s(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, s));
+      gemm(s, b.g_vp, 3 * F, q.WvpT, 3 * F, nullptr, b.g_vec, F, 3 * N, F, 3 * F, GEMM_ACCUM);
+      gemm(s, b.g_qkv, 5 * F, q.WqkvT, 5 * F, nullptr, b.g_xt, F, N, F, 5 * F);
+      KR(CAT_ELEMENTWISE, Nd * Fd * 16, launch_layernorm_bwd(b.g_xt, b.xh[l], b.rstd[l], q.ln_w, N, F, b.g_ln, s));
+      KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_et_add(b.g_ln, b.g_x, (int64_t)N * F, s));
+    }
+    if (hp.neighbor_embedding) {
+      gemm(s, b.g_x, F, W.WcT, F, nullptr, b.g_xcat, 2 * F, N, 2 * F, F);
+      KR(CAT_PAIR, Pd * Fd * 12, launch_et_nbr_embed_bwd(g, P, F, z, W.embN, b.g_xcat, b.dWn, b.gd2, s));
+    }
+    KR(CAT_PAIR, Pd * 48, launch_et_pair_combine(g, P, b.gd2, b.gr2, b.gd, b.g_rhat, s));
+    KR(CAT_PAIR, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s));
+    KR(CAT_PAIR, Ed * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
+  }
+  m->et->last = b;
+  m->et->lastN = N;
+  m->et->has_last = true;
+  HIP_TRY(m, hipGetLastError());
+  return TMDNET_OK;
+}
+
+int et_debug_tensor(tmdnet_model* m, hipStream_t s, const char* name, float* out, int64_t numel) {
+  if (!m->et->has_last || !name || !out) return TMDNET_ERR_STATE;
+  const EtBuffers& b = m->et->last;
+  const int64_t N = m->et->lastN, F = m->et->hp.hidden_channels;
+  const int L = m->et->hp.num_layers;
+  const std::string nm = name;
+  const float* src = nullptr;
+  int64_t n = 0;
+  if (nm == "x_embed") src = b.x[0], n = N * F;
+  else if (nm == "x_out") src = b.xf, n = N * F;
+  else if (nm == "g_x") src = b.g_x, n = N * F;
+  else if (nm == "g_vec") src = b.g_vec, n = N * 3 * F;
+  else if (nm.rfind("x_layer", 0) == 0 || nm.rfind("vec_layer", 0) == 0) {
+    const bool isx = nm[0] == 'x';
+    const int l = std::atoi(nm.c_str() + (isx ? 7 : 9));
+    if (l < 0 || l >= L) return fail(m, TMDNET_ERR_INVALID, "layer out of range");
+    src = isx ? b.x[l + 1] : b.vec[l + 1];
+    n = isx ? N * F : N * 3 * F;
+  }
+  if (!src) return fail(m, TMDNET_ERR_INVALID, "unknown tensor: " + nm);
+  if (numel != n) return fail(m, TMDNET_ERR_INVALID, "wrong size for " + nm);
+  HIP_TRY(m, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+  return TMDNET_OK;
+}

@@ -27,7 +27,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 enum DualKind : int {
   DUAL_PLAIN = 0,  // C = e ; C2 = r
   DUAL_SILU,       // C = silu(e) ; C2 = silu'(e) r
-  DUAL_FINAL       // C = silu(e) rs[m] ; C2 = silu'(e) r rs[m] + silu(e) rs2[m]
+  DUAL_FINAL,      // C = silu(e) rs[m] ; C2 = silu'(e) r rs[m] + silu(e) rs2[m]
+  DUAL_SCALE       // C = e rs[m] ; C2 = r rs[m] + e rs2[m]     (ET neighbour-embedding filter, models/utils.py:99-100)
 };
 
 template <int KIND>
@@ -37,6 +38,10 @@ __device__ __forceinline__ void dual_store(const GemmArgs& a, int row, int col, 
   if (KIND == DUAL_PLAIN) {
     *c1 = e;
     *c2 = r;
+  } else if (KIND == DUAL_SCALE) {
+    const float c = a.rowscale[row], dc = a.rowscale2[row];
+    *c1 = e * c;
+    *c2 = r * c + e * dc;
   } else {
     const float s = fast_sigmoid(e);
     const float f = e * s, df = s * (1.0f + e * (1.0f - s));
@@ -284,13 +289,14 @@ static int launch_dual_kind(const GemmArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-// kind: 0 plain, 1 silu, 2 final (rowscale = C(d), rowscale2 = C'(d))
+// kind: 0 plain, 1 silu, 2 final (rowscale = C(d), rowscale2 = C'(d)), 3 plain * rowscale
 int launch_gemm_dual(const GemmArgs& a, int kind, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0) return 0;
   if (gemm_dual_sb_ok(a)) return launch_gemm_dual_sb(a, kind, stream);
   switch (kind) {
     case DUAL_PLAIN: return launch_dual_kind<DUAL_PLAIN>(a, stream);
     case DUAL_SILU: return launch_dual_kind<DUAL_SILU>(a, stream);
+    case DUAL_SCALE: return launch_dual_kind<DUAL_SCALE>(a, stream);
     default: return launch_dual_kind<DUAL_FINAL>(a, stream);
   }
 }

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dual_sb2(GemmArgs a, int tiles_
         const int rl = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         const float ev = acc[0][i][j][e] + bv, rv = acc[1][i][j][e];
         float o1, o2;
-        if (KIND == 0) {
+        if (KIND == 0 || KIND == 3) {
           o1 = ev;
           o2 = rv;
         } else {
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dual_sb2(GemmArgs a, int tiles_
         float4 v1 = *reinterpret_cast<const float4*>(xv + rl * 32 + c4);
         float4 v2 = *reinterpret_cast<const float4*>(xv + 1024 + rl * 32 + c4);
         const int row = rb + rl;
-        if (KIND == 2 && row < M) {
+        if ((KIND == 2 || KIND == 3) && row < M) {
           const float c = a.rowscale[row], dc = a.rowscale2[row];
           v2 = make_float4(v2.x * c + v1.x * dc, v2.y * c + v1.y * dc, v2.z * c + v1.z * dc, v2.w * c + v1.w * dc);
           v1 = make_float4(v1.x * c, v1.y * c, v1.z * c, v1.w * c);
@@ -257,6 +257,7 @@ int launch_gemm_dual_sb(const GemmArgs& a, int kind, hipStream_t stream) {
   switch (kind) {
     case 0: hipLaunchKernelGGL((k_gemm_dual_sb2<0>), grid, block, 0, stream, a, tiles_m, tiles_n); break;
     case 1: hipLaunchKernelGGL((k_gemm_dual_sb2<1>), grid, block, 0, stream, a, tiles_m, tiles_n); break;
+    case 3: hipLaunchKernelGGL((k_gemm_dual_sb2<3>), grid, block, 0, stream, a, tiles_m, tiles_n); break;
     default: hipLaunchKernelGGL((k_gemm_dual_sb2<2>), grid, block, 0, stream, a, tiles_m, tiles_n); break;
   }
   return (int)hipGetLastError();

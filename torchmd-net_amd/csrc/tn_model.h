@@ -1,0 +1,194 @@
+// Host-side model state and launch helpers shared by the TensorNet schedule (tn_api.hip) and the Equivariant
+// Transformer schedule (tn_et_api.hip).  Internal to libtmdnet_amd.so; the public surface is include/tmdnet_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/tmdnet_amd.h"
+#include "tn_gemm.h"
+#include "tn_kernels.h"
+
+using namespace tn;
+
+
+struct LayerP {
+  const float *M1, *b1, *M1T, *M2, *b2, *M2T, *M3, *b3, *M3T;
+  const float* V[6];
+  const float* VT[6];
+  const uint16_t* M_sb[3];  // split-bf16 tile images of M1..M3 (tn_gemm_sb.hip)
+};
+
+struct DevParams {
+  const float *means, *betas;
+  const float *Wdp, *bdp, *WdpT;
+  const float *emb, *emb2_w, *emb2_b, *emb2_waT, *emb2_wbT;
+  const float* Ue[3];
+  const float* UeT[3];
+  const float *L1, *bL1, *L1T, *L2, *bL2, *L2T;
+  const float *ln0_w, *ln0_b;
+  std::vector<LayerP> layer;
+  const float *lnr_w, *lnr_b, *Lin, *bLin, *LinT;
+  const float *O1, *bO1, *O1T, *O2, *bO2;
+  const float* atomref;
+  const uint16_t* Wdp_sb;
+  const float *Utab, *Vtab;  // per-type pair-embedding tables (k_ztables at finalize)
+  float mean, std;
+};
+
+struct ParamSpec {
+  std::string name;
+  int64_t rows, cols;  // cols = 1 for vectors
+};
+
+// carve helper: 256-byte aligned sub-buffers of one caller-owned allocation
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(reinterpret_cast<char*>(p)) {}
+  template <typename T>
+  T* take(int64_t n) {
+    size_t bytes = (size_t)(n > 0 ? n : 0) * sizeof(T);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (bytes + 255) & ~size_t(255);
+    return p;
+  }
+};
+
+struct FwdBuffers {
+  float *phi, *dphi, *C, *dC;
+  float *Q, *u0, *s0n, *ln0, *xh0, *rstd0, *a1, *h1, *a2, *gates, *UX;
+  std::vector<float*> X;                               // L+1
+  std::vector<float*> w, dw, Pn, Mi, D;                 // per layer (dw = d w / d d, forward tangent)
+  float *he1, *he2, *te1, *te2, *dQ, *Xh, *Ch;
+  float *feat, *lnr, *xhr, *rstdr, *al, *x, *ao, *ea;
+  // reverse
+  float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *gd;
+  float *gUX, *g_a2, *g_a1, *g_ln0, *g_s0n, *g_u0l, *gA, *g_rhat, *g_delta;
+};
+
+
+enum ProfCat { CAT_GRAPH = 0, CAT_GEMM_EDGE, CAT_GEMM_NODE, CAT_MESSAGE, CAT_PAIR, CAT_SCATTER, CAT_ELEMENTWISE, CAT_COUNT };
+
+
+struct ProfRec {
+  int cat;
+  hipEvent_t a, b;
+  double flops, bytes;
+};
+struct Profiler {
+  bool on = false;
+  unsigned mask = 0;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  hipEvent_t get() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+};
+
+struct EtModel;  // tn_et_api.hip
+
+struct tmdnet_model {
+  tmdnet_hparams hp;
+  EtModel* et = nullptr;  // non-null: Equivariant Transformer handle (hp then only carries what the graph phase reads)
+  Profiler prof;
+  int64_t lastE = 0;
+  int cell_n[3] = {0, 0, 0};  // cell grid set by tmdnet_set_cell_grid (0 = brute force)
+  bool graph_is_cell = false; // last build used the cell list (atoms internally renumbered)
+  std::vector<ParamSpec> specs;
+  std::map<std::string, std::vector<float>> host;
+  float* dev = nullptr;  // packed parameters
+  uint16_t* dev_sb = nullptr;  // split-bf16 weight tile images
+  std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
+  DevParams P;
+  bool finalized = false;
+  std::string err;
+  // last-call bookkeeping for tmdnet_debug_tensor
+  FwdBuffers last{};
+  int64_t lastN = 0, lastP = 0;
+  bool has_last = false;
+};
+
+
+int fail(tmdnet_model* m, int code, const std::string& msg);
+#define HIP_TRY(m, expr)                                                                    \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(m, TMDNET_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// host-side packer: appends a tensor (optionally transposed) to the staging buffer, 64-float aligned
+struct Packer {
+  std::vector<float> buf;
+  size_t add(const std::vector<float>& v) {
+    size_t off = (buf.size() + 63) & ~size_t(63);
+    buf.resize(off + v.size());
+    std::memcpy(buf.data() + off, v.data(), v.size() * sizeof(float));
+    return off;
+  }
+  size_t add_T(const std::vector<float>& v, int64_t rows, int64_t cols) {
+    std::vector<float> t(v.size());
+    for (int64_t r = 0; r < rows; ++r)
+      for (int64_t c = 0; c < cols; ++c) t[c * rows + r] = v[r * cols + c];
+    return add(t);
+  }
+};
+
+// ---- launch-time context (thread local: a handle is not thread-safe, different handles on different threads are)
+extern thread_local tmdnet_model* g_cur;
+extern thread_local int g_gemm_cat;
+extern thread_local const int* g_mdev;  // device-side row count of pair-row GEMMs (see GemmArgs::m_dev)
+extern thread_local int g_madd;
+struct CurScope {  // g_cur is valid exactly while an entry point is enqueueing for that model (also on error returns)
+  explicit CurScope(tmdnet_model* m) { g_cur = m; }
+  ~CurScope() { g_cur = nullptr; }
+};
+struct ProfScope {
+  int idx = -1;
+  hipStream_t s;
+  ProfScope(hipStream_t s_, int cat, double flops, double bytes) : s(s_) {
+    tmdnet_model* m = g_cur;
+    if (!m || !m->prof.on || !((m->prof.mask >> cat) & 1u)) return;
+    ProfRec r{cat, m->prof.get(), m->prof.get(), flops, bytes};
+    (void)hipEventRecord(r.a, s);
+    idx = (int)m->prof.recs.size();
+    m->prof.recs.push_back(r);
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(g_cur->prof.recs[idx].b, s);
+  }
+};
+#define KR(cat, bytes, call)                      \
+  do {                                            \
+    ProfScope ps_(s, cat, 0.0, (double)(bytes));  \
+    call;                                         \
+  } while (0)
+
+// C = epilogue(A W^T + bias) through the path's MFMA GEMMs (split-bf16 kernels when W has a registered image)
+void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C, int64_t ldc, int M,
+          int N, int K, int flags = 0, float* pre = nullptr, int64_t ldpre = 0, const float* aux = nullptr, int64_t ldaux = 0,
+          const float* rowscale = nullptr);
+// value + d/dd tangent of a pair-row layer (kind: tn_gemm_dual.hip)
+void gemm_dual(hipStream_t s, int kind, const float* A, const float* A2, int64_t lda, const float* W, const float* bias, float* C,
+               float* C2, int64_t ldc, int M, int N, int K, const float* rs = nullptr, const float* rs2 = nullptr,
+               const uint16_t* Wsb = nullptr);
+Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total);
+
+// Equivariant Transformer (tn_et_api.hip)
+int et_create(tmdnet_model* m, const tmdnet_et_hparams* hp);
+void et_destroy(tmdnet_model* m);
+int et_finalize(tmdnet_model* m);
+int et_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int32_t want_forces, size_t* bytes);
+int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
+                     int64_t n_pairs, const int64_t* z, const int64_t* batch, int32_t want_forces, float* energy, float* forces);
+int et_debug_tensor(tmdnet_model* m, hipStream_t s, const char* name, float* out, int64_t numel);

@@ -30,6 +30,12 @@ class HParams(C.Structure):
     ]
 
 
+class EtHParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("hidden_channels", "num_layers", "num_rbf", "max_z", "max_num_neighbors", "num_heads",
+                                         "neighbor_embedding", "vector_cutoff", "distance_influence", "has_atomref")] + \
+               [("cutoff_lower", C.c_float), ("cutoff_upper", C.c_float)]
+
+
 _lib = None
 
 
@@ -46,6 +52,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
     L.tmdnet_create.argtypes = [C.POINTER(HParams), C.POINTER(vp)]
+    L.tmdnet_create_et.argtypes = [C.POINTER(EtHParams), C.POINTER(vp)]
     L.tmdnet_destroy.argtypes = [vp]
     L.tmdnet_last_error.argtypes = [vp]
     L.tmdnet_last_error.restype = C.c_char_p

@@ -54,6 +54,7 @@ def create_model(args, prior_model=None, mean=None, std=None):
         box_vecs=(torch.tensor(args["box_vecs"], dtype=dtype) if args["box_vecs"] is not None else None),
         dtype=dtype,
     )
+    is_equivariant = False
     if args["model"] == "tensornet":
         from torchmdnet_amd.models.tensornet import TensorNet
 
@@ -62,7 +63,20 @@ def create_model(args, prior_model=None, mean=None, std=None):
             static_shapes=args["static_shapes"],
             **shared_args,
         )
-    elif args["model"] in ("graph-network", "transformer", "equivariant-transformer", "tensornet2"):
+    elif args["model"] == "equivariant-transformer":
+        from torchmdnet_amd.models.torchmd_et import TorchMD_ET
+
+        is_equivariant = True
+        representation_model = TorchMD_ET(
+            attn_activation=args["attn_activation"],
+            num_heads=args["num_heads"],
+            distance_influence=args["distance_influence"],
+            neighbor_embedding=args["neighbor_embedding"],
+            vector_cutoff=args["vector_cutoff"],
+            static_shapes=args["static_shapes"],
+            **shared_args,
+        )
+    elif args["model"] in ("graph-network", "transformer", "tensornet2"):
         raise NotImplementedError(f'architecture {args["model"]} has no MI355X-native path in this build (SURVEY.md 8(f))')
     else:
         raise ValueError(f'Unknown architecture: {args["model"]}')
@@ -75,8 +89,16 @@ def create_model(args, prior_model=None, mean=None, std=None):
     if args["prior_model"] and prior_model is None:
         prior_model = create_prior_models(args)
 
-    if args["output_model"] != "Scalar":
+    if args["output_model"] not in ("Scalar", "EquivariantScalar"):
         raise NotImplementedError(f'output_model {args["output_model"]} has no HIP path (Scalar only)')
+    if is_equivariant:  # reference model.py:134-135: "Scalar" on an equivariant model is EquivariantScalar
+        output_model = output_modules.EquivariantScalar(
+            args["embedding_dimension"], activation=args["activation"], reduce_op=args["reduce_op"], dtype=dtype,
+            static_shapes=args.get("static_shapes", False), num_hidden_layers=args.get("output_mlp_num_layers", 0))
+        return TorchMD_Net(representation_model, output_model, prior_model=prior_model, mean=mean, std=std,
+                           derivative=args["derivative"], dtype=dtype)
+    if args["output_model"] != "Scalar":
+        raise NotImplementedError("EquivariantScalar needs an equivariant representation model")
     output_model = output_modules.Scalar(
         args["embedding_dimension"],
         activation=args["activation"],
@@ -294,6 +316,26 @@ class TorchMD_Net(nn.Module):
         hp.cutoff_upper = float(rm.cutoff_upper)
         return hp
 
+    def _is_et(self) -> bool:
+        return type(self.representation_model).__name__ == "TorchMD_ET"
+
+    def _et_hparams(self) -> _C.EtHParams:
+        rm = self.representation_model
+        hp = _C.EtHParams()
+        hp.hidden_channels = rm.hidden_channels
+        hp.num_layers = rm.num_layers
+        hp.num_rbf = rm.num_rbf
+        hp.max_z = rm.max_z
+        hp.max_num_neighbors = rm.max_num_neighbors
+        hp.num_heads = rm.num_heads
+        hp.neighbor_embedding = 1 if rm.neighbor_embedding is not None else 0
+        hp.vector_cutoff = 1 if rm.vector_cutoff else 0
+        hp.distance_influence = {"none": 0, "keys": 1, "values": 2, "both": 3}[rm.distance_influence]
+        hp.has_atomref = 1 if self._atomref_table() is not None else 0
+        hp.cutoff_lower = float(rm.cutoff_lower)
+        hp.cutoff_upper = float(rm.cutoff_upper)
+        return hp
+
     def _atomref_table(self) -> Optional[Tensor]:
         if self.prior_model is None:
             return None
@@ -321,9 +363,13 @@ class TorchMD_Net(nn.Module):
             return st
         L = _C.lib()
         st.release()
-        hp = self._hparams()
         handle = C.c_void_p()
-        rc = L.tmdnet_create(C.byref(hp), C.byref(handle))
+        if self._is_et():
+            hp = self._et_hparams()
+            rc = L.tmdnet_create_et(C.byref(hp), C.byref(handle))
+        else:
+            hp = self._hparams()
+            rc = L.tmdnet_create(C.byref(hp), C.byref(handle))
         if rc != _C.OK:
             raise RuntimeError(f"tmdnet_create failed with code {rc}")
         st.handle = handle
@@ -389,6 +435,8 @@ class TorchMD_Net(nn.Module):
             if box is not None:
                 box = box.detach().to(device=dev, dtype=torch.float32).contiguous()
                 box_mode = 1 if box.dim() == 2 else 2
+            if self._is_et():
+                q = None  # TorchMD_ET.forward takes q / s and ignores them (torchmd_et.py:188-196)
             if q is not None:
                 q = q.detach().to(device=dev, dtype=torch.float32).contiguous()
                 if q.numel() != n_mol:

@@ -5,7 +5,7 @@ from torch import nn
 
 from torchmdnet_amd.models.utils import MLP
 
-__all__ = ["Scalar"]
+__all__ = ["Scalar", "EquivariantScalar"]
 
 
 class OutputModel(nn.Module):
@@ -36,3 +36,46 @@ class Scalar(OutputModel):
 
     def reset_parameters(self):
         self.output_network.reset_parameters()
+
+
+class GatedEquivariantBlock(nn.Module):
+    """models/utils.py:583-625 (parameters only)."""
+
+    def __init__(self, hidden_channels, out_channels, intermediate_channels=None, activation="silu", scalar_activation=False,
+                 dtype=torch.float):
+        super().__init__()
+        self.out_channels = out_channels
+        if intermediate_channels is None:
+            intermediate_channels = hidden_channels
+        self.vec1_proj = nn.Linear(hidden_channels, hidden_channels, bias=False, dtype=dtype)
+        self.vec2_proj = nn.Linear(hidden_channels, out_channels, bias=False, dtype=dtype)
+        self.update_net = MLP(in_channels=hidden_channels * 2, out_channels=out_channels * 2, hidden_channels=intermediate_channels,
+                              activation=activation, num_hidden_layers=0, dtype=dtype)
+        self.scalar_activation = scalar_activation
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.vec1_proj.weight)
+        nn.init.xavier_uniform_(self.vec2_proj.weight)
+        self.update_net.reset_parameters()
+
+
+class EquivariantScalar(OutputModel):
+    """Two gated equivariant blocks F -> F/2 -> 1 (output_modules.py:120-163); what create_model builds for
+    output_model="Scalar" on the Equivariant Transformer (model.py:134-135)."""
+
+    def __init__(self, hidden_channels, activation="silu", allow_prior_model=True, reduce_op="sum", dtype=torch.float,
+                 static_shapes=False, **kwargs):
+        super().__init__(allow_prior_model=allow_prior_model, reduce_op=reduce_op, static_shapes=static_shapes)
+        if activation != "silu":
+            raise NotImplementedError("the HIP EquivariantScalar head implements SiLU")
+        if reduce_op not in ("sum", "add"):
+            raise NotImplementedError(f"reduce_op={reduce_op} has no HIP kernel (sum/add only)")
+        self.output_network = nn.ModuleList([
+            GatedEquivariantBlock(hidden_channels, hidden_channels // 2, activation=activation, scalar_activation=True, dtype=dtype),
+            GatedEquivariantBlock(hidden_channels // 2, 1, activation=activation, dtype=dtype),
+        ])
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for layer in self.output_network:
+            layer.reset_parameters()
