@@ -390,7 +390,6 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   }
   put("Wdp", Wdp);
   put("bdp", bdp);
-  putT("WdpT", Wdp, 3 * F, K);
   put("emb", h[T + "emb.weight"]);
   put("emb2_w", h[T + "emb2.weight"]);
   put("emb2_b", h[T + "emb2.bias"]);
@@ -423,7 +422,6 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     for (int k = 0; k < 3; ++k) {
       put(t + "M" + std::to_string(k), h[Lp + "linears_scalar." + std::to_string(k) + ".weight"]);
       put(t + "b" + std::to_string(k), h[Lp + "linears_scalar." + std::to_string(k) + ".bias"]);
-      putT(t + "MT" + std::to_string(k), h[Lp + "linears_scalar." + std::to_string(k) + ".weight"], dims[k][0], dims[k][1]);
     }
     for (int k = 0; k < 6; ++k) {
       put(t + "V" + std::to_string(k), h[Lp + "linears_tensor." + std::to_string(k) + ".weight"]);
@@ -458,7 +456,6 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   P.betas = D("betas");
   P.Wdp = D("Wdp");
   P.bdp = D("bdp");
-  P.WdpT = D("WdpT");
   P.emb = D("emb");
   P.emb2_w = D("emb2_w");
   P.emb2_b = D("emb2_b");
@@ -482,13 +479,10 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     LayerP& q = P.layer[l];
     q.M1 = D(t + "M0");
     q.b1 = D(t + "b0");
-    q.M1T = D(t + "MT0");
     q.M2 = D(t + "M1");
     q.b2 = D(t + "b1");
-    q.M2T = D(t + "MT1");
     q.M3 = D(t + "M2");
     q.b3 = D(t + "b2");
-    q.M3T = D(t + "MT2");
     for (int k = 0; k < 6; ++k) {
       q.V[k] = D(t + "V" + std::to_string(k));
       q.VT[k] = D(t + "VT" + std::to_string(k));

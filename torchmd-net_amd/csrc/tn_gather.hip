@@ -121,52 +121,6 @@ void launch_message_adjoint_v4(const Graph& g, int N, int F, const float* w, con
                      nullptr);
 }
 
-// per-pair weight gradient + first step of the edge-MLP reverse chain (see k_pair_bwd in tn_kernels.hip)
-__global__ __launch_bounds__(256) void k_pair_bwd_v4(Graph g, int P, int F, const float* __restrict__ gMi,
-                                                     const float* __restrict__ Pn, const float* __restrict__ e3,
-                                                     const float* __restrict__ C, float* __restrict__ g_e3,
-                                                     float* __restrict__ gC) {
-  const int tpa = F >> 2, ppb = 256 / tpa;
-  const int p = xcd_chunk(blockIdx.x, gridDim.x) * ppb + threadIdx.x / tpa;
-  if (p >= g.counts[0] || g.counts[2]) return;  // grid sized by capacity, true count on the device
-  const int f = (threadIdx.x % tpa) << 2;
-  const int i = g.pair_i[p], j = g.pair_j[p];
-  const float cp = C[p];
-  const int F9 = 9 * F, F3 = 3 * F;
-  const float* gi = gMi + (int64_t)i * F9 + f;
-  const float* gj = gMi + (int64_t)j * F9 + f;
-  const float* pi = Pn + (int64_t)i * F9 + f;
-  const float* pj = Pn + (int64_t)j * F9 + f;
-  float4 gw[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) gw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int c = 0; c < 9; ++c) {
-    const float4 a = ld4(gi + c * F), b = ld4(pj + c * F), cc = ld4(gj + c * F), d = ld4(pi + c * F);
-    float4& o = gw[c == 0 ? 0 : (c < 4 ? 1 : 2)];
-    fma4(o, a, b);
-    fma4(o, cc, d);
-  }
-  float part = 0.f;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float4 e = ld4(e3 + (int64_t)p * F3 + k * F + f);
-    float4 o;
-    o.x = gw[k].x * cp * silu_grad(e.x);
-    o.y = gw[k].y * cp * silu_grad(e.y);
-    o.z = gw[k].z * cp * silu_grad(e.z);
-    o.w = gw[k].w * cp * silu_grad(e.w);
-    st4(g_e3 + (int64_t)p * F3 + k * F + f, o);
-    part += gw[k].x * silu(e.x) + gw[k].y * silu(e.y) + gw[k].z * silu(e.z) + gw[k].w * silu(e.w);
-  }
-  part = group_sum(part, tpa);
-  if ((threadIdx.x % tpa) == 0) gC[p] += part;
-}
-void launch_pair_bwd_v4(const Graph& g, int P, int F, const float* gMi, const float* Pn, const float* e3, const float* C,
-                        float* g_e3, float* gC, hipStream_t s) {
-  const int ppb = 256 / (F >> 2);
-  hipLaunchKernelGGL(k_pair_bwd_v4, dim3(cdiv_(P, ppb)), dim3(256), 0, s, g, P, F, gMi, Pn, e3, C, g_e3, gC);
-}
 
 // embedding scatter (see k_embed_scatter in tn_kernels.hip)
 __global__ __launch_bounds__(256) void k_embed_scatter_v4(Graph g, int N, int F, const int64_t* __restrict__ z,
@@ -232,76 +186,5 @@ void launch_embed_scatter_v4(const Graph& g, int N, int F, const int64_t* z, con
   hipLaunchKernelGGL(k_embed_scatter_v4, dim3(cdiv_(N, apb)), dim3(256), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
 }
 
-// embedding adjoint per pair (see k_embed_bwd_pair in tn_kernels.hip)
-__global__ __launch_bounds__(256) void k_embed_bwd_pair_v4(Graph g, int P, int F, const int64_t* __restrict__ z,
-                                                           const float* __restrict__ Utab, const float* __restrict__ Vtab,
-                                                           const float* __restrict__ Q, const float* __restrict__ C,
-                                                           const float* __restrict__ gA, float* __restrict__ gQ,
-                                                           float* __restrict__ gC, float* __restrict__ g_rhat) {
-  const int tpa = F >> 2, ppb = 256 / tpa;
-  const int p = xcd_chunk(blockIdx.x, gridDim.x) * ppb + threadIdx.x / tpa;
-  if (p >= g.counts[0] || g.counts[2]) return;  // grid sized by capacity, true count on the device
-  const int f = (threadIdx.x % tpa) << 2;
-  const int i = g.pair_i[p], j = g.pair_j[p];
-  const int64_t zi = z[i], zj = z[j];
-  const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
-  const float cp = C[p];
-  const int F3 = 3 * F, F10 = 10 * F;
-  const float4 Ui = ld4(Utab + zi * F + f), Vi = ld4(Vtab + zi * F + f), Uj = ld4(Utab + zj * F + f), Vj = ld4(Vtab + zj * F + f);
-  const float* qp = Q + (int64_t)p * F3 + f;
-  const float4 q0v = ld4(qp), q1v = ld4(qp + F), q2v = ld4(qp + 2 * F);
-  float4 aiv[10], ajv[10];
-#pragma unroll
-  for (int c = 0; c < 10; ++c) {
-    aiv[c] = ld4(gA + (int64_t)i * F10 + c * F + f);
-    ajv[c] = ld4(gA + (int64_t)j * F10 + c * F + f);
-  }
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  float4 o0, o1, o2;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float Z1 = comp(Ui, k) + comp(Vj, k), Z2 = comp(Uj, k) + comp(Vi, k);
-    const float q0 = comp(q0v, k), q1 = comp(q1v, k), q2 = comp(q2v, k);
-    float ai[10], aj[10];
-#pragma unroll
-    for (int c = 0; c < 10; ++c) {
-      ai[c] = comp(aiv[c], k);
-      aj[c] = comp(ajv[c], k);
-    }
-    const float gW1_1 = ai[1] * r0 + ai[2] * r1 + ai[3] * r2;
-    const float gW1_2 = -(aj[1] * r0 + aj[2] * r1 + aj[3] * r2);
-    const float gW2_1 = ai[4] * r0 * r0 + ai[5] * r0 * r1 + ai[6] * r0 * r2 + ai[7] * r1 * r1 + ai[8] * r1 * r2 + ai[9] * r2 * r2;
-    const float gW2_2 = aj[4] * r0 * r0 + aj[5] * r0 * r1 + aj[6] * r0 * r2 + aj[7] * r1 * r1 + aj[8] * r1 * r2 + aj[9] * r2 * r2;
-    const float s0 = Z1 * ai[0] + Z2 * aj[0], s1 = Z1 * gW1_1 + Z2 * gW1_2, s2 = Z1 * gW2_1 + Z2 * gW2_2;
-    setc(o0, k, cp * s0);
-    setc(o1, k, cp * s1);
-    setc(o2, k, cp * s2);
-    acc[0] += q0 * s0 + q1 * s1 + q2 * s2;
-    const float W1_1 = cp * Z1 * q1, W2_1 = cp * Z1 * q2, W1_2 = cp * Z2 * q1, W2_2 = cp * Z2 * q2;
-    const float di0 = 2.f * ai[4] * r0 + ai[5] * r1 + ai[6] * r2, dj0 = 2.f * aj[4] * r0 + aj[5] * r1 + aj[6] * r2;
-    const float di1 = ai[5] * r0 + 2.f * ai[7] * r1 + ai[8] * r2, dj1 = aj[5] * r0 + 2.f * aj[7] * r1 + aj[8] * r2;
-    const float di2 = ai[6] * r0 + ai[8] * r1 + 2.f * ai[9] * r2, dj2 = aj[6] * r0 + aj[8] * r1 + 2.f * aj[9] * r2;
-    acc[1] += ai[1] * W1_1 - aj[1] * W1_2 + di0 * W2_1 + dj0 * W2_2;
-    acc[2] += ai[2] * W1_1 - aj[2] * W1_2 + di1 * W2_1 + dj1 * W2_2;
-    acc[3] += ai[3] * W1_1 - aj[3] * W1_2 + di2 * W2_1 + dj2 * W2_2;
-  }
-  float* go = gQ + (int64_t)p * F3 + f;
-  st4(go, o0);
-  st4(go + F, o1);
-  st4(go + 2 * F, o2);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) acc[k] = group_sum(acc[k], tpa);
-  if ((threadIdx.x % tpa) == 0) {
-    gC[p] += acc[0];
-    g_rhat[p * 3] = acc[1];
-    g_rhat[p * 3 + 1] = acc[2];
-    g_rhat[p * 3 + 2] = acc[3];
-  }
-}
-void launch_embed_bwd_pair_v4(const Graph& g, int P, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
-                              const float* C, const float* gA, float* gQ, float* gC, float* g_rhat, hipStream_t s) {
-  const int ppb = 256 / (F >> 2);
-  hipLaunchKernelGGL(k_embed_bwd_pair_v4, dim3(cdiv_(P, ppb)), dim3(256), 0, s, g, P, F, z, Utab, Vtab, Q, C, gA, gQ, gC, g_rhat);
-}
 
 }  // namespace tn

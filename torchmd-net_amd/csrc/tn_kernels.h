@@ -88,16 +88,10 @@ void launch_update_bwd(const float* G, const float* D, const float* q, const int
                        hipStream_t s);
 void launch_message_bwd_node(const float* gCh, const float* Pn, const float* Mi, const float* q, const int64_t* batch, int o3, int N,
                              int F, float* gMi, float* gPn, hipStream_t s);
-void launch_pair_bwd(const Graph& g, int P, int F, const float* gMi, const float* Pn, const float* e3, const float* C, float* g_e3,
-                     float* gC, hipStream_t s);
 void launch_norm_bwd(const float* X, const float* gXh_lin, int N, int F, float* G, hipStream_t s);
 void launch_embed_gate_bwd(const float* G, const float* UX, const float* gates, const float* a2, int N, int F, float* gUX, float* g_a2,
                            hipStream_t s);
 void launch_embed_bwd_atom(const float* g_u0_lin, const float* u0, const float* g_s0n, int N, int F, float* gA, hipStream_t s);
-void launch_embed_bwd_pair(const Graph& g, int P, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
-                           const float* C, const float* gA, float* gQ, float* gC, float* g_rhat, hipStream_t s);
-void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC, const float* g_phi, const float* dphi,
-                 const float* g_rhat, float* g_delta, hipStream_t s);
 void launch_force_gather(const Graph& g, int N, const float* g_delta, const int* perm, float* forces, hipStream_t s);
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);
 
@@ -133,11 +127,7 @@ bool gather_v4_ok(int F);
 void launch_message_v4(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
                        int o3, float* Mi, float* Ch, hipStream_t s);
 void launch_message_adjoint_v4(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);
-void launch_pair_bwd_v4(const Graph& g, int P, int F, const float* gMi, const float* Pn, const float* e3, const float* C,
-                        float* g_e3, float* gC, hipStream_t s);
 void launch_embed_scatter_v4(const Graph& g, int N, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
                              const float* C, float* u0, float* s0n, hipStream_t s);
-void launch_embed_bwd_pair_v4(const Graph& g, int P, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
-                              const float* C, const float* gA, float* gQ, float* gC, float* g_rhat, hipStream_t s);
 
 }  // namespace tn

@@ -776,44 +776,6 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red /* [4*NV] *
   }
 }
 
-// per-pair weight gradient of one interaction layer + the first step of the edge-MLP reverse chain
-//   g_w[p,k,f] = sum_{c in k} gMi[i,c,f] Pn[j,c,f] + gMi[j,c,f] Pn[i,c,f]
-//   g_e3 = g_w * C(d) * silu'(e3) ;  gC[p] += sum_{k,f} g_w * silu(e3)
-__global__ void k_pair_bwd(Graph g, int P, int F, const float* __restrict__ gMi, const float* __restrict__ Pn,
-                           const float* __restrict__ e3, const float* __restrict__ C, float* __restrict__ g_e3,
-                           float* __restrict__ gC) {
-  __shared__ float red[4];
-  const int p = blockIdx.x;
-  if (p >= g.counts[0] || g.counts[2]) return;
-  const int i = g.pair_i[p], j = g.pair_j[p];
-  const float cp = C[p];
-  const int F9 = 9 * F, F3 = 3 * F;
-  float part[1] = {0.f};
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {
-    const float* gi = gMi + (int64_t)i * F9 + f;
-    const float* gj = gMi + (int64_t)j * F9 + f;
-    const float* pi = Pn + (int64_t)i * F9 + f;
-    const float* pj = Pn + (int64_t)j * F9 + f;
-    float gw[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 9; ++c) gw[type_of(c)] += gi[c * F] * pj[c * F] + gj[c * F] * pi[c * F];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float e = e3[(int64_t)p * F3 + k * F + f];
-      g_e3[(int64_t)p * F3 + k * F + f] = gw[k] * cp * silu_grad(e);
-      part[0] += gw[k] * silu(e);
-    }
-  }
-  block_sum<1>(part, red);
-  if (threadIdx.x == 0) gC[p] += part[0];
-}
-void launch_pair_bwd(const Graph& g, int P, int F, const float* gMi, const float* Pn, const float* e3, const float* C, float* g_e3,
-                     float* gC, hipStream_t s) {
-  if (P <= 0) return;
-  if (gather_v4_ok(F)) return launch_pair_bwd_v4(g, P, F, gMi, Pn, e3, C, g_e3, gC, s);
-  hipLaunchKernelGGL(k_pair_bwd, dim3(P), dim3(fthreads(F)), 0, s, g, P, F, gMi, Pn, e3, C, g_e3, gC);
-}
-
 // G <- (G + gXh_lin)/(s+1) + dquad(X) * g_s ,  g_s = -sum (G + gXh_lin).X / (s+1)^2
 __global__ void k_norm_bwd(const float* __restrict__ X, const float* __restrict__ gl, int N, int F, float* __restrict__ G) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -897,93 +859,6 @@ __global__ void k_embed_bwd_atom(const float* __restrict__ gl, const float* __re
 void launch_embed_bwd_atom(const float* g_u0_lin, const float* u0, const float* g_s0n, int N, int F, float* gA, hipStream_t s) {
   if (N <= 0) return;
   hipLaunchKernelGGL(k_embed_bwd_atom, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, g_u0_lin, u0, g_s0n, N, F, gA);
-}
-
-// embedding adjoint per pair (both directions at once): gQ[p,3,F], gC[p] +=, g_rhat[p,3]
-__global__ void k_embed_bwd_pair(Graph g, int P, int F, const int64_t* __restrict__ z, const float* __restrict__ Utab,
-                                 const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ C,
-                                 const float* __restrict__ gA, float* __restrict__ gQ, float* __restrict__ gC,
-                                 float* __restrict__ g_rhat) {
-  __shared__ float red[16];
-  const int p = blockIdx.x;
-  if (p >= g.counts[0] || g.counts[2]) return;
-  const int i = g.pair_i[p], j = g.pair_j[p];
-  const int64_t zi = z[i], zj = z[j];
-  const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
-  const float cp = C[p];
-  const int F3 = 3 * F, F10 = 10 * F;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // gC, g_r0, g_r1, g_r2
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {
-    const float Z1 = Utab[zi * F + f] + Vtab[zj * F + f];  // edge i <- j
-    const float Z2 = Utab[zj * F + f] + Vtab[zi * F + f];  // edge j <- i
-    const float* qp = Q + (int64_t)p * F3 + f;
-    const float q0 = qp[0], q1 = qp[F], q2 = qp[2 * F];
-    float ai[10], aj[10];
-#pragma unroll
-    for (int c = 0; c < 10; ++c) {
-      ai[c] = gA[(int64_t)i * F10 + c * F + f];
-      aj[c] = gA[(int64_t)j * F10 + c * F + f];
-    }
-    const float gW0_1 = ai[0], gW0_2 = aj[0];
-    const float gW1_1 = ai[1] * r0 + ai[2] * r1 + ai[3] * r2;
-    const float gW1_2 = -(aj[1] * r0 + aj[2] * r1 + aj[3] * r2);
-    const float gW2_1 = ai[4] * r0 * r0 + ai[5] * r0 * r1 + ai[6] * r0 * r2 + ai[7] * r1 * r1 + ai[8] * r1 * r2 + ai[9] * r2 * r2;
-    const float gW2_2 = aj[4] * r0 * r0 + aj[5] * r0 * r1 + aj[6] * r0 * r2 + aj[7] * r1 * r1 + aj[8] * r1 * r2 + aj[9] * r2 * r2;
-    const float s0 = Z1 * gW0_1 + Z2 * gW0_2, s1 = Z1 * gW1_1 + Z2 * gW1_2, s2 = Z1 * gW2_1 + Z2 * gW2_2;
-    float* go = gQ + (int64_t)p * F3 + f;
-    go[0] = cp * s0;
-    go[F] = cp * s1;
-    go[2 * F] = cp * s2;
-    acc[0] += q0 * s0 + q1 * s1 + q2 * s2;
-    const float W1_1 = cp * Z1 * q1, W2_1 = cp * Z1 * q2, W1_2 = cp * Z2 * q1, W2_2 = cp * Z2 * q2;
-    // d(quadratic form)/dr for both atoms
-    const float di0 = 2.f * ai[4] * r0 + ai[5] * r1 + ai[6] * r2, dj0 = 2.f * aj[4] * r0 + aj[5] * r1 + aj[6] * r2;
-    const float di1 = ai[5] * r0 + 2.f * ai[7] * r1 + ai[8] * r2, dj1 = aj[5] * r0 + 2.f * aj[7] * r1 + aj[8] * r2;
-    const float di2 = ai[6] * r0 + ai[8] * r1 + 2.f * ai[9] * r2, dj2 = aj[6] * r0 + aj[8] * r1 + 2.f * aj[9] * r2;
-    acc[1] += ai[1] * W1_1 - aj[1] * W1_2 + di0 * W2_1 + dj0 * W2_2;
-    acc[2] += ai[2] * W1_1 - aj[2] * W1_2 + di1 * W2_1 + dj1 * W2_2;
-    acc[3] += ai[3] * W1_1 - aj[3] * W1_2 + di2 * W2_1 + dj2 * W2_2;
-  }
-  block_sum<4>(acc, red);
-  if (threadIdx.x == 0) {
-    gC[p] += acc[0];
-    g_rhat[p * 3] = acc[1];
-    g_rhat[p * 3 + 1] = acc[2];
-    g_rhat[p * 3 + 2] = acc[3];
-  }
-}
-void launch_embed_bwd_pair(const Graph& g, int P, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
-                           const float* C, const float* gA, float* gQ, float* gC, float* g_rhat, hipStream_t s) {
-  if (P <= 0) return;
-  if (gather_v4_ok(F)) return launch_embed_bwd_pair_v4(g, P, F, z, Utab, Vtab, Q, C, gA, gQ, gC, g_rhat, s);
-  hipLaunchKernelGGL(k_embed_bwd_pair, dim3(P), dim3(fthreads(F)), 0, s, g, P, F, z, Utab, Vtab, Q, C, gA, gQ, gC, g_rhat);
-}
-
-// g_d = gC C'(d) + sum_k g_phi phi_k'(d) ;  g_delta = (g_r - (g_r.r) r)/d + g_d r   (reference neighbor_utils.py:11-46)
-__global__ void k_geom(Graph g, int P, int K, const float* __restrict__ gC, const float* __restrict__ dC,
-                       const float* __restrict__ g_phi, const float* __restrict__ dphi, const float* __restrict__ g_rhat,
-                       float* __restrict__ g_delta) {
-  // one wave per pair: lanes stride over k (coalesced rows of g_phi / dphi), wave-level reduction
-  const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (p >= g.counts[0] || g.counts[2]) return;
-  const int lane = threadIdx.x & 63;
-  float part = 0.f;
-  for (int k = lane; k < K; k += 64) part += g_phi[(int64_t)p * K + k] * dphi[(int64_t)p * K + k];
-  float gd = wave_sum(part) + gC[p] * dC[p];
-  if (lane != 0) return;
-  const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
-  const float d = g.pd[p];
-  const float inv = d > 0.f ? 1.0f / d : 0.f;
-  const float a0 = g_rhat[p * 3], a1 = g_rhat[p * 3 + 1], a2 = g_rhat[p * 3 + 2];
-  const float dot = a0 * r0 + a1 * r1 + a2 * r2;
-  g_delta[p * 3] = (a0 - dot * r0) * inv + gd * r0;
-  g_delta[p * 3 + 1] = (a1 - dot * r1) * inv + gd * r1;
-  g_delta[p * 3 + 2] = (a2 - dot * r2) * inv + gd * r2;
-}
-void launch_geom(const Graph& g, int P, int K, const float* gC, const float* dC, const float* g_phi, const float* dphi,
-                 const float* g_rhat, float* g_delta, hipStream_t s) {
-  if (P <= 0) return;
-  hipLaunchKernelGGL(k_geom, dim3(cdiv(P, 4)), dim3(256), 0, s, g, P, K, gC, dC, g_phi, dphi, g_rhat, g_delta);
 }
 
 // F_i = - sum_{e in row(i)} sign(e) * g_delta[pair(e)]     (no atomics: CSR gather)

@@ -17,7 +17,7 @@ using namespace tn;
 
 
 struct LayerP {
-  const float *M1, *b1, *M1T, *M2, *b2, *M2T, *M3, *b3, *M3T;
+  const float *M1, *b1, *M2, *b2, *M3, *b3;
   const float* V[6];
   const float* VT[6];
   const uint16_t* M_sb[3];  // split-bf16 tile images of M1..M3 (tn_gemm_sb.hip)
@@ -25,7 +25,7 @@ struct LayerP {
 
 struct DevParams {
   const float *means, *betas;
-  const float *Wdp, *bdp, *WdpT;
+  const float *Wdp, *bdp;
   const float *emb, *emb2_w, *emb2_b, *emb2_waT, *emb2_wbT;
   const float* Ue[3];
   const float* UeT[3];
