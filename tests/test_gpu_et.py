@@ -105,3 +105,40 @@ def test_et_batch_properties(hip_lib):
     Ep, Fp = model(z[order].cuda(), (pos[order] + torch.tensor([3.0, -2.0, 1.0])).cuda(), newb.cuda())
     assert rel_err(Ep.cpu(), E.cpu()[perm]) < 1e-5
     assert rel_err(Fp.cpu(), F.cpu()[order]) < 1e-4
+
+
+def test_et_static_shapes_and_graph_replay(hip_lib, golden_dir):
+    """static_shapes=True (no read-back, capacity-sized launches) equals the dynamic path, and a captured HIP graph
+    replays with new positions (the MD use of the ET path)."""
+    g = torch.load(os.path.join(golden_dir, "et_tiny_ref.pt"))
+    dyn = _model_from_sd(g["args"], g["state_dict"])
+    sta = _model_from_sd(dict(g["args"], static_shapes=True), g["state_dict"])
+    z, pos, batch = g["z"].cuda(), g["pos"].cuda(), g["batch"].cuda()
+    Ed, Fd = dyn(z, pos, batch)
+    Es, Fs = sta(z, pos, batch)
+    torch.testing.assert_close(Es, Ed, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(Fs, Fd, atol=1e-5, rtol=1e-5)
+    replay = sta.capture(z, pos, batch)
+    E1, F1 = replay()
+    assert rel_err(E1.cpu(), g["E"]) < REL and rel_err(F1.cpu(), g["F"]) < REL
+    torch.manual_seed(0)
+    pos2 = pos + 0.05 * torch.randn_like(pos)
+    E2, F2 = replay(pos2)
+    E2, F2 = E2.clone(), F2.clone()
+    Er, Fr = dyn(z, pos2, batch)
+    assert rel_err(E2, Er) < 1e-5 and rel_err(F2, Fr) < 1e-5
+
+
+def test_et_periodic_box_vs_oracle(hip_lib, golden_dir):
+    """triclinic minimum image through the shared neighbour phase; oracle = oracle/et_torch.py with the same box."""
+    from oracle import et_torch as ET
+
+    g = torch.load(os.path.join(golden_dir, "et_tiny_vc_ref.pt"))
+    model = _model_from_sd(g["args"], g["state_dict"])
+    zz, pp = W.synthetic_molecule(55, n_atoms=40, density=0.03)
+    z, pos = torch.from_numpy(zz) % 19 + 1, torch.from_numpy(pp)
+    box = torch.tensor([[11.0, 0.0, 0.0], [0.4, 11.5, 0.0], [0.3, -0.6, 10.6]])
+    batch = torch.zeros(40, dtype=torch.long)
+    E, F = model(z.cuda(), pos.cuda(), batch.cuda(), box=box.cuda())
+    Eo, Fo = ET.energy_and_forces(g["state_dict"], ET.hparams_from_args(g["args"]), z, pos, batch, box=box)
+    assert rel_err(E.cpu(), Eo) < REL and rel_err(F.cpu(), Fo) < REL
