@@ -117,7 +117,7 @@ void launch_embed_pair_gd(const Graph& g, int Pcap, int F, const int64_t* z, con
 void launch_geom_gd(const Graph& g, int Pcap, const float* gd, const float* g_rhat, float* g_delta, hipStream_t s);
 
 // ---- LDS-staged tile sweeps (tn_message_tile.hip), selected by launch_message / launch_message_adjoint when message_tile_ok(F)
-bool message_tile_ok(int F);
+bool message_tile_ok(int N, int F);
 void launch_message_tile(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
                          int o3, float* Mi, float* Ch, hipStream_t s);
 void launch_message_adjoint_tile(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);

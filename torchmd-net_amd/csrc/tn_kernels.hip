@@ -215,12 +215,16 @@ __global__ void k_nbr_link(Graph g, int N) {
   }
 }
 
+__global__ void k_graph_reset(Graph g, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) g.mstart[i] = g.mend[i] = 0;
+  if (i < 8) g.counts[i] = 0;
+}
+
 void launch_graph_build_phase1(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
                                int B, float lo, float up, bool loop, hipStream_t s) {
-  // kernel fills instead of hipMemsetAsync (memset nodes did not replay reliably from a captured HIP graph)
-  launch_fill(reinterpret_cast<float*>(g.mstart), 0.f, B, s);
-  launch_fill(reinterpret_cast<float*>(g.mend), 0.f, B, s);
-  launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
+  // a kernel instead of hipMemsetAsync (memset nodes did not replay reliably from a captured HIP graph)
+  hipLaunchKernelGGL(k_graph_reset, dim3(cdiv(B > 8 ? B : 8, 256)), dim3(256), 0, s, g, B);
   if (N <= 0) return;
   hipLaunchKernelGGL(k_mol_ranges, dim3(cdiv(N, 256)), dim3(256), 0, s, batch, N, B, g.mstart, g.mend, g.counts);
   if (getenv("TMDNET_SCALAR_GRAPH"))  // developer switch: thread-per-atom specification kernels
@@ -526,7 +530,7 @@ __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, co
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
                     float* Mi, float* Ch, hipStream_t s) {
   if (N <= 0) return;
-  if (message_tile_ok(F)) return launch_message_tile(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
+  if (message_tile_ok(N, F)) return launch_message_tile(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   if (sweep_v4() && gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
 }
@@ -550,7 +554,7 @@ void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const 
   // the LDS-staged tile sweep is slower for the adjoint (read-modify-write of gPn; 231 vs 204 us at C2,
   // profiles/r01_notes.md), so it is opt-in here
   static const bool tile_adj = getenv("TMDNET_MSG_TILE_ADJOINT") != nullptr;
-  if (tile_adj && message_tile_ok(F)) return launch_message_adjoint_tile(g, N, F, w, gMi, gPn, s);
+  if (tile_adj && message_tile_ok(N, F)) return launch_message_adjoint_tile(g, N, F, w, gMi, gPn, s);
   if (sweep_v4() && gather_v4_ok(F)) return launch_message_adjoint_v4(g, N, F, w, gMi, gPn, s);
   hipLaunchKernelGGL(k_message_adjoint, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, gMi, gPn);
 }
@@ -621,36 +625,28 @@ void launch_head_energy(const float* ao, const float* O2, const float* bO2, int 
   hipLaunchKernelGGL(k_head_energy, dim3(cdiv(N, 4)), dim3(256), 0, s, ao, O2, bO2, N, H, std, atomref, z, ea);
 }
 
-// per-molecule sum (reference output_modules.py:43-73).  Sorted batch: one block per molecule, fixed order.
-__global__ __launch_bounds__(256) void k_mol_sum_sorted(Graph g, const float* __restrict__ ea, int B, float mean,
-                                                        float* __restrict__ energy) {
-  if (g.counts[3]) return;
+// per-molecule sum (reference output_modules.py:43-73): one block per molecule, fixed order (deterministic).
+// Sorted batch: the molecule's atom range; unsorted batch (rare): the block scans all atoms for its members.
+__global__ __launch_bounds__(256) void k_mol_sum(Graph g, const float* __restrict__ ea, const int64_t* __restrict__ batch, int N, int B,
+                                                 float mean, float* __restrict__ energy) {
   __shared__ float part[4];
   const int m = blockIdx.x;
-  const int i0 = g.mstart[m], i1 = g.mend[m];
   float s = 0.f;
-  for (int i = i0 + threadIdx.x; i < i1; i += 256) s += ea[i];
+  if (!g.counts[3]) {
+    const int i0 = g.mstart[m], i1 = g.mend[m];
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) s += ea[i];
+  } else {
+    for (int i = threadIdx.x; i < N; i += 256)
+      if (batch[i] == m) s += ea[i];
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) energy[m] = part[0] + part[1] + part[2] + part[3] + mean;
 }
-__global__ void k_mol_sum_unsorted(Graph g, const float* __restrict__ ea, const int64_t* __restrict__ batch, int N, int B,
-                                   float mean, float* __restrict__ energy, int phase) {
-  if (!g.counts[3]) return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (phase == 0) {
-    if (i < B) energy[i] = mean;
-  } else if (i < N) {
-    int64_t b = batch[i];
-    if (b >= 0 && b < B) atomicAdd(&energy[b], ea[i]);
-  }
-}
 void launch_mol_sum(const Graph& g, const float* ea, const int64_t* batch, int N, int B, float mean, float* energy, hipStream_t s) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_mol_sum_sorted, dim3(B), dim3(256), 0, s, g, ea, B, mean, energy);
-  hipLaunchKernelGGL(k_mol_sum_unsorted, dim3(cdiv(B, 256)), dim3(256), 0, s, g, ea, batch, N, B, mean, energy, 0);
-  if (N > 0) hipLaunchKernelGGL(k_mol_sum_unsorted, dim3(cdiv(N, 256)), dim3(256), 0, s, g, ea, batch, N, B, mean, energy, 1);
+  hipLaunchKernelGGL(k_mol_sum, dim3(B), dim3(256), 0, s, g, ea, batch, N, B, mean, energy);
 }
 
 // =====================================================================================

@@ -163,9 +163,11 @@ __global__ __launch_bounds__(MT_THREADS, 2) void k_message_tile(Graph g, int N, 
   }
 }
 
-bool message_tile_ok(int F) {
+bool message_tile_ok(int N, int F) {
   static const bool off = getenv("TMDNET_NO_MSG_TILE") != nullptr;  // developer switch: row-per-block kernels
-  return !off && F >= MT_FC && F % MT_FC == 0;
+  if (off || F < MT_FC || F % MT_FC) return false;
+  // a tile is one block of 16 waves walking 64 rows: it needs >= 2 blocks per CU to beat one block per row
+  return (int64_t)((N + MT_TA - 1) / MT_TA) * (F / MT_FC) >= 512;
 }
 
 void launch_message_tile(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
