@@ -305,6 +305,14 @@ int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out) {
   tmdnet_model* m = new tmdnet_model();
   m->hp = *hp;
   build_specs(m);
+  if (!getenv("TMDNET_NO_SIDE_STREAM")) {  // developer switch: everything on the caller's stream
+    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) m->side = nullptr;
+    if (m->side) {
+      (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
+      m->ev_join.resize(hp->num_layers);
+      for (auto& e : m->ev_join) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    }
+  }
   *out = m;
   return TMDNET_OK;
 }
@@ -336,6 +344,12 @@ int tmdnet_create_et(const tmdnet_et_hparams* hp, tmdnet_model** out) {
 int tmdnet_destroy(tmdnet_model* m) {
   if (!m) return TMDNET_OK;
   et_destroy(m);
+  if (m->side) {
+    (void)hipStreamSynchronize(m->side);
+    (void)hipEventDestroy(m->ev_fork);
+    for (auto& e : m->ev_join) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(m->side);
+  }
   if (m->dev) (void)hipFree(m->dev);
   if (m->dev_sb) (void)hipFree(m->dev_sb);
   delete m;
@@ -722,6 +736,30 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   // ---- radial functions per pair
   RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
   KR(CAT_ELEMENTWISE, Pd * (2 * K + 3) * 4, launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s));
+  // ---- edge MLPs of all layers: functions of the pair geometry only -> side stream (tn_model.h)
+  // only at batch scale: for a small system the cross-queue joins cost more than the overlap gives (graph replay of a
+  // 64-atom molecule 0.36 -> 0.40 ms, profiles/r01_notes.md)
+  hipStream_t es = (m->side && L > 0 && P >= 16384) ? m->side : s;
+  if (es != s) {
+    HIP_TRY(m, hipEventRecord(m->ev_fork, s));
+    HIP_TRY(m, hipStreamWaitEvent(es, m->ev_fork, 0));
+  }
+  for (int l = 0; l < L; ++l) {
+    const LayerP& q_ = W.layer[l];
+    EDGE(1);
+    if (want_forces) {
+      // edge MLP with its distance tangent carried forward (dw/dd): the reverse pass then needs no edge GEMM
+      gemm_dual(es, 1, b.phi, b.dphi, K, q_.M1, q_.b1, b.he1, b.te1, F, P1, F, K, nullptr, nullptr, q_.M_sb[0]);
+      gemm_dual(es, 1, b.he1, b.te1, F, q_.M2, q_.b2, b.he2, b.te2, 2 * F, P1, 2 * F, F, nullptr, nullptr, q_.M_sb[1]);
+      gemm_dual(es, 2, b.he2, b.te2, 2 * F, q_.M3, q_.b3, b.w[l], b.dw[l], 3 * F, P1, 3 * F, 2 * F, b.C, b.dC, q_.M_sb[2]);
+    } else {
+      gemm(es, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU);
+      gemm(es, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU);
+      gemm(es, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, nullptr, 0, nullptr, 0,
+           b.C);
+    }
+    if (es != s) HIP_TRY(m, hipEventRecord(m->ev_join[l], es));
+  }
   // ---- embedding
   // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
   EDGE(1);
@@ -737,18 +775,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   // ---- interaction layers
   for (int l = 0; l < L; ++l) {
     const LayerP& q_ = W.layer[l];
-    EDGE(1);
-    if (want_forces) {
-      // edge MLP with its distance tangent carried forward (dw/dd): the reverse pass then needs no edge GEMM
-      gemm_dual(s, 1, b.phi, b.dphi, K, q_.M1, q_.b1, b.he1, b.te1, F, P1, F, K, nullptr, nullptr, q_.M_sb[0]);
-      gemm_dual(s, 1, b.he1, b.te1, F, q_.M2, q_.b2, b.he2, b.te2, 2 * F, P1, 2 * F, F, nullptr, nullptr, q_.M_sb[1]);
-      gemm_dual(s, 2, b.he2, b.te2, 2 * F, q_.M3, q_.b3, b.w[l], b.dw[l], 3 * F, P1, 3 * F, 2 * F, b.C, b.dC, q_.M_sb[2]);
-    } else {
-      gemm(s, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU);
-      gemm(s, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU);
-      gemm(s, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, nullptr, 0, nullptr, 0,
-           b.C);
-    }
+    if (es != s) HIP_TRY(m, hipStreamWaitEvent(s, m->ev_join[l], 0));  // join: w[l] (and dw[l]) are ready
     KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], b.Xh, N, F, s));
     tensor_linear(s, b.Xh, q_.V, b.Pn[l], N, F);
     KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch, o3, b.Mi[l], b.Ch, s));
