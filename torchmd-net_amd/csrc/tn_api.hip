@@ -305,7 +305,7 @@ int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out) {
   tmdnet_model* m = new tmdnet_model();
   m->hp = *hp;
   build_specs(m);
-  if (!getenv("TMDNET_NO_SIDE_STREAM")) {  // developer switch: everything on the caller's stream
+  if (getenv("TMDNET_SIDE_STREAM")) {  // opt-in (profiles/r01_notes.md): +2 % batch throughput, but the GEMMs then share the chip
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) m->side = nullptr;
     if (m->side) {
       (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);

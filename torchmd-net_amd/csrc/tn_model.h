@@ -100,7 +100,7 @@ struct EtModel;  // tn_et_api.hip
 
 struct tmdnet_model {
   tmdnet_hparams hp;
-  // second stream + events: the edge MLPs of the interaction layers depend on the pair geometry only, so they are
+  // optional (TMDNET_SIDE_STREAM=1) second stream + events: the edge MLPs of the interaction layers depend on the pair geometry only, so they are
   // enqueued on `side` (fork after the radial kernel, one join per layer before its message sweep) and run beside the
   // per-atom chain; under HIP-graph capture the fork/join pattern becomes parallel branches of the graph
   hipStream_t side = nullptr;
