@@ -142,3 +142,27 @@ def test_et_periodic_box_vs_oracle(hip_lib, golden_dir):
     E, F = model(z.cuda(), pos.cuda(), batch.cuda(), box=box.cuda())
     Eo, Fo = ET.energy_and_forces(g["state_dict"], ET.hparams_from_args(g["args"]), z, pos, batch, box=box)
     assert rel_err(E.cpu(), Eo) < REL and rel_err(F.cpu(), Fo) < REL
+
+
+@pytest.mark.parametrize("F,H,K,di,ne,vc", [(64, 2, 20, "none", False, False), (64, 8, 16, "values", True, True),
+                                            (256, 4, 32, "both", True, False)])
+def test_et_shape_sweep_vs_oracle(hip_lib, F, H, K, di, ne, vc):
+    """head sizes 8 / 32 / 64 lanes, no / values-only distance influence, without neighbour embedding, K not a multiple of
+    16 (fp32-MFMA fallback of the pair GEMMs), a batch for the throughput kernels and a tiny one; oracle = et_torch."""
+    from oracle import et_torch as ET
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.C4_ARGS, embedding_dimension=F, num_heads=H, num_rbf=K, num_layers=2, distance_influence=di,
+                neighbor_embedding=ne, vector_cutoff=vc, cutoff_upper=5.0, max_z=20, max_num_neighbors=64)
+    torch.manual_seed(12)
+    model = create_model(dict(args)).to("cuda")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hp = ET.hparams_from_args(args)
+    for n_mol, n_atoms in ((40, 40), (2, 9)):
+        z, pos, batch = W.synthetic_batch(n_mol=n_mol, n_atoms=n_atoms, first_seed=700)
+        z = z % 19 + 1
+        E, Fo = model(z.cuda(), pos.cuda(), batch.cuda())
+        sel = batch < 2
+        Eo, Fr = ET.energy_and_forces(sd, hp, z[sel], pos[sel], batch[sel])
+        assert rel_err(E[:2].cpu(), Eo) < REL, (F, H, K, n_mol)
+        assert rel_err(Fo[sel.cuda()].cpu(), Fr) < REL, (F, H, K, n_mol)

@@ -323,3 +323,27 @@ def test_cell_list_equals_brute_force_and_oracle(hip_lib):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     Er, Fr = CO.energy_forces(sd, T.hparams_from_args(args), z, pos, batch, box=box)
     assert rel_err(Ec.cpu(), Er) < REL and rel_err(Fc.cpu(), Fr) < REL
+
+
+@pytest.mark.parametrize("F,L,K,group", [(64, 1, 16, "O(3)"), (256, 3, 32, "O(3)"), (96, 2, 50, "SO(3)"), (32, 2, 20, "O(3)")])
+def test_shape_sweep_vs_oracle(hip_lib, F, L, K, group):
+    """hyper-parameter shapes off the tuned one: QM9 example sizes (F=256, L=3), widths that are not a multiple of 64 or of
+    the 16-byte / split-bf16 kernels' granularity (F=96, K=50, K=20 take the fp32-MFMA and one-channel-per-lane paths),
+    a batch large enough for the throughput kernels and a tiny one for the latency kernels; oracle = tensornet_torch."""
+    from oracle import tensornet_torch as T
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.C2_ARGS, embedding_dimension=F, num_layers=L, num_rbf=K, equivariance_invariance_group=group, max_z=20)
+    torch.manual_seed(11)
+    model = create_model(dict(args)).to("cuda")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hp = T.hparams_from_args(args)
+    for n_mol, n_atoms in ((48, 40), (2, 9)):
+        z, pos, batch = W.synthetic_batch(n_mol=n_mol, n_atoms=n_atoms, first_seed=500)
+        z = z % 19 + 1
+        E, Fo = model(z.cuda(), pos.cuda(), batch.cuda())
+        sel = batch < 2
+        Eo, Fr = T.energy_and_forces(sd, hp, z[sel], pos[sel], batch[sel])
+        assert rel_err(E[:2].cpu(), Eo) < REL, (F, L, K, n_mol)
+        assert rel_err(Fo[sel.cuda()].cpu(), Fr) < REL, (F, L, K, n_mol)
