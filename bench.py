@@ -119,7 +119,7 @@ def cpu_baseline(args_dict, state_dict, budget_s=20.0):
 
 
 # HIP kernel behind each profiled class (rocprofv3 names; profiles/r01_kernel_stats.csv)
-KERNEL_OF = {"gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_nt", "message": "k_message / k_message_adjoint",
+KERNEL_OF = {"gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_sb1", "message": "k_message_tile / k_message_adjoint",
              "pair_bwd": "k_pair_gd_v4 / k_embed_pair_gd_v4"}
 
 
