@@ -16,6 +16,7 @@ struct EtAttnArgs {   // per-layer operands of the attention sweeps
   const float* dC;
   int F, hd, Wd, dk_off, dv_off;  // *_off = -1: the model has no such projection (factor 1)
   int vector_cutoff;
+  int64_t slot_stride;  // reverse target sweep: distance between the per-wave slot arrays of gd2 / gr2 (= 2 (P + 1))
 };
 
 void launch_et_embed(const int64_t* z, const float* emb, int N, int F, float* x, hipStream_t s);
@@ -32,7 +33,9 @@ void launch_et_attn_bwd_t(const Graph& g, int N, const EtAttnArgs& a, const floa
                           float* gd2, float* gr2, hipStream_t s);
 void launch_et_attn_bwd_s(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
                           float* g_vec, hipStream_t s);
-void launch_et_pair_combine(const Graph& g, int Pcap, const float* gd2, const float* gr2, float* gd, float* g_rhat, hipStream_t s);
+void launch_et_pair_combine(const Graph& g, int Pcap, const float* gd2, const float* gr2, int nw, int64_t stride,
+                            const float* gd_extra, float* gd, float* g_rhat, hipStream_t s);
+int et_sweep_waves(int F);  // waves per block of the attention sweeps = partial-sum slots per pair direction
 void launch_et_cat_norm(const float* xsrc, int Fx, const float* u, int ldu, int Fn, int N, float* hcat, hipStream_t s);
 void launch_et_norm_bwd(const float* g_n, int ldg, const float* u, int ldu, int Fn, int N, float* g_u, int ldgu, hipStream_t s);
 void launch_et_head_mid(const float* y, const float* u2, int ldu, int F2, int N, float* hcat2, float* vq, hipStream_t s);

@@ -23,6 +23,22 @@ __device__ __forceinline__ float head_sum(float v, int hd) {  // sum over the hd
   return v;
 }
 
+// four wave-wide sums for the price of seven exchanges: halve the value set at xor 32 and xor 16, then reduce one value
+// over 16 lanes.  Totals land in lane 0 (a), 16 (b), 32 (c), 48 (d).
+__device__ __forceinline__ float wave_sum4(float a, float b, float c, float d, int lane) {
+  const bool hi = lane & 32;
+  float k0 = hi ? c : a, k1 = hi ? d : b;          // kept pair
+  const float s0 = hi ? a : c, s1 = hi ? b : d;    // pair handed to the partner lane
+  k0 += __shfl_xor(s0, 32, 64);
+  k1 += __shfl_xor(s1, 32, 64);
+  const bool q = lane & 16;
+  float v = q ? k1 : k0;
+  v += __shfl_xor(q ? k0 : k1, 16, 64);
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------- embedding
 __global__ void k_et_embed(const int64_t* __restrict__ z, const float* __restrict__ emb, int N, int F, float* __restrict__ x) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,10 +241,9 @@ __device__ __forceinline__ EtEdge et_edge(const EtAttnArgs& a, float tq, const f
 // (slot 0: the row atom is the pair's i, slot 1: it is the pair's j; one writer per slot -> deterministic).
 __global__ void k_et_attn_bwd_t(Graph g, EtAttnArgs a, const float* __restrict__ g_xagg, const float* __restrict__ g_vagg,
                                 float* __restrict__ g_qkv, float* __restrict__ gd2, float* __restrict__ gr2) {
-  __shared__ float part[16][32][4];  // [wave][edge in chunk][g_d, g_rhat xyz]
   const int t = xcd_chunk(blockIdx.x, gridDim.x);
   if (g.counts[2]) return;
-  const int F = a.F, c = threadIdx.x, lane = c & 63, wave = c >> 6, nw = blockDim.x >> 6;
+  const int F = a.F, c = threadIdx.x, lane = c & 63, wave = c >> 6;
   const bool live = c < F;
   const int cc = live ? c : 0;
   const int e0 = g.rowptr[t], e1 = g.rowptr[t + 1];
@@ -238,10 +253,8 @@ __global__ void k_et_attn_bwd_t(Graph g, EtAttnArgs a, const float* __restrict__
   const float* gvp = g_vagg + (int64_t)t * 3 * F + cc;
   const float gv0 = live ? gvp[0] : 0.f, gv1 = live ? gvp[F] : 0.f, gv2 = live ? gvp[2 * F] : 0.f;
   float gq = 0.f;
-  for (int eb = e0; eb < e1; eb += 32) {
-    const int n = min(32, e1 - eb);
-    for (int k = 0; k < n; ++k) {
-      const int e = eb + k;
+  for (int e = e0; e < e1; ++e) {
+    {
       const int s = g.col[e], p = g.epair[e];
       const float sg = g.esign[e];
       const float* sq = a.qkv + (int64_t)s * F5 + cc;
@@ -271,28 +284,16 @@ __global__ void k_et_attn_bwd_t(Graph g, EtAttnArgs a, const float* __restrict__
       const float gca = ((cc % a.hd) == 0) ? g_A * silu(ed.a) : 0.f;
       gd += (a.vector_cutoff ? gcv : gca) * a.dC[p];
       if (!live) gd = 0.f;
-      const float w0 = wave_sum(gd), w1 = wave_sum(live ? gv0 * ed.s2 : 0.f), w2 = wave_sum(live ? gv1 * ed.s2 : 0.f),
-                  w3 = wave_sum(live ? gv2 * ed.s2 : 0.f);
-      if (lane == 0) {
-        part[wave][k][0] = w0;
-        part[wave][k][1] = w1;
-        part[wave][k][2] = w2;
-        part[wave][k][3] = w3;
+      // per-edge totals over the channels of THIS wave; every wave owns its slot (wave, pair, direction): one writer per
+      // slot and a fixed order in k_et_pair_combine -> deterministic, no LDS round trip, no barrier
+      const float tot = wave_sum4(gd, live ? gv0 * ed.s2 : 0.f, live ? gv1 * ed.s2 : 0.f, live ? gv2 * ed.s2 : 0.f, lane);
+      if (sg != 0.f && (lane & 15) == 0) {  // self edges: d = 0 and rhat = 0 carry no position dependence
+        const int64_t slot = (int64_t)wave * a.slot_stride + 2 * (int64_t)p + (sg > 0.f ? 0 : 1);
+        const int comp = lane >> 4;
+        if (comp == 0) gd2[slot] = tot;   // plain stores: the slot arrays are per (layer, wave)
+        else gr2[slot * 3 + comp - 1] = tot;
       }
     }
-    __syncthreads();
-    for (int idx = c; idx < n * 4; idx += blockDim.x) {
-      const int k = idx >> 2, comp = idx & 3, e = eb + k;
-      const float sg = g.esign[e];
-      if (sg != 0.f) {  // self edges: d = 0 and rhat = 0 carry no position dependence
-        float v = 0.f;
-        for (int w = 0; w < nw; ++w) v += part[w][k][comp];
-        const int64_t slot = 2 * (int64_t)g.epair[e] + (sg > 0.f ? 0 : 1);
-        if (comp == 0) gd2[slot] += v;
-        else gr2[slot * 3 + comp - 1] += v;
-      }
-    }
-    __syncthreads();
   }
   if (live) g_qkv[(int64_t)t * F5 + c] = gq;
 }
@@ -361,18 +362,29 @@ void launch_et_attn_bwd_s(const Graph& g, int N, const EtAttnArgs& a, const floa
 }
 
 // gd[p] = gd2[2p] + gd2[2p+1] ; g_prhat[p] = -gr2[2p] + gr2[2p+1]   (rhat of the target sweep = -esign * prhat)
-__global__ void k_et_pair_combine(Graph g, const float* __restrict__ gd2, const float* __restrict__ gr2, float* __restrict__ gd,
-                                  float* __restrict__ g_rhat) {
+__global__ void k_et_pair_combine(Graph g, const float* __restrict__ gd2, const float* __restrict__ gr2, int nw, int64_t stride,
+                                  const float* __restrict__ gd_extra, float* __restrict__ gd, float* __restrict__ g_rhat) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= g.counts[0] || g.counts[2]) return;
-  gd[p] = gd2[2 * (int64_t)p] + gd2[2 * (int64_t)p + 1];
-#pragma unroll
-  for (int ax = 0; ax < 3; ++ax) g_rhat[(int64_t)p * 3 + ax] = -gr2[(2 * (int64_t)p) * 3 + ax] + gr2[(2 * (int64_t)p + 1) * 3 + ax];
+  float d = gd_extra[2 * (int64_t)p], r0 = 0.f, r1 = 0.f, r2 = 0.f;
+  for (int w = 0; w < nw; ++w) {  // the per-(layer, wave) partial sums of the target sweeps, fixed order
+    const int64_t s0 = w * stride + 2 * (int64_t)p, s1 = s0 + 1;
+    d += gd2[s0] + gd2[s1];
+    r0 += -gr2[s0 * 3] + gr2[s1 * 3];
+    r1 += -gr2[s0 * 3 + 1] + gr2[s1 * 3 + 1];
+    r2 += -gr2[s0 * 3 + 2] + gr2[s1 * 3 + 2];
+  }
+  gd[p] = d;
+  g_rhat[(int64_t)p * 3] = r0;
+  g_rhat[(int64_t)p * 3 + 1] = r1;
+  g_rhat[(int64_t)p * 3 + 2] = r2;
 }
-void launch_et_pair_combine(const Graph& g, int Pcap, const float* gd2, const float* gr2, float* gd, float* g_rhat, hipStream_t s) {
+void launch_et_pair_combine(const Graph& g, int Pcap, const float* gd2, const float* gr2, int nw, int64_t stride,
+                            const float* gd_extra, float* gd, float* g_rhat, hipStream_t s) {
   if (Pcap <= 0) return;
-  hipLaunchKernelGGL(k_et_pair_combine, dim3(cdiv_(Pcap, 256)), dim3(256), 0, s, g, gd2, gr2, gd, g_rhat);
+  hipLaunchKernelGGL(k_et_pair_combine, dim3(cdiv_(Pcap, 256)), dim3(256), 0, s, g, gd2, gr2, nw, stride, gd_extra, gd, g_rhat);
 }
+int et_sweep_waves(int F) { return bthreads(F) / 64; }
 
 // ---------------------------------------------------------------------------------------------- head (GatedEquivariantBlock)
 // hcat[n] = [ xsrc[n] (Fx, optional) | norm_a u[3n+a] (Fn) ]      (models/utils.py:626-646)

@@ -207,8 +207,8 @@ EtBuffers et_carve(void* ws, const tmdnet_et_hparams& hp, int64_t N, int64_t B, 
     b.g_xt = c.take<float>(N * F);
     b.g_ln = c.take<float>(N * F);
     b.g_xcat = c.take<float>(N * 2 * F);
-    b.gd2 = c.take<float>(2 * P1);
-    b.gr2 = c.take<float>(6 * P1);
+    b.gd2 = c.take<float>(2 * P1 * (et_sweep_waves((int)F) * L + 1));  // [layer][wave] slot arrays + one for the embedding
+    b.gr2 = c.take<float>(6 * P1 * et_sweep_waves((int)F) * L);
     b.gd = c.take<float>(P1);
     b.g_rhat = c.take<float>(3 * P1);
     b.g_delta = c.take<float>(3 * P1);
@@ -436,7 +436,7 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     EtAttnArgs& a = aa[l];
     a = EtAttnArgs{b.qkv[l], b.vec[l], b.dkv[l], b.tkv[l], b.C, b.dC, F, hd, Wd,
                    (hp.distance_influence & 1) ? 0 : -1, (hp.distance_influence & 2) ? ((hp.distance_influence & 1) ? F : 0) : -1,
-                   hp.vector_cutoff};
+                   hp.vector_cutoff, 2 * (int64_t)P1};
     KR(CAT_MESSAGE, Ed * Fd * 4 * 12, launch_et_attn_fwd(g, N, a, b.xagg, b.vagg, s));
     NODE();
     gemm(s, b.xagg, F, q.Wo, F, q.bo, b.o[l], 3 * F, N, 3 * F, F);
@@ -473,8 +473,10 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     // LayerNorm adjoint of out_norm: its input gradient is the first F columns of g_h1 (row stride 2F) -> compact copy
     KR(CAT_ELEMENTWISE, Nd * Fd * 8, launch_et_copy2d(b.g_h1, 2 * F, b.g_xf, F, N, F, s));
     KR(CAT_ELEMENTWISE, Nd * Fd * 16, launch_layernorm_bwd(b.g_xf, b.xfh, b.rstdf, W.lno_w, N, F, b.g_x, s));
-    KR(CAT_ELEMENTWISE, Pd * 32, launch_fill(b.gd2, 0.f, 2 * (int64_t)P1, s));
-    KR(CAT_ELEMENTWISE, Pd * 32, launch_fill(b.gr2, 0.f, 6 * (int64_t)P1, s));
+    const int nwv = et_sweep_waves(F);
+    const int64_t sstride = 2 * (int64_t)P1;   // one slot array: [pair][direction]
+    float* gd_emb = b.gd2 + sstride * nwv * L;   // the neighbour-embedding term of g_d gets its own array
+    KR(CAT_ELEMENTWISE, Pd * 8, launch_fill(gd_emb, 0.f, sstride, s));
     for (int l = L - 1; l >= 0; --l) {
       const EtLayerP& q = W.layer[l];
       NODE();
@@ -483,7 +485,7 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
       gemm(s, b.g_o, 3 * F, q.WoT, 3 * F, nullptr, b.g_xagg, F, N, F, 3 * F);
       // g_vagg = g_vec (read by both sweeps before sweep "s" adds the source terms into it: snapshot in vagg)
       KR(CAT_ELEMENTWISE, Nd * Fd * 24, launch_et_copy2d(b.g_vec, 3 * F, b.vagg, 3 * F, N, 3 * F, s));
-      KR(CAT_PAIR, Ed * Fd * 4 * 16, launch_et_attn_bwd_t(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.gd2, b.gr2, s));
+      KR(CAT_PAIR, Ed * Fd * 4 * 16, launch_et_attn_bwd_t(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
       KR(CAT_PAIR, Ed * Fd * 4 * 16, launch_et_attn_bwd_s(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, s));
       gemm(s, b.g_vp, 3 * F, q.WvpT, 3 * F, nullptr, b.g_vec, F, 3 * N, F, 3 * F, GEMM_ACCUM);
       gemm(s, b.g_qkv, 5 * F, q.WqkvT, 5 * F, nullptr, b.g_xt, F, N, F, 5 * F);
@@ -492,9 +494,9 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     }
     if (hp.neighbor_embedding) {
       gemm(s, b.g_x, F, W.WcT, F, nullptr, b.g_xcat, 2 * F, N, 2 * F, F);
-      KR(CAT_PAIR, Pd * Fd * 12, launch_et_nbr_embed_bwd(g, P, F, z, W.embN, b.g_xcat, b.dWn, b.gd2, s));
+      KR(CAT_PAIR, Pd * Fd * 12, launch_et_nbr_embed_bwd(g, P, F, z, W.embN, b.g_xcat, b.dWn, gd_emb, s));
     }
-    KR(CAT_PAIR, Pd * 48, launch_et_pair_combine(g, P, b.gd2, b.gr2, b.gd, b.g_rhat, s));
+    KR(CAT_PAIR, Pd * 48, launch_et_pair_combine(g, P, b.gd2, b.gr2, nwv * L, sstride, gd_emb, b.gd, b.g_rhat, s));
     KR(CAT_PAIR, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s));
     KR(CAT_PAIR, Ed * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
   }
