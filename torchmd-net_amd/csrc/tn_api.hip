@@ -776,42 +776,53 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   for (int l = 0; l < L; ++l) {
     const LayerP& q_ = W.layer[l];
     if (es != s) HIP_TRY(m, hipStreamWaitEvent(s, m->ev_join[l], 0));  // join: w[l] (and dw[l]) are ready
-    KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], b.Xh, N, F, s));
+    // X_hat of layer l > 0 was written by the previous layer's update kernel (in place over its own X_hat)
+    if (l == 0) KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], b.Xh, N, F, s));
     tensor_linear(s, b.Xh, q_.V, b.Pn[l], N, F);
     KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch, o3, b.Mi[l], b.Ch, s));
     tensor_linear(s, b.Ch, q_.V + 3, b.D[l], N, F);
-    KR(CAT_ELEMENTWISE, 3 * nodeB, launch_layer_update(b.Xh, b.D[l], q, batch, N, F, b.X[l + 1], s));
+    // update fused with the next consumer of the new X: the next layer's normalisation, or the readout invariants
+    KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(b.Xh, b.D[l], q, batch, N, F, b.X[l + 1], l + 1 < L ? 1 : 2,
+                                                       l + 1 < L ? b.Xh : b.feat, s));
   }
   // ---- readout + head + per-molecule sum
-  KR(CAT_ELEMENTWISE, nodeB + Nd * 3 * Fd * 4, launch_readout_feat(b.X[L], N, F, b.feat, s));
+  if (L == 0) KR(CAT_ELEMENTWISE, nodeB + Nd * 3 * Fd * 4, launch_readout_feat(b.X[L], N, F, b.feat, s));
   KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_fwd(b.feat, W.lnr_w, W.lnr_b, N, 3 * F, b.lnr, b.xhr, b.rstdr, s));
   NODE();
   gemm(s, b.lnr, 3 * F, W.Lin, 3 * F, W.bLin, b.x, F, N, F, 3 * F, GEMM_ACT_SILU, b.al, F);
   gemm(s, b.x, F, W.O1, F, W.bO1, b.ao, H, N, H, F);
-  KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s));
-  KR(CAT_ELEMENTWISE, Nd * 4, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
+  KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_mol_sum(g, b.ao, W.O2, W.bO2, N, B, H, W.std, W.atomref, z, batch, W.mean, energy, s));
 
   if (want_forces) {
     KR(CAT_ELEMENTWISE, Nd * H * 8, launch_head_bwd(b.ao, W.O2, N, H, W.std, b.g_ao, s));
     NODE();
     gemm(s, b.g_ao, H, W.O1T, H, nullptr, b.g_al, F, N, F, H, GEMM_MUL_DSILU_AUX, nullptr, 0, b.al, F);
     gemm(s, b.g_al, F, W.LinT, F, nullptr, b.g_ln, 3 * F, N, 3 * F, F);
-    KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, 3 * F, b.g_feat, s));
-    KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 4, launch_readout_bwd(b.X[L], b.g_feat, N, F, b.G, s));
+    if (F % 64 == 0) {
+      KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 8, launch_lnbwd_readout_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, F, b.X[L], b.G, s));
+    } else {
+      KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, 3 * F, b.g_feat, s));
+      KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 4, launch_readout_bwd(b.X[L], b.g_feat, N, F, b.G, s));
+    }
     // zero-fills are kernels, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to
     // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
     launch_fill(b.gd, 0.f, P1, s);
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];
-      KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch, N, F, b.gD, s));
+      // gD of the layers below the top one comes out of the previous iteration's fused normalisation adjoint
+      if (l == L - 1) KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch, N, F, b.gD, s));
       tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
       KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch, o3, N, F, b.gMi, b.gPn, s));
       KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
       KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));
       tensor_linear(s, b.gPn, q_.VT, b.gXl, N, F);
-      KR(CAT_ELEMENTWISE, 4 * nodeB, launch_norm_bwd(b.X[l], b.gXl, N, F, b.G, s));
+      if (l > 0)
+        KR(CAT_ELEMENTWISE, 6 * nodeB, launch_norm_bwd_update_bwd(b.X[l], b.gXl, N, F, b.G, b.D[l - 1], q, batch, b.gD, s));
+      else
+        KR(CAT_ELEMENTWISE, 5 * nodeB + Nd * 3 * Fd * 12,
+           launch_norm_bwd_gate_bwd(b.X[0], b.gXl, N, F, b.G, b.UX, b.gates, b.a2, b.gUX, b.g_a2, s));
     }
-    KR(CAT_ELEMENTWISE, 3 * nodeB + Nd * 3 * Fd * 12, launch_embed_gate_bwd(b.G, b.UX, b.gates, b.a2, N, F, b.gUX, b.g_a2, s));
+    if (L == 0) KR(CAT_ELEMENTWISE, 3 * nodeB + Nd * 3 * Fd * 12, launch_embed_gate_bwd(b.G, b.UX, b.gates, b.a2, N, F, b.gUX, b.g_a2, s));
     NODE();
     gemm(s, b.g_a2, 3 * F, W.L2T, 3 * F, nullptr, b.g_a1, 2 * F, N, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.a1, 2 * F);
     gemm(s, b.g_a1, 2 * F, W.L1T, 2 * F, nullptr, b.g_ln0, F, N, F, 2 * F);

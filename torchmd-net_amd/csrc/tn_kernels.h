@@ -73,8 +73,9 @@ void launch_norm_x(const float* X, float* Xh, int N, int F, hipStream_t s);
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
                     float* Mi, float* Ch, hipStream_t s);
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);
-void launch_layer_update(const float* Xh, const float* D, const float* q, const int64_t* batch, int N, int F, float* Xn,
-                         hipStream_t s);
+// next = 0: plain; 1: nxt = X_hat of the new X (next layer's k_norm_x); 2: nxt = readout invariants of the new X
+void launch_layer_update(const float* Xh, const float* D, const float* q, const int64_t* batch, int N, int F, float* Xn, int next,
+                         float* nxt, hipStream_t s);
 // ---- readout (reference tensornet.py:384-398, output_modules.py:43-117, model.py:591-607)
 void launch_readout_feat(const float* X, int N, int F, float* feat, hipStream_t s);
 void launch_head_energy(const float* ao, const float* O2, const float* bO2, int N, int H, float std, const float* atomref,
@@ -89,6 +90,15 @@ void launch_update_bwd(const float* G, const float* D, const float* q, const int
 void launch_message_bwd_node(const float* gCh, const float* Pn, const float* Mi, const float* q, const int64_t* batch, int o3, int N,
                              int F, float* gMi, float* gPn, hipStream_t s);
 void launch_norm_bwd(const float* X, const float* gXh_lin, int N, int F, float* G, hipStream_t s);
+// the same followed in-register by the update adjoint of the layer below / by the embedding gate adjoint (G then not stored)
+void launch_norm_bwd_update_bwd(const float* X, const float* gXh_lin, int N, int F, float* G, const float* Dn, const float* q,
+                                const int64_t* batch, float* gD, hipStream_t s);
+void launch_norm_bwd_gate_bwd(const float* X, const float* gXh_lin, int N, int F, float* G, const float* UX, const float* gates,
+                              const float* a2, float* gUX, float* g_a2, hipStream_t s);
+void launch_lnbwd_readout_bwd(const float* g, const float* xhat, const float* rstd, const float* w, int N, int F, const float* X,
+                              float* G, hipStream_t s);
+void launch_head_mol_sum(const Graph& g, const float* ao, const float* O2, const float* bO2, int N, int B, int H, float std,
+                         const float* atomref, const int64_t* z, const int64_t* batch, float mean, float* energy, hipStream_t s);
 void launch_embed_gate_bwd(const float* G, const float* UX, const float* gates, const float* a2, int N, int F, float* gUX, float* g_a2,
                            hipStream_t s);
 void launch_embed_bwd_atom(const float* g_u0_lin, const float* u0, const float* g_s0n, int N, int F, float* gA, hipStream_t s);

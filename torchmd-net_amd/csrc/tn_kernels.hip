@@ -448,6 +448,7 @@ void launch_layernorm_bwd(const float* g, const float* xhat, const float* rstd, 
   hipLaunchKernelGGL(k_layernorm_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, s, g, xhat, rstd, w, rows, R, gx);
 }
 
+
 // =====================================================================================
 //                               interaction layer, node side
 // =====================================================================================
@@ -560,8 +561,11 @@ void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const 
 }
 
 // X_new = X_hat + dX + kappa * dX.dX    (reference tensornet.py:811-812; residual on the normalised X)
+// NEXT 0: plain ; 1: also the next layer's X_hat = X_new / (||X_new||^2 + 1) (k_norm_x) ; 2: also the readout invariants
+// [3 I^2 ; ||A||^2 ; ||S||^2] of X_new (k_readout_feat) -- the consumer's read of X_new and one launch are saved
+template <int NEXT>
 __global__ void k_layer_update(const float* __restrict__ Xh, const float* __restrict__ D, const float* __restrict__ q,
-                               const int64_t* __restrict__ batch, int N, int F, float* __restrict__ Xn) {
+                               const int64_t* __restrict__ batch, int N, int F, float* __restrict__ Xn, float* __restrict__ nxt) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)N * F) return;
   int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
@@ -574,11 +578,26 @@ __global__ void k_layer_update(const float* __restrict__ Xh, const float* __rest
   float o[9];
   decompose(Xf, o);
   store9(Xn + (int64_t)n * 9 * F + f, F, o);
+  if (NEXT == 1) {
+    const float inv = 1.0f / (quad(o) + 1.0f);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c] *= inv;
+    store9(nxt + (int64_t)n * 9 * F + f, F, o);
+  } else if (NEXT == 2) {
+    float* ft = nxt + (int64_t)n * 3 * F + f;
+    const float t = o[4] + o[7];
+    ft[0] = 3.0f * o[0] * o[0];
+    ft[F] = 2.0f * (o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    ft[2 * F] = o[4] * o[4] + o[7] * o[7] + t * t + 2.0f * (o[5] * o[5] + o[6] * o[6] + o[8] * o[8]);
+  }
 }
-void launch_layer_update(const float* Xh, const float* D, const float* q, const int64_t* batch, int N, int F, float* Xn,
-                         hipStream_t s) {
+void launch_layer_update(const float* Xh, const float* D, const float* q, const int64_t* batch, int N, int F, float* Xn, int next,
+                         float* nxt, hipStream_t s) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(k_layer_update, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, Xh, D, q, batch, N, F, Xn);
+  const dim3 grid(cdiv((int64_t)N * F, 256)), block(256);
+  if (next == 1) hipLaunchKernelGGL((k_layer_update<1>), grid, block, 0, s, Xh, D, q, batch, N, F, Xn, nxt);
+  else if (next == 2) hipLaunchKernelGGL((k_layer_update<2>), grid, block, 0, s, Xh, D, q, batch, N, F, Xn, nxt);
+  else hipLaunchKernelGGL((k_layer_update<0>), grid, block, 0, s, Xh, D, q, batch, N, F, Xn, nxt);
 }
 
 // =====================================================================================
@@ -647,6 +666,73 @@ __global__ __launch_bounds__(256) void k_mol_sum(Graph g, const float* __restric
 void launch_mol_sum(const Graph& g, const float* ea, const int64_t* batch, int N, int B, float mean, float* energy, hipStream_t s) {
   if (B <= 0) return;
   hipLaunchKernelGGL(k_mol_sum, dim3(B), dim3(256), 0, s, g, ea, batch, N, B, mean, energy);
+}
+
+// head energy + per-molecule sum in one launch: block per molecule, its 4 waves take the molecule's atoms in turn
+// (e = silu(ao) . O2 + b, * std, + atomref[z]); unsorted batch: the block scans all atoms for its members
+__global__ __launch_bounds__(256) void k_head_mol_sum(Graph g, const float* __restrict__ ao, const float* __restrict__ O2,
+                                                      const float* __restrict__ bO2, int N, int H, float std,
+                                                      const float* __restrict__ atomref, const int64_t* __restrict__ z,
+                                                      const int64_t* __restrict__ batch, float mean, float* __restrict__ energy) {
+  __shared__ float part[4];
+  const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool sorted = !g.counts[3];
+  const int i0 = sorted ? g.mstart[m] : 0, i1 = sorted ? g.mend[m] : N;
+  float acc = 0.f;  // lane 0 of each wave: sum over its atoms, fixed order
+  for (int n = i0 + wave; n < i1; n += 4) {
+    if (!sorted && batch[n] != m) continue;
+    float s = 0.f;
+    for (int k = lane; k < H; k += 64) s += silu(ao[(int64_t)n * H + k]) * O2[k];
+    s = wave_sum(s);
+    float e = (s + bO2[0]) * std;
+    if (atomref) e += atomref[z[n]];
+    acc += e;
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) energy[m] = part[0] + part[1] + part[2] + part[3] + mean;
+}
+void launch_head_mol_sum(const Graph& g, const float* ao, const float* O2, const float* bO2, int N, int B, int H, float std,
+                         const float* atomref, const int64_t* z, const int64_t* batch, float mean, float* energy, hipStream_t s) {
+  if (B <= 0) return;
+  hipLaunchKernelGGL(k_head_mol_sum, dim3(B), dim3(256), 0, s, g, ao, O2, bO2, N, H, std, atomref, z, batch, mean, energy);
+}
+
+// LayerNorm adjoint of the readout row [3F] followed by the adjoint of the invariants (k_readout_bwd): with F % 64 == 0 the
+// lane that holds g_feat[f] also holds g_feat[F + f] and g_feat[2F + f], so G[n, :, f] is written straight away
+__global__ __launch_bounds__(256) void k_lnbwd_readout_bwd(const float* __restrict__ g, const float* __restrict__ xhat,
+                                                           const float* __restrict__ rstd, const float* __restrict__ w, int rows,
+                                                           int F, const float* __restrict__ X, float* __restrict__ G) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int R = 3 * F;
+  const float* gr = g + (int64_t)row * R;
+  const float* xh = xhat + (int64_t)row * R;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = lane; k < R; k += 64) {
+    float gw = gr[k] * w[k];
+    s1 += gw;
+    s2 += gw * xh[k];
+  }
+  s1 = wave_sum(s1) / R;
+  s2 = wave_sum(s2) / R;
+  const float rs = rstd[row];
+  for (int f = lane; f < F; f += 64) {
+    const float gI = (gr[f] * w[f] - s1 - xh[f] * s2) * rs;
+    const float gA = (gr[F + f] * w[F + f] - s1 - xh[F + f] * s2) * rs;
+    const float gS = (gr[2 * F + f] * w[2 * F + f] - s1 - xh[2 * F + f] * s2) * rs;
+    float u[9], dq[9];
+    load9(X + (int64_t)row * 9 * F + f, F, u);
+    dquad(u, dq);
+    float o[9] = {dq[0] * gI, dq[1] * gA, dq[2] * gA, dq[3] * gA, dq[4] * gS, dq[5] * gS, dq[6] * gS, dq[7] * gS, dq[8] * gS};
+    store9(G + (int64_t)row * 9 * F + f, F, o);
+  }
+}
+void launch_lnbwd_readout_bwd(const float* g, const float* xhat, const float* rstd, const float* w, int N, int F, const float* X,
+                              float* G, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_lnbwd_readout_bwd, dim3(cdiv(N, 4)), dim3(256), 0, s, g, xhat, rstd, w, N, F, X, G);
 }
 
 // =====================================================================================
@@ -773,7 +859,13 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red /* [4*NV] *
 }
 
 // G <- (G + gXh_lin)/(s+1) + dquad(X) * g_s ,  g_s = -sum (G + gXh_lin).X / (s+1)^2
-__global__ void k_norm_bwd(const float* __restrict__ X, const float* __restrict__ gl, int N, int F, float* __restrict__ G) {
+// NEXT 0: plain ; 1: also the update adjoint of the layer below, gD = G + kappa (G D^T + D^T G) (k_update_bwd) ;
+// 2: also the embedding gate adjoint (k_embed_gate_bwd) -- then the new G itself is not stored at all
+template <int NEXT>
+__global__ void k_norm_bwd(const float* __restrict__ X, const float* __restrict__ gl, int N, int F, float* __restrict__ G,
+                           const float* __restrict__ Dn, const float* __restrict__ q, const int64_t* __restrict__ batch,
+                           float* __restrict__ gD, const float* __restrict__ UX, const float* __restrict__ gates,
+                           const float* __restrict__ a2, float* __restrict__ gUX, float* __restrict__ g_a2) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)N * F) return;
   int n = (int)(idx / F), f = (int)(idx - (int64_t)n * F);
@@ -792,11 +884,49 @@ __global__ void k_norm_bwd(const float* __restrict__ X, const float* __restrict_
   const float g_s = -dot * inv * inv;
 #pragma unroll
   for (int c = 0; c < 9; ++c) gx[c] = gx[c] * inv + dq[c] * g_s;
-  store9(G + (int64_t)n * 9 * F + f, F, gx);
+  if (NEXT != 2) store9(G + (int64_t)n * 9 * F + f, F, gx);
+  if (NEXT == 1) {
+    float d[9];
+    load9(Dn + (int64_t)n * 9 * F + f, F, d);
+    const float kap = kappa_of(q, batch, n);
+    const M3 Gf = decompose_T(gx);
+    const M3 dXt = transpose(compose(d));
+    const M3 gdx = add(Gf, scale(add(matmul(Gf, dXt), matmul(dXt, Gf)), kap));
+    float o[9];
+    compose_T(gdx, o);
+    store9(gD + (int64_t)n * 9 * F + f, F, o);
+  } else if (NEXT == 2) {
+    float ux[9], o[9];
+    load9(UX + (int64_t)n * 9 * F + f, F, ux);
+    const float* gt = gates + (int64_t)n * 3 * F + f;
+    const float g3[3] = {gt[0], gt[F], gt[2 * F]};
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      o[c] = gx[c] * g3[type_of(c)];
+      acc[type_of(c)] += gx[c] * ux[c];
+    }
+    store9(gUX + (int64_t)n * 9 * F + f, F, o);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g_a2[(int64_t)n * 3 * F + k * F + f] = acc[k] * silu_grad(a2[(int64_t)n * 3 * F + k * F + f]);
+  }
 }
 void launch_norm_bwd(const float* X, const float* gXh_lin, int N, int F, float* G, hipStream_t s) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(k_norm_bwd, dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, X, gXh_lin, N, F, G);
+  hipLaunchKernelGGL((k_norm_bwd<0>), dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, X, gXh_lin, N, F, G, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+void launch_norm_bwd_update_bwd(const float* X, const float* gXh_lin, int N, int F, float* G, const float* Dn, const float* q,
+                                const int64_t* batch, float* gD, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL((k_norm_bwd<1>), dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, X, gXh_lin, N, F, G, Dn, q, batch, gD,
+                     nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+void launch_norm_bwd_gate_bwd(const float* X, const float* gXh_lin, int N, int F, float* G, const float* UX, const float* gates,
+                              const float* a2, float* gUX, float* g_a2, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL((k_norm_bwd<2>), dim3(cdiv((int64_t)N * F, 256)), dim3(256), 0, s, X, gXh_lin, N, F, G, nullptr, nullptr, nullptr,
+                     nullptr, UX, gates, a2, gUX, g_a2);
 }
 
 // X1[c] = UX[c] * gate[type(c)]: gUX = G * gate ; g_gate = sum_c G*UX ; g_a2 = g_gate * silu'(a2)
