@@ -454,8 +454,13 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
   gemm(s, b.vq, F2, W.W21, F2, nullptr, b.w1, F2, 3 * N, F2, F2);
   KR(CAT_ELEMENTWISE, Nd * Fd * 8, launch_et_cat_norm(nullptr, F2, b.w1, F2, F2, N, b.hcat2, s));
   gemm(s, b.hcat2, F, W.Wn1, F, W.bn1, b.m2, F2, N, F2, F, GEMM_ACT_SILU, b.pre2, F2);
-  KR(CAT_ELEMENTWISE, Nd * F2 * 4,
-     launch_head_mol_sum(g, b.pre2, W.Wn2, W.bn2, N, B, F2, W.std, W.atomref, z, batch, W.mean, energy, s));
+  if ((int64_t)N <= 256 * (int64_t)B) {
+    KR(CAT_ELEMENTWISE, Nd * F2 * 4,
+       launch_head_mol_sum(g, b.pre2, W.Wn2, W.bn2, N, B, F2, W.std, W.atomref, z, batch, W.mean, energy, s));
+  } else {
+    KR(CAT_ELEMENTWISE, Nd * F2 * 4, launch_head_energy(b.pre2, W.Wn2, W.bn2, N, F2, W.std, W.atomref, z, b.ea, s));
+    KR(CAT_ELEMENTWISE, Nd * 12, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
+  }
 
   // ---------------- reverse (oracle/et_adjoint.py)
   if (want_forces) {

@@ -383,10 +383,62 @@ __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict
     s0n[(int64_t)i * F + f] = quad(u);
   }
 }
+// small-system variant: 4 thread groups take every 4th edge of the row (see k_message_split)
+__global__ __launch_bounds__(512) void k_embed_scatter_split(Graph g, int N, int F, const int64_t* __restrict__ z,
+                                                             const float* __restrict__ Utab, const float* __restrict__ Vtab,
+                                                             const float* __restrict__ Q, const float* __restrict__ C,
+                                                             float* __restrict__ u0, float* __restrict__ s0n) {
+  __shared__ float part[3][10][128];
+  const int i = blockIdx.x;
+  if (g.counts[2]) return;
+  const int grp = threadIdx.x / F, f = threadIdx.x - grp * F;
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  const int64_t zi = z[i];
+  const int F3 = 3 * F;
+  const float Ui = Utab[zi * F + f];
+  float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // I0, v0..2, t00, t01, t02, t11, t12, t22
+  for (int e = e0 + grp; e < e1; e += 4) {
+    const int j = g.col[e], p = g.epair[e];
+    const float sg = g.esign[e];
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (sg != 0.f) {
+      rx = sg * g.prhat[p * 3];
+      ry = sg * g.prhat[p * 3 + 1];
+      rz = sg * g.prhat[p * 3 + 2];
+    }
+    const float cz = C[p] * (Ui + Vtab[z[j] * F + f]);
+    const float* qq = Q + (int64_t)p * F3 + f;
+    const float W0 = cz * qq[0], W1 = cz * qq[F], W2 = cz * qq[2 * F];
+    a[0] += W0;
+    a[1] += W1 * rx; a[2] += W1 * ry; a[3] += W1 * rz;
+    a[4] += W2 * rx * rx; a[5] += W2 * rx * ry; a[6] += W2 * rx * rz;
+    a[7] += W2 * ry * ry; a[8] += W2 * ry * rz; a[9] += W2 * rz * rz;
+  }
+  if (grp > 0) {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) part[grp - 1][c][f] = a[c];
+  }
+  __syncthreads();
+  if (grp > 0) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int c = 0; c < 10; ++c) a[c] += part[k][c][f];
+  const float tr3 = (a[4] + a[7] + a[9]) * (1.0f / 3.0f);
+  float u[9] = {a[0], a[1], a[2], a[3], a[4] - tr3, a[5], a[6], a[7] - tr3, a[8]};
+  float* o = u0 + (int64_t)i * 9 * F + f;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) o[c * F] = u[c];
+  s0n[(int64_t)i * F + f] = quad(u);
+}
 void launch_embed_scatter(const Graph& g, int N, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
                           const float* C, float* u0, float* s0n, hipStream_t s) {
   if (N <= 0) return;
   // measured on MI355X (profiles/r01_notes.md): the 16-byte CSR sweep is slower than one-channel-per-lane here (scalar edge loads, 4x the waves)
+  if (N <= 512 && F <= 128 && F % 64 == 0) {
+    hipLaunchKernelGGL(k_embed_scatter_split, dim3(N), dim3(4 * F), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
+    return;
+  }
   if (sweep_v4() && gather_v4_ok(F)) return launch_embed_scatter_v4(g, N, F, z, Utab, Vtab, Q, C, u0, s0n, s);
   hipLaunchKernelGGL(k_embed_scatter, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
 }
@@ -528,9 +580,78 @@ __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, co
     store9(Ch + (int64_t)i * 9 * F + f, F, uc);
   }
 }
+// Small systems (single-molecule MD): a row's ~25 edges are a serial chain of dependent loads, and the chip is mostly idle, so
+// EG = 4 thread groups of a block take every 4th edge of the row and their partial sums are combined through LDS in a
+// fixed order.  Used below `kSplitRows` rows; the summation order differs from the one-group kernels by rounding only.
+constexpr int kEG = 4;
+constexpr int kSplitRows = 512;  // measured: 64 atoms 13 -> 7 us per sweep, 1029 atoms slower with the split
+template <int MODE>  // 0: forward message + group product + normalisation ; 1: adjoint (out += gather)
+__global__ __launch_bounds__(512) void k_message_split(Graph g, int N, int F, const float* __restrict__ w,
+                                                       const float* __restrict__ src, const float* __restrict__ q,
+                                                       const int64_t* __restrict__ batch, int o3, float* __restrict__ Mi,
+                                                       float* __restrict__ out) {
+  __shared__ float part[kEG - 1][9][128];
+  const int i = blockIdx.x;
+  if (g.counts[2]) return;
+  const int grp = threadIdx.x / F, f = threadIdx.x - grp * F;
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  const int F3 = 3 * F, F9 = 9 * F;
+  float acc[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+  for (int e = e0 + grp; e < e1; e += kEG) {
+    const int j = g.col[e], p = g.epair[e];
+    const float* wp = w + (int64_t)p * F3 + f;
+    const float* sp = src + (int64_t)j * F9 + f;
+    const float w0 = wp[0], w1 = wp[F], w2 = wp[2 * F];
+    acc[0] += w0 * sp[0];
+    acc[1] += w1 * sp[F];
+    acc[2] += w1 * sp[2 * F];
+    acc[3] += w1 * sp[3 * F];
+    acc[4] += w2 * sp[4 * F];
+    acc[5] += w2 * sp[5 * F];
+    acc[6] += w2 * sp[6 * F];
+    acc[7] += w2 * sp[7 * F];
+    acc[8] += w2 * sp[8 * F];
+  }
+  if (grp > 0) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) part[grp - 1][c][f] = acc[c];
+  }
+  __syncthreads();
+  if (grp > 0) return;
+#pragma unroll
+  for (int k = 0; k < kEG - 1; ++k)
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] += part[k][c][f];
+  float* o = out + (int64_t)i * F9 + f;
+  if (MODE == 1) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c * F] += acc[c];
+  } else {
+    float y[9];
+    load9(src + (int64_t)i * F9 + f, F, y);
+    store9(Mi + (int64_t)i * F9 + f, F, acc);
+    const float kap = kappa_of(q, batch, i);
+    const M3 Y = compose(y), M = compose(acc);
+    M3 Cm = o3 ? scale(add(matmul(Y, M), matmul(M, Y)), kap) : scale(matmul(Y, M), 2.0f);
+    float uc[9];
+    decompose(Cm, uc);
+    const float inv = 1.0f / (frob2(Cm) + 1.0f);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) uc[c] *= inv;
+    store9(o, F, uc);
+  }
+}
+static bool split_rows_ok(int N, int F) { return N <= kSplitRows && F <= 128 && F % 64 == 0; }
+
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
                     float* Mi, float* Ch, hipStream_t s) {
   if (N <= 0) return;
+  if (split_rows_ok(N, F)) {
+    hipLaunchKernelGGL((k_message_split<0>), dim3(N), dim3(kEG * F), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
+    return;
+  }
   if (message_tile_ok(N, F)) return launch_message_tile(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   if (sweep_v4() && gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
@@ -552,6 +673,10 @@ __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict
 }
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
   if (N <= 0) return;
+  if (split_rows_ok(N, F)) {
+    hipLaunchKernelGGL((k_message_split<1>), dim3(N), dim3(kEG * F), 0, s, g, N, F, w, gMi, nullptr, nullptr, 0, nullptr, gPn);
+    return;
+  }
   // the LDS-staged tile sweep is slower for the adjoint (read-modify-write of gPn; 231 vs 204 us at C2,
   // profiles/r01_notes.md), so it is opt-in here
   static const bool tile_adj = getenv("TMDNET_MSG_TILE_ADJOINT") != nullptr;
