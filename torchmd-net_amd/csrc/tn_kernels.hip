@@ -793,18 +793,18 @@ void launch_mol_sum(const Graph& g, const float* ea, const int64_t* batch, int N
   hipLaunchKernelGGL(k_mol_sum, dim3(B), dim3(256), 0, s, g, ea, batch, N, B, mean, energy);
 }
 
-// head energy + per-molecule sum in one launch: block per molecule, its 4 waves take the molecule's atoms in turn
+// head energy + per-molecule sum in one launch: block per molecule, its 16 waves take the molecule's atoms in turn
 // (e = silu(ao) . O2 + b, * std, + atomref[z]); unsorted batch: the block scans all atoms for its members
-__global__ __launch_bounds__(256) void k_head_mol_sum(Graph g, const float* __restrict__ ao, const float* __restrict__ O2,
+__global__ __launch_bounds__(1024) void k_head_mol_sum(Graph g, const float* __restrict__ ao, const float* __restrict__ O2,
                                                       const float* __restrict__ bO2, int N, int H, float std,
                                                       const float* __restrict__ atomref, const int64_t* __restrict__ z,
                                                       const int64_t* __restrict__ batch, float mean, float* __restrict__ energy) {
-  __shared__ float part[4];
+  __shared__ float part[16];
   const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool sorted = !g.counts[3];
   const int i0 = sorted ? g.mstart[m] : 0, i1 = sorted ? g.mend[m] : N;
   float acc = 0.f;  // lane 0 of each wave: sum over its atoms, fixed order
-  for (int n = i0 + wave; n < i1; n += 4) {
+  for (int n = i0 + wave; n < i1; n += 16) {
     if (!sorted && batch[n] != m) continue;
     float s = 0.f;
     for (int k = lane; k < H; k += 64) s += silu(ao[(int64_t)n * H + k]) * O2[k];
@@ -815,12 +815,16 @@ __global__ __launch_bounds__(256) void k_head_mol_sum(Graph g, const float* __re
   }
   if (lane == 0) part[wave] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) energy[m] = part[0] + part[1] + part[2] + part[3] + mean;
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int k = 0; k < 16; ++k) tot += part[k];
+    energy[m] = tot + mean;
+  }
 }
 void launch_head_mol_sum(const Graph& g, const float* ao, const float* O2, const float* bO2, int N, int B, int H, float std,
                          const float* atomref, const int64_t* z, const int64_t* batch, float mean, float* energy, hipStream_t s) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_head_mol_sum, dim3(B), dim3(256), 0, s, g, ao, O2, bO2, N, H, std, atomref, z, batch, mean, energy);
+  hipLaunchKernelGGL(k_head_mol_sum, dim3(B), dim3(1024), 0, s, g, ao, O2, bO2, N, H, std, atomref, z, batch, mean, energy);
 }
 
 // LayerNorm adjoint of the readout row [3F] followed by the adjoint of the invariants (k_readout_bwd): with F % 64 == 0 the
