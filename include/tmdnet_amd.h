@@ -102,7 +102,9 @@ const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel);
  * Returns TMDNET_ERR_OVERFLOW when E > max_num_neighbors * n_atoms. */
 int tmdnet_graph_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, size_t* bytes);
 /* O(N) cell list (reference "cell" strategy: extensions/neighbor_utils.py:89-150, warp_kernels/neighbors_cell.py:17-153;
- * orthorhombic boxes, one box for the whole system).  The caller supplies the grid n_axis = floor(L_axis / cutoff_upper)
+ * the reference handles orthorhombic boxes only; here any box in the reduced lower-triangular form a=(ax,0,0),
+ * b=(bx,by,0), c=(cx,cy,cz) is taken, one box for the whole system).  The caller supplies the grid n_axis =
+ * floor(w_axis / cutoff_upper), w_axis = perpendicular width of the box along that axis (= L_axis when orthorhombic),
  * computed on the host from the box it owns (0,0,0 = always brute force).  The graph builders use the cell list when
  * n_mol == 1, box_mode == 1, every n_axis >= 3 and n_x*n_y*n_z <= 8*n_atoms; otherwise the brute-force sweep runs.
  * Same pair set either way; with the cell list atoms are renumbered in cell order internally and forces are

@@ -294,8 +294,10 @@ def test_static_shapes_equals_dynamic_and_graph_replay(hip_lib, golden_dir):
         small(z, pos, batch)
 
 
-def test_cell_list_equals_brute_force_and_oracle(hip_lib):
-    """Large periodic orthorhombic system: the O(N) cell-list graph (atoms renumbered in cell order internally)
+@pytest.mark.parametrize("triclinic", [False, True])
+def test_cell_list_equals_brute_force_and_oracle(hip_lib, triclinic):
+    """Large periodic system, orthorhombic and triclinic (reduced lower-triangular box; the reference's cell path stops at
+    orthorhombic, neighbors_cell.py:5): the O(N) cell-list graph (atoms renumbered in cell order internally)
     gives the same energies/forces as the brute-force sweep; sampled forces also checked against the oracle
     (reference: cell and brute strategies return the same pair set, tests/test_neighbors.py:74-148)."""
     from oracle import tensornet_c as CO, tensornet_torch as T
@@ -310,12 +312,17 @@ def test_cell_list_equals_brute_force_and_oracle(hip_lib):
     # shift atoms out of the primary cell: wrapping must not matter
     pos = pos + torch.tensor([30.0, -55.0, 12.0])
     batch = torch.zeros_like(z)
+    if triclinic:  # skew the lattice: same fractional coordinates in a sheared box (a_x >= 2 b_x, 2 c_x; b_y >= 2 c_y)
+        frac = pos @ torch.linalg.inv(box)
+        box = box + torch.tensor([[0.0, 0.0, 0.0], [3.1, 0.0, 0.0], [-2.3, 4.0, 0.0]])
+        pos = (frac @ box).float()
     model.cell_list_min_atoms = 10 ** 9
     Eb, Fb = model(z.cuda(), pos.cuda(), batch.cuda(), box=box.cuda())
     cb = model._engine.counts
     model.cell_list_min_atoms = 1
     Ec, Fc = model(z.cuda(), pos.cuda(), batch.cuda(), box=box.cuda())
     cc = model._engine.counts
+    assert model._cell_grid(box.cuda())[0] >= 3  # the cell list really ran
     assert cb[:2] == cc[:2], (cb, cc)
     assert rel_err(Ec, Eb) < 1e-5 and rel_err(Fc, Fb) < 1e-5
     Ec2, Fc2 = model(z.cuda(), pos.cuda(), batch.cuda(), box=box.cuda())

@@ -199,7 +199,7 @@ Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   g.cell_start = c.take<int>(8 * N + 2);
   g.pos_s = c.take<float>(3 * N);
   g.z_s = c.take<int64_t>(N);
-  g.boxd = c.take<float>(4);
+  g.boxd = c.take<float>(12);
   g.sort_tmp_bytes = cell_sort_temp_bytes(N);
   g.sort_tmp = c.take<char>((int64_t)g.sort_tmp_bytes);
   if (total) *total = c.off;

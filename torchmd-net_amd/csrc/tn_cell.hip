@@ -1,7 +1,7 @@
-// O(N) cell-list neighbour graph for one large periodic (orthorhombic) system, gfx950.
+// O(N) cell-list neighbour graph for one large periodic system (orthorhombic or reduced triclinic box), gfx950.
 //
 // Reference: torchmdnet/extensions/neighbor_utils.py:89-150 (build_cell_list: wrap, bin, sort, cell bounds) and
-// warp_kernels/neighbors_cell.py:17-153 (27-cell sweep, orthorhombic minimum image).  Same pair set as the
+// warp_kernels/neighbors_cell.py:17-153 (27-cell sweep; the reference is orthorhombic-only, fractional cells extend it to triclinic).  Same pair set as the
 // brute-force search (the reference's tests assert that, tests/test_neighbors.py:74-148).
 //
 // MI355X design: atoms are RENUMBERED in cell order (stable radix sort of (cell id, atom index), rocPRIM) and the
@@ -35,13 +35,17 @@ size_t cell_sort_temp_bytes(int64_t n) {
   return bytes;
 }
 
-// cell id of every atom from its wrapped position (orthorhombic box, diagonal bx,by,bz); iota for the sort values
+// cell id of every atom from its wrapped FRACTIONAL position; iota for the sort values.  Box rows a = (ax,0,0),
+// b = (bx,by,0), c = (cx,cy,cz) (the reference's reduced form, torchmdnet/models/utils.py:206-229; orthorhombic when
+// the off-diagonals vanish): r = sa a + sb b + sc c is solved back to front.
 __global__ void k_cell_assign(const float* __restrict__ pos, const float* __restrict__ box, int N, int ncx, int ncy, int ncz,
                               int* __restrict__ key, int* __restrict__ iota) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float bx = box[0], by = box[4], bz = box[8];
-  float fx = pos[i * 3] / bx, fy = pos[i * 3 + 1] / by, fz = pos[i * 3 + 2] / bz;
+  const float x = pos[i * 3], y = pos[i * 3 + 1], zc = pos[i * 3 + 2];
+  float fz = zc / box[8];
+  float fy = (y - fz * box[7]) / box[4];
+  float fx = (x - fy * box[3] - fz * box[6]) / box[0];
   fx -= floorf(fx);
   fy -= floorf(fy);
   fz -= floorf(fz);
@@ -78,14 +82,19 @@ void launch_permute_z(const Graph& g, const int64_t* z, int N, hipStream_t s) {
   hipLaunchKernelGGL(k_permute_z, dim3(cdivc(N, 256)), dim3(256), 0, s, z, g.perm, N, g.z_s);
 }
 
-__device__ __forceinline__ float ortho_d2(const float* __restrict__ pos, int hi, int lo, float bx, float by, float bz, float& dx,
-                                          float& dy, float& dz) {
+// minimum image, z -> y -> x (reference neighbors_brute.py / models/utils.py:206-229); same operation order as the brute-force
+// kernels (tn_graph_wave.hip) so that both strategies produce bit-identical deltas
+__device__ __forceinline__ float cell_d2(const float* __restrict__ pos, int hi, int lo, const float* __restrict__ box, float& dx,
+                                         float& dy, float& dz) {
   dx = pos[hi * 3 + 0] - pos[lo * 3 + 0];
   dy = pos[hi * 3 + 1] - pos[lo * 3 + 1];
   dz = pos[hi * 3 + 2] - pos[lo * 3 + 2];
-  dz -= roundf(dz / bz) * bz;  // same operation order as the triclinic formula with zero off-diagonals
-  dy -= roundf(dy / by) * by;
-  dx -= roundf(dx / bx) * bx;
+  const float s3 = roundf(dz / box[8]);
+  dx -= s3 * box[6]; dy -= s3 * box[7]; dz -= s3 * box[8];
+  const float s2 = roundf(dy / box[4]);
+  dx -= s2 * box[3]; dy -= s2 * box[4];
+  const float s1 = roundf(dx / box[0]);
+  dx -= s1 * box[0];
   return dx * dx + dy * dy + dz * dz;
 }
 
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(256) void k_nbr_cell(Graph g, int N, float lo2, flo
   if (i >= N) return;
   if (FILL && g.counts[2]) return;
   const float* __restrict__ pos = g.pos_s;
-  const float bx = g.boxd[0], by = g.boxd[1], bz = g.boxd[2];
+  const float* __restrict__ box = g.boxd;
   const int ncx = g.ncx, ncy = g.ncy, ncz = g.ncz;
   const int ci = g.cell_key_sorted[i];
   const int cz = ci % ncz, cy = (ci / ncz) % ncy, cx = ci / (ncz * ncy);
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256) void k_nbr_cell(Graph g, int N, float lo2, flo
           hit = true;
           self = true;
         } else {
-          d2 = (j < i) ? ortho_d2(pos, i, j, bx, by, bz, dx, dy, dz) : ortho_d2(pos, j, i, bx, by, bz, dx, dy, dz);
+          d2 = (j < i) ? cell_d2(pos, i, j, box, dx, dy, dz) : cell_d2(pos, j, i, box, dx, dy, dz);
           hit = d2 < up2 && d2 >= lo2;
         }
       }
@@ -188,9 +197,7 @@ __global__ __launch_bounds__(256) void k_nbr_cell(Graph g, int N, float lo2, flo
 
 __global__ void k_set_boxd(const float* __restrict__ box, float* boxd, int* mstart, int* mend, int N) {
   if (threadIdx.x == 0) {
-    boxd[0] = box[0];
-    boxd[1] = box[4];
-    boxd[2] = box[8];
+    for (int k = 0; k < 9; ++k) boxd[k] = box[k];
     mstart[0] = 0;  // one molecule: the per-molecule energy sum runs over all atoms
     mend[0] = N;
   }

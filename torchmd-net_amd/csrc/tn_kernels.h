@@ -31,7 +31,7 @@ struct Graph {  // device pointers into the graph workspace
   int* cell_start;       // [ncells+1]
   float* pos_s;          // [N,3] positions in internal order
   int64_t* z_s;          // [N] atomic numbers in internal order
-  float* boxd;           // [4] box diagonal
+  float* boxd;           // [9] device copy of the box (rows a, b, c)
   void* sort_tmp;
   size_t sort_tmp_bytes;
   int ncx, ncy, ncz, use_cell;

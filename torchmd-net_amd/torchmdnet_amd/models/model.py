@@ -394,21 +394,26 @@ class TorchMD_Net(nn.Module):
         return st
 
     def _cell_grid(self, box: Tensor):
-        """floor(L/rc) cells per axis (reference get_cell_dimensions, extensions/neighbor_utils.py:76-86) for an
-        orthorhombic box; (0,0,0) = not applicable.  The host copy of the box is cached per tensor version so
-        that replayed / repeated calls do not synchronise."""
+        """Cells per axis = floor(w / rc) with w the perpendicular width of the box along that axis (for an orthorhombic
+        box the edge length: reference get_cell_dimensions, extensions/neighbor_utils.py:76-86; the reference's cell path
+        stops there, triclinic boxes in its reduced lower-triangular form are handled here as well); (0,0,0) = not
+        applicable.  The host copy of the box is cached per tensor version so that repeated calls do not synchronise."""
         key = (box.data_ptr(), box._version)
         cache = self._engine.__dict__.setdefault("box_cache", {})
         if key not in cache:
             b = box.detach().to("cpu", torch.float64)
-            off = b - torch.diag(torch.diagonal(b))
             rc = float(self.representation_model.cutoff_upper)
-            if float(off.abs().max()) != 0.0:
-                cache.clear()
-                cache[key] = (0, 0, 0)  # triclinic: brute force (the reference's cell path has the same limit)
+            cache.clear()
+            upper = torch.triu(b, diagonal=1)
+            if float(upper.abs().max()) != 0.0 or float(torch.diagonal(b).min()) <= 0.0:
+                cache[key] = (0, 0, 0)  # not in the reduced form a=(ax,0,0), b=(bx,by,0), c=(cx,cy,cz): brute force
             else:
-                cache.clear()
-                cache[key] = tuple(int(torch.floor(b[a, a] / rc)) for a in range(3))
+                vol = float(torch.det(b).abs())
+                a_, b_, c_ = b[0], b[1], b[2]
+                widths = (vol / float(torch.linalg.norm(torch.linalg.cross(b_, c_))),
+                          vol / float(torch.linalg.norm(torch.linalg.cross(c_, a_))),
+                          vol / float(torch.linalg.norm(torch.linalg.cross(a_, b_))))
+                cache[key] = tuple(int(w // rc) for w in widths)
         return cache[key]
 
     @staticmethod
