@@ -18,8 +18,19 @@ namespace tn {
 static inline int cdiv_(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int bthreads(int F) { return ((F + 63) / 64) * 64; }
 
+// all-reduce over aligned groups of 2 / 4 / 8 / 16 lanes with DPP moves (VALU, no LDS round trip): quad_perm xor 1,
+// quad_perm xor 2, row_half_mirror (lane i <-> 7 - i, pairs the two quads of 8), row_mirror (i <-> 15 - i)
+__device__ __forceinline__ float row_sum(float v, int n) {  // n in {1, 2, 4, 8, 16}
+  if (n >= 2) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  if (n >= 4) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  if (n >= 8) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  if (n >= 16) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  return v;
+}
 __device__ __forceinline__ float head_sum(float v, int hd) {  // sum over the hd lanes of one head (hd = 2^k <= 64)
-  for (int off = hd >> 1; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = row_sum(v, hd < 16 ? hd : 16);
+  if (hd >= 32) v += __shfl_xor(v, 16, 64);
+  if (hd >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -34,9 +45,7 @@ __device__ __forceinline__ float wave_sum4(float a, float b, float c, float d, i
   const bool q = lane & 16;
   float v = q ? k1 : k0;
   v += __shfl_xor(q ? k0 : k1, 16, 64);
-#pragma unroll
-  for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  return row_sum(v, 16);
 }
 
 // ---------------------------------------------------------------------------------------------- embedding
