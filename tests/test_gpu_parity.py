@@ -354,3 +354,31 @@ def test_shape_sweep_vs_oracle(hip_lib, F, L, K, group):
         Eo, Fr = T.energy_and_forces(sd, hp, z[sel], pos[sel], batch[sel])
         assert rel_err(E[:2].cpu(), Eo) < REL, (F, L, K, n_mol)
         assert rel_err(Fo[sel.cuda()].cpu(), Fr) < REL, (F, L, K, n_mol)
+
+
+def test_forward_is_capturable_like_the_torchmd_adapter(hip_lib, golden_dir):
+    """The reference's TorchMD adapter (torchmdnet/calculators.py:26-177, `External` with use_cuda_graph=True) loads the
+    model with static_shapes=True, warms `model(z, pos, batch, box)` up on a side stream, captures that very call with
+    torch.cuda.graph and then replays it after `pos.copy_`.  The same sequence must work on the drop-in forward."""
+    g = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    dyn = _model_from_sd(g["args"], g["state_dict"])
+    model = _model_from_sd(dict(g["args"], static_shapes=True), g["state_dict"])
+    model.eval()
+    z, batch = g["z"].cuda(), g["batch"].cuda()
+    pos = g["pos"].cuda().clone()
+    stream = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            energy, forces = model(z, pos, batch, None)
+        with torch.cuda.graph(graph):
+            energy, forces = model(z, pos, batch, None)
+    torch.cuda.current_stream().wait_stream(stream)
+    for step in range(3):
+        new = g["pos"].cuda() + 0.03 * step * torch.randn(g["pos"].shape, generator=torch.Generator().manual_seed(step)).cuda()
+        with torch.no_grad():
+            pos.copy_(new)
+        graph.replay()
+        E, F = energy.clone(), forces.clone()
+        Er, Fr = dyn(z, new.clone(), batch)
+        assert rel_err(E, Er) < 1e-5 and rel_err(F, Fr) < 1e-5, step

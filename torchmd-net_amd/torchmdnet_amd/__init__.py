@@ -15,7 +15,8 @@ def install_as_torchmdnet():
     """Register ``torchmdnet``, ``torchmdnet.models``, ``torchmdnet.models.model`` ... aliases."""
     import importlib
 
-    names = ["", ".models", ".models.model", ".models.utils", ".models.tensornet", ".models.output_modules", ".priors"]
+    names = ["", ".models", ".models.model", ".models.utils", ".models.tensornet", ".models.torchmd_et",
+             ".models.output_modules", ".priors"]
     for n in names:
         mod = importlib.import_module("torchmdnet_amd" + n)
         sys.modules["torchmdnet" + n] = mod

@@ -552,7 +552,17 @@ class TorchMD_Net(nn.Module):
             raise NotImplementedError("torchmdnet_amd computes in fp32; cast positions to float32")
         if self.derivative:
             pos.requires_grad_(True)  # reference side effect (model.py:584-585)
-        n_mol = int(num_systems) if num_systems is not None else (int(batch.max().item()) + 1 if z.numel() else 0)
+        if num_systems is not None:
+            n_mol = int(num_systems)
+        else:
+            # reference OutputModel.reduce (output_modules.py:43-73): the molecule count is read from `batch` (a host sync)
+            # except while the stream is being captured into a CUDA/HIP graph, where the value of the warm-up calls is used
+            capturing = pos.is_cuda and torch.cuda.is_current_stream_capturing()
+            if not capturing:
+                self.output_model.dim_size = int(batch.max().item()) + 1 if z.numel() else 0
+            else:
+                assert self.output_model.dim_size > 0, "Warming up is needed before capturing the model into a CUDA graph"
+            n_mol = self.output_model.dim_size
         rm = self.representation_model
         if box is None and rm.distance.use_periodic:
             box = rm.distance.box
