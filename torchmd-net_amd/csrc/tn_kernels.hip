@@ -97,45 +97,74 @@ __global__ void k_nbr_count(Graph g, const float* __restrict__ pos, const int64_
 }
 
 // single-block exclusive scan of nlow -> pairptr and ntot -> rowptr; publishes P, E and the overflow flag.
-// Each thread owns one contiguous chunk (all its loads are independent and in flight together), the 1024 chunk
-// sums are scanned through LDS, then the chunk is re-read (cache hit) and its prefixes written.
+// Tiles of 8192 elements go through LDS: coalesced loads (8 per thread and array), every thread scans 8 consecutive
+// elements out of LDS, one block scan of the 1024 chunk sums, coalesced stores; a carry links the tiles.
 __global__ __launch_bounds__(1024) void k_scan_counts(Graph g, int N) {
+  constexpr int T = 8192, PER = 8;
+  __shared__ int la[T], lb[T];
   __shared__ int wsum[2][16];
+  __shared__ int carry[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int chunk = (N + 1023) >> 10;
-  const int b0 = min(tid * chunk, N), b1 = min(b0 + chunk, N);
-  int a = 0, b = 0;
-  for (int i = b0; i < b1; ++i) {
-    a += g.nlow[i];
-    b += g.ntot[i];
-  }
-  int ia = a, ib = b;  // inclusive wave scans of the chunk sums
+  if (tid == 0) carry[0] = carry[1] = 0;
+  for (int base = 0; base < N; base += T) {
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int ta = __shfl_up(ia, off, 64), tb = __shfl_up(ib, off, 64);
-    if (lane >= off) {
-      ia += ta;
-      ib += tb;
+    for (int r = 0; r < PER; ++r) {
+      const int i = base + r * 1024 + tid;
+      la[r * 1024 + tid] = i < N ? g.nlow[i] : 0;
+      lb[r * 1024 + tid] = i < N ? g.ntot[i] : 0;
     }
+    __syncthreads();
+    int va[PER], vb[PER], a = 0, b = 0;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      va[r] = la[tid * PER + r];
+      vb[r] = lb[tid * PER + r];
+      a += va[r];
+      b += vb[r];
+    }
+    int ia = a, ib = b;  // inclusive wave scans of the chunk sums
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int ta = __shfl_up(ia, off, 64), tb = __shfl_up(ib, off, 64);
+      if (lane >= off) {
+        ia += ta;
+        ib += tb;
+      }
+    }
+    if (lane == 63) {
+      wsum[0][wave] = ia;
+      wsum[1][wave] = ib;
+    }
+    __syncthreads();
+    int oa = carry[0] + ia - a, ob = carry[1] + ib - b;
+    for (int w = 0; w < wave; ++w) {
+      oa += wsum[0][w];
+      ob += wsum[1][w];
+    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      la[tid * PER + r] = oa;
+      lb[tid * PER + r] = ob;
+      oa += va[r];
+      ob += vb[r];
+    }
+    __syncthreads();
+    if (tid == 1023) {
+      carry[0] = oa;
+      carry[1] = ob;
+    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int i = base + r * 1024 + tid;
+      if (i < N) {
+        g.pairptr[i] = la[r * 1024 + tid];
+        g.rowptr[i] = lb[r * 1024 + tid];
+      }
+    }
+    __syncthreads();
   }
-  if (lane == 63) {
-    wsum[0][wave] = ia;
-    wsum[1][wave] = ib;
-  }
-  __syncthreads();
-  int oa = ia - a, ob = ib - b;
-  for (int w = 0; w < wave; ++w) {
-    oa += wsum[0][w];
-    ob += wsum[1][w];
-  }
-  for (int i = b0; i < b1; ++i) {
-    g.pairptr[i] = oa;
-    g.rowptr[i] = ob;
-    oa += g.nlow[i];
-    ob += g.ntot[i];
-  }
-  if (tid == 1023) {
-    const int P = oa, E = ob;  // the last thread's running totals are the grand totals
+  if (tid == 0) {
+    const int P = carry[0], E = carry[1];
     g.pairptr[N] = P;
     g.rowptr[N] = E;
     g.counts[0] = P;
