@@ -244,6 +244,19 @@ def main():
                        "parallelism": f"molecule-sharded x{world}, RCCL all-reduce of energies"},
             "roofline": roof,
         }
+        # north_star: "achieved HBM GB/s on the scatter": the CSR message sweeps (class "message"), from the fully profiled
+        # warm-up step (HIP events around each launch); algorithmic bytes as defined in DESIGN.md section 4
+        msg = table.get("message")
+        if msg and msg["launches"]:
+            ach_m = msg["bytes"] / (msg["ms"] * 1e-3) / 1e9
+            out["roofline_scatter"] = {"bound": "hbm", "kernel": f"message ({KERNEL_OF['message']})", "achieved": ach_m,
+                                       "peak": PEAK["hbm_gbs"], "unit": "GB/s", "frac": ach_m / PEAK["hbm_gbs"],
+                                       "launches_per_step": msg["launches"], "avg_launch_us": msg["ms"] * 1e3 / msg["launches"],
+                                       "traffic": None}
+            try:
+                out["roofline_scatter"]["traffic"] = json.load(open(pmc)).get("message")
+            except Exception:
+                pass
         if world == 1 and not a.no_md:
             out["md_single_system"] = md_latency(model, args_dict, dev)
         if world == 1 and not a.no_cpu_baseline:
