@@ -166,3 +166,34 @@ def test_et_shape_sweep_vs_oracle(hip_lib, F, H, K, di, ne, vc):
         Eo, Fr = ET.energy_and_forces(sd, hp, z[sel], pos[sel], batch[sel])
         assert rel_err(E[:2].cpu(), Eo) < REL, (F, H, K, n_mol)
         assert rel_err(Fo[sel.cuda()].cpu(), Fr) < REL, (F, H, K, n_mol)
+
+
+def test_et_randomised_small_systems_vs_oracle(hip_lib, golden_dir):
+    """single atoms, isolated atoms (only the self loop: vec stays zero -> the norm's zero-row mask), ragged sizes, unsorted
+    batch vectors, periodic boxes; oracle = oracle/et_torch.py."""
+    import numpy as np
+    from oracle import et_torch as ET
+
+    for fixture in ("et_tiny_ref.pt", "et_tiny_vc_ref.pt"):
+        g = torch.load(os.path.join(golden_dir, fixture))
+        model = _model_from_sd(g["args"], g["state_dict"])
+        hp = ET.hparams_from_args(g["args"])
+        rng = np.random.default_rng(7)
+        for case in range(10):
+            n_mol = int(rng.integers(1, 5))
+            sizes = [int(rng.integers(1, 12)) for _ in range(n_mol)]
+            spread = float(rng.choice([1.5, 3.0, 9.0]))
+            pos = np.concatenate([rng.uniform(0, spread * max(s, 2) ** (1 / 3), size=(s, 3)) for s in sizes]).astype(np.float32)
+            z = rng.integers(1, 20, size=sum(sizes))
+            batch = np.repeat(np.arange(n_mol), sizes)
+            box = torch.tensor([[12.0, 0, 0], [0.5, 12.5, 0], [-0.4, 0.7, 13.0]]) if case % 3 == 1 else None
+            if case % 4 == 3 and n_mol > 1:
+                perm = rng.permutation(len(z))
+                pos, z, batch = pos[perm], z[perm], batch[perm]
+            zt, pt, bt = torch.from_numpy(z), torch.from_numpy(pos), torch.from_numpy(batch)
+            E, F = model(zt.cuda(), pt.cuda(), bt.cuda(), box=None if box is None else box.cuda())
+            for m in range(n_mol):
+                sel = bt == m
+                Eo, Fo = ET.energy_and_forces(g["state_dict"], hp, zt[sel], pt[sel], torch.zeros(int(sel.sum()), dtype=torch.long), box=box)
+                assert abs(E[m].item() - Eo.item()) < 1e-4 * max(1.0, abs(Eo.item())), (fixture, case, m)
+                assert (F[sel.cuda()].cpu() - Fo).abs().max().item() < 1e-4 * max(1.0, Fo.abs().max().item()), (fixture, case, m)

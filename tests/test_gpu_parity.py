@@ -382,3 +382,41 @@ def test_forward_is_capturable_like_the_torchmd_adapter(hip_lib, golden_dir):
         E, F = energy.clone(), forces.clone()
         Er, Fr = dyn(z, new.clone(), batch)
         assert rel_err(E, Er) < 1e-5 and rel_err(F, Fr) < 1e-5, step
+
+
+def test_randomised_small_systems_vs_oracle(hip_lib, golden_dir):
+    """Seeded random sweep over the awkward corners: single atoms, isolated atoms (no neighbour but the self loop), ragged
+    molecule sizes, unsorted batch vectors, per-molecule triclinic boxes, total charges, molecules out of the cutoff's
+    reach; oracle = scalar C transliteration of the kernel-level spec (oracle/tensornet_c.c)."""
+    import numpy as np
+    from oracle import tensornet_c as CO, tensornet_torch as T
+
+    g = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    model = _model_from_sd(g["args"], g["state_dict"])
+    hp = T.hparams_from_args(g["args"])
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        n_mol = int(rng.integers(1, 6))
+        sizes = [int(rng.integers(1, 14)) for _ in range(n_mol)]
+        spread = float(rng.choice([1.5, 3.0, 9.0]))  # 9.0: most atoms isolated at rc = 5
+        pos = np.concatenate([rng.uniform(0, spread * max(s, 2) ** (1 / 3), size=(s, 3)) for s in sizes]).astype(np.float32)
+        z = rng.integers(1, 20, size=sum(sizes))
+        batch = np.repeat(np.arange(n_mol), sizes)
+        use_box = case % 3 == 1
+        use_q = case % 4 == 2
+        box = None
+        if use_box:
+            box = torch.tensor([[[12.0 + m, 0, 0], [0.5, 12.5, 0], [-0.4, 0.7, 13.0]] for m in range(n_mol)], dtype=torch.float32)
+        q = torch.tensor(rng.integers(-2, 3, size=n_mol), dtype=torch.float32) if use_q else None
+        if case % 5 == 4 and n_mol > 1:  # unsorted batch: shuffle the atoms
+            perm = rng.permutation(len(z))
+            pos, z, batch = pos[perm], z[perm], batch[perm]
+        zt, pt, bt = torch.from_numpy(z), torch.from_numpy(pos), torch.from_numpy(batch)
+        E, F = model(zt.cuda(), pt.cuda(), bt.cuda(), box=None if box is None else box.cuda(), q=None if q is None else q.cuda())
+        # the oracles take sorted batches: evaluate molecule by molecule
+        for m in range(n_mol):
+            sel = bt == m
+            Eo, Fo = CO.energy_forces(g["state_dict"], hp, zt[sel], pt[sel], torch.zeros(int(sel.sum()), dtype=torch.long),
+                                      box=None if box is None else box[m], q=None if q is None else q[m:m + 1])
+            assert abs(E[m].item() - Eo.item()) < 1e-4 * max(1.0, abs(Eo.item())), (case, m)
+            assert (F[sel.cuda()].cpu() - Fo).abs().max().item() < 1e-4 * max(1.0, Fo.abs().max().item()), (case, m)
