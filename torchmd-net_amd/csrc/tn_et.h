@@ -33,6 +33,9 @@ void launch_et_attn_bwd_t(const Graph& g, int N, const EtAttnArgs& a, const floa
                           float* gd2, float* gr2, hipStream_t s);
 void launch_et_attn_bwd_s(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
                           float* g_vec, hipStream_t s);
+// both roles of the row atom in one sweep (replaces the two launches above: the per-pair rows are read once per directed edge)
+void launch_et_attn_bwd(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
+                        float* g_vec, float* gd2, float* gr2, hipStream_t s);
 void launch_et_pair_combine(const Graph& g, int Pcap, const float* gd2, const float* gr2, int nw, int64_t stride,
                             const float* gd_extra, float* gd, float* g_rhat, hipStream_t s);
 int et_sweep_waves(int F);  // waves per block of the attention sweeps = partial-sum slots per pair direction

@@ -370,6 +370,118 @@ void launch_et_attn_bwd_s(const Graph& g, int N, const EtAttnArgs& a, const floa
   hipLaunchKernelGGL(k_et_attn_bwd_s, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec);
 }
 
+// Both roles of the row atom r in ONE sweep (the per-pair rows dkv / tkv are then read once per directed edge instead of
+// twice): as TARGET of the message j -> r (g_q[r], the per-edge scalars g_d, g_rhat) and as SOURCE of the message r -> j
+// (g_k[r], g_v[r], g_vec[r]).  rhat(r <- j) = -esign * prhat, rhat(j <- r) = +esign * prhat.
+__global__ void k_et_attn_bwd(Graph g, EtAttnArgs a, const float* __restrict__ g_xagg, const float* __restrict__ g_vagg,
+                              float* __restrict__ g_qkv, float* __restrict__ g_vec, float* __restrict__ gd2, float* __restrict__ gr2) {
+  const int r = xcd_chunk(blockIdx.x, gridDim.x);
+  if (g.counts[2]) return;
+  const int F = a.F, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+  const bool live = c < F;
+  const int cc = live ? c : 0;
+  const int e0 = g.rowptr[r], e1 = g.rowptr[r + 1];
+  const int64_t F5 = 5 * (int64_t)F;
+  const float* rq = a.qkv + (int64_t)r * F5 + cc;
+  const float qr = rq[0], kr = rq[F], vxr = rq[2 * F], v1r = rq[3 * F], v2r = rq[4 * F];
+  const float* vr = a.vec + (int64_t)r * 3 * F + cc;
+  const float vr0 = vr[0], vr1 = vr[F], vr2 = vr[2 * F];
+  const float gxr = live ? g_xagg[(int64_t)r * F + cc] : 0.f;
+  const float* gvr = g_vagg + (int64_t)r * 3 * F + cc;
+  const float gr0 = live ? gvr[0] : 0.f, gr1 = live ? gvr[F] : 0.f, gr2_ = live ? gvr[2 * F] : 0.f;
+  float gq = 0.f, gk = 0.f, gvx = 0.f, gv1 = 0.f, gv2 = 0.f, gvec0 = 0.f, gvec1 = 0.f, gvec2 = 0.f;
+  for (int e = e0; e < e1; ++e) {
+    const int j = g.col[e], p = g.epair[e];
+    const float sg = g.esign[e];
+    const float* jq = a.qkv + (int64_t)j * F5 + cc;
+    const float qj = jq[0], kj = jq[F], vxj = jq[2 * F], v1j = jq[3 * F], v2j = jq[4 * F];
+    const float* dkv = a.dkv + (int64_t)p * a.Wd;
+    const float* tkv = a.tkv + (int64_t)p * a.Wd;
+    const float C = a.C[p];
+    const float cv = a.vector_cutoff ? C : 1.0f, ca = a.vector_cutoff ? 1.0f : C;
+    float dk = 1.f, tk = 0.f, dvx = 1.f, dv1 = 1.f, dv2 = 1.f, tvx = 0.f, tv1 = 0.f, tv2 = 0.f;
+    if (a.dk_off >= 0) {
+      dk = dkv[a.dk_off + cc];
+      tk = tkv[a.dk_off + cc];
+    }
+    if (a.dv_off >= 0) {
+      dvx = dkv[a.dv_off + cc];
+      dv1 = dkv[a.dv_off + F + cc];
+      dv2 = dkv[a.dv_off + 2 * F + cc];
+      tvx = tkv[a.dv_off + cc];
+      tv1 = tkv[a.dv_off + F + cc];
+      tv2 = tkv[a.dv_off + 2 * F + cc];
+    }
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;  // prhat with the edge's sign: rhat(j <- r); rhat(r <- j) is its negative
+    if (sg != 0.f) {
+      p0 = sg * g.prhat[(int64_t)p * 3];
+      p1 = sg * g.prhat[(int64_t)p * 3 + 1];
+      p2 = sg * g.prhat[(int64_t)p * 3 + 2];
+    }
+    // ---- role TARGET: message j -> r
+    {
+      const float at = head_sum(live ? qr * kj * dk : 0.f, a.hd);
+      const float A = silu(at) * ca;
+      const float sx = vxj * cv * dvx, s2 = v2j * cv * dv2;
+      const float* vj = a.vec + (int64_t)j * 3 * F + cc;
+      const float g_sx = gxr * A;
+      const float g_A = head_sum(gxr * sx, a.hd);
+      const float g_s1 = gr0 * vj[0] + gr1 * vj[F] + gr2_ * vj[2 * F];
+      const float g_s2 = -(gr0 * p0 + gr1 * p1 + gr2_ * p2);
+      const float g_a = g_A * silu_grad(at) * ca;
+      gq += g_a * kj * dk;
+      float gd = cv * (g_sx * vxj * tvx + g_s1 * v1j * tv1 + g_s2 * v2j * tv2) + g_a * qr * kj * tk;
+      const float gcv = g_sx * vxj * dvx + g_s1 * v1j * dv1 + g_s2 * v2j * dv2;
+      const float gca = ((cc % a.hd) == 0) ? g_A * silu(at) : 0.f;
+      gd += (a.vector_cutoff ? gcv : gca) * a.dC[p];
+      if (!live) gd = 0.f;
+      // g_rhat is taken with respect to rhat(r <- j) = -p: the slot convention of k_et_pair_combine
+      const float tot = wave_sum4(gd, live ? gr0 * s2 : 0.f, live ? gr1 * s2 : 0.f, live ? gr2_ * s2 : 0.f, lane);
+      if (sg != 0.f && (lane & 15) == 0) {
+        const int64_t slot = (int64_t)wave * a.slot_stride + 2 * (int64_t)p + (sg > 0.f ? 0 : 1);
+        const int comp = lane >> 4;
+        if (comp == 0) gd2[slot] = tot;
+        else gr2[slot * 3 + comp - 1] = tot;
+      }
+    }
+    // ---- role SOURCE: message r -> j
+    {
+      const float as = head_sum(live ? qj * kr * dk : 0.f, a.hd);
+      const float A = silu(as) * ca;
+      const float sx = vxr * cv * dvx, s1 = v1r * cv * dv1;
+      const float gxj = live ? g_xagg[(int64_t)j * F + cc] : 0.f;
+      const float* gvj = g_vagg + (int64_t)j * 3 * F + cc;
+      const float gj0 = gvj[0], gj1 = gvj[F], gj2 = gvj[2 * F];
+      const float g_A = head_sum(gxj * sx, a.hd);
+      const float g_a = g_A * silu_grad(as) * ca;
+      gk += g_a * qj * dk;
+      gvx += gxj * A * cv * dvx;
+      gv1 += (gj0 * vr0 + gj1 * vr1 + gj2 * vr2) * cv * dv1;
+      gv2 += (gj0 * p0 + gj1 * p1 + gj2 * p2) * cv * dv2;
+      gvec0 += gj0 * s1;
+      gvec1 += gj1 * s1;
+      gvec2 += gj2 * s1;
+    }
+  }
+  if (live) {
+    float* o = g_qkv + (int64_t)r * F5 + c;
+    o[0] = gq;
+    o[F] = gk;
+    o[2 * F] = gvx;
+    o[3 * F] = gv1;
+    o[4 * F] = gv2;
+    float* gv = g_vec + (int64_t)r * 3 * F + c;
+    gv[0] += gvec0;
+    gv[F] += gvec1;
+    gv[2 * F] += gvec2;
+  }
+}
+void launch_et_attn_bwd(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
+                        float* g_vec, float* gd2, float* gr2, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_attn_bwd, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2);
+}
+
 // gd[p] = gd2[2p] + gd2[2p+1] ; g_prhat[p] = -gr2[2p] + gr2[2p+1]   (rhat of the target sweep = -esign * prhat)
 __global__ void k_et_pair_combine(Graph g, const float* __restrict__ gd2, const float* __restrict__ gr2, int nw, int64_t stride,
                                   const float* __restrict__ gd_extra, float* __restrict__ gd, float* __restrict__ g_rhat) {
