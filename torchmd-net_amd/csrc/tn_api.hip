@@ -277,6 +277,7 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
     b.gPn = c.take<float>(N9);
     b.gXl = c.take<float>(N9);
     b.gd = c.take<float>(P1);
+    b.gd_slots = c.take<float>(2 * P1 * (int64_t)L * ((F + 63) / 64));  // [layer][wave][pair][direction] partial g_d
     b.gUX = c.take<float>(N9);
     b.g_a2 = c.take<float>(N * 3 * F);
     b.g_a1 = c.take<float>(N * 2 * F);
@@ -812,14 +813,23 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     // zero-fills are kernels, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to
     // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
     launch_fill(b.gd, 0.f, P1, s);
+    const bool merged_gd = message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD");
+    const int gd_nw = message_adjoint_gd_waves(F);
+    const int64_t gd_stride = 2 * (int64_t)P1;
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];
       // gD of the layers below the top one comes out of the previous iteration's fused normalisation adjoint
       if (l == L - 1) KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch, N, F, b.gD, s));
       tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
       KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch, o3, N, F, b.gMi, b.gPn, s));
-      KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
-      KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));
+      if (merged_gd) {
+        KR(CAT_MESSAGE, 2 * msgB + 4 * nodeB,
+           launch_message_adjoint_gd(g, N, F, b.w[l], b.dw[l], b.gMi, b.Pn[l], b.gPn, b.gd_slots + (int64_t)l * gd_nw * gd_stride,
+                                     gd_stride, s));
+      } else {
+        KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
+        KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));
+      }
       tensor_linear(s, b.gPn, q_.VT, b.gXl, N, F);
       if (l > 0)
         KR(CAT_ELEMENTWISE, 6 * nodeB, launch_norm_bwd_update_bwd(b.X[l], b.gXl, N, F, b.G, b.D[l - 1], q, batch, b.gD, s));
@@ -836,7 +846,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
     KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
        launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s));
-    KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s));
+    KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s, merged_gd ? b.gd_slots : nullptr,
+                                               merged_gd ? L * gd_nw : 0, gd_stride));
     KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
   }
   NODE();

@@ -154,9 +154,20 @@ __device__ __forceinline__ int xcd_chunk(int b, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+// all-reduce over aligned groups of 2 / 4 / 8 / 16 lanes with DPP moves (VALU, no LDS round trip): quad_perm xor 1,
+// quad_perm xor 2, row_half_mirror (lane i <-> 7 - i, pairs the two quads of 8), row_mirror (i <-> 15 - i)
+__device__ __forceinline__ float row_sum(float v, int n) {  // n in {1, 2, 4, 8, 16}
+  if (n >= 2) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  if (n >= 4) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  if (n >= 8) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  if (n >= 16) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+// sum over the 64 lanes of a wave, result in every lane: 4 DPP steps inside the rows of 16, 2 cross-row exchanges
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = row_sum(v, 16);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 

@@ -18,15 +18,6 @@ namespace tn {
 static inline int cdiv_(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int bthreads(int F) { return ((F + 63) / 64) * 64; }
 
-// all-reduce over aligned groups of 2 / 4 / 8 / 16 lanes with DPP moves (VALU, no LDS round trip): quad_perm xor 1,
-// quad_perm xor 2, row_half_mirror (lane i <-> 7 - i, pairs the two quads of 8), row_mirror (i <-> 15 - i)
-__device__ __forceinline__ float row_sum(float v, int n) {  // n in {1, 2, 4, 8, 16}
-  if (n >= 2) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-  if (n >= 4) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-  if (n >= 8) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
-  if (n >= 16) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
-  return v;
-}
 __device__ __forceinline__ float head_sum(float v, int hd) {  // sum over the hd lanes of one head (hd = 2^k <= 64)
   v = row_sum(v, hd < 16 ? hd : 16);
   if (hd >= 32) v += __shfl_xor(v, 16, 64);

@@ -73,6 +73,12 @@ void launch_norm_x(const float* X, float* Xh, int N, int F, hipStream_t s);
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
                     float* Mi, float* Ch, hipStream_t s);
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);
+// adjoint sweep + the layer's per-pair distance gradient in one pass (replaces launch_message_adjoint + launch_pair_gd when
+// message_adjoint_gd_ok): partial sums go to slots[wave][2 * pair + direction], summed by launch_geom_gd
+bool message_adjoint_gd_ok(int N, int F);
+int message_adjoint_gd_waves(int F);
+void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
+                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
 // next = 0: plain; 1: nxt = X_hat of the new X (next layer's k_norm_x); 2: nxt = readout invariants of the new X
 void launch_layer_update(const float* Xh, const float* D, const float* q, const int64_t* batch, int N, int F, float* Xn, int next,
                          float* nxt, hipStream_t s);
@@ -124,7 +130,9 @@ void launch_permute_z(const Graph& g, const int64_t* z, int N, hipStream_t s);
 void launch_pair_gd(const Graph& g, int Pcap, int F, const float* gMi, const float* Pn, const float* dw, float* gd, hipStream_t s);
 void launch_embed_pair_gd(const Graph& g, int Pcap, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
                           const float* dQ, const float* C, const float* dC, const float* gA, float* gd, float* g_rhat, hipStream_t s);
-void launch_geom_gd(const Graph& g, int Pcap, const float* gd, const float* g_rhat, float* g_delta, hipStream_t s);
+// g_d[p] = gd[p] + sum of the n_slots slot arrays (each [2 * slot_stride/2]: pair, direction) when slots != null
+void launch_geom_gd(const Graph& g, int Pcap, const float* gd, const float* g_rhat, float* g_delta, hipStream_t s,
+                    const float* slots = nullptr, int n_slots = 0, int64_t slot_stride = 0);
 
 // ---- LDS-staged tile sweeps (tn_message_tile.hip), selected by launch_message / launch_message_adjoint when message_tile_ok(F)
 bool message_tile_ok(int N, int F);

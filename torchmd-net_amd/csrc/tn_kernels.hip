@@ -700,6 +700,60 @@ __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict
     for (int c = 0; c < 9; ++c) o[c * F] += a[c];
   }
 }
+// Adjoint sweep that also produces the layer's distance gradient: at row i, edge (i, j, pair p) contributes
+//     h(i <- j) = sum_{k,f} dw[p,k,f] * sum_{c in k} gMi[j,c,f] * Pn[i,c,f]
+// and g_d[p] = h(i <- j) + h(j <- i) (tn_pairgrad.hip); gMi[j] is loaded for the adjoint anyway and Pn[i] is the row's own,
+// so the separate per-pair kernel (a 4-row gather per pair) disappears.  The per-edge channel sum of a wave goes to its
+// own slot (wave, pair, direction): one writer per slot, summed in fixed order by k_geom_gd -> deterministic.
+__global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ dw,
+                                     const float* __restrict__ gMi, const float* __restrict__ Pn, float* __restrict__ gPn,
+                                     float* __restrict__ slots, int64_t slot_stride) {
+  const int i = xcd_chunk(blockIdx.x, gridDim.x);
+  if (g.counts[2]) return;
+  const int f = threadIdx.x, lane = f & 63, wave = f >> 6;  // blockDim.x == F (multiple of 64)
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  const int F3 = 3 * F, F9 = 9 * F;
+  float y[9], acc[9];
+  load9(Pn + (int64_t)i * F9 + f, F, y);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+  for (int e = e0; e < e1; ++e) {
+    const int j = g.col[e], p = g.epair[e];
+    const float sg = g.esign[e];
+    const float* wp = w + (int64_t)p * F3 + f;
+    const float* dp = dw + (int64_t)p * F3 + f;
+    const float* sp = gMi + (int64_t)j * F9 + f;
+    const float w0 = wp[0], w1 = wp[F], w2 = wp[2 * F];
+    const float d0 = dp[0], d1 = dp[F], d2 = dp[2 * F];
+    float s9[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s9[c] = sp[c * F];
+    acc[0] += w0 * s9[0];
+    acc[1] += w1 * s9[1];
+    acc[2] += w1 * s9[2];
+    acc[3] += w1 * s9[3];
+    acc[4] += w2 * s9[4];
+    acc[5] += w2 * s9[5];
+    acc[6] += w2 * s9[6];
+    acc[7] += w2 * s9[7];
+    acc[8] += w2 * s9[8];
+    float h = d0 * (s9[0] * y[0]) + d1 * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
+              d2 * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
+    h = wave_sum(h);
+    if (lane == 0 && sg != 0.f) slots[(int64_t)wave * slot_stride + 2 * (int64_t)p + (sg > 0.f ? 0 : 1)] = h;
+  }
+  float* o = gPn + (int64_t)i * F9 + f;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) o[c * F] += acc[c];
+}
+bool message_adjoint_gd_ok(int N, int F) { return N > kSplitRows && F % 64 == 0 && F <= 1024; }
+int message_adjoint_gd_waves(int F) { return F / 64; }
+void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
+                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_message_adjoint_gd, dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride);
+}
+
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
   if (N <= 0) return;
   if (split_rows_ok(N, F)) {

@@ -67,7 +67,7 @@ struct FwdBuffers {
   float *he1, *he2, *te1, *te2, *dQ, *Xh, *Ch;
   float *feat, *lnr, *xhr, *rstdr, *al, *x, *ao, *ea;
   // reverse
-  float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *gd;
+  float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *gd, *gd_slots;
   float *gUX, *g_a2, *g_a1, *g_ln0, *g_s0n, *g_u0l, *gA, *g_rhat, *g_delta;
 };
 

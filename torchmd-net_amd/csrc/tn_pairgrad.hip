@@ -211,7 +211,8 @@ void launch_embed_pair_gd(const Graph& g, int Pcap, int F, const int64_t* z, con
 }
 
 // g_delta = (g_r - (g_r . r) r) / d + g_d r     (reference neighbor_utils.py:11-46; zero for d = 0)
-__global__ void k_geom_gd(Graph g, const float* __restrict__ gd, const float* __restrict__ g_rhat, float* __restrict__ g_delta) {
+__global__ void k_geom_gd(Graph g, const float* __restrict__ gd, const float* __restrict__ g_rhat, float* __restrict__ g_delta,
+                          const float* __restrict__ slots, int n_slots, int64_t slot_stride) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= g.counts[0] || g.counts[2]) return;
   const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
@@ -219,14 +220,17 @@ __global__ void k_geom_gd(Graph g, const float* __restrict__ gd, const float* __
   const float inv = d > 0.f ? 1.0f / d : 0.f;
   const float a0 = g_rhat[p * 3], a1 = g_rhat[p * 3 + 1], a2 = g_rhat[p * 3 + 2];
   const float dot = a0 * r0 + a1 * r1 + a2 * r2;
-  const float s = gd[p];
+  float s = gd[p];
+  for (int k = 0; k < n_slots; ++k)  // per-(layer, wave) partial sums of the merged adjoint sweeps, both directions
+    s += slots[k * slot_stride + 2 * (int64_t)p] + slots[k * slot_stride + 2 * (int64_t)p + 1];
   g_delta[p * 3] = (a0 - dot * r0) * inv + s * r0;
   g_delta[p * 3 + 1] = (a1 - dot * r1) * inv + s * r1;
   g_delta[p * 3 + 2] = (a2 - dot * r2) * inv + s * r2;
 }
-void launch_geom_gd(const Graph& g, int Pcap, const float* gd, const float* g_rhat, float* g_delta, hipStream_t s) {
+void launch_geom_gd(const Graph& g, int Pcap, const float* gd, const float* g_rhat, float* g_delta, hipStream_t s, const float* slots,
+                    int n_slots, int64_t slot_stride) {
   if (Pcap <= 0) return;
-  hipLaunchKernelGGL(k_geom_gd, dim3(cdivp(Pcap, 256)), dim3(256), 0, s, g, gd, g_rhat, g_delta);
+  hipLaunchKernelGGL(k_geom_gd, dim3(cdivp(Pcap, 256)), dim3(256), 0, s, g, gd, g_rhat, g_delta, slots, n_slots, slot_stride);
 }
 
 }  // namespace tn
