@@ -614,34 +614,49 @@ __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, co
 // fixed order.  Used below `kSplitRows` rows; the summation order differs from the one-group kernels by rounding only.
 constexpr int kEG = 4;
 constexpr int kSplitRows = 512;  // measured: 64 atoms 13 -> 7 us per sweep, 1029 atoms slower with the split
-template <int MODE>  // 0: forward message + group product + normalisation ; 1: adjoint (out += gather)
+// MODE 0: forward message + group product + normalisation ; 1: adjoint (out += gather) ; 2: adjoint + the per-pair distance
+// gradient halves h(i <- j) = sum dw[p] * gMi[j] * Pn[i] (see k_message_adjoint_gd; Mi then carries Pn, q carries dw)
+template <int MODE>
 __global__ __launch_bounds__(512) void k_message_split(Graph g, int N, int F, const float* __restrict__ w,
                                                        const float* __restrict__ src, const float* __restrict__ q,
                                                        const int64_t* __restrict__ batch, int o3, float* __restrict__ Mi,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, float* __restrict__ slots = nullptr,
+                                                       int64_t slot_stride = 0) {
   __shared__ float part[kEG - 1][9][128];
   const int i = blockIdx.x;
   if (g.counts[2]) return;
   const int grp = threadIdx.x / F, f = threadIdx.x - grp * F;
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   const int F3 = 3 * F, F9 = 9 * F;
-  float acc[9];
+  float acc[9], y[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+  for (int c = 0; c < 9; ++c) acc[c] = y[c] = 0.f;
+  if (MODE == 2) load9(Mi + (int64_t)i * F9 + f, F, y);  // Pn[i]
   for (int e = e0 + grp; e < e1; e += kEG) {
     const int j = g.col[e], p = g.epair[e];
     const float* wp = w + (int64_t)p * F3 + f;
     const float* sp = src + (int64_t)j * F9 + f;
     const float w0 = wp[0], w1 = wp[F], w2 = wp[2 * F];
-    acc[0] += w0 * sp[0];
-    acc[1] += w1 * sp[F];
-    acc[2] += w1 * sp[2 * F];
-    acc[3] += w1 * sp[3 * F];
-    acc[4] += w2 * sp[4 * F];
-    acc[5] += w2 * sp[5 * F];
-    acc[6] += w2 * sp[6 * F];
-    acc[7] += w2 * sp[7 * F];
-    acc[8] += w2 * sp[8 * F];
+    float s9[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s9[c] = sp[c * F];
+    acc[0] += w0 * s9[0];
+    acc[1] += w1 * s9[1];
+    acc[2] += w1 * s9[2];
+    acc[3] += w1 * s9[3];
+    acc[4] += w2 * s9[4];
+    acc[5] += w2 * s9[5];
+    acc[6] += w2 * s9[6];
+    acc[7] += w2 * s9[7];
+    acc[8] += w2 * s9[8];
+    if (MODE == 2) {
+      const float* dp = q + (int64_t)p * F3 + f;  // dw
+      float h = dp[0] * (s9[0] * y[0]) + dp[F] * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
+                dp[2 * F] * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
+      h = wave_sum(h);
+      const float sg = g.esign[e];
+      if ((f & 63) == 0 && sg != 0.f) slots[(int64_t)(f >> 6) * slot_stride + 2 * (int64_t)p + (sg > 0.f ? 0 : 1)] = h;
+    }
   }
   if (grp > 0) {
 #pragma unroll
@@ -654,11 +669,10 @@ __global__ __launch_bounds__(512) void k_message_split(Graph g, int N, int F, co
 #pragma unroll
     for (int c = 0; c < 9; ++c) acc[c] += part[k][c][f];
   float* o = out + (int64_t)i * F9 + f;
-  if (MODE == 1) {
+  if (MODE >= 1) {
 #pragma unroll
     for (int c = 0; c < 9; ++c) o[c * F] += acc[c];
   } else {
-    float y[9];
     load9(src + (int64_t)i * F9 + f, F, y);
     store9(Mi + (int64_t)i * F9 + f, F, acc);
     const float kap = kappa_of(q, batch, i);
@@ -746,11 +760,16 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
 #pragma unroll
   for (int c = 0; c < 9; ++c) o[c * F] += acc[c];
 }
-bool message_adjoint_gd_ok(int N, int F) { return N > kSplitRows && F % 64 == 0 && F <= 1024; }
+bool message_adjoint_gd_ok(int N, int F) { return F % 64 == 0 && (split_rows_ok(N, F) || (N > kSplitRows && F <= 1024)); }
 int message_adjoint_gd_waves(int F) { return F / 64; }
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
   if (N <= 0) return;
+  if (split_rows_ok(N, F)) {
+    hipLaunchKernelGGL((k_message_split<2>), dim3(N), dim3(kEG * F), 0, s, g, N, F, w, gMi, dw, nullptr, 0, const_cast<float*>(Pn), gPn,
+                       slots, slot_stride);
+    return;
+  }
   hipLaunchKernelGGL(k_message_adjoint_gd, dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride);
 }
 
