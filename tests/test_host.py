@@ -193,3 +193,26 @@ def test_install_as_torchmdnet_alias():
         for k in [k for k in sys.modules if k == "torchmdnet" or k.startswith("torchmdnet.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_load_model_equivariant_transformer_checkpoint(tmp_path):
+    """An Equivariant Transformer Lightning checkpoint as the reference writes it (hyper_parameters + "model."-prefixed state
+    dict) loads to the same tensors here and in the live reference."""
+    torch.manual_seed(9)
+    args = dict(W.ET_TINY_ARGS)
+    model = create_model(dict(args))
+    path = str(tmp_path / "et.ckpt")
+    torch.save({"state_dict": {"model." + k: v.clone() for k, v in model.state_dict().items()}, "hyper_parameters": dict(args)}, path)
+    loaded = load_model(path, derivative=True)
+    assert type(loaded.representation_model).__name__ == "TorchMD_ET"
+    for k, v in model.state_dict().items():
+        assert torch.equal(loaded.state_dict()[k], v), k
+    if R.reference_available():
+        mm = R.reference_model_module()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = mm.load_model(path, derivative=True)
+        assert set(ref.state_dict()) == set(loaded.state_dict())
+        for k, v in ref.state_dict().items():
+            assert torch.equal(loaded.state_dict()[k], v), k
