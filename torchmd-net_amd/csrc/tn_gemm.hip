@@ -64,7 +64,7 @@ __device__ __forceinline__ void store_panel(const float4 (&reg)[ROWS * 8 / 256],
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int DBG>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int tiles_n) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -125,11 +125,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
     else load_panel<BN, false>(rb, W, a.ldw, n0, N, k0, K, w_vec, tid);
   };
 
-  if (DBG & 16) {  // experiment: de-synchronise the co-resident blocks of the first round
-    const int grp = (DBG & 32) ? ((DBG & 64) ? (blockIdx.x >> 3) % 3 : blockIdx.x % 3) : (blockIdx.x >> 8) % 3;
-    if (blockIdx.x < 768)
-      for (int i = 0; i < grp * nk / 2; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   fetch(0);
   store_panel<BM>(ra, As, tid);
   store_panel<BN>(rb, Bs, tid);
@@ -141,7 +136,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
 
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
-    if (more && !(DBG & 1)) fetch(kt + 1);
+    if (more) fetch(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       float4 af[MI], bf[NI];
@@ -157,8 +152,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            if (DBG & 4) acc[mi][ni][tt] += afp[mi * 4 + tt] * bfp[ni * 4 + tt];
-            else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(afp[mi * 4 + tt], bfp[ni * 4 + tt], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(afp[mi * 4 + tt], bfp[ni * 4 + tt], acc[mi][ni], 0, 0, 0);
           }
     }
     __syncthreads();
@@ -187,7 +181,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
         const int row = m0 + wm * WTM + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (row >= M) continue;
         float v = acc[mi][ni][e] + bv;
-        if ((DBG & 2) && v != 12345.678f) continue;
         float* cp = C + (int64_t)row * a.ldc + col;
         if (EPI == EPI_PLAIN) {
           *cp = v;
@@ -218,12 +211,12 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs a, int tiles_m, int ti
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int DBG = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
 static int launch_one(const GemmArgs& a, hipStream_t stream) {
   int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   int total = tiles_m * tiles_n * a.groups;
   if (total <= 0) return 0;
-  hipLaunchKernelGGL((k_gemm_nt<BM, BN, WAVES_M, WAVES_N, EPI, DBG>), dim3(total), dim3(256), 0, stream, a, tiles_m, tiles_n);
+  hipLaunchKernelGGL((k_gemm_nt<BM, BN, WAVES_M, WAVES_N, EPI>), dim3(total), dim3(256), 0, stream, a, tiles_m, tiles_n);
   return (int)hipGetLastError();
 }
 
@@ -242,21 +235,6 @@ static int launch_variant(const GemmArgs& a, hipStream_t stream) {
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0) return 0;
-  static const int dbg = getenv("TMDNET_GEMM_DBG") ? atoi(getenv("TMDNET_GEMM_DBG")) : 0;
-  if (dbg) {  // developer ablations on the main tile shape only (results are wrong by construction)
-    switch (dbg) {
-      case 1: return launch_one<128, 128, 2, 2, EPI_GENERIC, 1>(a, stream);
-      case 2: return launch_one<128, 128, 2, 2, EPI_GENERIC, 2>(a, stream);
-      case 3: return launch_one<128, 128, 2, 2, EPI_GENERIC, 3>(a, stream);
-      case 4: return launch_one<128, 128, 2, 2, EPI_GENERIC, 4>(a, stream);
-      case 5: return launch_one<128, 128, 2, 2, EPI_GENERIC, 5>(a, stream);
-      case 7: return launch_one<128, 128, 2, 2, EPI_GENERIC, 7>(a, stream);
-      case 16: return launch_one<128, 128, 2, 2, EPI_GENERIC, 16>(a, stream);
-      case 48: return launch_one<128, 128, 2, 2, EPI_GENERIC, 48>(a, stream);
-      case 112: return launch_one<128, 128, 2, 2, EPI_GENERIC, 112>(a, stream);
-      default: return launch_one<128, 128, 2, 2, EPI_GENERIC, 0>(a, stream);
-    }
-  }
   if (gemm_sb1_ok(a)) return launch_gemm_sb1(a, stream);  // bf16 matrix pipe, exact 3-way split (tn_gemm_sb1.hip)
   // few tiles: the chip would be mostly idle and every launch would cost K/32 dependent iterations ->
   // latency-oriented split-K kernel (single molecules, small MD systems)
