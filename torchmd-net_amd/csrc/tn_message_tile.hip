@@ -22,7 +22,7 @@ constexpr int MT_W = 64;    // window capacity (rows staged in LDS)
 constexpr int MT_THREADS = 512;
 constexpr int MT_SLOTS = MT_THREADS / 32;
 
-template <int MODE, int DBG = 0>  // 0: forward message + group product + normalisation -> Mi, Ch ; 1: adjoint, out += gather
+template <int MODE>  // 0: forward message + group product + normalisation -> Mi, Ch ; 1: adjoint, out += gather
 __global__ __launch_bounds__(MT_THREADS, 2) void k_message_tile(Graph g, int N, int F, const float* __restrict__ w,
                                                          const float* __restrict__ src, const float* __restrict__ q,
                                                          const int64_t* __restrict__ batch, int o3, float* __restrict__ Mi,
@@ -99,13 +99,9 @@ __global__ __launch_bounds__(MT_THREADS, 2) void k_message_tile(Graph g, int N, 
           const int p = __shfl(myp, kc, 32);
           const float* wp = w + (int64_t)p * F3 + f;
           const float msk = valid ? 1.0f : 0.0f;
-          if (DBG & 1) {  // ablation: no weight loads
-            wv[u][0] = wv[u][1] = wv[u][2] = msk * (float)p;
-          } else {
-            wv[u][0] = wp[0] * msk;
-            wv[u][1] = wp[F] * msk;
-            wv[u][2] = wp[2 * F] * msk;
-          }
+          wv[u][0] = wp[0] * msk;
+          wv[u][1] = wp[F] * msk;
+          wv[u][2] = wp[2 * F] * msk;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -136,10 +132,6 @@ __global__ __launch_bounds__(MT_THREADS, 2) void k_message_tile(Graph g, int N, 
       }
     }
     float* o = out + (int64_t)i * F9 + f;
-    if (DBG & 2) {  // ablation: one store per row instead of 9 / 18
-      if (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7] + acc[8] == 123.456f) o[0] = 1.f;
-      continue;
-    }
     if (MODE == 1) {
 #pragma unroll
       for (int c = 0; c < 9; ++c) o[c * F] += acc[c];
@@ -173,19 +165,6 @@ bool message_tile_ok(int N, int F) {
 void launch_message_tile(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
                          int o3, float* Mi, float* Ch, hipStream_t s) {
   const int nchunks = F / MT_FC, tiles = (N + MT_TA - 1) / MT_TA;
-  static const int dbg = getenv("TMDNET_MT_DBG") ? atoi(getenv("TMDNET_MT_DBG")) : 0;
-  if (dbg == 1) {
-    hipLaunchKernelGGL((k_message_tile<0, 1>), dim3(tiles * nchunks), dim3(MT_THREADS), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, nchunks);
-    return;
-  }
-  if (dbg == 2) {
-    hipLaunchKernelGGL((k_message_tile<0, 2>), dim3(tiles * nchunks), dim3(MT_THREADS), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, nchunks);
-    return;
-  }
-  if (dbg == 3) {
-    hipLaunchKernelGGL((k_message_tile<0, 3>), dim3(tiles * nchunks), dim3(MT_THREADS), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, nchunks);
-    return;
-  }
   hipLaunchKernelGGL((k_message_tile<0>), dim3(tiles * nchunks), dim3(MT_THREADS), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, nchunks);
 }
 void launch_message_adjoint_tile(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
