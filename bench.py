@@ -258,9 +258,15 @@ def main():
             except Exception:
                 pass
         if world == 1 and not a.no_md:
-            out["md_single_system"] = md_latency(model, args_dict, dev)
+            try:  # an auxiliary leg must never cost the main line
+                out["md_single_system"] = md_latency(model, args_dict, dev)
+            except Exception as exc:  # noqa: BLE001
+                out["md_single_system"] = {"error": repr(exc)}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args_dict, model.state_dict())
+            try:
+                out["cpu_baseline"] = cpu_baseline(args_dict, model.state_dict())
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(exc)}
         if a.breakdown:
             os.makedirs(os.path.dirname(os.path.abspath(a.breakdown)), exist_ok=True)
             with open(a.breakdown, "w") as fh:
