@@ -197,3 +197,18 @@ def test_et_randomised_small_systems_vs_oracle(hip_lib, golden_dir):
                 Eo, Fo = ET.energy_and_forces(g["state_dict"], hp, zt[sel], pt[sel], torch.zeros(int(sel.sum()), dtype=torch.long), box=box)
                 assert abs(E[m].item() - Eo.item()) < 1e-4 * max(1.0, abs(Eo.item())), (fixture, case, m)
                 assert (F[sel.cuda()].cpu() - Fo).abs().max().item() < 1e-4 * max(1.0, Fo.abs().max().item()), (fixture, case, m)
+
+
+def test_et_energy_only_and_backward(hip_lib, golden_dir):
+    """derivative=False: energies alone (the pair GEMMs then carry no tangents), and energy.backward() filling pos.grad the way
+    the ASE calculator uses the model (calculators.py:311-316)."""
+    g = torch.load(os.path.join(golden_dir, "et_tiny_ref.pt"))
+    model = _model_from_sd(dict(g["args"], derivative=False), g["state_dict"])
+    z, batch = g["z"].cuda(), g["batch"].cuda()
+    with torch.no_grad():
+        E0, empty = model(z, g["pos"].cuda(), batch)
+    assert empty.numel() == 0 and rel_err(E0.cpu(), g["E"]) < REL
+    pos = g["pos"].cuda().clone().requires_grad_(True)
+    E1, _ = model(z, pos, batch)
+    E1.sum().backward()
+    assert rel_err(-pos.grad.cpu(), g["F"]) < REL and rel_err(E1.detach().cpu(), g["E"]) < REL

@@ -414,7 +414,8 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
   KR(CAT_ELEMENTWISE, Pd * K * 8, launch_radial(g, P, RadialParams{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper}, b.phi, b.dphi, b.C, b.dC, s));
   if (hp.neighbor_embedding) {
     EDGE(1);
-    gemm_dual(s, 3, b.phi, b.dphi, K, W.Wn, W.bn, b.Wn, b.dWn, F, P1, F, K, b.C, b.dC, W.Wn_sb);
+    if (want_forces) gemm_dual(s, 3, b.phi, b.dphi, K, W.Wn, W.bn, b.Wn, b.dWn, F, P1, F, K, b.C, b.dC, W.Wn_sb);
+    else gemm(s, b.phi, K, W.Wn, K, W.bn, b.Wn, F, P1, F, K, GEMM_ROWSCALE, nullptr, 0, nullptr, 0, b.C);  // energies only: no tangents
     KR(CAT_SCATTER, Ed * Fd * 8, launch_et_nbr_embed(g, N, F, z, W.emb, W.embN, b.Wn, b.xcat, s));
     NODE();
     gemm(s, b.xcat, 2 * F, W.Wc, 2 * F, W.bc, b.x[0], F, N, F, 2 * F);
@@ -431,7 +432,8 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     gemm(s, b.vec[l], F, q.Wvp, F, nullptr, b.vp[l], 3 * F, 3 * N, 3 * F, F);
     if (Wd > 0) {
       EDGE(1);
-      gemm_dual(s, 1, b.phi, b.dphi, K, q.Wdkv, q.bdkv, b.dkv[l], b.tkv[l], Wd, P1, Wd, K, nullptr, nullptr, q.Wdkv_sb);
+      if (want_forces) gemm_dual(s, 1, b.phi, b.dphi, K, q.Wdkv, q.bdkv, b.dkv[l], b.tkv[l], Wd, P1, Wd, K, nullptr, nullptr, q.Wdkv_sb);
+      else gemm(s, b.phi, K, q.Wdkv, K, q.bdkv, b.dkv[l], Wd, P1, Wd, K, GEMM_ACT_SILU);
     }
     EtAttnArgs& a = aa[l];
     a = EtAttnArgs{b.qkv[l], b.vec[l], b.dkv[l], b.tkv[l], b.C, b.dC, F, hd, Wd,
