@@ -1,21 +1,33 @@
 """bench.py -- molecules/s of the TensorNet energy+force path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-One "step" = one full pass of the hot path over one batch resident in HBM: neighbour graph build,
-radial functions, embedding, L interaction layers, readout, per-molecule energies AND the hand-written
-reverse pass for the forces (BASELINE configs[1]: TensorNet 128-hidden 2-layer, synthetic 64-atom x
-256-molecule batch, fp32).  Multi-GPU = weak scaling: every rank evaluates its own 256 molecules
-(no data-path collective) and the per-molecule energies are all-reduced over RCCL each step.
+With N > 1 and no torch.distributed environment the script launches its own N ranks (one per GPU) through
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; launched by the driver under
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events recorded by the library
-on the launch stream around every launch of the dominant kernel class during the timed region;
-`cpu_baseline` is the oracle (a restatement of the reference's PyTorch CPU path) timed on this host.
+One "step" = one full pass of the hot path over one batch resident in HBM: neighbour graph build, radial functions,
+embedding, L interaction layers, readout, per-molecule energies AND the hand-written reverse pass for the forces
+(BASELINE configs[1]: TensorNet 128-hidden 2-layer, synthetic 64-atom x 256-molecule batch, fp32).
+  weak   (default): every rank evaluates its own 256 molecules, no data-path collective, one RCCL all-reduce of the
+                    zero-padded per-molecule energy vector per step;
+  strong (BASELINE configs[2]): the SAME 256-molecule batch is sharded over the ranks by contiguous molecule ranges
+                    (torchmdnet_amd.parallel.ShardedEvaluator: forces stay local, energies all-reduced over RCCL).
+With N > 1 the other mode is timed as well and reported in a sub-object.
+
+Prints ONE JSON line (rank 0).  `roofline` = the dominant KERNEL (one kernel on one shape) of the dominant kernel class,
+measured live with HIP events recorded by the library on the launch stream around every launch during the timed
+region, with the class average beside it; `roofline_scatter` = the CSR message sweeps against the HBM peak;
+`cpu_baseline` = the oracle (a restatement of the reference's PyTorch CPU path) timed on this host; `et_c4` and
+`water10k` = BASELINE configs[3] / configs[4] with their own dominant-kernel rooflines; `md_single_system` = ns/day of
+a HIP-graph-replayed 64-atom system.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,21 +36,26 @@ for p in (ROOT, os.path.join(ROOT, "torchmd-net_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 N_MOL, N_ATOMS = 256, 64
-# /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA 157.3 TF, dense bf16 MFMA 2.5 PF, HBM 8 TB/s.  The pair-row GEMMs
-# (class gemm_edge) compute every fp32 product as 6 bf16 MFMA products (exact 3-way split, fp32 accumulation,
-# tn_gemm_sb.hip), so their fp32-equivalent ceiling is 2500 / 6 TF; the per-atom GEMMs run on the fp32 MFMA pipe.
+# /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA 157.3 TF, dense bf16 MFMA 2.5 PF, HBM 8 TB/s.  The split-bf16 GEMMs
+# compute every fp32 product as 6 bf16 MFMA products (exact 3-way split, fp32 accumulation, tn_gemm_sb.hip), so their
+# fp32-equivalent ceiling is 2500 / 6 TF.
 PEAK = {"mfma_f32_tflops": 157.3, "mfma_bf16_tflops": 2500.0, "hbm_gbs": 8000.0}
 SPLIT_PRODUCTS = 6
+# HIP kernels behind each profiled class (rocprofv3 names, profiles/r02_kernel_stats*.csv)
+KERNEL_OF = {"gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_sb1", "message": "k_message_tile / k_message_adjoint_gd",
+             "pair_bwd": "k_embed_pair_gd_v4 / k_geom_gd", "embed_scatter": "k_embed_scatter", "elementwise": "elementwise",
+             "graph": "k_nbr_wave / k_scan_counts"}
 
 
-def profile_classes(model, L, stream_ptr, mask):
-    n = L.tmdnet_profile_num_categories()
+# ----------------------------------------------------------------------------------------------- profiling helpers
+def profile_begin(model, L, mask=0xFFFFFFFF):
     L.tmdnet_profile_begin(model._engine.handle, mask)
-    return n
+
+
+def profile_classes(model, L, stream_ptr, mask):  # kept for tools/*.py
+    profile_begin(model, L, mask)
+    return L.tmdnet_profile_num_categories()
 
 
 def profile_collect(model, L, stream_ptr, n):
@@ -52,10 +69,91 @@ def profile_collect(model, L, stream_ptr, n):
     return {names[i]: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(ln[i])) for i in range(n)}
 
 
+def profile_records(model, L, stream_ptr, cap=65536):
+    """Per-launch records of the profiled region -> (per-class table, per-kernel groups).  A group = launches that share
+    (class, label): one kernel on one shape."""
+    cat = (C.c_int32 * cap)()
+    ms = (C.c_double * cap)()
+    fl = (C.c_double * cap)()
+    by = (C.c_double * cap)()
+    lab = C.create_string_buffer(64 * cap)
+    n = C.c_int64(0)
+    rc = L.tmdnet_profile_end_records(model._engine.handle, stream_ptr, cap, cat, ms, fl, by, lab, C.byref(n))
+    assert rc == 0, rc
+    names = [L.tmdnet_profile_category_name(i).decode() for i in range(L.tmdnet_profile_num_categories())]
+    classes = {k: dict(ms=0.0, flops=0.0, bytes=0.0, launches=0) for k in names}
+    groups = {}
+    for i in range(min(int(n.value), cap)):
+        cls = names[cat[i]]
+        label = lab.raw[64 * i:64 * i + 64].split(b"\0", 1)[0].decode()
+        for d in (classes[cls], groups.setdefault((cls, label), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))):
+            d["ms"] += ms[i]
+            d["flops"] += fl[i]
+            d["bytes"] += by[i]
+            d["launches"] += 1
+    return classes, groups
+
+
+def roofline_of(rec, cls, label, pmc=None, note_kernel=None):
+    """rec: summed ms / flops / bytes / launches of one kernel (or class).  MFMA-bound when it carries FLOPs."""
+    launches = max(rec["launches"], 1)
+    avg_s = rec["ms"] * 1e-3 / launches
+    kernel = note_kernel or KERNEL_OF.get(cls, cls)
+    if rec["flops"] > 0:
+        ach = rec["flops"] / launches / avg_s / 1e12
+        split = not os.environ.get("TMDNET_NO_SPLIT_BF16")
+        peak = PEAK["mfma_bf16_tflops"] / SPLIT_PRODUCTS if split else PEAK["mfma_f32_tflops"]
+        inst = "v_mfma_f32_32x32x16_bf16 x6 per fp32 product" if split else "v_mfma_f32_32x32x2_f32"
+        roof = {"bound": "mfma", "kernel": f"{kernel} [{label}] ({inst})", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak,
+                "peak_note": ("fp32-equivalent: dense bf16 MFMA peak 2500 TF / 6 split products; achieved counts algorithmic "
+                              "fp32 FLOPs (x6 = executed bf16 FLOPs)") if split else "fp32 MFMA peak",
+                "algorithmic_bytes_per_launch": rec["bytes"] / launches}
+    else:
+        ach = rec["bytes"] / launches / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": f"{kernel} [{label}]", "achieved": ach, "peak": PEAK["hbm_gbs"], "unit": "GB/s",
+                "frac": ach / PEAK["hbm_gbs"], "algorithmic_bytes_per_launch": rec["bytes"] / launches}
+    roof.update({"traffic": None, "launches": rec["launches"], "avg_launch_us": avg_s * 1e6})
+    if pmc is not None:
+        roof["traffic"] = pmc
+        roof["traffic_ratio"] = pmc / max(rec["bytes"] / launches, 1.0)  # HBM bytes moved / algorithmic bytes
+    return roof
+
+
+def dominant(groups, cls=None):
+    items = [(k, v) for k, v in groups.items() if cls is None or k[0] == cls]
+    return max(items, key=lambda kv: kv[1]["ms"])
+
+
+def pmc_kernel_bytes(pmc, cls, label):
+    """HBM bytes per launch (PMC, tools/pmc_traffic.py) of the kernel behind a profile label, when the label names one
+    template instance whose launches all have this shape (e.g. gemm_dual<2> = k_gemm_dual_sb2<2>: only the 2F -> 3F GEMM)."""
+    per = pmc.get("_per_kernel_total", {})
+    head = label.split(" ")[0].split("(")[0]
+    names = {"gemm_dual<2>": ["k_edge_mlp", "k_gemm_dual_sb2<2>"], "gemm_dual<0>": ["k_gemm_dual_sb2<0>"],
+             "launch_message": ["k_message_pair<0>", "k_message_tile<0>"],
+             "launch_message_adjoint_gd": ["k_message_pair<1>", "k_message_adjoint_gd"],
+             "launch_embed_scatter": ["k_embed_scatter"], "launch_embed_pair_gd": ["k_embed_pair_gd_v4"]}.get(head, [])
+    for n in names:
+        if n in per:
+            return per[n]
+    return None
+
+
+def load_pmc():
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
+
+
+# ----------------------------------------------------------------------------------------------- auxiliary legs
 def md_latency(model, args_dict, dev, steps=300, dt_fs=1.0):
-    """Second half of BASELINE.json's metric: ns/day of single-system stepping (one 64-atom molecule,
-    energies + forces every step, neighbour list rebuilt every step) replayed from a captured HIP graph
-    (static_shapes=True, reference tensornet.py:277-290 / calculators.py:117-128).  ns/day = steps/s * dt * 0.0864."""
+    """Second half of BASELINE.json's metric: ns/day of single-system stepping (one 64-atom molecule, energies + forces
+    every step, neighbour list rebuilt every step) replayed from a captured HIP graph (static_shapes=True, reference
+    tensornet.py:277-290 / calculators.py:117-128).  ns/day = steps/s * dt * 0.0864."""
+    import torch
     from torchmdnet_amd import workloads as W
     from torchmdnet_amd.models.model import create_model
 
@@ -76,9 +174,79 @@ def md_latency(model, args_dict, dev, steps=300, dt_fs=1.0):
             "ns_per_day": 86400.0 / dt * dt_fs * 1e-6, "dt_fs": dt_fs}
 
 
-def cpu_baseline(args_dict, state_dict, budget_s=20.0):
-    """Oracle (oracle/tensornet_torch.py: the reference's pure-PyTorch CPU algorithm, autograd forces)
-    on a bounded sample of the same workload: batches of 16 molecules until ~budget_s seconds."""
+def timed_leg(model, L, dev, step, steps, warmup):
+    """warm-up, one fully profiled step (per-kernel groups), `steps` timed steps.  Returns (s per step, classes, groups)."""
+    import torch
+
+    sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    profile_begin(model, L)
+    step()
+    classes, groups = profile_records(model, L, sp)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps, classes, groups, out
+
+
+def et_c4_leg(dev, L, steps=8, warmup=3):
+    """BASELINE configs[3]: ET-SPICE.yaml Equivariant Transformer (F=128, 5 layers, 8 heads, K=64, rc=10 A, neighbour
+    embedding, distance influence on keys and values, vector cutoff), 256 x 64-atom molecules, E+F.  The config says bf16:
+    the GEMMs run on the bf16 matrix pipe through the exact 3-way split, i.e. at fp32 accuracy."""
+    import torch
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(0)
+    model = create_model(dict(W.C4_ARGS)).to(dev)
+    z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS)
+    z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
+    dt, classes, groups, (e, f) = timed_leg(model, L, dev, lambda: model.energy_and_forces(z, pos, batch, None, None, N_MOL), steps, warmup)
+    assert torch.isfinite(e).all() and torch.isfinite(f).all()
+    (cls, label), rec = dominant(groups)
+    return {"workload": "BASELINE configs[3]: ET-SPICE.yaml hyper-parameters, S-mol64 256 x 64 atoms, E+F, random-init (seed 0)",
+            "ms_per_step": dt * 1e3, "molecules_per_s": N_MOL / dt, "dtype": "f32 (bf16 MFMA, exact 3-way split)",
+            "pairs": model._engine.counts[0], "roofline": roofline_of(rec, cls, label, note_kernel=ET_KERNEL_OF.get(cls)),
+            "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
+
+
+ET_KERNEL_OF = {"message": "k_et_attn_fwd", "pair_bwd": "k_et_attn_bwd", "gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_sb1"}
+
+
+def water10k_leg(dev, L, steps=8, warmup=3, dt_fs=1.0):
+    """BASELINE configs[4]: 10k-atom periodic water box, O(N) cell-list neighbours, ns/day of E+F stepping on one GPU
+    (the AceFF-1.1 checkpoint is not available offline: TensorNet with the C2 hyper-parameters, random-init)."""
+    import torch
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(0)
+    model = create_model(dict(W.C2_ARGS, max_num_neighbors=96)).to(dev)
+    z, pos, box = W.water_box(n_side=15)  # 10 125 atoms, 46.5 A box (0.1 atoms / A^3)
+    z, pos, box = z.to(dev), pos.to(dev), box.to(dev)
+    batch = torch.zeros_like(z)
+    n = int(z.shape[0])
+    dt, classes, groups, (e, f) = timed_leg(model, L, dev, lambda: model.energy_and_forces(z, pos, batch, box, None, 1), steps, warmup)
+    assert torch.isfinite(e).all() and torch.isfinite(f).all()
+    grid = model.cell_grid(n)
+    (cls, label), rec = dominant(groups)
+    return {"workload": f"BASELINE configs[4]-like: {n}-atom periodic water box, TensorNet F=128 L=2 K=32 rc=5.0 (random-init), "
+                        "cell-list neighbours rebuilt every step, E+F",
+            "atoms": n, "pairs": model._engine.counts[0], "cell_grid": grid[:3], "cell_list": bool(grid[3]),
+            "ms_per_step": dt * 1e3, "ns_per_day": 86400.0 / dt * dt_fs * 1e-6, "dt_fs": dt_fs,
+            "roofline": roofline_of(rec, cls, label), "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
+
+
+def cpu_baseline(args_dict, state_dict, budget_s=25.0):
+    """Oracle (oracle/tensornet_torch.py: the reference's pure-PyTorch CPU algorithm, autograd forces; the unmodified
+    reference cannot travel to the GPU box) on a bounded sample of the same workload, BASELINE.md section 3 protocol:
+    chunks of 16 molecules (the [E,3,3,F] temporaries of a 256-molecule batch do not fit a cache), 2 warm-ups, best of 5
+    timed evaluations per chunk, chunk times summed.  The thread count is the fastest of {all, 64, 32, 16, 8}."""
+    import torch
     from oracle import tensornet_torch as T
     from torchmdnet_amd import workloads as W
 
@@ -86,8 +254,8 @@ def cpu_baseline(args_dict, state_dict, budget_s=20.0):
     sd = {k: v.detach().cpu() for k, v in state_dict.items()}
     chunk = 16
     z, pos, batch = W.synthetic_batch(n_mol=chunk)
-    T.energy_and_forces(sd, hp, z, pos, batch)  # warm-up
-    # the fastest thread count on this host is the baseline (many-core hosts oversubscribe small tensor ops)
+    T.energy_and_forces(sd, hp, z, pos, batch)  # first-touch warm-up
+    host_cores = os.cpu_count() or 1
     all_threads = torch.get_num_threads()
     best_t, best = all_threads, None
     for t in sorted({all_threads, 64, 32, 16, 8}):
@@ -101,26 +269,45 @@ def cpu_baseline(args_dict, state_dict, budget_s=20.0):
         if best is None or el1 < best:
             best, best_t = el1, t
     torch.set_num_threads(best_t)
-    budget_s = max(budget_s - 10 * best, 5.0)
-    t0 = time.perf_counter()
-    done = 0
-    while True:
-        z, pos, batch = W.synthetic_batch(n_mol=chunk, first_seed=done % N_MOL)
-        t1 = time.perf_counter()
-        T.energy_and_forces(sd, hp, z, pos, batch)
+    t_start = time.perf_counter()
+    done, total = 0, 0.0
+    while done < N_MOL:
+        z, pos, batch = W.synthetic_batch(n_mol=chunk, first_seed=done)
+        times = []
+        for rep in range(7):  # 2 warm-ups + 5 timed
+            t1 = time.perf_counter()
+            T.energy_and_forces(sd, hp, z, pos, batch)
+            if rep >= 2:
+                times.append(time.perf_counter() - t1)
+        total += min(times)
         done += chunk
-        if time.perf_counter() - t0 > budget_s or done >= N_MOL:
+        if time.perf_counter() - t_start > budget_s:
             break
-    el = time.perf_counter() - t0
-    # input generation is excluded by timing only the evaluations? keep it simple: it is < 1 % of el
-    return {"value": done / el, "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} of the {N_MOL} S-mol64 molecules in batches of {chunk}, oracle/tensornet_torch.py "
-                      f"(reference PyTorch CPU algorithm, autograd forces), {el:.1f} s"}
+    torch.set_num_threads(all_threads)
+    return {"value": done / total, "unit": "molecules/s", "cores": host_cores, "threads": best_t, "kind": "port",
+            "sample": f"{done} of the {N_MOL} S-mol64 molecules in chunks of {chunk}, oracle/tensornet_torch.py (reference "
+                      f"PyTorch CPU algorithm, autograd forces), 2 warm-ups + best of 5 per chunk, {time.perf_counter() - t_start:.1f} s; "
+                      "the unmodified reference on the build container: BASELINE.md section 4"}
 
 
-# HIP kernel behind each profiled class (rocprofv3 names; profiles/r01_kernel_stats.csv)
-KERNEL_OF = {"gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_sb1", "message": "k_message_tile / k_message_adjoint",
-             "pair_bwd": "k_pair_gd_v4 / k_embed_pair_gd_v4"}
+# ----------------------------------------------------------------------------------------------- launch
+def self_launch(a):
+    """`python bench.py --gpus N` outside torch.distributed: start N ranks of this script, one per GPU."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        print(json.dumps({"error": f"--gpus {a.gpus} requested but only {have} GPU(s) are visible; nothing was measured"}))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -128,10 +315,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-md", action="store_true", help="skip the single-system HIP-graph latency leg (profiling runs)")
-    ap.add_argument("--breakdown", type=str, default="", help="write the per-class timing table to this file")
+    ap.add_argument("--no-md", action="store_true", help="skip the HIP-graph latency leg (rocprofv3 --pmc cannot trace graph replays)")
+    ap.add_argument("--no-aux", action="store_true", help="skip the configs[3] / configs[4] legs (profiling runs)")
+    ap.add_argument("--breakdown", type=str, default="", help="write the per-class / per-kernel timing table to this file")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -152,116 +347,147 @@ def main():
         dist.barrier()
     from torchmdnet_amd import _C, workloads as W
     from torchmdnet_amd.models.model import create_model
+    from torchmdnet_amd.parallel import ShardedEvaluator
 
     L = _C.lib()
     torch.manual_seed(0)
     args_dict = dict(W.C2_ARGS)
     model = create_model(dict(args_dict)).to(dev)
-    # weak scaling: rank r owns molecules [r*256, (r+1)*256) of the synthetic stream
-    z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS, first_seed=rank * N_MOL)
-    z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
-    e_all = torch.zeros(world * N_MOL, dtype=torch.float32, device=dev)
     stream_ptr = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
-    def step():
-        e, f = model.energy_and_forces(z, pos, batch, None, None, N_MOL, want_forces=True)
+    # weak scaling: rank r owns molecules [r*256, (r+1)*256) of the synthetic stream
+    zw, pw, bw = (t.to(dev) for t in W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS, first_seed=rank * N_MOL))
+    e_all = torch.zeros(world * N_MOL, dtype=torch.float32, device=dev)
+
+    def step_weak():
+        e, f = model.energy_and_forces(zw, pw, bw, None, None, N_MOL, want_forces=True)
         if world > 1:
             e_all.zero_()
             e_all[rank * N_MOL:(rank + 1) * N_MOL] = e
             dist.all_reduce(e_all)  # RCCL over xGMI: the path's only exchange
         return e, f
 
+    # strong scaling (BASELINE configs[2]): the same 256 molecules on every rank, each evaluates its molecule range
+    zs, ps, bs = (t.to(dev) for t in W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS, first_seed=0))
+    sharded = ShardedEvaluator(lambda zl, pl, bl, boxl, ql, nm: model.energy_and_forces(zl, pl, bl, boxl, ql, nm, want_forces=True))
+
+    ranges = sharded.plan(bs, N_MOL)  # depends on the batch vector only: computed once, outside the timed region
+
+    def step_strong():
+        e, f, _ = sharded.evaluate(zs, ps, bs, n_mol=N_MOL, ranges=ranges)
+        return e, f
+
+    def timed(step, steps, mask):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        profile_begin(model, L, mask)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        _, groups = profile_records(model, L, stream_ptr)
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, groups, out
+
+    step = step_weak if a.scaling == "weak" else step_strong
     for _ in range(max(a.warmup - 1, 0)):
         step()
-    # one fully profiled warm-up step picks the dominant kernel class and records the breakdown
+    # one fully profiled warm-up step picks the dominant kernel class / kernel and records the breakdown
     step()
     torch.cuda.synchronize(dev)
-    ncat = profile_classes(model, L, stream_ptr, 0xFFFFFFFF)
+    profile_begin(model, L)
     step()
-    table = profile_collect(model, L, stream_ptr, ncat)
-    dominant = max(table, key=lambda k: table[k]["ms"])
-    dom_idx = list(table).index(dominant)
+    classes, groups = profile_records(model, L, stream_ptr)
+    dom_cls = max(classes, key=lambda k: classes[k]["ms"])
+    names = list(classes)
+    (_, dom_label), _ = dominant(groups, dom_cls)
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    profile_classes(model, L, stream_ptr, 1 << dom_idx)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        e, f = step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    timed = profile_collect(model, L, stream_ptr, ncat)[dominant]
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el, tgroups, (e, f) = timed(step, a.steps, 1 << names.index(dom_cls))
     assert torch.isfinite(e).all() and torch.isfinite(f).all()
+    mols_per_step = world * N_MOL if a.scaling == "weak" else N_MOL
+
+    other = None
+    if world > 1:  # the other scaling mode, same step count, for the record
+        ostep = step_strong if a.scaling == "weak" else step_weak
+        for _ in range(3):
+            ostep()
+        oel, _, _ = timed(ostep, a.steps, 0)
+        omols = N_MOL if a.scaling == "weak" else world * N_MOL
+        other = {"scaling": "strong" if a.scaling == "weak" else "weak", "value": omols * a.steps / oel, "unit": "molecules/s",
+                 "ms_per_step": oel / a.steps * 1e3, "molecules_per_step": omols}
 
     if rank == 0:
         n_pairs, n_edges, _ = model._engine.counts
-        launches = max(timed["launches"], 1)
-        avg_s = timed["ms"] * 1e-3 / launches
-        if timed["flops"] > 0:
-            ach = timed["flops"] / launches / avg_s / 1e12
-            split = dominant == "gemm_edge" and not os.environ.get("TMDNET_NO_SPLIT_BF16")
-            peak = PEAK["mfma_bf16_tflops"] / SPLIT_PRODUCTS if split else PEAK["mfma_f32_tflops"]
-            inst = "v_mfma_f32_32x32x16_bf16 x6 per fp32 product" if split else "v_mfma_f32_32x32x2_f32"
-            roof = {"bound": "mfma", "kernel": f"{dominant} ({KERNEL_OF.get(dominant, dominant)}, {inst})", "achieved": ach,
-                    "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                    "peak_note": ("fp32-equivalent: dense bf16 MFMA peak 2500 TF / 6 split products; achieved counts "
-                                  "algorithmic fp32 FLOPs (x6 = executed bf16 FLOPs)") if split else "fp32 MFMA peak"}
-        else:
-            ach = timed["bytes"] / launches / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": PEAK["hbm_gbs"], "unit": "GB/s",
-                    "frac": ach / PEAK["hbm_gbs"]}
-        roof.update({"traffic": None, "launches_per_step": launches // max(a.steps, 1), "avg_launch_us": avg_s * 1e6,
-                     "share_of_step": timed["ms"] / (el * 1e3)})
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                roof["traffic"] = json.load(open(pmc)).get(dominant)
-            except Exception:
-                pass
+        pmc = load_pmc()
+        kern_rec = tgroups[(dom_cls, dom_label)]
+        cls_rec = dict(ms=0.0, flops=0.0, bytes=0.0, launches=0)
+        for (c, _), v in tgroups.items():
+            if c == dom_cls:
+                for k in cls_rec:
+                    cls_rec[k] += v[k]
+        roof = roofline_of(kern_rec, dom_cls, dom_label, pmc=pmc_kernel_bytes(pmc, dom_cls, dom_label))
+        roof["launches_per_step"] = kern_rec["launches"] // max(a.steps, 1)
+        roof["share_of_step"] = kern_rec["ms"] / (el * 1e3)
+        cavg = roofline_of(cls_rec, dom_cls, "class average", pmc=pmc.get(dom_cls))
+        roof["class"] = {"name": dom_cls, "achieved": cavg["achieved"], "frac": cavg["frac"], "launches_per_step":
+                         cls_rec["launches"] // max(a.steps, 1), "share_of_step": cls_rec["ms"] / (el * 1e3),
+                         "traffic": cavg.get("traffic"), "traffic_ratio": cavg.get("traffic_ratio")}
         out = {
             "metric": "molecules/sec (64-atom molecules) TensorNet E+F",
-            "value": world * N_MOL * a.steps / el,
+            "value": mols_per_step * a.steps / el,
             "unit": "molecules/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: TensorNet F=128 L=2 K=32 rc=5.0, S-mol64 256 molecules x 64 atoms "
-                                   "per GPU, energies + forces, random-init weights (seed 0)",
-                       "atoms_per_gpu": N_MOL * N_ATOMS, "pairs_per_gpu": n_pairs, "directed_edges_per_gpu": n_edges,
+            "config": {"workload": ("BASELINE configs[1]: TensorNet F=128 L=2 K=32 rc=5.0, S-mol64 256 molecules x 64 atoms per GPU, "
+                                    "energies + forces, random-init weights (seed 0)") if a.scaling == "weak" else
+                                   ("BASELINE configs[2]: the configs[1] batch (256 molecules x 64 atoms in total) sharded over "
+                                    "the GPUs by molecule ranges, energies + forces, random-init weights (seed 0)"),
+                       "atoms_per_gpu": N_MOL * N_ATOMS if a.scaling == "weak" else ranges[0][3] - ranges[0][2],
+                       "pairs_per_gpu": n_pairs, "directed_edges_per_gpu": n_edges,
                        "parallelism": f"molecule-sharded x{world}, RCCL all-reduce of energies"},
             "roofline": roof,
         }
-        # north_star: "achieved HBM GB/s on the scatter": the CSR message sweeps (class "message"), from the fully profiled
-        # warm-up step (HIP events around each launch); algorithmic bytes as defined in DESIGN.md section 4
-        msg = table.get("message")
-        if msg and msg["launches"]:
-            ach_m = msg["bytes"] / (msg["ms"] * 1e-3) / 1e9
-            out["roofline_scatter"] = {"bound": "hbm", "kernel": f"message ({KERNEL_OF['message']})", "achieved": ach_m,
-                                       "peak": PEAK["hbm_gbs"], "unit": "GB/s", "frac": ach_m / PEAK["hbm_gbs"],
-                                       "launches_per_step": msg["launches"], "avg_launch_us": msg["ms"] * 1e3 / msg["launches"],
-                                       "traffic": None}
-            try:
-                out["roofline_scatter"]["traffic"] = json.load(open(pmc)).get("message")
-            except Exception:
-                pass
+        if other:
+            out["other_scaling_mode"] = other
+        # north_star: "achieved HBM GB/s on the scatter": the CSR message sweeps, per kernel, from the fully profiled step
+        # (HIP events around each launch); algorithmic bytes = every distinct tensor once
+        msg = {lab: v for (c, lab), v in groups.items() if c == "message"}
+        if msg:
+            tot = dict(ms=sum(v["ms"] for v in msg.values()), flops=0.0, bytes=sum(v["bytes"] for v in msg.values()),
+                       launches=sum(v["launches"] for v in msg.values()))
+            rs = roofline_of(tot, "message", "class average", pmc=pmc.get("message"))
+            rs["launches_per_step"] = tot["launches"]
+            rs["kernels"] = {}
+            for lab, v in msg.items():
+                r1 = roofline_of(v, "message", lab, pmc=pmc_kernel_bytes(pmc, "message", lab))
+                rs["kernels"][lab.split("(")[0]] = {k: r1[k] for k in ("achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch",
+                                                                        "traffic", "traffic_ratio") if k in r1}
+            out["roofline_scatter"] = rs
         if world == 1 and not a.no_md:
             try:  # an auxiliary leg must never cost the main line
                 out["md_single_system"] = md_latency(model, args_dict, dev)
             except Exception as exc:  # noqa: BLE001
                 out["md_single_system"] = {"error": repr(exc)}
+        if world == 1 and not a.no_aux:
+            for key, leg in (("et_c4", et_c4_leg), ("water10k", water10k_leg)):
+                try:
+                    out[key] = leg(dev, L)
+                except Exception as exc:  # noqa: BLE001
+                    out[key] = {"error": repr(exc)}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args_dict, model.state_dict())
@@ -270,7 +496,8 @@ def main():
         if a.breakdown:
             os.makedirs(os.path.dirname(os.path.abspath(a.breakdown)), exist_ok=True)
             with open(a.breakdown, "w") as fh:
-                json.dump({"one_step_profiled_ms": table, "step_ms": el / a.steps * 1e3}, fh, indent=1)
+                json.dump({"one_step_profiled_ms": classes, "kernels": {f"{c}: {lab}": v for (c, lab), v in groups.items()},
+                           "step_ms": el / a.steps * 1e3}, fh, indent=1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

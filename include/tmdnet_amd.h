@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 #define TMDNET_OK 0
-#define TMDNET_ERR_INVALID 1   /* bad argument / unknown parameter / wrong size */
+#define TMDNET_ERR_INVALID 1   /* bad argument / unknown parameter / wrong size; also: atomic number or molecule
+                                  index out of range (the reference's nn.Embedding / scatter raise there) */
 #define TMDNET_ERR_HIP 2       /* a HIP runtime call failed */
 #define TMDNET_ERR_OVERFLOW 3  /* more neighbour pairs than max_num_neighbors * n_atoms:
                                   the reference raises RuntimeError here (models/utils.py:297-300) */
@@ -98,20 +99,28 @@ const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel);
  * optional triclinic minimum image (box_mode 1: one [3,3] box, 2: one box per molecule [B,3,3]).
  * Produces a deterministic pair list + symmetric CSR inside `graph_ws`.
  * counts_host[0] = number of undirected pairs P, [1] = number of directed edges incl. self loops E,
- * [2] = overflow flag, [3] = 1 if `batch` was not sorted (slow path).
+ * [2] = overflow flag, [3] = 1 if `batch` was not sorted (slow path), [4] = 1 if an atomic number was outside
+ * [0, max_z), [5] = 1 if a molecule index was outside [0, n_mol); [6..7] reserved.
+ * `z` (int64 [n_atoms], may be NULL) is validated here, in the same read-back: out-of-range values return
+ * TMDNET_ERR_INVALID before any table is indexed with them (the reference's nn.Embedding raises IndexError,
+ * tensornet.py:473); a validated copy in the graph's internal atom order is kept in `graph_ws` and used by
+ * tmdnet_energy_forces.  With z = NULL nothing is checked and tmdnet_energy_forces uses its own `z` argument as is.
  * Returns TMDNET_ERR_OVERFLOW when E > max_num_neighbors * n_atoms. */
 int tmdnet_graph_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, size_t* bytes);
 /* O(N) cell list (reference "cell" strategy: extensions/neighbor_utils.py:89-150, warp_kernels/neighbors_cell.py:17-153;
  * the reference handles orthorhombic boxes only; here any box in the reduced lower-triangular form a=(ax,0,0),
- * b=(bx,by,0), c=(cx,cy,cz) is taken, one box for the whole system).  The caller supplies the grid n_axis =
- * floor(w_axis / cutoff_upper), w_axis = perpendicular width of the box along that axis (= L_axis when orthorhombic),
- * computed on the host from the box it owns (0,0,0 = always brute force).  The graph builders use the cell list when
- * n_mol == 1, box_mode == 1, every n_axis >= 3 and n_x*n_y*n_z <= 8*n_atoms; otherwise the brute-force sweep runs.
- * Same pair set either way; with the cell list atoms are renumbered in cell order internally and forces are
- * returned in the caller's order. */
+ * b=(bx,by,0), c=(cx,cy,cz) is taken, one box for the whole system).
+ *   (0,0,0)   : always brute force (default);
+ *   negative  : cell list whenever n_mol == 1 and box_mode == 1, with the grid n_axis = floor(w_axis / cutoff_upper)
+ *               (w_axis = perpendicular width of the box along that axis) computed ON THE DEVICE from the box of
+ *               each call -- no host copy of the box, and a captured HIP graph stays valid when the box changes (NPT);
+ *   positive  : the same with an explicit grid (n_x*n_y*n_z <= 8*n_atoms, else brute force).
+ * Any grid gives the same pair set as brute force (axes with fewer than 3 cells visit each cell once); atoms are
+ * renumbered in cell order internally and forces are returned in the caller's order. */
 int tmdnet_set_cell_grid(tmdnet_model* m, int32_t ncx, int32_t ncy, int32_t ncz);
 int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms, int64_t n_mol,
-                       const float* pos, const int64_t* batch, const float* box, int32_t box_mode, int64_t counts_host[4]);
+                       const float* pos, const int64_t* batch, const int64_t* z, const float* box, int32_t box_mode,
+                       int64_t counts_host[8]);
 
 /* Static (HIP-graph capturable) variant: same kernels, NO read-back and no synchronisation.  The pair count
  * stays in device memory; call tmdnet_energy_forces with n_pairs = -1 and workspaces sized for the pair
@@ -120,14 +129,20 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
  * tmdnet_graph_counts (synchronises; returns TMDNET_ERR_OVERFLOW) whenever convenient -- the analogue of the
  * reference's torch._assert_async (torchmdnet/models/utils.py:297-300). */
 int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms,
-                              int64_t n_mol, const float* pos, const int64_t* batch, const float* box, int32_t box_mode);
-int tmdnet_graph_counts(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t counts_host[4]);
+                              int64_t n_mol, const float* pos, const int64_t* batch, const int64_t* z, const float* box,
+                              int32_t box_mode);
+/* out-of-range z / batch (flags [4], [5]) return TMDNET_ERR_INVALID here; in static mode the kernels ran on clamped
+ * atomic numbers (memory-safe, results meaningless) */
+int tmdnet_graph_counts(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t counts_host[8]);
+/* cell grid of the last build on this workspace (synchronises): grid_host = {n_x, n_y, n_z, 1 if the cell list ran else 0} */
+int tmdnet_graph_cell_grid(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t grid_host[4]);
 
 /* ---- phase B: energies and forces ---------------------------------------------------------------
  * Replaces TorchMD_Net.forward for TensorNet + Scalar (torchmdnet/models/model.py:530-631):
  * energy[n_mol] = sum over atoms of the per-atom scalar (* std, + atomref[z]) + mean, and
  * forces[n_atoms,3] = -d(sum_m energy[m])/d(pos) from the hand-written reverse pass
  * (want_forces = 0 skips it).  `q` = total charge per molecule [n_mol] or NULL (tensornet.py:341-344).
+ * `z` may be NULL when tmdnet_build_graph[_static] received (and validated) it.
  * Must be called after tmdnet_build_graph on the same graph_ws (which holds the pair geometry);
  * n_pairs = counts_host[0] of that call (or -1 after tmdnet_build_graph_static).  Enqueues only: no
  * synchronisation, no allocation. */
@@ -142,12 +157,16 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
  * neighbors int64 [2,max_num_pairs] padded with -1, deltas [max_num_pairs,3], distances
  * [max_num_pairs], num_pairs int32[1] (the true count, may exceed max_num_pairs).  Pair order is
  * deterministic: lower pairs (i>j) sorted by (i,j), then their transposes, then self loops.
+ * strategy 0 = brute force inside each molecule; 1 = O(N) cell list (tn_cell.hip) over all molecules at once, pairs kept
+ * inside a molecule: one periodic box (box_mode 1) or, without a box, a fictitious one around the bounding box of the
+ * positions (the reference: models/utils.py:206-212); per-molecule boxes (box_mode 2) always take strategy 0.  Same
+ * pair set either way (order differs: cell order).
  * `ws` must hold tmdnet_neighbor_workspace_bytes(n_atoms, n_mol, max_num_pairs). */
 int tmdnet_neighbor_workspace_bytes(int64_t n_atoms, int64_t n_mol, int64_t max_num_pairs, size_t* bytes);
 int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol, const float* pos,
                           const int64_t* batch, const float* box, int32_t box_mode, float cutoff_lower, float cutoff_upper,
-                          int64_t max_num_pairs, int32_t loop, int32_t include_transpose, int64_t* neighbors, float* deltas,
-                          float* distances, int32_t* num_pairs);
+                          int64_t max_num_pairs, int32_t loop, int32_t include_transpose, int32_t strategy, int64_t* neighbors,
+                          float* deltas, float* distances, int32_t* num_pairs);
 
 /* ---- per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
  * selected classes; bit c of category_mask selects class c).  tmdnet_profile_end synchronises the
@@ -156,6 +175,11 @@ int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_ato
  * Arrays must hold tmdnet_profile_num_categories() entries.  Used by bench.py for `roofline`. */
 int tmdnet_profile_begin(tmdnet_model* m, uint32_t category_mask);
 int tmdnet_profile_end(tmdnet_model* m, void* stream, double* ms, double* flops, double* bytes, int64_t* launches);
+/* the same per launch, in launch order (up to `cap` records are written, *n_out = number recorded); `labels` (may be
+ * NULL) receives one 64-byte NUL-terminated string per record naming the launch (kernel wrapper + shape): bench.py groups
+ * by it to single out the dominant KERNEL of a class */
+int tmdnet_profile_end_records(tmdnet_model* m, void* stream, int64_t cap, int32_t* cat, double* ms, double* flops, double* bytes,
+                               char* labels, int64_t* n_out);
 int tmdnet_profile_num_categories(void);
 const char* tmdnet_profile_category_name(int idx);
 

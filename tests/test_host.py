@@ -202,8 +202,12 @@ def test_load_model_equivariant_transformer_checkpoint(tmp_path):
     args = dict(W.ET_TINY_ARGS)
     model = create_model(dict(args))
     path = str(tmp_path / "et.ckpt")
-    torch.save({"state_dict": {"model." + k: v.clone() for k, v in model.state_dict().items()}, "hyper_parameters": dict(args)}, path)
-    loaded = load_model(path, derivative=True)
+    # 'check_errors' was a global training argument: old ET checkpoints carry it too, and must NOT get the TensorNet remix
+    # (reference model.py:333-372 applies it to tensornet / tensornet2 only)
+    torch.save({"state_dict": {"model." + k: v.clone() for k, v in model.state_dict().items()},
+                "hyper_parameters": dict(args, check_errors=True)}, path)
+    with pytest.warns(UserWarning, match="Old-format"):
+        loaded = load_model(path, derivative=True)
     assert type(loaded.representation_model).__name__ == "TorchMD_ET"
     for k, v in model.state_dict().items():
         assert torch.equal(loaded.state_dict()[k], v), k
@@ -216,3 +220,21 @@ def test_load_model_equivariant_transformer_checkpoint(tmp_path):
         assert set(ref.state_dict()) == set(loaded.state_dict())
         for k, v in ref.state_dict().items():
             assert torch.equal(loaded.state_dict()[k], v), k
+
+
+def test_fingerprint_cache_follows_module_changes():
+    """The cached tensor list behind the parameter-change detector is dropped by .to()/.float() (new buffer objects) and
+    sees in-place updates (load_state_dict, optimiser steps) through the tensors' version counters."""
+    model = create_model(dict(W.TINY_ARGS))
+    fp0 = model._fingerprint()
+    assert model._fingerprint() == fp0
+    with torch.no_grad():
+        model.mean.add_(1.0)
+    fp1 = model._fingerprint()
+    assert fp1 != fp0
+    model.load_state_dict(copy.deepcopy(model.state_dict()))
+    assert model._fingerprint() != fp1
+    model.double()
+    assert model._engine.tensors is None  # rebuilt lazily with the new tensor objects
+    assert len(model._fingerprint()) == len(fp0)
+    assert "equivariant-transformer" in __import__("torchmdnet_amd.models", fromlist=["x"]).__all_models__

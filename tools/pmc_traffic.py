@@ -17,9 +17,13 @@ import os
 import sys
 from collections import defaultdict
 
-CLASS_OF = [("k_gemm_dual", "gemm_edge"), ("k_gemm_nt", "gemm_node"), ("k_gemm_skinny", "gemm_node"),
-            ("k_message", "message"), ("k_pair_gd", "pair_bwd"), ("k_embed_pair_gd", "pair_bwd"), ("k_geom_gd", "pair_bwd"),
-            ("k_embed_scatter", "embed_scatter")]
+import re
+
+# kernel (rocprofv3 short name, template instance kept) -> profiled class of the library (tn_model.h ProfCat).  Exact
+# patterns: `k_message_bwd_node` is an elementwise kernel, not a sweep.
+CLASS_OF = [(r"k_gemm_dual", "gemm_edge"), (r"k_edge_mlp", "gemm_edge"), (r"k_gemm_(nt|skinny|sb1)", "gemm_node"),
+            (r"k_message(_tile|_pair|_adjoint|_adjoint_gd|_adjoint_pair|_split)?(<.*>)?$", "message"),
+            (r"k_(pair_gd|embed_pair_gd|geom_gd)", "pair_bwd"), (r"k_embed_scatter", "embed_scatter")]
 
 
 def read_counter(dirname, counter):
@@ -36,7 +40,8 @@ def read_counter(dirname, counter):
 def per_kernel(rows):
     by = defaultdict(list)
     for name, grid, val in rows:
-        by[name.split("(")[0].split("<")[0].replace("void ", "").replace("tn::", "").strip()].append((grid, val, name))
+        short = name.split("(")[0].replace("void ", "").replace("tn::", "").strip()  # "k_gemm_dual_sb2<2>"
+        by[short].append((grid, val, name))
     out = {}
     for k, lst in by.items():
         gmax = max(g for g, _, _ in lst)
@@ -57,14 +62,15 @@ def main():
                       "grid": rd.get(k, wr.get(k))["grid"]}
     classes = defaultdict(lambda: [0.0, 0])
     for k, v in kernels.items():
-        for prefix, cls in CLASS_OF:
-            if k.startswith(prefix):
+        for pat, cls in CLASS_OF:
+            if re.match(pat, k):
                 n = v["launches_seen"]
                 classes[cls][0] += (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) * n
                 classes[cls][1] += n
                 break
     res = {cls: tot / max(n, 1) for cls, (tot, n) in classes.items()}  # mean HBM bytes per launch of the class
     res["_per_kernel"] = kernels
+    res["_per_kernel_total"] = {k: v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for k, v in kernels.items()}
     res["_note"] = "bytes per launch; reads = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), writes = WRITE_SIZE KiB x 1024"
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)

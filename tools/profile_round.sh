@@ -5,9 +5,9 @@ export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 cd /tmp
 python $R/bench.py --breakdown $R/gpurun_out/breakdown.json > $R/gpurun_out/bench.json 2> $R/gpurun_out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-md > $R/gpurun_out/prof.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_rd -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-md > $R/gpurun_out/pmc_rd.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_wr -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-md > $R/gpurun_out/pmc_wr.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-md --no-aux > $R/gpurun_out/prof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_rd -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-md --no-aux > $R/gpurun_out/pmc_rd.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_wr -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-md --no-aux > $R/gpurun_out/pmc_wr.log 2>&1
 python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_rd $R/gpurun_out/pmc_wr $R/gpurun_out/pmc_traffic.json
 # keep only the summaries (counter CSVs of every dispatch are large)
 find $R/gpurun_out/pmc_rd $R/gpurun_out/pmc_wr -name '*.csv' -size +4M -delete

@@ -60,7 +60,9 @@ void gemm(hipStream_t s, const float* A, int64_t lda, const float* W, int64_t ld
   if (g_wsb_debug) a.Wsbg[0] = g_wsb_debug;
   // algorithmic traffic: A and W read once, C (and the saved pre-activation / aux operand) once
   const double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (1 + (pre ? 1 : 0) + (aux ? 1 : 0) + ((flags & GEMM_ACCUM) ? 1 : 0)));
-  ProfScope ps_(s, g_gemm_cat, 2.0 * M * N * K, bytes);
+  char lab[64];
+  std::snprintf(lab, sizeof(lab), "gemm %dx%dx%d", M, N, K);
+  ProfScope ps_(s, g_gemm_cat, 2.0 * M * N * K, bytes, lab);
   launch_gemm(a, s);
 }
 
@@ -88,7 +90,9 @@ void gemm_dual(hipStream_t s, int kind, const float* A, const float* A2, int64_t
   a.m_dev = g_mdev;
   a.m_add = g_madd;
   const double bytes = 4.0 * (2.0 * M * K + (double)N * K + 2.0 * M * N);
-  ProfScope ps_(s, CAT_GEMM_EDGE, 4.0 * M * N * K, bytes);
+  char lab[64];
+  std::snprintf(lab, sizeof(lab), "gemm_dual<%d> %dx%dx%d", kind, M, N, K);
+  ProfScope ps_(s, CAT_GEMM_EDGE, 4.0 * M * N * K, bytes, lab);
   launch_gemm_dual(a, kind, s);
 }
 
@@ -166,7 +170,9 @@ void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], floa
   a.groups = 9;
   a.flags = flags;
   const double bytes = 4.0 * (9.0 * N * F * (2 + (pre ? 1 : 0)) + (gates ? 3.0 * N * F : 0.0) + 3.0 * F * F);
-  ProfScope ps_(s, CAT_GEMM_NODE, 2.0 * 9 * N * (double)F * F, bytes);
+  char lab[64];
+  std::snprintf(lab, sizeof(lab), "tensor_linear 9x%dx%dx%d", N, F, F);
+  ProfScope ps_(s, CAT_GEMM_NODE, 2.0 * 9 * N * (double)F * F, bytes, lab);
   launch_gemm(a, s);
 }
 
@@ -200,26 +206,31 @@ Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   g.pos_s = c.take<float>(3 * N);
   g.z_s = c.take<int64_t>(N);
   g.boxd = c.take<float>(12);
+  g.cgrid = c.take<int>(4);
+  g.bat_s = c.take<int>(N);
+  g.z_c = c.take<int64_t>(N);
   g.sort_tmp_bytes = cell_sort_temp_bytes(N);
   g.sort_tmp = c.take<char>((int64_t)g.sort_tmp_bytes);
   if (total) *total = c.off;
   return g;
 }
 
-// the cell list applies to ONE periodic orthorhombic system with at least 3 cells per axis (so that the 27
-// neighbour cells are distinct) and a bounded number of cells; everything else takes the brute-force sweep
+// the cell list applies to ONE periodic system in one box (orthorhombic or reduced triclinic); everything else takes the
+// brute-force sweep.  cell_n < 0: the grid is computed on the device from the current box on every call (tn_cell.hip).
 namespace {
 bool cell_applicable(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int box_mode) {
   const int* n = m->cell_n;
-  if (n_mol != 1 || box_mode != 1) return false;
-  if (n[0] < 3 || n[1] < 3 || n[2] < 3) return false;
+  if (n_mol != 1 || box_mode != 1 || n_atoms < 1) return false;
+  if (n[0] < 0) return true;
+  if (n[0] < 1 || n[1] < 1 || n[2] < 1) return false;
   return (int64_t)n[0] * n[1] * n[2] <= 8 * n_atoms;
 }
 void set_cell(Graph& g, const tmdnet_model* m, bool on) {
   g.use_cell = on ? 1 : 0;
-  g.ncx = m->cell_n[0];
-  g.ncy = m->cell_n[1];
-  g.ncz = m->cell_n[2];
+  const bool explicit_grid = m->cell_n[0] > 0;
+  g.ncx = explicit_grid ? m->cell_n[0] : 0;
+  g.ncy = explicit_grid ? m->cell_n[1] : 0;
+  g.ncz = explicit_grid ? m->cell_n[2] : 0;
 }
 
 FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, int64_t P, bool bwd, size_t* total) {
@@ -265,6 +276,7 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
   b.x = c.take<float>(N * F);
   b.ao = c.take<float>(N * H);
   b.ea = c.take<float>(N);
+  b.kap = c.take<float>(N);
   if (bwd) {
     b.g_ao = c.take<float>(N * H);
     b.g_al = c.take<float>(N * F);
@@ -574,7 +586,8 @@ int tmdnet_finalize_params(tmdnet_model* m) {
 
 // ------------------------------------------------------------------------------------ graph
 int tmdnet_set_cell_grid(tmdnet_model* m, int32_t ncx, int32_t ncy, int32_t ncz) {
-  if (!m || ncx < 0 || ncy < 0 || ncz < 0) return TMDNET_ERR_INVALID;
+  if (!m) return TMDNET_ERR_INVALID;
+  if (ncx < 0 || ncy < 0 || ncz < 0) ncx = ncy = ncz = -1;  // automatic
   m->cell_n[0] = ncx;
   m->cell_n[1] = ncy;
   m->cell_n[2] = ncz;
@@ -589,7 +602,8 @@ int tmdnet_graph_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t
 }
 
 int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms, int64_t n_mol,
-                       const float* pos, const int64_t* batch, const float* box, int32_t box_mode, int64_t counts_host[4]) {
+                       const float* pos, const int64_t* batch, const int64_t* z, const float* box, int32_t box_mode,
+                       int64_t counts_host[8]) {
   if (!m || !graph_ws || !counts_host || n_atoms < 0 || n_mol < 0) return TMDNET_ERR_INVALID;
   if (n_atoms >= (int64_t)1 << 30) return fail(m, TMDNET_ERR_INVALID, "n_atoms too large for 32-bit indices");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -601,22 +615,28 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
   set_cell(g, m, cell);
   m->graph_is_cell = cell;
+  m->graph_has_z = z != nullptr;
   CurScope cur_(m);
   {
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
     if (cell) {
       launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
-      launch_cell_phase1(g, pos, box, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, s);
+      launch_cell_phase1(g, pos, batch, box, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
       launch_scan_counts(g, (int)n_atoms, s);
     } else {
       launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
                                 true, s);
     }
+    if (z) launch_prepare_z(g, z, cell ? g.perm : nullptr, (int)n_atoms, m->hp.max_z, s);
   }
-  int counts[4] = {0, 0, 0, 0};
+  int counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(m, hipMemcpyAsync(counts, g.counts, sizeof(counts), hipMemcpyDeviceToHost, s));
   HIP_TRY(m, hipStreamSynchronize(s));
-  for (int k = 0; k < 4; ++k) counts_host[k] = counts[k];
+  for (int k = 0; k < 8; ++k) counts_host[k] = counts[k];
+  if (counts[5])
+    return fail(m, TMDNET_ERR_INVALID, "batch index out of range: every entry must be in [0, " + std::to_string(n_mol) + ")");
+  if (counts[4])
+    return fail(m, TMDNET_ERR_INVALID, "atomic number out of range: every z must be in [0, max_z = " + std::to_string(m->hp.max_z) + ")");
   if (counts[2])
     return fail(m, TMDNET_ERR_OVERFLOW, "Found num_pairs > max_num_pairs, please increase max_num_pairs (found " +
                                             std::to_string(counts[1]) + " edges, capacity " + std::to_string(ecap) + ")");
@@ -624,10 +644,11 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   {
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)counts[1] * 12 + (double)counts[0] * 40);
     if (cell) {
-      launch_cell_phase2(g, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, s);
+      launch_cell_phase2(g, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
       launch_nbr_link_wave(g, (int)n_atoms, s);
     } else {
-      launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+      launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper, true,
+                                s);
     }
   }
   HIP_TRY(m, hipGetLastError());
@@ -635,7 +656,7 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
 }
 
 int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms, int64_t n_mol,
-                              const float* pos, const int64_t* batch, const float* box, int32_t box_mode) {
+                              const float* pos, const int64_t* batch, const int64_t* z, const float* box, int32_t box_mode) {
   if (!m || !graph_ws || n_atoms < 0 || n_mol < 0) return TMDNET_ERR_INVALID;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t ecap = (int64_t)m->hp.max_num_neighbors * n_atoms;
@@ -646,35 +667,55 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
   const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
   set_cell(g, m, cell);
   m->graph_is_cell = cell;
+  m->graph_has_z = z != nullptr;
   CurScope cur_(m);
   {
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
     if (cell) {
       launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
-      launch_cell_phase1(g, pos, box, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, s);
+      launch_cell_phase1(g, pos, batch, box, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
       launch_scan_counts(g, (int)n_atoms, s);
-      launch_cell_phase2(g, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, s);
+      launch_cell_phase2(g, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
       launch_nbr_link_wave(g, (int)n_atoms, s);
     } else {
       launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
                                 true, s);
-      launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+      launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper, true,
+                                s);
     }
+    if (z) launch_prepare_z(g, z, cell ? g.perm : nullptr, (int)n_atoms, m->hp.max_z, s);
   }
   m->lastE = ecap;
   HIP_TRY(m, hipGetLastError());
   return TMDNET_OK;
 }
 
-int tmdnet_graph_counts(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t counts_host[4]) {
+int tmdnet_graph_counts(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t counts_host[8]) {
   if (!m || !graph_ws || !counts_host) return TMDNET_ERR_INVALID;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, (int64_t)m->hp.max_num_neighbors * n_atoms, nullptr);
-  int counts[4] = {0, 0, 0, 0};
+  int counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(m, hipMemcpyAsync(counts, g.counts, sizeof(counts), hipMemcpyDeviceToHost, s));
   HIP_TRY(m, hipStreamSynchronize(s));
-  for (int k = 0; k < 4; ++k) counts_host[k] = counts[k];
+  for (int k = 0; k < 8; ++k) counts_host[k] = counts[k];
+  if (counts[5]) return fail(m, TMDNET_ERR_INVALID, "batch index out of range: every entry must be in [0, " + std::to_string(n_mol) + ")");
+  if (counts[4])
+    return fail(m, TMDNET_ERR_INVALID, "atomic number out of range: every z must be in [0, max_z = " + std::to_string(m->hp.max_z) + ")");
   return counts[2] ? TMDNET_ERR_OVERFLOW : TMDNET_OK;
+}
+
+int tmdnet_graph_cell_grid(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t grid_host[4]) {
+  if (!m || !graph_ws || !grid_host) return TMDNET_ERR_INVALID;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  Graph g = carve_graph(graph_ws, n_atoms, n_mol, (int64_t)m->hp.max_num_neighbors * n_atoms, nullptr);
+  int grid[4] = {0, 0, 0, 0};
+  if (m->graph_is_cell) {
+    HIP_TRY(m, hipMemcpyAsync(grid, g.cgrid, sizeof(grid), hipMemcpyDeviceToHost, s));
+    HIP_TRY(m, hipStreamSynchronize(s));
+  }
+  for (int k = 0; k < 3; ++k) grid_host[k] = grid[k];
+  grid_host[3] = m->graph_is_cell ? 1 : 0;
+  return TMDNET_OK;
 }
 
 // ------------------------------------------------------------------------------------ forward + reverse
@@ -704,11 +745,14 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   if (m->et) {
     if (q) return fail(m, TMDNET_ERR_INVALID, "the Equivariant Transformer takes no total charge (reference torchmd_et.py:188-196)");
     CurScope cur_(m);
-    if (m->graph_is_cell) {
+    if (m->graph_has_z) {  // validated + renumbered by the graph phase
+      z = g.z_c;
+    } else if (m->graph_is_cell) {
       set_cell(g, m, true);
       launch_permute_z(g, z, (int)n_atoms, s);
       z = g.z_s;
     }
+    if (!z) return fail(m, TMDNET_ERR_INVALID, "z is required (here or in tmdnet_build_graph)");
     return et_energy_forces(m, s, g, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, want_forces, energy, forces);
   }
   // n_pairs >= 0: exact count read back by tmdnet_build_graph (launch grids sized exactly);
@@ -724,13 +768,25 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   const int* perm = nullptr;
   if (m->graph_is_cell) {  // the graph lives in cell order: renumber z here, scatter the forces back at the end
     set_cell(g, m, true);
-    launch_permute_z(g, z, N, s);
-    z = g.z_s;
+    if (!m->graph_has_z) {
+      launch_permute_z(g, z, N, s);
+      z = g.z_s;
+    }
     perm = g.perm;
+  }
+  if (m->graph_has_z) z = g.z_c;  // validated (clamped) and renumbered by the graph phase
+  if (!z) return fail(m, TMDNET_ERR_INVALID, "z is required (here or in tmdnet_build_graph)");
+  const int64_t* batch_k = batch;
+  if (q) {  // per-atom charge factor once; the kernels then read kap[n] (no dependent batch -> q gather, no range hazard)
+    launch_kappa(q, batch, N, B, b.kap, s);
+    q = b.kap;
+    batch_k = nullptr;
   }
   const double E_ = (double)m->lastE, Nd = N, Pd = P, Fd = F;
   const double nodeB = Nd * 9 * Fd * 4;             // one [N,9,F] tensor
-  const double msgB = E_ * (12 * Fd + 8);           // per directed edge: 3F weights + indices
+  // CSR sweep, algorithmic bytes (every distinct tensor once): the per-pair weights [P+1,3,F] are ONE tensor
+  // although both rows of a pair read them; per directed edge only the indices (col, epair, esign)
+  const double wB = (Pd + 1) * 12 * Fd, idxB = E_ * 12;
   auto EDGE = [&](int add) { g_gemm_cat = CAT_GEMM_EDGE; g_mdev = g.counts; g_madd = add; };
   auto NODE = [&]() { g_gemm_cat = CAT_GEMM_NODE; g_mdev = nullptr; g_madd = 0; };
 
@@ -780,10 +836,10 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     // X_hat of layer l > 0 was written by the previous layer's update kernel (in place over its own X_hat)
     if (l == 0) KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], b.Xh, N, F, s));
     tensor_linear(s, b.Xh, q_.V, b.Pn[l], N, F);
-    KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch, o3, b.Mi[l], b.Ch, s));
+    KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], b.Ch, s));
     tensor_linear(s, b.Ch, q_.V + 3, b.D[l], N, F);
     // update fused with the next consumer of the new X: the next layer's normalisation, or the readout invariants
-    KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(b.Xh, b.D[l], q, batch, N, F, b.X[l + 1], l + 1 < L ? 1 : 2,
+    KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(b.Xh, b.D[l], q, batch_k, N, F, b.X[l + 1], l + 1 < L ? 1 : 2,
                                                        l + 1 < L ? b.Xh : b.feat, s));
   }
   // ---- readout + head + per-molecule sum
@@ -819,20 +875,20 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];
       // gD of the layers below the top one comes out of the previous iteration's fused normalisation adjoint
-      if (l == L - 1) KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch, N, F, b.gD, s));
+      if (l == L - 1) KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch_k, N, F, b.gD, s));
       tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
-      KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch, o3, N, F, b.gMi, b.gPn, s));
+      KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch_k, o3, N, F, b.gMi, b.gPn, s));
       if (merged_gd) {
-        KR(CAT_MESSAGE, 2 * msgB + 4 * nodeB,
+        KR(CAT_MESSAGE, 2 * wB + idxB + 4 * nodeB + 8 * (Pd + 1) * gd_nw,  // w, dw, gMi, Pn, gPn (read + write), g_d slots
            launch_message_adjoint_gd(g, N, F, b.w[l], b.dw[l], b.gMi, b.Pn[l], b.gPn, b.gd_slots + (int64_t)l * gd_nw * gd_stride,
                                      gd_stride, s));
       } else {
-        KR(CAT_MESSAGE, msgB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
+        KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
         KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));
       }
       tensor_linear(s, b.gPn, q_.VT, b.gXl, N, F);
       if (l > 0)
-        KR(CAT_ELEMENTWISE, 6 * nodeB, launch_norm_bwd_update_bwd(b.X[l], b.gXl, N, F, b.G, b.D[l - 1], q, batch, b.gD, s));
+        KR(CAT_ELEMENTWISE, 6 * nodeB, launch_norm_bwd_update_bwd(b.X[l], b.gXl, N, F, b.G, b.D[l - 1], q, batch_k, b.gD, s));
       else
         KR(CAT_ELEMENTWISE, 5 * nodeB + Nd * 3 * Fd * 12,
            launch_norm_bwd_gate_bwd(b.X[0], b.gXl, N, F, b.G, b.UX, b.gates, b.a2, b.gUX, b.g_a2, s));
@@ -870,8 +926,8 @@ int tmdnet_neighbor_workspace_bytes(int64_t n_atoms, int64_t n_mol, int64_t max_
 
 int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol, const float* pos,
                           const int64_t* batch, const float* box, int32_t box_mode, float cutoff_lower, float cutoff_upper,
-                          int64_t max_num_pairs, int32_t loop, int32_t include_transpose, int64_t* neighbors, float* deltas,
-                          float* distances, int32_t* num_pairs) {
+                          int64_t max_num_pairs, int32_t loop, int32_t include_transpose, int32_t strategy, int64_t* neighbors,
+                          float* deltas, float* distances, int32_t* num_pairs) {
   if (!ws || !neighbors || !deltas || !distances || !num_pairs) return TMDNET_ERR_INVALID;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t ecap = 2 * max_num_pairs + n_atoms + 2;
@@ -879,9 +935,22 @@ int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_ato
   Graph g = carve_graph(ws, n_atoms, n_mol, ecap, &need);
   if (need > ws_bytes) return TMDNET_ERR_WORKSPACE;
   // internal CSR always carries self loops + both directions; the export selects what the caller asked for
-  launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, cutoff_lower, cutoff_upper, true, s);
-  launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, cutoff_lower, cutoff_upper, true, s);
-  launch_export_pairs(g, (int)n_atoms, include_transpose != 0, loop != 0, max_num_pairs, neighbors, deltas, distances, num_pairs, s);
+  // strategy 1 = cell list (one box or none for all molecules; per-molecule boxes have no common grid -> brute force)
+  const bool cell = strategy == 1 && box_mode != 2 && n_atoms > 0;
+  if (cell) {
+    g.use_cell = n_mol > 1 ? 2 : 1;
+    g.ncx = g.ncy = g.ncz = 0;
+    launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
+    launch_cell_phase1(g, pos, batch, box_mode == 1 ? box : nullptr, (int)n_atoms, cutoff_lower, cutoff_upper, true, s);
+    launch_scan_counts(g, (int)n_atoms, s);
+    launch_cell_phase2(g, (int)n_atoms, cutoff_lower, cutoff_upper, true, s);
+    launch_nbr_link_wave(g, (int)n_atoms, s);
+  } else {
+    launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, cutoff_lower, cutoff_upper, true, s);
+    launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, cutoff_lower, cutoff_upper, true, s);
+  }
+  launch_export_pairs(g, (int)n_atoms, include_transpose != 0, loop != 0, max_num_pairs, cell ? g.perm : nullptr, neighbors, deltas,
+                      distances, num_pairs, s);
   return hipGetLastError() == hipSuccess ? TMDNET_OK : TMDNET_ERR_HIP;
 }
 
@@ -907,6 +976,29 @@ int tmdnet_profile_end(tmdnet_model* m, void* stream, double* ms, double* flops,
     bytes[r.cat] += r.bytes;
     launches[r.cat] += 1;
   }
+  m->prof.on = false;
+  m->prof.recs.clear();
+  m->prof.used = 0;
+  return TMDNET_OK;
+}
+
+int tmdnet_profile_end_records(tmdnet_model* m, void* stream, int64_t cap, int32_t* cat, double* ms, double* flops, double* bytes,
+                               char* labels, int64_t* n_out) {
+  if (!m || !cat || !ms || !flops || !bytes || !n_out || cap < 0) return TMDNET_ERR_INVALID;
+  HIP_TRY(m, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  int64_t n = 0;
+  for (const ProfRec& r : m->prof.recs) {
+    if (n >= cap) break;
+    float t = 0.f;
+    HIP_TRY(m, hipEventElapsedTime(&t, r.a, r.b));
+    cat[n] = r.cat;
+    ms[n] = t;
+    flops[n] = r.flops;
+    bytes[n] = r.bytes;
+    if (labels) std::memcpy(labels + 64 * n, r.label, 64);
+    ++n;
+  }
+  *n_out = (int64_t)m->prof.recs.size();
   m->prof.on = false;
   m->prof.recs.clear();
   m->prof.used = 0;

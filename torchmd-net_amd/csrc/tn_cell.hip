@@ -38,10 +38,11 @@ size_t cell_sort_temp_bytes(int64_t n) {
 // cell id of every atom from its wrapped FRACTIONAL position; iota for the sort values.  Box rows a = (ax,0,0),
 // b = (bx,by,0), c = (cx,cy,cz) (the reference's reduced form, torchmdnet/models/utils.py:206-229; orthorhombic when
 // the off-diagonals vanish): r = sa a + sb b + sc c is solved back to front.
-__global__ void k_cell_assign(const float* __restrict__ pos, const float* __restrict__ box, int N, int ncx, int ncy, int ncz,
+__global__ void k_cell_assign(const float* __restrict__ pos, const float* __restrict__ box, int N, const int* __restrict__ cgrid,
                               int* __restrict__ key, int* __restrict__ iota) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  const int ncx = cgrid[0], ncy = cgrid[1], ncz = cgrid[2];
   const float x = pos[i * 3], y = pos[i * 3 + 1], zc = pos[i * 3 + 2];
   float fz = zc / box[8];
   float fy = (y - fz * box[7]) / box[4];
@@ -55,8 +56,9 @@ __global__ void k_cell_assign(const float* __restrict__ pos, const float* __rest
 }
 
 // cell_start[c] = first sorted position whose cell id >= c (lower bound); c in [0, ncells]
-__global__ void k_cell_bounds(const int* __restrict__ sorted_key, int N, int ncells, int* __restrict__ cell_start) {
+__global__ void k_cell_bounds(const int* __restrict__ sorted_key, int N, const int* __restrict__ cgrid, int* __restrict__ cell_start) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ncells = cgrid[3];
   if (c > ncells) return;
   int lo = 0, hi = N;
   while (lo < hi) {
@@ -66,13 +68,15 @@ __global__ void k_cell_bounds(const int* __restrict__ sorted_key, int N, int nce
   cell_start[c] = lo;
 }
 
-__global__ void k_permute_pos(const float* __restrict__ pos, const int* __restrict__ perm, int N, float* __restrict__ pos_s) {
+__global__ void k_permute_pos(const float* __restrict__ pos, const int64_t* __restrict__ batch, const int* __restrict__ perm, int N,
+                              float* __restrict__ pos_s, int* __restrict__ bat_s) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int o = perm[i];
   pos_s[i * 3] = pos[o * 3];
   pos_s[i * 3 + 1] = pos[o * 3 + 1];
   pos_s[i * 3 + 2] = pos[o * 3 + 2];
+  if (batch) bat_s[i] = (int)batch[o];  // several molecules in one box (neighbour operator only): pairs stay inside a molecule
 }
 __global__ void k_permute_z(const int64_t* __restrict__ z, const int* __restrict__ perm, int N, int64_t* __restrict__ z_s) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,6 +84,21 @@ __global__ void k_permute_z(const int64_t* __restrict__ z, const int* __restrict
 }
 void launch_permute_z(const Graph& g, const int64_t* z, int N, hipStream_t s) {
   hipLaunchKernelGGL(k_permute_z, dim3(cdivc(N, 256)), dim3(256), 0, s, z, g.perm, N, g.z_s);
+}
+__global__ void k_prepare_z(const int64_t* __restrict__ z, const int* __restrict__ perm, int N, int max_z, int64_t* __restrict__ z_c,
+                            int* __restrict__ counts) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int64_t v = z[perm ? perm[i] : i];
+  if (v < 0 || v >= max_z) {
+    counts[4] = 1;
+    v = v < 0 ? 0 : max_z - 1;
+  }
+  z_c[i] = v;
+}
+void launch_prepare_z(const Graph& g, const int64_t* z, const int* perm, int N, int max_z, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_prepare_z, dim3(cdivc(N, 256)), dim3(256), 0, s, z, perm, N, max_z, g.z_c, g.counts);
 }
 
 // minimum image, z -> y -> x (reference neighbors_brute.py / models/utils.py:206-229); same operation order as the brute-force
@@ -98,17 +117,21 @@ __device__ __forceinline__ float cell_d2(const float* __restrict__ pos, int hi, 
   return dx * dx + dy * dy + dz * dz;
 }
 
-// wave per (cell-sorted) atom: sort the 27 neighbour cell ids, sweep their atom ranges in ascending order
+// wave per (cell-sorted) atom: sort the 27 neighbour cell ids, sweep their atom ranges in ascending order.
+// With fewer than 3 cells along an axis several of the 27 offsets name the same cell: duplicates are adjacent after
+// the sort and are skipped, so any grid (down to 1 x 1 x 1 = brute force) gives the same pair set.
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_nbr_cell(Graph g, int N, float lo2, float up2) {
+__global__ __launch_bounds__(256) void k_nbr_cell(Graph g, int N, float lo2, float up2, int loop) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= N) return;
   if (FILL && g.counts[2]) return;
   const float* __restrict__ pos = g.pos_s;
   const float* __restrict__ box = g.boxd;
-  const int ncx = g.ncx, ncy = g.ncy, ncz = g.ncz;
+  const int* __restrict__ bat = g.use_cell > 1 ? g.bat_s : nullptr;  // > 1: several molecules share the box
+  const int ncx = g.cgrid[0], ncy = g.cgrid[1], ncz = g.cgrid[2];
   const int ci = g.cell_key_sorted[i];
+  const int bi = bat ? bat[i] : 0;
   const int cz = ci % ncz, cy = (ci / ncz) % ncy, cx = ci / (ncz * ncy);
   // lanes 0..26 -> neighbour cell id (periodic wrap); others -> +inf; 32-lane bitonic sort ascending
   int nid = 0x7fffffff;
@@ -132,12 +155,12 @@ __global__ __launch_bounds__(256) void k_nbr_cell(Graph g, int N, float lo2, flo
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   int t = 0;
   while (t < 27) {
-    // merge consecutive cell ids into one contiguous atom range
+    // merge consecutive (and repeated) cell ids into one contiguous atom range
     int c0 = __shfl(nid, t, 64), c1 = c0;
     ++t;
     while (t < 27) {
       const int cn = __shfl(nid, t, 64);
-      if (cn != c1 + 1) break;
+      if (cn != c1 && cn != c1 + 1) break;
       c1 = cn;
       ++t;
     }
@@ -148,9 +171,9 @@ __global__ __launch_bounds__(256) void k_nbr_cell(Graph g, int N, float lo2, flo
       float dx = 0.f, dy = 0.f, dz = 0.f, d2 = 0.f;
       if (j < j1) {
         if (j == i) {
-          hit = true;
+          hit = loop != 0;
           self = true;
-        } else {
+        } else if (!bat || bat[j] == bi) {
           d2 = (j < i) ? cell_d2(pos, i, j, box, dx, dy, dz) : cell_d2(pos, j, i, box, dx, dy, dz);
           hit = d2 < up2 && d2 >= lo2;
         }
@@ -195,29 +218,100 @@ __global__ __launch_bounds__(256) void k_nbr_cell(Graph g, int N, float lo2, flo
   if (FILL && i == 0 && lane == 0) g.pd[P] = 0.f;
 }
 
-__global__ void k_set_boxd(const float* __restrict__ box, float* boxd, int* mstart, int* mend, int N) {
-  if (threadIdx.x == 0) {
-    for (int k = 0; k < 9; ++k) boxd[k] = box[k];
-    mstart[0] = 0;  // one molecule: the per-molecule energy sum runs over all atoms
-    mend[0] = N;
+// One block: device copy of the box and the cell grid.
+//   periodic (box != null): grid n_axis = floor(w_axis / rc), w = perpendicular width of the reduced lower-triangular box
+//     a = (ax,0,0), b = (bx,by,0), c = (cx,cy,cz) (reference get_cell_dimensions, extensions/neighbor_utils.py:76-86, for the
+//     orthorhombic case), recomputed from the CURRENT box on every call: no host copy, valid under graph replay when the
+//     box changes; an explicit grid (tmdnet_set_cell_grid) overrides it.
+//   non-periodic (box == null; neighbour operator only): a fictitious orthorhombic box around the bounding box of the
+//     positions, edge = extent + 1.01 rc (>= 3 rc), so that no periodic image is ever within the cutoff (the reference
+//     uses a fixed 3 rc box and clamps, models/utils.py:206-212).
+// Every axis is clamped to [1, ncap] with ncap^3 <= 8 N (the capacity of cell_start).
+__global__ __launch_bounds__(1024) void k_cell_setup(const float* __restrict__ box, const float* __restrict__ pos, int N, float rc,
+                                                    int ncap, int ex, int ey, int ez, float* __restrict__ boxd,
+                                                    int* __restrict__ cgrid, int* mstart, int* mend, int one_mol) {
+  __shared__ float red[6][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float w[3];
+  if (box) {
+    if (tid == 0) {
+      for (int k = 0; k < 9; ++k) boxd[k] = box[k];
+      const float ax = box[0], bx = box[3], by = box[4], cx = box[6], cy = box[7], cz = box[8];
+      const float vol = fabsf(ax * by * cz);
+      const float bcx = by * cz, bcy = -bx * cz, bcz = bx * cy - by * cx;  // b x c
+      w[0] = vol / sqrtf(bcx * bcx + bcy * bcy + bcz * bcz);
+      w[1] = vol / (fabsf(ax) * sqrtf(cz * cz + cy * cy));                // |c x a| = |ax| sqrt(cz^2 + cy^2)
+      w[2] = fabsf(cz);                                                  // |a x b| = |ax by|
+    }
+  } else {
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = tid; i < N; i += 1024)
+      for (int a = 0; a < 3; ++a) {
+        const float v = pos[i * 3 + a];
+        mn[a] = fminf(mn[a], v);
+        mx[a] = fmaxf(mx[a], v);
+      }
+    for (int a = 0; a < 3; ++a) {
+      for (int off = 32; off >= 1; off >>= 1) {
+        mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+        mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+      }
+      if (lane == 0) {
+        red[a][wave] = mn[a];
+        red[3 + a][wave] = mx[a];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 0; k < 9; ++k) boxd[k] = 0.f;
+      for (int a = 0; a < 3; ++a) {
+        float lo = red[a][0], hi = red[3 + a][0];
+        for (int k = 1; k < 16; ++k) {
+          lo = fminf(lo, red[a][k]);
+          hi = fmaxf(hi, red[3 + a][k]);
+        }
+        const float ext = N > 0 ? hi - lo : 0.f;
+        w[a] = fmaxf(ext + 1.01f * rc + 1e-3f * ext, 3.0f * rc);
+        boxd[a * 4] = w[a];
+      }
+    }
+  }
+  if (tid == 0) {
+    const int ex3[3] = {ex, ey, ez};
+    int n[3];
+    for (int a = 0; a < 3; ++a) {
+      int v = ex3[a] > 0 ? ex3[a] : (int)floorf(w[a] / rc);
+      n[a] = v < 1 ? 1 : (v > ncap ? ncap : v);
+      cgrid[a] = n[a];
+    }
+    cgrid[3] = n[0] * n[1] * n[2];
+    if (one_mol) {
+      mstart[0] = 0;  // one molecule: the per-molecule energy sum runs over all atoms
+      mend[0] = N;
+    }
   }
 }
 
 // phase 1: bin + stable sort + permute positions + count ; phase 2: fill (link: launch_nbr_link_wave)
-void launch_cell_phase1(const Graph& g, const float* pos, const float* box, int N, float lo, float up, hipStream_t s) {
-  const int ncells = g.ncx * g.ncy * g.ncz;
-  hipLaunchKernelGGL(k_set_boxd, dim3(1), dim3(64), 0, s, box, g.boxd, g.mstart, g.mend, N);
-  hipLaunchKernelGGL(k_cell_assign, dim3(cdivc(N, 256)), dim3(256), 0, s, pos, box, N, g.ncx, g.ncy, g.ncz, g.cell_key, g.iota);
+void launch_cell_phase1(const Graph& g, const float* pos, const int64_t* batch, const float* box, int N, float lo, float up, bool loop,
+                        hipStream_t s) {
+  int ncap = 1;
+  while ((int64_t)(ncap + 1) * (ncap + 1) * (ncap + 1) <= 8 * (int64_t)N) ++ncap;  // cell_start holds 8 N + 2 entries
+  hipLaunchKernelGGL(k_cell_setup, dim3(1), dim3(1024), 0, s, box, pos, N, up, ncap, g.ncx, g.ncy, g.ncz, g.boxd, g.cgrid, g.mstart,
+                     g.mend, g.use_cell == 1 ? 1 : 0);
+  hipLaunchKernelGGL(k_cell_assign, dim3(cdivc(N, 256)), dim3(256), 0, s, pos, g.boxd, N, g.cgrid, g.cell_key, g.iota);
+  const int64_t cap = 8 * (int64_t)N + 1;
   int bits = 1;
-  while ((1 << bits) < ncells && bits < 31) ++bits;
+  while (((int64_t)1 << bits) < cap && bits < 31) ++bits;
   size_t tmp = g.sort_tmp_bytes;
   (void)rocprim::radix_sort_pairs(g.sort_tmp, tmp, g.cell_key, g.cell_key_sorted, g.iota, g.perm, (size_t)N, 0, (unsigned)bits, s);
-  hipLaunchKernelGGL(k_cell_bounds, dim3(cdivc(ncells + 1, 256)), dim3(256), 0, s, g.cell_key_sorted, N, ncells, g.cell_start);
-  hipLaunchKernelGGL(k_permute_pos, dim3(cdivc(N, 256)), dim3(256), 0, s, pos, g.perm, N, g.pos_s);
-  hipLaunchKernelGGL(k_nbr_cell<false>, dim3(cdivc(N, 4)), dim3(256), 0, s, g, N, lo * lo, up * up);
+  hipLaunchKernelGGL(k_cell_bounds, dim3(cdivc(cap + 1, 256)), dim3(256), 0, s, g.cell_key_sorted, N, g.cgrid, g.cell_start);
+  hipLaunchKernelGGL(k_permute_pos, dim3(cdivc(N, 256)), dim3(256), 0, s, pos, g.use_cell > 1 ? batch : nullptr, g.perm, N, g.pos_s,
+                     g.bat_s);
+  hipLaunchKernelGGL(k_nbr_cell<false>, dim3(cdivc(N, 4)), dim3(256), 0, s, g, N, lo * lo, up * up, (int)loop);
 }
-void launch_cell_phase2(const Graph& g, int N, float lo, float up, hipStream_t s) {
-  hipLaunchKernelGGL(k_nbr_cell<true>, dim3(cdivc(N, 4)), dim3(256), 0, s, g, N, lo * lo, up * up);
+void launch_cell_phase2(const Graph& g, int N, float lo, float up, bool loop, hipStream_t s) {
+  hipLaunchKernelGGL(k_nbr_cell<true>, dim3(cdivc(N, 4)), dim3(256), 0, s, g, N, lo * lo, up * up, (int)loop);
 }
 
 }  // namespace tn

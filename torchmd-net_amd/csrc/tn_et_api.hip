@@ -225,7 +225,6 @@ int et_create(tmdnet_model* m, const tmdnet_et_hparams* hp) {
   if (F % H) return TMDNET_ERR_INVALID;
   const int hd = F / H;
   if (hd > 64 || (hd & (hd - 1)) || (F & 1) || F > 1024) return TMDNET_ERR_INVALID;  // head reductions are wave shuffles
-  if (hp->cutoff_lower != 0.0f) return TMDNET_ERR_INVALID;
   m->et = new EtModel();
   m->et->hp = *hp;
   et_build_specs(m);

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_message_v4(Graph g, int N, int F, const
     }
     return;
   }
-  const float kap = q ? 1.0f + 0.1f * q[batch[i]] : 1.0f;
+  const float kap = q ? (batch ? 1.0f + 0.1f * q[batch[i]] : q[i]) : 1.0f;
   float4 y[9], ch[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) {

@@ -30,15 +30,18 @@ __device__ __forceinline__ float pair_d2(const float* __restrict__ pos, int hi, 
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_nbr_wave(Graph g, const float* __restrict__ pos, const int64_t* __restrict__ batch,
-                                                  const float* __restrict__ box, int box_mode, int N, float lo2, float up2,
+                                                  const float* __restrict__ box, int box_mode, int N, int B, float lo2, float up2,
                                                   int loop) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= N) return;
   if (FILL && g.counts[2]) return;
-  const int64_t b = batch[i];
+  int64_t b = batch[i];
   int j0 = 0, j1 = N;
-  if (!g.counts[3]) {
+  if (b < 0 || b >= B) {  // invalid molecule index (counts[5] is set, the host raises): no candidates, no box read
+    b = 0;
+    j1 = 0;
+  } else if (!g.counts[3]) {
     j0 = g.mstart[b];
     j1 = g.mend[b];
   }
@@ -119,14 +122,14 @@ __global__ __launch_bounds__(256) void k_nbr_link_wave(Graph g, int N) {
   }
 }
 
-void launch_nbr_count_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, float lo,
-                           float up, bool loop, hipStream_t s) {
-  hipLaunchKernelGGL(k_nbr_wave<false>, dim3(cdivw(N, 4)), dim3(256), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up,
+void launch_nbr_count_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, int B,
+                           float lo, float up, bool loop, hipStream_t s) {
+  hipLaunchKernelGGL(k_nbr_wave<false>, dim3(cdivw(N, 4)), dim3(256), 0, s, g, pos, batch, box, box_mode, N, B, lo * lo, up * up,
                      (int)loop);
 }
-void launch_nbr_fill_link_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
+void launch_nbr_fill_link_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, int B,
                                float lo, float up, bool loop, hipStream_t s) {
-  hipLaunchKernelGGL(k_nbr_wave<true>, dim3(cdivw(N, 4)), dim3(256), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up,
+  hipLaunchKernelGGL(k_nbr_wave<true>, dim3(cdivw(N, 4)), dim3(256), 0, s, g, pos, batch, box, box_mode, N, B, lo * lo, up * up,
                      (int)loop);
   hipLaunchKernelGGL(k_nbr_link_wave, dim3(cdivw(N, 4)), dim3(256), 0, s, g, N);
 }

@@ -21,7 +21,7 @@ struct Graph {  // device pointers into the graph workspace
   float* pd;     // [Pcap+1] distance (self pair: 0)
   float* pdelta; // [Pcap,3] pos_i - pos_j (+ minimum image)
   float* prhat;  // [Pcap,3] unit vector
-  int* counts;   // [8]: 0 = P, 1 = E, 2 = overflow, 3 = batch unsorted
+  int* counts;   // [8]: 0 = P, 1 = E, 2 = overflow, 3 = batch unsorted, 4 = z out of range, 5 = batch out of range
   int64_t ecap, pcap;
   // ---- cell-list path (tn_cell.hip): atoms renumbered in cell order
   int* perm;             // [N] internal index -> caller's atom index
@@ -31,10 +31,15 @@ struct Graph {  // device pointers into the graph workspace
   int* cell_start;       // [ncells+1]
   float* pos_s;          // [N,3] positions in internal order
   int64_t* z_s;          // [N] atomic numbers in internal order
-  float* boxd;           // [9] device copy of the box (rows a, b, c)
+  float* boxd;           // [9] device copy of the box (rows a, b, c); fictitious box of a non-periodic cell search
+  int* cgrid;            // [4] cells per axis + their product, computed on the device from the current box
+  int* bat_s;            // [N] molecule index per internal atom (several molecules in one box: neighbour operator)
+  int64_t* z_c;          // [N] validated (clamped to [0, max_z)) atomic numbers in internal order (tmdnet_build_graph with z)
   void* sort_tmp;
   size_t sort_tmp_bytes;
-  int ncx, ncy, ncz, use_cell;
+  int ncx, ncy, ncz;     // explicit grid (tmdnet_set_cell_grid); 0 = from the box
+  int use_cell;          // 0: brute force, 1: cell list / one molecule, 2: cell list / several molecules
+  int max_z;
 };
 
 struct RadialParams {
@@ -49,10 +54,10 @@ struct RadialParams {
 void launch_graph_build_phase1(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
                                int B, float lo, float up, bool loop, hipStream_t s);
 void launch_graph_build_phase2(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
-                               float lo, float up, bool loop, hipStream_t s);
+                               int B, float lo, float up, bool loop, hipStream_t s);
 // COO export in the reference operator's format (warp_ops/neighbors.py:34-148)
-void launch_export_pairs(const Graph& g, int N, bool include_transpose, bool loop, int64_t max_pairs, int64_t* neighbors,
-                         float* deltas, float* distances, int* num_pairs, hipStream_t s);
+void launch_export_pairs(const Graph& g, int N, bool include_transpose, bool loop, int64_t max_pairs, const int* perm,
+                         int64_t* neighbors, float* deltas, float* distances, int* num_pairs, hipStream_t s);
 
 // ---- radial basis + cutoff per pair (reference models/utils.py:402-407, 506-528)
 void launch_radial(const Graph& g, int P, RadialParams rp, float* phi, float* dphi, float* C, float* dC, hipStream_t s);
@@ -110,11 +115,12 @@ void launch_embed_gate_bwd(const float* G, const float* UX, const float* gates, 
 void launch_embed_bwd_atom(const float* g_u0_lin, const float* u0, const float* g_s0n, int N, int F, float* gA, hipStream_t s);
 void launch_force_gather(const Graph& g, int N, const float* g_delta, const int* perm, float* forces, hipStream_t s);
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);
+void launch_kappa(const float* q, const int64_t* batch, int N, int B, float* kap, hipStream_t s);
 
 // ---- wave-per-atom neighbour kernels (tn_graph_wave.hip)
-void launch_nbr_count_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, float lo,
-                           float up, bool loop, hipStream_t s);
-void launch_nbr_fill_link_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
+void launch_nbr_count_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, int B,
+                           float lo, float up, bool loop, hipStream_t s);
+void launch_nbr_fill_link_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, int B,
                                float lo, float up, bool loop, hipStream_t s);
 
 void launch_nbr_link_wave(const Graph& g, int N, hipStream_t s);
@@ -122,9 +128,12 @@ void launch_scan_counts(const Graph& g, int N, hipStream_t s);
 
 // ---- O(N) cell list for one periodic orthorhombic system (tn_cell.hip)
 size_t cell_sort_temp_bytes(int64_t n);
-void launch_cell_phase1(const Graph& g, const float* pos, const float* box, int N, float lo, float up, hipStream_t s);
-void launch_cell_phase2(const Graph& g, int N, float lo, float up, hipStream_t s);
+void launch_cell_phase1(const Graph& g, const float* pos, const int64_t* batch, const float* box, int N, float lo, float up, bool loop,
+                        hipStream_t s);
+void launch_cell_phase2(const Graph& g, int N, float lo, float up, bool loop, hipStream_t s);
 void launch_permute_z(const Graph& g, const int64_t* z, int N, hipStream_t s);
+// z_c[i] = clamp(z[perm ? perm[i] : i], 0, max_z - 1); counts[4] = 1 when any value was out of range (reference: nn.Embedding raises)
+void launch_prepare_z(const Graph& g, const int64_t* z, const int* perm, int N, int max_z, hipStream_t s);
 
 // ---- per-pair reverse kernels of the forward-tangent formulation (tn_pairgrad.hip)
 void launch_pair_gd(const Graph& g, int Pcap, int F, const float* gMi, const float* Pn, const float* dw, float* gd, hipStream_t s);

@@ -25,7 +25,8 @@ __global__ void k_mol_ranges(const int64_t* __restrict__ batch, int N, int B, in
   if (i >= N) return;
   int64_t b = batch[i];
   if (b < 0 || b >= B) {
-    counts[3] = 1;  // unusable for the range trick: fall back to the full scan
+    counts[3] = 1;
+    counts[5] = 1;  // the host raises (the reference's scatter over `batch` raises as well); kernels skip via counts[2]
     return;
   }
   if (i > 0) {
@@ -77,6 +78,7 @@ __global__ void k_nbr_count(Graph g, const float* __restrict__ pos, const int64_
   int64_t b = batch[i];
   int j0, j1;
   cand_range(g.mstart, g.mend, g.counts, b, N, j0, j1);
+  if (g.counts[5]) j1 = j0 = 0;
   const float* bx = box_mode == 0 ? nullptr : (box_mode == 1 ? box : box + b * 9);
   int nl = 0, nt = 0;
   for (int j = j0; j < j1; ++j) {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(Graph g, int N) {
     g.rowptr[N] = E;
     g.counts[0] = P;
     g.counts[1] = E;
-    g.counts[2] = (E > g.ecap || P > g.pcap) ? 1 : 0;
+    g.counts[2] = (E > g.ecap || P > g.pcap || g.counts[5]) ? 1 : 0;
   }
 }
 
@@ -259,7 +261,7 @@ void launch_graph_build_phase1(const Graph& g, const float* pos, const int64_t* 
   if (getenv("TMDNET_SCALAR_GRAPH"))  // developer switch: thread-per-atom specification kernels
     hipLaunchKernelGGL(k_nbr_count, dim3(cdiv(N, 64)), dim3(64), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up, (int)loop);
   else
-    launch_nbr_count_wave(g, pos, batch, box, box_mode, N, lo, up, loop, s);
+    launch_nbr_count_wave(g, pos, batch, box, box_mode, N, B, lo, up, loop, s);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, g, N);
 }
 
@@ -268,19 +270,21 @@ void launch_scan_counts(const Graph& g, int N, hipStream_t s) {
 }
 
 void launch_graph_build_phase2(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N,
-                               float lo, float up, bool loop, hipStream_t s) {
+                               int B, float lo, float up, bool loop, hipStream_t s) {
   if (N <= 0) return;
   if (getenv("TMDNET_SCALAR_GRAPH")) {
     hipLaunchKernelGGL(k_nbr_fill, dim3(cdiv(N, 64)), dim3(64), 0, s, g, pos, batch, box, box_mode, N, lo * lo, up * up, (int)loop);
     hipLaunchKernelGGL(k_nbr_link, dim3(cdiv(N, 64)), dim3(64), 0, s, g, N);
   } else {
-    launch_nbr_fill_link_wave(g, pos, batch, box, box_mode, N, lo, up, loop, s);
+    launch_nbr_fill_link_wave(g, pos, batch, box, box_mode, N, B, lo, up, loop, s);
   }
 }
 
-// COO list in the reference operator's format: lower pairs (i>j) [+ transposes] [+ self loops], padded with -1/0
-__global__ void k_export_pairs(Graph g, int N, int include_transpose, int loop, int64_t max_pairs, int64_t* neighbors,
-                               float* deltas, float* distances, int* num_pairs) {
+// COO list in the reference operator's format: lower pairs (i>j) [+ transposes] [+ self loops], padded with -1/0.
+// perm != null (cell strategy): pair ends are internal (cell-order) indices; they are mapped back to the caller's and
+// oriented so that the first block again has i > j.
+__global__ void k_export_pairs(Graph g, int N, int include_transpose, int loop, int64_t max_pairs, const int* __restrict__ perm,
+                               int64_t* neighbors, float* deltas, float* distances, int* num_pairs) {
   const int P = g.counts[0];
   const int64_t total = (int64_t)P * (include_transpose ? 2 : 1) + (loop ? N : 0);
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,13 +294,18 @@ __global__ void k_export_pairs(Graph g, int N, int include_transpose, int loop, 
   float dx = 0.f, dy = 0.f, dz = 0.f, d = 0.f;
   if (idx < total && !g.counts[2]) {
     int64_t k = idx;
-    if (k < P) {
+    const bool tr = include_transpose && k >= P && k < 2 * (int64_t)P;
+    if (k < P || tr) {
+      if (tr) k -= P;
       a = g.pair_i[k]; b = g.pair_j[k];
       dx = g.pdelta[k * 3]; dy = g.pdelta[k * 3 + 1]; dz = g.pdelta[k * 3 + 2]; d = g.pd[k];
-    } else if (include_transpose && k < 2 * (int64_t)P) {
-      k -= P;
-      a = g.pair_j[k]; b = g.pair_i[k];
-      dx = -g.pdelta[k * 3]; dy = -g.pdelta[k * 3 + 1]; dz = -g.pdelta[k * 3 + 2]; d = g.pd[k];
+      if (perm) {
+        a = perm[a]; b = perm[b];
+      }
+      if ((a < b) != tr) {  // orient: i > j in the first block, j < i ... transposed in the second
+        const int64_t t = a; a = b; b = t;
+        dx = -dx; dy = -dy; dz = -dz;
+      }
     } else {
       a = b = k - (int64_t)P * (include_transpose ? 2 : 1);
     }
@@ -307,10 +316,10 @@ __global__ void k_export_pairs(Graph g, int N, int include_transpose, int loop, 
   distances[idx] = d;
 }
 
-void launch_export_pairs(const Graph& g, int N, bool include_transpose, bool loop, int64_t max_pairs, int64_t* neighbors,
-                         float* deltas, float* distances, int* num_pairs, hipStream_t s) {
+void launch_export_pairs(const Graph& g, int N, bool include_transpose, bool loop, int64_t max_pairs, const int* perm,
+                         int64_t* neighbors, float* deltas, float* distances, int* num_pairs, hipStream_t s) {
   int64_t n = max_pairs > 0 ? max_pairs : 1;
-  hipLaunchKernelGGL(k_export_pairs, dim3(cdiv(n, 256)), dim3(256), 0, s, g, N, (int)include_transpose, (int)loop, max_pairs,
+  hipLaunchKernelGGL(k_export_pairs, dim3(cdiv(n, 256)), dim3(256), 0, s, g, N, (int)include_transpose, (int)loop, max_pairs, perm,
                      neighbors, deltas, distances, num_pairs);
 }
 
@@ -542,7 +551,8 @@ __device__ __forceinline__ void store9(float* __restrict__ p, int F, const float
   for (int c = 0; c < 9; ++c) p[c * F] = u[c];
 }
 __device__ __forceinline__ float kappa_of(const float* __restrict__ q, const int64_t* __restrict__ batch, int n) {
-  return q ? 1.0f + 0.1f * q[batch[n]] : 1.0f;
+  // batch == null: q already is the per-atom factor (k_kappa, energy_forces passes it that way)
+  return q ? (batch ? 1.0f + 0.1f * q[batch[n]] : q[n]) : 1.0f;
 }
 
 // X_hat = X / (||X||^2 + 1)   (reference tensornet.py:745)
@@ -1252,6 +1262,20 @@ __global__ __launch_bounds__(256) void k_force_gather(Graph g, int N, const floa
 void launch_force_gather(const Graph& g, int N, const float* g_delta, const int* perm, float* forces, hipStream_t s) {
   if (N <= 0) return;
   hipLaunchKernelGGL(k_force_gather, dim3(cdiv(N, 16)), dim3(256), 0, s, g, N, g_delta, perm, forces);
+}
+
+// per-atom charge factor kappa_n = 1 + 0.1 q[batch_n] (reference tensornet.py:789, 812); an out-of-range molecule index
+// (reported through counts[5]) reads q[0]
+__global__ void k_kappa(const float* __restrict__ q, const int64_t* __restrict__ batch, int N, int B, float* __restrict__ kap) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int64_t b = batch[i];
+  if (b < 0 || b >= B) b = 0;
+  kap[i] = 1.0f + 0.1f * q[b];
+}
+void launch_kappa(const float* q, const int64_t* batch, int N, int B, float* kap, hipStream_t s) {
+  if (N <= 0 || B <= 0) return;
+  hipLaunchKernelGGL(k_kappa, dim3(cdiv(N, 256)), dim3(256), 0, s, q, batch, N, B, kap);
 }
 
 __global__ void k_fill(float* p, float v, int64_t n) {

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(MT_THREADS, 2) void k_message_tile(Graph g, int N, 
       float* mo = Mi + (int64_t)i * F9 + f;
 #pragma unroll
       for (int c = 0; c < 9; ++c) mo[c * F] = acc[c];
-      const float kap = q ? 1.0f + 0.1f * q[batch[i]] : 1.0f;
+      const float kap = q ? (batch ? 1.0f + 0.1f * q[batch[i]] : q[i]) : 1.0f;
       const M3 Y = compose(y), M = compose(acc);
       M3 Cm = o3 ? scale(add(matmul(Y, M), matmul(M, Y)), kap) : scale(matmul(Y, M), 2.0f);
       float uc[9];

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
@@ -65,7 +66,7 @@ struct FwdBuffers {
   std::vector<float*> X;                               // L+1
   std::vector<float*> w, dw, Pn, Mi, D;                 // per layer (dw = d w / d d, forward tangent)
   float *he1, *he2, *te1, *te2, *dQ, *Xh, *Ch;
-  float *feat, *lnr, *xhr, *rstdr, *al, *x, *ao, *ea;
+  float *feat, *lnr, *xhr, *rstdr, *al, *x, *ao, *ea, *kap;
   // reverse
   float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *gd, *gd_slots;
   float *gUX, *g_a2, *g_a1, *g_ln0, *g_s0n, *g_u0l, *gA, *g_rhat, *g_delta;
@@ -79,6 +80,7 @@ struct ProfRec {
   int cat;
   hipEvent_t a, b;
   double flops, bytes;
+  char label[64];  // kernel + shape, e.g. "k_gemm_dual_sb2<2> 193710x384x256" (empty: the class name says it all)
 };
 struct Profiler {
   bool on = false;
@@ -109,8 +111,9 @@ struct tmdnet_model {
   EtModel* et = nullptr;  // non-null: Equivariant Transformer handle (hp then only carries what the graph phase reads)
   Profiler prof;
   int64_t lastE = 0;
-  int cell_n[3] = {0, 0, 0};  // cell grid set by tmdnet_set_cell_grid (0 = brute force)
+  int cell_n[3] = {0, 0, 0};  // cell grid set by tmdnet_set_cell_grid (0 = brute force, < 0 = from the box, on the device)
   bool graph_is_cell = false; // last build used the cell list (atoms internally renumbered)
+  bool graph_has_z = false;   // last build validated z into Graph::z_c (internal order)
   std::vector<ParamSpec> specs;
   std::map<std::string, std::vector<float>> host;
   float* dev = nullptr;  // packed parameters
@@ -162,10 +165,11 @@ struct CurScope {  // g_cur is valid exactly while an entry point is enqueueing 
 struct ProfScope {
   int idx = -1;
   hipStream_t s;
-  ProfScope(hipStream_t s_, int cat, double flops, double bytes) : s(s_) {
+  ProfScope(hipStream_t s_, int cat, double flops, double bytes, const char* label = nullptr) : s(s_) {
     tmdnet_model* m = g_cur;
     if (!m || !m->prof.on || !((m->prof.mask >> cat) & 1u)) return;
-    ProfRec r{cat, m->prof.get(), m->prof.get(), flops, bytes};
+    ProfRec r{cat, m->prof.get(), m->prof.get(), flops, bytes, {0}};
+    if (label) std::snprintf(r.label, sizeof(r.label), "%s", label);
     (void)hipEventRecord(r.a, s);
     idx = (int)m->prof.recs.size();
     m->prof.recs.push_back(r);
@@ -174,10 +178,10 @@ struct ProfScope {
     if (idx >= 0) (void)hipEventRecord(g_cur->prof.recs[idx].b, s);
   }
 };
-#define KR(cat, bytes, call)                      \
-  do {                                            \
-    ProfScope ps_(s, cat, 0.0, (double)(bytes));  \
-    call;                                         \
+#define KR(cat, bytes, call)                             \
+  do {                                                   \
+    ProfScope ps_(s, cat, 0.0, (double)(bytes), #call);  \
+    call;                                                \
   } while (0)
 
 // C = epilogue(A W^T + bias) through the path's MFMA GEMMs (split-bf16 kernels when W has a registered image)

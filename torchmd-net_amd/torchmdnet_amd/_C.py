@@ -63,16 +63,19 @@ def lib():
     L.tmdnet_param_name.argtypes = [vp, C.c_int, C.POINTER(i64)]
     L.tmdnet_param_name.restype = C.c_char_p
     L.tmdnet_graph_workspace_bytes.argtypes = [vp, i64, i64, C.POINTER(sz)]
-    L.tmdnet_build_graph.argtypes = [vp, vp, vp, sz, i64, i64, vp, vp, vp, i32, C.POINTER(i64)]
+    L.tmdnet_build_graph.argtypes = [vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, i32, C.POINTER(i64)]
     L.tmdnet_set_cell_grid.argtypes = [vp, i32, i32, i32]
-    L.tmdnet_build_graph_static.argtypes = [vp, vp, vp, sz, i64, i64, vp, vp, vp, i32]
+    L.tmdnet_build_graph_static.argtypes = [vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, i32]
     L.tmdnet_graph_counts.argtypes = [vp, vp, vp, i64, i64, C.POINTER(i64)]
+    L.tmdnet_graph_cell_grid.argtypes = [vp, vp, vp, i64, i64, C.POINTER(i64)]
     L.tmdnet_forward_workspace_bytes.argtypes = [vp, i64, i64, i64, i64, i32, C.POINTER(sz)]
     L.tmdnet_energy_forces.argtypes = [vp, vp, vp, vp, sz, i64, i64, i64, vp, vp, vp, i32, vp, vp]
     L.tmdnet_neighbor_workspace_bytes.argtypes = [i64, i64, i64, C.POINTER(sz)]
-    L.tmdnet_neighbor_pairs.argtypes = [vp, vp, sz, i64, i64, vp, vp, vp, i32, f32, f32, i64, i32, i32, vp, vp, vp, vp]
+    L.tmdnet_neighbor_pairs.argtypes = [vp, vp, sz, i64, i64, vp, vp, vp, i32, f32, f32, i64, i32, i32, i32, vp, vp, vp, vp]
     L.tmdnet_profile_begin.argtypes = [vp, C.c_uint32]
     L.tmdnet_profile_end.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
+    L.tmdnet_profile_end_records.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double), C.c_char_p, C.POINTER(i64)]
     L.tmdnet_profile_category_name.argtypes = [C.c_int]
     L.tmdnet_profile_category_name.restype = C.c_char_p
     L.tmdnet_debug_tensor.argtypes = [vp, vp, C.c_char_p, vp, i64]

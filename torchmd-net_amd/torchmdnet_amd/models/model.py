@@ -1,3 +1,7 @@
+# Host glue mirroring torchmd-net's torchmdnet/models/model.py (Copyright Universitat Pompeu Fabra 2020-2023,
+# https://www.compscience.org, MIT License): `load_ensemble`, `create_prior_models`, `Ensemble` and the checkpoint
+# key-rename / remix rules of `load_model` restate the reference's logic (model.py:167-205, 261-372, 377-448, 634-680)
+# because they ARE the checkpoint / argument contract; everything numerical is this repository's own HIP code.
 """Model assembly with the reference's public surface (torchmdnet/models/model.py):
 ``create_model(args, prior_model=None, mean=None, std=None)``, ``load_model(filepath, args=None, device="cpu",
 return_std=False, **kwargs)``, ``load_ensemble``, ``create_prior_models`` and the ``TorchMD_Net`` /
@@ -180,8 +184,13 @@ def load_model(filepath, args=None, device="cpu", return_std=False, **kwargs):
             warnings.warn("Old-format checkpoint detected ('check_errors' found in hyper_parameters). Automatically "
                           "applying compatibility_load to remap linear-layer weights. Pass compatibility_load=False "
                           "to suppress this.")
-        keys = ["representation_model.tensor_embedding.linears_scalar.1"]
-        keys += [f"representation_model.layers.{l}.linears_scalar.2" for l in range(args["num_layers"])]
+        # only the TensorNet families carry these layers (reference model.py:333-372): an old Equivariant Transformer
+        # checkpoint also has 'check_errors' in its hyper-parameters and must load untouched
+        keys = []
+        if args["model"] in ("tensornet", "tensornet2"):
+            keys.append("representation_model.tensor_embedding.linears_scalar.1")
+        if args["model"] == "tensornet":
+            keys += [f"representation_model.layers.{l}.linears_scalar.2" for l in range(args["num_layers"])]
         for k in keys:
             state_dict[k + ".weight"], state_dict[k + ".bias"] = _remix_rows(state_dict[k + ".weight"], state_dict[k + ".bias"])
 
@@ -224,9 +233,11 @@ class _EngineState:
     def __init__(self):
         self.handle = None
         self.fingerprint = None
+        self.tensors = None
         self.graph_ws = None
         self.fwd_ws = None
         self.counts = None
+        self.generation = 0  # bumped whenever the handle or a workspace is re-created: captured graphs of older generations are stale
 
     def release(self):
         if self.handle is not None:
@@ -349,8 +360,18 @@ class TorchMD_Net(nn.Module):
             out[:n] += t[:n].float().cpu()
         return out
 
+    def _apply(self, fn, recurse=True):
+        # .to() / .cuda() / .float() replace buffers by new tensor objects: drop the cached tensor list of _fingerprint
+        self._engine.tensors = None
+        return super()._apply(fn, recurse)
+
     def _fingerprint(self):
-        fp = [(k, v._version, v.data_ptr()) for k, v in self.state_dict(keep_vars=True).items()]
+        """Cheap change detector for the uploaded parameters: (version, address) of every tensor of the state dict.  The
+        tensor list itself is cached (rebuilding ``state_dict()`` costs more than a small MD step); ``_apply`` drops it."""
+        st = self._engine
+        if st.tensors is None:
+            st.tensors = list(self.state_dict(keep_vars=True).values())
+        fp = [(v._version, v.data_ptr()) for v in st.tensors]
         if self.prior_model is not None:
             fp.append(tuple(p.enable for p in self.prior_model))
         return tuple(fp)
@@ -363,6 +384,7 @@ class TorchMD_Net(nn.Module):
             return st
         L = _C.lib()
         st.release()
+        st.generation += 1
         handle = C.c_void_p()
         if self._is_et():
             hp = self._et_hparams()
@@ -393,34 +415,19 @@ class TorchMD_Net(nn.Module):
         st.fingerprint = fp
         return st
 
-    def _cell_grid(self, box: Tensor):
-        """Cells per axis = floor(w / rc) with w the perpendicular width of the box along that axis (for an orthorhombic
-        box the edge length: reference get_cell_dimensions, extensions/neighbor_utils.py:76-86; the reference's cell path
-        stops there, triclinic boxes in its reduced lower-triangular form are handled here as well); (0,0,0) = not
-        applicable.  The host copy of the box is cached per tensor version so that repeated calls do not synchronise."""
-        key = (box.data_ptr(), box._version)
-        cache = self._engine.__dict__.setdefault("box_cache", {})
-        if key not in cache:
-            b = box.detach().to("cpu", torch.float64)
-            rc = float(self.representation_model.cutoff_upper)
-            cache.clear()
-            upper = torch.triu(b, diagonal=1)
-            if float(upper.abs().max()) != 0.0 or float(torch.diagonal(b).min()) <= 0.0:
-                cache[key] = (0, 0, 0)  # not in the reduced form a=(ax,0,0), b=(bx,by,0), c=(cx,cy,cz): brute force
-            else:
-                vol = float(torch.det(b).abs())
-                a_, b_, c_ = b[0], b[1], b[2]
-                widths = (vol / float(torch.linalg.norm(torch.linalg.cross(b_, c_))),
-                          vol / float(torch.linalg.norm(torch.linalg.cross(c_, a_))),
-                          vol / float(torch.linalg.norm(torch.linalg.cross(a_, b_))))
-                cache[key] = tuple(int(w // rc) for w in widths)
-        return cache[key]
-
-    @staticmethod
-    def _grow(buf, nbytes, device):
+    def _grow(self, buf, nbytes, device):
         if buf is None or buf.numel() < nbytes or buf.device != device:
+            self._engine.generation += 1
             return torch.empty(max(int(nbytes * 1.1), 256), dtype=torch.uint8, device=device)
         return buf
+
+    @staticmethod
+    def _check_input(t: Tensor, name: str, dev, dtypes):
+        if t.device != dev:
+            raise RuntimeError(f"torchmdnet_amd: `{name}` is on {t.device} but `pos` is on {dev}; all inputs must live on the "
+                               "same AMD GPU (the HIP kernels receive raw device pointers)")
+        if t.dtype not in dtypes:
+            raise TypeError(f"torchmdnet_amd: `{name}` must have dtype {' or '.join(str(d) for d in dtypes)}, got {t.dtype}")
 
     def energy_and_forces(self, z, pos, batch, box, q, n_mol, want_forces=True) -> Tuple[Tensor, Optional[Tensor]]:
         """Raw engine call: returns (E [n_mol], F [N,3] or None), both fp32 on ``pos.device``."""
@@ -429,6 +436,10 @@ class TorchMD_Net(nn.Module):
         dev = pos.device
         if next(self.parameters()).device != dev:
             raise RuntimeError("model and inputs are on different devices")
+        self._check_input(z, "z", dev, (torch.long,))
+        self._check_input(batch, "batch", dev, (torch.long, torch.int32))
+        if z.shape[0] != pos.shape[0] or batch.shape[0] != pos.shape[0]:
+            raise ValueError(f"z [{z.shape[0]}], pos [{pos.shape[0]}] and batch [{batch.shape[0]}] must have one entry per atom")
         with torch.cuda.device(dev):
             st = self._sync_engine()
             stream = _stream_ptr(dev)
@@ -446,27 +457,27 @@ class TorchMD_Net(nn.Module):
                 q = q.detach().to(device=dev, dtype=torch.float32).contiguous()
                 if q.numel() != n_mol:
                     raise ValueError(f"q must have one entry per molecule ({n_mol}), got {q.numel()}")
-            # neighbour strategy: O(N) cell list for one large orthorhombic periodic system, brute force otherwise
-            grid = (0, 0, 0)
-            if box_mode == 1 and n_mol == 1 and n >= self.cell_list_min_atoms:
-                grid = self._cell_grid(box)
-            L.tmdnet_set_cell_grid(st.handle, *grid)
+            # neighbour strategy: O(N) cell list for one large periodic system (grid computed on the device from the box of
+            # THIS call: nothing about the box is cached on the host), brute force inside each molecule otherwise
+            auto = box_mode == 1 and n_mol == 1 and n >= self.cell_list_min_atoms
+            L.tmdnet_set_cell_grid(st.handle, *((-1, -1, -1) if auto else (0, 0, 0)))
             nbytes = C.c_size_t(0)
             L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
             st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
-            counts = (C.c_int64 * 4)()
+            counts = (C.c_int64 * 8)()
             static = bool(getattr(self.representation_model, "static_shapes", False))
             if static:
                 # static shapes (reference tensornet.py:277-290): no read-back, no synchronisation -> the whole call
                 # can be captured in a HIP graph; launch grids / workspaces are sized by max_num_neighbors * N
                 rc = L.tmdnet_build_graph_static(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32),
-                                                 _ptr(batch), _ptr(box), box_mode)
+                                                 _ptr(batch), _ptr(z), _ptr(box), box_mode)
                 n_pairs, n_edges = -1, -1
             else:
                 rc = L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32),
-                                          _ptr(batch), _ptr(box), box_mode, counts)
+                                          _ptr(batch), _ptr(z), _ptr(box), box_mode, counts)
                 n_pairs, n_edges = int(counts[0]), int(counts[1])
                 st.counts = (n_pairs, n_edges, int(counts[3]))
+                self._raise_bad_indices(counts, L.tmdnet_last_error(st.handle).decode())
             if rc == _C.ERR_OVERFLOW:
                 # same exception type and message as the reference (models/utils.py:297-300)
                 raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
@@ -486,17 +497,33 @@ class TorchMD_Net(nn.Module):
                 self.check_overflow(n, n_mol)
         return energy, forces
 
+    @staticmethod
+    def _raise_bad_indices(counts, msg):
+        if int(counts[5]):  # the reference's scatter over `batch` raises a RuntimeError for an index outside [0, dim_size)
+            raise RuntimeError(msg)
+        if int(counts[4]):  # nn.Embedding raises IndexError (tensornet.py:473, torchmd_et.py:144)
+            raise IndexError(msg)
+
     def check_overflow(self, n_atoms: int, n_mol: int):
         """Poll the device-side pair counters of the last static-shape evaluation (synchronises)."""
         L = _C.lib()
         st = self._engine
-        counts = (C.c_int64 * 4)()
+        counts = (C.c_int64 * 8)()
         rc = L.tmdnet_graph_counts(st.handle, _stream_ptr(st.graph_ws.device), _ptr(st.graph_ws), n_atoms, n_mol, counts)
         st.counts = (int(counts[0]), int(counts[1]), int(counts[3]))
+        self._raise_bad_indices(counts, L.tmdnet_last_error(st.handle).decode())
         if rc == _C.ERR_OVERFLOW:
             raise RuntimeError("Found num_pairs > max_num_pairs, please increase max_num_pairs "
                                f"(found {int(counts[1])} edges for max_num_neighbors={self.representation_model.max_num_neighbors})")
         return st.counts
+
+    def cell_grid(self, n_atoms: int, n_mol: int = 1):
+        """(n_x, n_y, n_z, used) of the last evaluation's neighbour search; used = 0: brute force ran (synchronises)."""
+        L = _C.lib()
+        st = self._engine
+        grid = (C.c_int64 * 4)()
+        L.tmdnet_graph_cell_grid(st.handle, _stream_ptr(st.graph_ws.device), _ptr(st.graph_ws), n_atoms, n_mol, grid)
+        return tuple(int(v) for v in grid)
 
     def capture(self, z: Tensor, pos: Tensor, batch: Optional[Tensor] = None, box: Optional[Tensor] = None,
                 q: Optional[Tensor] = None, num_systems: Optional[int] = None, warmup: int = 3):
@@ -521,8 +548,13 @@ class TorchMD_Net(nn.Module):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             s_e, s_f = self.energy_and_forces(z, s_pos, batch, box, q, n_mol, want_forces=True)
+        engine, generation = self._engine, self._engine.generation
 
         def replay(new_pos: Optional[Tensor] = None):
+            # the graph holds raw pointers into the engine's parameter block and workspaces: an eager call after a parameter
+            # change / device move, or with a larger system, re-creates them; replaying would then touch freed memory
+            if self._engine is not engine or engine.generation != generation:
+                raise RuntimeError("stale HIP graph: the model's parameters or workspaces changed after capture(); capture again")
             if new_pos is not None:
                 s_pos.copy_(new_pos)
             graph.replay()

@@ -92,8 +92,6 @@ class TorchMD_ET(nn.Module):
         assert attn_activation in act_class_mapping, f'Unknown attention activation function "{attn_activation}".'
         if activation != "silu" or attn_activation != "silu":
             raise NotImplementedError("the HIP Equivariant Transformer path implements SiLU activations (ET-SPICE.yaml)")
-        if float(cutoff_lower) != 0.0:
-            raise NotImplementedError("cutoff_lower > 0 has no HIP kernel on the Equivariant Transformer path")
         hd = hidden_channels // num_heads
         if hidden_channels % num_heads or hd > 64 or (hd & (hd - 1)):
             raise NotImplementedError("head_dim must be a power of two <= 64 on the HIP path")

@@ -101,7 +101,10 @@ class OptimizedDistance(nn.Module):
     """Neighbour list with the reference's interface and conventions (models/utils.py:120-313):
     ``edge_vec = pos[edge_index[0]] - pos[edge_index[1]]`` (+ triclinic minimum image), pairs padded
     with (-1,-1) unless ``resize_to_fit``, RuntimeError when more than ``max_num_pairs`` are found.
-    Both strategies run the same molecule-restricted HIP pair search (deterministic order)."""
+    ``strategy="brute"``: molecule-restricted wave-per-atom search (tn_graph_wave.hip); ``strategy="cell"``: the O(N) cell
+    list (tn_cell.hip) over all molecules at once - one periodic box, or without a box a fictitious one around the
+    bounding box of the positions (the reference uses a fixed 3*cutoff box there, models/utils.py:206-212); one box per
+    molecule has no common grid and takes the brute-force kernel.  Same pair set, deterministic order, either way."""
 
     def __init__(self, cutoff_lower=0.0, cutoff_upper=5.0, max_num_pairs=-32, return_vecs=False, loop=False,
                  strategy="brute", include_transpose=True, resize_to_fit=True, box=None, long_edge_index=True):
@@ -152,7 +155,8 @@ class OptimizedDistance(nn.Module):
         rc = L.tmdnet_neighbor_pairs(_stream_ptr(pos.device), _ptr(self._ws), self._ws.numel(), n, n_mol, _ptr(p),
                                      _ptr(batch), _ptr(box if use_periodic else None), box_mode, float(self.cutoff_lower),
                                      float(self.cutoff_upper), max_pairs, int(self.loop), int(self.include_transpose),
-                                     _ptr(neighbors), _ptr(deltas), _ptr(dist), _ptr(num_pairs))
+                                     1 if self.strategy == "cell" else 0, _ptr(neighbors), _ptr(deltas), _ptr(dist),
+                                     _ptr(num_pairs))
         if rc != _C.OK:
             raise RuntimeError(f"tmdnet_neighbor_pairs failed with code {rc}")
         if int(num_pairs.item()) > max_pairs:  # reference: torch._assert_async -> RuntimeError (models/utils.py:297-300)

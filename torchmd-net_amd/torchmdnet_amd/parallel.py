@@ -40,14 +40,25 @@ class ShardedEvaluator:
         self.group = group
         self.gather_forces = gather_forces
 
-    def evaluate(self, z, pos, batch, q=None, box=None, n_mol=None) -> Tuple[torch.Tensor, torch.Tensor, Tuple[int, int]]:
+    def plan(self, batch, n_mol=None):
+        """Partition of a (sorted) batch vector over the ranks: list of (mol_lo, mol_hi, atom_lo, atom_hi).  It depends on
+        `batch` only, so an MD loop or a benchmark computes it once and passes it to evaluate(ranges=...): the check and the
+        partition read `batch` on the host (one synchronisation)."""
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
         if n_mol is None:
             n_mol = int(batch.max().item()) + 1
         if not bool((batch[1:] >= batch[:-1]).all()):
             raise ValueError("sharded evaluation needs atoms of a molecule to be contiguous (sorted batch)")
-        m_lo, m_hi, a_lo, a_hi = molecule_ranges(batch, n_mol, world)[rank]
+        return molecule_ranges(batch, n_mol, world)
+
+    def evaluate(self, z, pos, batch, q=None, box=None, n_mol=None, ranges=None) -> Tuple[torch.Tensor, torch.Tensor, Tuple[int, int]]:
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        if n_mol is None:
+            n_mol = int(batch.max().item()) + 1
+        if ranges is None:
+            ranges = self.plan(batch, n_mol)
+        m_lo, m_hi, a_lo, a_hi = ranges[rank]
         energy = torch.zeros(n_mol, dtype=torch.float32, device=pos.device)
         if m_hi > m_lo:
             zl, pl = z[a_lo:a_hi], pos[a_lo:a_hi]
@@ -61,7 +72,6 @@ class ShardedEvaluator:
         if world > 1:
             dist.all_reduce(energy, op=dist.ReduceOp.SUM, group=self.group)
         if self.gather_forces and world > 1:
-            ranges = molecule_ranges(batch, n_mol, world)
             mx = max(r[3] - r[2] for r in ranges)
             pad = torch.zeros((mx, 3), dtype=torch.float32, device=pos.device)
             pad[: f_loc.shape[0]] = f_loc
