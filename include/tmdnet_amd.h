@@ -168,6 +168,14 @@ int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_ato
                           int64_t max_num_pairs, int32_t loop, int32_t include_transpose, int32_t strategy, int64_t* neighbors,
                           float* deltas, float* distances, int32_t* num_pairs);
 
+/* Gradient of (deltas, distances) wrt the positions: the reference's neighbor_grad_positions
+ * (torchmdnet/extensions/neighbor_utils.py:11-46), registered as the backward of its neighbour ops
+ * (warp_ops/neighbors.py:105-148).  neighbors int64 [2, num_entries] (padding -1 is skipped, d = 0 contributes nothing),
+ * grad_deltas [num_entries,3] / grad_distances [num_entries] may be NULL (= zero); grad_positions [n_atoms,3] is overwritten. */
+int tmdnet_neighbor_grad(void* stream, const int64_t* neighbors, const float* deltas, const float* distances,
+                         const float* grad_deltas, const float* grad_distances, int64_t num_entries, int64_t n_atoms,
+                         float* grad_positions);
+
 /* ---- per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
  * selected classes; bit c of category_mask selects class c).  tmdnet_profile_end synchronises the
  * stream and returns, per class: summed milliseconds, algorithmic FLOPs, algorithmic bytes (each distinct

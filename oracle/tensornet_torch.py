@@ -144,7 +144,7 @@ def tensornet_representation(sd: Dict[str, Tensor], hp: dict, z: Tensor, pos: Te
     # ---- TensorEmbedding.forward, tensornet.py:543-619
     T = P + "tensor_embedding."
     Z = Fn.embedding(z, sd[T + "emb.weight"])
-    Zij = lin(torch.cat([Z[ei], Z[ej]], dim=-1), sd, T + "emb2")  # :526-541
+    Zij = lin(Z.index_select(0, edge_index.t().reshape(-1)).view(-1, 2 * F), sd, T + "emb2")  # :526-541
     C = cosine_cutoff(d, lo, up)
     W = (C[:, None] * Zij)[:, None, :] * torch.stack(
         [lin(phi, sd, T + "distance_proj1"), lin(phi, sd, T + "distance_proj2"), lin(phi, sd, T + "distance_proj3")],
@@ -181,11 +181,14 @@ def tensornet_representation(sd: Dict[str, Tensor], hp: dict, z: Tensor, pos: Te
         A = lin(A, sd, Lp + "linears_tensor.1", bias=False)
         S = lin(S, sd, Lp + "linears_tensor.2", bias=False)
         Y = I[:, None, None, :] * _eye(X) + A + S  # :755
-        # message passing :622-679 (skew<->vector round trip is the identity on skew tensors)
-        Im = torch.zeros_like(I).index_add(0, ei, w[:, 0] * I[ej])
-        Am = torch.zeros_like(A).index_add(0, ei, w[:, 1, None, None, :] * A[ej])
-        Sm = torch.zeros_like(S).index_add(0, ei, w[:, 2, None, None, :] * S[ej])
-        M = Im[:, None, None, :] * _eye(X) + Am + Sm
+        # message passing :622-679, same op sequence as the reference (this function is also bench.py's CPU baseline):
+        # the skew part travels as a vector (skewtensor_to_vector :106-123), gathers are index_select, sums index_add
+        Af = A.flatten(1, 2)
+        Av = 0.5 * torch.stack((Af[:, 7] - Af[:, 5], Af[:, 2] - Af[:, 6], Af[:, 3] - Af[:, 1]), dim=1)
+        Im = torch.zeros_like(I).index_add(0, ei, w[:, 0] * I.index_select(0, ej))
+        Avm = torch.zeros_like(Av).index_add(0, ei, w[:, 1, None, :] * Av.index_select(0, ej))
+        Sm = torch.zeros_like(S).index_add(0, ei, w[:, 2, None, None, :] * S.index_select(0, ej))
+        M = Im[:, None, None, :] * _eye(X) + skew(Avm) + Sm
         if hp.get("equivariance_invariance_group", "O(3)") == "O(3)":
             Cm = kappa * (matmul33(M, Y) + matmul33(Y, M))  # :788-790
         else:

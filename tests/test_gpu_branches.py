@@ -441,3 +441,44 @@ def test_neighbor_operator_cell_strategy_large(hip_lib, box_kind, n_mol):
             assert np.allclose(got[1], ref[1], atol=1e-5) and np.allclose(got[2], ref[2], atol=1e-5)
         if not tr:
             assert (outs[0][0][0] > outs[0][0][1]).all()  # i > j orientation survives the cell-order renumbering
+
+
+# ------------------------------------------------------------------ (i) torch custom ops: opcheck, compile, export
+def test_custom_ops_opcheck_compile_export(hip_lib, golden_dir):
+    """The model's forward is one registered torch op (tmdnet::energy_forces; fake + autograd registered), so the tracing
+    front ends of the reference's deployment paths work: torch.library.opcheck, torch.compile (calculators.py:297) and
+    torch.export (tests/test_export.py)."""
+    from torchmdnet_amd import ops
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    model = create_model(dict(g["args"], derivative=False))
+    model.load_state_dict(g["state_dict"])
+    model = model.to("cuda").eval()
+    z, pos, batch = g["z"].cuda(), g["pos"].cuda(), g["batch"].cuda()
+    n_mol = int(batch.max()) + 1
+    y0, _ = model(z, pos, batch)
+    key = model._engine.op_key
+    pg = pos.clone().requires_grad_(True)
+    torch.library.opcheck(torch.ops.tmdnet.energy_forces, (z, pg, batch, None, None, key, n_mol, True),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    torch.library.opcheck(torch.ops.tmdnet.neighbor_pairs, (pg, batch, None, 0.0, 4.0, 600, True, True, 0, n_mol),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    # autograd through the op == the forces
+    y, _ = model(z, pg, batch)
+    y.sum().backward()
+    assert rel_err(-pg.grad.cpu(), g["F_q0"]) < REL
+    # torch.compile: dynamo traces the module, the op stays one node (aot_eager: no code generation involved)
+    compiled = torch.compile(model, backend="aot_eager")
+    with torch.no_grad():
+        yc, _ = compiled(z, pos, batch, num_systems=n_mol)
+    assert torch.equal(yc, y0)
+    pc = pos.clone().requires_grad_(True)
+    yc2, _ = compiled(z, pc, batch, num_systems=n_mol)
+    yc2.sum().backward()
+    assert rel_err(-pc.grad.cpu(), g["F_q0"]) < REL
+    # torch.export: the exported program contains the op and reproduces the energies
+    ep = torch.export.export(model, (z, pos, batch), kwargs={"num_systems": n_mol}, strict=False)
+    assert "tmdnet.energy_forces" in str(ep.graph)
+    ye, _ = ep.module()(z, pos, batch, num_systems=n_mol)
+    assert torch.equal(ye, y0)

@@ -28,8 +28,7 @@ def test_neighbors(hip_lib, strategy, n_batches, cutoff, loop, include_transpose
     from oracle.neighbors_numpy import reference_neighbors, sort_neighbors
     from torchmdnet_amd.models.utils import OptimizedDistance
 
-    if strategy == "cell" and box_type == "triclinic":
-        pytest.skip("reference: triclinic not supported for cell")
+    # (the reference skips cell + triclinic, tests/test_neighbors.py:88: its cell kernel is orthorhombic-only; tn_cell.hip is not)
     lbox = 10.0
     pos, batch = _system(n_batches, lbox=lbox)
     box = None
@@ -85,7 +84,7 @@ def test_pair_overflow_raises_runtime_error(hip_lib):
         nl(pos)
 
 
-def test_neighbor_gradients(hip_lib):
+def test_neighbor_gradients(hip_lib):  # backward = tmdnet::neighbor_grad (HIP kernel)
     """d(deltas, distances)/d(pos) vs a pure-torch evaluation on the same pair list
     (reference tests/test_neighbors.py:151-261; fp32 tolerance 1e-2 there)."""
     from torchmdnet_amd.models.utils import OptimizedDistance

@@ -238,3 +238,28 @@ def test_fingerprint_cache_follows_module_changes():
     assert model._engine.tensors is None  # rebuilt lazily with the new tensor objects
     assert len(model._fingerprint()) == len(fp0)
     assert "equivariant-transformer" in __import__("torchmdnet_amd.models", fromlist=["x"]).__all_models__
+
+
+def test_custom_ops_are_registered_with_fake_impls():
+    """torch.ops.tmdnet.{energy_forces, neighbor_pairs, neighbor_grad} exist with fake (meta) implementations: shape
+    propagation works on fake CUDA tensors without a GPU - what torch.compile / torch.export need to trace the model
+    (reference: register_fake of its Warp ops, warp_ops/neighbors.py:61-104)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    from torchmdnet_amd import ops  # noqa: F401
+
+    with FakeTensorMode():
+        z = torch.empty(7, dtype=torch.long, device="cuda")
+        pos = torch.empty(7, 3, device="cuda")
+        b = torch.zeros(7, dtype=torch.long, device="cuda")
+        e, f = torch.ops.tmdnet.energy_forces(z, pos, b, None, None, 1, 2, True)
+        assert e.shape == (2,) and f.shape == (7, 3) and e.device.type == "cuda"
+        e, f = torch.ops.tmdnet.energy_forces(z, pos, b, None, None, 1, 2, False)
+        assert f.shape == (0, 3)
+        nb, d, w, n = torch.ops.tmdnet.neighbor_pairs(pos, b, None, 0.0, 5.0, 40, True, True, 0, 1)
+        assert nb.shape == (2, 40) and nb.dtype == torch.long and d.shape == (40, 3) and w.shape == (40,) and n.dtype == torch.int32
+        g = torch.ops.tmdnet.neighbor_grad(nb, d, w, d, w, 7)
+        assert g.shape == (7, 3)
+    model = create_model(dict(W.TINY_ARGS))
+    clone = copy.deepcopy(model)
+    assert clone._engine.op_key is None and model._engine.op_key is None  # keys are handed out on first use, never shared

@@ -954,6 +954,15 @@ int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_ato
   return hipGetLastError() == hipSuccess ? TMDNET_OK : TMDNET_ERR_HIP;
 }
 
+int tmdnet_neighbor_grad(void* stream, const int64_t* neighbors, const float* deltas, const float* distances,
+                         const float* grad_deltas, const float* grad_distances, int64_t num_entries, int64_t n_atoms,
+                         float* grad_positions) {
+  if (!neighbors || !deltas || !distances || !grad_positions || num_entries < 0 || n_atoms < 0) return TMDNET_ERR_INVALID;
+  launch_neighbor_grad(neighbors, deltas, distances, grad_deltas, grad_distances, num_entries, (int)n_atoms, grad_positions,
+                       reinterpret_cast<hipStream_t>(stream));
+  return hipGetLastError() == hipSuccess ? TMDNET_OK : TMDNET_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------ profiling
 int tmdnet_profile_begin(tmdnet_model* m, uint32_t category_mask) {
   if (!m) return TMDNET_ERR_INVALID;

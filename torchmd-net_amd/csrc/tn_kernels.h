@@ -59,6 +59,9 @@ void launch_graph_build_phase2(const Graph& g, const float* pos, const int64_t* 
 void launch_export_pairs(const Graph& g, int N, bool include_transpose, bool loop, int64_t max_pairs, const int* perm,
                          int64_t* neighbors, float* deltas, float* distances, int* num_pairs, hipStream_t s);
 
+void launch_neighbor_grad(const int64_t* nb, const float* deltas, const float* dist, const float* g_delta, const float* g_dist,
+                          int64_t M, int N, float* out, hipStream_t s);
+
 // ---- radial basis + cutoff per pair (reference models/utils.py:402-407, 506-528)
 void launch_radial(const Graph& g, int P, RadialParams rp, float* phi, float* dphi, float* C, float* dC, hipStream_t s);
 

@@ -323,6 +323,33 @@ void launch_export_pairs(const Graph& g, int N, bool include_transpose, bool loo
                      neighbors, deltas, distances, num_pairs);
 }
 
+// Gradient of the neighbour operator's outputs wrt the positions (reference extensions/neighbor_utils.py:11-46):
+//   g = g_delta[p] + delta[p] / d[p] * g_dist[p]   (zero for padded entries and for d = 0) ; out[i] += g ; out[j] -= g
+// The COO list carries no row structure, so the sum uses float atomics (this operator is off the model's hot path, whose
+// own force reduction is the atomic-free CSR gather k_force_gather).
+__global__ void k_neighbor_grad(const int64_t* __restrict__ nb, const float* __restrict__ deltas, const float* __restrict__ dist,
+                                const float* __restrict__ g_delta, const float* __restrict__ g_dist, int64_t M, int N,
+                                float* __restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const int64_t i = nb[p], j = nb[M + p];
+  const float d = dist[p];
+  if (i < 0 || j < 0 || i >= N || j >= N || d == 0.f) return;
+  const float gd = g_dist ? g_dist[p] / d : 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float g = (g_delta ? g_delta[p * 3 + a] : 0.f) + deltas[p * 3 + a] * gd;
+    atomicAdd(out + i * 3 + a, g);
+    atomicAdd(out + j * 3 + a, -g);
+  }
+}
+void launch_neighbor_grad(const int64_t* nb, const float* deltas, const float* dist, const float* g_delta, const float* g_dist,
+                          int64_t M, int N, float* out, hipStream_t s) {
+  launch_fill(out, 0.f, (int64_t)N * 3, s);
+  if (M <= 0) return;
+  hipLaunchKernelGGL(k_neighbor_grad, dim3(cdiv(M, 256)), dim3(256), 0, s, nb, deltas, dist, g_delta, g_dist, M, N, out);
+}
+
 // =====================================================================================
 //                         radial basis + cutoff (one thread per (pair, k))
 // =====================================================================================

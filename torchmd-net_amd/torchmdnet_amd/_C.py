@@ -72,6 +72,7 @@ def lib():
     L.tmdnet_energy_forces.argtypes = [vp, vp, vp, vp, sz, i64, i64, i64, vp, vp, vp, i32, vp, vp]
     L.tmdnet_neighbor_workspace_bytes.argtypes = [i64, i64, i64, C.POINTER(sz)]
     L.tmdnet_neighbor_pairs.argtypes = [vp, vp, sz, i64, i64, vp, vp, vp, i32, f32, f32, i64, i32, i32, i32, vp, vp, vp, vp]
+    L.tmdnet_neighbor_grad.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, vp]
     L.tmdnet_profile_begin.argtypes = [vp, C.c_uint32]
     L.tmdnet_profile_end.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     L.tmdnet_profile_end_records.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double),

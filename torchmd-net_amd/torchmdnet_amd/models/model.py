@@ -25,7 +25,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 from torch import Tensor, nn
 
-from torchmdnet_amd import _C, priors
+from torchmdnet_amd import _C, ops, priors
 from torchmdnet_amd.models import output_modules
 from torchmdnet_amd.models.utils import _ptr, _require_cuda, _stream_ptr, dtype_mapping
 
@@ -237,6 +237,7 @@ class _EngineState:
         self.graph_ws = None
         self.fwd_ws = None
         self.counts = None
+        self.op_key = None   # key of the owning module in torchmdnet_amd.ops' registry (custom-op calls carry it)
         self.generation = 0  # bumped whenever the handle or a workspace is re-created: captured graphs of older generations are stale
 
     def release(self):
@@ -258,22 +259,6 @@ class _EngineState:
 
     def __setstate__(self, state):
         self.__init__()
-
-
-class _AttachPosGrad(torch.autograd.Function):
-    """Makes the energy differentiable wrt ``pos`` when ``derivative=False`` (ASE calculator and OpenMM
-    wrapper call ``energy.backward()``, reference calculators.py:311-316).  Molecules are independent,
-    so d(sum_m g_m E_m)/d pos_i = g_{batch_i} * dE/dpos_i = -g_{batch_i} * F_i."""
-
-    @staticmethod
-    def forward(ctx, pos, y, forces, batch):
-        ctx.save_for_backward(forces, batch)
-        return y.clone()
-
-    @staticmethod
-    def backward(ctx, grad_y):
-        forces, batch = ctx.saved_tensors
-        return -forces * grad_y.reshape(-1)[batch].unsqueeze(-1), None, None, None
 
 
 class TorchMD_Net(nn.Module):
@@ -598,13 +583,17 @@ class TorchMD_Net(nn.Module):
         rm = self.representation_model
         if box is None and rm.distance.use_periodic:
             box = rm.distance.box
-        want_forces = self.derivative or (pos.requires_grad and torch.is_grad_enabled())
-        energy, forces = self.energy_and_forces(z, pos, batch, box, q, n_mol, want_forces=want_forces)
+        want_forces = bool(self.derivative or (pos.requires_grad and torch.is_grad_enabled()))
+        _require_cuda(pos, "TorchMD_Net.forward")
+        if self._engine.op_key is None:
+            self._engine.op_key = ops.register_engine(self)
+        # one registered torch op (fake + autograd registered, torchmdnet_amd/ops.py): torch.compile / torch.export trace
+        # through it, and `energy.backward()` (ASE calculator, OpenMM wrapper: reference calculators.py:311-316) gets
+        # d(sum_m g_m E_m)/d pos_i = -g_{batch_i} F_i from its registered backward
+        energy, forces = torch.ops.tmdnet.energy_forces(z, pos, batch, box, q, self._engine.op_key, n_mol, want_forces)
         y = energy.view(-1, 1)
         if self.derivative:
-            return y, forces
-        if want_forces:
-            y = _AttachPosGrad.apply(pos, y, forces, batch.to(torch.long))
+            return y, forces.detach()
         # an empty tensor keeps the reference's "always two tensors" contract (model.py:629-631)
         return y, torch.empty(0, device=y.device)
 

@@ -124,7 +124,6 @@ class OptimizedDistance(nn.Module):
         if box is None:
             box = torch.zeros((3, 3), device="cpu")
         self.register_buffer("box", box, persistent=True)
-        self._ws = None
 
     def forward(self, pos: Tensor, batch: Optional[Tensor] = None, box: Optional[Tensor] = None
                 ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
@@ -141,29 +140,17 @@ class OptimizedDistance(nn.Module):
             batch = torch.zeros(n, dtype=torch.long, device=pos.device)
         batch = batch.to(torch.long).contiguous()
         n_mol = int(batch.max().item()) + 1 if n > 0 else 0
-        box_mode = 0 if not use_periodic else (1 if box.dim() == 2 else 2)
-        L = _C.lib()
-        nbytes = C.c_size_t(0)
-        L.tmdnet_neighbor_workspace_bytes(n, n_mol, max_pairs, C.byref(nbytes))
-        if self._ws is None or self._ws.numel() < nbytes.value or self._ws.device != pos.device:
-            self._ws = torch.empty(nbytes.value, dtype=torch.uint8, device=pos.device)
-        neighbors = torch.empty((2, max_pairs), dtype=torch.long, device=pos.device)
-        deltas = torch.empty((max_pairs, 3), dtype=pos.dtype, device=pos.device)
-        dist = torch.empty((max_pairs,), dtype=pos.dtype, device=pos.device)
-        num_pairs = torch.zeros(1, dtype=torch.int32, device=pos.device)
-        p = pos.detach().contiguous()
-        rc = L.tmdnet_neighbor_pairs(_stream_ptr(pos.device), _ptr(self._ws), self._ws.numel(), n, n_mol, _ptr(p),
-                                     _ptr(batch), _ptr(box if use_periodic else None), box_mode, float(self.cutoff_lower),
-                                     float(self.cutoff_upper), max_pairs, int(self.loop), int(self.include_transpose),
-                                     1 if self.strategy == "cell" else 0, _ptr(neighbors), _ptr(deltas), _ptr(dist),
-                                     _ptr(num_pairs))
-        if rc != _C.OK:
-            raise RuntimeError(f"tmdnet_neighbor_pairs failed with code {rc}")
-        if int(num_pairs.item()) > max_pairs:  # reference: torch._assert_async -> RuntimeError (models/utils.py:297-300)
+        # registered torch op (torchmdnet_amd/ops.py: fake impl + autograd = the reference's neighbor_grad_positions as a HIP
+        # kernel), same outputs as torch.ops.torchmdnet.warp_neighbor_{brute,cell}_fwd (warp_ops/neighbors.py:34-148)
+        from torchmdnet_amd import ops  # noqa: F401  (registers torch.ops.tmdnet.*)
+
+        neighbors, deltas, dist, num_pairs = torch.ops.tmdnet.neighbor_pairs(
+            pos, batch, box if use_periodic else None, float(self.cutoff_lower), float(self.cutoff_upper), int(max_pairs),
+            bool(self.loop), bool(self.include_transpose), 1 if self.strategy == "cell" else 0, n_mol)
+        if not torch.compiler.is_compiling() and int(num_pairs.item()) > max_pairs:
+            # reference: torch._assert_async -> RuntimeError (models/utils.py:297-300)
             raise RuntimeError("Found num_pairs > max_num_pairs, please increase max_num_pairs")
         edge_index, edge_vec, edge_weight = neighbors, deltas, dist
-        if pos.requires_grad:
-            edge_vec, edge_weight = _NeighborGrad.apply(pos, neighbors, deltas, dist)
         if self.resize_to_fit:
             mask = edge_index[0] != -1
             edge_index = edge_index[:, mask]
@@ -172,27 +159,3 @@ class OptimizedDistance(nn.Module):
         if not self.long_edge_index:
             edge_index = edge_index.to(torch.int32)
         return (edge_index, edge_weight, edge_vec) if self.return_vecs else (edge_index, edge_weight, None)
-
-
-class _NeighborGrad(torch.autograd.Function):
-    """Gradient of (deltas, distances) wrt positions, as extensions/neighbor_utils.py:11-46 defines it
-    (zero for d = 0).  Plain torch index_add on the GPU: this is glue for standalone use of
-    OptimizedDistance, the model's own force path never goes through it."""
-
-    @staticmethod
-    def forward(ctx, pos, neighbors, deltas, dist):
-        ctx.save_for_backward(neighbors, deltas, dist)
-        ctx.n = pos.shape[0]
-        return deltas.clone(), dist.clone()
-
-    @staticmethod
-    def backward(ctx, g_delta, g_dist):
-        neighbors, deltas, dist = ctx.saved_tensors
-        zero = dist.eq(0) | neighbors[0].eq(-1)
-        safe = dist.masked_fill(zero, 1)
-        g = g_delta.masked_fill(zero[:, None], 0) + (deltas / safe[:, None]) * g_dist.masked_fill(zero, 0)[:, None]
-        idx = neighbors.masked_fill(zero[None, :].expand_as(neighbors), 0)
-        out = torch.zeros((ctx.n, 3), dtype=deltas.dtype, device=deltas.device)
-        out.index_add_(0, idx[0], g)
-        out.index_add_(0, idx[1], -g)
-        return out, None, None, None
