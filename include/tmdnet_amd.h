@@ -92,6 +92,19 @@ int tmdnet_finalize_params(tmdnet_model* m);
 int tmdnet_num_params(const tmdnet_model* m);
 const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel);
 
+/* ---- radial tables of the per-pair functions --------------------------------------------------------------------
+ * Q_c(d) = P_c phi(d) + b_c and every layer's edge MLP w^l(d) (reference tensornet.py:558-560, 738-743) depend on the pair
+ * distance only.  tmdnet_finalize_params evaluates them and their d/dd once on a uniform grid in double precision,
+ * stores fp32 rows, and verifies the step's cubic Hermite interpolation against the fp64 evaluation at every interval
+ * midpoint (bounds: 5e-7 of the table's largest value, 2e-6 of its largest slope; the grid is refined 8192 -> 65536
+ * intervals until they hold, else the tables stay off) and tmdnet_energy_forces then interpolates per pair instead of running the pair-row
+ * GEMMs, when the system has at least `edge_table_min_pairs` pairs (default 8192).  TMDNET_EDGE_TABLE=0 in the
+ * environment disables the tables (direct GEMMs every step).
+ * Options: "edge_table_min_pairs".  Info: "edge_table_T" (0 = off), "edge_table_err_value", "edge_table_err_slope"
+ * (measured at the midpoints), "edge_table_min_pairs". */
+int tmdnet_set_option(tmdnet_model* m, const char* name, double value);
+int tmdnet_get_info(const tmdnet_model* m, const char* name, double* value);
+
 /* ---- phase A: neighbour graph ------------------------------------------------------------------
  * Replaces OptimizedDistance.forward + get_neighbor_pairs_kernel + graph_transform
  * (torchmdnet/models/utils.py:233-313, extensions/ops.py:14, warp_ops/graph_transform.py:160-179).

@@ -482,3 +482,66 @@ def test_custom_ops_opcheck_compile_export(hip_lib, golden_dir):
     assert "tmdnet.energy_forces" in str(ep.graph)
     ye, _ = ep.module()(z, pos, batch, num_systems=n_mol)
     assert torch.equal(ye, y0)
+
+
+# ------------------------------------------------------------------ (j) radial tables of the per-pair functions
+def test_edge_tables_equal_direct_evaluation(hip_lib, golden_dir):
+    """Q(d) and every layer's edge MLP w(d) are functions of the distance alone: tabulated at parameter upload (verified
+    there against the direct evaluation at all interval midpoints) and Hermite-interpolated per pair.  The table path must
+    reproduce the direct pair-row GEMMs to fp32 rounding, on fixtures of the unmodified reference, with a lower cutoff,
+    with total charges, under static shapes + graph replay, and at the full C2 size."""
+    from oracle import tensornet_torch as T
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    model = create_model(dict(g["args"]))
+    model.load_state_dict(g["state_dict"])
+    model = model.to("cuda")
+    z, pos, batch, q = g["z"].cuda(), g["pos"].cuda(), g["batch"].cuda(), g["q"].cuda()
+    assert model.engine_info("edge_table_T") >= 8192  # built and verified at upload
+    assert model.engine_info("edge_table_err_value") < 1e-6 and model.engine_info("edge_table_err_slope") < 2e-5
+    Ed, Fd = model(z, pos, batch, q=q)  # 2 molecules: far below edge_table_min_pairs -> direct GEMMs
+    model.set_engine_option("edge_table_min_pairs", 0)
+    Et, Ft = model(z, pos, batch, q=q)
+    assert rel_err(Et, Ed) < 2e-6 and rel_err(Ft, Fd) < 2e-6
+    assert rel_err(Et.cpu(), g["E"]) < REL and rel_err(Ft.cpu(), g["F"]) < REL
+    assert rel_err(Et.cpu().double(), g["E64"]) < REL and rel_err(Ft.cpu().double(), g["F64"]) < REL
+    # energies only (no tangents are written)
+    model.derivative = False
+    with torch.no_grad():
+        y, _ = model(z, pos, batch, q=q)
+    assert rel_err(y.view(-1), Ed.view(-1)) < 2e-6
+    model.derivative = True
+    # lower cutoff (the self pair sits below the grid: it has its own exact row), sharper basis (K = 64)
+    for extra in (dict(cutoff_lower=1.2, cutoff_upper=4.5), dict(num_rbf=64)):
+        args = dict(W.TINY_ARGS, **extra)
+        torch.manual_seed(8)
+        m2 = create_model(dict(args)).to("cuda")
+        z2, p2, b2 = _ragged([18, 30, 4, 11], seed=90)
+        E0, F0 = m2(z2.cuda(), p2.cuda(), b2.cuda())
+        m2.set_engine_option("edge_table_min_pairs", 0)
+        assert m2.engine_info("edge_table_T") >= 8192
+        E1, F1 = m2(z2.cuda(), p2.cuda(), b2.cuda())
+        assert rel_err(E1, E0) < 2e-6 and rel_err(F1, F0) < 2e-6, extra
+        sd = {k: v.detach().cpu() for k, v in m2.state_dict().items()}
+        Er, Fr = T.energy_and_forces(sd, T.hparams_from_args(args), z2, p2, b2)
+        assert rel_err(E1.cpu(), Er) < REL and rel_err(F1.cpu(), Fr) < REL, extra
+    # static shapes: the sort runs over the pair capacity, replayed from a HIP graph
+    sta = create_model(dict(g["args"], static_shapes=True))
+    sta.load_state_dict(g["state_dict"])
+    sta = sta.to("cuda")
+    sta.set_engine_option("edge_table_min_pairs", 0)
+    replay = sta.capture(z, pos, batch, q=q)
+    for step in range(3):
+        new = pos + 0.04 * step * torch.randn(pos.shape, generator=torch.Generator().manual_seed(step)).cuda()
+        Es, Fs = replay(new)
+        Er, Fr = model(z, new.clone(), batch, q=q)
+        assert rel_err(Es, Er) < 2e-6 and rel_err(Fs, Fr) < 2e-6, step
+    # full C2 batch: tables (default at this size) vs direct GEMMs
+    torch.manual_seed(0)
+    big = create_model(dict(W.C2_ARGS)).to("cuda")
+    zb, pb, bb = (t.cuda() for t in W.synthetic_batch(n_mol=256))
+    Et, Ft = big(zb, pb, bb)
+    big.set_engine_option("edge_table_min_pairs", 10 ** 12)
+    Ed, Fd = big(zb, pb, bb)
+    assert rel_err(Et, Ed) < 2e-6 and rel_err(Ft, Fd) < 2e-6

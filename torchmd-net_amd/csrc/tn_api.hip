@@ -7,7 +7,9 @@
 // reverse pass that replaces torch.autograd.grad (model.py:618-628).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <unordered_map>
@@ -18,7 +20,7 @@
 
 using namespace tn;
 
-static const char* kCatNames[CAT_COUNT] = {"graph", "gemm_edge", "gemm_node", "message", "pair_bwd", "embed_scatter", "elementwise"};
+static const char* kCatNames[CAT_COUNT] = {"graph", "gemm_edge", "gemm_node", "message", "pair_bwd", "embed_scatter", "elementwise", "edge_table"};
 
 int fail(tmdnet_model* m, int code, const std::string& msg) {
   if (m) m->err = msg;
@@ -277,6 +279,12 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
   b.ao = c.take<float>(N * H);
   b.ea = c.take<float>(N);
   b.kap = c.take<float>(N);
+  b.skeys = c.take<unsigned>(P1);
+  b.skeys_s = c.take<unsigned>(P1);
+  b.svals = c.take<int>(P1);
+  b.svals_s = c.take<int>(P1);
+  b.sort_tmp_bytes = edge_sort_temp_bytes(P1);
+  b.sort_tmp = c.take<char>((int64_t)b.sort_tmp_bytes);
   if (bwd) {
     b.g_ao = c.take<float>(N * H);
     b.g_al = c.take<float>(N * F);
@@ -289,7 +297,7 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
     b.gPn = c.take<float>(N9);
     b.gXl = c.take<float>(N9);
     b.gd = c.take<float>(P1);
-    b.gd_slots = c.take<float>(2 * P1 * (int64_t)L * ((F + 63) / 64));  // [layer][wave][pair][direction] partial g_d
+    b.gd_slots = c.take<float>(2 * P1 * (int64_t)L * ((F + 31) / 32));  // [layer][wave or channel chunk][pair][direction] partial g_d
     b.gUX = c.take<float>(N9);
     b.g_a2 = c.take<float>(N * 3 * F);
     b.g_a1 = c.take<float>(N * 2 * F);
@@ -302,6 +310,118 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
   }
   if (total) *total = c.off;
   return b;
+}
+
+void free_edge_tables(tmdnet_model* m) {
+  for (float* t : m->tabs.tab)
+    if (t) (void)hipFree(t);
+  m->tabs = EdgeTables{};
+}
+
+// Radial tables (tn_edge_table.hip): evaluate Q(d) and every layer's w(d) with their d/dd on a uniform grid in fp64, pack
+// them as fp32 rows (value | slope | divided difference), then verify the step's fp32 interpolation against the fp64
+// evaluation at all interval midpoints; refine the grid until the measured error is below the bound, or leave the tables off.
+int build_edge_tables(tmdnet_model* m) {
+  free_edge_tables(m);
+  const char* env = getenv("TMDNET_EDGE_TABLE");
+  if (env && atoi(env) == 0) return TMDNET_OK;  // developer / benchmark switch: direct GEMMs every step
+  const tmdnet_hparams& hp = m->hp;
+  const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, R = 3 * F;
+  if (F % 4 || L + 1 > 8 || 3 * F / 4 > 256) return TMDNET_OK;  // what the interpolation kernel's thread layout covers
+  const DevParams& W = m->P;
+  const double lo = hp.cutoff_lower, up = hp.cutoff_upper;
+  const double tol_value = 5e-7, tol_slope = 2e-6;  // relative to the table's largest |value| / |slope|
+  hipStream_t s = nullptr;
+  for (int T = 8192; T <= 65536; T *= 2) {
+    const int M = T + 2;
+    std::vector<void*> tmp;
+    bool alloc_ok = true;
+    auto D_ = [&](int64_t n) {
+      double* p = nullptr;
+      alloc_ok = (hipMalloc(reinterpret_cast<void**>(&p), (size_t)n * sizeof(double)) == hipSuccess) && alloc_ok;
+      tmp.push_back(p);
+      return p;
+    };
+    auto F_ = [&](int64_t n) {
+      float* p = nullptr;
+      alloc_ok = (hipMalloc(reinterpret_cast<void**>(&p), (size_t)n * sizeof(float)) == hipSuccess) && alloc_ok;
+      tmp.push_back(p);
+      return p;
+    };
+    double *dist = D_(M), *phi = D_((int64_t)M * K), *dphi = D_((int64_t)M * K), *C = D_(M), *dC = D_(M);
+    double *he1 = D_((int64_t)M * F), *te1 = D_((int64_t)M * F), *he2 = D_((int64_t)M * 2 * F), *te2 = D_((int64_t)M * 2 * F);
+    double *fv = D_((int64_t)M * R), *fs = D_((int64_t)M * R);
+    float *ip = F_((int64_t)T * R), *dip = F_((int64_t)T * R);
+    std::vector<float*> tab(1 + L, nullptr);
+    for (auto& t : tab) alloc_ok = (hipMalloc(reinterpret_cast<void**>(&t), (size_t)M * 3 * R * sizeof(float)) == hipSuccess) && alloc_ok;
+    auto cleanup = [&](bool keep_tabs) {
+      for (void* p : tmp)
+        if (p) (void)hipFree(p);
+      if (!keep_tabs)
+        for (float* t : tab)
+          if (t) (void)hipFree(t);
+    };
+    if (!alloc_ok) {
+      cleanup(false);
+      return TMDNET_OK;  // no memory for tables: the direct path stays
+    }
+    // function t at the distances currently described by (rows, mid): value -> fv, slope -> fs   (fp64)
+    auto evaluate = [&](int t, int rows, bool mid) {
+      launch_radial_f64(rows, lo, up, T, mid, W.means, W.betas, K, dist, phi, dphi, C, dC, s);
+      if (t == 0) {
+        launch_dense_f64(phi, dphi, K, W.Wdp, W.bdp, rows, R, K, 0, nullptr, nullptr, fv, fs, R, s);
+      } else {
+        const LayerP& q_ = W.layer[t - 1];
+        launch_dense_f64(phi, dphi, K, q_.M1, q_.b1, rows, F, K, 1, nullptr, nullptr, he1, te1, F, s);
+        launch_dense_f64(he1, te1, F, q_.M2, q_.b2, rows, 2 * F, F, 1, nullptr, nullptr, he2, te2, 2 * F, s);
+        launch_dense_f64(he2, te2, 2 * F, q_.M3, q_.b3, rows, R, 2 * F, 2, C, dC, fv, fs, R, s);
+      }
+    };
+    double worst_v = 0.0, worst_s = 0.0;
+    std::vector<double> hv((size_t)T * R), hs((size_t)T * R);
+    std::vector<float> hip_((size_t)T * R), hdip((size_t)T * R);
+    bool fail = false;
+    for (int t = 0; t <= L && !fail; ++t) {
+      evaluate(t, M, false);
+      launch_table_pack(fv, fs, T, R, (up - lo) / (double)T, tab[t], s);
+      evaluate(t, T, true);  // fp64 truth at the interval midpoints
+      launch_interp_list(tab[t], dist, T, R, T, (float)lo, (float)up, ip, dip, s);
+      if (hipMemcpy(hv.data(), fv, hv.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(hs.data(), fs, hs.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(hip_.data(), ip, hip_.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(hdip.data(), dip, hdip.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        fail = true;
+        break;
+      }
+      double mv = 0.0, ms = 0.0, ev = 0.0, es = 0.0;
+      for (size_t i = 0; i < hv.size(); ++i) {
+        mv = std::max(mv, std::fabs(hv[i]));
+        ms = std::max(ms, std::fabs(hs[i]));
+        ev = std::max(ev, std::fabs(hv[i] - (double)hip_[i]));
+        es = std::max(es, std::fabs(hs[i] - (double)hdip[i]));
+      }
+      if (!(mv > 0.0) || !std::isfinite(ev) || !std::isfinite(es)) {
+        fail = true;
+        break;
+      }
+      worst_v = std::max(worst_v, ev / mv);
+      worst_s = std::max(worst_s, ms > 0.0 ? es / ms : 0.0);
+    }
+    const bool good = !fail && worst_v <= tol_value && worst_s <= tol_slope;
+    m->tabs.err_value = worst_v;  // of the last grid tried (reported also when the tables stay off)
+    m->tabs.err_slope = worst_s;
+    if (getenv("TMDNET_DEBUG"))
+      fprintf(stderr, "[tmdnet] radial tables T=%d: value err %.3e, slope err %.3e, fail=%d\n", T, worst_v, worst_s, (int)fail);
+    cleanup(good);
+    if (good) {
+      m->tabs.ok = true;
+      m->tabs.T = T;
+      m->tabs.tab = tab;
+      return TMDNET_OK;
+    }
+    if (fail) return TMDNET_OK;
+  }
+  return TMDNET_OK;  // bound not met even on the finest grid: direct GEMMs
 }
 
 }  // namespace
@@ -363,6 +483,7 @@ int tmdnet_destroy(tmdnet_model* m) {
     for (auto& e : m->ev_join) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(m->side);
   }
+  free_edge_tables(m);
   if (m->dev) (void)hipFree(m->dev);
   if (m->dev_sb) (void)hipFree(m->dev_sb);
   delete m;
@@ -580,7 +701,31 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   P.Vtab = m->dev + off.at("Vtab");
   launch_ztables(P.emb, P.emb2_waT, P.emb2_wbT, P.emb2_b, m->hp.max_z, F, m->dev + off.at("Utab"), m->dev + off.at("Vtab"), nullptr);
   HIP_TRY(m, hipStreamSynchronize(nullptr));
+  const int rc_tab = build_edge_tables(m);
+  if (rc_tab != TMDNET_OK) return rc_tab;
+  HIP_TRY(m, hipStreamSynchronize(nullptr));
   m->finalized = true;
+  return TMDNET_OK;
+}
+
+int tmdnet_set_option(tmdnet_model* m, const char* name, double value) {
+  if (!m || !name) return TMDNET_ERR_INVALID;
+  const std::string n(name);
+  if (n == "edge_table_min_pairs") {
+    m->tab_min_pairs = value < 0 ? 0 : (int64_t)value;
+    return TMDNET_OK;
+  }
+  return fail(m, TMDNET_ERR_INVALID, "unknown option: " + n);
+}
+
+int tmdnet_get_info(const tmdnet_model* m, const char* name, double* value) {
+  if (!m || !name || !value) return TMDNET_ERR_INVALID;
+  const std::string n(name);
+  if (n == "edge_table_T") *value = m->tabs.ok ? m->tabs.T : 0;
+  else if (n == "edge_table_err_value") *value = m->tabs.err_value;
+  else if (n == "edge_table_err_slope") *value = m->tabs.err_slope;
+  else if (n == "edge_table_min_pairs") *value = (double)m->tab_min_pairs;
+  else return TMDNET_ERR_INVALID;
   return TMDNET_OK;
 }
 
@@ -790,38 +935,61 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   auto EDGE = [&](int add) { g_gemm_cat = CAT_GEMM_EDGE; g_mdev = g.counts; g_madd = add; };
   auto NODE = [&]() { g_gemm_cat = CAT_GEMM_NODE; g_mdev = nullptr; g_madd = 0; };
 
-  // ---- radial functions per pair
-  RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
-  KR(CAT_ELEMENTWISE, Pd * (2 * K + 3) * 4, launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s));
-  // ---- edge MLPs of all layers: functions of the pair geometry only -> side stream (tn_model.h)
-  // only at batch scale: for a small system the cross-queue joins cost more than the overlap gives (graph replay of a
-  // 64-atom molecule 0.36 -> 0.40 ms, profiles/r01_notes.md)
-  hipStream_t es = (m->side && L > 0 && P >= 16384) ? m->side : s;
-  if (es != s) {
-    HIP_TRY(m, hipEventRecord(m->ev_fork, s));
-    HIP_TRY(m, hipStreamWaitEvent(es, m->ev_fork, 0));
-  }
-  for (int l = 0; l < L; ++l) {
-    const LayerP& q_ = W.layer[l];
-    EDGE(1);
-    if (want_forces) {
-      // edge MLP with its distance tangent carried forward (dw/dd): the reverse pass then needs no edge GEMM
-      gemm_dual(es, 1, b.phi, b.dphi, K, q_.M1, q_.b1, b.he1, b.te1, F, P1, F, K, nullptr, nullptr, q_.M_sb[0]);
-      gemm_dual(es, 1, b.he1, b.te1, F, q_.M2, q_.b2, b.he2, b.te2, 2 * F, P1, 2 * F, F, nullptr, nullptr, q_.M_sb[1]);
-      gemm_dual(es, 2, b.he2, b.te2, 2 * F, q_.M3, q_.b3, b.w[l], b.dw[l], 3 * F, P1, 3 * F, 2 * F, b.C, b.dC, q_.M_sb[2]);
-    } else {
-      gemm(es, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU);
-      gemm(es, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU);
-      gemm(es, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, nullptr, 0, nullptr, 0,
-           b.C);
+  // ---- per-pair functions of the distance: Q (embedding) and every layer's w, with their d/dd when forces are wanted
+  const bool use_tab = m->tabs.ok && (int64_t)P1 >= m->tab_min_pairs && (int)m->tabs.tab.size() == 1 + L && L + 1 <= 8;
+  hipStream_t es = s;
+  if (use_tab) {
+    // radial tables (tn_edge_table.hip): sort the pairs by distance, one streaming Hermite-interpolation kernel for all
+    // tables; no basis functions, no pair-row GEMMs in the step
+    const float* tabs[8];
+    float* outs[8];
+    float* douts[8];
+    tabs[0] = m->tabs.tab[0];
+    outs[0] = b.Q;
+    douts[0] = want_forces ? b.dQ : nullptr;
+    for (int l = 0; l < L; ++l) {
+      tabs[1 + l] = m->tabs.tab[1 + l];
+      outs[1 + l] = b.w[l];
+      douts[1 + l] = want_forces ? b.dw[l] : nullptr;
     }
-    if (es != s) HIP_TRY(m, hipEventRecord(m->ev_join[l], es));
+    const double rowB = 12.0 * Fd;
+    KR(CAT_EDGE_TABLE, (Pd + 1) * (rowB * (L + 1) * (want_forces ? 2 : 1) + 24) + (double)(m->tabs.T + 2) * 2 * rowB * (L + 1),
+       launch_edge_tables(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1 + L, tabs, outs, douts, b.C, b.dC, b.skeys,
+                          b.svals, b.skeys_s, b.svals_s, b.sort_tmp, b.sort_tmp_bytes, s));
+  } else {
+    // ---- radial functions per pair
+    RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
+    KR(CAT_ELEMENTWISE, Pd * (2 * K + 3) * 4, launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s));
+    // ---- edge MLPs of all layers: functions of the pair geometry only -> side stream (tn_model.h)
+    // only at batch scale: for a small system the cross-queue joins cost more than the overlap gives (graph replay of a
+    // 64-atom molecule 0.36 -> 0.40 ms, profiles/r01_notes.md)
+    es = (m->side && L > 0 && P >= 16384) ? m->side : s;
+    if (es != s) {
+      HIP_TRY(m, hipEventRecord(m->ev_fork, s));
+      HIP_TRY(m, hipStreamWaitEvent(es, m->ev_fork, 0));
+    }
+    for (int l = 0; l < L; ++l) {
+      const LayerP& q_ = W.layer[l];
+      EDGE(1);
+      if (want_forces) {
+        // edge MLP with its distance tangent carried forward (dw/dd): the reverse pass then needs no edge GEMM
+        gemm_dual(es, 1, b.phi, b.dphi, K, q_.M1, q_.b1, b.he1, b.te1, F, P1, F, K, nullptr, nullptr, q_.M_sb[0]);
+        gemm_dual(es, 1, b.he1, b.te1, F, q_.M2, q_.b2, b.he2, b.te2, 2 * F, P1, 2 * F, F, nullptr, nullptr, q_.M_sb[1]);
+        gemm_dual(es, 2, b.he2, b.te2, 2 * F, q_.M3, q_.b3, b.w[l], b.dw[l], 3 * F, P1, 3 * F, 2 * F, b.C, b.dC, q_.M_sb[2]);
+      } else {
+        gemm(es, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU);
+        gemm(es, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU);
+        gemm(es, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, nullptr, 0, nullptr, 0,
+             b.C);
+      }
+      if (es != s) HIP_TRY(m, hipEventRecord(m->ev_join[l], es));
+    }
+    // ---- embedding
+    // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
+    EDGE(1);
+    if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);  // distance projections + d/dd
+    else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
   }
-  // ---- embedding
-  // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
-  EDGE(1);
-  if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);  // distance projections + d/dd
-  else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
   KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
      launch_embed_scatter(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.u0, b.s0n, s));
   KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s));
@@ -870,7 +1038,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
     launch_fill(b.gd, 0.f, P1, s);
     const bool merged_gd = message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD");
-    const int gd_nw = message_adjoint_gd_waves(F);
+    const int gd_nw = message_adjoint_gd_waves(N, F);
     const int64_t gd_stride = 2 * (int64_t)P1;
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];

@@ -1,0 +1,328 @@
+// Radial tables of the per-pair functions of TensorNet (gfx950).
+//
+// Every per-pair quantity of the model is a function of the pair DISTANCE alone:
+//     Q_c(d)   = P_c phi(d) + b_c                      (distance projections of the embedding, reference tensornet.py:558-560)
+//     w^l(d)   = silu(M3 silu(M2 silu(M1 phi(d)))) C(d)  (edge MLP of interaction layer l, reference tensornet.py:738-743)
+// (phi = ExpNormal basis, C = cosine cutoff; the atom types enter later, in the scatter).  They are smooth maps
+// [r_lo, r_c) -> R^{3F}, so instead of pushing P ~ 2e5 pair rows through K -> F -> 2F -> 3F GEMMs every step
+// (83 % of the model's FLOPs), the functions and their d/dd are evaluated ONCE, when the parameters are
+// uploaded, on a uniform grid of T + 1 distances - in DOUBLE precision (plain fp64 kernels below; it happens once) - and
+// each step evaluates the cubic Hermite interpolant (value AND slope are tabulated: the interpolant is C1) per pair,
+// written in the divided-difference form that has no cancellation,  D_k = (f_{k+1} - f_k) / h  (formed in fp64):
+//     f(d)  ~ f_k + h [ D_k (3t^2 - 2t^3) + s_k (t^3 - 2t^2 + t) + s_{k+1} (t^3 - t^2) ],      d = r_lo + (k + t) h
+//     f'(d) ~ D_k (6t - 6t^2) + s_k (3t^2 - 4t + 1) + s_{k+1} (3t^2 - 2t)                     (s = tabulated slope)
+// (the second line is the exact derivative of the first: energies and forces stay consistent).  The truncation error is
+// of fourth order in h: ~1e-9 relative at h = (r_c - r_lo) / 8192; what remains is the fp32 rounding of the stored
+// entries, i.e. the tables are CLOSER to the exact functions than the direct fp32 GEMM chain (accumulated rounding
+// ~4e-7).  The build VERIFIES it: every table is compared with the fp64 evaluation at all interval midpoints, value and
+// slope, and the grid is refined or the tables are left off if the bounds are not met.  Weights-only precomputation,
+// like the per-type tables U[z], V[z] (k_ztables) and the split-bf16 weight images: valid for any input, rebuilt with
+// the weights.
+//
+// Per step: pair ids are sorted by distance (rocPRIM radix sort on the upper 20 bits of the fp32 distance), so that
+// consecutive pairs read neighbouring table rows (38 MB per table: the gathers hit L2), and one streaming kernel writes
+// Q, dQ/dd, w^l, dw^l/dd for all tables.  It is bound by those writes (HBM).  The self pair (d = 0, below r_lo when a
+// lower cutoff is set) has its own exactly evaluated row.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "tn_common.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+static inline int cdive(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- build (fp64) ------------------------------------------------------------------------------------------------
+// rows 0..T: d_k = lo + k h ; row T + 1: the self pair (d = 0) ; mid = 1: the T interval midpoints
+__device__ __forceinline__ double grid_d(int k, double lo, double h, int T, int mid) {
+  if (mid) return lo + ((double)k + 0.5) * h;
+  return k <= T ? lo + (double)k * h : 0.0;
+}
+__device__ __forceinline__ void cosine_cutoff_f64(double d, double lo, double up, double& c, double& dc) {
+  const double PI = 3.14159265358979323846;
+  if (lo > 0.0) {
+    const double k = 2.0 * PI / (up - lo), arg = PI * (2.0 * (d - lo) / (up - lo) + 1.0);
+    const bool in = (d < up) && (d > lo);
+    c = in ? 0.5 * (cos(arg) + 1.0) : 0.0;
+    dc = in ? -0.5 * sin(arg) * k : 0.0;
+  } else {
+    const double k = PI / up;
+    const bool in = d < up;
+    c = in ? 0.5 * (cos(d * k) + 1.0) : 0.0;
+    dc = in ? -0.5 * sin(d * k) * k : 0.0;
+  }
+}
+// ExpNormal basis + cutoffs (reference models/utils.py:402-407, 506-528) in double
+__global__ void k_radial_f64(int rows, double lo, double up, double h, int T, int mid, const float* __restrict__ means,
+                             const float* __restrict__ betas, int K, double* __restrict__ dist, double* __restrict__ phi,
+                             double* __restrict__ dphi, double* __restrict__ C, double* __restrict__ dC) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)rows * K) return;
+  const int p = (int)(idx / K), k = (int)(idx - (int64_t)p * K);
+  const double d = grid_d(p, lo, h, T, mid);
+  double c0, dc0;
+  cosine_cutoff_f64(d, 0.0, up, c0, dc0);
+  const double alpha = 5.0 / (up - lo);
+  const double u = exp(-alpha * (d - lo));
+  const double mu = means[k], beta = betas[k];
+  const double gk = exp(-beta * (u - mu) * (u - mu));
+  phi[idx] = c0 * gk;
+  dphi[idx] = dc0 * gk + c0 * gk * (-2.0 * beta * (u - mu)) * (-alpha * u);
+  if (k == 0) {
+    double c, dc;
+    cosine_cutoff_f64(d, lo, up, c, dc);
+    C[p] = c;
+    dC[p] = dc;
+    dist[p] = d;
+  }
+}
+// one output per thread: e = b + A W^T, r = A2 W^T ; kind 0: (e, r) ; 1: (silu e, silu' e r) ; 2: (silu e rs, silu' e r rs + silu e rs2)
+__global__ void k_dense_f64(const double* __restrict__ A, const double* __restrict__ A2, int lda, const float* __restrict__ W,
+                            const float* __restrict__ bias, int M, int N, int K, int kind, const double* __restrict__ rs,
+                            const double* __restrict__ rs2, double* __restrict__ C, double* __restrict__ C2, int ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);
+  const double* a = A + (int64_t)m * lda;
+  const double* a2 = A2 + (int64_t)m * lda;
+  const float* w = W + (int64_t)n * K;
+  double e = bias ? (double)bias[n] : 0.0, r = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double wk = w[k];
+    e += a[k] * wk;
+    r += a2[k] * wk;
+  }
+  if (kind != 0) {
+    const double sg = 1.0 / (1.0 + exp(-e));
+    const double f = e * sg, df = sg * (1.0 + e * (1.0 - sg));
+    if (kind == 1) {
+      e = f;
+      r = df * r;
+    } else {
+      e = f * rs[m];
+      r = df * r * rs[m] + f * rs2[m];
+    }
+  }
+  C[(int64_t)m * ldc + n] = e;
+  C2[(int64_t)m * ldc + n] = r;
+}
+// table rows [T + 2][3][R] (fp32): value | slope | divided difference to the next grid point (formed in fp64)
+__global__ void k_table_pack(const double* __restrict__ f, const double* __restrict__ sl, int T, int R, double h, float* __restrict__ tab) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)(T + 2) * R) return;
+  const int k = (int)(idx / R), c = (int)(idx - (int64_t)k * R);
+  const double v = f[idx];
+  float* row = tab + (int64_t)k * 3 * R + c;
+  row[0] = (float)v;
+  row[R] = (float)sl[idx];
+  // true divided difference (fp64), rounded once: the interpolant's slope is then accurate to fp32 rounding, and its value
+  // is continuous across grid points to one ulp of the stored values
+  row[2 * R] = k < T ? (float)((f[idx + R] - v) / h) : 0.f;
+}
+void launch_radial_f64(int rows, double lo, double up, int T, bool mid, const float* means, const float* betas, int K, double* dist,
+                       double* phi, double* dphi, double* C, double* dC, hipStream_t s) {
+  hipLaunchKernelGGL(k_radial_f64, dim3(cdive((int64_t)rows * K, 256)), dim3(256), 0, s, rows, lo, up, (up - lo) / (double)T, T,
+                     mid ? 1 : 0, means, betas, K, dist, phi, dphi, C, dC);
+}
+void launch_dense_f64(const double* A, const double* A2, int lda, const float* W, const float* bias, int M, int N, int K, int kind,
+                      const double* rs, const double* rs2, double* C, double* C2, int ldc, hipStream_t s) {
+  hipLaunchKernelGGL(k_dense_f64, dim3(cdive((int64_t)M * N, 256)), dim3(256), 0, s, A, A2, lda, W, bias, M, N, K, kind, rs, rs2, C, C2,
+                     ldc);
+}
+void launch_table_pack(const double* f, const double* sl, int T, int R, double h, float* tab, hipStream_t s) {
+  hipLaunchKernelGGL(k_table_pack, dim3(cdive((int64_t)(T + 2) * R, 256)), dim3(256), 0, s, f, sl, T, R, h, tab);
+}
+
+// ---- per step ---------------------------------------------------------------------------------------------------
+// cutoff function per pair (the only radial quantity the rest of the step still needs) + sort keys
+__global__ void k_pair_cutoff_keys(Graph g, int Pcap, float lo, float up, float* __restrict__ C, float* __restrict__ dC,
+                                   unsigned* __restrict__ keys, int* __restrict__ vals) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > Pcap) return;
+  const int P = g.counts[0];
+  if (p > P || g.counts[2]) {  // beyond the pair list (static shapes: the grid is sized by the capacity)
+    keys[p] = 0xFFFFFFFFu;
+    vals[p] = p;
+    return;
+  }
+  const float d = p < P ? g.pd[p] : 0.f;  // p == P: the self pair
+  float c, dc;
+  cosine_cutoff(d, lo, up, c, dc);
+  C[p] = c;
+  dC[p] = dc;
+  keys[p] = __float_as_uint(d);
+  vals[p] = p;
+}
+
+size_t edge_sort_temp_bytes(int64_t n) {
+  static thread_local int64_t last_n = -1;
+  static thread_local size_t last_bytes = 0;
+  if (n == last_n) return last_bytes;
+  last_n = n;
+  size_t& bytes = last_bytes;
+  bytes = 0;
+  unsigned* k = nullptr;
+  int* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 32, (hipStream_t)0);
+  return bytes;
+}
+
+struct InterpArgs {
+  const float* tab[8];  // [T + 2][3][R]: value | slope | divided difference per grid row, row T + 1 = self pair
+  float* out[8];        // [P + 1][R]
+  float* dout[8];       // [P + 1][R] or null
+  int ntab;
+};
+
+// Pairs in distance order.  A group of R4 = 3F/4 threads (one float4 column each) walks a RUN of consecutive sorted pairs:
+// consecutive pairs fall into the same or the next grid interval (2e5 pairs over 8192 intervals), so the four table
+// vectors of a column stay in registers until the interval changes - the table traffic drops from 4 rows per pair to 4
+// rows per visited interval and the kernel is left with its output writes.
+constexpr int EI_RUN = 32;  // sorted pairs per group
+template <int NT>
+__global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const unsigned* __restrict__ keys_sorted,
+                                                    const int* __restrict__ vals_sorted, InterpArgs a, int R4, int T, float lo,
+                                                    float h, float inv_h) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int groups = blockDim.x / R4;
+  const int grp = threadIdx.x / R4, c4 = threadIdx.x - grp * R4;
+  if (grp >= groups) return;
+  const int R = 4 * R4;
+  const int P = g.counts[0];
+  const int s0 = (blockIdx.x * groups + grp) * EI_RUN;
+  int kcur = -1;
+  f4 f0[NT], sl0[NT], D[NT], sl1[NT];
+  for (int s = s0; s < s0 + EI_RUN && s <= Pcap; ++s) {
+    const unsigned key = keys_sorted[s];
+    if (key == 0xFFFFFFFFu) break;  // sorted: nothing valid follows
+    const int p = vals_sorted[s];
+    if (p == P) {  // self pair: its own exact row
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float* row = a.tab[t] + (int64_t)(T + 1) * 3 * R + 4 * c4;
+        *reinterpret_cast<f4*>(a.out[t] + (int64_t)p * R + 4 * c4) = *reinterpret_cast<const f4*>(row);
+        if (a.dout[t]) *reinterpret_cast<f4*>(a.dout[t] + (int64_t)p * R + 4 * c4) = *reinterpret_cast<const f4*>(row + R);
+      }
+      continue;
+    }
+    const float d = __uint_as_float(key);  // the key holds all 32 bits of the distance
+    const float x = (d - lo) * inv_h;
+    int k = (int)x;
+    k = k < 0 ? 0 : (k > T - 1 ? T - 1 : k);
+    if (k != kcur) {
+      kcur = k;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float* row = a.tab[t] + (int64_t)k * 3 * R + 4 * c4;
+        f0[t] = *reinterpret_cast<const f4*>(row);
+        sl0[t] = *reinterpret_cast<const f4*>(row + R);
+        D[t] = *reinterpret_cast<const f4*>(row + 2 * R);
+        sl1[t] = *reinterpret_cast<const f4*>(row + 4 * R);
+      }
+    }
+    const float t = x - (float)k, t2 = t * t, t3 = t2 * t;
+    const float aD = (3.f * t2 - 2.f * t3) * h, a0 = (t3 - 2.f * t2 + t) * h, a1 = (t3 - t2) * h;  // value: f0 + aD D + a0 s0 + a1 s1
+    const float bD = 6.f * t - 6.f * t2, b0 = 3.f * t2 - 4.f * t + 1.f, b1 = 3.f * t2 - 2.f * t;   // slope: bD D + b0 s0 + b1 s1
+#pragma unroll
+    for (int tb = 0; tb < NT; ++tb) {
+      *reinterpret_cast<f4*>(a.out[tb] + (int64_t)p * R + 4 * c4) = f0[tb] + (aD * D[tb] + a0 * sl0[tb] + a1 * sl1[tb]);
+      if (a.dout[tb]) *reinterpret_cast<f4*>(a.dout[tb] + (int64_t)p * R + 4 * c4) = bD * D[tb] + b0 * sl0[tb] + b1 * sl1[tb];
+    }
+  }
+}
+
+// C, dC, and the tables' outputs for all pairs.  keys / vals / keys_s / vals_s: [Pcap + 1] each
+void launch_edge_tables(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
+                        float* const* outs, float* const* douts, float* C, float* dC, unsigned* keys, int* vals, unsigned* keys_s,
+                        int* vals_s, void* sort_tmp, size_t sort_tmp_bytes, hipStream_t s) {
+  const int n = Pcap + 1;
+  hipLaunchKernelGGL(k_pair_cutoff_keys, dim3(cdive(n, 256)), dim3(256), 0, s, g, Pcap, lo, up, C, dC, keys, vals);
+  size_t tmp = sort_tmp_bytes;
+  hipError_t serr = rocprim::radix_sort_pairs(sort_tmp, tmp, keys, keys_s, vals, vals_s, (size_t)n, 0, 32, s);
+  if (getenv("TMDNET_DEBUG")) {
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned> hk(n), hks(n);
+    std::vector<int> hv(n);
+    (void)hipMemcpy(hk.data(), keys, n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hks.data(), keys_s, n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hv.data(), vals_s, n * 4, hipMemcpyDeviceToHost);
+    int zeros_in = 0, zeros_out = 0, unsorted = 0, badval = 0, mismatch = 0;
+    for (int i = 0; i < n; ++i) {
+      zeros_in += hk[i] == 0;
+      zeros_out += hks[i] == 0;
+      if (i && (hks[i] >> 12) < (hks[i - 1] >> 12)) ++unsorted;
+      if (hv[i] < 0 || hv[i] >= n) ++badval;
+      else if (hk[hv[i]] != hks[i]) ++mismatch;
+    }
+    fprintf(stderr, "[tmdnet] sort n=%d err=%d tmp=%zu/%zu zeros in %d out %d unsorted %d badval %d mismatch %d\n", n, (int)serr, tmp,
+            sort_tmp_bytes, zeros_in, zeros_out, unsorted, badval, mismatch);
+  }
+  InterpArgs a{};
+  a.ntab = ntab;
+  for (int t = 0; t < ntab; ++t) {
+    a.tab[t] = tabs[t];
+    a.out[t] = outs[t];
+    a.dout[t] = douts[t];
+  }
+  const float h = (up - lo) / (float)T;
+  const int R4 = R / 4;
+  const int groups = R4 >= 256 ? 1 : 256 / R4;
+  const dim3 grid(cdive(n, groups * EI_RUN)), block(groups * R4);
+#define EI_LAUNCH(NT) hipLaunchKernelGGL((k_edge_interp<NT>), grid, block, 0, s, g, Pcap, keys_s, vals_s, a, R4, T, lo, h, 1.0f / h)
+  switch (ntab) {
+    case 1: EI_LAUNCH(1); break;
+    case 2: EI_LAUNCH(2); break;
+    case 3: EI_LAUNCH(3); break;
+    case 4: EI_LAUNCH(4); break;
+    default: {  // deeper models: four tables per launch
+      for (int t0 = 0; t0 < ntab; t0 += 4) {
+        InterpArgs b{};
+        b.ntab = ntab - t0 < 4 ? ntab - t0 : 4;
+        for (int t = 0; t < b.ntab; ++t) {
+          b.tab[t] = tabs[t0 + t];
+          b.out[t] = outs[t0 + t];
+          b.dout[t] = douts[t0 + t];
+        }
+        a = b;
+        switch (b.ntab) {
+          case 1: EI_LAUNCH(1); break;
+          case 2: EI_LAUNCH(2); break;
+          case 3: EI_LAUNCH(3); break;
+          default: EI_LAUNCH(4); break;
+        }
+      }
+    }
+  }
+#undef EI_LAUNCH
+}
+
+// interpolate table `tab` at M listed distances with the step's fp32 arithmetic (build-time verification)
+__global__ void k_interp_list(const float* __restrict__ tab, const double* __restrict__ dist, int M, int R, int T, float lo, float h,
+                              float inv_h, float* __restrict__ out, float* __restrict__ dout) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)M * R) return;
+  const int m = (int)(idx / R), c = (int)(idx - (int64_t)m * R);
+  const float x = ((float)dist[m] - lo) * inv_h;
+  int k = (int)x;
+  k = k < 0 ? 0 : (k > T - 1 ? T - 1 : k);
+  const float t = x - (float)k, t2 = t * t, t3 = t2 * t;
+  const float aD = (3.f * t2 - 2.f * t3) * h, a0 = (t3 - 2.f * t2 + t) * h, a1 = (t3 - t2) * h;
+  const float bD = 6.f * t - 6.f * t2, b0 = 3.f * t2 - 4.f * t + 1.f, b1 = 3.f * t2 - 2.f * t;
+  const float* row = tab + (int64_t)k * 3 * R + c;
+  const float f0 = row[0], s0 = row[R], D = row[2 * R], s1 = row[4 * R];
+  out[idx] = f0 + (aD * D + a0 * s0 + a1 * s1);
+  dout[idx] = bD * D + b0 * s0 + b1 * s1;
+}
+void launch_interp_list(const float* tab, const double* dist, int M, int R, int T, float lo, float up, float* out, float* dout,
+                        hipStream_t s) {
+  const float h = (up - lo) / (float)T;
+  hipLaunchKernelGGL(k_interp_list, dim3(cdive((int64_t)M * R, 256)), dim3(256), 0, s, tab, dist, M, R, T, lo, h, 1.0f / h, out, dout);
+}
+
+}  // namespace tn

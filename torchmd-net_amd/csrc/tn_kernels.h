@@ -84,7 +84,7 @@ void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const 
 // adjoint sweep + the layer's per-pair distance gradient in one pass (replaces launch_message_adjoint + launch_pair_gd when
 // message_adjoint_gd_ok): partial sums go to slots[wave][2 * pair + direction], summed by launch_geom_gd
 bool message_adjoint_gd_ok(int N, int F);
-int message_adjoint_gd_waves(int F);
+int message_adjoint_gd_waves(int N, int F);  // number of slot arrays the sweep writes per layer
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
 // next = 0: plain; 1: nxt = X_hat of the new X (next layer's k_norm_x); 2: nxt = readout invariants of the new X
@@ -145,6 +145,27 @@ void launch_embed_pair_gd(const Graph& g, int Pcap, int F, const int64_t* z, con
 // g_d[p] = gd[p] + sum of the n_slots slot arrays (each [2 * slot_stride/2]: pair, direction) when slots != null
 void launch_geom_gd(const Graph& g, int Pcap, const float* gd, const float* g_rhat, float* g_delta, hipStream_t s,
                     const float* slots = nullptr, int n_slots = 0, int64_t slot_stride = 0);
+
+// ---- radial tables of the per-pair functions (tn_edge_table.hip)
+void launch_radial_f64(int rows, double lo, double up, int T, bool mid, const float* means, const float* betas, int K, double* dist,
+                       double* phi, double* dphi, double* C, double* dC, hipStream_t s);
+void launch_dense_f64(const double* A, const double* A2, int lda, const float* W, const float* bias, int M, int N, int K, int kind,
+                      const double* rs, const double* rs2, double* C, double* C2, int ldc, hipStream_t s);
+void launch_table_pack(const double* f, const double* sl, int T, int R, double h, float* tab, hipStream_t s);
+size_t edge_sort_temp_bytes(int64_t n);
+void launch_edge_tables(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
+                        float* const* outs, float* const* douts, float* C, float* dC, unsigned* keys, int* vals, unsigned* keys_s,
+                        int* vals_s, void* sort_tmp, size_t sort_tmp_bytes, hipStream_t s);
+void launch_interp_list(const float* tab, const double* dist, int M, int R, int T, float lo, float up, float* out, float* dout,
+                        hipStream_t s);
+
+// ---- pair-major LDS-staged sweeps (tn_message_pair.hip): every per-pair row is read from HBM once per tile
+bool message_pair_ok(int N, int F);
+int message_pair_slots(int F);
+void launch_message_pair(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
+                         int o3, float* Mi, float* Ch, hipStream_t s);
+void launch_message_pair_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi,
+                                    const float* Pn, float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
 
 // ---- LDS-staged tile sweeps (tn_message_tile.hip), selected by launch_message / launch_message_adjoint when message_tile_ok(F)
 bool message_tile_ok(int N, int F);

@@ -732,6 +732,7 @@ void launch_message(const Graph& g, int N, int F, const float* w, const float* s
     hipLaunchKernelGGL((k_message_split<0>), dim3(N), dim3(kEG * F), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
     return;
   }
+  if (message_pair_ok(N, F)) return launch_message_pair(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   if (message_tile_ok(N, F)) return launch_message_tile(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   if (sweep_v4() && gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
@@ -798,7 +799,13 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
   for (int c = 0; c < 9; ++c) o[c * F] += acc[c];
 }
 bool message_adjoint_gd_ok(int N, int F) { return F % 64 == 0 && (split_rows_ok(N, F) || (N > kSplitRows && F <= 1024)); }
-int message_adjoint_gd_waves(int F) { return F / 64; }
+// the 16-byte-per-lane layout (tn_message_pair.hip) wins for the forward sweep only: the reverse sweep carries twice the
+// per-lane state (216 VGPRs, one block per CU) and measured 340 vs 307 us at C2 (profiles/r02_notes.md); opt-in
+static bool adjoint_rows8(int N, int F) {
+  static const bool on = getenv("TMDNET_MSG_ROWS8_ADJOINT") != nullptr;
+  return on && !split_rows_ok(N, F) && message_pair_ok(N, F);
+}
+int message_adjoint_gd_waves(int N, int F) { return adjoint_rows8(N, F) ? message_pair_slots(F) : F / 64; }
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
   if (N <= 0) return;
@@ -807,6 +814,7 @@ void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, con
                        slots, slot_stride);
     return;
   }
+  if (adjoint_rows8(N, F)) return launch_message_pair_adjoint_gd(g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, s);
   hipLaunchKernelGGL(k_message_adjoint_gd, dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride);
 }
 

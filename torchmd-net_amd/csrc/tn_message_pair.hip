@@ -1,0 +1,238 @@
+// LDS-staged message sweeps with 16 bytes per lane (reference tensornet.py:757-806 and its adjoint), gfx950.
+//
+//     acc[i, c, f] = sum_{e in row(i)} w[pair(e), type(c), f] * src[col(e), c, f]
+//
+// Same tiling as tn_message_tile.hip - a block owns 64 consecutive rows x 32 channels and stages the rows of its
+// column window [<= 64][9][32] (72 KB) in LDS once - but a different thread layout.  There a half-wave owned a row
+// with one channel per lane: every edge cost a wave 3 dword loads, 9 ds_read_b32 and 9 v_fma for 2 rows x 32 channels, and
+// the sweep was bound by instruction issue (4 cycles per wave64 VALU / LDS instruction), not by HBM or LDS bandwidth
+// (profiles/r02_notes.md: 113 us of the 200 us remained with the weight loads removed, against 29 us of LDS time).
+// Here EIGHT lanes own a row and each lane carries FOUR channels: an edge costs a wave 3 global_load_dwordx4,
+// 9 ds_read_b128 and 18 v_pk_fma_f32 for 8 rows x 32 channels - a quarter of the instructions per channel - and all 64
+// rows of the tile advance together (8 waves), so the two reads of a pair's weights (by its row i and by its row j) fall
+// within the few microseconds a tile takes instead of being spread over a long block lifetime.
+//
+// The 8 lanes of a row fetch 8 edges' (column, pair id) with one coalesced load each and hand them round with ds_bpermute;
+// weights are loaded two edges ahead.  Same edge order per (row, channel) as every other sweep: bit-identical sums,
+// deterministic, no atomics.  A tile whose column window is wider than 64 rows (large systems in cell order, ragged
+// molecules straddling the tile) gathers its sources from global memory instead of LDS; the choice is block-uniform.
+//
+// MODE 0: forward message + group product + normalisation -> Mi, Ch
+// MODE 1: reverse: gPn[i] += sum_e w * gMi[j], and the layer's distance-gradient halves
+//         h(i <- j) = sum_f dw[p] . (gMi[j] * Pn[i]) -> slots[channel chunk][2 p + direction]   (see k_message_adjoint_gd)
+#include <cstdlib>
+
+#include "tn_common.h"
+#include "tn_kernels.h"
+
+namespace tn {
+
+constexpr int MP_TA = 64;        // rows per tile
+constexpr int MP_FC = 32;        // channels per block (8 lanes x 4)
+constexpr int MP_W = 64;         // source-window capacity (rows staged in LDS)
+constexpr int MP_THREADS = 512;  // 64 rows x 8 lanes
+constexpr int MP_U = 2;          // edges whose weights are loaded ahead of their use
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4v ldg4(const float* p) { return *reinterpret_cast<const f4v*>(p); }
+
+template <int MODE>
+__global__ __launch_bounds__(MP_THREADS, 2) void k_message_rows8(Graph g, int N, int F, const float* __restrict__ w,
+                                                                const float* __restrict__ dw, const float* __restrict__ src,
+                                                                const float* __restrict__ Pn, const float* __restrict__ q,
+                                                                const int64_t* __restrict__ batch, int o3,
+                                                                float* __restrict__ Mi, float* __restrict__ out,
+                                                                float* __restrict__ slots, int64_t slot_stride, int nchunks) {
+  __shared__ __attribute__((aligned(16))) float win[MP_W * 9 * MP_FC];
+  __shared__ int s_lo[MP_THREADS / 64], s_hi[MP_THREADS / 64];
+  if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
+  const int b = xcd_chunk(blockIdx.x, gridDim.x);
+  const int tile = b / nchunks, chunk = b - tile * nchunks;
+  const int r0 = tile * MP_TA, r1 = min(N, r0 + MP_TA);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int F9 = 9 * F, F3 = 3 * F, c0 = chunk * MP_FC;
+
+  // ---- column window of the tile (rows are sorted ascending: first / last entry of each row)
+  int lo = 0x7fffffff, hi = -1;
+  if (tid < r1 - r0) {
+    const int e0 = g.rowptr[r0 + tid], e1 = g.rowptr[r0 + tid + 1];
+    if (e1 > e0) {
+      lo = g.col[e0];
+      hi = g.col[e1 - 1];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off, 64));
+    hi = max(hi, __shfl_xor(hi, off, 64));
+  }
+  if (lane == 0) {
+    s_lo[wave] = lo;
+    s_hi[wave] = hi;
+  }
+  __syncthreads();
+  lo = s_lo[0];
+  hi = s_hi[0];
+#pragma unroll
+  for (int k = 1; k < MP_THREADS / 64; ++k) {
+    lo = min(lo, s_lo[k]);
+    hi = max(hi, s_hi[k]);
+  }
+  const int wn = hi - lo + 1;
+  const bool staged = hi >= lo && wn <= MP_W;  // block-uniform
+  if (staged) {
+    // window rows -> LDS as [row][9][32]: 8 lanes x 16 B cover the 32 channels of one (row, component)
+    const int pieces = wn * 9 * (MP_FC / 4);
+    for (int idx = tid; idx < pieces; idx += MP_THREADS) {
+      const int rc = idx >> 3, f4 = (idx & 7) << 2;
+      const int row = rc / 9, c = rc - row * 9;
+      *reinterpret_cast<f4v*>(&win[rc * MP_FC + f4]) = ldg4(src + (int64_t)(lo + row) * F9 + c * F + c0 + f4);
+    }
+    __syncthreads();
+  }
+
+  const int i = r0 + (tid >> 3), ql = tid & 7, f = c0 + 4 * ql;  // row, lane within the row's group, first channel
+  const bool live = i < r1;
+  const int e0 = live ? g.rowptr[i] : 0, e1 = live ? g.rowptr[i + 1] : 0;
+  const int grp = lane & ~7;  // first lane of this row's group within the wave
+  f4v acc[9], y[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) acc[c] = y[c] = (f4v)(0.f);
+  if (MODE == 1 && live) {
+    const float* yp = Pn + (int64_t)i * F9 + f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) y[c] = ldg4(yp + c * F);
+  }
+
+  // the 8 rows of a wave advance together: trip count = the longest of them (a row past its end adds zeros)
+  int nmax = e1 - e0;
+#pragma unroll
+  for (int off = 8; off <= 32; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+
+  for (int eb = 0; eb < nmax; eb += 8) {
+    const int me = min(e0 + eb + ql, e1 - 1);  // clamped: lanes past the row's end repeat its last edge with zero weights
+    const int myc = (e1 > e0) ? g.col[me] : 0, myp = (e1 > e0) ? g.epair[me] : 0;
+    const int n = min(8, nmax - eb);
+    for (int k = 0; k < n; k += MP_U) {
+      int jj[MP_U], pp[MP_U];
+      f4v wv[MP_U][3], dv[MP_U][3];
+      float msk[MP_U];
+#pragma unroll
+      for (int u = 0; u < MP_U; ++u) {
+        const bool valid = e0 + eb + k + u < e1;
+        const int srcl = grp + min(k + u, 7);
+        jj[u] = __shfl(myc, srcl, 64);
+        pp[u] = __shfl(myp, srcl, 64);
+        msk[u] = valid ? 1.0f : 0.0f;
+        const float* wp = w + (int64_t)pp[u] * F3 + f;
+        wv[u][0] = ldg4(wp);
+        wv[u][1] = ldg4(wp + F);
+        wv[u][2] = ldg4(wp + 2 * F);
+        if (MODE == 1) {
+          const float* dp = dw + (int64_t)pp[u] * F3 + f;
+          dv[u][0] = ldg4(dp);
+          dv[u][1] = ldg4(dp + F);
+          dv[u][2] = ldg4(dp + 2 * F);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < MP_U; ++u) {
+        f4v s9[9];
+        if (staged) {
+          const float* sp = win + (jj[u] - lo) * (9 * MP_FC) + 4 * ql;
+#pragma unroll
+          for (int c = 0; c < 9; ++c) s9[c] = *reinterpret_cast<const f4v*>(sp + c * MP_FC);
+        } else {
+          const float* sp = src + (int64_t)jj[u] * F9 + f;
+#pragma unroll
+          for (int c = 0; c < 9; ++c) s9[c] = ldg4(sp + c * F);
+        }
+        const f4v w0 = wv[u][0] * msk[u], w1 = wv[u][1] * msk[u], w2 = wv[u][2] * msk[u];
+        acc[0] += w0 * s9[0];
+        acc[1] += w1 * s9[1];
+        acc[2] += w1 * s9[2];
+        acc[3] += w1 * s9[3];
+        acc[4] += w2 * s9[4];
+        acc[5] += w2 * s9[5];
+        acc[6] += w2 * s9[6];
+        acc[7] += w2 * s9[7];
+        acc[8] += w2 * s9[8];
+        if (MODE == 1) {
+          const f4v hv = dv[u][0] * (s9[0] * y[0]) + dv[u][1] * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
+                         dv[u][2] * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
+          float h = (hv.x + hv.y) + (hv.z + hv.w);
+          h = row_sum(h, 8);  // the 8 lanes = 32 channels of this row in this block
+          const bool valid = msk[u] != 0.f;
+          if (ql == 0 && valid && jj[u] != i)
+            slots[(int64_t)chunk * slot_stride + 2 * (int64_t)pp[u] + (jj[u] < i ? 0 : 1)] = h;
+        }
+      }
+    }
+  }
+  if (!live) return;
+
+  float* o = out + (int64_t)i * F9 + f;
+  if (MODE == 1) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const f4v prev = ldg4(o + c * F);
+      *reinterpret_cast<f4v*>(o + c * F) = prev + acc[c];
+    }
+    return;
+  }
+  f4v yy[9], res[9];
+  if (staged && i >= lo && i <= hi) {  // the row's own source row is in its window whenever it has a self edge
+    const float* yp = win + (i - lo) * (9 * MP_FC) + 4 * ql;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) yy[c] = *reinterpret_cast<const f4v*>(yp + c * MP_FC);
+  } else {
+    const float* yp = src + (int64_t)i * F9 + f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) yy[c] = ldg4(yp + c * F);
+  }
+  float* mo = Mi + (int64_t)i * F9 + f;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) *reinterpret_cast<f4v*>(mo + c * F) = acc[c];
+  const float kap = q ? (batch ? 1.0f + 0.1f * q[batch[i]] : q[i]) : 1.0f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    float m9[9], y9[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      m9[c] = acc[c][t];
+      y9[c] = yy[c][t];
+    }
+    const M3 Y = compose(y9), M = compose(m9);
+    M3 Cm = o3 ? scale(add(matmul(Y, M), matmul(M, Y)), kap) : scale(matmul(Y, M), 2.0f);
+    float uc[9];
+    decompose(Cm, uc);
+    const float inv = 1.0f / (frob2(Cm) + 1.0f);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) res[c][t] = uc[c] * inv;
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) *reinterpret_cast<f4v*>(o + c * F) = res[c];
+}
+
+bool message_pair_ok(int N, int F) {
+  static const bool off = getenv("TMDNET_NO_MSG_ROWS8") != nullptr;  // developer switch: one-channel-per-lane sweeps
+  if (off || F < MP_FC || F % MP_FC) return false;
+  return (int64_t)((N + MP_TA - 1) / MP_TA) * (F / MP_FC) >= 512;
+}
+int message_pair_slots(int F) { return F / MP_FC; }
+
+void launch_message_pair(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
+                         int o3, float* Mi, float* Ch, hipStream_t s) {
+  const int nchunks = F / MP_FC, tiles = (N + MP_TA - 1) / MP_TA;
+  hipLaunchKernelGGL((k_message_rows8<0>), dim3(tiles * nchunks), dim3(MP_THREADS), 0, s, g, N, F, w, nullptr, src, nullptr, q, batch,
+                     o3, Mi, Ch, nullptr, 0, nchunks);
+}
+void launch_message_pair_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi,
+                                    const float* Pn, float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
+  const int nchunks = F / MP_FC, tiles = (N + MP_TA - 1) / MP_TA;
+  hipLaunchKernelGGL((k_message_rows8<1>), dim3(tiles * nchunks), dim3(MP_THREADS), 0, s, g, N, F, w, dw, gMi, Pn, nullptr, nullptr, 0,
+                     nullptr, gPn, slots, slot_stride, nchunks);
+}
+
+}  // namespace tn

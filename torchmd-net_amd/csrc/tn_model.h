@@ -68,12 +68,16 @@ struct FwdBuffers {
   float *he1, *he2, *te1, *te2, *dQ, *Xh, *Ch;
   float *feat, *lnr, *xhr, *rstdr, *al, *x, *ao, *ea, *kap;
   // reverse
+  unsigned *skeys, *skeys_s;  // radial tables: sort keys (fp32 distance bits) and their sorted copy
+  int *svals, *svals_s;       // pair ids / pair ids in distance order
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
   float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *gd, *gd_slots;
   float *gUX, *g_a2, *g_a1, *g_ln0, *g_s0n, *g_u0l, *gA, *g_rhat, *g_delta;
 };
 
 
-enum ProfCat { CAT_GRAPH = 0, CAT_GEMM_EDGE, CAT_GEMM_NODE, CAT_MESSAGE, CAT_PAIR, CAT_SCATTER, CAT_ELEMENTWISE, CAT_COUNT };
+enum ProfCat { CAT_GRAPH = 0, CAT_GEMM_EDGE, CAT_GEMM_NODE, CAT_MESSAGE, CAT_PAIR, CAT_SCATTER, CAT_ELEMENTWISE, CAT_EDGE_TABLE, CAT_COUNT };
 
 
 struct ProfRec {
@@ -100,6 +104,15 @@ struct Profiler {
 
 struct EtModel;  // tn_et_api.hip
 
+// radial tables of the per-pair functions (tn_edge_table.hip): built by tmdnet_finalize_params, verified against the direct
+// evaluation; tab[0] = distance projections Q (embedding), tab[1 + l] = edge MLP of layer l; each [T + 2][2][3F]
+struct EdgeTables {
+  bool ok = false;
+  int T = 0;
+  std::vector<float*> tab;
+  double err_value = 0.0, err_slope = 0.0;  // measured at the interval midpoints, relative to the table's largest entry
+};
+
 struct tmdnet_model {
   tmdnet_hparams hp;
   // optional (TMDNET_SIDE_STREAM=1) second stream + events: the edge MLPs of the interaction layers depend on the pair geometry only, so they are
@@ -120,6 +133,8 @@ struct tmdnet_model {
   uint16_t* dev_sb = nullptr;  // split-bf16 weight tile images
   std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
   DevParams P;
+  EdgeTables tabs;
+  int64_t tab_min_pairs = 8192;  // below this many pairs the direct GEMMs are cheaper than sort + interpolation
   bool finalized = false;
   std::string err;
   // last-call bookkeeping for tmdnet_debug_tensor

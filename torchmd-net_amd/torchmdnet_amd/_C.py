@@ -62,6 +62,8 @@ def lib():
     L.tmdnet_num_params.argtypes = [vp]
     L.tmdnet_param_name.argtypes = [vp, C.c_int, C.POINTER(i64)]
     L.tmdnet_param_name.restype = C.c_char_p
+    L.tmdnet_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    L.tmdnet_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
     L.tmdnet_graph_workspace_bytes.argtypes = [vp, i64, i64, C.POINTER(sz)]
     L.tmdnet_build_graph.argtypes = [vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, i32, C.POINTER(i64)]
     L.tmdnet_set_cell_grid.argtypes = [vp, i32, i32, i32]

@@ -397,6 +397,8 @@ class TorchMD_Net(nn.Module):
         rc = L.tmdnet_finalize_params(handle)
         if rc != _C.OK:
             raise RuntimeError(L.tmdnet_last_error(handle).decode())
+        for name, value in getattr(st, "options", {}).items():
+            L.tmdnet_set_option(handle, name.encode(), value)
         st.fingerprint = fp
         return st
 
@@ -501,6 +503,21 @@ class TorchMD_Net(nn.Module):
             raise RuntimeError("Found num_pairs > max_num_pairs, please increase max_num_pairs "
                                f"(found {int(counts[1])} edges for max_num_neighbors={self.representation_model.max_num_neighbors})")
         return st.counts
+
+    def engine_info(self, name: str) -> float:
+        """Library-side facts about the uploaded model, e.g. "edge_table_T" (0: radial tables off), "edge_table_err_value"."""
+        st = self._sync_engine()
+        v = C.c_double(0.0)
+        if _C.lib().tmdnet_get_info(st.handle, name.encode(), C.byref(v)) != _C.OK:
+            raise KeyError(name)
+        return v.value
+
+    def set_engine_option(self, name: str, value: float):
+        """Library-side switches, e.g. ("edge_table_min_pairs", n): systems with fewer pairs run the pair-row GEMMs directly."""
+        st = self._sync_engine()
+        self._engine.options = dict(getattr(self._engine, "options", {}), **{name: float(value)})
+        if _C.lib().tmdnet_set_option(st.handle, name.encode(), float(value)) != _C.OK:
+            raise KeyError(name)
 
     def cell_grid(self, n_atoms: int, n_mol: int = 1):
         """(n_x, n_y, n_z, used) of the last evaluation's neighbour search; used = 0: brute force ran (synchronises)."""
