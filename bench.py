@@ -43,7 +43,8 @@ N_MOL, N_ATOMS = 256, 64
 PEAK = {"mfma_f32_tflops": 157.3, "mfma_bf16_tflops": 2500.0, "hbm_gbs": 8000.0}
 SPLIT_PRODUCTS = 6
 # HIP kernels behind each profiled class (rocprofv3 names, profiles/r02_kernel_stats*.csv)
-KERNEL_OF = {"gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_sb1", "message": "k_message_tile / k_message_adjoint_gd",
+KERNEL_OF = {"gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_sb1", "message": "k_message_rows8 / k_message_adjoint_gd",
+             "edge_table": "k_edge_interp (+ k_pair_cutoff_hist, k_bucket_scan, k_bucket_scatter)",
              "pair_bwd": "k_embed_pair_gd_v4 / k_geom_gd", "embed_scatter": "k_embed_scatter", "elementwise": "elementwise",
              "graph": "k_nbr_wave / k_scan_counts"}
 
@@ -131,8 +132,9 @@ def pmc_kernel_bytes(pmc, cls, label):
     per = pmc.get("_per_kernel_total", {})
     head = label.split(" ")[0].split("(")[0]
     names = {"gemm_dual<2>": ["k_edge_mlp", "k_gemm_dual_sb2<2>"], "gemm_dual<0>": ["k_gemm_dual_sb2<0>"],
-             "launch_message": ["k_message_pair<0>", "k_message_tile<0>"],
-             "launch_message_adjoint_gd": ["k_message_pair<1>", "k_message_adjoint_gd"],
+             "launch_message": ["k_message_rows8<0>", "k_message_tile<0, 0>", "k_message_tile<0>"],
+             "launch_message_adjoint_gd": ["k_message_rows8<1>", "k_message_adjoint_gd"],
+             "launch_edge_tables": ["k_edge_interp<3>", "k_edge_interp<2>", "k_edge_interp<4>", "k_edge_interp<1>"],
              "launch_embed_scatter": ["k_embed_scatter"], "launch_embed_pair_gd": ["k_embed_pair_gd_v4"]}.get(head, [])
     for n in names:
         if n in per:

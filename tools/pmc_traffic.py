@@ -22,7 +22,8 @@ import re
 # kernel (rocprofv3 short name, template instance kept) -> profiled class of the library (tn_model.h ProfCat).  Exact
 # patterns: `k_message_bwd_node` is an elementwise kernel, not a sweep.
 CLASS_OF = [(r"k_gemm_dual", "gemm_edge"), (r"k_edge_mlp", "gemm_edge"), (r"k_gemm_(nt|skinny|sb1)", "gemm_node"),
-            (r"k_message(_tile|_pair|_adjoint|_adjoint_gd|_adjoint_pair|_split)?(<.*>)?$", "message"),
+            (r"k_message(_tile|_rows8|_adjoint|_adjoint_gd|_split)?(<.*>)?$", "message"),
+            (r"k_(edge_interp|pair_cutoff_hist|bucket_scan|bucket_scatter)", "edge_table"),
             (r"k_(pair_gd|embed_pair_gd|geom_gd)", "pair_bwd"), (r"k_embed_scatter", "embed_scatter")]
 
 

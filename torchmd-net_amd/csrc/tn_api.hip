@@ -279,12 +279,9 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
   b.ao = c.take<float>(N * H);
   b.ea = c.take<float>(N);
   b.kap = c.take<float>(N);
-  b.skeys = c.take<unsigned>(P1);
   b.skeys_s = c.take<unsigned>(P1);
-  b.svals = c.take<int>(P1);
   b.svals_s = c.take<int>(P1);
-  b.sort_tmp_bytes = edge_sort_temp_bytes(P1);
-  b.sort_tmp = c.take<char>((int64_t)b.sort_tmp_bytes);
+  b.shist = c.take<int>(65536 + 2);
   if (bwd) {
     b.g_ao = c.take<float>(N * H);
     b.g_al = c.take<float>(N * F);
@@ -954,8 +951,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     }
     const double rowB = 12.0 * Fd;
     KR(CAT_EDGE_TABLE, (Pd + 1) * (rowB * (L + 1) * (want_forces ? 2 : 1) + 24) + (double)(m->tabs.T + 2) * 2 * rowB * (L + 1),
-       launch_edge_tables(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1 + L, tabs, outs, douts, b.C, b.dC, b.skeys,
-                          b.svals, b.skeys_s, b.svals_s, b.sort_tmp, b.sort_tmp_bytes, s));
+       launch_edge_tables(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1 + L, tabs, outs, douts, b.C, b.dC, b.shist,
+                          b.skeys_s, b.svals_s, s));
   } else {
     // ---- radial functions per pair
     RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};

@@ -19,17 +19,11 @@
 // like the per-type tables U[z], V[z] (k_ztables) and the split-bf16 weight images: valid for any input, rebuilt with
 // the weights.
 //
-// Per step: pair ids are sorted by distance (rocPRIM radix sort on the upper 20 bits of the fp32 distance), so that
-// consecutive pairs read neighbouring table rows (38 MB per table: the gathers hit L2), and one streaming kernel writes
+// Per step: pair ids are bucketed by grid interval (counting sort: histogram, scan, scatter), so that consecutive
+// pairs read the same or neighbouring table rows (38 MB per table: the gathers hit L2), and one streaming kernel writes
 // Q, dQ/dd, w^l, dw^l/dd for all tables.  It is bound by those writes (HBM).  The self pair (d = 0, below r_lo when a
 // lower cutoff is set) has its own exactly evaluated row.
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <vector>
-
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "tn_common.h"
 #include "tn_kernels.h"
@@ -140,37 +134,72 @@ void launch_table_pack(const double* f, const double* sl, int T, int R, double h
 }
 
 // ---- per step ---------------------------------------------------------------------------------------------------
-// cutoff function per pair (the only radial quantity the rest of the step still needs) + sort keys
-__global__ void k_pair_cutoff_keys(Graph g, int Pcap, float lo, float up, float* __restrict__ C, float* __restrict__ dC,
-                                   unsigned* __restrict__ keys, int* __restrict__ vals) {
+// Counting sort of the pairs by grid interval (T + 2 buckets: intervals 0..T-1, the self pair, "beyond the pair list"):
+// histogram -> single-block scan -> scatter.  The order inside a bucket is whatever the atomics give; it only decides
+// which thread writes which output row, never a value, so the results stay bit-reproducible.
+__device__ __forceinline__ int interval_of(float d, float lo, float inv_h, int T) {
+  const int k = (int)((d - lo) * inv_h);
+  return k < 0 ? 0 : (k > T - 1 ? T - 1 : k);
+}
+// cutoff function per pair (the only radial quantity the rest of the step still needs) + bucket histogram
+__global__ void k_pair_cutoff_hist(Graph g, int Pcap, float lo, float up, float inv_h, int T, float* __restrict__ C,
+                                   float* __restrict__ dC, int* __restrict__ hist) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p > Pcap) return;
   const int P = g.counts[0];
-  if (p > P || g.counts[2]) {  // beyond the pair list (static shapes: the grid is sized by the capacity)
-    keys[p] = 0xFFFFFFFFu;
-    vals[p] = p;
-    return;
-  }
+  if (p > P || g.counts[2]) return;  // beyond the pair list (static shapes: the grid is sized by the capacity)
   const float d = p < P ? g.pd[p] : 0.f;  // p == P: the self pair
   float c, dc;
   cosine_cutoff(d, lo, up, c, dc);
   C[p] = c;
   dC[p] = dc;
-  keys[p] = __float_as_uint(d);
-  vals[p] = p;
+  atomicAdd(hist + (p < P ? interval_of(d, lo, inv_h, T) : T), 1);
+}
+// exclusive scan of the T + 1 bucket counts in place (one block), total -> hist[T + 1]
+__global__ __launch_bounds__(1024) void k_bucket_scan(int* __restrict__ hist, int nb) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + tid;
+    const int v = i < nb ? hist[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int pre = carry;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    if (i < nb) hist[i] = pre + inc - v;
+    __syncthreads();
+    if (tid == 1023) carry = pre + inc;
+    __syncthreads();
+  }
+  if (tid == 0) hist[nb] = carry;
+}
+__global__ void k_bucket_scatter(Graph g, int Pcap, float lo, float inv_h, int T, int* __restrict__ cursor, unsigned* __restrict__ keys_s,
+                                 int* __restrict__ vals_s) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > Pcap) return;
+  const int P = g.counts[0];
+  if (p > P || g.counts[2]) {  // slots past the valid pairs: marked so that the interpolation stops there
+    keys_s[p] = 0xFFFFFFFFu;  // the P + 1 valid pairs fill the slots 0..P, so a slot p > P is never one of theirs
+    return;
+  }
+  const float d = p < P ? g.pd[p] : 0.f;
+  const int slot = atomicAdd(cursor + (p < P ? interval_of(d, lo, inv_h, T) : T), 1);
+  keys_s[slot] = __float_as_uint(d);
+  vals_s[slot] = p;
 }
 
-size_t edge_sort_temp_bytes(int64_t n) {
-  static thread_local int64_t last_n = -1;
-  static thread_local size_t last_bytes = 0;
-  if (n == last_n) return last_bytes;
-  last_n = n;
-  size_t& bytes = last_bytes;
-  bytes = 0;
-  unsigned* k = nullptr;
-  int* v = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, 32, (hipStream_t)0);
-  return bytes;
+__global__ void k_fill_int(int* p, int v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
 }
 
 struct InterpArgs {
@@ -237,32 +266,16 @@ __global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const un
   }
 }
 
-// C, dC, and the tables' outputs for all pairs.  keys / vals / keys_s / vals_s: [Pcap + 1] each
+// C, dC, and the tables' outputs for all pairs.  hist: [T + 2] ints; keys_s / vals_s: [Pcap + 1] each
 void launch_edge_tables(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
-                        float* const* outs, float* const* douts, float* C, float* dC, unsigned* keys, int* vals, unsigned* keys_s,
-                        int* vals_s, void* sort_tmp, size_t sort_tmp_bytes, hipStream_t s) {
+                        float* const* outs, float* const* douts, float* C, float* dC, int* hist, unsigned* keys_s, int* vals_s,
+                        hipStream_t s) {
   const int n = Pcap + 1;
-  hipLaunchKernelGGL(k_pair_cutoff_keys, dim3(cdive(n, 256)), dim3(256), 0, s, g, Pcap, lo, up, C, dC, keys, vals);
-  size_t tmp = sort_tmp_bytes;
-  hipError_t serr = rocprim::radix_sort_pairs(sort_tmp, tmp, keys, keys_s, vals, vals_s, (size_t)n, 0, 32, s);
-  if (getenv("TMDNET_DEBUG")) {
-    (void)hipStreamSynchronize(s);
-    std::vector<unsigned> hk(n), hks(n);
-    std::vector<int> hv(n);
-    (void)hipMemcpy(hk.data(), keys, n * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(hks.data(), keys_s, n * 4, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(hv.data(), vals_s, n * 4, hipMemcpyDeviceToHost);
-    int zeros_in = 0, zeros_out = 0, unsorted = 0, badval = 0, mismatch = 0;
-    for (int i = 0; i < n; ++i) {
-      zeros_in += hk[i] == 0;
-      zeros_out += hks[i] == 0;
-      if (i && (hks[i] >> 12) < (hks[i - 1] >> 12)) ++unsorted;
-      if (hv[i] < 0 || hv[i] >= n) ++badval;
-      else if (hk[hv[i]] != hks[i]) ++mismatch;
-    }
-    fprintf(stderr, "[tmdnet] sort n=%d err=%d tmp=%zu/%zu zeros in %d out %d unsorted %d badval %d mismatch %d\n", n, (int)serr, tmp,
-            sort_tmp_bytes, zeros_in, zeros_out, unsorted, badval, mismatch);
-  }
+  const float h0 = (up - lo) / (float)T, inv_h0 = 1.0f / h0;
+  hipLaunchKernelGGL(k_fill_int, dim3(cdive(T + 2, 256)), dim3(256), 0, s, hist, 0, T + 2);
+  hipLaunchKernelGGL(k_pair_cutoff_hist, dim3(cdive(n, 256)), dim3(256), 0, s, g, Pcap, lo, up, inv_h0, T, C, dC, hist);
+  hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, s, hist, T + 1);
+  hipLaunchKernelGGL(k_bucket_scatter, dim3(cdive(n, 256)), dim3(256), 0, s, g, Pcap, lo, inv_h0, T, hist, keys_s, vals_s);
   InterpArgs a{};
   a.ntab = ntab;
   for (int t = 0; t < ntab; ++t) {

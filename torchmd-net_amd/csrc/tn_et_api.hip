@@ -438,7 +438,9 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     a = EtAttnArgs{b.qkv[l], b.vec[l], b.dkv[l], b.tkv[l], b.C, b.dC, F, hd, Wd,
                    (hp.distance_influence & 1) ? 0 : -1, (hp.distance_influence & 2) ? ((hp.distance_influence & 1) ? F : 0) : -1,
                    hp.vector_cutoff, 2 * (int64_t)P1};
-    KR(CAT_MESSAGE, Ed * Fd * 4 * 12, launch_et_attn_fwd(g, N, a, b.xagg, b.vagg, s));
+    // algorithmic bytes (every distinct tensor once): dkv [P+1, Wd], qkv [N,5F], vec [N,3F] in; xagg [N,F],
+    // vagg [N,3F] out; edge indices
+    KR(CAT_MESSAGE, (Pd + 1) * Wd * 4 + Nd * Fd * 4 * 12 + Ed * 12, launch_et_attn_fwd(g, N, a, b.xagg, b.vagg, s));
     NODE();
     gemm(s, b.xagg, F, q.Wo, F, q.bo, b.o[l], 3 * F, N, 3 * F, F);
     KR(CAT_ELEMENTWISE, Nd * Fd * 4 * 20,
@@ -493,10 +495,11 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
       KR(CAT_ELEMENTWISE, Nd * Fd * 24, launch_et_copy2d(b.g_vec, 3 * F, b.vagg, 3 * F, N, 3 * F, s));
       static const bool two_sweeps = getenv("TMDNET_ET_TWO_SWEEPS") != nullptr;  // developer switch: target / source sweeps apart
       if (two_sweeps) {
-        KR(CAT_PAIR, Ed * Fd * 4 * 16, launch_et_attn_bwd_t(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
-        KR(CAT_PAIR, Ed * Fd * 4 * 16, launch_et_attn_bwd_s(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, s));
+        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * 4 + Nd * Fd * 4 * 17 + Ed * 12 + (Pd + 1) * 32 * nwv, launch_et_attn_bwd_t(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
+        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * 4 + Nd * Fd * 4 * 18 + Ed * 12, launch_et_attn_bwd_s(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, s));
       } else {
-        KR(CAT_PAIR, Ed * Fd * 4 * 24,
+        // dkv + tkv, qkv, vec, g_xagg, g_vagg in; g_qkv out, g_vec read + written; the (pair, direction) slots of g_d, g_rhat
+        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * 4 + Nd * Fd * 4 * 23 + Ed * 12 + (Pd + 1) * 32 * nwv,
            launch_et_attn_bwd(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
       }
       gemm(s, b.g_vp, 3 * F, q.WvpT, 3 * F, nullptr, b.g_vec, F, 3 * N, F, 3 * F, GEMM_ACCUM);

@@ -38,7 +38,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4v ldg4(const float* p) { return *reinterpret_cast<const f4v*>(p); }
 
 template <int MODE>
-__global__ __launch_bounds__(MP_THREADS, 2) void k_message_rows8(Graph g, int N, int F, const float* __restrict__ w,
+__global__ __launch_bounds__(MP_THREADS) void k_message_rows8(Graph g, int N, int F, const float* __restrict__ w,
                                                                 const float* __restrict__ dw, const float* __restrict__ src,
                                                                 const float* __restrict__ Pn, const float* __restrict__ q,
                                                                 const int64_t* __restrict__ batch, int o3,
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(MP_THREADS, 2) void k_message_rows8(Graph g, int N,
     }
     return;
   }
-  f4v yy[9], res[9];
+  f4v yy[9];  // the row's own source row; overwritten component by component with the result
   if (staged && i >= lo && i <= hi) {  // the row's own source row is in its window whenever it has a self edge
     const float* yp = win + (i - lo) * (9 * MP_FC) + 4 * ql;
 #pragma unroll
@@ -209,10 +209,10 @@ __global__ __launch_bounds__(MP_THREADS, 2) void k_message_rows8(Graph g, int N,
     decompose(Cm, uc);
     const float inv = 1.0f / (frob2(Cm) + 1.0f);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) res[c][t] = uc[c] * inv;
+    for (int c = 0; c < 9; ++c) yy[c][t] = uc[c] * inv;
   }
 #pragma unroll
-  for (int c = 0; c < 9; ++c) *reinterpret_cast<f4v*>(o + c * F) = res[c];
+  for (int c = 0; c < 9; ++c) *reinterpret_cast<f4v*>(o + c * F) = yy[c];
 }
 
 bool message_pair_ok(int N, int F) {

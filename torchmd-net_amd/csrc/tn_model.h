@@ -68,10 +68,8 @@ struct FwdBuffers {
   float *he1, *he2, *te1, *te2, *dQ, *Xh, *Ch;
   float *feat, *lnr, *xhr, *rstdr, *al, *x, *ao, *ea, *kap;
   // reverse
-  unsigned *skeys, *skeys_s;  // radial tables: sort keys (fp32 distance bits) and their sorted copy
-  int *svals, *svals_s;       // pair ids / pair ids in distance order
-  void* sort_tmp;
-  size_t sort_tmp_bytes;
+  unsigned* skeys_s;  // radial tables: fp32 distance bits of the pairs in grid-interval order
+  int *svals_s, *shist;  // pair ids in that order; bucket counters [T + 2]
   float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *gd, *gd_slots;
   float *gUX, *g_a2, *g_a1, *g_ln0, *g_s0n, *g_u0l, *gA, *g_rhat, *g_delta;
 };
