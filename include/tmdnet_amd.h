@@ -98,7 +98,7 @@ const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel);
  * stores fp32 rows, and verifies the step's cubic Hermite interpolation against the fp64 evaluation at every interval
  * midpoint (bounds: 5e-7 of the table's largest value, 2e-6 of its largest slope; the grid is refined 8192 -> 65536
  * intervals until they hold, else the tables stay off) and tmdnet_energy_forces then interpolates per pair instead of running the pair-row
- * GEMMs, when the system has at least `edge_table_min_pairs` pairs (default 8192).  TMDNET_EDGE_TABLE=0 in the
+ * GEMMs, when the system has at least `edge_table_min_pairs` pairs (default 1024: single systems from about 100 atoms on).  TMDNET_EDGE_TABLE=0 in the
  * environment disables the tables (direct GEMMs every step).
  * Options: "edge_table_min_pairs".  Info: "edge_table_T" (0 = off), "edge_table_err_value", "edge_table_err_slope"
  * (measured at the midpoints), "edge_table_min_pairs". */

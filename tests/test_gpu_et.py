@@ -212,3 +212,21 @@ def test_et_energy_only_and_backward(hip_lib, golden_dir):
     E1, _ = model(z, pos, batch)
     E1.sum().backward()
     assert rel_err(-pos.grad.cpu(), g["F"]) < REL and rel_err(E1.detach().cpu(), g["E"]) < REL
+
+
+@pytest.mark.parametrize("fixture", ["et_tiny_ref.pt", "et_tiny_vc_ref.pt"])
+def test_et_radial_tables_equal_direct_evaluation(hip_lib, golden_dir, fixture):
+    """The distance filters of every attention layer and of the neighbour embedding are functions of the pair distance alone:
+    tabulated at parameter upload (fp64 build, verified at the interval midpoints) and interpolated per pair instead of the
+    pair-row GEMMs (csrc/tn_edge_table.hip).  Same numbers as the direct path to fp32 rounding."""
+    g = torch.load(os.path.join(golden_dir, fixture))
+    model = _model_from_sd(g["args"], g["state_dict"])
+    z, pos, batch = g["z"].cuda(), g["pos"].cuda(), g["batch"].cuda()
+    assert model.engine_info("edge_table_T") >= 8192
+    assert model.engine_info("edge_table_err_value") < 5e-7 and model.engine_info("edge_table_err_slope") < 2e-6
+    model.set_engine_option("edge_table_min_pairs", 10 ** 12)
+    Ed, Fd = model(z, pos, batch)
+    model.set_engine_option("edge_table_min_pairs", 0)
+    Et, Ft = model(z, pos, batch)
+    assert rel_err(Et, Ed) < 2e-6 and rel_err(Ft, Fd) < 2e-6
+    assert rel_err(Et.cpu(), g["E"]) < REL and rel_err(Ft.cpu(), g["F"]) < REL

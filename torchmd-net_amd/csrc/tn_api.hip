@@ -309,26 +309,33 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
   return b;
 }
 
-void free_edge_tables(tmdnet_model* m) {
-  for (float* t : m->tabs.tab)
-    if (t) (void)hipFree(t);
-  m->tabs = EdgeTables{};
+}  // namespace
+
+void free_radial_tables(EdgeTables& t) {
+  for (float* p : t.tab)
+    if (p) (void)hipFree(p);
+  t = EdgeTables{};
 }
 
-// Radial tables (tn_edge_table.hip): evaluate Q(d) and every layer's w(d) with their d/dd on a uniform grid in fp64, pack
-// them as fp32 rows (value | slope | divided difference), then verify the step's fp32 interpolation against the fp64
-// evaluation at all interval midpoints; refine the grid until the measured error is below the bound, or leave the tables off.
-int build_edge_tables(tmdnet_model* m) {
-  free_edge_tables(m);
+// Radial tables (tn_edge_table.hip): evaluate every table's function and its d/dd on a uniform grid in fp64, pack them as
+// fp32 rows (value | slope | divided difference), then verify the step's fp32 interpolation against the fp64 evaluation at
+// all interval midpoints; refine the grid until the measured error is below the bound, or leave the tables off.
+int build_radial_tables(tmdnet_model* m, EdgeTables& out, const std::vector<TableSpec>& specs, const float* means, const float* betas,
+                        int K, double lo, double up) {
+  free_radial_tables(out);
   const char* env = getenv("TMDNET_EDGE_TABLE");
   if (env && atoi(env) == 0) return TMDNET_OK;  // developer / benchmark switch: direct GEMMs every step
-  const tmdnet_hparams& hp = m->hp;
-  const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, R = 3 * F;
-  if (F % 4 || L + 1 > 8 || 3 * F / 4 > 256) return TMDNET_OK;  // what the interpolation kernel's thread layout covers
-  const DevParams& W = m->P;
-  const double lo = hp.cutoff_lower, up = hp.cutoff_upper;
+  int Rmax = 0, Nmax = 0;
+  for (const TableSpec& sp : specs) {
+    const int R = sp.chain.back().N;
+    if (R % 4 || R / 4 > 256) return TMDNET_OK;  // what the interpolation kernel's thread layout covers
+    Rmax = std::max(Rmax, R);
+    for (const TableLayer& l : sp.chain) Nmax = std::max(Nmax, l.N);
+  }
+  if (specs.empty()) return TMDNET_OK;
   const double tol_value = 5e-7, tol_slope = 2e-6;  // relative to the table's largest |value| / |slope|
   hipStream_t s = nullptr;
+  const int ntab = (int)specs.size();
   for (int T = 8192; T <= 65536; T *= 2) {
     const int M = T + 2;
     std::vector<void*> tmp;
@@ -346,11 +353,13 @@ int build_edge_tables(tmdnet_model* m) {
       return p;
     };
     double *dist = D_(M), *phi = D_((int64_t)M * K), *dphi = D_((int64_t)M * K), *C = D_(M), *dC = D_(M);
-    double *he1 = D_((int64_t)M * F), *te1 = D_((int64_t)M * F), *he2 = D_((int64_t)M * 2 * F), *te2 = D_((int64_t)M * 2 * F);
-    double *fv = D_((int64_t)M * R), *fs = D_((int64_t)M * R);
-    float *ip = F_((int64_t)T * R), *dip = F_((int64_t)T * R);
-    std::vector<float*> tab(1 + L, nullptr);
-    for (auto& t : tab) alloc_ok = (hipMalloc(reinterpret_cast<void**>(&t), (size_t)M * 3 * R * sizeof(float)) == hipSuccess) && alloc_ok;
+    double* hv_[2] = {D_((int64_t)M * Nmax), D_((int64_t)M * Nmax)};  // ping-pong: layer outputs (value)
+    double* hs_[2] = {D_((int64_t)M * Nmax), D_((int64_t)M * Nmax)};  // (slope)
+    float *ip = F_((int64_t)T * Rmax), *dip = F_((int64_t)T * Rmax);
+    std::vector<float*> tab(ntab, nullptr);
+    for (int t = 0; t < ntab; ++t)
+      alloc_ok = (hipMalloc(reinterpret_cast<void**>(&tab[t]), (size_t)M * 3 * specs[t].chain.back().N * sizeof(float)) == hipSuccess) &&
+                 alloc_ok;
     auto cleanup = [&](bool keep_tabs) {
       for (void* p : tmp)
         if (p) (void)hipFree(p);
@@ -362,32 +371,35 @@ int build_edge_tables(tmdnet_model* m) {
       cleanup(false);
       return TMDNET_OK;  // no memory for tables: the direct path stays
     }
-    // function t at the distances currently described by (rows, mid): value -> fv, slope -> fs   (fp64)
+    // function t at the distances described by (rows, mid), fp64: returns which ping-pong buffer holds (value, slope)
     auto evaluate = [&](int t, int rows, bool mid) {
-      launch_radial_f64(rows, lo, up, T, mid, W.means, W.betas, K, dist, phi, dphi, C, dC, s);
-      if (t == 0) {
-        launch_dense_f64(phi, dphi, K, W.Wdp, W.bdp, rows, R, K, 0, nullptr, nullptr, fv, fs, R, s);
-      } else {
-        const LayerP& q_ = W.layer[t - 1];
-        launch_dense_f64(phi, dphi, K, q_.M1, q_.b1, rows, F, K, 1, nullptr, nullptr, he1, te1, F, s);
-        launch_dense_f64(he1, te1, F, q_.M2, q_.b2, rows, 2 * F, F, 1, nullptr, nullptr, he2, te2, 2 * F, s);
-        launch_dense_f64(he2, te2, 2 * F, q_.M3, q_.b3, rows, R, 2 * F, 2, C, dC, fv, fs, R, s);
+      launch_radial_f64(rows, lo, up, T, mid, means, betas, K, dist, phi, dphi, C, dC, s);
+      const double *a = phi, *a2 = phi == nullptr ? nullptr : dphi;
+      int lda = K, cur = 0;
+      for (const TableLayer& l : specs[t].chain) {
+        launch_dense_f64(a, a2, lda, l.W, l.b, rows, l.N, l.K, l.kind, C, dC, hv_[cur], hs_[cur], l.N, s);
+        a = hv_[cur];
+        a2 = hs_[cur];
+        lda = l.N;
+        cur ^= 1;
       }
+      return cur ^ 1;
     };
     double worst_v = 0.0, worst_s = 0.0;
-    std::vector<double> hv((size_t)T * R), hs((size_t)T * R);
-    std::vector<float> hip_((size_t)T * R), hdip((size_t)T * R);
-    bool fail = false;
-    for (int t = 0; t <= L && !fail; ++t) {
-      evaluate(t, M, false);
-      launch_table_pack(fv, fs, T, R, (up - lo) / (double)T, tab[t], s);
-      evaluate(t, T, true);  // fp64 truth at the interval midpoints
+    bool fail_ = false;
+    for (int t = 0; t < ntab && !fail_; ++t) {
+      const int R = specs[t].chain.back().N;
+      int w = evaluate(t, M, false);
+      launch_table_pack(hv_[w], hs_[w], T, R, (up - lo) / (double)T, tab[t], s);
+      w = evaluate(t, T, true);  // fp64 truth at the interval midpoints
       launch_interp_list(tab[t], dist, T, R, T, (float)lo, (float)up, ip, dip, s);
-      if (hipMemcpy(hv.data(), fv, hv.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-          hipMemcpy(hs.data(), fs, hs.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+      std::vector<double> hv((size_t)T * R), hs((size_t)T * R);
+      std::vector<float> hip_((size_t)T * R), hdip((size_t)T * R);
+      if (hipMemcpy(hv.data(), hv_[w], hv.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(hs.data(), hs_[w], hs.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
           hipMemcpy(hip_.data(), ip, hip_.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
           hipMemcpy(hdip.data(), dip, hdip.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
-        fail = true;
+        fail_ = true;
         break;
       }
       double mv = 0.0, ms = 0.0, ev = 0.0, es = 0.0;
@@ -397,28 +409,48 @@ int build_edge_tables(tmdnet_model* m) {
         ev = std::max(ev, std::fabs(hv[i] - (double)hip_[i]));
         es = std::max(es, std::fabs(hs[i] - (double)hdip[i]));
       }
-      if (!(mv > 0.0) || !std::isfinite(ev) || !std::isfinite(es)) {
-        fail = true;
+      if (!std::isfinite(ev) || !std::isfinite(es) || !std::isfinite(mv)) {
+        fail_ = true;
         break;
       }
-      worst_v = std::max(worst_v, ev / mv);
-      worst_s = std::max(worst_s, ms > 0.0 ? es / ms : 0.0);
+      if (mv > 0.0) worst_v = std::max(worst_v, ev / mv);
+      if (ms > 0.0) worst_s = std::max(worst_s, es / ms);
     }
-    const bool good = !fail && worst_v <= tol_value && worst_s <= tol_slope;
-    m->tabs.err_value = worst_v;  // of the last grid tried (reported also when the tables stay off)
-    m->tabs.err_slope = worst_s;
+    const bool good = !fail_ && worst_v <= tol_value && worst_s <= tol_slope;
+    out.err_value = worst_v;  // of the last grid tried (reported also when the tables stay off)
+    out.err_slope = worst_s;
     if (getenv("TMDNET_DEBUG"))
-      fprintf(stderr, "[tmdnet] radial tables T=%d: value err %.3e, slope err %.3e, fail=%d\n", T, worst_v, worst_s, (int)fail);
+      fprintf(stderr, "[tmdnet] radial tables T=%d: value err %.3e, slope err %.3e, fail=%d\n", T, worst_v, worst_s, (int)fail_);
     cleanup(good);
     if (good) {
-      m->tabs.ok = true;
-      m->tabs.T = T;
-      m->tabs.tab = tab;
+      out.ok = true;
+      out.T = T;
+      out.tab = tab;
+      for (const TableSpec& sp : specs) out.R.push_back(sp.chain.back().N);
       return TMDNET_OK;
     }
-    if (fail) return TMDNET_OK;
+    if (fail_) return TMDNET_OK;
   }
+  (void)m;
   return TMDNET_OK;  // bound not met even on the finest grid: direct GEMMs
+}
+
+namespace {
+
+int build_edge_tables(tmdnet_model* m) {
+  const tmdnet_hparams& hp = m->hp;
+  const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers;
+  const DevParams& W = m->P;
+  std::vector<TableSpec> specs;
+  if (L + 1 <= 8) {
+    specs.push_back(TableSpec{{TableLayer{W.Wdp, W.bdp, 3 * F, K, 0}}});
+    for (int l = 0; l < L; ++l) {
+      const LayerP& q_ = W.layer[l];
+      specs.push_back(TableSpec{{TableLayer{q_.M1, q_.b1, F, K, 1}, TableLayer{q_.M2, q_.b2, 2 * F, F, 1},
+                                 TableLayer{q_.M3, q_.b3, 3 * F, 2 * F, 2}}});
+    }
+  }
+  return build_radial_tables(m, m->tabs, specs, W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper);
 }
 
 }  // namespace
@@ -434,6 +466,7 @@ int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out) {
     return TMDNET_ERR_INVALID;
   tmdnet_model* m = new tmdnet_model();
   m->hp = *hp;
+  if (const char* e = getenv("TMDNET_EDGE_TABLE_MIN_PAIRS")) m->tab_min_pairs = atoll(e);  // developer switch (default: tn_model.h)
   build_specs(m);
   if (getenv("TMDNET_SIDE_STREAM")) {  // opt-in (profiles/r01_notes.md): +2 % batch throughput, but the GEMMs then share the chip
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) m->side = nullptr;
@@ -480,7 +513,7 @@ int tmdnet_destroy(tmdnet_model* m) {
     for (auto& e : m->ev_join) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(m->side);
   }
-  free_edge_tables(m);
+  free_radial_tables(m->tabs);
   if (m->dev) (void)hipFree(m->dev);
   if (m->dev_sb) (void)hipFree(m->dev_sb);
   delete m;
@@ -951,8 +984,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     }
     const double rowB = 12.0 * Fd;
     KR(CAT_EDGE_TABLE, (Pd + 1) * (rowB * (L + 1) * (want_forces ? 2 : 1) + 24) + (double)(m->tabs.T + 2) * 2 * rowB * (L + 1),
-       launch_edge_tables(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1 + L, tabs, outs, douts, b.C, b.dC, b.shist,
-                          b.skeys_s, b.svals_s, s));
+       (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
+        launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1 + L, tabs, outs, douts, b.skeys_s, b.svals_s, s)));
   } else {
     // ---- radial functions per pair
     RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};

@@ -76,7 +76,8 @@ __global__ void k_radial_f64(int rows, double lo, double up, double h, int T, in
     dist[p] = d;
   }
 }
-// one output per thread: e = b + A W^T, r = A2 W^T ; kind 0: (e, r) ; 1: (silu e, silu' e r) ; 2: (silu e rs, silu' e r rs + silu e rs2)
+// one output per thread: e = b + A W^T, r = A2 W^T ; kind 0: (e, r) ; 1: (silu e, silu' e r) ; 2: (silu e rs, silu' e r rs + silu e rs2) ;
+// 3: (e rs, r rs + e rs2)
 __global__ void k_dense_f64(const double* __restrict__ A, const double* __restrict__ A2, int lda, const float* __restrict__ W,
                             const float* __restrict__ bias, int M, int N, int K, int kind, const double* __restrict__ rs,
                             const double* __restrict__ rs2, double* __restrict__ C, double* __restrict__ C2, int ldc) {
@@ -92,7 +93,11 @@ __global__ void k_dense_f64(const double* __restrict__ A, const double* __restri
     e += a[k] * wk;
     r += a2[k] * wk;
   }
-  if (kind != 0) {
+  if (kind == 3) {  // plain * row scale: (e rs, r rs + e rs2)
+    const double e0 = e;
+    e = e0 * rs[m];
+    r = r * rs[m] + e0 * rs2[m];
+  } else if (kind != 0) {
     const double sg = 1.0 / (1.0 + exp(-e));
     const double f = e * sg, df = sg * (1.0 + e * (1.0 - sg));
     if (kind == 1) {
@@ -266,16 +271,21 @@ __global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const un
   }
 }
 
-// C, dC, and the tables' outputs for all pairs.  hist: [T + 2] ints; keys_s / vals_s: [Pcap + 1] each
-void launch_edge_tables(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
-                        float* const* outs, float* const* douts, float* C, float* dC, int* hist, unsigned* keys_s, int* vals_s,
-                        hipStream_t s) {
+// C, dC per pair and the pairs in grid-interval order.  hist: [T + 2] ints; keys_s / vals_s: [Pcap + 1] each
+void launch_pair_buckets(const Graph& g, int Pcap, float lo, float up, int T, float* C, float* dC, int* hist, unsigned* keys_s,
+                         int* vals_s, hipStream_t s) {
   const int n = Pcap + 1;
   const float h0 = (up - lo) / (float)T, inv_h0 = 1.0f / h0;
   hipLaunchKernelGGL(k_fill_int, dim3(cdive(T + 2, 256)), dim3(256), 0, s, hist, 0, T + 2);
   hipLaunchKernelGGL(k_pair_cutoff_hist, dim3(cdive(n, 256)), dim3(256), 0, s, g, Pcap, lo, up, inv_h0, T, C, dC, hist);
   hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, s, hist, T + 1);
   hipLaunchKernelGGL(k_bucket_scatter, dim3(cdive(n, 256)), dim3(256), 0, s, g, Pcap, lo, inv_h0, T, hist, keys_s, vals_s);
+}
+
+// the tables' outputs for all pairs (tables of one row length R per call)
+void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
+                        float* const* outs, float* const* douts, const unsigned* keys_s, const int* vals_s, hipStream_t s) {
+  const int n = Pcap + 1;
   InterpArgs a{};
   a.ntab = ntab;
   for (int t = 0; t < ntab; ++t) {

@@ -44,6 +44,8 @@ struct EtParams {
 
 struct EtBuffers {
   float *phi, *dphi, *C, *dC, *Wn, *dWn, *xcat;
+  unsigned* skeys_s;  // radial tables: pairs in grid-interval order (tn_edge_table.hip)
+  int *svals_s, *shist;
   std::vector<float*> x, vec;                               // L+1
   std::vector<float*> xt, xh, rstd, qkv, vp, o, vdot, dkv, tkv;  // per layer
   float *xagg, *vagg;
@@ -188,6 +190,9 @@ EtBuffers et_carve(void* ws, const tmdnet_et_hparams& hp, int64_t N, int64_t B, 
   b.pre2 = c.take<float>(N * F2);
   b.m2 = c.take<float>(N * F2);
   b.ea = c.take<float>(N);
+  b.skeys_s = c.take<unsigned>(P1);
+  b.svals_s = c.take<int>(P1);
+  b.shist = c.take<int>(65536 + 2);
   if (bwd) {
     b.g_pre2 = c.take<float>(N * F2);
     b.g_h2 = c.take<float>(N * F);
@@ -384,6 +389,18 @@ int et_finalize(tmdnet_model* m) {
   P.atomref = hp.has_atomref ? D("atomref") : nullptr;
   P.mean = h["mean"][0];
   P.std = h["std"][0];
+  {  // radial tables (tn_edge_table.hip): every layer's distance filters silu(D phi + b) [Wd] and the neighbour-embedding
+     // filter (D phi + b) C(d) [F] are functions of the pair distance alone (reference torchmd_et.py:375-384, models/utils.py:99-104)
+    HIP_TRY(m, hipStreamSynchronize(nullptr));
+    std::vector<TableSpec> specs;
+    const int Wd = wd_of(hp);
+    if (Wd > 0)
+      for (int l = 0; l < L; ++l) specs.push_back(TableSpec{{TableLayer{P.layer[l].Wdkv, P.layer[l].bdkv, Wd, K, 1}}});
+    if (hp.neighbor_embedding) specs.push_back(TableSpec{{TableLayer{P.Wn, P.bn, F, K, 3}}});
+    const int rc_tab = build_radial_tables(m, m->tabs, specs, P.means, P.betas, K, hp.cutoff_lower, hp.cutoff_upper);
+    if (rc_tab != TMDNET_OK) return rc_tab;
+    HIP_TRY(m, hipStreamSynchronize(nullptr));
+  }
   m->finalized = true;
   return TMDNET_OK;
 }
@@ -410,10 +427,38 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
   const double Nd = N, Pd = P, Fd = F, Ed = (double)m->lastE;
 
   // ---------------- forward
-  KR(CAT_ELEMENTWISE, Pd * K * 8, launch_radial(g, P, RadialParams{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper}, b.phi, b.dphi, b.C, b.dC, s));
+  const int n_dkv = Wd > 0 ? L : 0;
+  const bool use_tab = m->tabs.ok && (int64_t)P1 >= m->tab_min_pairs &&
+                       (int)m->tabs.tab.size() == n_dkv + (hp.neighbor_embedding ? 1 : 0) && !m->tabs.tab.empty();
+  if (use_tab) {
+    // all per-pair filters from the radial tables: one bucket sort of the pairs, one interpolation launch per row length
+    std::vector<const float*> tabs;
+    std::vector<float*> outs, douts;
+    for (int l = 0; l < n_dkv; ++l) {
+      tabs.push_back(m->tabs.tab[l]);
+      outs.push_back(b.dkv[l]);
+      douts.push_back(want_forces ? b.tkv[l] : nullptr);
+    }
+    const double nt = (double)m->tabs.T + 2;
+    KR(CAT_EDGE_TABLE, (Pd + 1) * (4.0 * Wd * n_dkv * (want_forces ? 2 : 1) + 24) + nt * 12.0 * Wd * n_dkv,
+       (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
+        n_dkv ? launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, Wd, n_dkv, tabs.data(), outs.data(), douts.data(),
+                                   b.skeys_s, b.svals_s, s)
+              : (void)0));
+    if (hp.neighbor_embedding) {
+      const float* t1[1] = {m->tabs.tab[n_dkv]};
+      float* o1[1] = {b.Wn};
+      float* d1[1] = {want_forces ? b.dWn : nullptr};
+      KR(CAT_EDGE_TABLE, (Pd + 1) * 4.0 * Fd * (want_forces ? 2 : 1) + nt * 12.0 * Fd,
+         launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, F, 1, t1, o1, d1, b.skeys_s, b.svals_s, s));
+    }
+  } else {
+    KR(CAT_ELEMENTWISE, Pd * K * 8, launch_radial(g, P, RadialParams{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper}, b.phi, b.dphi, b.C, b.dC, s));
+  }
   if (hp.neighbor_embedding) {
     EDGE(1);
-    if (want_forces) gemm_dual(s, 3, b.phi, b.dphi, K, W.Wn, W.bn, b.Wn, b.dWn, F, P1, F, K, b.C, b.dC, W.Wn_sb);
+    if (use_tab) {
+    } else if (want_forces) gemm_dual(s, 3, b.phi, b.dphi, K, W.Wn, W.bn, b.Wn, b.dWn, F, P1, F, K, b.C, b.dC, W.Wn_sb);
     else gemm(s, b.phi, K, W.Wn, K, W.bn, b.Wn, F, P1, F, K, GEMM_ROWSCALE, nullptr, 0, nullptr, 0, b.C);  // energies only: no tangents
     KR(CAT_SCATTER, Ed * Fd * 8, launch_et_nbr_embed(g, N, F, z, W.emb, W.embN, b.Wn, b.xcat, s));
     NODE();
@@ -429,7 +474,7 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.x[l], q.ln_w, q.ln_b, N, F, b.xt[l], b.xh[l], b.rstd[l], s));
     gemm(s, b.xt[l], F, q.Wqkv, F, q.bqkv, b.qkv[l], 5 * F, N, 5 * F, F);
     gemm(s, b.vec[l], F, q.Wvp, F, nullptr, b.vp[l], 3 * F, 3 * N, 3 * F, F);
-    if (Wd > 0) {
+    if (Wd > 0 && !use_tab) {
       EDGE(1);
       if (want_forces) gemm_dual(s, 1, b.phi, b.dphi, K, q.Wdkv, q.bdkv, b.dkv[l], b.tkv[l], Wd, P1, Wd, K, nullptr, nullptr, q.Wdkv_sb);
       else gemm(s, b.phi, K, q.Wdkv, K, q.bdkv, b.dkv[l], Wd, P1, Wd, K, GEMM_ACT_SILU);

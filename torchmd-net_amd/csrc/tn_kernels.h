@@ -152,9 +152,10 @@ void launch_radial_f64(int rows, double lo, double up, int T, bool mid, const fl
 void launch_dense_f64(const double* A, const double* A2, int lda, const float* W, const float* bias, int M, int N, int K, int kind,
                       const double* rs, const double* rs2, double* C, double* C2, int ldc, hipStream_t s);
 void launch_table_pack(const double* f, const double* sl, int T, int R, double h, float* tab, hipStream_t s);
-void launch_edge_tables(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
-                        float* const* outs, float* const* douts, float* C, float* dC, int* hist, unsigned* keys_s, int* vals_s,
-                        hipStream_t s);
+void launch_pair_buckets(const Graph& g, int Pcap, float lo, float up, int T, float* C, float* dC, int* hist, unsigned* keys_s,
+                         int* vals_s, hipStream_t s);
+void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
+                        float* const* outs, float* const* douts, const unsigned* keys_s, const int* vals_s, hipStream_t s);
 void launch_interp_list(const float* tab, const double* dist, int M, int R, int T, float lo, float up, float* out, float* dout,
                         hipStream_t s);
 

@@ -108,7 +108,17 @@ struct EdgeTables {
   bool ok = false;
   int T = 0;
   std::vector<float*> tab;
+  std::vector<int> R;                       // row length of each table
   double err_value = 0.0, err_slope = 0.0;  // measured at the interval midpoints, relative to the table's largest entry
+};
+// one table = a chain of dense layers applied to the radial basis; kind: 0 plain, 1 silu, 2 silu * C(d), 3 plain * C(d)
+struct TableLayer {
+  const float* W;  // [N][K] fp32 (device)
+  const float* b;  // [N] or null
+  int N, K, kind;
+};
+struct TableSpec {
+  std::vector<TableLayer> chain;  // the last layer's N is the table's row length
 };
 
 struct tmdnet_model {
@@ -132,7 +142,7 @@ struct tmdnet_model {
   std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
   DevParams P;
   EdgeTables tabs;
-  int64_t tab_min_pairs = 8192;  // below this many pairs the direct GEMMs are cheaper than sort + interpolation
+  int64_t tab_min_pairs = 1024;  // below this many pairs the direct (skinny) GEMMs are as fast as sort + interpolation (tools/latency_probe.sh)
   bool finalized = false;
   std::string err;
   // last-call bookkeeping for tmdnet_debug_tensor
@@ -206,6 +216,10 @@ void gemm_dual(hipStream_t s, int kind, const float* A, const float* A2, int64_t
                float* C2, int64_t ldc, int M, int N, int K, const float* rs = nullptr, const float* rs2 = nullptr,
                const uint16_t* Wsb = nullptr);
 Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total);
+// radial tables (tn_api.hip): fp64 build + midpoint verification; `out.ok` says whether they may be used
+int build_radial_tables(tmdnet_model* m, EdgeTables& out, const std::vector<TableSpec>& specs, const float* means, const float* betas,
+                        int K, double lo, double up);
+void free_radial_tables(EdgeTables& t);
 
 // Equivariant Transformer (tn_et_api.hip)
 int et_create(tmdnet_model* m, const tmdnet_et_hparams* hp);
