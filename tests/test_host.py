@@ -189,6 +189,35 @@ def test_install_as_torchmdnet_alias():
         from torchmdnet.models.model import create_model as cm  # noqa: F401
 
         assert cm is create_model
+        # the reference's adapters (TorchMD `External`, ASE `TMDNETCalculator`) are loaded from the reference's own file
+        # and bind to this package's load_model; `ase` is stubbed when it is not installed (it only provides a base class)
+        if R.reference_available():
+            import types
+
+            stubbed = []
+            try:
+                import ase.calculators.calculator  # noqa: F401
+            except ImportError:
+                for name in ("ase", "ase.calculators", "ase.calculators.calculator"):
+                    sys.modules[name] = types.ModuleType(name)
+                    stubbed.append(name)
+                sys.modules["ase.calculators.calculator"].Calculator = object
+                sys.modules["ase.calculators.calculator"].all_changes = []
+            try:
+                for k in [k for k in sys.modules if k == "torchmdnet" or k.startswith("torchmdnet.")]:
+                    del sys.modules[k]
+                done = torchmdnet_amd.install_as_torchmdnet(reference_root=R.REFERENCE_ROOT)
+                assert "torchmdnet.calculators" in done
+                calc = sys.modules["torchmdnet.calculators"]
+                from torchmdnet_amd.models.model import load_model as lm
+
+                assert calc.load_model is lm and hasattr(calc, "External") and hasattr(calc, "TMDNETCalculator")
+                # External with a module instead of a path: the adapter's own code runs up to the first model call
+                ext = calc.External(create_model(dict(W.TINY_ARGS)), torch.ones(1, 5, dtype=torch.long), device="cpu")
+                assert ext.n_atoms == 5 and ext.model.training is False
+            finally:
+                for name in stubbed:
+                    sys.modules.pop(name, None)
     finally:
         for k in [k for k in sys.modules if k == "torchmdnet" or k.startswith("torchmdnet.")]:
             del sys.modules[k]
