@@ -124,6 +124,41 @@ def lin(x, sd, key, bias=True):
     return Fn.linear(x, sd[key + ".weight"], sd[key + ".bias"] if bias else None)
 
 
+def tensor_embedding(sd: Dict[str, Tensor], hp: dict, z: Tensor, edge_index: Tensor, d: Tensor, rhat: Tensor, phi: Tensor) -> Tensor:
+    """TensorEmbedding.forward, tensornet.py:543-619 (shared by TensorNet and TensorNet2)."""
+    P = "representation_model."
+    F = hp["hidden_channels"]
+    lo, up = float(hp["cutoff_lower"]), float(hp["cutoff_upper"])
+    n = z.shape[0]
+    ei, ej = edge_index
+    pos_dtype = d.dtype
+    # ---- TensorEmbedding.forward, tensornet.py:543-619
+    T = P + "tensor_embedding."
+    Z = Fn.embedding(z, sd[T + "emb.weight"])
+    Zij = lin(Z.index_select(0, edge_index.t().reshape(-1)).view(-1, 2 * F), sd, T + "emb2")  # :526-541
+    C = cosine_cutoff(d, lo, up)
+    W = (C[:, None] * Zij)[:, None, :] * torch.stack(
+        [lin(phi, sd, T + "distance_proj1"), lin(phi, sd, T + "distance_proj2"), lin(phi, sd, T + "distance_proj3")],
+        dim=1,
+    )  # [E,3,F]  :558-567
+    # tensornet_embedding_message_passing, :405-445
+    I0 = torch.zeros(n, F, dtype=pos_dtype).index_add(0, ei, W[:, 0])
+    v0 = torch.zeros(n, 3, F, dtype=pos_dtype).index_add(0, ei, W[:, 1, None, :] * rhat[:, :, None])
+    outer = rhat[:, :, None] * rhat[:, None, :]
+    T0 = torch.zeros(n, 3, 3, F, dtype=pos_dtype).index_add(0, ei, W[:, 2, None, None, :] * outer[..., None])
+    A0 = skew(v0)
+    S0 = 0.5 * (T0 + T0.transpose(1, 2)) - T0.diagonal(dim1=1, dim2=2).mean(-1)[:, None, None, :] * _eye(T0)  # :133-141
+    X = I0[:, None, None, :] * _eye(T0) + A0 + S0
+    norm = Fn.layer_norm(tnorm(X), (F,), sd[T + "init_norm.weight"], sd[T + "init_norm.bias"])  # :589
+    norm = Fn.silu(lin(norm, sd, T + "linears_scalar.0"))
+    norm = Fn.silu(lin(norm, sd, T + "linears_scalar.1")).reshape(n, 3, F)  # :590-593
+    I1 = lin(I0, sd, T + "linears_tensor.0", bias=False) * norm[:, 0]
+    A1 = lin(A0, sd, T + "linears_tensor.1", bias=False) * norm[:, 1, None, None, :]
+    S1 = lin(S0, sd, T + "linears_tensor.2", bias=False) * norm[:, 2, None, None, :]
+    X = I1[:, None, None, :] * _eye(T0) + A1 + S1  # :617
+    return X
+
+
 # ----------------------------------------------------------------------------------------------
 # TensorNet representation: torchmdnet/models/tensornet.py:308-402 (OPT=False branch)
 # ----------------------------------------------------------------------------------------------
@@ -141,30 +176,8 @@ def tensornet_representation(sd: Dict[str, Tensor], hp: dict, z: Tensor, pos: Te
     is_self = ei == ej
     rhat = vec / torch.where(is_self, torch.ones_like(d), d)[:, None]  # :363-366
 
-    # ---- TensorEmbedding.forward, tensornet.py:543-619
-    T = P + "tensor_embedding."
-    Z = Fn.embedding(z, sd[T + "emb.weight"])
-    Zij = lin(Z.index_select(0, edge_index.t().reshape(-1)).view(-1, 2 * F), sd, T + "emb2")  # :526-541
+    X = tensor_embedding(sd, hp, z, edge_index, d, rhat, phi)
     C = cosine_cutoff(d, lo, up)
-    W = (C[:, None] * Zij)[:, None, :] * torch.stack(
-        [lin(phi, sd, T + "distance_proj1"), lin(phi, sd, T + "distance_proj2"), lin(phi, sd, T + "distance_proj3")],
-        dim=1,
-    )  # [E,3,F]  :558-567
-    # tensornet_embedding_message_passing, :405-445
-    I0 = torch.zeros(n, F, dtype=pos.dtype).index_add(0, ei, W[:, 0])
-    v0 = torch.zeros(n, 3, F, dtype=pos.dtype).index_add(0, ei, W[:, 1, None, :] * rhat[:, :, None])
-    outer = rhat[:, :, None] * rhat[:, None, :]
-    T0 = torch.zeros(n, 3, 3, F, dtype=pos.dtype).index_add(0, ei, W[:, 2, None, None, :] * outer[..., None])
-    A0 = skew(v0)
-    S0 = 0.5 * (T0 + T0.transpose(1, 2)) - T0.diagonal(dim1=1, dim2=2).mean(-1)[:, None, None, :] * _eye(T0)  # :133-141
-    X = I0[:, None, None, :] * _eye(T0) + A0 + S0
-    norm = Fn.layer_norm(tnorm(X), (F,), sd[T + "init_norm.weight"], sd[T + "init_norm.bias"])  # :589
-    norm = Fn.silu(lin(norm, sd, T + "linears_scalar.0"))
-    norm = Fn.silu(lin(norm, sd, T + "linears_scalar.1")).reshape(n, 3, F)  # :590-593
-    I1 = lin(I0, sd, T + "linears_tensor.0", bias=False) * norm[:, 0]
-    A1 = lin(A0, sd, T + "linears_tensor.1", bias=False) * norm[:, 1, None, None, :]
-    S1 = lin(S0, sd, T + "linears_tensor.2", bias=False) * norm[:, 2, None, None, :]
-    X = I1[:, None, None, :] * _eye(T0) + A1 + S1  # :617
     inter = {"edge_index": edge_index, "d": d, "rhat": rhat, "phi": phi, "X_embed": X}
 
     # ---- Interaction.forward x L, tensornet.py:729-814

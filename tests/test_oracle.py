@@ -208,3 +208,27 @@ def test_et_reference_golden_vector(golden_dir):
         E, F = fn(sd, hp, z, pos, batch)
         torch.testing.assert_close(E, g["pred"], atol=1e-5, rtol=1e-5, msg=name)
         torch.testing.assert_close(F, g["deriv"], atol=1e-5, rtol=1e-5, msg=name)
+
+
+@pytest.mark.parametrize("fixture", ["tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_tensornet2_oracle_matches_reference_fixture(golden_dir, fixture):
+    """oracle/tn2_torch.py (TensorNet2 + ScalarPlusWeightedCoulomb restatement) against fixtures written by the UNMODIFIED
+    reference (oracle/make_golden_tn2.py): energies, forces, every layer's tensor features and charge channels, fp64 1e-10;
+    all-to-all Coulomb with total charges on ragged molecules, and the reaction-field branch in a triclinic periodic box."""
+    from oracle import tn2_torch as T2
+    from oracle import tensornet_torch as T
+
+    g = torch.load(os.path.join(golden_dir, fixture))
+    hp = T2.hparams_from_args(g["args"])
+    sd64 = T.cast_state_dict(g["state_dict"], torch.float64)
+    box = None if g["box"] is None else g["box"].double()
+    inter = {}
+    pos = g["pos"].double().requires_grad_(True)
+    y = T2.energy(sd64, hp, g["z"], pos, g["batch"], box=box, q=g["q"].double(), inter=inter)
+    (dy,) = torch.autograd.grad([y], [pos], grad_outputs=[torch.ones_like(y)])
+    assert (y - g["E64"]).abs().max() < 1e-10 and (-dy - g["F64"]).abs().max() < 1e-10
+    for k, v in g["inter64"].items():
+        assert (inter[k] - v).abs().max() < 1e-10, k
+    # fp32 evaluation agrees with the reference's fp32 run to rounding
+    E, F = T2.energy_and_forces(g["state_dict"], hp, g["z"], g["pos"], g["batch"], box=g["box"], q=g["q"])
+    assert (E - g["E"]).abs().max() < 2e-5 * g["E"].abs().max() and (F - g["F"]).abs().max() < 2e-5 * g["F"].abs().max()
