@@ -72,8 +72,24 @@ typedef struct tmdnet_et_hparams {
   float cutoff_upper;
 } tmdnet_et_hparams;
 
+/* Hyper-parameters of TensorNet2 + ScalarPlusWeightedCoulomb (AceFF-2.0; reference
+ * torchmdnet/models/tensornet2.py:160-330, output_modules.py:344-441, model.py:106-152).  TensorNet with per-atom charge
+ * channels: a ChargePredict head after the embedding and after every layer (invariants -> LayerNorm -> MLP -> charge
+ * equilibration to the molecule's total charge `q`), the next layer's edge MLP takes [phi(d), c_i, c_j], and the head adds
+ * the damped pair Coulomb energy of all (num_layers + 1) * q_dim charge channels, weighted by `output_model.qweights`. */
+typedef struct tmdnet_tn2_hparams {
+  int32_t hidden_channels, num_layers, num_rbf, max_z, max_num_neighbors, group_o3, head_hidden, has_atomref;
+  int32_t q_dim;                 /* charge channels per ChargePredict head, (num_layers + 1) * q_dim <= 64 */
+  float cutoff_lower, cutoff_upper;
+  float coulomb_cutoff;          /* <= 0: all pairs of a molecule (no PBC); > 0: reaction field inside this cutoff */
+  float coulomb_epsilon_solvent; /* reaction-field dielectric constant (reference default 78.3) */
+} tmdnet_tn2_hparams;
+
 /* ---- lifecycle ------------------------------------------------------------------------------- */
 int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out);
+/* TensorNet2 handle: parameters by the reference's state-dict keys, every other entry point shared.  tmdnet_build_graph must
+ * be given the positions / box it should use for the Coulomb sum as well (it keeps the pointers until tmdnet_energy_forces). */
+int tmdnet_create_tn2(const tmdnet_tn2_hparams* hp, tmdnet_model** out);
 /* Equivariant Transformer handle: every other entry point (parameters by state-dict key, graph, energy_forces with
  * q = NULL, workspaces, profiling) is shared with the TensorNet handle. */
 int tmdnet_create_et(const tmdnet_et_hparams* hp, tmdnet_model** out);

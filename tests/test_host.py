@@ -292,3 +292,34 @@ def test_custom_ops_are_registered_with_fake_impls():
     model = create_model(dict(W.TINY_ARGS))
     clone = copy.deepcopy(model)
     assert clone._engine.op_key is None and model._engine.op_key is None  # keys are handed out on first use, never shared
+
+
+def test_tensornet2_host_mirror_matches_reference_init_and_keys(hip_lib):
+    """TensorNet2 + ScalarPlusWeightedCoulomb (AceFF-2.0): same seed -> same state dict as the unmodified reference (keys, shapes,
+    values), with and without a Coulomb cutoff; the C side expects exactly those tensors."""
+    args = dict(W.TINY_ARGS, model="tensornet2", output_model="ScalarPlusWeightedCoulomb", q_dim=8, q_weights=[1.0, 0.5, 2.0])
+    for extra in ({}, {"coulomb_cutoff": 6.0}):
+        a = dict(args, **extra)
+        torch.manual_seed(17)
+        mine = create_model(dict(a))
+        sd = mine.state_dict()
+        if R.reference_available():
+            mm = R.reference_model_module()
+            torch.manual_seed(17)
+            ref = mm.create_model(dict(a)).state_dict()
+            assert set(ref) == set(sd), set(ref) ^ set(sd)
+            for k, v in ref.items():
+                assert torch.equal(v, sd[k]), k
+        hp = mine._tn2_hparams()
+        handle = C.c_void_p()
+        assert hip_lib.tmdnet_create_tn2(C.byref(hp), C.byref(handle)) == 0
+        names = set()
+        for i in range(hip_lib.tmdnet_num_params(handle)):
+            numel = C.c_int64()
+            name = hip_lib.tmdnet_param_name(handle, i, C.byref(numel)).decode()
+            assert name in sd and sd[name].numel() == numel.value, name
+            names.add(name)
+        assert set(sd) - names <= {"representation_model.distance.box", "output_model.distance.box"}
+        hip_lib.tmdnet_destroy(handle)
+    with pytest.raises(NotImplementedError):
+        create_model(dict(args, output_model="Scalar"))

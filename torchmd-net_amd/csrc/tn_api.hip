@@ -124,7 +124,8 @@ void build_specs(tmdnet_model* m) {
   s.push_back({T + "init_norm.bias", F, 1});
   for (int l = 0; l < L; ++l) {
     const std::string Lp = R + "layers." + std::to_string(l) + ".";
-    const int64_t dims[3][2] = {{F, K}, {2 * F, F}, {3 * F, 2 * F}};
+    const int64_t K1 = m->tn2 ? K + 2 * m->tn2->hp.q_dim : K;  // TensorNet2: [phi ; c_i ; c_j]
+    const int64_t dims[3][2] = {{F, K1}, {2 * F, F}, {3 * F, 2 * F}};
     for (int k = 0; k < 3; ++k) {
       s.push_back({Lp + "linears_scalar." + std::to_string(k) + ".weight", dims[k][0], dims[k][1]});
       s.push_back({Lp + "linears_scalar." + std::to_string(k) + ".bias", dims[k][0], 1});
@@ -143,10 +144,27 @@ void build_specs(tmdnet_model* m) {
   s.push_back({"mean", 1, 1});
   s.push_back({"std", 1, 1});
   if (m->hp.has_atomref) s.push_back({"atomref", Z, 1});
+  if (m->tn2) {
+    const int qd = m->tn2->hp.q_dim;
+    for (int l = 0; l <= L; ++l) {
+      const std::string Cp = R + (l == 0 ? std::string("charge_predict_0.") : "charge_predicts." + std::to_string(l - 1) + ".");
+      s.push_back({Cp + "q_norm.weight", 3 * F, 1});
+      s.push_back({Cp + "q_norm.bias", 3 * F, 1});
+      s.push_back({Cp + "q_mlp.layers.0.weight", F, 3 * F});
+      s.push_back({Cp + "q_mlp.layers.0.bias", F, 1});
+      s.push_back({Cp + "q_mlp.layers.2.weight", F, F});
+      s.push_back({Cp + "q_mlp.layers.2.bias", F, 1});
+      s.push_back({Cp + "q_mlp.layers.4.weight", 2 * qd, F});
+      s.push_back({Cp + "q_mlp.layers.4.bias", 2 * qd, 1});
+    }
+    s.push_back({"output_model.qweights", (int64_t)(L + 1) * qd, 1});
+  }
 }
 
-void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], float* C, int N, int F, int flags = 0,
-                   float* pre = nullptr, const float* gates = nullptr) {
+}  // namespace
+
+void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], float* C, int N, int F, int flags, float* pre,
+                   const float* gates) {
   GemmArgs a{};
   a.A = A;
   a.C = C;
@@ -178,7 +196,7 @@ void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], floa
   launch_gemm(a, s);
 }
 
-}  // namespace
+
 Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   Carver c(ws);
   Graph g{};
@@ -442,7 +460,10 @@ int build_edge_tables(tmdnet_model* m) {
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers;
   const DevParams& W = m->P;
   std::vector<TableSpec> specs;
-  if (L + 1 <= 8) {
+  if (m->tn2) {  // TensorNet2: Q of the embedding and the pair block of every layer's first edge-MLP layer, M1a phi(d) + b1
+    specs.push_back(TableSpec{{TableLayer{W.Wdp, W.bdp, 3 * F, K, 0}}});
+    for (int l = 0; l < L; ++l) specs.push_back(TableSpec{{TableLayer{m->tn2->layer[l].M1a, W.layer[l].b1, F, K, 0}}});
+  } else if (L + 1 <= 8) {
     specs.push_back(TableSpec{{TableLayer{W.Wdp, W.bdp, 3 * F, K, 0}}});
     for (int l = 0; l < L; ++l) {
       const LayerP& q_ = W.layer[l];
@@ -476,6 +497,23 @@ int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out) {
       for (auto& e : m->ev_join) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     }
   }
+  *out = m;
+  return TMDNET_OK;
+}
+
+int tmdnet_create_tn2(const tmdnet_tn2_hparams* hp, tmdnet_model** out) {
+  if (!hp || !out) return TMDNET_ERR_INVALID;
+  if (hp->hidden_channels <= 0 || hp->num_layers < 0 || hp->num_rbf <= 0 || hp->max_z <= 0 || hp->head_hidden <= 0 ||
+      hp->max_num_neighbors <= 0 || !(hp->cutoff_upper > hp->cutoff_lower) || hp->q_dim <= 0 || hp->q_dim > 64 ||
+      (hp->num_layers + 1) * hp->q_dim > 64)
+    return TMDNET_ERR_INVALID;
+  tmdnet_model* m = new tmdnet_model();
+  m->hp = tmdnet_hparams{hp->hidden_channels, hp->num_layers, hp->num_rbf, hp->max_z, hp->max_num_neighbors, hp->group_o3,
+                         hp->head_hidden, hp->has_atomref, hp->cutoff_lower, hp->cutoff_upper};
+  m->tn2 = new Tn2Model();
+  m->tn2->hp = *hp;
+  if (const char* e = getenv("TMDNET_EDGE_TABLE_MIN_PAIRS")) m->tab_min_pairs = atoll(e);
+  build_specs(m);
   *out = m;
   return TMDNET_OK;
 }
@@ -514,6 +552,7 @@ int tmdnet_destroy(tmdnet_model* m) {
     (void)hipStreamDestroy(m->side);
   }
   free_radial_tables(m->tabs);
+  delete m->tn2;
   if (m->dev) (void)hipFree(m->dev);
   if (m->dev_sb) (void)hipFree(m->dev_sb);
   delete m;
@@ -606,6 +645,44 @@ int tmdnet_finalize_params(tmdnet_model* m) {
       putT(t + "VT" + std::to_string(k), h[Lp + "linears_tensor." + std::to_string(k) + ".weight"], F, F);
     }
   }
+  if (m->tn2) {  // TensorNet2: column blocks of linears_scalar.0, transposes for the reverse pass, ChargePredict heads
+    const int qd = m->tn2->hp.q_dim, K1 = K + 2 * qd;
+    for (int l = 0; l < L; ++l) {
+      const std::string Lp = R + "layers." + std::to_string(l) + ".", t = "l" + std::to_string(l) + ".";
+      const auto& w1 = h[Lp + "linears_scalar.0.weight"];
+      std::vector<float> a((size_t)F * K), bq((size_t)F * qd), cq((size_t)F * qd);
+      for (int f = 0; f < F; ++f) {
+        for (int k = 0; k < K; ++k) a[(size_t)f * K + k] = w1[(size_t)f * K1 + k];
+        for (int k = 0; k < qd; ++k) {
+          bq[(size_t)f * qd + k] = w1[(size_t)f * K1 + K + k];
+          cq[(size_t)f * qd + k] = w1[(size_t)f * K1 + K + qd + k];
+        }
+      }
+      put(t + "M1a", a);
+      put(t + "M1b", bq);
+      put(t + "M1c", cq);
+      putT(t + "M1bT", bq, F, qd);
+      putT(t + "M1cT", cq, F, qd);
+      putT(t + "M2T", h[Lp + "linears_scalar.1.weight"], 2 * F, F);
+      putT(t + "M3T", h[Lp + "linears_scalar.2.weight"], 3 * F, 2 * F);
+    }
+    for (int l = 0; l <= L; ++l) {
+      const std::string Cp = R + (l == 0 ? std::string("charge_predict_0.") : "charge_predicts." + std::to_string(l - 1) + "."),
+                        t = "cp" + std::to_string(l) + ".";
+      put(t + "ln_w", h[Cp + "q_norm.weight"]);
+      put(t + "ln_b", h[Cp + "q_norm.bias"]);
+      put(t + "W1", h[Cp + "q_mlp.layers.0.weight"]);
+      put(t + "b1", h[Cp + "q_mlp.layers.0.bias"]);
+      putT(t + "W1T", h[Cp + "q_mlp.layers.0.weight"], F, 3 * F);
+      put(t + "W2", h[Cp + "q_mlp.layers.2.weight"]);
+      put(t + "b2", h[Cp + "q_mlp.layers.2.bias"]);
+      putT(t + "W2T", h[Cp + "q_mlp.layers.2.weight"], F, F);
+      put(t + "W3", h[Cp + "q_mlp.layers.4.weight"]);
+      put(t + "b3", h[Cp + "q_mlp.layers.4.bias"]);
+      putT(t + "W3T", h[Cp + "q_mlp.layers.4.weight"], 2 * qd, F);
+    }
+    put("qweights", h["output_model.qweights"]);
+  }
   put("lnr_w", h[R + "out_norm.weight"]);
   put("lnr_b", h[R + "out_norm.bias"]);
   put("Lin", h[R + "linear.weight"]);
@@ -684,6 +761,7 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     std::vector<Img> imgs;
     std::vector<uint16_t> sb;
     auto add_sb = [&](const std::string& key, int64_t n, int64_t k) {  // packed matrix `key` is [n][k] row-major
+      if ((k & 15) || (n & 3)) return;  // shapes the split kernels do not take stay on the fp32-MFMA kernels
       const size_t o = sb.size();
       sb.resize(o + split_weight_elems(n, k));
       split_weight_tiles(pk.buf.data() + off.at(key), n, k, sb.data() + o);
@@ -700,12 +778,34 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     add_sb("L2T", 2 * F, 3 * F);
     for (int l = 0; l < L; ++l) {
       const std::string t = "l" + std::to_string(l) + ".";
-      add_sb(t + "M0", F, K);
+      add_sb(t + "M0", F, m->tn2 ? K + 2 * m->tn2->hp.q_dim : K);
       add_sb(t + "M1", 2 * F, F);
       add_sb(t + "M2", 3 * F, 2 * F);
       for (int k = 0; k < 6; ++k) {
         add_sb(t + "V" + std::to_string(k), F, F);
         add_sb(t + "VT" + std::to_string(k), F, F);
+      }
+    }
+    if (m->tn2) {
+      const int qd = m->tn2->hp.q_dim;
+      for (int l = 0; l < L; ++l) {
+        const std::string t = "l" + std::to_string(l) + ".";
+        add_sb(t + "M1a", F, K);
+        add_sb(t + "M1b", F, qd);
+        add_sb(t + "M1c", F, qd);
+        add_sb(t + "M1bT", qd, F);
+        add_sb(t + "M1cT", qd, F);
+        add_sb(t + "M2T", F, 2 * F);
+        add_sb(t + "M3T", 2 * F, 3 * F);
+      }
+      for (int l = 0; l <= L; ++l) {
+        const std::string t = "cp" + std::to_string(l) + ".";
+        add_sb(t + "W1", F, 3 * F);
+        add_sb(t + "W1T", 3 * F, F);
+        add_sb(t + "W2", F, F);
+        add_sb(t + "W2T", F, F);
+        add_sb(t + "W3", 2 * qd, F);
+        add_sb(t + "W3T", F, 2 * qd);
       }
     }
     add_sb("Lin", F, 3 * F);
@@ -720,11 +820,30 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     HIP_TRY(m, hipMemcpy(m->dev_sb, sb.data(), sb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     m->sb_of.clear();
     for (const auto& im : imgs) m->sb_of[m->dev + off.at(im.key)] = m->dev_sb + im.o;
-    P.Wdp_sb = m->sb_of.at(P.Wdp);
+    auto sb_or_null = [&](const float* w) -> const uint16_t* {
+      auto it = m->sb_of.find(w);
+      return it == m->sb_of.end() ? nullptr : it->second;
+    };
+    P.Wdp_sb = sb_or_null(P.Wdp);
     for (int l = 0; l < L; ++l) {
-      P.layer[l].M_sb[0] = m->sb_of.at(P.layer[l].M1);
-      P.layer[l].M_sb[1] = m->sb_of.at(P.layer[l].M2);
-      P.layer[l].M_sb[2] = m->sb_of.at(P.layer[l].M3);
+      P.layer[l].M_sb[0] = sb_or_null(P.layer[l].M1);
+      P.layer[l].M_sb[1] = sb_or_null(P.layer[l].M2);
+      P.layer[l].M_sb[2] = sb_or_null(P.layer[l].M3);
+    }
+    if (m->tn2) {
+      Tn2Model& t2 = *m->tn2;
+      t2.layer.resize(L);
+      t2.cp.resize(L + 1);
+      for (int l = 0; l < L; ++l) {
+        const std::string t = "l" + std::to_string(l) + ".";
+        t2.layer[l] = Tn2LayerP{D(t + "M1a"), D(t + "M1b"), D(t + "M1c"), D(t + "M1bT"), D(t + "M1cT"), D(t + "M2T"), D(t + "M3T")};
+      }
+      for (int l = 0; l <= L; ++l) {
+        const std::string t = "cp" + std::to_string(l) + ".";
+        t2.cp[l] = CpParams{D(t + "ln_w"), D(t + "ln_b"), D(t + "W1"), D(t + "b1"), D(t + "W1T"), D(t + "W2"),
+                            D(t + "b2"), D(t + "W2T"), D(t + "W3"), D(t + "b3"), D(t + "W3T")};
+      }
+      t2.qweights = D("qweights");
     }
   }
   P.Utab = m->dev + off.at("Utab");
@@ -791,6 +910,9 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   set_cell(g, m, cell);
   m->graph_is_cell = cell;
   m->graph_has_z = z != nullptr;
+  m->g_pos = pos;
+  m->g_box = box;
+  m->g_box_mode = box_mode;
   CurScope cur_(m);
   {
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
@@ -843,6 +965,9 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
   set_cell(g, m, cell);
   m->graph_is_cell = cell;
   m->graph_has_z = z != nullptr;
+  m->g_pos = pos;
+  m->g_box = box;
+  m->g_box_mode = box_mode;
   CurScope cur_(m);
   {
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
@@ -900,6 +1025,7 @@ int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64
   (void)n_edges;
   if (n_pairs < 0) n_pairs = ((int64_t)m->hp.max_num_neighbors * n_atoms) / 2 + 1;  // static mode: pair capacity
   if (m->et) return et_forward_workspace_bytes(m, n_atoms, n_mol, n_pairs, want_forces, bytes);
+  if (m->tn2) return tn2_forward_workspace_bytes(m, n_atoms, n_mol, n_pairs, n_edges, want_forces, bytes);
   carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes);
   return TMDNET_OK;
 }
@@ -929,6 +1055,19 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     }
     if (!z) return fail(m, TMDNET_ERR_INVALID, "z is required (here or in tmdnet_build_graph)");
     return et_energy_forces(m, s, g, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, want_forces, energy, forces);
+  }
+  if (m->tn2) {
+    CurScope cur_(m);
+    if (m->graph_has_z) {
+      z = g.z_c;
+    } else if (m->graph_is_cell) {
+      set_cell(g, m, true);
+      launch_permute_z(g, z, (int)n_atoms, s);
+      z = g.z_s;
+    }
+    if (!z) return fail(m, TMDNET_ERR_INVALID, "z is required (here or in tmdnet_build_graph)");
+    if (m->graph_is_cell) set_cell(g, m, true);
+    return tn2_energy_forces(m, s, g, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, q, want_forces, energy, forces);
   }
   // n_pairs >= 0: exact count read back by tmdnet_build_graph (launch grids sized exactly);
   // n_pairs <  0: static mode, grids and workspace sized by the pair capacity, true count read on the device
@@ -1236,6 +1375,7 @@ int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* 
   else if (nm == "Q") { src = b.Q; n = P1 * 3 * F; }
   else if (nm == "u0") { src = b.u0; n = N * 9 * F; }
   else if (nm == "G_embed") { src = b.G; n = N * 9 * F; }
+  else if (nm == "charges" && m->tn2) { src = m->tn2_last_chg; n = N * (int64_t)(m->hp.num_layers + 1) * m->tn2->hp.q_dim; }
   else return fail(m, TMDNET_ERR_INVALID, "unknown debug tensor");
   if (!src || numel != n) return fail(m, TMDNET_ERR_INVALID, "debug tensor size mismatch: expected " + std::to_string(n));
   HIP_TRY(m, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s));

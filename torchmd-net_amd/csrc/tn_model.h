@@ -102,6 +102,20 @@ struct Profiler {
 
 struct EtModel;  // tn_et_api.hip
 
+// TensorNet2 extras (tn_tn2_api.hip); everything TensorNet has lives in DevParams
+struct CpParams {  // one ChargePredict head (tensornet2.py:49-66): LayerNorm(3F) + MLP 3F -> F -> F -> 2 q_dim
+  const float *ln_w, *ln_b, *W1, *b1, *W1T, *W2, *b2, *W2T, *W3, *b3, *W3T;
+};
+struct Tn2LayerP {  // blocks of linears_scalar.0 = [M1a (F x K) | M1b (F x q) | M1c (F x q)] and transposes for the reverse pass
+  const float *M1a, *M1b, *M1c, *M1bT, *M1cT, *M2T, *M3T;
+};
+struct Tn2Model {
+  tmdnet_tn2_hparams hp;
+  std::vector<CpParams> cp;      // num_layers + 1
+  std::vector<Tn2LayerP> layer;
+  const float* qweights = nullptr;  // [(L + 1) q_dim]
+};
+
 // radial tables of the per-pair functions (tn_edge_table.hip): built by tmdnet_finalize_params, verified against the direct
 // evaluation; tab[0] = distance projections Q (embedding), tab[1 + l] = edge MLP of layer l; each [T + 2][2][3F]
 struct EdgeTables {
@@ -130,6 +144,11 @@ struct tmdnet_model {
   hipEvent_t ev_fork = nullptr;
   std::vector<hipEvent_t> ev_join;
   EtModel* et = nullptr;  // non-null: Equivariant Transformer handle (hp then only carries what the graph phase reads)
+  Tn2Model* tn2 = nullptr;  // non-null: TensorNet2 handle (hp carries the shared TensorNet hyper-parameters)
+  // geometry of the last graph build (caller-owned device pointers; the TensorNet2 Coulomb head needs positions again)
+  const float* g_pos = nullptr;
+  const float* g_box = nullptr;
+  int g_box_mode = 0;
   Profiler prof;
   int64_t lastE = 0;
   int cell_n[3] = {0, 0, 0};  // cell grid set by tmdnet_set_cell_grid (0 = brute force, < 0 = from the box, on the device)
@@ -149,6 +168,7 @@ struct tmdnet_model {
   FwdBuffers last{};
   int64_t lastN = 0, lastP = 0;
   bool has_last = false;
+  const float* tn2_last_chg = nullptr;  // TensorNet2: [N, (L + 1) q_dim] charge channels of the last call (debug tensor "charges")
 };
 
 
@@ -216,10 +236,20 @@ void gemm_dual(hipStream_t s, int kind, const float* A, const float* A2, int64_t
                float* C2, int64_t ldc, int M, int N, int K, const float* rs = nullptr, const float* rs2 = nullptr,
                const uint16_t* Wsb = nullptr);
 Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total);
+// the three weight matrices act on the channel axis of the 1 + 3 + 5 irreducible components: one grouped launch, 9 groups
+void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], float* C, int N, int F, int flags = 0, float* pre = nullptr,
+                   const float* gates = nullptr);
 // radial tables (tn_api.hip): fp64 build + midpoint verification; `out.ok` says whether they may be used
 int build_radial_tables(tmdnet_model* m, EdgeTables& out, const std::vector<TableSpec>& specs, const float* means, const float* betas,
                         int K, double lo, double up);
 void free_radial_tables(EdgeTables& t);
+
+// TensorNet2 (tn_tn2_api.hip)
+int tn2_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int64_t n_edges, int32_t want_forces,
+                                size_t* bytes);
+int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
+                      int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q, int32_t want_forces, float* energy,
+                      float* forces);
 
 // Equivariant Transformer (tn_et_api.hip)
 int et_create(tmdnet_model* m, const tmdnet_et_hparams* hp);

@@ -36,6 +36,13 @@ class EtHParams(C.Structure):
                [("cutoff_lower", C.c_float), ("cutoff_upper", C.c_float)]
 
 
+class Tn2HParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("hidden_channels", "num_layers", "num_rbf", "max_z", "max_num_neighbors", "group_o3",
+                                         "head_hidden", "has_atomref", "q_dim")] + \
+               [("cutoff_lower", C.c_float), ("cutoff_upper", C.c_float), ("coulomb_cutoff", C.c_float),
+                ("coulomb_epsilon_solvent", C.c_float)]
+
+
 _lib = None
 
 
@@ -53,6 +60,7 @@ def lib():
     vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
     L.tmdnet_create.argtypes = [C.POINTER(HParams), C.POINTER(vp)]
     L.tmdnet_create_et.argtypes = [C.POINTER(EtHParams), C.POINTER(vp)]
+    L.tmdnet_create_tn2.argtypes = [C.POINTER(Tn2HParams), C.POINTER(vp)]
     L.tmdnet_destroy.argtypes = [vp]
     L.tmdnet_last_error.argtypes = [vp]
     L.tmdnet_last_error.restype = C.c_char_p

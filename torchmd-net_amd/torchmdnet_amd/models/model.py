@@ -80,7 +80,17 @@ def create_model(args, prior_model=None, mean=None, std=None):
             static_shapes=args["static_shapes"],
             **shared_args,
         )
-    elif args["model"] in ("graph-network", "transformer", "tensornet2"):
+    elif args["model"] == "tensornet2":
+        from torchmdnet_amd.models.tensornet2 import TensorNet2
+
+        representation_model = TensorNet2(
+            equivariance_invariance_group=args["equivariance_invariance_group"],
+            static_shapes=args["static_shapes"],
+            q_dim=args.get("q_dim", 0),
+            output_charges=True if "Coul" in args["output_model"] else False,
+            **shared_args,
+        )
+    elif args["model"] in ("graph-network", "transformer"):
         raise NotImplementedError(f'architecture {args["model"]} has no MI355X-native path in this build (SURVEY.md 8(f))')
     else:
         raise ValueError(f'Unknown architecture: {args["model"]}')
@@ -93,8 +103,21 @@ def create_model(args, prior_model=None, mean=None, std=None):
     if args["prior_model"] and prior_model is None:
         prior_model = create_prior_models(args)
 
+    if args["output_model"] == "ScalarPlusWeightedCoulomb":
+        if args["model"] != "tensornet2":
+            raise NotImplementedError("ScalarPlusWeightedCoulomb needs the charge channels of TensorNet2")
+        output_model = output_modules.ScalarPlusWeightedCoulomb(
+            args["embedding_dimension"], activation=args["activation"], reduce_op=args["reduce_op"], dtype=dtype,
+            static_shapes=args.get("static_shapes", False), num_hidden_layers=args.get("output_mlp_num_layers", 0),
+            num_layers=args["num_layers"], q_dim=args.get("q_dim", 0), q_weights=args.get("q_weights", []),
+            coulomb_cutoff=args.get("coulomb_cutoff", None), coulomb_max_num_neighbors=args.get("coulomb_max_num_neighbors", None),
+            coulomb_neighbor_strategy=args.get("coulomb_neighbor_strategy", "brute"))
+        return TorchMD_Net(representation_model, output_model, prior_model=prior_model, mean=mean, std=std,
+                           derivative=args["derivative"], dtype=dtype)
+    if args["model"] == "tensornet2":
+        raise NotImplementedError("TensorNet2 has a HIP path with output_model: ScalarPlusWeightedCoulomb only")
     if args["output_model"] not in ("Scalar", "EquivariantScalar"):
-        raise NotImplementedError(f'output_model {args["output_model"]} has no HIP path (Scalar only)')
+        raise NotImplementedError(f'output_model {args["output_model"]} has no HIP path (Scalar, ScalarPlusWeightedCoulomb)')
     if is_equivariant:  # reference model.py:134-135: "Scalar" on an equivariant model is EquivariantScalar
         output_model = output_modules.EquivariantScalar(
             args["embedding_dimension"], activation=args["activation"], reduce_op=args["reduce_op"], dtype=dtype,
@@ -177,6 +200,10 @@ def load_model(filepath, args=None, device="cpu", return_std=False, **kwargs):
         state_dict = {re.sub(pat, rep, k): v for k, v in state_dict.items()}
     if "representation_model.distance.box" not in state_dict:
         state_dict["representation_model.distance.box"] = torch.zeros((3, 3), device="cpu")
+
+    if ("coulomb_cutoff" in args and args["coulomb_cutoff"] is not None and "output_model.distance.box" not in state_dict
+            and hasattr(model.output_model, "distance")):  # reference model.py:283-291
+        state_dict["output_model.distance.box"] = torch.zeros((3, 3), device="cpu")
 
     is_old = "check_errors" in ckpt.get("hyper_parameters", {})
     if kwargs.get("compatibility_load", is_old):
@@ -315,6 +342,27 @@ class TorchMD_Net(nn.Module):
     def _is_et(self) -> bool:
         return type(self.representation_model).__name__ == "TorchMD_ET"
 
+    def _is_tn2(self) -> bool:
+        return type(self.representation_model).__name__ == "TensorNet2"
+
+    def _tn2_hparams(self) -> _C.Tn2HParams:
+        rm, om = self.representation_model, self.output_model
+        hp = _C.Tn2HParams()
+        hp.hidden_channels = rm.hidden_channels
+        hp.num_layers = rm.num_layers
+        hp.num_rbf = rm.num_rbf
+        hp.max_z = rm.max_z
+        hp.max_num_neighbors = rm.max_num_neighbors
+        hp.group_o3 = 1 if rm.equivariance_invariance_group == "O(3)" else 0
+        hp.head_hidden = om.output_network.layers[0].out_features
+        hp.has_atomref = 1 if self._atomref_table() is not None else 0
+        hp.q_dim = rm.q_dim
+        hp.cutoff_lower = float(rm.cutoff_lower)
+        hp.cutoff_upper = float(rm.cutoff_upper)
+        hp.coulomb_cutoff = -1.0 if om.cutoff is None else float(om.cutoff)
+        hp.coulomb_epsilon_solvent = float(om.epsilon_solvent)
+        return hp
+
     def _et_hparams(self) -> _C.EtHParams:
         rm = self.representation_model
         hp = _C.EtHParams()
@@ -374,6 +422,9 @@ class TorchMD_Net(nn.Module):
         if self._is_et():
             hp = self._et_hparams()
             rc = L.tmdnet_create_et(C.byref(hp), C.byref(handle))
+        elif self._is_tn2():
+            hp = self._tn2_hparams()
+            rc = L.tmdnet_create_tn2(C.byref(hp), C.byref(handle))
         else:
             hp = self._hparams()
             rc = L.tmdnet_create(C.byref(hp), C.byref(handle))
