@@ -19,7 +19,8 @@ Prints ONE JSON line (rank 0).  `roofline` = the dominant KERNEL (one kernel on 
 measured live with HIP events recorded by the library on the launch stream around every launch during the timed
 region, with the class average beside it; `roofline_scatter` = the CSR message sweeps against the HBM peak;
 `cpu_baseline` = the oracle (a restatement of the reference's PyTorch CPU path) timed on this host; `et_c4` and
-`water10k` = BASELINE configs[3] / configs[4] with their own dominant-kernel rooflines; `md_single_system` = ns/day of
+`water10k` = BASELINE configs[3] / configs[4] with their own dominant-kernel rooflines; `tensornet2` = the AceFF-2.0
+architecture at the same batch; `md_single_system` = ns/day of
 a HIP-graph-replayed 64-atom system.
 """
 import argparse
@@ -240,6 +241,27 @@ def water10k_leg(dev, L, steps=8, warmup=3, dt_fs=1.0):
                         "cell-list neighbours rebuilt every step, E+F",
             "atoms": n, "pairs": model._engine.counts[0], "cell_grid": grid[:3], "cell_list": bool(grid[3]),
             "ms_per_step": dt * 1e3, "ns_per_day": 86400.0 / dt * dt_fs * 1e-6, "dt_fs": dt_fs,
+            "roofline": roofline_of(rec, cls, label), "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
+
+
+def tn2_leg(dev, L, steps=8, warmup=3):
+    """TensorNet2 + ScalarPlusWeightedCoulomb (the AceFF-2.0 architecture) at the reference test's sizes
+    (tests/test_staticshapes.py:9-32: F=128, L=2, K=32, q_dim=16, rc=5), S-mol64 256 x 64 atoms, E+F, random-init."""
+    import torch
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(0)
+    args = dict(W.C2_ARGS, model="tensornet2", output_model="ScalarPlusWeightedCoulomb", q_dim=16, q_weights=[1.0, 1.0, 1.0])
+    model = create_model(dict(args)).to(dev)
+    z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS)
+    z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
+    dt, classes, groups, (e, f) = timed_leg(model, L, dev, lambda: model.energy_and_forces(z, pos, batch, None, None, N_MOL), steps, warmup)
+    assert torch.isfinite(e).all() and torch.isfinite(f).all()
+    (cls, label), rec = dominant(groups)
+    return {"workload": "TensorNet2 + ScalarPlusWeightedCoulomb F=128 L=2 K=32 q_dim=16 rc=5.0 (all-to-all Coulomb), S-mol64 256 x 64 atoms, "
+                        "E+F, random-init (seed 0)",
+            "ms_per_step": dt * 1e3, "molecules_per_s": N_MOL / dt, "pairs": model._engine.counts[0],
             "roofline": roofline_of(rec, cls, label), "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
 
 
@@ -485,7 +507,7 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 out["md_single_system"] = {"error": repr(exc)}
         if world == 1 and not a.no_aux:
-            for key, leg in (("et_c4", et_c4_leg), ("water10k", water10k_leg)):
+            for key, leg in (("et_c4", et_c4_leg), ("water10k", water10k_leg), ("tensornet2", tn2_leg)):
                 try:
                     out[key] = leg(dev, L)
                 except Exception as exc:  # noqa: BLE001
