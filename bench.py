@@ -177,7 +177,10 @@ def md_latency(model, args_dict, dev, steps=300, dt_fs=1.0):
             "ns_per_day": 86400.0 / dt * dt_fs * 1e-6, "dt_fs": dt_fs}
 
 
-def timed_leg(model, L, dev, step, steps, warmup):
+AUX_GROUPS = {}  # leg name -> per-kernel groups of its profiled step (written by --breakdown)
+
+
+def timed_leg(model, L, dev, step, steps, warmup, name=None):
     """warm-up, one fully profiled step (per-kernel groups), `steps` timed steps.  Returns (s per step, classes, groups)."""
     import torch
 
@@ -188,6 +191,8 @@ def timed_leg(model, L, dev, step, steps, warmup):
     profile_begin(model, L)
     step()
     classes, groups = profile_records(model, L, sp)
+    if name:
+        AUX_GROUPS[name] = {f"{c}: {l}": r for (c, l), r in groups.items()}
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -208,7 +213,8 @@ def et_c4_leg(dev, L, steps=8, warmup=3):
     model = create_model(dict(W.C4_ARGS)).to(dev)
     z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS)
     z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
-    dt, classes, groups, (e, f) = timed_leg(model, L, dev, lambda: model.energy_and_forces(z, pos, batch, None, None, N_MOL), steps, warmup)
+    dt, classes, groups, (e, f) = timed_leg(model, L, dev, lambda: model.energy_and_forces(z, pos, batch, None, None, N_MOL), steps, warmup,
+                                             name="et_c4")
     assert torch.isfinite(e).all() and torch.isfinite(f).all()
     (cls, label), rec = dominant(groups)
     return {"workload": "BASELINE configs[3]: ET-SPICE.yaml hyper-parameters, S-mol64 256 x 64 atoms, E+F, random-init (seed 0)",
@@ -233,7 +239,8 @@ def water10k_leg(dev, L, steps=8, warmup=3, dt_fs=1.0):
     z, pos, box = z.to(dev), pos.to(dev), box.to(dev)
     batch = torch.zeros_like(z)
     n = int(z.shape[0])
-    dt, classes, groups, (e, f) = timed_leg(model, L, dev, lambda: model.energy_and_forces(z, pos, batch, box, None, 1), steps, warmup)
+    dt, classes, groups, (e, f) = timed_leg(model, L, dev, lambda: model.energy_and_forces(z, pos, batch, box, None, 1), steps, warmup,
+                                             name="water10k")
     assert torch.isfinite(e).all() and torch.isfinite(f).all()
     grid = model.cell_grid(n)
     (cls, label), rec = dominant(groups)
@@ -256,7 +263,8 @@ def tn2_leg(dev, L, steps=8, warmup=3):
     model = create_model(dict(args)).to(dev)
     z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS)
     z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
-    dt, classes, groups, (e, f) = timed_leg(model, L, dev, lambda: model.energy_and_forces(z, pos, batch, None, None, N_MOL), steps, warmup)
+    dt, classes, groups, (e, f) = timed_leg(model, L, dev, lambda: model.energy_and_forces(z, pos, batch, None, None, N_MOL), steps, warmup,
+                                             name="tensornet2")
     assert torch.isfinite(e).all() and torch.isfinite(f).all()
     (cls, label), rec = dominant(groups)
     return {"workload": "TensorNet2 + ScalarPlusWeightedCoulomb F=128 L=2 K=32 q_dim=16 rc=5.0 (all-to-all Coulomb), S-mol64 256 x 64 atoms, "
@@ -521,7 +529,7 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(a.breakdown)), exist_ok=True)
             with open(a.breakdown, "w") as fh:
                 json.dump({"one_step_profiled_ms": classes, "kernels": {f"{c}: {lab}": v for (c, lab), v in groups.items()},
-                           "step_ms": el / a.steps * 1e3}, fh, indent=1)
+                           "step_ms": el / a.steps * 1e3, "aux_legs": AUX_GROUPS}, fh, indent=1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
