@@ -500,8 +500,9 @@ def test_edge_tables_equal_direct_evaluation(hip_lib, golden_dir):
     z, pos, batch, q = g["z"].cuda(), g["pos"].cuda(), g["batch"].cuda(), g["q"].cuda()
     assert model.engine_info("edge_table_T") >= 8192  # built and verified at upload
     assert model.engine_info("edge_table_err_value") < 1e-6 and model.engine_info("edge_table_err_slope") < 2e-5
-    Ed, Fd = model(z, pos, batch, q=q)  # 2 molecules: far below edge_table_min_pairs -> direct GEMMs
-    model.set_engine_option("edge_table_min_pairs", 0)
+    model.set_engine_option("edge_table_min_pairs", 10 ** 12)  # the value + tangent GEMMs on the pair rows
+    Ed, Fd = model(z, pos, batch, q=q)
+    model.set_engine_option("edge_table_min_pairs", 0)  # the tables (a pair list this small: the one-launch interpolation)
     Et, Ft = model(z, pos, batch, q=q)
     assert rel_err(Et, Ed) < 2e-6 and rel_err(Ft, Fd) < 2e-6
     assert rel_err(Et.cpu(), g["E"]) < REL and rel_err(Ft.cpu(), g["F"]) < REL

@@ -977,13 +977,16 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
       launch_scan_counts(g, (int)n_atoms, s);
       launch_cell_phase2(g, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
       launch_nbr_link_wave(g, (int)n_atoms, s);
+    } else if (graph_small_ok((int)n_atoms)) {
+      launch_graph_small(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper, true, z,
+                         m->hp.max_z, s);
     } else {
       launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
                                 true, s);
       launch_graph_build_phase2(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper, true,
                                 s);
     }
-    if (z) launch_prepare_z(g, z, cell ? g.perm : nullptr, (int)n_atoms, m->hp.max_z, s);
+    if (z && (cell || !graph_small_ok((int)n_atoms))) launch_prepare_z(g, z, cell ? g.perm : nullptr, (int)n_atoms, m->hp.max_z, s);
   }
   m->lastE = ecap;
   HIP_TRY(m, hipGetLastError());
@@ -1124,7 +1127,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     const double rowB = 12.0 * Fd;
     KR(CAT_EDGE_TABLE, (Pd + 1) * (rowB * (L + 1) * (want_forces ? 2 : 1) + 24) + (double)(m->tabs.T + 2) * 2 * rowB * (L + 1),
        (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
-        launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1 + L, tabs, outs, douts, b.skeys_s, b.svals_s, s)));
+        launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1 + L, tabs, outs, douts, b.skeys_s, b.svals_s, s, b.C,
+                           b.dC)));
   } else {
     // ---- radial functions per pair
     RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};

@@ -25,6 +25,8 @@
 // lower cutoff is set) has its own exactly evaluated row.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "tn_common.h"
 #include "tn_kernels.h"
 
@@ -271,10 +273,68 @@ __global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const un
   }
 }
 
+// Few pairs (single molecules, MD stepping): the pair-order machinery above costs five launches and a serial walk of 32
+// pairs per thread group for nothing - the whole pair list is smaller than one table.  One launch instead: a thread group
+// per pair computes the cutoff, finds its grid interval and reads its four table rows (L2).  Same arithmetic on the same
+// distance bits as k_edge_interp: bit-identical outputs.
+template <int NT>
+__global__ __launch_bounds__(256) void k_edge_interp_direct(Graph g, int Pcap, InterpArgs a, int R4, int T, float lo, float up, float h,
+                                                           float inv_h, float* __restrict__ C, float* __restrict__ dC) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int groups = blockDim.x / R4;
+  const int grp = threadIdx.x / R4, c4 = threadIdx.x - grp * R4;
+  if (grp >= groups) return;
+  const int p = blockIdx.x * groups + grp;
+  if (p > Pcap) return;
+  const int P = g.counts[0];
+  if (p > P || g.counts[2]) return;
+  const int R = 4 * R4;
+  const float d = p < P ? g.pd[p] : 0.f;  // p == P: the self pair
+  if (C && c4 == 0) {
+    float c, dc;
+    cosine_cutoff(d, lo, up, c, dc);
+    C[p] = c;
+    dC[p] = dc;
+  }
+  if (p == P) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float* row = a.tab[t] + (int64_t)(T + 1) * 3 * R + 4 * c4;
+      *reinterpret_cast<f4*>(a.out[t] + (int64_t)p * R + 4 * c4) = *reinterpret_cast<const f4*>(row);
+      if (a.dout[t]) *reinterpret_cast<f4*>(a.dout[t] + (int64_t)p * R + 4 * c4) = *reinterpret_cast<const f4*>(row + R);
+    }
+    return;
+  }
+  const float x = (d - lo) * inv_h;
+  int k = (int)x;
+  k = k < 0 ? 0 : (k > T - 1 ? T - 1 : k);
+  const float t = x - (float)k, t2 = t * t, t3 = t2 * t;
+  const float aD = (3.f * t2 - 2.f * t3) * h, a0 = (t3 - 2.f * t2 + t) * h, a1 = (t3 - t2) * h;
+  const float bD = 6.f * t - 6.f * t2, b0 = 3.f * t2 - 4.f * t + 1.f, b1 = 3.f * t2 - 2.f * t;
+#pragma unroll
+  for (int tb = 0; tb < NT; ++tb) {
+    const float* row = a.tab[tb] + (int64_t)k * 3 * R + 4 * c4;
+    const f4 f0 = *reinterpret_cast<const f4*>(row), sl0 = *reinterpret_cast<const f4*>(row + R);
+    const f4 D = *reinterpret_cast<const f4*>(row + 2 * R), sl1 = *reinterpret_cast<const f4*>(row + 4 * R);
+    *reinterpret_cast<f4*>(a.out[tb] + (int64_t)p * R + 4 * c4) = f0 + (aD * D + a0 * sl0 + a1 * sl1);
+    if (a.dout[tb]) *reinterpret_cast<f4*>(a.dout[tb] + (int64_t)p * R + 4 * c4) = bD * D + b0 * sl0 + b1 * sl1;
+  }
+}
+
+// pair capacities up to this take the one-launch path (no bucketing)
+bool edge_interp_direct(int Pcap) {
+  static const int lim = [] {
+    const char* e = getenv("TMDNET_EDGE_DIRECT_MAX");
+    return e ? atoi(e) : 16384;
+  }();
+  return Pcap + 1 <= lim;
+}
+
 // C, dC per pair and the pairs in grid-interval order.  hist: [T + 2] ints; keys_s / vals_s: [Pcap + 1] each
 void launch_pair_buckets(const Graph& g, int Pcap, float lo, float up, int T, float* C, float* dC, int* hist, unsigned* keys_s,
                          int* vals_s, hipStream_t s) {
   const int n = Pcap + 1;
+  if (edge_interp_direct(Pcap)) return;  // C, dC come from the first launch_edge_interp of the step
   const float h0 = (up - lo) / (float)T, inv_h0 = 1.0f / h0;
   hipLaunchKernelGGL(k_fill_int, dim3(cdive(T + 2, 256)), dim3(256), 0, s, hist, 0, T + 2);
   hipLaunchKernelGGL(k_pair_cutoff_hist, dim3(cdive(n, 256)), dim3(256), 0, s, g, Pcap, lo, up, inv_h0, T, C, dC, hist);
@@ -284,7 +344,8 @@ void launch_pair_buckets(const Graph& g, int Pcap, float lo, float up, int T, fl
 
 // the tables' outputs for all pairs (tables of one row length R per call)
 void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
-                        float* const* outs, float* const* douts, const unsigned* keys_s, const int* vals_s, hipStream_t s) {
+                        float* const* outs, float* const* douts, const unsigned* keys_s, const int* vals_s, hipStream_t s, float* C,
+                        float* dC) {
   const int n = Pcap + 1;
   InterpArgs a{};
   a.ntab = ntab;
@@ -296,8 +357,14 @@ void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int
   const float h = (up - lo) / (float)T;
   const int R4 = R / 4;
   const int groups = R4 >= 256 ? 1 : 256 / R4;
-  const dim3 grid(cdive(n, groups * EI_RUN)), block(groups * R4);
-#define EI_LAUNCH(NT) hipLaunchKernelGGL((k_edge_interp<NT>), grid, block, 0, s, g, Pcap, keys_s, vals_s, a, R4, T, lo, h, 1.0f / h)
+  const bool direct = edge_interp_direct(Pcap);
+  const dim3 grid(direct ? cdive(n, groups) : cdive(n, groups * EI_RUN)), block(groups * R4);
+#define EI_LAUNCH(NT)                                                                                                          \
+  if (direct) {                                                                                                                \
+    hipLaunchKernelGGL((k_edge_interp_direct<NT>), grid, block, 0, s, g, Pcap, a, R4, T, lo, up, h, 1.0f / h, C, dC);          \
+    C = dC = nullptr; /* written once */                                                                                        \
+  } else                                                                                                                       \
+    hipLaunchKernelGGL((k_edge_interp<NT>), grid, block, 0, s, g, Pcap, keys_s, vals_s, a, R4, T, lo, h, 1.0f / h)
   switch (ntab) {
     case 1: EI_LAUNCH(1); break;
     case 2: EI_LAUNCH(2); break;

@@ -443,14 +443,15 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     KR(CAT_EDGE_TABLE, (Pd + 1) * (4.0 * Wd * n_dkv * (want_forces ? 2 : 1) + 24) + nt * 12.0 * Wd * n_dkv,
        (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
         n_dkv ? launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, Wd, n_dkv, tabs.data(), outs.data(), douts.data(),
-                                   b.skeys_s, b.svals_s, s)
+                                   b.skeys_s, b.svals_s, s, b.C, b.dC)
               : (void)0));
     if (hp.neighbor_embedding) {
       const float* t1[1] = {m->tabs.tab[n_dkv]};
       float* o1[1] = {b.Wn};
       float* d1[1] = {want_forces ? b.dWn : nullptr};
       KR(CAT_EDGE_TABLE, (Pd + 1) * 4.0 * Fd * (want_forces ? 2 : 1) + nt * 12.0 * Fd,
-         launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, F, 1, t1, o1, d1, b.skeys_s, b.svals_s, s));
+         launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, F, 1, t1, o1, d1, b.skeys_s, b.svals_s, s,
+                            n_dkv ? nullptr : b.C, n_dkv ? nullptr : b.dC));
     }
   } else {
     KR(CAT_ELEMENTWISE, Pd * K * 8, launch_radial(g, P, RadialParams{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper}, b.phi, b.dphi, b.C, b.dC, s));

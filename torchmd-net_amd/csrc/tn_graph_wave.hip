@@ -5,6 +5,8 @@
 // by neighbour index without atomics.  Replaces the thread-per-atom versions of tn_kernels.hip (kept as the
 // readable specification): same pair set, same order, ~10x lower latency for single molecules and coalesced
 // O(N^2/64) wave-passes for one large system.  Semantics: reference warp_kernels/neighbors_brute.py:98-197.
+#include <cstdlib>
+
 #include "tn_common.h"
 #include "tn_kernels.h"
 
@@ -28,14 +30,12 @@ __device__ __forceinline__ float pair_d2(const float* __restrict__ pos, int hi, 
   return dx * dx + dy * dy + dz * dz;
 }
 
+// one atom's row, by one wave: count pass (FILL = false: nlow, ntot) or fill pass (FILL = true: col / epair / esign and the
+// pair records of its lower neighbours)
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_nbr_wave(Graph g, const float* __restrict__ pos, const int64_t* __restrict__ batch,
-                                                  const float* __restrict__ box, int box_mode, int N, int B, float lo2, float up2,
-                                                  int loop) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (i >= N) return;
-  if (FILL && g.counts[2]) return;
+__device__ __forceinline__ void nbr_wave_row(const Graph& g, const float* __restrict__ pos, const int64_t* __restrict__ batch,
+                                             const float* __restrict__ box, int box_mode, int N, int B, float lo2, float up2, int loop,
+                                             int i, int lane) {
   int64_t b = batch[i];
   int j0 = 0, j1 = N;
   if (b < 0 || b >= B) {  // invalid molecule index (counts[5] is set, the host raises): no candidates, no box read
@@ -102,12 +102,20 @@ __global__ __launch_bounds__(256) void k_nbr_wave(Graph g, const float* __restri
   if (FILL && i == 0 && lane == 0) g.pd[P] = 0.f;  // the self pair
 }
 
-// upper edges (i <- j, j > i) take the pair id of the lower edge (j <- i): lanes over the row's edges, binary
-// search of i among the sorted lower neighbours of j
-__global__ __launch_bounds__(256) void k_nbr_link_wave(Graph g, int N) {
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_nbr_wave(Graph g, const float* __restrict__ pos, const int64_t* __restrict__ batch,
+                                                  const float* __restrict__ box, int box_mode, int N, int B, float lo2, float up2,
+                                                  int loop) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (i >= N || g.counts[2]) return;
+  if (i >= N) return;
+  if (FILL && g.counts[2]) return;
+  nbr_wave_row<FILL>(g, pos, batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
+}
+
+// upper edges (i <- j, j > i) take the pair id of the lower edge (j <- i): lanes over the row's edges, binary
+// search of i among the sorted lower neighbours of j
+__device__ __forceinline__ void nbr_link_row(const Graph& g, int i, int lane) {
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   for (int e = e0 + lane; e < e1; e += 64) {
     const int j = g.col[e];
@@ -120,6 +128,104 @@ __global__ __launch_bounds__(256) void k_nbr_link_wave(Graph g, int N) {
     }
     g.epair[e] = g.pairptr[j] + (lo - base);
   }
+}
+__global__ __launch_bounds__(256) void k_nbr_link_wave(Graph g, int N) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= N || g.counts[2]) return;
+  nbr_link_row(g, i, lane);
+}
+
+// ---- small systems (single molecules, MD stepping): the whole graph phase in ONE launch.  The seven kernels of the
+// general path (reset, molecule ranges, count, scan, fill, link, z check) each take microseconds of work but ~5 us of
+// launch-to-launch latency inside a replayed HIP graph; one block of 16 waves runs the same phases separated by block
+// barriers (the arrays are written and read through global memory by the same CU: a barrier orders them).  Same row
+// functions as the general kernels: identical graph.
+constexpr int GS_MAX_ATOMS = 256;
+__global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __restrict__ pos, const int64_t* __restrict__ batch,
+                                                      const float* __restrict__ box, int box_mode, int N, int B, float lo2, float up2,
+                                                      int loop, const int64_t* __restrict__ z, int max_z) {
+  __shared__ int s_low[GS_MAX_ATOMS], s_tot[GS_MAX_ATOMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // reset (k_graph_reset)
+  for (int i = tid; i < B; i += 1024) g.mstart[i] = g.mend[i] = 0;
+  if (tid < 8) g.counts[tid] = 0;
+  __syncthreads();
+  // molecule ranges (k_mol_ranges) and the atomic-number check (k_prepare_z)
+  if (tid < N) {
+    const int i = tid;
+    const int64_t b = batch[i];
+    if (b < 0 || b >= B) {
+      g.counts[3] = 1;
+      g.counts[5] = 1;
+    } else {
+      if (i > 0) {
+        const int64_t bp = batch[i - 1];
+        if (bp > b) g.counts[3] = 1;
+        if (bp != b) g.mstart[b] = i;
+      } else {
+        g.mstart[b] = 0;
+      }
+      if (i == N - 1 || batch[i + 1] != b) g.mend[b] = i + 1;
+    }
+    if (z) {
+      int64_t v = z[i];
+      if (v < 0 || v >= max_z) {
+        g.counts[4] = 1;
+        v = v < 0 ? 0 : max_z - 1;
+      }
+      g.z_c[i] = v;
+    }
+  }
+  __syncthreads();
+  // count
+  for (int i = wave; i < N; i += 16) nbr_wave_row<false>(g, pos, batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
+  __syncthreads();
+  // exclusive scans nlow -> pairptr, ntot -> rowptr (k_scan_counts); N <= 256: four waves' worth, Hillis-Steele in LDS
+  if (tid < GS_MAX_ATOMS) {
+    s_low[tid] = tid < N ? g.nlow[tid] : 0;
+    s_tot[tid] = tid < N ? g.ntot[tid] : 0;
+  }
+  __syncthreads();
+  for (int off = 1; off < GS_MAX_ATOMS; off <<= 1) {
+    int a = 0, b = 0;
+    if (tid < GS_MAX_ATOMS && tid >= off) {
+      a = s_low[tid - off];
+      b = s_tot[tid - off];
+    }
+    __syncthreads();
+    if (tid < GS_MAX_ATOMS) {
+      s_low[tid] += a;
+      s_tot[tid] += b;
+    }
+    __syncthreads();
+  }
+  if (tid < N) {  // inclusive -> exclusive
+    g.pairptr[tid] = tid ? s_low[tid - 1] : 0;
+    g.rowptr[tid] = tid ? s_tot[tid - 1] : 0;
+  }
+  if (tid == 0) {
+    const int P = N ? s_low[N - 1] : 0, E = N ? s_tot[N - 1] : 0;
+    g.pairptr[N] = P;
+    g.rowptr[N] = E;
+    g.counts[0] = P;
+    g.counts[1] = E;
+    g.counts[2] = (E > g.ecap || P > g.pcap || g.counts[5]) ? 1 : 0;
+  }
+  __syncthreads();
+  if (g.counts[2]) return;  // block-uniform
+  // fill, then link
+  for (int i = wave; i < N; i += 16) nbr_wave_row<true>(g, pos, batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
+  __syncthreads();
+  for (int i = wave; i < N; i += 16) nbr_link_row(g, i, lane);
+}
+bool graph_small_ok(int N) {
+  static const bool off = getenv("TMDNET_NO_GRAPH_SMALL") != nullptr;  // developer switch: the general kernels
+  return !off && N > 0 && N <= GS_MAX_ATOMS;
+}
+void launch_graph_small(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, int B, float lo,
+                        float up, bool loop, const int64_t* z, int max_z, hipStream_t s) {
+  hipLaunchKernelGGL(k_graph_small, dim3(1), dim3(1024), 0, s, g, pos, batch, box, box_mode, N, B, lo * lo, up * up, (int)loop, z, max_z);
 }
 
 void launch_nbr_count_wave(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, int B,

@@ -127,6 +127,10 @@ void launch_nbr_fill_link_wave(const Graph& g, const float* pos, const int64_t* 
                                float lo, float up, bool loop, hipStream_t s);
 
 void launch_nbr_link_wave(const Graph& g, int N, hipStream_t s);
+// small systems: reset + molecule ranges + count + scan + fill + link + atomic-number check in one launch (one block)
+bool graph_small_ok(int N);
+void launch_graph_small(const Graph& g, const float* pos, const int64_t* batch, const float* box, int box_mode, int N, int B, float lo,
+                        float up, bool loop, const int64_t* z, int max_z, hipStream_t s);
 void launch_scan_counts(const Graph& g, int N, hipStream_t s);
 
 // ---- O(N) cell list for one periodic orthorhombic system (tn_cell.hip)
@@ -154,8 +158,12 @@ void launch_dense_f64(const double* A, const double* A2, int lda, const float* W
 void launch_table_pack(const double* f, const double* sl, int T, int R, double h, float* tab, hipStream_t s);
 void launch_pair_buckets(const Graph& g, int Pcap, float lo, float up, int T, float* C, float* dC, int* hist, unsigned* keys_s,
                          int* vals_s, hipStream_t s);
+// C / dC: the step's cutoff arrays; written by the first call of a step when the pair list is small enough for the
+// one-launch path (edge_interp_direct: launch_pair_buckets is a no-op then), ignored otherwise
+bool edge_interp_direct(int Pcap);
 void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
-                        float* const* outs, float* const* douts, const unsigned* keys_s, const int* vals_s, hipStream_t s);
+                        float* const* outs, float* const* douts, const unsigned* keys_s, const int* vals_s, hipStream_t s, float* C,
+                        float* dC);
 void launch_interp_list(const float* tab, const double* dist, int M, int R, int T, float lo, float up, float* out, float* dout,
                         hipStream_t s);
 

@@ -161,7 +161,7 @@ struct tmdnet_model {
   std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
   DevParams P;
   EdgeTables tabs;
-  int64_t tab_min_pairs = 1024;  // below this many pairs the direct (skinny) GEMMs are as fast as sort + interpolation (tools/latency_probe.sh)
+  int64_t tab_min_pairs = 1;  // developer / test switch (option "edge_table_min_pairs"): fewer pairs take the value + tangent GEMMs
   bool finalized = false;
   std::string err;
   // last-call bookkeeping for tmdnet_debug_tensor

@@ -205,9 +205,9 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
     }
     KR(CAT_EDGE_TABLE, (Pd + 1) * (12 * Fd + 4 * Fd * L) * (bwd ? 2 : 1),
        (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
-        launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1, t0, o0, d0, b.skeys_s, b.svals_s, s),
+        launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1, t0, o0, d0, b.skeys_s, b.svals_s, s, b.C, b.dC),
         L ? launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, F, L, tl.data(), ol.data(), dl.data(), b.skeys_s,
-                               b.svals_s, s)
+                               b.svals_s, s, nullptr, nullptr)
           : (void)0));
   } else {
     RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};

@@ -609,11 +609,14 @@ class TorchMD_Net(nn.Module):
             if self._engine is not engine or engine.generation != generation:
                 raise RuntimeError("stale HIP graph: the model's parameters or workspaces changed after capture(); capture again")
             if new_pos is not None:
-                s_pos.copy_(new_pos)
+                # an elementwise kernel, not Tensor.copy_: a same-dtype device copy goes through the runtime's blit path, which
+                # costs ~3x a small kernel between two graph launches.  Integrators that can write in place use replay.pos.
+                torch.mul(new_pos.detach(), 1.0, out=s_pos)
             graph.replay()
             return s_e.view(-1, 1), s_f
 
         replay.graph = graph
+        replay.pos = s_pos  # the positions the graph reads: write them in place and call replay() to skip the copy
         replay.n_atoms, replay.n_mol = int(z.shape[0]), n_mol
         return replay
 
