@@ -1190,15 +1190,15 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   gemm(s, b.lnr, 3 * F, W.Lin, 3 * F, W.bLin, b.x, F, N, F, 3 * F, GEMM_ACT_SILU, b.al, F);
   gemm(s, b.x, F, W.O1, F, W.bO1, b.ao, H, N, H, F);
   if ((int64_t)N <= 256 * (int64_t)B) {  // small molecules: head + per-molecule sum in one launch (a block walks its molecule)
-    KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_mol_sum(g, b.ao, W.O2, W.bO2, N, B, H, W.std, W.atomref, z, batch, W.mean, energy, s));
+    KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_mol_sum(g, b.ao, W.O2, W.bO2, N, B, H, W.std, W.atomref, z, batch, W.mean, energy, s,
+                                                        want_forces ? b.g_ao : nullptr));
   } else {
-    KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s));
+    KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s, want_forces ? b.g_ao : nullptr));
     KR(CAT_ELEMENTWISE, Nd * 4, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
   }
 
   if (want_forces) {
-    KR(CAT_ELEMENTWISE, Nd * H * 8, launch_head_bwd(b.ao, W.O2, N, H, W.std, b.g_ao, s));
-    NODE();
+    NODE();  // g_ao = d energy / d ao came out of the head kernel
     gemm(s, b.g_ao, H, W.O1T, H, nullptr, b.g_al, F, N, F, H, GEMM_MUL_DSILU_AUX, nullptr, 0, b.al, F);
     gemm(s, b.g_al, F, W.LinT, F, nullptr, b.g_ln, 3 * F, N, 3 * F, F);
     if (F % 64 == 0) {
@@ -1209,10 +1209,10 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     }
     // zero-fills are kernels, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to
     // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
-    launch_fill(b.gd, 0.f, P1, s);
     const bool merged_gd = message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD");
     const int gd_nw = message_adjoint_gd_waves(N, F);
     const int64_t gd_stride = 2 * (int64_t)P1;
+    if (!merged_gd) launch_fill(b.gd, 0.f, P1, s);  // the per-layer pair kernels accumulate into it
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];
       // gD of the layers below the top one comes out of the previous iteration's fused normalisation adjoint
@@ -1242,9 +1242,9 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
     KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
-       launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s));
-    KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s, merged_gd ? b.gd_slots : nullptr,
-                                               merged_gd ? L * gd_nw : 0, gd_stride));
+       launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s, merged_gd ? b.g_delta : nullptr,
+                            b.gd_slots, L * gd_nw, gd_stride));
+    if (!merged_gd) KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s, nullptr, 0, gd_stride));
     KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
   }
   NODE();

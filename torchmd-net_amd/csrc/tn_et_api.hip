@@ -505,16 +505,16 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
   gemm(s, b.hcat2, F, W.Wn1, F, W.bn1, b.m2, F2, N, F2, F, GEMM_ACT_SILU, b.pre2, F2);
   if ((int64_t)N <= 256 * (int64_t)B) {
     KR(CAT_ELEMENTWISE, Nd * F2 * 4,
-       launch_head_mol_sum(g, b.pre2, W.Wn2, W.bn2, N, B, F2, W.std, W.atomref, z, batch, W.mean, energy, s));
+       launch_head_mol_sum(g, b.pre2, W.Wn2, W.bn2, N, B, F2, W.std, W.atomref, z, batch, W.mean, energy, s,
+                           want_forces ? b.g_pre2 : nullptr));
   } else {
-    KR(CAT_ELEMENTWISE, Nd * F2 * 4, launch_head_energy(b.pre2, W.Wn2, W.bn2, N, F2, W.std, W.atomref, z, b.ea, s));
+    KR(CAT_ELEMENTWISE, Nd * F2 * 4, launch_head_energy(b.pre2, W.Wn2, W.bn2, N, F2, W.std, W.atomref, z, b.ea, s, want_forces ? b.g_pre2 : nullptr));
     KR(CAT_ELEMENTWISE, Nd * 12, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
   }
 
   // ---------------- reverse (oracle/et_adjoint.py)
   if (want_forces) {
     NODE();
-    KR(CAT_ELEMENTWISE, Nd * F2 * 8, launch_head_bwd(b.pre2, W.Wn2, N, F2, W.std, b.g_pre2, s));
     gemm(s, b.g_pre2, F2, W.Wn1T, F2, nullptr, b.g_h2, F, N, F, F2);                       // (g_xs | g_n2)
     KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_et_norm_bwd(b.g_h2 + F2, F, b.w1, F2, F2, N, b.g_w1, F2, s));
     gemm(s, b.g_w1, F2, W.W21T, F2, nullptr, b.g_vq, F2, 3 * N, F2, F2);

@@ -146,7 +146,13 @@ __global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __re
                                                       const float* __restrict__ box, int box_mode, int N, int B, float lo2, float up2,
                                                       int loop, const int64_t* __restrict__ z, int max_z) {
   __shared__ int s_low[GS_MAX_ATOMS], s_tot[GS_MAX_ATOMS];
+  __shared__ float s_pos[3 * GS_MAX_ATOMS];
+  __shared__ int64_t s_batch[GS_MAX_ATOMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // positions and molecule indices go to LDS once: a wave walks several rows one after the other, and every row would
+  // otherwise start with a round trip to L2
+  for (int k = tid; k < 3 * N; k += 1024) s_pos[k] = pos[k];
+  if (tid < N) s_batch[tid] = batch[tid];
   // reset (k_graph_reset)
   for (int i = tid; i < B; i += 1024) g.mstart[i] = g.mend[i] = 0;
   if (tid < 8) g.counts[tid] = 0;
@@ -179,24 +185,36 @@ __global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __re
   }
   __syncthreads();
   // count
-  for (int i = wave; i < N; i += 16) nbr_wave_row<false>(g, pos, batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
+  for (int i = wave; i < N; i += 16) nbr_wave_row<false>(g, s_pos, s_batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
   __syncthreads();
   // exclusive scans nlow -> pairptr, ntot -> rowptr (k_scan_counts); N <= 256: four waves' worth, Hillis-Steele in LDS
-  if (tid < GS_MAX_ATOMS) {
-    s_low[tid] = tid < N ? g.nlow[tid] : 0;
-    s_tot[tid] = tid < N ? g.ntot[tid] : 0;
-  }
-  __syncthreads();
-  for (int off = 1; off < GS_MAX_ATOMS; off <<= 1) {
+  {  // inclusive scans: four waves of 64 elements each, then the three carries
+    __shared__ int c_low[4], c_tot[4];
     int a = 0, b = 0;
-    if (tid < GS_MAX_ATOMS && tid >= off) {
-      a = s_low[tid - off];
-      b = s_tot[tid - off];
+    if (tid < GS_MAX_ATOMS) {
+      a = tid < N ? g.nlow[tid] : 0;
+      b = tid < N ? g.ntot[tid] : 0;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int ta = __shfl_up(a, off, 64), tb = __shfl_up(b, off, 64);
+        if (lane >= off) {
+          a += ta;
+          b += tb;
+        }
+      }
+      if (lane == 63) {
+        c_low[wave] = a;
+        c_tot[wave] = b;
+      }
     }
     __syncthreads();
     if (tid < GS_MAX_ATOMS) {
-      s_low[tid] += a;
-      s_tot[tid] += b;
+      for (int w = 0; w < wave; ++w) {
+        a += c_low[w];
+        b += c_tot[w];
+      }
+      s_low[tid] = a;
+      s_tot[tid] = b;
     }
     __syncthreads();
   }
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __re
   __syncthreads();
   if (g.counts[2]) return;  // block-uniform
   // fill, then link
-  for (int i = wave; i < N; i += 16) nbr_wave_row<true>(g, pos, batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
+  for (int i = wave; i < N; i += 16) nbr_wave_row<true>(g, s_pos, s_batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
   __syncthreads();
   for (int i = wave; i < N; i += 16) nbr_link_row(g, i, lane);
 }

@@ -93,7 +93,7 @@ void launch_layer_update(const float* Xh, const float* D, const float* q, const 
 // ---- readout (reference tensornet.py:384-398, output_modules.py:43-117, model.py:591-607)
 void launch_readout_feat(const float* X, int N, int F, float* feat, hipStream_t s);
 void launch_head_energy(const float* ao, const float* O2, const float* bO2, int N, int H, float std, const float* atomref,
-                        const int64_t* z, float* ea, hipStream_t s);
+                        const int64_t* z, float* ea, hipStream_t s, float* g_ao = nullptr);  // g_ao: also d e / d ao (launch_head_bwd)
 void launch_mol_sum(const Graph& g, const float* ea, const int64_t* batch, int N, int B, float mean, float* energy, hipStream_t s);
 
 // ---- reverse pass
@@ -112,7 +112,8 @@ void launch_norm_bwd_gate_bwd(const float* X, const float* gXh_lin, int N, int F
 void launch_lnbwd_readout_bwd(const float* g, const float* xhat, const float* rstd, const float* w, int N, int F, const float* X,
                               float* G, hipStream_t s);
 void launch_head_mol_sum(const Graph& g, const float* ao, const float* O2, const float* bO2, int N, int B, int H, float std,
-                         const float* atomref, const int64_t* z, const int64_t* batch, float mean, float* energy, hipStream_t s);
+                         const float* atomref, const int64_t* z, const int64_t* batch, float mean, float* energy, hipStream_t s,
+                         float* g_ao = nullptr);
 void launch_embed_gate_bwd(const float* G, const float* UX, const float* gates, const float* a2, int N, int F, float* gUX, float* g_a2,
                            hipStream_t s);
 void launch_embed_bwd_atom(const float* g_u0_lin, const float* u0, const float* g_s0n, int N, int F, float* gA, hipStream_t s);
@@ -145,7 +146,10 @@ void launch_prepare_z(const Graph& g, const int64_t* z, const int* perm, int N, 
 // ---- per-pair reverse kernels of the forward-tangent formulation (tn_pairgrad.hip)
 void launch_pair_gd(const Graph& g, int Pcap, int F, const float* gMi, const float* Pn, const float* dw, float* gd, hipStream_t s);
 void launch_embed_pair_gd(const Graph& g, int Pcap, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
-                          const float* dQ, const float* C, const float* dC, const float* gA, float* gd, float* g_rhat, hipStream_t s);
+                          const float* dQ, const float* C, const float* dC, const float* gA, float* gd, float* g_rhat, hipStream_t s,
+                          float* g_delta = nullptr, const float* slots = nullptr, int n_slots = 0, int64_t slot_stride = 0);
+// g_delta != null: the embedding is the only writer of g_d besides the sweeps' slots, so the kernel finishes the pair
+// (launch_geom_gd's arithmetic) itself: gd / g_rhat are not touched and need neither a zero fill nor a second launch
 // g_d[p] = gd[p] + sum of the n_slots slot arrays (each [2 * slot_stride/2]: pair, direction) when slots != null
 void launch_geom_gd(const Graph& g, int Pcap, const float* gd, const float* g_rhat, float* g_delta, hipStream_t s,
                     const float* slots = nullptr, int n_slots = 0, int64_t slot_stride = 0);

@@ -118,11 +118,28 @@ __device__ __forceinline__ void embed_pair_channel(float Z1, float Z2, float q0,
   acc[3] += ai[3] * W1_1 - aj[3] * W1_2 + di2 * W2_1 + dj2 * W2_2;
 }
 
+// the pair's last step, g_delta = (g_r - (g_r . r) r) / d + g_d r with g_d = this kernel's part + the sweeps' slots
+// (k_geom_gd's arithmetic and summation order)
+__device__ __forceinline__ void pair_finish(const Graph& g, int p, float gd_embed, float a0, float a1, float a2, float r0, float r1,
+                                            float r2, const float* __restrict__ slots, int n_slots, int64_t slot_stride,
+                                            float* __restrict__ g_delta) {
+  const float d = g.pd[p];
+  const float inv = d > 0.f ? 1.0f / d : 0.f;
+  const float dot = a0 * r0 + a1 * r1 + a2 * r2;
+  float s = gd_embed;
+  for (int k = 0; k < n_slots; ++k) s += slots[k * slot_stride + 2 * (int64_t)p] + slots[k * slot_stride + 2 * (int64_t)p + 1];
+  g_delta[p * 3] = (a0 - dot * r0) * inv + s * r0;
+  g_delta[p * 3 + 1] = (a1 - dot * r1) * inv + s * r1;
+  g_delta[p * 3 + 2] = (a2 - dot * r2) * inv + s * r2;
+}
+
 __global__ __launch_bounds__(256) void k_embed_pair_gd_v4(Graph g, int F, const int64_t* __restrict__ z, const float* __restrict__ Utab,
                                                           const float* __restrict__ Vtab, const float* __restrict__ Q,
                                                           const float* __restrict__ dQ, const float* __restrict__ C,
                                                           const float* __restrict__ dC, const float* __restrict__ gA,
-                                                          float* __restrict__ gd, float* __restrict__ g_rhat) {
+                                                          float* __restrict__ gd, float* __restrict__ g_rhat,
+                                                          float* __restrict__ g_delta, const float* __restrict__ slots, int n_slots,
+                                                          int64_t slot_stride) {
   const int tpa = F >> 2, ppb = 256 / tpa;
   const int p = xcd_chunk(blockIdx.x, gridDim.x) * ppb + threadIdx.x / tpa;
   if (p >= g.counts[0] || g.counts[2]) return;
@@ -158,16 +175,21 @@ __global__ __launch_bounds__(256) void k_embed_pair_gd_v4(Graph g, int F, const 
 #pragma unroll
   for (int k = 0; k < 4; ++k) acc[k] = pgroup_sum(acc[k], tpa);
   if ((threadIdx.x % tpa) == 0) {
-    gd[p] += acc[0];
-    g_rhat[p * 3] = acc[1];
-    g_rhat[p * 3 + 1] = acc[2];
-    g_rhat[p * 3 + 2] = acc[3];
+    if (g_delta) {
+      pair_finish(g, p, acc[0], acc[1], acc[2], acc[3], r0, r1, r2, slots, n_slots, slot_stride, g_delta);
+    } else {
+      gd[p] += acc[0];
+      g_rhat[p * 3] = acc[1];
+      g_rhat[p * 3 + 1] = acc[2];
+      g_rhat[p * 3 + 2] = acc[3];
+    }
   }
 }
 __global__ void k_embed_pair_gd(Graph g, int F, const int64_t* __restrict__ z, const float* __restrict__ Utab,
                                 const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ dQ,
                                 const float* __restrict__ C, const float* __restrict__ dC, const float* __restrict__ gA,
-                                float* __restrict__ gd, float* __restrict__ g_rhat) {
+                                float* __restrict__ gd, float* __restrict__ g_rhat, float* __restrict__ g_delta,
+                                const float* __restrict__ slots, int n_slots, int64_t slot_stride) {
   __shared__ float red[4];
   const int p = xcd_chunk(blockIdx.x, gridDim.x);
   if (p >= g.counts[0] || g.counts[2]) return;
@@ -193,20 +215,27 @@ __global__ void k_embed_pair_gd(Graph g, int F, const int64_t* __restrict__ z, c
 #pragma unroll
   for (int k = 0; k < 4; ++k) tot[k] = pblock_sum(acc[k], red);
   if (threadIdx.x == 0) {
-    gd[p] += tot[0];
-    g_rhat[p * 3] = tot[1];
-    g_rhat[p * 3 + 1] = tot[2];
-    g_rhat[p * 3 + 2] = tot[3];
+    if (g_delta) {
+      pair_finish(g, p, tot[0], tot[1], tot[2], tot[3], r0, r1, r2, slots, n_slots, slot_stride, g_delta);
+    } else {
+      gd[p] += tot[0];
+      g_rhat[p * 3] = tot[1];
+      g_rhat[p * 3 + 1] = tot[2];
+      g_rhat[p * 3 + 2] = tot[3];
+    }
   }
 }
 void launch_embed_pair_gd(const Graph& g, int Pcap, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
-                          const float* dQ, const float* C, const float* dC, const float* gA, float* gd, float* g_rhat, hipStream_t s) {
+                          const float* dQ, const float* C, const float* dC, const float* gA, float* gd, float* g_rhat, hipStream_t s,
+                          float* g_delta, const float* slots, int n_slots, int64_t slot_stride) {
   if (Pcap <= 0) return;
   if (gather_v4_ok(F)) {
     const int ppb = 256 / (F >> 2);
-    hipLaunchKernelGGL(k_embed_pair_gd_v4, dim3(cdivp(Pcap, ppb)), dim3(256), 0, s, g, F, z, Utab, Vtab, Q, dQ, C, dC, gA, gd, g_rhat);
+    hipLaunchKernelGGL(k_embed_pair_gd_v4, dim3(cdivp(Pcap, ppb)), dim3(256), 0, s, g, F, z, Utab, Vtab, Q, dQ, C, dC, gA, gd, g_rhat, g_delta, slots,
+                       n_slots, slot_stride);
   } else {
-    hipLaunchKernelGGL(k_embed_pair_gd, dim3(Pcap), dim3(fthreads_p(F)), 0, s, g, F, z, Utab, Vtab, Q, dQ, C, dC, gA, gd, g_rhat);
+    hipLaunchKernelGGL(k_embed_pair_gd, dim3(Pcap), dim3(fthreads_p(F)), 0, s, g, F, z, Utab, Vtab, Q, dQ, C, dC, gA, gd, g_rhat, g_delta, slots,
+                       n_slots, slot_stride);
   }
 }
 
