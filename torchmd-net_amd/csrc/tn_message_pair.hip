@@ -28,22 +28,34 @@
 namespace tn {
 
 constexpr int MP_TA = 64;        // rows per tile
-constexpr int MP_FC = 32;        // channels per block (8 lanes x 4)
-constexpr int MP_W = 64;         // source-window capacity (rows staged in LDS)
-constexpr int MP_THREADS = 512;  // 64 rows x 8 lanes
-constexpr int MP_U = 2;          // edges whose weights are loaded ahead of their use
+constexpr int MP_FC = 32;  // channels per block
+constexpr int MP_W = 64;   // source-window capacity (rows staged in LDS)
+constexpr int MP_U = 2;    // edges whose weights are loaded ahead of their use
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int VW> struct VecOf;
+template <> struct VecOf<4> { typedef f4v T; };
+template <> struct VecOf<2> { typedef f2v T; };
 
 __device__ __forceinline__ f4v ldg4(const float* p) { return *reinterpret_cast<const f4v*>(p); }
+__device__ __forceinline__ float hsum(f4v v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float hsum(f2v v) { return v.x + v.y; }
 
-template <int MODE>
-__global__ __launch_bounds__(MP_THREADS) void k_message_rows8(Graph g, int N, int F, const float* __restrict__ w,
+// LPR lanes own a row, VW channels per lane (LPR * VW = 32 channels per block).  8 x 4: 512 threads, 16-byte accesses, the
+// fewest instructions per channel - but the reverse sweep's per-lane state (two 9-vectors, weights and their derivatives
+// two edges ahead) is then 216 VGPRs = two waves per SIMD, too few to cover the loads.  16 x 2: 1024 threads, 8-byte
+// accesses, half the state per lane (four waves per SIMD in one block per CU).
+template <int MODE, int LPR, int VW>
+__global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int F, const float* __restrict__ w,
                                                                 const float* __restrict__ dw, const float* __restrict__ src,
                                                                 const float* __restrict__ Pn, const float* __restrict__ q,
                                                                 const int64_t* __restrict__ batch, int o3,
                                                                 float* __restrict__ Mi, float* __restrict__ out,
                                                                 float* __restrict__ slots, int64_t slot_stride, int nchunks) {
+  constexpr int MP_FC = VW * LPR, MP_THREADS = 64 * LPR, PIECES = MP_FC / 4;
+  typedef typename VecOf<VW>::T vf;
+  auto ldv = [](const float* p) { return *reinterpret_cast<const vf*>(p); };
   __shared__ __attribute__((aligned(16))) float win[MP_W * 9 * MP_FC];
   __shared__ int s_lo[MP_THREADS / 64], s_hi[MP_THREADS / 64];
   if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
@@ -83,72 +95,72 @@ __global__ __launch_bounds__(MP_THREADS) void k_message_rows8(Graph g, int N, in
   const bool staged = hi >= lo && wn <= MP_W;  // block-uniform
   if (staged) {
     // window rows -> LDS as [row][9][32]: 8 lanes x 16 B cover the 32 channels of one (row, component)
-    const int pieces = wn * 9 * (MP_FC / 4);
+    const int pieces = wn * 9 * PIECES;
     for (int idx = tid; idx < pieces; idx += MP_THREADS) {
-      const int rc = idx >> 3, f4 = (idx & 7) << 2;
+      const int rc = idx / PIECES, f4 = (idx % PIECES) << 2;
       const int row = rc / 9, c = rc - row * 9;
       *reinterpret_cast<f4v*>(&win[rc * MP_FC + f4]) = ldg4(src + (int64_t)(lo + row) * F9 + c * F + c0 + f4);
     }
     __syncthreads();
   }
 
-  const int i = r0 + (tid >> 3), ql = tid & 7, f = c0 + 4 * ql;  // row, lane within the row's group, first channel
+  const int i = r0 + tid / LPR, ql = tid & (LPR - 1), f = c0 + VW * ql;  // row, lane within the row's group, first channel
   const bool live = i < r1;
   const int e0 = live ? g.rowptr[i] : 0, e1 = live ? g.rowptr[i + 1] : 0;
-  const int grp = lane & ~7;  // first lane of this row's group within the wave
-  f4v acc[9], y[9];
+  const int grp = lane & ~(LPR - 1);  // first lane of this row's group within the wave
+  vf acc[9], y[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) acc[c] = y[c] = (f4v)(0.f);
+  for (int c = 0; c < 9; ++c) acc[c] = y[c] = (vf)(0.f);
   if (MODE == 1 && live) {
     const float* yp = Pn + (int64_t)i * F9 + f;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) y[c] = ldg4(yp + c * F);
+    for (int c = 0; c < 9; ++c) y[c] = ldv(yp + c * F);
   }
 
   // the 8 rows of a wave advance together: trip count = the longest of them (a row past its end adds zeros)
   int nmax = e1 - e0;
 #pragma unroll
-  for (int off = 8; off <= 32; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+  for (int off = LPR; off <= 32; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
 
-  for (int eb = 0; eb < nmax; eb += 8) {
+  for (int eb = 0; eb < nmax; eb += LPR) {
     const int me = min(e0 + eb + ql, e1 - 1);  // clamped: lanes past the row's end repeat its last edge with zero weights
     const int myc = (e1 > e0) ? g.col[me] : 0, myp = (e1 > e0) ? g.epair[me] : 0;
-    const int n = min(8, nmax - eb);
+    const int n = min(LPR, nmax - eb);
     for (int k = 0; k < n; k += MP_U) {
       int jj[MP_U], pp[MP_U];
-      f4v wv[MP_U][3], dv[MP_U][3];
+      vf wv[MP_U][3], dv[MP_U][3];
       float msk[MP_U];
 #pragma unroll
       for (int u = 0; u < MP_U; ++u) {
         const bool valid = e0 + eb + k + u < e1;
-        const int srcl = grp + min(k + u, 7);
+        const int srcl = grp + min(k + u, LPR - 1);
         jj[u] = __shfl(myc, srcl, 64);
         pp[u] = __shfl(myp, srcl, 64);
         msk[u] = valid ? 1.0f : 0.0f;
         const float* wp = w + (int64_t)pp[u] * F3 + f;
-        wv[u][0] = ldg4(wp);
-        wv[u][1] = ldg4(wp + F);
-        wv[u][2] = ldg4(wp + 2 * F);
+        wv[u][0] = ldv(wp);
+        wv[u][1] = ldv(wp + F);
+        wv[u][2] = ldv(wp + 2 * F);
         if (MODE == 1) {
           const float* dp = dw + (int64_t)pp[u] * F3 + f;
-          dv[u][0] = ldg4(dp);
-          dv[u][1] = ldg4(dp + F);
-          dv[u][2] = ldg4(dp + 2 * F);
+          dv[u][0] = ldv(dp);
+          dv[u][1] = ldv(dp + F);
+          dv[u][2] = ldv(dp + 2 * F);
         }
       }
 #pragma unroll
       for (int u = 0; u < MP_U; ++u) {
-        f4v s9[9];
+        vf s9[9];
         if (staged) {
-          const float* sp = win + (jj[u] - lo) * (9 * MP_FC) + 4 * ql;
+          const float* sp = win + (jj[u] - lo) * (9 * MP_FC) + VW * ql;
 #pragma unroll
-          for (int c = 0; c < 9; ++c) s9[c] = *reinterpret_cast<const f4v*>(sp + c * MP_FC);
+          for (int c = 0; c < 9; ++c) s9[c] = ldv(sp + c * MP_FC);
         } else {
           const float* sp = src + (int64_t)jj[u] * F9 + f;
 #pragma unroll
-          for (int c = 0; c < 9; ++c) s9[c] = ldg4(sp + c * F);
+          for (int c = 0; c < 9; ++c) s9[c] = ldv(sp + c * F);
         }
-        const f4v w0 = wv[u][0] * msk[u], w1 = wv[u][1] * msk[u], w2 = wv[u][2] * msk[u];
+        const vf w0 = wv[u][0] * msk[u], w1 = wv[u][1] * msk[u], w2 = wv[u][2] * msk[u];
         acc[0] += w0 * s9[0];
         acc[1] += w1 * s9[1];
         acc[2] += w1 * s9[2];
@@ -159,10 +171,10 @@ __global__ __launch_bounds__(MP_THREADS) void k_message_rows8(Graph g, int N, in
         acc[7] += w2 * s9[7];
         acc[8] += w2 * s9[8];
         if (MODE == 1) {
-          const f4v hv = dv[u][0] * (s9[0] * y[0]) + dv[u][1] * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
+          const vf hv = dv[u][0] * (s9[0] * y[0]) + dv[u][1] * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
                          dv[u][2] * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
-          float h = (hv.x + hv.y) + (hv.z + hv.w);
-          h = row_sum(h, 8);  // the 8 lanes = 32 channels of this row in this block
+          float h = hsum(hv);
+          h = row_sum(h, LPR);  // the row's lanes = its 32 channels in this block
           const bool valid = msk[u] != 0.f;
           if (ql == 0 && valid && jj[u] != i)
             slots[(int64_t)chunk * slot_stride + 2 * (int64_t)pp[u] + (jj[u] < i ? 0 : 1)] = h;
@@ -176,27 +188,27 @@ __global__ __launch_bounds__(MP_THREADS) void k_message_rows8(Graph g, int N, in
   if (MODE == 1) {
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      const f4v prev = ldg4(o + c * F);
-      *reinterpret_cast<f4v*>(o + c * F) = prev + acc[c];
+      const vf prev = ldv(o + c * F);
+      *reinterpret_cast<vf*>(o + c * F) = prev + acc[c];
     }
     return;
   }
-  f4v yy[9];  // the row's own source row; overwritten component by component with the result
+  vf yy[9];  // the row's own source row; overwritten component by component with the result
   if (staged && i >= lo && i <= hi) {  // the row's own source row is in its window whenever it has a self edge
-    const float* yp = win + (i - lo) * (9 * MP_FC) + 4 * ql;
+    const float* yp = win + (i - lo) * (9 * MP_FC) + VW * ql;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) yy[c] = *reinterpret_cast<const f4v*>(yp + c * MP_FC);
+    for (int c = 0; c < 9; ++c) yy[c] = ldv(yp + c * MP_FC);
   } else {
     const float* yp = src + (int64_t)i * F9 + f;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) yy[c] = ldg4(yp + c * F);
+    for (int c = 0; c < 9; ++c) yy[c] = ldv(yp + c * F);
   }
   float* mo = Mi + (int64_t)i * F9 + f;
 #pragma unroll
-  for (int c = 0; c < 9; ++c) *reinterpret_cast<f4v*>(mo + c * F) = acc[c];
+  for (int c = 0; c < 9; ++c) *reinterpret_cast<vf*>(mo + c * F) = acc[c];
   const float kap = q ? (batch ? 1.0f + 0.1f * q[batch[i]] : q[i]) : 1.0f;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < VW; ++t) {
     float m9[9], y9[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
@@ -212,7 +224,13 @@ __global__ __launch_bounds__(MP_THREADS) void k_message_rows8(Graph g, int N, in
     for (int c = 0; c < 9; ++c) yy[c][t] = uc[c] * inv;
   }
 #pragma unroll
-  for (int c = 0; c < 9; ++c) *reinterpret_cast<f4v*>(o + c * F) = yy[c];
+  for (int c = 0; c < 9; ++c) *reinterpret_cast<vf*>(o + c * F) = yy[c];
+}
+
+static int env_layout(const char* name, int dflt) {  // 8 (lanes per row, x 4 channels) or 16 (x 2 channels)
+  const char* e = getenv(name);
+  const int x = e ? atoi(e) : dflt;
+  return x == 16 ? 16 : 8;
 }
 
 bool message_pair_ok(int N, int F) {
@@ -224,15 +242,25 @@ int message_pair_slots(int F) { return F / MP_FC; }
 
 void launch_message_pair(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
                          int o3, float* Mi, float* Ch, hipStream_t s) {
+  static const int lpr = env_layout("TMDNET_MSG_LPR", 8);
   const int nchunks = F / MP_FC, tiles = (N + MP_TA - 1) / MP_TA;
-  hipLaunchKernelGGL((k_message_rows8<0>), dim3(tiles * nchunks), dim3(MP_THREADS), 0, s, g, N, F, w, nullptr, src, nullptr, q, batch,
-                     o3, Mi, Ch, nullptr, 0, nchunks);
+  if (lpr == 16)
+    hipLaunchKernelGGL((k_message_rows8<0, 16, 2>), dim3(tiles * nchunks), dim3(1024), 0, s, g, N, F, w, nullptr, src, nullptr, q, batch,
+                       o3, Mi, Ch, nullptr, 0, nchunks);
+  else
+    hipLaunchKernelGGL((k_message_rows8<0, 8, 4>), dim3(tiles * nchunks), dim3(512), 0, s, g, N, F, w, nullptr, src, nullptr, q, batch, o3,
+                       Mi, Ch, nullptr, 0, nchunks);
 }
 void launch_message_pair_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi,
                                     const float* Pn, float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
+  static const int lpr = env_layout("TMDNET_MSG_LPR_ADJOINT", 16);
   const int nchunks = F / MP_FC, tiles = (N + MP_TA - 1) / MP_TA;
-  hipLaunchKernelGGL((k_message_rows8<1>), dim3(tiles * nchunks), dim3(MP_THREADS), 0, s, g, N, F, w, dw, gMi, Pn, nullptr, nullptr, 0,
-                     nullptr, gPn, slots, slot_stride, nchunks);
+  if (lpr == 16)
+    hipLaunchKernelGGL((k_message_rows8<1, 16, 2>), dim3(tiles * nchunks), dim3(1024), 0, s, g, N, F, w, dw, gMi, Pn, nullptr, nullptr, 0,
+                       nullptr, gPn, slots, slot_stride, nchunks);
+  else
+    hipLaunchKernelGGL((k_message_rows8<1, 8, 4>), dim3(tiles * nchunks), dim3(512), 0, s, g, N, F, w, dw, gMi, Pn, nullptr, nullptr, 0,
+                       nullptr, gPn, slots, slot_stride, nchunks);
 }
 
 }  // namespace tn
