@@ -154,6 +154,15 @@ __device__ __forceinline__ int xcd_chunk(int b, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+// Capacity-sized grids (static shapes: the grid covers the pair CAPACITY, only the first n_act items exist): deal the
+// existing items to the XCDs in contiguous chunks, -1 for a block that has none.  With xcd_chunk over the capacity the
+// existing items would all land on the first few XCDs.  Needs gridDim >= n_act.
+__device__ __forceinline__ int xcd_chunk_act(int b, int n_act) {
+  const int q = n_act >> 3, r = n_act & 7, x = b & 7, k = b >> 3;
+  if (k >= q + (x < r ? 1 : 0)) return -1;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 // all-reduce over aligned groups of 2 / 4 / 8 / 16 lanes with DPP moves (VALU, no LDS round trip): quad_perm xor 1,
 // quad_perm xor 2, row_half_mirror (lane i <-> 7 - i, pairs the two quads of 8), row_mirror (i <-> 15 - i)
 __device__ __forceinline__ float row_sum(float v, int n) {  // n in {1, 2, 4, 8, 16}

@@ -78,8 +78,11 @@ void launch_et_nbr_embed(const Graph& g, int N, int F, const int64_t* z, const f
 __global__ __launch_bounds__(256) void k_et_nbr_embed_bwd(Graph g, int F, const int64_t* __restrict__ z, const float* __restrict__ embN,
                                                            const float* __restrict__ g_xcat, const float* __restrict__ dWn,
                                                            float* __restrict__ gd2) {
-  const int p = xcd_chunk(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (p >= g.counts[0] || g.counts[2]) return;
+  if (g.counts[2]) return;
+  const int item = xcd_chunk_act(blockIdx.x, (g.counts[0] + 3) >> 2);
+  if (item < 0) return;
+  const int p = item * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= g.counts[0]) return;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const float* gi = g_xcat + (int64_t)i * 2 * F + F;
   const float* gj = g_xcat + (int64_t)j * 2 * F + F;

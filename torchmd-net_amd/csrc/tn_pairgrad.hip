@@ -40,8 +40,11 @@ __device__ __forceinline__ float pblock_sum(float v, float* red) {
 __global__ __launch_bounds__(256) void k_pair_gd_v4(Graph g, int F, const float* __restrict__ gMi, const float* __restrict__ Pn,
                                                     const float* __restrict__ dw, float* __restrict__ gd) {
   const int tpa = F >> 2, ppb = 256 / tpa;
-  const int p = xcd_chunk(blockIdx.x, gridDim.x) * ppb + threadIdx.x / tpa;
-  if (p >= g.counts[0] || g.counts[2]) return;
+  if (g.counts[2]) return;
+  const int item = xcd_chunk_act(blockIdx.x, (g.counts[0] + ppb - 1) / ppb);  // grid: pair capacity; items: existing pairs
+  if (item < 0) return;
+  const int p = item * ppb + threadIdx.x / tpa;
+  if (p >= g.counts[0]) return;
   const int f = (threadIdx.x % tpa) << 2;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const int F9 = 9 * F, F3 = 3 * F;
@@ -70,8 +73,9 @@ __global__ __launch_bounds__(256) void k_pair_gd_v4(Graph g, int F, const float*
 __global__ void k_pair_gd(Graph g, int F, const float* __restrict__ gMi, const float* __restrict__ Pn, const float* __restrict__ dw,
                           float* __restrict__ gd) {
   __shared__ float red[4];
-  const int p = xcd_chunk(blockIdx.x, gridDim.x);
-  if (p >= g.counts[0] || g.counts[2]) return;
+  if (g.counts[2]) return;
+  const int p = xcd_chunk_act(blockIdx.x, g.counts[0]);
+  if (p < 0) return;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const int F9 = 9 * F, F3 = 3 * F;
   float part = 0.f;
@@ -141,8 +145,11 @@ __global__ __launch_bounds__(256) void k_embed_pair_gd_v4(Graph g, int F, const 
                                                           float* __restrict__ g_delta, const float* __restrict__ slots, int n_slots,
                                                           int64_t slot_stride) {
   const int tpa = F >> 2, ppb = 256 / tpa;
-  const int p = xcd_chunk(blockIdx.x, gridDim.x) * ppb + threadIdx.x / tpa;
-  if (p >= g.counts[0] || g.counts[2]) return;
+  if (g.counts[2]) return;
+  const int item = xcd_chunk_act(blockIdx.x, (g.counts[0] + ppb - 1) / ppb);  // grid: pair capacity; items: existing pairs
+  if (item < 0) return;
+  const int p = item * ppb + threadIdx.x / tpa;
+  if (p >= g.counts[0]) return;
   const int f = (threadIdx.x % tpa) << 2;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const int64_t zi = z[i], zj = z[j];
@@ -191,8 +198,9 @@ __global__ void k_embed_pair_gd(Graph g, int F, const int64_t* __restrict__ z, c
                                 float* __restrict__ gd, float* __restrict__ g_rhat, float* __restrict__ g_delta,
                                 const float* __restrict__ slots, int n_slots, int64_t slot_stride) {
   __shared__ float red[4];
-  const int p = xcd_chunk(blockIdx.x, gridDim.x);
-  if (p >= g.counts[0] || g.counts[2]) return;
+  if (g.counts[2]) return;
+  const int p = xcd_chunk_act(blockIdx.x, g.counts[0]);
+  if (p < 0) return;
   const int i = g.pair_i[p], j = g.pair_j[p];
   const int64_t zi = z[i], zj = z[j];
   const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
