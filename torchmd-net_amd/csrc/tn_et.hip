@@ -10,6 +10,8 @@
 // Edge sweeps are row-per-block, one channel per lane, deterministic (no atomics).  The reverse pass runs two sweeps
 // over the same CSR: "t" (row = target: g_q and the per-edge scalars g_d, g_rhat) and "s" (row = source: g_k, g_v,
 // g_vec); both recompute the attention weights instead of storing per-edge activations.
+#include <cstdlib>
+
 #include "tn_common.h"
 #include "tn_et.h"
 
@@ -153,8 +155,107 @@ __global__ void k_et_attn_fwd(Graph g, EtAttnArgs a, float* __restrict__ xagg, f
     o[2 * F] = va2;
   }
 }
+
+// ---- pipelined sweeps (the configurations that ship: every channel live, head width <= 16).  The generic kernels above
+// walk an edge in three dependent memory phases (indices -> rows of j and of the pair -> second batch) with run-time
+// branches on the model's options in between: ~3 us per edge, latency-bound at a third of the HBM rate.  Here the options
+// are template parameters and ALL loads of edge e+1 are issued before edge e is computed (one struct of registers ahead).
+struct EtFwdIn {
+  float kj, vxj, v1j, v2j, dk, dvx, dv1, dv2, vs0, vs1, vs2, C, r0, r1, r2;
+};
+struct EtIdx {  // an edge's indices: loaded two edges ahead (scalar loads), its rows one edge ahead
+  int j, p;
+  float sg;
+};
+__device__ __forceinline__ EtIdx et_idx(const Graph& g, int e) { return EtIdx{g.col[e], g.epair[e], g.esign[e]}; }
+template <int HD>
+__device__ __forceinline__ float head_sum_t(float v, int hd) {  // HD = 16 / 8 / 4: compile-time width (no branches)
+  return HD > 0 ? row_sum(v, HD) : head_sum(v, hd);
+}
+template <bool HAS_DK, bool HAS_DV>
+__device__ __forceinline__ void et_fwd_load(const Graph& g, const EtAttnArgs& a, const EtIdx& ix, int c, EtFwdIn& o) {
+  const int F = a.F;
+  const int s = ix.j, p = ix.p;
+  const float sg = ix.sg;
+  const float* qs = a.qkv + (int64_t)s * 5 * F + c;
+  o.kj = qs[F];
+  o.vxj = qs[2 * F];
+  o.v1j = qs[3 * F];
+  o.v2j = qs[4 * F];
+  const float* dkv = a.dkv + (int64_t)p * a.Wd + c;
+  o.dk = HAS_DK ? dkv[a.dk_off] : 1.0f;
+  o.dvx = HAS_DV ? dkv[a.dv_off] : 1.0f;
+  o.dv1 = HAS_DV ? dkv[a.dv_off + F] : 1.0f;
+  o.dv2 = HAS_DV ? dkv[a.dv_off + 2 * F] : 1.0f;
+  const float* vs = a.vec + (int64_t)s * 3 * F + c;
+  o.vs0 = vs[0];
+  o.vs1 = vs[F];
+  o.vs2 = vs[2 * F];
+  o.C = a.C[p];
+  const float h0 = g.prhat[(int64_t)p * 3], h1 = g.prhat[(int64_t)p * 3 + 1], h2 = g.prhat[(int64_t)p * 3 + 2];
+  o.r0 = sg != 0.f ? -sg * h0 : 0.f;  // self edge: rhat = 0 (the self pair's geometry slot is not written)
+  o.r1 = sg != 0.f ? -sg * h1 : 0.f;
+  o.r2 = sg != 0.f ? -sg * h2 : 0.f;
+}
+template <bool HAS_DK, bool HAS_DV, bool VCUT, int HD>
+__global__ void k_et_attn_fwd_p(Graph g, EtAttnArgs a, float* __restrict__ xagg, float* __restrict__ vagg) {
+  const int t = xcd_chunk(blockIdx.x, gridDim.x);
+  if (g.counts[2]) return;
+  const int F = a.F, hd = a.hd, c = threadIdx.x;  // blockDim.x == F
+  const int e0 = g.rowptr[t], e1 = g.rowptr[t + 1];
+  const float qt = a.qkv[(int64_t)t * 5 * F + c];
+  float xa = 0.f, va0 = 0.f, va1 = 0.f, va2 = 0.f;
+  EtFwdIn cur, nxt;
+  EtIdx in = {0, 0, 0.f}, inn;
+  if (e0 < e1) {
+    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, e0), c, cur);
+    in = et_idx(g, e0 + 1 < e1 ? e0 + 1 : e0);
+  }
+  for (int e = e0; e < e1; ++e) {
+    inn = et_idx(g, e + 2 < e1 ? e + 2 : e1 - 1);
+    et_fwd_load<HAS_DK, HAS_DV>(g, a, in, c, nxt);
+    in = inn;
+    const float cv = VCUT ? cur.C : 1.0f, ca = VCUT ? 1.0f : cur.C;
+    const float ak = head_sum_t<HD>(qt * cur.kj * cur.dk, hd);
+    const float A = silu(ak) * ca;
+    const float sx = cur.vxj * cv * cur.dvx, s1 = cur.v1j * cv * cur.dv1, s2 = cur.v2j * cv * cur.dv2;
+    xa += sx * A;
+    va0 += cur.vs0 * s1 + s2 * cur.r0;
+    va1 += cur.vs1 * s1 + s2 * cur.r1;
+    va2 += cur.vs2 * s1 + s2 * cur.r2;
+    cur = nxt;
+  }
+  xagg[(int64_t)t * F + c] = xa;
+  float* o = vagg + (int64_t)t * 3 * F + c;
+  o[0] = va0;
+  o[F] = va1;
+  o[2 * F] = va2;
+}
+static bool et_pipelined_ok(const EtAttnArgs& a) {
+  static const bool off = getenv("TMDNET_ET_GENERIC_SWEEPS") != nullptr;  // developer switch: the generic kernels
+  return !off && a.F % 64 == 0 && a.F <= 1024 && a.hd <= 16;
+}
 void launch_et_attn_fwd(const Graph& g, int N, const EtAttnArgs& a, float* xagg, float* vagg, hipStream_t s) {
   if (N <= 0) return;
+  if (et_pipelined_ok(a)) {
+    const dim3 grid(N), block(a.F);
+#define ET_FWD(DK, DV, VC)                                                                                     \
+  if (a.hd == 16) hipLaunchKernelGGL((k_et_attn_fwd_p<DK, DV, VC, 16>), grid, block, 0, s, g, a, xagg, vagg); \
+  else hipLaunchKernelGGL((k_et_attn_fwd_p<DK, DV, VC, 0>), grid, block, 0, s, g, a, xagg, vagg)
+    const int key = (a.dk_off >= 0 ? 4 : 0) | (a.dv_off >= 0 ? 2 : 0) | (a.vector_cutoff ? 1 : 0);
+    switch (key) {
+      case 0: ET_FWD(false, false, false); break;
+      case 1: ET_FWD(false, false, true); break;
+      case 2: ET_FWD(false, true, false); break;
+      case 3: ET_FWD(false, true, true); break;
+      case 4: ET_FWD(true, false, false); break;
+      case 5: ET_FWD(true, false, true); break;
+      case 6: ET_FWD(true, true, false); break;
+      default: ET_FWD(true, true, true); break;
+    }
+#undef ET_FWD
+    return;
+  }
   hipLaunchKernelGGL(k_et_attn_fwd, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, xagg, vagg);
 }
 
@@ -470,9 +571,156 @@ __global__ void k_et_attn_bwd(Graph g, EtAttnArgs a, const float* __restrict__ g
     gv[2 * F] += gvec2;
   }
 }
+
+struct EtBwdIn {
+  float qj, kj, vxj, v1j, v2j, dk, tk, dvx, dv1, dv2, tvx, tv1, tv2, vj0, vj1, vj2, gxj, gj0, gj1, gj2, C, dC, p0, p1, p2, sg;
+  int p;
+};
+template <bool HAS_DK, bool HAS_DV>
+__device__ __forceinline__ void et_bwd_load(const Graph& g, const EtAttnArgs& a, const float* __restrict__ g_xagg,
+                                            const float* __restrict__ g_vagg, const EtIdx& ix, int c, EtBwdIn& o) {
+  const int F = a.F;
+  const int j = ix.j, p = ix.p;
+  const float sg = ix.sg;
+  o.p = p;
+  o.sg = sg;
+  const float* jq = a.qkv + (int64_t)j * 5 * F + c;
+  o.qj = jq[0];
+  o.kj = jq[F];
+  o.vxj = jq[2 * F];
+  o.v1j = jq[3 * F];
+  o.v2j = jq[4 * F];
+  const float* dkv = a.dkv + (int64_t)p * a.Wd + c;
+  const float* tkv = a.tkv + (int64_t)p * a.Wd + c;
+  o.dk = HAS_DK ? dkv[a.dk_off] : 1.f;
+  o.tk = HAS_DK ? tkv[a.dk_off] : 0.f;
+  o.dvx = HAS_DV ? dkv[a.dv_off] : 1.f;
+  o.dv1 = HAS_DV ? dkv[a.dv_off + F] : 1.f;
+  o.dv2 = HAS_DV ? dkv[a.dv_off + 2 * F] : 1.f;
+  o.tvx = HAS_DV ? tkv[a.dv_off] : 0.f;
+  o.tv1 = HAS_DV ? tkv[a.dv_off + F] : 0.f;
+  o.tv2 = HAS_DV ? tkv[a.dv_off + 2 * F] : 0.f;
+  const float* vj = a.vec + (int64_t)j * 3 * F + c;
+  o.vj0 = vj[0];
+  o.vj1 = vj[F];
+  o.vj2 = vj[2 * F];
+  o.gxj = g_xagg[(int64_t)j * F + c];
+  const float* gvj = g_vagg + (int64_t)j * 3 * F + c;
+  o.gj0 = gvj[0];
+  o.gj1 = gvj[F];
+  o.gj2 = gvj[2 * F];
+  o.C = a.C[p];
+  o.dC = a.dC[p];
+  const float h0 = g.prhat[(int64_t)p * 3], h1 = g.prhat[(int64_t)p * 3 + 1], h2 = g.prhat[(int64_t)p * 3 + 2];
+  o.p0 = sg != 0.f ? sg * h0 : 0.f;  // prhat with the edge's sign: rhat(j <- r); rhat(r <- j) is its negative
+  o.p1 = sg != 0.f ? sg * h1 : 0.f;
+  o.p2 = sg != 0.f ? sg * h2 : 0.f;
+}
+// k_et_attn_bwd (both roles of the row atom in one sweep), pipelined: same arithmetic in the same order
+template <bool HAS_DK, bool HAS_DV, bool VCUT, int HD>
+__global__ void k_et_attn_bwd_p(Graph g, EtAttnArgs a, const float* __restrict__ g_xagg, const float* __restrict__ g_vagg,
+                                float* __restrict__ g_qkv, float* __restrict__ g_vec, float* __restrict__ gd2,
+                                float* __restrict__ gr2) {
+  const int r = xcd_chunk(blockIdx.x, gridDim.x);
+  if (g.counts[2]) return;
+  const int F = a.F, c = threadIdx.x, lane = c & 63, wave = c >> 6, hd = a.hd;  // blockDim.x == F
+  const int e0 = g.rowptr[r], e1 = g.rowptr[r + 1];
+  const int64_t F5 = 5 * (int64_t)F;
+  const float* rq = a.qkv + (int64_t)r * F5 + c;
+  const float qr = rq[0], kr = rq[F], vxr = rq[2 * F], v1r = rq[3 * F], v2r = rq[4 * F];
+  const float* vr = a.vec + (int64_t)r * 3 * F + c;
+  const float vr0 = vr[0], vr1 = vr[F], vr2 = vr[2 * F];
+  const float gxr = g_xagg[(int64_t)r * F + c];
+  const float* gvr = g_vagg + (int64_t)r * 3 * F + c;
+  const float gr0 = gvr[0], gr1 = gvr[F], gr2_ = gvr[2 * F];
+  const bool head0 = (c % hd) == 0;
+  float gq = 0.f, gk = 0.f, gvx = 0.f, gv1 = 0.f, gv2 = 0.f, gvec0 = 0.f, gvec1 = 0.f, gvec2 = 0.f;
+  EtBwdIn u, nxt;
+  EtIdx in = {0, 0, 0.f}, inn;
+  if (e0 < e1) {
+    et_bwd_load<HAS_DK, HAS_DV>(g, a, g_xagg, g_vagg, et_idx(g, e0), c, u);
+    in = et_idx(g, e0 + 1 < e1 ? e0 + 1 : e0);
+  }
+  for (int e = e0; e < e1; ++e) {
+    inn = et_idx(g, e + 2 < e1 ? e + 2 : e1 - 1);
+    et_bwd_load<HAS_DK, HAS_DV>(g, a, g_xagg, g_vagg, in, c, nxt);
+    in = inn;
+    const float cv = VCUT ? u.C : 1.0f, ca = VCUT ? 1.0f : u.C;
+    // ---- role TARGET: message j -> r
+    {
+      const float at = head_sum_t<HD>(qr * u.kj * u.dk, hd);
+      const float A = silu(at) * ca;
+      const float sx = u.vxj * cv * u.dvx, s2 = u.v2j * cv * u.dv2;
+      const float g_sx = gxr * A;
+      const float g_A = head_sum_t<HD>(gxr * sx, hd);
+      const float g_s1 = gr0 * u.vj0 + gr1 * u.vj1 + gr2_ * u.vj2;
+      const float g_s2 = -(gr0 * u.p0 + gr1 * u.p1 + gr2_ * u.p2);
+      const float g_a = g_A * silu_grad(at) * ca;
+      gq += g_a * u.kj * u.dk;
+      float gd = cv * (g_sx * u.vxj * u.tvx + g_s1 * u.v1j * u.tv1 + g_s2 * u.v2j * u.tv2) + g_a * qr * u.kj * u.tk;
+      const float gcv = g_sx * u.vxj * u.dvx + g_s1 * u.v1j * u.dv1 + g_s2 * u.v2j * u.dv2;
+      const float gca = head0 ? g_A * silu(at) : 0.f;
+      gd += (VCUT ? gcv : gca) * u.dC;
+      const float tot = wave_sum4(gd, gr0 * s2, gr1 * s2, gr2_ * s2, lane);
+      if (u.sg != 0.f && (lane & 15) == 0) {
+        const int64_t slot = (int64_t)wave * a.slot_stride + 2 * (int64_t)u.p + (u.sg > 0.f ? 0 : 1);
+        const int comp = lane >> 4;
+        if (comp == 0) gd2[slot] = tot;
+        else gr2[slot * 3 + comp - 1] = tot;
+      }
+    }
+    // ---- role SOURCE: message r -> j
+    {
+      const float as = head_sum_t<HD>(u.qj * kr * u.dk, hd);
+      const float A = silu(as) * ca;
+      const float sx = vxr * cv * u.dvx, s1 = v1r * cv * u.dv1;
+      const float g_A = head_sum_t<HD>(u.gxj * sx, hd);
+      const float g_a = g_A * silu_grad(as) * ca;
+      gk += g_a * u.qj * u.dk;
+      gvx += u.gxj * A * cv * u.dvx;
+      gv1 += (u.gj0 * vr0 + u.gj1 * vr1 + u.gj2 * vr2) * cv * u.dv1;
+      gv2 += (u.gj0 * u.p0 + u.gj1 * u.p1 + u.gj2 * u.p2) * cv * u.dv2;
+      gvec0 += u.gj0 * s1;
+      gvec1 += u.gj1 * s1;
+      gvec2 += u.gj2 * s1;
+    }
+    u = nxt;
+  }
+  float* o = g_qkv + (int64_t)r * F5 + c;
+  o[0] = gq;
+  o[F] = gk;
+  o[2 * F] = gvx;
+  o[3 * F] = gv1;
+  o[4 * F] = gv2;
+  float* gv = g_vec + (int64_t)r * 3 * F + c;
+  gv[0] += gvec0;
+  gv[F] += gvec1;
+  gv[2 * F] += gvec2;
+}
 void launch_et_attn_bwd(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
                         float* g_vec, float* gd2, float* gr2, hipStream_t s) {
   if (N <= 0) return;
+  if (et_pipelined_ok(a)) {
+    const dim3 grid(N), block(a.F);
+#define ET_BWD(DK, DV, VC)                                                                                                   \
+  if (a.hd == 16)                                                                                                           \
+    hipLaunchKernelGGL((k_et_attn_bwd_p<DK, DV, VC, 16>), grid, block, 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2); \
+  else                                                                                                                      \
+    hipLaunchKernelGGL((k_et_attn_bwd_p<DK, DV, VC, 0>), grid, block, 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2)
+    const int key = (a.dk_off >= 0 ? 4 : 0) | (a.dv_off >= 0 ? 2 : 0) | (a.vector_cutoff ? 1 : 0);
+    switch (key) {
+      case 0: ET_BWD(false, false, false); break;
+      case 1: ET_BWD(false, false, true); break;
+      case 2: ET_BWD(false, true, false); break;
+      case 3: ET_BWD(false, true, true); break;
+      case 4: ET_BWD(true, false, false); break;
+      case 5: ET_BWD(true, false, true); break;
+      case 6: ET_BWD(true, true, false); break;
+      default: ET_BWD(true, true, true); break;
+    }
+#undef ET_BWD
+    return;
+  }
   hipLaunchKernelGGL(k_et_attn_bwd, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2);
 }
 
