@@ -168,6 +168,23 @@ struct EtIdx {  // an edge's indices: loaded two edges ahead (scalar loads), its
   float sg;
 };
 __device__ __forceinline__ EtIdx et_idx(const Graph& g, int e) { return EtIdx{g.col[e], g.epair[e], g.esign[e]}; }
+// rows walk their edge lists in the order (row + column) mod 64 - symmetric in the two atoms of a pair, so the rows of a
+// molecule (dispatched together on one XCD) reach a common pair at the same point of their loops
+__device__ __forceinline__ int et_rot_start(const int* __restrict__ col, int e0, int e1, int i) {
+  if (e1 <= e0) return e0;
+  const int j0 = col[e0];
+  const int target = j0 + ((64 - ((i + j0) & 63)) & 63);
+  int lo = e0, hi = e1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  return lo < e1 ? lo : e0;
+}
+__device__ __forceinline__ int et_rot(int it, int e0, int e1, int rot) {  // it-th edge of the rotated list
+  const int e = it + rot - e0;
+  return e < e1 ? e : e - (e1 - e0);
+}
 template <int HD>
 __device__ __forceinline__ float head_sum_t(float v, int hd) {  // HD = 16 / 8 / 4: compile-time width (no branches)
   return HD > 0 ? row_sum(v, HD) : head_sum(v, hd);
@@ -207,12 +224,13 @@ __global__ void k_et_attn_fwd_p(Graph g, EtAttnArgs a, float* __restrict__ xagg,
   float xa = 0.f, va0 = 0.f, va1 = 0.f, va2 = 0.f;
   EtFwdIn cur, nxt;
   EtIdx in = {0, 0, 0.f}, inn;
+  const int rot = et_rot_start(g.col, e0, e1, t);
   if (e0 < e1) {
-    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, e0), c, cur);
-    in = et_idx(g, e0 + 1 < e1 ? e0 + 1 : e0);
+    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e0, e0, e1, rot)), c, cur);
+    in = et_idx(g, et_rot(e0 + 1 < e1 ? e0 + 1 : e0, e0, e1, rot));
   }
   for (int e = e0; e < e1; ++e) {
-    inn = et_idx(g, e + 2 < e1 ? e + 2 : e1 - 1);
+    inn = et_idx(g, et_rot(e + 2 < e1 ? e + 2 : e1 - 1, e0, e1, rot));
     et_fwd_load<HAS_DK, HAS_DV>(g, a, in, c, nxt);
     in = inn;
     const float cv = VCUT ? cur.C : 1.0f, ca = VCUT ? 1.0f : cur.C;
@@ -637,12 +655,13 @@ __global__ void k_et_attn_bwd_p(Graph g, EtAttnArgs a, const float* __restrict__
   float gq = 0.f, gk = 0.f, gvx = 0.f, gv1 = 0.f, gv2 = 0.f, gvec0 = 0.f, gvec1 = 0.f, gvec2 = 0.f;
   EtBwdIn u, nxt;
   EtIdx in = {0, 0, 0.f}, inn;
+  const int rot = et_rot_start(g.col, e0, e1, r);
   if (e0 < e1) {
-    et_bwd_load<HAS_DK, HAS_DV>(g, a, g_xagg, g_vagg, et_idx(g, e0), c, u);
-    in = et_idx(g, e0 + 1 < e1 ? e0 + 1 : e0);
+    et_bwd_load<HAS_DK, HAS_DV>(g, a, g_xagg, g_vagg, et_idx(g, et_rot(e0, e0, e1, rot)), c, u);
+    in = et_idx(g, et_rot(e0 + 1 < e1 ? e0 + 1 : e0, e0, e1, rot));
   }
   for (int e = e0; e < e1; ++e) {
-    inn = et_idx(g, e + 2 < e1 ? e + 2 : e1 - 1);
+    inn = et_idx(g, et_rot(e + 2 < e1 ? e + 2 : e1 - 1, e0, e1, rot));
     et_bwd_load<HAS_DK, HAS_DV>(g, a, g_xagg, g_vagg, in, c, nxt);
     in = inn;
     const float cv = VCUT ? u.C : 1.0f, ca = VCUT ? 1.0f : u.C;
@@ -747,7 +766,7 @@ void launch_et_pair_combine(const Graph& g, int Pcap, const float* gd2, const fl
   if (Pcap <= 0) return;
   hipLaunchKernelGGL(k_et_pair_combine, dim3(cdiv_(Pcap, 256)), dim3(256), 0, s, g, gd2, gr2, nw, stride, gd_extra, gd, g_rhat);
 }
-int et_sweep_waves(int F) { return bthreads(F) / 64; }
+
 
 // ---------------------------------------------------------------------------------------------- head (GatedEquivariantBlock)
 // hcat[n] = [ xsrc[n] (Fx, optional) | norm_a u[3n+a] (Fn) ]      (models/utils.py:626-646)
@@ -849,5 +868,7 @@ void launch_et_add(const float* in, float* out, int64_t n, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_et_axpy, dim3(cdiv_(n, 256)), dim3(256), 0, s, in, out, n);
 }
+
+int et_sweep_waves(int F) { return bthreads(F) / 64; }
 
 }  // namespace tn
