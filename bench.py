@@ -133,8 +133,10 @@ def pmc_kernel_bytes(pmc, cls, label):
     per = pmc.get("_per_kernel_total", {})
     head = label.split(" ")[0].split("(")[0]
     names = {"gemm_dual<2>": ["k_edge_mlp", "k_gemm_dual_sb2<2>"], "gemm_dual<0>": ["k_gemm_dual_sb2<0>"],
-             "launch_message": ["k_message_rows8<0>", "k_message_tile<0, 0>", "k_message_tile<0>"],
-             "launch_message_adjoint_gd": ["k_message_rows8<1>", "k_message_adjoint_gd"],
+             "launch_message": ["k_message_rows8<0, 8, 4>", "k_message_rows8<0, 16, 2>", "k_message_rows8<0>", "k_message_tile<0, 0>",
+                                "k_message_tile<0>"],
+             "launch_message_adjoint_gd": ["k_message_rows8<1, 16, 2>", "k_message_rows8<1, 8, 4>", "k_message_rows8<1>",
+                                           "k_message_adjoint_gd"],
              "launch_edge_tables": ["k_edge_interp<3>", "k_edge_interp<2>", "k_edge_interp<4>", "k_edge_interp<1>"],
              "launch_embed_scatter": ["k_embed_scatter"], "launch_embed_pair_gd": ["k_embed_pair_gd_v4"]}.get(head, [])
     for n in names:
