@@ -546,3 +546,72 @@ def test_edge_tables_equal_direct_evaluation(hip_lib, golden_dir):
     big.set_engine_option("edge_table_min_pairs", 10 ** 12)
     Ed, Fd = big(zb, pb, bb)
     assert rel_err(Et, Ed) < 2e-6 and rel_err(Ft, Fd) < 2e-6
+
+
+# ------------------------------------------------------------------ single-system latency path (round 2)
+@pytest.mark.parametrize("sizes", [[1], [5], [64], [17, 40, 3, 60], [200], [256], [257], [100, 180]])
+@pytest.mark.parametrize("periodic", [False, True])
+def test_small_system_graph_kernel_equals_general_path(hip_lib, sizes, periodic):
+    """Static shapes build the neighbour graph of <= 256 atoms in ONE single-block launch (k_graph_small); the eager call
+    uses the general seven-kernel path: same pairs in the same order -> energies and forces agree to rounding of the
+    different sweep kernels; 257 / 280 atoms take the general path in both.  Unsorted molecule indices too."""
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(11)
+    z, pos, batch = _ragged(sizes, seed=910)
+    box = None
+    if periodic:
+        if len(sizes) > 1:
+            pytest.skip("one box per call in this test")
+        box = torch.tensor([[13.0, 0.0, 0.0], [1.5, 12.0, 0.0], [-1.0, 2.0, 14.0]])
+    dyn = create_model(_args("tensornet")).to("cuda")
+    sta = create_model(_args("tensornet", static_shapes=True, max_num_neighbors=64))
+    sta.load_state_dict(dyn.state_dict())
+    sta = sta.to("cuda")
+    zc, pc, bc = z.cuda(), pos.cuda(), batch.cuda()
+    bx = None if box is None else box.cuda()
+    E0, F0 = dyn(zc, pc, bc, box=bx)
+    E1, F1 = sta(zc, pc, bc, box=bx)
+    assert dyn._engine.counts[:2] == sta._engine.counts[:2]
+    assert rel_err(E1, E0) < 2e-6 and rel_err(F1, F0) < 2e-6
+    if len(sizes) > 1:  # unsorted batch: the graph kernels scan all atoms for the members of a molecule
+        perm = torch.randperm(z.shape[0], generator=torch.Generator().manual_seed(3)).cuda()
+        E2, F2 = sta(zc[perm], pc[perm], bc[perm])
+        assert rel_err(E2, E0) < 2e-6 and rel_err(F2, F0[perm]) < 2e-6
+    # the HIP graph of the captured step replays it
+    replay = sta.capture(zc, pc, bc, box=bx)
+    moved = pc + 0.03 * torch.randn(pc.shape, generator=torch.Generator().manual_seed(5)).cuda()
+    E3, F3 = replay(moved)
+    E4, F4 = dyn(zc, moved.clone(), bc, box=bx)
+    assert rel_err(E3, E4) < 2e-6 and rel_err(F3, F4) < 2e-6
+    assert replay.pos.data_ptr() != moved.data_ptr() and torch.equal(replay.pos, moved)
+
+
+def test_one_launch_interpolation_equals_bucketed(hip_lib, golden_dir, tmp_path):
+    """Short pair lists interpolate the radial tables in one launch (k_edge_interp_direct); TMDNET_EDGE_DIRECT_MAX=0 in a
+    fresh process forces the bucketed batch path on the same input: same arithmetic on the same distance bits (the compiler
+    contracts the two kernels' multiply-adds differently: agreement to the last bits, not bit for bit)."""
+    import subprocess
+    import sys
+
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    model = create_model(dict(g["args"]))
+    model.load_state_dict(g["state_dict"])
+    model = model.to("cuda")
+    E, F = model(g["z"].cuda(), g["pos"].cuda(), g["batch"].cuda(), q=g["q"].cuda())
+    out = tmp_path / "bucketed.pt"
+    code = (
+        "import os, sys, torch\n"
+        f"sys.path[:0] = {[p for p in sys.path if p]!r}\n"
+        "from torchmdnet_amd.models.model import create_model\n"
+        f"g = torch.load({os.path.join(golden_dir, 'tiny_ref.pt')!r})\n"
+        "m = create_model(dict(g['args'])); m.load_state_dict(g['state_dict']); m = m.to('cuda')\n"
+        "E, F = m(g['z'].cuda(), g['pos'].cuda(), g['batch'].cuda(), q=g['q'].cuda())\n"
+        f"torch.save((E.cpu(), F.cpu()), {str(out)!r})\n"
+    )
+    env = dict(os.environ, TMDNET_EDGE_DIRECT_MAX="0")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    Eb, Fb = torch.load(out)
+    assert rel_err(E.detach().cpu(), Eb.detach()) < 1e-6 and rel_err(F.detach().cpu(), Fb.detach()) < 1e-6

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const un
 // Few pairs (single molecules, MD stepping): the pair-order machinery above costs five launches and a serial walk of 32
 // pairs per thread group for nothing - the whole pair list is smaller than one table.  One launch instead: a thread group
 // per pair computes the cutoff, finds its grid interval and reads its four table rows (L2).  Same arithmetic on the same
-// distance bits as k_edge_interp: bit-identical outputs.
+// distance bits as k_edge_interp.
 template <int NT>
 __global__ __launch_bounds__(256) void k_edge_interp_direct(Graph g, int Pcap, InterpArgs a, int R4, int T, float lo, float up, float h,
                                                            float inv_h, float* __restrict__ C, float* __restrict__ dC) {
