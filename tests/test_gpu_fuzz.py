@@ -115,3 +115,40 @@ def test_tensornet2_shapes(hip_lib, case):
                 num_layers=L, q_dim=qd, q_weights=[0.5 + 0.25 * i for i in range(L + 1)], cutoff_upper=4.5, max_z=12)
     q = torch.tensor([float(i % 3 - 1) for i in range(len(sizes))])
     _check(args, T, sizes, seed=7 * F + qd, q=q)
+
+
+def test_interleaved_models_sizes_and_streams(hip_lib):
+    """Three engines alive at once, called in random order with batch sizes between 1 atom and ~3000 atoms (workspaces grow
+    and are reused), on the default and on a side stream: every (model, input) pair returns bit-identical results each time
+    it comes round again - nothing leaks between calls through a reused workspace, a cached count or the parameter block."""
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(5)
+    models = [create_model(dict(W.TINY_ARGS)).to("cuda"), create_model(dict(W.ET_TINY_ARGS)).to("cuda"),
+              create_model(dict(W.TINY_ARGS, model="tensornet2", output_model="ScalarPlusWeightedCoulomb", q_dim=4,
+                                q_weights=[1.0, 1.0, 1.0])).to("cuda")]
+    inputs = []
+    for k, sizes in enumerate([[1], [64] * 40, [3, 17], [30] * 100, [90, 5, 64], [64] * 8, [2]]):
+        z, pos, batch = _batch(sizes, 4000 + 50 * k, 12)
+        inputs.append((z.cuda(), pos.cuda(), batch.cuda(), torch.zeros(len(sizes)).cuda()))
+    side = torch.cuda.Stream()
+    seen = {}
+    gen = torch.Generator().manual_seed(9)
+    for it in range(60):
+        mi = int(torch.randint(0, len(models), (1,), generator=gen))
+        ii = int(torch.randint(0, len(inputs), (1,), generator=gen))
+        z, pos, batch, q = inputs[ii]
+        use_side = it % 3 == 2
+        if use_side:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side if use_side else torch.cuda.current_stream()):
+            E, F = models[mi](z, pos, batch, q=q if mi != 1 else None)
+        if use_side:
+            torch.cuda.current_stream().wait_stream(side)
+        E, F = E.detach().clone(), F.detach().clone()
+        key = (mi, ii)
+        if key in seen:
+            assert torch.equal(E, seen[key][0]) and torch.equal(F, seen[key][1]), (it, key)
+        else:
+            assert torch.isfinite(E).all() and torch.isfinite(F).all()
+            seen[key] = (E, F)
