@@ -448,12 +448,13 @@ __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict
     s0n[(int64_t)i * F + f] = quad(u);
   }
 }
-// small-system variant: 4 thread groups take every 4th edge of the row (see k_message_split)
-__global__ __launch_bounds__(512) void k_embed_scatter_split(Graph g, int N, int F, const int64_t* __restrict__ z,
+// small-system variant: kES thread groups take every kES-th edge of the row (see k_message_split)
+constexpr int kES = 8;
+__global__ __launch_bounds__(1024) void k_embed_scatter_split(Graph g, int N, int F, const int64_t* __restrict__ z,
                                                              const float* __restrict__ Utab, const float* __restrict__ Vtab,
                                                              const float* __restrict__ Q, const float* __restrict__ C,
                                                              float* __restrict__ u0, float* __restrict__ s0n) {
-  __shared__ float part[3][10][128];
+  __shared__ float part[kES - 1][10][128];
   const int i = blockIdx.x;
   if (g.counts[2]) return;
   const int grp = threadIdx.x / F, f = threadIdx.x - grp * F;
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(512) void k_embed_scatter_split(Graph g, int N, int
   const int F3 = 3 * F;
   const float Ui = Utab[zi * F + f];
   float a[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // I0, v0..2, t00, t01, t02, t11, t12, t22
-  for (int e = e0 + grp; e < e1; e += 4) {
+  for (int e = e0 + grp; e < e1; e += kES) {
     const int j = g.col[e], p = g.epair[e];
     const float sg = g.esign[e];
     float rx = 0.f, ry = 0.f, rz = 0.f;
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(512) void k_embed_scatter_split(Graph g, int N, int
   __syncthreads();
   if (grp > 0) return;
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
+  for (int k = 0; k < kES - 1; ++k)
 #pragma unroll
     for (int c = 0; c < 10; ++c) a[c] += part[k][c][f];
   const float tr3 = (a[4] + a[7] + a[9]) * (1.0f / 3.0f);
@@ -501,7 +502,7 @@ void launch_embed_scatter(const Graph& g, int N, int F, const int64_t* z, const 
   if (N <= 0) return;
   // measured on MI355X (profiles/r01_notes.md): the 16-byte CSR sweep is slower than one-channel-per-lane here (scalar edge loads, 4x the waves)
   if (N <= 512 && F <= 128 && F % 64 == 0) {
-    hipLaunchKernelGGL(k_embed_scatter_split, dim3(N), dim3(4 * F), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
+    hipLaunchKernelGGL(k_embed_scatter_split, dim3(N), dim3(kES * F), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
     return;
   }
   if (sweep_v4() && gather_v4_ok(F)) return launch_embed_scatter_v4(g, N, F, z, Utab, Vtab, Q, C, u0, s0n, s);
@@ -649,12 +650,12 @@ __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, co
 // Small systems (single-molecule MD): a row's ~25 edges are a serial chain of dependent loads, and the chip is mostly idle, so
 // EG = 4 thread groups of a block take every 4th edge of the row and their partial sums are combined through LDS in a
 // fixed order.  Used below `kSplitRows` rows; the summation order differs from the one-group kernels by rounding only.
-constexpr int kEG = 4;
-constexpr int kSplitRows = 512;  // measured: 64 atoms 13 -> 7 us per sweep, 1029 atoms slower with the split
+constexpr int kEG = 8;
+constexpr int kSplitRows = 512;  // measured: 64 atoms 13 -> 7 us per sweep (4 groups; 8 groups: another -10 us per step), 1029 atoms slower with the split
 // MODE 0: forward message + group product + normalisation ; 1: adjoint (out += gather) ; 2: adjoint + the per-pair distance
 // gradient halves h(i <- j) = sum dw[p] * gMi[j] * Pn[i] (see k_message_adjoint_gd; Mi then carries Pn, q carries dw)
 template <int MODE>
-__global__ __launch_bounds__(512) void k_message_split(Graph g, int N, int F, const float* __restrict__ w,
+__global__ __launch_bounds__(1024) void k_message_split(Graph g, int N, int F, const float* __restrict__ w,
                                                        const float* __restrict__ src, const float* __restrict__ q,
                                                        const int64_t* __restrict__ batch, int o3, float* __restrict__ Mi,
                                                        float* __restrict__ out, float* __restrict__ slots = nullptr,
