@@ -30,9 +30,11 @@ __device__ __forceinline__ float4 ld_row4(const float* __restrict__ base, int64_
   return v;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs a, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) float part[4][32][33];
+// NW waves split K: 4 (K <= 192: 128 threads of reduction work per 32 columns is already the launch floor) or 8 (longer
+// contractions: the readout / gate GEMMs with K = 256..640 were 8-10 us of dependent slabs in the single-molecule step)
+template <int EPI, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gemm_skinny(GemmArgs a, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float part[NW][32][33];
   const int per_group = tiles_m * tiles_n;
   const int g = blockIdx.x / per_group;
   const int rem = blockIdx.x - g * per_group;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs a, int tiles_m, in
   const int r = lane & 31, kq = (lane >> 5) << 2;
 
   // K range of this wave: multiples of 8 (one 16-byte load per lane covers k = k0 + kq + {0..3})
-  const int chunk = ((K + 31) / 32) * 8;
+  const int chunk = ((K + 8 * NW - 1) / (8 * NW)) * 8;
   const int kbeg = wave * chunk, kend = (kbeg + chunk < K) ? kbeg + chunk : K;
 
   floatx16 acc;
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs a, int tiles_m, in
 #pragma unroll
   for (int e = 0; e < 16; ++e) part[wave][(e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)][lane & 31] = acc[e];
   __syncthreads();
-  // fixed-order reduction over the 4 waves; thread -> (row = tid/8, 4 consecutive columns)
+  // fixed-order reduction over the NW waves; thread -> (row = tid/8, 4 consecutive columns)
+  if (tid >= 256) return;
   const int row = tid >> 3, c0 = (tid & 7) << 2;
   const int grow = m0 + row;
   if (grow >= M) return;
@@ -94,6 +97,8 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(GemmArgs a, int tiles_m, in
     const int col = n0 + c0 + j;
     if (col >= N) continue;
     float v = ((part[0][row][c0 + j] + part[1][row][c0 + j]) + part[2][row][c0 + j]) + part[3][row][c0 + j];
+#pragma unroll
+    for (int wv = 4; wv < NW; ++wv) v += part[wv][row][c0 + j];
     if (bias) v += bias[col];
     epilogue_store<EPI>(a, C, pre, aux, grow, col, v);
   }
@@ -104,7 +109,10 @@ static int launch_skinny_one(const GemmArgs& a, hipStream_t stream) {
   const int tiles_m = (a.M + 31) / 32, tiles_n = (a.N + 31) / 32;
   const int total = tiles_m * tiles_n * a.groups;
   if (total <= 0) return 0;
-  hipLaunchKernelGGL((k_gemm_skinny<EPI>), dim3(total), dim3(256), 0, stream, a, tiles_m, tiles_n);
+  if (a.K >= 256)
+    hipLaunchKernelGGL((k_gemm_skinny<EPI, 8>), dim3(total), dim3(512), 0, stream, a, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL((k_gemm_skinny<EPI, 4>), dim3(total), dim3(256), 0, stream, a, tiles_m, tiles_n);
   return (int)hipGetLastError();
 }
 
