@@ -145,39 +145,51 @@ constexpr int GS_MAX_ATOMS = 256;
 __global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __restrict__ pos, const int64_t* __restrict__ batch,
                                                       const float* __restrict__ box, int box_mode, int N, int B, float lo2, float up2,
                                                       int loop, const int64_t* __restrict__ z, int max_z) {
-  __shared__ int s_low[GS_MAX_ATOMS], s_tot[GS_MAX_ATOMS];
+  // Everything the phases hand to each other lives in LDS (positions, molecule indices and ranges, per-row counts, the two
+  // prefix sums, the flags): the row functions reach it through the same Graph fields, re-pointed at the LDS copies (flat
+  // addressing), so no phase starts with a round trip to L2.  The global copies are written once at the end.
+  __shared__ int s_mstart[GS_MAX_ATOMS], s_mend[GS_MAX_ATOMS], s_nlow[GS_MAX_ATOMS], s_ntot[GS_MAX_ATOMS];
+  __shared__ int s_rowptr[GS_MAX_ATOMS + 1], s_pairptr[GS_MAX_ATOMS + 1], s_counts[8], c_low[4], c_tot[4];
   __shared__ float s_pos[3 * GS_MAX_ATOMS];
   __shared__ int64_t s_batch[GS_MAX_ATOMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // positions and molecule indices go to LDS once: a wave walks several rows one after the other, and every row would
-  // otherwise start with a round trip to L2
+  const bool mol_lds = B <= GS_MAX_ATOMS;  // more molecule slots than atoms (empty molecules): ranges stay in global memory
+  Graph gl = g;
+  gl.nlow = s_nlow;
+  gl.ntot = s_ntot;
+  gl.rowptr = s_rowptr;
+  gl.pairptr = s_pairptr;
+  gl.counts = s_counts;
+  if (mol_lds) {
+    gl.mstart = s_mstart;
+    gl.mend = s_mend;
+  }
   for (int k = tid; k < 3 * N; k += 1024) s_pos[k] = pos[k];
   if (tid < N) s_batch[tid] = batch[tid];
-  // reset (k_graph_reset)
-  for (int i = tid; i < B; i += 1024) g.mstart[i] = g.mend[i] = 0;
-  if (tid < 8) g.counts[tid] = 0;
+  for (int i = tid; i < B; i += 1024) gl.mstart[i] = gl.mend[i] = 0;  // k_graph_reset
+  if (tid < 8) s_counts[tid] = 0;
   __syncthreads();
   // molecule ranges (k_mol_ranges) and the atomic-number check (k_prepare_z)
   if (tid < N) {
     const int i = tid;
-    const int64_t b = batch[i];
+    const int64_t b = s_batch[i];
     if (b < 0 || b >= B) {
-      g.counts[3] = 1;
-      g.counts[5] = 1;
+      s_counts[3] = 1;
+      s_counts[5] = 1;
     } else {
       if (i > 0) {
-        const int64_t bp = batch[i - 1];
-        if (bp > b) g.counts[3] = 1;
-        if (bp != b) g.mstart[b] = i;
+        const int64_t bp = s_batch[i - 1];
+        if (bp > b) s_counts[3] = 1;
+        if (bp != b) gl.mstart[b] = i;
       } else {
-        g.mstart[b] = 0;
+        gl.mstart[b] = 0;
       }
-      if (i == N - 1 || batch[i + 1] != b) g.mend[b] = i + 1;
+      if (i == N - 1 || s_batch[i + 1] != b) gl.mend[b] = i + 1;
     }
     if (z) {
       int64_t v = z[i];
       if (v < 0 || v >= max_z) {
-        g.counts[4] = 1;
+        s_counts[4] = 1;
         v = v < 0 ? 0 : max_z - 1;
       }
       g.z_c[i] = v;
@@ -185,15 +197,14 @@ __global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __re
   }
   __syncthreads();
   // count
-  for (int i = wave; i < N; i += 16) nbr_wave_row<false>(g, s_pos, s_batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
+  for (int i = wave; i < N; i += 16) nbr_wave_row<false>(gl, s_pos, s_batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
   __syncthreads();
-  // exclusive scans nlow -> pairptr, ntot -> rowptr (k_scan_counts); N <= 256: four waves' worth, Hillis-Steele in LDS
-  {  // inclusive scans: four waves of 64 elements each, then the three carries
-    __shared__ int c_low[4], c_tot[4];
+  // exclusive scans nlow -> pairptr, ntot -> rowptr (k_scan_counts): four waves of 64 elements each, then the three carries
+  {
     int a = 0, b = 0;
     if (tid < GS_MAX_ATOMS) {
-      a = tid < N ? g.nlow[tid] : 0;
-      b = tid < N ? g.ntot[tid] : 0;
+      a = tid < N ? s_nlow[tid] : 0;
+      b = tid < N ? s_ntot[tid] : 0;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         const int ta = __shfl_up(a, off, 64), tb = __shfl_up(b, off, 64);
@@ -213,29 +224,41 @@ __global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __re
         a += c_low[w];
         b += c_tot[w];
       }
-      s_low[tid] = a;
-      s_tot[tid] = b;
+      if (tid < N) {  // inclusive -> exclusive: element tid + 1
+        s_pairptr[tid + 1] = a;
+        s_rowptr[tid + 1] = b;
+      }
+      if (tid == 0) s_pairptr[0] = s_rowptr[0] = 0;
     }
     __syncthreads();
   }
-  if (tid < N) {  // inclusive -> exclusive
-    g.pairptr[tid] = tid ? s_low[tid - 1] : 0;
-    g.rowptr[tid] = tid ? s_tot[tid - 1] : 0;
-  }
   if (tid == 0) {
-    const int P = N ? s_low[N - 1] : 0, E = N ? s_tot[N - 1] : 0;
-    g.pairptr[N] = P;
-    g.rowptr[N] = E;
-    g.counts[0] = P;
-    g.counts[1] = E;
-    g.counts[2] = (E > g.ecap || P > g.pcap || g.counts[5]) ? 1 : 0;
+    const int P = s_pairptr[N], E = s_rowptr[N];
+    s_counts[0] = P;
+    s_counts[1] = E;
+    s_counts[2] = (E > g.ecap || P > g.pcap || s_counts[5]) ? 1 : 0;
   }
   __syncthreads();
-  if (g.counts[2]) return;  // block-uniform
-  // fill, then link
-  for (int i = wave; i < N; i += 16) nbr_wave_row<true>(g, s_pos, s_batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
-  __syncthreads();
-  for (int i = wave; i < N; i += 16) nbr_link_row(g, i, lane);
+  if (!s_counts[2]) {  // block-uniform
+    // fill, then link
+    for (int i = wave; i < N; i += 16) nbr_wave_row<true>(gl, s_pos, s_batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
+    __syncthreads();
+    for (int i = wave; i < N; i += 16) nbr_link_row(gl, i, lane);
+  }
+  // the global copies the later kernels (and the host, for the flags) read
+  if (tid <= N) {
+    g.rowptr[tid] = s_rowptr[tid];
+    g.pairptr[tid] = s_pairptr[tid];
+  }
+  if (tid < N) {
+    g.nlow[tid] = s_nlow[tid];
+    g.ntot[tid] = s_ntot[tid];
+  }
+  if (mol_lds && tid < B) {
+    g.mstart[tid] = s_mstart[tid];
+    g.mend[tid] = s_mend[tid];
+  }
+  if (tid < 8) g.counts[tid] = s_counts[tid];
 }
 bool graph_small_ok(int N) {
   static const bool off = getenv("TMDNET_NO_GRAPH_SMALL") != nullptr;  // developer switch: the general kernels
