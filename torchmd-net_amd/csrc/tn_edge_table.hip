@@ -224,17 +224,17 @@ constexpr int EI_RUN = 32;  // sorted pairs per group
 template <int NT>
 __global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const unsigned* __restrict__ keys_sorted,
                                                     const int* __restrict__ vals_sorted, InterpArgs a, int R4, int T, float lo,
-                                                    float h, float inv_h) {
+                                                    float h, float inv_h, int run) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int groups = blockDim.x / R4;
   const int grp = threadIdx.x / R4, c4 = threadIdx.x - grp * R4;
   if (grp >= groups) return;
   const int R = 4 * R4;
   const int P = g.counts[0];
-  const int s0 = (blockIdx.x * groups + grp) * EI_RUN;
+  const int s0 = (blockIdx.x * groups + grp) * run;
   int kcur = -1;
   f4 f0[NT], sl0[NT], D[NT], sl1[NT];
-  for (int s = s0; s < s0 + EI_RUN && s <= Pcap; ++s) {
+  for (int s = s0; s < s0 + run && s <= Pcap; ++s) {
     const unsigned key = keys_sorted[s];
     if (key == 0xFFFFFFFFu) break;  // sorted: nothing valid follows
     const int p = vals_sorted[s];
@@ -358,13 +358,17 @@ void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int
   const int R4 = R / 4;
   const int groups = R4 >= 256 ? 1 : 256 / R4;
   const bool direct = edge_interp_direct(Pcap);
-  const dim3 grid(direct ? cdive(n, groups) : cdive(n, groups * EI_RUN)), block(groups * R4);
+  // pairs per thread group: EI_RUN at batch scale (consecutive sorted pairs share their interval's rows); a mid-size pair
+  // list (one system of ~1000 atoms) has ~1 pair per interval and too few groups to fill the chip: shorter runs
+  static const int run_env = getenv("TMDNET_EI_RUN") ? atoi(getenv("TMDNET_EI_RUN")) : 0;  // developer switch
+  const int run = run_env > 0 ? run_env : (n / 4096 < 4 ? 4 : (n / 4096 > EI_RUN ? EI_RUN : n / 4096));
+  const dim3 grid(direct ? cdive(n, groups) : cdive(n, groups * run)), block(groups * R4);
 #define EI_LAUNCH(NT)                                                                                                          \
   if (direct) {                                                                                                                \
     hipLaunchKernelGGL((k_edge_interp_direct<NT>), grid, block, 0, s, g, Pcap, a, R4, T, lo, up, h, 1.0f / h, C, dC);          \
     C = dC = nullptr; /* written once */                                                                                        \
   } else                                                                                                                       \
-    hipLaunchKernelGGL((k_edge_interp<NT>), grid, block, 0, s, g, Pcap, keys_s, vals_s, a, R4, T, lo, h, 1.0f / h)
+    hipLaunchKernelGGL((k_edge_interp<NT>), grid, block, 0, s, g, Pcap, keys_s, vals_s, a, R4, T, lo, h, 1.0f / h, run)
   switch (ntab) {
     case 1: EI_LAUNCH(1); break;
     case 2: EI_LAUNCH(2); break;

@@ -407,6 +407,13 @@ void launch_ztables(const float* emb, const float* WaT, const float* WbT, const 
   hipLaunchKernelGGL(k_ztables, dim3(Z), dim3(fthreads(F)), 0, s, emb, WaT, WbT, b2, Z, F, Utab, Vtab);
 }
 
+static int embed_split_rows() {
+  static const int v = [] {
+    const char* e = getenv("TMDNET_SPLIT_ROWS");
+    return e ? atoi(e) : 1024;
+  }();
+  return v;
+}
 static bool sweep_v4() {
   static const bool on = getenv("TMDNET_V4_SWEEP") != nullptr;  // developer switch (profiles/r01_notes.md)
   return on;
@@ -501,7 +508,7 @@ void launch_embed_scatter(const Graph& g, int N, int F, const int64_t* z, const 
                           const float* C, float* u0, float* s0n, hipStream_t s) {
   if (N <= 0) return;
   // measured on MI355X (profiles/r01_notes.md): the 16-byte CSR sweep is slower than one-channel-per-lane here (scalar edge loads, 4x the waves)
-  if (N <= 512 && F <= 128 && F % 64 == 0) {
+  if (N <= embed_split_rows() && F <= 128 && F % 64 == 0) {
     hipLaunchKernelGGL(k_embed_scatter_split, dim3(N), dim3(kES * F), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
     return;
   }
@@ -651,7 +658,16 @@ __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, co
 // EG = 4 thread groups of a block take every 4th edge of the row and their partial sums are combined through LDS in a
 // fixed order.  Used below `kSplitRows` rows; the summation order differs from the one-group kernels by rounding only.
 constexpr int kEG = 8;
-constexpr int kSplitRows = 512;  // measured: 64 atoms 13 -> 7 us per sweep (4 groups; 8 groups: another -10 us per step), 1029 atoms slower with the split
+static int split_rows_max() {
+  static const int v = [] {
+    const char* e = getenv("TMDNET_SPLIT_ROWS");  // developer switch
+    return e ? atoi(e) : 1024;
+  }();
+  return v;
+}
+// measured (profiles/r02_notes.md): 64 atoms 13 -> 7 us per sweep with 4 groups, another -10 us per step with 8; 1024 atoms
+// 0.67 -> 0.64 ms per step; 2048 atoms slower with the split
+#define kSplitRows split_rows_max()
 // MODE 0: forward message + group product + normalisation ; 1: adjoint (out += gather) ; 2: adjoint + the per-pair distance
 // gradient halves h(i <- j) = sum dw[p] * gMi[j] * Pn[i] (see k_message_adjoint_gd; Mi then carries Pn, q carries dw)
 template <int MODE>
