@@ -95,11 +95,27 @@ __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int 
   const bool staged = hi >= lo && wn <= MP_W;  // block-uniform
   if (staged) {
     // window rows -> LDS as [row][9][32]: 8 lanes x 16 B cover the 32 channels of one (row, component)
+    // all of a thread's pieces are requested before the first one is stored: as a plain loop (trip count unknown to the
+    // compiler) this was nine dependent load -> store round trips, 9 of the 44 us a block lives
     const int pieces = wn * 9 * PIECES;
-    for (int idx = tid; idx < pieces; idx += MP_THREADS) {
-      const int rc = idx / PIECES, f4 = (idx % PIECES) << 2;
-      const int row = rc / 9, c = rc - row * 9;
-      *reinterpret_cast<f4v*>(&win[rc * MP_FC + f4]) = ldg4(src + (int64_t)(lo + row) * F9 + c * F + c0 + f4);
+    constexpr int NIT = (MP_W * 9 * PIECES + MP_THREADS - 1) / MP_THREADS;
+    f4v tmp[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = tid + k * MP_THREADS;
+      if (idx < pieces) {
+        const int rc = idx / PIECES, f4 = (idx % PIECES) << 2;
+        const int row = rc / 9, c = rc - row * 9;
+        tmp[k] = ldg4(src + (int64_t)(lo + row) * F9 + c * F + c0 + f4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = tid + k * MP_THREADS;
+      if (idx < pieces) {
+        const int rc = idx / PIECES, f4 = (idx % PIECES) << 2;
+        *reinterpret_cast<f4v*>(&win[rc * MP_FC + f4]) = tmp[k];
+      }
     }
     __syncthreads();
   }
