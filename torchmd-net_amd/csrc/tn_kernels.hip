@@ -430,18 +430,32 @@ __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
     const float Ui = Utab[zi * F + f];
     float I0 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f, t00 = 0.f, t01 = 0.f, t02 = 0.f, t11 = 0.f, t12 = 0.f, t22 = 0.f;
-    for (int e = e0; e < e1; ++e) {
+    // software pipeline: the operands of edge e+1 are requested before edge e is accumulated
+    struct In {
+      float rx, ry, rz, c, v, q0, q1, q2;
+    };
+    auto load = [&](int e, In& o) {
       const int j = g.col[e], p = g.epair[e];
       const float sg = g.esign[e];
-      float rx = 0.f, ry = 0.f, rz = 0.f;
-      if (sg != 0.f) {
-        rx = sg * g.prhat[p * 3];
-        ry = sg * g.prhat[p * 3 + 1];
-        rz = sg * g.prhat[p * 3 + 2];
-      }
-      const float cz = C[p] * (Ui + Vtab[z[j] * F + f]);
+      const float h0 = g.prhat[p * 3], h1 = g.prhat[p * 3 + 1], h2 = g.prhat[p * 3 + 2];
+      o.rx = sg != 0.f ? sg * h0 : 0.f;
+      o.ry = sg != 0.f ? sg * h1 : 0.f;
+      o.rz = sg != 0.f ? sg * h2 : 0.f;
+      o.c = C[p];
+      o.v = Vtab[z[j] * F + f];
       const float* q = Q + (int64_t)p * F3 + f;
-      const float W0 = cz * q[0], W1 = cz * q[F], W2 = cz * q[2 * F];
+      o.q0 = q[0];
+      o.q1 = q[F];
+      o.q2 = q[2 * F];
+    };
+    In cur, nxt;
+    if (e0 < e1) load(e0, cur);
+    for (int e = e0; e < e1; ++e) {
+      load(e + 1 < e1 ? e + 1 : e, nxt);
+      const float rx = cur.rx, ry = cur.ry, rz = cur.rz;
+      const float cz = cur.c * (Ui + cur.v);
+      const float W0 = cz * cur.q0, W1 = cz * cur.q1, W2 = cz * cur.q2;
+      cur = nxt;
       I0 += W0;
       v0 += W1 * rx; v1 += W1 * ry; v2 += W1 * rz;
       t00 += W2 * rx * rx; t01 += W2 * rx * ry; t02 += W2 * rx * rz;
