@@ -220,7 +220,7 @@ struct InterpArgs {
 // consecutive pairs fall into the same or the next grid interval (2e5 pairs over 8192 intervals), so the four table
 // vectors of a column stay in registers until the interval changes - the table traffic drops from 4 rows per pair to 4
 // rows per visited interval and the kernel is left with its output writes.
-constexpr int EI_RUN = 32;  // sorted pairs per group
+constexpr int EI_RUN = 8;  // sorted pairs per group (measured at C2: 1 -> 0.56, 2 -> 0.47, 4 -> 0.41, 8 -> 0.39, 16 -> 0.41, 32 -> 0.42, 64 -> 0.44 ms)
 template <int NT>
 __global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const unsigned* __restrict__ keys_sorted,
                                                     const int* __restrict__ vals_sorted, InterpArgs a, int R4, int T, float lo,
@@ -358,8 +358,8 @@ void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int
   const int R4 = R / 4;
   const int groups = R4 >= 256 ? 1 : 256 / R4;
   const bool direct = edge_interp_direct(Pcap);
-  // pairs per thread group: EI_RUN at batch scale (consecutive sorted pairs share their interval's rows); a mid-size pair
-  // list (one system of ~1000 atoms) has ~1 pair per interval and too few groups to fill the chip: shorter runs
+  // pairs per thread group: EI_RUN at batch scale (consecutive sorted pairs share their interval's rows, but long runs leave
+  // too few groups in flight); a mid-size pair list (one system of ~1000 atoms) has ~1 pair per interval: shorter runs
   static const int run_env = getenv("TMDNET_EI_RUN") ? atoi(getenv("TMDNET_EI_RUN")) : 0;  // developer switch
   const int run = run_env > 0 ? run_env : (n / 4096 < 4 ? 4 : (n / 4096 > EI_RUN ? EI_RUN : n / 4096));
   const dim3 grid(direct ? cdive(n, groups) : cdive(n, groups * run)), block(groups * R4);
