@@ -236,7 +236,8 @@ int launch_gemm_sb1(const GemmArgs& a, hipStream_t stream) {
     return n;
   }();
   const int total = tiles_m * tiles_n * a.groups;
-  const dim3 grid(total < 3 * n_cu ? total : 3 * n_cu), block(256);  // persistent: 3 blocks per CU
+  static const int bpc = getenv("TMDNET_GEMM_BPC") ? atoi(getenv("TMDNET_GEMM_BPC")) : 3;  // developer switch
+  const dim3 grid(total < bpc * n_cu ? total : bpc * n_cu), block(256);  // persistent: 3 blocks per CU
   switch (epi_kind(a)) {
     case EPI_PLAIN: hipLaunchKernelGGL((k_gemm_sb1<EPI_PLAIN>), grid, block, 0, stream, a, tiles_m, tiles_n); break;
     case EPI_SILU_PRE: hipLaunchKernelGGL((k_gemm_sb1<EPI_SILU_PRE>), grid, block, 0, stream, a, tiles_m, tiles_n); break;
