@@ -180,6 +180,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// four wave-wide sums for the price of seven exchanges: halve the value set at xor 32 and xor 16, then reduce one value
+// over 16 lanes.  Totals land in lane 0 (a), 16 (b), 32 (c), 48 (d).
+__device__ __forceinline__ float wave_sum4(float a, float b, float c, float d, int lane) {
+  const bool hi = lane & 32;
+  float k0 = hi ? c : a, k1 = hi ? d : b;          // kept pair
+  const float s0 = hi ? a : c, s1 = hi ? b : d;    // pair handed to the partner lane
+  k0 += __shfl_xor(s0, 32, 64);
+  k1 += __shfl_xor(s1, 32, 64);
+  const bool q = lane & 16;
+  float v = q ? k1 : k0;
+  v += __shfl_xor(q ? k0 : k1, 16, 64);
+  return row_sum(v, 16);
+}
+
 // CosineCutoff and derivative (reference models/utils.py:506-528)
 __device__ __forceinline__ void cosine_cutoff(float d, float lo, float up, float& c, float& dc) {
   const float PI = 3.14159265358979323846f;

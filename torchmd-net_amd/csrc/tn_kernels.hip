@@ -800,7 +800,9 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
   load9(Pn + (int64_t)i * F9 + f, F, y);
 #pragma unroll
   for (int c = 0; c < 9; ++c) acc[c] = 0.f;
-  for (int e = e0; e < e1; ++e) {
+  // the per-edge channel sums h are reduced FOUR edges at a time (wave_sum4: seven exchanges for four wave sums instead
+  // of six each; the totals land in lanes 0 / 16 / 32 / 48, which write the four slots)
+  auto edge = [&](int e, float& h, int& slot_idx) {
     const int j = g.col[e], p = g.epair[e];
     const float sg = g.esign[e];
     const float* wp = w + (int64_t)p * F3 + f;
@@ -820,10 +822,31 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
     acc[6] += w2 * s9[6];
     acc[7] += w2 * s9[7];
     acc[8] += w2 * s9[8];
-    float h = d0 * (s9[0] * y[0]) + d1 * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
-              d2 * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
+    h = d0 * (s9[0] * y[0]) + d1 * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
+        d2 * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
+    slot_idx = sg != 0.f ? 2 * p + (sg > 0.f ? 0 : 1) : -1;  // self edge: no slot
+  };
+  int e = e0;
+  for (; e + 4 <= e1; e += 4) {
+    float h0, h1, h2, h3;
+    int s0, s1, s2, s3;
+    edge(e, h0, s0);
+    edge(e + 1, h1, s1);
+    edge(e + 2, h2, s2);
+    edge(e + 3, h3, s3);
+    const float tot = wave_sum4(h0, h1, h2, h3, lane);
+    if ((lane & 15) == 0) {
+      const int q4 = lane >> 4;
+      const int si = q4 == 0 ? s0 : (q4 == 1 ? s1 : (q4 == 2 ? s2 : s3));
+      if (si >= 0) slots[(int64_t)wave * slot_stride + si] = tot;
+    }
+  }
+  for (; e < e1; ++e) {
+    float h;
+    int si;
+    edge(e, h, si);
     h = wave_sum(h);
-    if (lane == 0 && sg != 0.f) slots[(int64_t)wave * slot_stride + 2 * (int64_t)p + (sg > 0.f ? 0 : 1)] = h;
+    if (lane == 0 && si >= 0) slots[(int64_t)wave * slot_stride + si] = h;
   }
   float* o = gPn + (int64_t)i * F9 + f;
 #pragma unroll
