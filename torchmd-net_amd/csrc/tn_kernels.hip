@@ -430,7 +430,6 @@ __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
     const float Ui = Utab[zi * F + f];
     float I0 = 0.f, v0 = 0.f, v1 = 0.f, v2 = 0.f, t00 = 0.f, t01 = 0.f, t02 = 0.f, t11 = 0.f, t12 = 0.f, t22 = 0.f;
-    // software pipeline: the operands of edge e+1 are requested before edge e is accumulated
     struct In {
       float rx, ry, rz, c, v, q0, q1, q2;
     };
@@ -448,18 +447,31 @@ __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict
       o.q1 = q[F];
       o.q2 = q[2 * F];
     };
-    In cur, nxt;
-    if (e0 < e1) load(e0, cur);
-    for (int e = e0; e < e1; ++e) {
-      load(e + 1 < e1 ? e + 1 : e, nxt);
-      const float rx = cur.rx, ry = cur.ry, rz = cur.rz;
-      const float cz = cur.c * (Ui + cur.v);
-      const float W0 = cz * cur.q0, W1 = cz * cur.q1, W2 = cz * cur.q2;
-      cur = nxt;
+    auto add = [&](const In& c) {
+      const float rx = c.rx, ry = c.ry, rz = c.rz;
+      const float cz = c.c * (Ui + c.v);
+      const float W0 = cz * c.q0, W1 = cz * c.q1, W2 = cz * c.q2;
       I0 += W0;
       v0 += W1 * rx; v1 += W1 * ry; v2 += W1 * rz;
       t00 += W2 * rx * rx; t01 += W2 * rx * ry; t02 += W2 * rx * rz;
       t11 += W2 * ry * ry; t12 += W2 * ry * rz; t22 += W2 * rz * rz;
+    };
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) {  // four edges' operands in flight together, accumulated in edge order
+      In a0, a1, a2, a3;
+      load(e, a0);
+      load(e + 1, a1);
+      load(e + 2, a2);
+      load(e + 3, a3);
+      add(a0);
+      add(a1);
+      add(a2);
+      add(a3);
+    }
+    for (; e < e1; ++e) {
+      In a0;
+      load(e, a0);
+      add(a0);
     }
     const float tr3 = (t00 + t11 + t22) * (1.0f / 3.0f);
     float u[9] = {I0, v0, v1, v2, t00 - tr3, t01, t02, t11 - tr3, t12};
