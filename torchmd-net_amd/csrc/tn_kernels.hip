@@ -712,7 +712,8 @@ __global__ __launch_bounds__(1024) void k_message_split(Graph g, int N, int F, c
 #pragma unroll
   for (int c = 0; c < 9; ++c) acc[c] = y[c] = 0.f;
   if (MODE == 2) load9(Mi + (int64_t)i * F9 + f, F, y);  // Pn[i]
-  for (int e = e0 + grp; e < e1; e += kEG) {
+  // an edge of this thread group: accumulate, and (MODE 2) the channel product whose wave sum is the g_d half
+  auto edge = [&](int e, float& h, int& si) {
     const int j = g.col[e], p = g.epair[e];
     const float* wp = w + (int64_t)p * F3 + f;
     const float* sp = src + (int64_t)j * F9 + f;
@@ -731,11 +732,35 @@ __global__ __launch_bounds__(1024) void k_message_split(Graph g, int N, int F, c
     acc[8] += w2 * s9[8];
     if (MODE == 2) {
       const float* dp = q + (int64_t)p * F3 + f;  // dw
-      float h = dp[0] * (s9[0] * y[0]) + dp[F] * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
-                dp[2 * F] * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
-      h = wave_sum(h);
+      h = dp[0] * (s9[0] * y[0]) + dp[F] * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
+          dp[2 * F] * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
       const float sg = g.esign[e];
-      if ((f & 63) == 0 && sg != 0.f) slots[(int64_t)(f >> 6) * slot_stride + 2 * (int64_t)p + (sg > 0.f ? 0 : 1)] = h;
+      si = sg != 0.f ? 2 * p + (sg > 0.f ? 0 : 1) : -1;
+    }
+  };
+  // two edges of the group per trip: their loads are independent and issue together (a group walks 3-4 edges of a row)
+  int e = e0 + grp;
+  for (; e + kEG < e1; e += 2 * kEG) {
+    float h0 = 0.f, h1 = 0.f;
+    int s0 = -1, s1 = -1;
+    edge(e, h0, s0);
+    edge(e + kEG, h1, s1);
+    if (MODE == 2) {
+      h0 = wave_sum(h0);
+      h1 = wave_sum(h1);
+      if ((f & 63) == 0) {
+        if (s0 >= 0) slots[(int64_t)(f >> 6) * slot_stride + s0] = h0;
+        if (s1 >= 0) slots[(int64_t)(f >> 6) * slot_stride + s1] = h1;
+      }
+    }
+  }
+  if (e < e1) {
+    float h0 = 0.f;
+    int s0 = -1;
+    edge(e, h0, s0);
+    if (MODE == 2) {
+      h0 = wave_sum(h0);
+      if ((f & 63) == 0 && s0 >= 0) slots[(int64_t)(f >> 6) * slot_stride + s0] = h0;
     }
   }
   if (grp > 0) {
