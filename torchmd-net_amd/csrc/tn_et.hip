@@ -208,17 +208,8 @@ __global__ void k_et_attn_fwd_p(Graph g, EtAttnArgs a, float* __restrict__ xagg,
   const int e0 = g.rowptr[t], e1 = g.rowptr[t + 1];
   const float qt = a.qkv[(int64_t)t * 5 * F + c];
   float xa = 0.f, va0 = 0.f, va1 = 0.f, va2 = 0.f;
-  EtFwdIn cur, nxt;
-  EtIdx in = {0, 0, 0.f}, inn;
   const int rot = et_rot_start(g.col, e0, e1, t);
-  if (e0 < e1) {
-    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e0, e0, e1, rot)), c, cur);
-    in = et_idx(g, et_rot(e0 + 1 < e1 ? e0 + 1 : e0, e0, e1, rot));
-  }
-  for (int e = e0; e < e1; ++e) {
-    inn = et_idx(g, et_rot(e + 2 < e1 ? e + 2 : e1 - 1, e0, e1, rot));
-    et_fwd_load<HAS_DK, HAS_DV>(g, a, in, c, nxt);
-    in = inn;
+  auto add = [&](const EtFwdIn& cur) {
     const float cv = VCUT ? cur.C : 1.0f, ca = VCUT ? 1.0f : cur.C;
     const float ak = head_sum_t<HD>(qt * cur.kj * cur.dk, hd);
     const float A = silu(ak) * ca;
@@ -227,7 +218,24 @@ __global__ void k_et_attn_fwd_p(Graph g, EtAttnArgs a, float* __restrict__ xagg,
     va0 += cur.vs0 * s1 + s2 * cur.r0;
     va1 += cur.vs1 * s1 + s2 * cur.r1;
     va2 += cur.vs2 * s1 + s2 * cur.r2;
-    cur = nxt;
+  };
+  // four edges per trip: their rows are requested together (independent loads), then accumulated in list order
+  int e = e0;
+  for (; e + 4 <= e1; e += 4) {
+    EtFwdIn a0, a1, a2, a3;
+    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e, e0, e1, rot)), c, a0);
+    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e + 1, e0, e1, rot)), c, a1);
+    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e + 2, e0, e1, rot)), c, a2);
+    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e + 3, e0, e1, rot)), c, a3);
+    add(a0);
+    add(a1);
+    add(a2);
+    add(a3);
+  }
+  for (; e < e1; ++e) {
+    EtFwdIn a0;
+    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e, e0, e1, rot)), c, a0);
+    add(a0);
   }
   xagg[(int64_t)t * F + c] = xa;
   float* o = vagg + (int64_t)t * 3 * F + c;
