@@ -211,7 +211,8 @@ __global__ void k_tn2_edge_gw(Graph g, int N, int F, const float* __restrict__ g
   float gm[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) gm[c] = act ? gMi[(int64_t)i * F9 + c * F + fc_] : 0.f;
-  for (int e = e0; e < e1; ++e) {
+  // one edge: g_pre3 row of the edge, and the channel product whose wave sum is g_C[e]
+  auto edge = [&](int e, float& h) {
     const int j = g.col[e];
     const float* sp = Pn + (int64_t)j * F9 + fc_;
     const float gw0 = gm[0] * sp[0];
@@ -226,7 +227,22 @@ __global__ void k_tn2_edge_gw(Graph g, int N, int F, const float* __restrict__ g
       o[F] = gw1 * ce * silu_grad(p1);
       o[2 * F] = gw2 * ce * silu_grad(p2);
     }
-    float h = gw0 * silu(p0) + gw1 * silu(p1) + gw2 * silu(p2);  // inactive lanes: gm = 0 -> h = 0
+    h = gw0 * silu(p0) + gw1 * silu(p1) + gw2 * silu(p2);  // inactive lanes: gm = 0 -> h = 0
+  };
+  // four edges per trip: independent loads in flight together, one wave_sum4 for the four channel sums
+  int e = e0;
+  for (; e + 4 <= e1; e += 4) {
+    float h0, h1, h2, h3;
+    edge(e, h0);
+    edge(e + 1, h1);
+    edge(e + 2, h2);
+    edge(e + 3, h3);
+    const float tot = wave_sum4(h0, h1, h2, h3, lane);
+    if ((lane & 15) == 0) gCe_slots[(int64_t)wave * slot_stride + e + (lane >> 4)] = tot;
+  }
+  for (; e < e1; ++e) {
+    float h;
+    edge(e, h);
     h = wave_sum(h);
     if (lane == 0) gCe_slots[(int64_t)wave * slot_stride + e] = h;
   }
@@ -247,12 +263,32 @@ __global__ void k_tn2_edge_reduce(Graph g, int N, int F, const float* __restrict
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
     float sb = 0.f, sc = 0.f;
-    for (int e = e0; e < e1; ++e) {
-      const int j = g.col[e], r = erev[e];
-      const float a = g_pre1[(int64_t)e * F + f], b = g_pre1[(int64_t)r * F + f];
+    auto edge = [&](int e, float& a, float& b) {
+      const int r = erev[e];
+      a = g_pre1[(int64_t)e * F + f];
+      b = g_pre1[(int64_t)r * F + f];
+    };
+    auto put = [&](int e, float a, float b) {
       sb += a;
       sc += b;
-      if (j < i) gAp[(int64_t)g.epair[e] * F + f] = a + b;
+      if (g.col[e] < i) gAp[(int64_t)g.epair[e] * F + f] = a + b;
+    };
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) {  // four edges' loads in flight together, summed in list order
+      float a0, b0, a1, b1, a2, b2, a3, b3;
+      edge(e, a0, b0);
+      edge(e + 1, a1, b1);
+      edge(e + 2, a2, b2);
+      edge(e + 3, a3, b3);
+      put(e, a0, b0);
+      put(e + 1, a1, b1);
+      put(e + 2, a2, b2);
+      put(e + 3, a3, b3);
+    }
+    for (; e < e1; ++e) {
+      float a, b;
+      edge(e, a, b);
+      put(e, a, b);
     }
     gB[(int64_t)i * F + f] = sb;
     gCs[(int64_t)i * F + f] = sc;
