@@ -201,6 +201,7 @@ Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   Carver c(ws);
   Graph g{};
   const int64_t pcap = ecap / 2 + 1;
+  g.small_mols = N <= 96 * (B > 0 ? B : 1) ? 1 : 0;
   g.counts = c.take<int>(8);
   g.mstart = c.take<int>(B);
   g.mend = c.take<int>(B);

@@ -40,6 +40,7 @@ struct Graph {  // device pointers into the graph workspace
   int ncx, ncy, ncz;     // explicit grid (tmdnet_set_cell_grid); 0 = from the box
   int use_cell;          // 0: brute force, 1: cell list / one molecule, 2: cell list / several molecules
   int max_z;
+  int small_mols;        // host hint: on average <= 96 atoms per molecule, i.e. the column window of a 64-row tile fits LDS
 };
 
 struct RadialParams {

@@ -825,8 +825,11 @@ void launch_message(const Graph& g, int N, int F, const float* w, const float* s
     hipLaunchKernelGGL((k_message_split<0>), dim3(N), dim3(kEG * F), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
     return;
   }
-  if (message_pair_ok(N, F)) return launch_message_pair(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
-  if (message_tile_ok(N, F)) return launch_message_tile(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
+  // the tile kernels pay off when a tile's column window fits LDS (batches of small molecules); one large system in cell
+  // order has windows of hundreds of rows: there the row kernel with four edges in flight is faster (10 k-atom box:
+  // 0.36 -> 0.26 ms per sweep)
+  if (g.small_mols && message_pair_ok(N, F)) return launch_message_pair(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
+  if (g.small_mols && message_tile_ok(N, F)) return launch_message_tile(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   if (sweep_v4() && gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
 }
