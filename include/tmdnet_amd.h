@@ -96,6 +96,11 @@ int tmdnet_create_et(const tmdnet_et_hparams* hp, tmdnet_model** out);
 int tmdnet_destroy(tmdnet_model* m);
 const char* tmdnet_last_error(const tmdnet_model* m);
 const char* tmdnet_version(void);
+/* ABI revision of this header: bumped whenever an exported signature or struct layout changes (3: `z` in
+ * tmdnet_build_graph[_static], `strategy` in tmdnet_neighbor_pairs).  A binding compares its compile-time
+ * TMDNET_ABI_VERSION with the loaded library's tmdnet_abi_version() before its first call. */
+#define TMDNET_ABI_VERSION 3
+int tmdnet_abi_version(void);
 
 /* Parameters are addressed by the reference's state-dict keys without the "model." prefix
  * (SURVEY.md Appendix A), e.g. "representation_model.layers.0.linears_scalar.2.weight", plus

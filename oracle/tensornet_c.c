@@ -1,4 +1,5 @@
-/* TEST INFRASTRUCTURE ONLY -- plain-C, single-thread restatement of the TensorNet energy+force path.
+/* TEST INFRASTRUCTURE ONLY -- plain-C restatement (scalar arithmetic; OpenMP over independent rows only, so every output
+ * element is still one sequential chain and the results do not depend on the thread count) of the TensorNet energy+force path.
  *
  * Role: checker for the HIP kernels (tests/, __graft_entry__.smoke(), bench.py cpu_baseline leg).
  * The product (torchmd-net_amd/) never links, imports or calls this file.
@@ -107,6 +108,7 @@ static void tr3(const REAL a[3][3], REAL t[3][3]) { for (int i = 0; i < 3; ++i) 
 
 /* y[rows,out] = x[rows,in] W[out,in]^T (+b) ; transposed: y[rows,in] = x[rows,out] W[out,in] */
 static void linear(const REAL* x, int rows, int in, int out, const REAL* W, const REAL* b, REAL* y) {
+#pragma omp parallel for schedule(static)
   for (int r = 0; r < rows; ++r)
     for (int o = 0; o < out; ++o) {
       REAL s = b ? b[o] : 0;
@@ -115,6 +117,7 @@ static void linear(const REAL* x, int rows, int in, int out, const REAL* W, cons
     }
 }
 static void linear_T(const REAL* g, int rows, int in, int out, const REAL* W, REAL* gx) {
+#pragma omp parallel for schedule(static)
   for (int r = 0; r < rows; ++r)
     for (int k = 0; k < in; ++k) {
       REAL s = 0;
@@ -124,6 +127,7 @@ static void linear_T(const REAL* g, int rows, int in, int out, const REAL* W, RE
 }
 /* channel mixing of the 9 components with 3 weight matrices (I, A, S)  (tensornet.py:595-617,752-754,808-810) */
 static void tensor_linear(const REAL* u, int N, int F, const REAL* const W[3], int transpose, REAL* out) {
+#pragma omp parallel for schedule(static)
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < 9; ++c) {
       const REAL* x = u + ((size_t)n * 9 + c) * F;
@@ -167,10 +171,13 @@ static void layernorm_bwd(const REAL* g, int rows, int R, const REAL* xh, const 
 /* out[i,c,:] = sum over directed edges (i <- j) of w[pair,type(c),:] * src[j,c,:]   (tensornet.py:622-679) */
 static void gather_sum(int N, int F, int E, const int* er, const int* ec, const int* ep, const REAL* w, const REAL* src, REAL* out) {
   memset(out, 0, sizeof(REAL) * (size_t)N * 9 * F);
-  for (int e = 0; e < E; ++e)
-    for (int c = 0; c < 9; ++c)
-      for (int f = 0; f < F; ++f)
-        out[((size_t)er[e] * 9 + c) * F + f] += w[((size_t)ep[e] * 3 + TYPE_OF[c]) * F + f] * src[((size_t)ec[e] * 9 + c) * F + f];
+  /* threads own channel ranges; every output element still adds its edges in list order */
+#pragma omp parallel for schedule(static)
+  for (int f0 = 0; f0 < F; f0 += 8)
+    for (int e = 0; e < E; ++e)
+      for (int c = 0; c < 9; ++c)
+        for (int f = f0; f < F && f < f0 + 8; ++f)
+          out[((size_t)er[e] * 9 + c) * F + f] += w[((size_t)ep[e] * 3 + TYPE_OF[c]) * F + f] * src[((size_t)ec[e] * 9 + c) * F + f];
 }
 
 int tn_oracle_energy_forces(const TnParams* p, int N, int B, const int64_t* z, const REAL* pos, const int64_t* batch,
@@ -237,8 +244,10 @@ int tn_oracle_energy_forces(const TnParams* p, int N, int B, const int64_t* z, c
     for (int k = 0; k < P1; ++k) memcpy(Q + ((size_t)k * 3 + c) * F, tmp + (size_t)k * F, sizeof(REAL) * F);
     free(tmp);
   }
-  REAL *Zij = NEW((size_t)E * F), *cat = NEW(2 * F);
+  REAL *Zij = NEW((size_t)E * F);
+#pragma omp parallel for schedule(static)
   for (int e = 0; e < E; ++e) { /* emb2([emb(z_i), emb(z_j)]), tensornet.py:526-541 */
+    REAL cat[2 * F];
     memcpy(cat, p->emb + (size_t)z[er[e]] * F, sizeof(REAL) * F);
     memcpy(cat + F, p->emb + (size_t)z[ec[e]] * F, sizeof(REAL) * F);
     linear(cat, 1, 2 * F, F, p->emb2_w, p->emb2_b, Zij + (size_t)e * F);
@@ -422,6 +431,7 @@ int tn_oracle_energy_forces(const TnParams* p, int N, int B, const int64_t* z, c
         }
       gather_sum(N, F, E, er, ec, ep, w[l], gMi, tmp9); /* symmetric graph + pair-symmetric weights */
       for (size_t k = 0; k < N9; ++k) gPn[k] += tmp9[k];
+#pragma omp parallel for schedule(static)
       for (int k = 0; k < P; ++k) { /* the self pair has no position dependence */
         for (int f = 0; f < F; ++f) {
           REAL gw[3] = {0, 0, 0};
@@ -537,7 +547,7 @@ done:
   for (int l = 0; l <= L; ++l) free(X[l]);
   free(X); free(Xh); free(Ch); free(tA); free(tB); free(feat); free(lnr); free(xhr); free(rstdr); free(al); free(x); free(ao);
   free(pi); free(pj); free(pd); free(pr); free(er); free(ec); free(ep); free(re); free(phi); free(dphi); free(C); free(dC); free(kap);
-  free(Q); free(Zij); free(cat); free(I0); free(vec); free(T6); free(Wd); free(u0); free(s0n); free(ln0); free(xh0); free(rstd0);
+  free(Q); free(Zij); free(I0); free(vec); free(T6); free(Wd); free(u0); free(s0n); free(ln0); free(xh0); free(rstd0);
   free(a1); free(h1); free(a2); free(gates); free(UX);
   return P;
 }

@@ -29,11 +29,13 @@ def _batch(sizes, seed, z_max):
     return torch.cat(zs), torch.cat(ps), torch.cat(bs)
 
 
-def _check(args, T, sizes, seed, box=None, q=None, hp_extra=None):
+def _check(args, T, sizes, seed, box=None, q=None, hp_extra=None, options=None):
     from torchmdnet_amd.models.model import create_model
 
     torch.manual_seed(seed)
     model = create_model(dict(args)).to("cuda")
+    for name, value in (options or {}).items():
+        model.set_engine_option(name, value)
     z, pos, batch = _batch(sizes, 1000 + seed, int(args["max_z"]))
     kw = {}
     if box is not None:
@@ -115,6 +117,21 @@ def test_tensornet2_shapes(hip_lib, case):
                 num_layers=L, q_dim=qd, q_weights=[0.5 + 0.25 * i for i in range(L + 1)], cutoff_upper=4.5, max_z=12)
     q = torch.tensor([float(i % 3 - 1) for i in range(len(sizes))])
     _check(args, T, sizes, seed=7 * F + qd, q=q)
+
+
+def test_tensornet2_nine_layers_through_the_tables(hip_lib):
+    """TensorNet2 allows num_layers >= 9 when q_dim is small ((L + 1) q_dim <= 64); its L per-layer pair-block
+    tables then exceed the eight slots of one interpolation launch -> they go in chunks of four.  Tables forced on for a
+    short pair list (both the bucketed and the one-launch interpolation), and 8 + 1 TensorNet tables likewise."""
+    from oracle import tn2_torch as T2
+    from oracle import tensornet_torch as T
+
+    args = dict(W.TINY_ARGS, model="tensornet2", output_model="ScalarPlusWeightedCoulomb", embedding_dimension=32, num_rbf=8,
+                num_layers=9, q_dim=4, q_weights=[1.0] * 10, cutoff_upper=4.5, max_z=12)
+    q = torch.tensor([1.0, -1.0])
+    _check(args, T2, [20, 9], seed=77, q=q, options={"edge_table_min_pairs": 0})
+    args = dict(W.TINY_ARGS, embedding_dimension=32, num_rbf=8, num_layers=7, cutoff_upper=4.5, max_z=12)
+    _check(args, T, [20, 9], seed=78, options={"edge_table_min_pairs": 0})
 
 
 def test_interleaved_models_sizes_and_streams(hip_lib):

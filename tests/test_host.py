@@ -266,6 +266,19 @@ def test_fingerprint_cache_follows_module_changes():
     model.double()
     assert model._engine.tensors is None  # rebuilt lazily with the new tensor objects
     assert len(model._fingerprint()) == len(fp0)
+    # replaced tensor OBJECTS: same version / possibly same address, different identity
+    model.float()
+    fp2 = model._fingerprint()
+    model.load_state_dict(copy.deepcopy(model.state_dict()), assign=True)
+    fp3 = model._fingerprint()
+    assert fp3 != fp2
+    lin = model.representation_model.linear
+    lin.weight = torch.nn.Parameter(lin.weight.detach().clone())
+    fp4 = model._fingerprint()
+    assert fp4 != fp3
+    model.output_model = copy.deepcopy(model.output_model)  # swapped submodule
+    assert model._fingerprint() != fp4
+    assert model._fingerprint() == model._fingerprint()
     assert "equivariant-transformer" in __import__("torchmdnet_amd.models", fromlist=["x"]).__all_models__
 
 

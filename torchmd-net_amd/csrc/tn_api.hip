@@ -479,7 +479,8 @@ int build_edge_tables(tmdnet_model* m) {
 
 extern "C" {
 
-const char* tmdnet_version(void) { return "tmdnet_amd 0.1 (gfx950)"; }
+const char* tmdnet_version(void) { return "tmdnet_amd 0.3 (gfx950)"; }
+int tmdnet_abi_version(void) { return TMDNET_ABI_VERSION; }
 
 int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out) {
   if (!hp || !out) return TMDNET_ERR_INVALID;

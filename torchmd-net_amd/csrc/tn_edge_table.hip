@@ -347,13 +347,7 @@ void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int
                         float* const* outs, float* const* douts, const unsigned* keys_s, const int* vals_s, hipStream_t s, float* C,
                         float* dC) {
   const int n = Pcap + 1;
-  InterpArgs a{};
-  a.ntab = ntab;
-  for (int t = 0; t < ntab; ++t) {
-    a.tab[t] = tabs[t];
-    a.out[t] = outs[t];
-    a.dout[t] = douts[t];
-  }
+  InterpArgs a{};  // filled per chunk of four tables below: `ntab` is not bounded by the struct's eight slots
   const float h = (up - lo) / (float)T;
   const int R4 = R / 4;
   const int groups = R4 >= 256 ? 1 : 256 / R4;
@@ -369,28 +363,19 @@ void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int
     C = dC = nullptr; /* written once */                                                                                        \
   } else                                                                                                                       \
     hipLaunchKernelGGL((k_edge_interp<NT>), grid, block, 0, s, g, Pcap, keys_s, vals_s, a, R4, T, lo, h, 1.0f / h, run)
-  switch (ntab) {
-    case 1: EI_LAUNCH(1); break;
-    case 2: EI_LAUNCH(2); break;
-    case 3: EI_LAUNCH(3); break;
-    case 4: EI_LAUNCH(4); break;
-    default: {  // deeper models: four tables per launch
-      for (int t0 = 0; t0 < ntab; t0 += 4) {
-        InterpArgs b{};
-        b.ntab = ntab - t0 < 4 ? ntab - t0 : 4;
-        for (int t = 0; t < b.ntab; ++t) {
-          b.tab[t] = tabs[t0 + t];
-          b.out[t] = outs[t0 + t];
-          b.dout[t] = douts[t0 + t];
-        }
-        a = b;
-        switch (b.ntab) {
-          case 1: EI_LAUNCH(1); break;
-          case 2: EI_LAUNCH(2); break;
-          case 3: EI_LAUNCH(3); break;
-          default: EI_LAUNCH(4); break;
-        }
-      }
+  for (int t0 = 0; t0 < ntab; t0 += 4) {  // four tables per launch (one launch for TensorNet's L + 1 <= 4)
+    a = InterpArgs{};
+    a.ntab = ntab - t0 < 4 ? ntab - t0 : 4;
+    for (int t = 0; t < a.ntab; ++t) {
+      a.tab[t] = tabs[t0 + t];
+      a.out[t] = outs[t0 + t];
+      a.dout[t] = douts ? douts[t0 + t] : nullptr;
+    }
+    switch (a.ntab) {
+      case 1: EI_LAUNCH(1); break;
+      case 2: EI_LAUNCH(2); break;
+      case 3: EI_LAUNCH(3); break;
+      default: EI_LAUNCH(4); break;
     }
   }
 #undef EI_LAUNCH

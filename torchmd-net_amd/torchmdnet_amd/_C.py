@@ -94,6 +94,9 @@ def lib():
     L.tmdnet_debug_split_weight.argtypes = [vp, i64, i64, vp]
     L.tmdnet_debug_split_weight.restype = i64
     L.tmdnet_debug_gemm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]
+    abi = int(re.search(r"#define\s+TMDNET_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read()).group(1))
+    if L.tmdnet_abi_version() != abi:
+        raise ImportError(f"{LIB_PATH} has ABI revision {L.tmdnet_abi_version()}, include/tmdnet_amd.h declares {abi}: rebuild")
     for name in declared_symbols():
         fn = getattr(L, name)
         if fn.restype is C.c_int:

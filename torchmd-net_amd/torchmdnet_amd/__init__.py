@@ -8,7 +8,7 @@ reference (tests/test_model.py, TMDNETCalculator, OpenMM wrappers) imports it un
 """
 import sys
 
-__version__ = "0.1.0"
+__version__ = "0.3.0"
 
 
 def install_as_torchmdnet(reference_root=None):
@@ -23,7 +23,7 @@ def install_as_torchmdnet(reference_root=None):
     import importlib.util
     import os
 
-    names = ["", ".models", ".models.model", ".models.utils", ".models.tensornet", ".models.torchmd_et",
+    names = ["", ".models", ".models.model", ".models.utils", ".models.tensornet", ".models.tensornet2", ".models.torchmd_et",
              ".models.output_modules", ".priors", ".ops"]
     done = []
     for n in names:

@@ -398,13 +398,38 @@ class TorchMD_Net(nn.Module):
         self._engine.tensors = None
         return super()._apply(fn, recurse)
 
+    def _index_tensors(self):
+        """(owning dict, key, tensor) of every parameter / persistent buffer and (dict, key, child) of every submodule."""
+        slots, mods, sizes = [], [], []
+        for mod in self.modules():
+            for k, p in mod._parameters.items():
+                if p is not None:
+                    slots.append((mod._parameters, k, p))
+            for k, b in mod._buffers.items():
+                if b is not None and k not in mod._non_persistent_buffers_set:
+                    slots.append((mod._buffers, k, b))
+            for k, ch in mod._modules.items():
+                mods.append((mod._modules, k, ch))
+            sizes.extend(((mod._parameters, len(mod._parameters)), (mod._buffers, len(mod._buffers)), (mod._modules, len(mod._modules))))
+        return slots, mods, sizes
+
     def _fingerprint(self):
-        """Cheap change detector for the uploaded parameters: (version, address) of every tensor of the state dict.  The
-        tensor list itself is cached (rebuilding ``state_dict()`` costs more than a small MD step); ``_apply`` drops it."""
+        """Cheap change detector for the uploaded parameters: (version, address) of every tensor of the state dict.  Walking
+        the module tree costs more than a small MD step, so the (dict, key, tensor) slots are cached and only re-checked for
+        IDENTITY: a replaced Parameter / buffer object (``load_state_dict(assign=True)``, ``mod.weight = nn.Parameter(..)``,
+        a swapped submodule, a parametrization) no longer matches its slot and the index is rebuilt."""
         st = self._engine
-        if st.tensors is None:
-            st.tensors = list(self.state_dict(keep_vars=True).values())
-        fp = [(v._version, v.data_ptr()) for v in st.tensors]
+        idx = st.tensors
+        if idx is not None:
+            slots, mods, sizes = idx
+            if not (all(d.get(k) is t for d, k, t in slots) and all(d.get(k) is c for d, k, c in mods)
+                    and all(len(d) == n for d, n in sizes)):
+                idx = None
+                st.index_epoch = getattr(st, "index_epoch", 0) + 1
+        if idx is None:
+            idx = st.tensors = self._index_tensors()
+        fp = [getattr(st, "index_epoch", 0)]
+        fp.extend((t._version, t.data_ptr()) for _, _, t in idx[0])
         if self.prior_model is not None:
             fp.append(tuple(p.enable for p in self.prior_model))
         return tuple(fp)

@@ -94,10 +94,14 @@ def neighbor_pairs(pos: Tensor, batch: Tensor, box: Optional[Tensor], cutoff_low
     with torch.cuda.device(dev):
         nbytes = C.c_size_t(0)
         L.tmdnet_neighbor_workspace_bytes(n, n_mol, max_num_pairs, C.byref(nbytes))
-        ws = _ws_cache.get(dev)
+        # scratch for the CSR build: one buffer per (device, stream) - two calls in flight on different streams must not share
+        # it, and a buffer that is outgrown stays referenced by the launches already queued on ITS stream only (the caching
+        # allocator frees stream-ordered on the allocating stream, which is the stream of those launches)
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _ws_cache.get(key)
         if ws is None or ws.numel() < nbytes.value:
             ws = torch.empty(int(nbytes.value * 1.1) + 256, dtype=torch.uint8, device=dev)
-            _ws_cache[dev] = ws
+            _ws_cache[key] = ws
         neighbors = torch.empty((2, max_num_pairs), dtype=torch.long, device=dev)
         deltas = torch.empty((max_num_pairs, 3), dtype=torch.float32, device=dev)
         dist = torch.empty((max_num_pairs,), dtype=torch.float32, device=dev)
