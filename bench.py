@@ -116,10 +116,38 @@ def roofline_of(rec, cls, label, pmc=None, note_kernel=None):
         roof = {"bound": "hbm", "kernel": f"{kernel} [{label}]", "achieved": ach, "peak": PEAK["hbm_gbs"], "unit": "GB/s",
                 "frac": ach / PEAK["hbm_gbs"], "algorithmic_bytes_per_launch": rec["bytes"] / launches}
     roof.update({"traffic": None, "launches": rec["launches"], "avg_launch_us": avg_s * 1e6})
+    if isinstance(pmc, tuple):  # (bytes, kernel name in the PMC summary, summary): stamped with its provenance
+        pmc, pmc_kernel, pmc_file = pmc
+        if pmc is not None:
+            roof["traffic_source"] = traffic_source(pmc_file, pmc_kernel)
     if pmc is not None:
         roof["traffic"] = pmc
         roof["traffic_ratio"] = pmc / max(rec["bytes"] / launches, 1.0)  # HBM bytes moved / algorithmic bytes
     return roof
+
+
+def roofline_mfma_of(rec, label, pmc=None):
+    """north_star "MFMA utilisation on the linears": the dominant per-atom GEMM (one kernel, one shape).  Its arithmetic is the
+    exact 3-way bf16 split: every fp32 product = 6 bf16 MFMA products, so `executed` counts 6 x the algorithmic FLOPs against the
+    dense bf16 peak, `achieved` the algorithmic fp32 FLOPs against peak / 6; with K = 128 the launch streams its operands once,
+    so the HBM fraction on its algorithmic bytes is reported next to it (the binding roofline of this kernel)."""
+    launches = max(rec["launches"], 1)
+    avg_s = rec["ms"] * 1e-3 / launches
+    split = not os.environ.get("TMDNET_NO_SPLIT_BF16")
+    fl, by = rec["flops"] / launches, rec["bytes"] / launches
+    peak = PEAK["mfma_bf16_tflops"] / SPLIT_PRODUCTS if split else PEAK["mfma_f32_tflops"]
+    out = {"bound": "mfma", "kernel": f"k_gemm_sb1 [{label}]" + (" (v_mfma_f32_32x32x16_bf16 x6 per fp32 product)" if split else ""),
+           "achieved": fl / avg_s / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / peak,
+           "executed_bf16_tflops": (SPLIT_PRODUCTS if split else 1) * fl / avg_s / 1e12,
+           "executed_frac_of_bf16_peak": (SPLIT_PRODUCTS * fl / avg_s / 1e12 / PEAK["mfma_bf16_tflops"]) if split else None,
+           "hbm": {"achieved": by / avg_s / 1e9, "peak": PEAK["hbm_gbs"], "unit": "GB/s", "frac": by / avg_s / 1e9 / PEAK["hbm_gbs"],
+                   "algorithmic_bytes_per_launch": by},
+           "binding": "hbm" if by / avg_s / 1e9 / PEAK["hbm_gbs"] > fl / avg_s / 1e12 / peak else "mfma",
+           "launches": rec["launches"], "avg_launch_us": avg_s * 1e6, "traffic": None}
+    if pmc is not None and pmc[0] is not None:
+        out["traffic"], out["traffic_ratio"] = pmc[0], pmc[0] / max(by, 1.0)
+        out["traffic_source"] = traffic_source(pmc[2], pmc[1])
+    return out
 
 
 def dominant(groups, cls=None):
@@ -141,8 +169,16 @@ def pmc_kernel_bytes(pmc, cls, label):
              "launch_embed_scatter": ["k_embed_scatter"], "launch_embed_pair_gd": ["k_embed_pair_gd_v4"]}.get(head, [])
     for n in names:
         if n in per:
-            return per[n]
-    return None
+            return per[n], n
+    return None, None
+
+
+def traffic_source(pmc, kernel_name):
+    """Provenance of a `traffic` figure: it is read from a committed PMC summary (two separate `rocprofv3 --pmc` passes, which
+    cannot run inside the timed region), so the line says which file, which commit's library and which kernel it belongs to."""
+    meta = pmc.get("_meta", {})
+    return {"file": "profiles/pmc_traffic.json", "git_commit": meta.get("git_commit"), "recipe": meta.get("recipe", "tools/profile_round.sh"),
+            "kernel_name": kernel_name, "measured_in_this_run": False}
 
 
 def load_pmc():
@@ -318,7 +354,14 @@ def cpu_baseline(args_dict, state_dict, budget_s=25.0):
         if time.perf_counter() - t_start > budget_s:
             break
     torch.set_num_threads(all_threads)
-    return {"value": done / total, "unit": "molecules/s", "cores": host_cores, "threads": best_t, "kind": "port",
+    ref_note = {}
+    try:  # the UNMODIFIED reference and this port timed on the same host (the build container; the reference cannot travel)
+        r = json.load(open(os.path.join(ROOT, "profiles", "r02_reference_cpu.json")))
+        ref_note = {"reference_same_host_ratio": r["reference_molecules_per_s"] / r["port_molecules_per_s"],
+                    "reference_same_host": {k: r[k] for k in ("reference_molecules_per_s", "port_molecules_per_s", "cpu", "threads", "cores") if k in r}}
+    except Exception:  # noqa: BLE001
+        pass
+    return {**ref_note, "value": done / total, "unit": "molecules/s", "cores": host_cores, "threads": best_t, "kind": "port",
             "sample": f"{done} of the {N_MOL} S-mol64 molecules in chunks of {chunk}, oracle/tensornet_torch.py (reference "
                       f"PyTorch CPU algorithm, autograd forces), 2 warm-ups + best of 5 per chunk, {time.perf_counter() - t_start:.1f} s; "
                       "the unmodified reference on the build container: BASELINE.md section 4"}
@@ -350,6 +393,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--rank-step", choices=["auto", "eager", "graph"], default="auto",
+                    help="auto: eager two-phase call on one GPU (per-kernel events in the timed region), HIP-graph replay + RCCL "
+                         "all-reduce per rank for N > 1; graph: force the N > 1 path (testable on one GPU under torch.distributed.run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-md", action="store_true", help="skip the HIP-graph latency leg (rocprofv3 --pmc cannot trace graph replays)")
     ap.add_argument("--no-aux", action="store_true", help="skip the configs[3] / configs[4] legs (profiling runs)")
@@ -371,13 +417,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_graph_step = a.rank_step == "graph" or (a.rank_step == "auto" and world > 1)
+    use_dist = world > 1 or (use_graph_step and "MASTER_PORT" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build_hip(verbose=False)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from torchmdnet_amd import _C, workloads as W
     from torchmdnet_amd.models.model import create_model
@@ -391,28 +439,44 @@ def main():
 
     # weak scaling: rank r owns molecules [r*256, (r+1)*256) of the synthetic stream
     zw, pw, bw = (t.to(dev) for t in W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS, first_seed=rank * N_MOL))
-    e_all = torch.zeros(world * N_MOL, dtype=torch.float32, device=dev)
-
-    def step_weak():
-        e, f = model.energy_and_forces(zw, pw, bw, None, None, N_MOL, want_forces=True)
-        if world > 1:
-            e_all.zero_()
-            e_all[rank * N_MOL:(rank + 1) * N_MOL] = e
-            dist.all_reduce(e_all)  # RCCL over xGMI: the path's only exchange
-        return e, f
-
     # strong scaling (BASELINE configs[2]): the same 256 molecules on every rank, each evaluates its molecule range
     zs, ps, bs = (t.to(dev) for t in W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS, first_seed=0))
-    sharded = ShardedEvaluator(lambda zl, pl, bl, boxl, ql, nm: model.energy_and_forces(zl, pl, bl, boxl, ql, nm, want_forces=True))
 
-    ranges = sharded.plan(bs, N_MOL)  # depends on the batch vector only: computed once, outside the timed region
+    if not use_graph_step:
+        # one GPU: the eager two-phase call (graph build with its 3-integer read-back, then the enqueue-only E+F call), every
+        # launch bracketed by the library's HIP events -> the per-kernel rooflines come from the timed region itself
+        def step_weak():
+            return model.energy_and_forces(zw, pw, bw, None, None, N_MOL, want_forces=True)
 
-    def step_strong():
-        e, f, _ = sharded.evaluate(zs, ps, bs, n_mol=N_MOL, ranges=ranges)
-        return e, f
+        step_strong = step_weak  # one rank: the shard is the whole batch
+        ranges = [(0, N_MOL, 0, N_MOL * N_ATOMS)]
+        rank_step = "eager: tmdnet_build_graph (pair-count read-back) + tmdnet_energy_forces"
+    else:
+        # N > 1: a rank's step is ONE replayed HIP graph (static shapes: neighbour list, forward, reverse pass, zero-padding of
+        # the energy vector) + ONE RCCL all-reduce; the shard is cut once outside the timed region (parallel.ShardSession).
+        # S-mol64 molecules have 64 atoms, so 64 neighbour slots per atom can never overflow.
+        sta = create_model(dict(args_dict, static_shapes=True, max_num_neighbors=N_ATOMS)).to(dev)
+        sta.load_state_dict(model.state_dict())
+        sharded = ShardedEvaluator(lambda zl, pl, bl, boxl, ql, nm: sta.energy_and_forces(zl, pl, bl, boxl, ql, nm, want_forces=True))
+        guard = lambda: (id(sta._engine), sta._engine.generation)  # noqa: E731
+        ranges = sharded.plan(bs, N_MOL)  # depends on the batch vector only: computed once, outside the timed region
+        ses_strong = sharded.prepare(zs, ps, bs, n_mol=N_MOL, ranges=ranges, graph=True, guard=guard)
+        ses_weak = sharded.prepare_local(zw, pw, bw, n_mol=world * N_MOL, mol_lo=rank * N_MOL, atom_lo=rank * N_MOL * N_ATOMS,
+                                         graph=True, guard=guard)
+        sta.check_overflow(int(ses_weak.z_l.shape[0]), N_MOL)  # the replays are unchecked: poll the device-side flag once
+
+        def step_weak():
+            e, f, _ = ses_weak.step()
+            return e, f
+
+        def step_strong():
+            e, f, _ = ses_strong.step()
+            return e, f
+
+        rank_step = "HIP-graph replay of the static-shape step (parallel.ShardSession) + one RCCL all-reduce of the energies"
 
     def timed(step, steps, mask):
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
         profile_begin(model, L, mask)
@@ -420,30 +484,40 @@ def main():
         for _ in range(steps):
             out = step()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         el = time.perf_counter() - t0
         _, groups = profile_records(model, L, stream_ptr)
-        if world > 1:
+        if use_dist:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, groups, out
 
     step = step_weak if a.scaling == "weak" else step_strong
+
+    def eager_profile_step():  # per-launch HIP events need eager launches (a replayed graph has no per-kernel events)
+        if not use_graph_step:
+            return step()
+        if a.scaling == "weak":
+            return model.energy_and_forces(zw, pw, bw, None, None, N_MOL, want_forces=True)
+        m_lo, m_hi, a_lo, a_hi = ranges[rank]
+        return model.energy_and_forces(zs[a_lo:a_hi], ps[a_lo:a_hi], bs[a_lo:a_hi] - m_lo, None, None, m_hi - m_lo, want_forces=True)
+
     for _ in range(max(a.warmup - 1, 0)):
         step()
     # one fully profiled warm-up step picks the dominant kernel class / kernel and records the breakdown
-    step()
+    eager_profile_step()
     torch.cuda.synchronize(dev)
     profile_begin(model, L)
-    step()
+    eager_profile_step()
     classes, groups = profile_records(model, L, stream_ptr)
     dom_cls = max(classes, key=lambda k: classes[k]["ms"])
     names = list(classes)
     (_, dom_label), _ = dominant(groups, dom_cls)
+    (_, gemm_label), _ = dominant(groups, "gemm_node")
 
-    el, tgroups, (e, f) = timed(step, a.steps, 1 << names.index(dom_cls))
+    el, tgroups, (e, f) = timed(step, a.steps, (1 << names.index(dom_cls)) | (1 << names.index("gemm_node")))
     assert torch.isfinite(e).all() and torch.isfinite(f).all()
     mols_per_step = world * N_MOL if a.scaling == "weak" else N_MOL
 
@@ -460,19 +534,26 @@ def main():
     if rank == 0:
         n_pairs, n_edges, _ = model._engine.counts
         pmc = load_pmc()
-        kern_rec = tgroups[(dom_cls, dom_label)]
+        # N = 1: records of the timed region.  N > 1: the timed region replays HIP graphs (no per-kernel events), so the
+        # records of the eager profiled step of this rank's shard stand in and the line says so.
+        live = (dom_cls, dom_label) in tgroups
+        rgroups, rsteps = (tgroups, a.steps) if live else (groups, 1)
+        kern_rec = rgroups[(dom_cls, dom_label)]
         cls_rec = dict(ms=0.0, flops=0.0, bytes=0.0, launches=0)
-        for (c, _), v in tgroups.items():
+        for (c, _), v in rgroups.items():
             if c == dom_cls:
                 for k in cls_rec:
                     cls_rec[k] += v[k]
-        roof = roofline_of(kern_rec, dom_cls, dom_label, pmc=pmc_kernel_bytes(pmc, dom_cls, dom_label))
-        roof["launches_per_step"] = kern_rec["launches"] // max(a.steps, 1)
-        roof["share_of_step"] = kern_rec["ms"] / (el * 1e3)
+        roof = roofline_of(kern_rec, dom_cls, dom_label, pmc=pmc_kernel_bytes(pmc, dom_cls, dom_label) + (pmc,))
+        roof["measured"] = ("HIP events around every launch of this kernel inside the timed region" if live else
+                            "HIP events of one eager profiled step of this rank's shard (the timed region replays HIP graphs)")
+        roof["launches_per_step"] = kern_rec["launches"] // max(rsteps, 1)
+        roof["share_of_step"] = kern_rec["ms"] / rsteps / (el / a.steps * 1e3)
         cavg = roofline_of(cls_rec, dom_cls, "class average", pmc=pmc.get(dom_cls))
         roof["class"] = {"name": dom_cls, "achieved": cavg["achieved"], "frac": cavg["frac"], "launches_per_step":
-                         cls_rec["launches"] // max(a.steps, 1), "share_of_step": cls_rec["ms"] / (el * 1e3),
+                         cls_rec["launches"] // max(rsteps, 1), "share_of_step": cls_rec["ms"] / rsteps / (el / a.steps * 1e3),
                          "traffic": cavg.get("traffic"), "traffic_ratio": cavg.get("traffic_ratio")}
+        gemm_rec = rgroups.get(("gemm_node", gemm_label))
         out = {
             "metric": "molecules/sec (64-atom molecules) TensorNet E+F",
             "value": mols_per_step * a.steps / el,
@@ -495,6 +576,14 @@ def main():
                        "parallelism": f"molecule-sharded x{world}, RCCL all-reduce of energies"},
             "roofline": roof,
         }
+        out["config"]["rank_step"] = rank_step
+        if gemm_rec:
+            out["roofline_mfma"] = roofline_mfma_of(gemm_rec, gemm_label, pmc=(pmc.get("_per_kernel_total", {}).get("k_gemm_sb1<0>"), "k_gemm_sb1<0>", pmc)
+                                                    if gemm_label.startswith("tensor_linear") else None)
+        if use_dist:
+            out["ranks_seen_by_rccl"] = dist.get_world_size()
+            out["rccl"] = {"backend": dist.get_backend(), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                           "collective_per_step": f"all_reduce(sum) of a zero-padded fp32[{mols_per_step}] energy vector"}
         if other:
             out["other_scaling_mode"] = other
         # north_star: "achieved HBM GB/s on the scatter": the CSR message sweeps, per kernel, from the fully profiled step
@@ -507,7 +596,7 @@ def main():
             rs["launches_per_step"] = tot["launches"]
             rs["kernels"] = {}
             for lab, v in msg.items():
-                r1 = roofline_of(v, "message", lab, pmc=pmc_kernel_bytes(pmc, "message", lab))
+                r1 = roofline_of(v, "message", lab, pmc=pmc_kernel_bytes(pmc, "message", lab)[0])
                 rs["kernels"][lab.split("(")[0]] = {k: r1[k] for k in ("achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch",
                                                                         "traffic", "traffic_ratio") if k in r1}
             out["roofline_scatter"] = rs
@@ -533,7 +622,7 @@ def main():
                 json.dump({"one_step_profiled_ms": classes, "kernels": {f"{c}: {lab}": v for (c, lab), v in groups.items()},
                            "step_ms": el / a.steps * 1e3, "aux_legs": AUX_GROUPS}, fh, indent=1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

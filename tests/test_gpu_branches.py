@@ -405,6 +405,28 @@ def test_sharded_evaluator_hip_model_nccl_world1(hip_lib):
             assert torch.equal(t, torch.ones(4, device="cuda"))
             assert (a0, a1) == (0, z.shape[0])
             assert torch.equal(E.view(-1, 1), Er) and torch.equal(F, Fr)
+        # stepping form: shard cut once, local evaluation captured into one HIP graph (static shapes), all-reduce per step
+        sta = create_model(dict(W.TINY_ARGS, static_shapes=True))
+        sta.load_state_dict(model.state_dict())
+        sta = sta.to("cuda")
+
+        def compute_static(zl, pl, bl, boxl, ql, nm):
+            return sta.energy_and_forces(zl, pl, bl, boxl, ql, nm, want_forces=True)
+
+        ev = ShardedEvaluator(compute_static)
+        ses = ev.prepare(z.cuda(), pos.cuda(), batch.cuda(), q=q.cuda(), graph=True,
+                         guard=lambda: (id(sta._engine), sta._engine.generation))
+        assert ses.graph is not None
+        for k in range(3):
+            newpos = (pos + 0.02 * k * torch.randn(pos.shape, generator=torch.Generator().manual_seed(k))).cuda()
+            Es, Fs, (a0, a1) = ses.step(newpos)
+            Ek, Fk = model(z.cuda(), newpos.clone(), batch.cuda(), q=q.cuda())
+            assert rel_err(Es.view(-1, 1), Ek) < 1e-5 and rel_err(Fs, Fk) < 1e-5, k
+        with torch.no_grad():
+            sta.mean.add_(1.0)
+        sta(z.cuda(), pos.cuda(), batch.cuda(), q=q.cuda())  # re-uploads the parameters: the captured pointers are stale now
+        with pytest.raises(RuntimeError, match="stale HIP graph"):
+            ses.step()
     finally:
         dist.destroy_process_group()
 

@@ -59,6 +59,25 @@ def _worker(rank, world, port, tmpdir):
     ev2 = ShardedEvaluator(compute, gather_forces=False)
     E2, Fl, (a0, a1) = ev2.evaluate(z, pos, batch, q=q)
     ok = ok and torch.allclose(E2.view(-1, 1), Er, atol=1e-6) and torch.allclose(Fl, Fr[a0:a1], atol=1e-6)
+    # stepping form: shard cut once, static buffers, new positions per step (no graph on CPU)
+    ses = ev2.prepare(z, pos, batch, q=q)
+    for k in range(3):
+        newpos = pos + 0.01 * k
+        Es, Fs, (s0, s1) = ses.step(newpos)
+        Ek, Fk = CO.energy_forces(sd, hp, z, newpos, batch, q=q)
+        ok = ok and torch.allclose(Es.view(-1, 1), Ek, atol=1e-6) and torch.allclose(Fs, Fk[s0:s1], atol=1e-6) and (s0, s1) == (a0, a1)
+    # weak form: every rank holds only its own molecules; energies land in the rank's slots of the global vector
+    own = [m for m in range(len(sizes)) if m % world == rank]
+    zl = torch.cat([zs[m] for m in own]); pl = torch.cat([ps[m] for m in own])
+    bl = torch.cat([torch.full((sizes[m],), i, dtype=torch.long) for i, m in enumerate(own)])
+    n_glob, lo = 3 * world, 3 * rank  # 3 slots per rank (rank 1 fills only 2 of them)
+    sw = ShardedEvaluator(lambda zz, pp, bb, boxl, ql, nm: CO.energy_forces(sd, hp, zz, pp, bb)).prepare_local(zl, pl, bl, n_glob, lo)
+    Ew, Fw, _ = sw.step()
+    Eall, _ = CO.energy_forces(sd, hp, z, pos, batch)
+    for r in range(world):
+        for i, m in enumerate([m for m in range(len(sizes)) if m % world == r]):
+            ok = ok and abs(float(Ew[3 * r + i]) - float(Eall[m])) < 1e-5
+    ok = ok and (world < 2 or float(Ew[5]) == 0.0) and Fw.shape[0] == zl.shape[0]
     with open(os.path.join(tmpdir, f"ok{rank}"), "w") as fh:
         fh.write("1" if ok else "0")
     dist.destroy_process_group()

@@ -72,6 +72,8 @@ def main():
     res = {cls: tot / max(n, 1) for cls, (tot, n) in classes.items()}  # mean HBM bytes per launch of the class
     res["_per_kernel"] = kernels
     res["_per_kernel_total"] = {k: v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for k, v in kernels.items()}
+    res["_meta"] = {"git_commit": os.environ.get("GIT_COMMIT"), "recipe": "tools/profile_round.sh (two rocprofv3 --pmc passes: FETCH_SIZE, WRITE_SIZE)",
+                    "bench_command": "python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-md --no-aux"}
     res["_note"] = "bytes per launch; reads = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), writes = WRITE_SIZE KiB x 1024"
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Round profile recipe (run on the GPU box through gpurun): bench line, rocprofv3 kernel stats, PMC HBM traffic.
+# The snapshot has no .git: pass the commit the library was built from, e.g.  gpurun -- "GIT_COMMIT=$(git rev-parse --short HEAD) tools/profile_round.sh"
+export GIT_COMMIT=${GIT_COMMIT:-unknown}
 R=${GRAFT_REPO_ROOT:-$PWD}
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out

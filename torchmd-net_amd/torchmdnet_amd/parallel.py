@@ -80,3 +80,88 @@ class ShardedEvaluator:
             f_all = torch.cat([blocks[r][: ranges[r][3] - ranges[r][2]] for r in range(world)])
             return energy, f_all, (0, pos.shape[0])
         return energy, f_loc, (a_lo, a_hi)
+
+    def prepare(self, z, pos, batch, q=None, box=None, n_mol=None, ranges=None, graph=False, guard=None, warmup=3):
+        """Stepping form of ``evaluate`` for MD loops and benchmarks: the rank's shard is cut out ONCE, the outputs are static
+        buffers, and with ``graph=True`` the local evaluation (+ the zero-padding of the energy vector) is captured into one
+        HIP graph, so a step is `graph.replay()` + one RCCL all-reduce - no slicing, no allocation, no host synchronisation
+        (the capture pattern of the reference's TorchMD adapter, calculators.py:117-128).  ``compute`` must then be
+        capture-safe (a model created with static_shapes=True).  Returns a :class:`ShardSession`."""
+        if n_mol is None:
+            n_mol = int(batch.max().item()) + 1
+        if ranges is None:
+            ranges = self.plan(batch, n_mol)
+        return ShardSession(self, z, pos, batch, q, box, n_mol, ranges, graph, guard, warmup)
+
+    def prepare_local(self, z_l, pos_l, batch_l, n_mol, mol_lo, atom_lo=0, q_l=None, box_l=None, graph=False, guard=None, warmup=3):
+        """``prepare`` for a rank that holds ONLY its own molecules (weak scaling, data-parallel inference over a stream of
+        molecules): ``batch_l`` counts from 0, the rank's energies land in slots [mol_lo, mol_lo + n_local) of the global
+        zero-padded vector of ``n_mol`` entries."""
+        n_loc = int(batch_l.max().item()) + 1 if batch_l.numel() else 0
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        ranges = [None] * world
+        ranges[rank] = (mol_lo, mol_lo + n_loc, atom_lo, atom_lo + int(z_l.shape[0]))
+        return ShardSession(self, z_l, pos_l, batch_l + mol_lo, q_l, box_l, n_mol, ranges, graph, guard, warmup, local=True)
+
+
+class ShardSession:
+    """One rank's prepared shard (see ShardedEvaluator.prepare).  ``step(new_pos=None)`` returns
+    ``(energy [n_mol] summed over the ranks, forces of the local atoms, (atom_lo, atom_hi))``; the tensors are static buffers
+    that the next step overwrites."""
+
+    def __init__(self, ev, z, pos, batch, q, box, n_mol, ranges, graph, guard, warmup, local=False):
+        self.ev, self.n_mol, self.ranges = ev, n_mol, ranges
+        self.world = dist.get_world_size(ev.group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(ev.group) if dist.is_initialized() else 0
+        m_lo, m_hi, a_lo, a_hi = ranges[self.rank]
+        self.m_lo, self.m_hi, self.a_lo, self.a_hi = m_lo, m_hi, a_lo, a_hi
+        dev = pos.device
+        self.energy = torch.zeros(n_mol, dtype=torch.float32, device=dev)
+        sl_a = slice(None) if local else slice(a_lo, a_hi)  # local: the inputs already are this rank's rows
+        sl_m = slice(None) if local else slice(m_lo, m_hi)
+        self.local = local
+        self.z_l = z[sl_a].contiguous()
+        self.pos_l = pos[sl_a].detach().clone().contiguous()
+        self.batch_l = (batch[sl_a] - m_lo).contiguous()
+        self.q_l = None if q is None else q[sl_m].contiguous()
+        self.box_l = box if (box is None or box.dim() == 2) else box[sl_m].contiguous()
+        self.f_loc = torch.zeros((a_hi - a_lo, 3), dtype=torch.float32, device=dev)
+        self.graph, self.guard, self._token = None, guard, None
+        if graph and m_hi > m_lo:
+            if not pos.is_cuda:
+                raise RuntimeError("graph=True needs device tensors")
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(max(warmup, 1)):
+                    self._local()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._local()
+            self._token = guard() if guard else None
+
+    def _local(self):
+        self.energy.zero_()
+        if self.m_hi > self.m_lo:
+            e_loc, f_loc = self.ev.compute(self.z_l, self.pos_l, self.batch_l, self.box_l, self.q_l, self.m_hi - self.m_lo)
+            self.energy[self.m_lo:self.m_hi] = e_loc.reshape(-1)
+            self.f_loc = f_loc
+
+    def step(self, new_pos=None):
+        if new_pos is not None:  # full-system positions: the rank keeps its own rows
+            src = (new_pos if self.local else new_pos[self.a_lo:self.a_hi]).detach()
+            if self.pos_l.is_cuda:
+                torch.mul(src, 1.0, out=self.pos_l)  # an elementwise kernel, not the runtime's blit path (see TorchMD_Net.capture)
+            else:
+                self.pos_l.copy_(src)
+        if self.graph is not None:
+            if self.guard and self.guard() != self._token:
+                raise RuntimeError("stale HIP graph: the model's parameters or workspaces changed after prepare(); prepare again")
+            self.graph.replay()
+        else:
+            self._local()
+        if dist.is_initialized():  # also at world size 1: the collective path is the same code on every node size
+            dist.all_reduce(self.energy, op=dist.ReduceOp.SUM, group=self.ev.group)
+        return self.energy, self.f_loc, (self.a_lo, self.a_hi)
