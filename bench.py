@@ -239,7 +239,7 @@ def timed_leg(model, L, dev, step, steps, warmup, name=None):
     return (time.perf_counter() - t0) / steps, classes, groups, out
 
 
-def et_c4_leg(dev, L, steps=8, warmup=3):
+def et_c4_leg(dev, L, steps=8, warmup=3, pair_storage="fp32"):
     """BASELINE configs[3]: ET-SPICE.yaml Equivariant Transformer (F=128, 5 layers, 8 heads, K=64, rc=10 A, neighbour
     embedding, distance influence on keys and values, vector cutoff), 256 x 64-atom molecules, E+F.  The config says bf16:
     the GEMMs run on the bf16 matrix pipe through the exact 3-way split, i.e. at fp32 accuracy."""
@@ -248,15 +248,17 @@ def et_c4_leg(dev, L, steps=8, warmup=3):
     from torchmdnet_amd.models.model import create_model
 
     torch.manual_seed(0)
-    model = create_model(dict(W.C4_ARGS)).to(dev)
+    model = create_model(dict(W.C4_ARGS, pair_storage=pair_storage)).to(dev)
     z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS)
     z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
     dt, classes, groups, (e, f) = timed_leg(model, L, dev, lambda: model.energy_and_forces(z, pos, batch, None, None, N_MOL), steps, warmup,
-                                             name="et_c4")
+                                             name="et_c4" if pair_storage == "fp32" else "et_c4_bf16")
     assert torch.isfinite(e).all() and torch.isfinite(f).all()
     (cls, label), rec = dominant(groups)
     return {"workload": "BASELINE configs[3]: ET-SPICE.yaml hyper-parameters, S-mol64 256 x 64 atoms, E+F, random-init (seed 0)",
-            "ms_per_step": dt * 1e3, "molecules_per_s": N_MOL / dt, "dtype": "f32 (bf16 MFMA, exact 3-way split)",
+            "ms_per_step": dt * 1e3, "molecules_per_s": N_MOL / dt,
+            "dtype": "f32 (bf16 MFMA, exact 3-way split)" if pair_storage == "fp32" else
+                     "f32 arithmetic, per-pair filter rows stored as bf16 (pair_storage='bf16': <= 2e-3 rel. vs the fp32 oracle, tests/test_gpu_et.py)",
             "pairs": model._engine.counts[0], "roofline": roofline_of(rec, cls, label, note_kernel=ET_KERNEL_OF.get(cls)),
             "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
 
@@ -606,7 +608,8 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 out["md_single_system"] = {"error": repr(exc)}
         if world == 1 and not a.no_aux:
-            for key, leg in (("et_c4", et_c4_leg), ("water10k", water10k_leg), ("tensornet2", tn2_leg)):
+            for key, leg in (("et_c4", et_c4_leg), ("et_c4_bf16", lambda d, l: et_c4_leg(d, l, pair_storage="bf16")),
+                             ("water10k", water10k_leg), ("tensornet2", tn2_leg)):
                 try:
                     out[key] = leg(dev, L)
                 except Exception as exc:  # noqa: BLE001

@@ -121,7 +121,9 @@ const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel);
  * intervals until they hold, else the tables stay off) and tmdnet_energy_forces then interpolates per pair instead of running the pair-row
  * GEMMs, when the system has at least `edge_table_min_pairs` pairs (default 1024: single systems from about 100 atoms on).  TMDNET_EDGE_TABLE=0 in the
  * environment disables the tables (direct GEMMs every step).
- * Options: "edge_table_min_pairs".  Info: "edge_table_T" (0 = off), "edge_table_err_value", "edge_table_err_slope"
+ * Options: "edge_table_min_pairs"; "pair_rows_bf16" (Equivariant Transformer handle only; 1: the per-pair distance-filter
+ * rows silu(dk_proj phi) | silu(dv_proj phi) and their d/dd - reference torchmd_et.py:375-415 - are written by the table
+ * interpolation as bf16 and widened when the attention sweeps load them; products and sums stay fp32; default 0).  Info: "edge_table_T" (0 = off), "edge_table_err_value", "edge_table_err_slope"
  * (measured at the midpoints), "edge_table_min_pairs". */
 int tmdnet_set_option(tmdnet_model* m, const char* name, double value);
 int tmdnet_get_info(const tmdnet_model* m, const char* name, double* value);

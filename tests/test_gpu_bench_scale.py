@@ -114,3 +114,34 @@ def test_et_c4_bench_scale_vs_oracle(hip_lib):
         Eo, Fo = ET.energy_and_forces(sd, hp, z[sel], pos[sel], torch.zeros(int(sel.sum()), dtype=torch.long))
         assert rel_err(E[m].cpu().reshape(1, 1), Eo) < REL
         assert rel_err(F[sel.cuda()].cpu(), Fo) < REL
+
+
+def test_nonperiodic_30k_atoms_through_the_cell_list(hip_lib):
+    """One large NON-periodic system (a 32 k-atom water droplet cut from the lattice): the model takes the O(N) cell list with a
+    fictitious box around the bounding box (reference models/utils.py:206-212: the cell strategy without a box), atoms
+    renumbered in cell order by the hand-written counting sort (tn_cell.hip).  Same pair set and the same energies / forces as
+    the brute-force sweep; forces of every atom against the scalar-C oracle."""
+    from oracle import tensornet_c as CO, tensornet_torch as T
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(0)
+    args = dict(W.TINY_ARGS, max_num_neighbors=96)
+    model = create_model(dict(args)).to("cuda")
+    z, pos, _ = W.water_box(n_side=22, spacing=3.1)  # 31 944 atoms
+    z = z % 19 + 1
+    pos = pos + torch.tensor([-100.0, 37.0, 5.0])
+    batch = torch.zeros_like(z)
+    zc, pc, bc = z.cuda(), pos.cuda(), batch.cuda()
+    Ec, Fc = model(zc, pc, bc)
+    grid = model.cell_grid(z.shape[0])
+    assert grid[3] == 1 and min(grid[:3]) >= 3, grid  # the cell list ran (default threshold: 1024 atoms)
+    counts_cell = model._engine.counts[:2]
+    Ec2, Fc2 = model(zc, pc.clone(), bc)
+    assert torch.equal(Ec, Ec2) and torch.equal(Fc, Fc2)  # the placement atomics do not leak into the result
+    model.cell_list_min_atoms = 10 ** 9
+    Eb, Fb = model(zc, pc.clone(), bc)
+    assert model.cell_grid(z.shape[0])[3] == 0 and model._engine.counts[:2] == counts_cell
+    assert rel_err(Ec, Eb) < 1e-5 and rel_err(Fc, Fb) < 2e-5
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    Er, Fr = CO.energy_forces(sd, T.hparams_from_args(args), z, pos, batch)
+    assert rel_err(Ec.cpu(), Er) < REL and rel_err(Fc.cpu(), Fr) < REL

@@ -236,12 +236,14 @@ Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   return g;
 }
 
-// the cell list applies to ONE periodic system in one box (orthorhombic or reduced triclinic); everything else takes the
-// brute-force sweep.  cell_n < 0: the grid is computed on the device from the current box on every call (tn_cell.hip).
+// the cell list applies to ONE system: periodic in one box (orthorhombic or reduced triclinic), or non-periodic (box_mode 0:
+// a fictitious orthorhombic box around the bounding box of the positions, as the reference does with a fixed box,
+// models/utils.py:206-212); batches of molecules take the brute-force sweep inside each molecule.
+// cell_n < 0: the grid is computed on the device from the current box / bounding box on every call (tn_cell.hip).
 namespace {
 bool cell_applicable(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int box_mode) {
   const int* n = m->cell_n;
-  if (n_mol != 1 || box_mode != 1 || n_atoms < 1) return false;
+  if (n_mol != 1 || box_mode == 2 || n_atoms < 1) return false;
   if (n[0] < 0) return true;
   if (n[0] < 1 || n[1] < 1 || n[2] < 1) return false;
   return (int64_t)n[0] * n[1] * n[2] <= 8 * n_atoms;
@@ -866,6 +868,11 @@ int tmdnet_set_option(tmdnet_model* m, const char* name, double value) {
     m->tab_min_pairs = value < 0 ? 0 : (int64_t)value;
     return TMDNET_OK;
   }
+  if (n == "pair_rows_bf16") {
+    if (!m->et) return fail(m, TMDNET_ERR_INVALID, "pair_rows_bf16 applies to the Equivariant Transformer handle only");
+    m->pair_bf16 = value != 0.0 ? 1 : 0;
+    return TMDNET_OK;
+  }
   return fail(m, TMDNET_ERR_INVALID, "unknown option: " + n);
 }
 
@@ -876,6 +883,7 @@ int tmdnet_get_info(const tmdnet_model* m, const char* name, double* value) {
   else if (n == "edge_table_err_value") *value = m->tabs.err_value;
   else if (n == "edge_table_err_slope") *value = m->tabs.err_slope;
   else if (n == "edge_table_min_pairs") *value = (double)m->tab_min_pairs;
+  else if (n == "pair_rows_bf16") *value = (double)m->pair_bf16;
   else return TMDNET_ERR_INVALID;
   return TMDNET_OK;
 }
@@ -920,7 +928,7 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
     if (cell) {
       launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
-      launch_cell_phase1(g, pos, batch, box, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+      launch_cell_phase1(g, pos, batch, box_mode == 1 ? box : nullptr, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
       launch_scan_counts(g, (int)n_atoms, s);
     } else {
       launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
@@ -975,7 +983,7 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
     if (cell) {
       launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
-      launch_cell_phase1(g, pos, batch, box, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+      launch_cell_phase1(g, pos, batch, box_mode == 1 ? box : nullptr, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
       launch_scan_counts(g, (int)n_atoms, s);
       launch_cell_phase2(g, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
       launch_nbr_link_wave(g, (int)n_atoms, s);

@@ -4,7 +4,8 @@
 // warp_kernels/neighbors_cell.py:17-153 (27-cell sweep; the reference is orthorhombic-only, fractional cells extend it to triclinic).  Same pair set as the
 // brute-force search (the reference's tests assert that, tests/test_neighbors.py:74-148).
 //
-// MI355X design: atoms are RENUMBERED in cell order (stable radix sort of (cell id, atom index), rocPRIM) and the
+// MI355X design: atoms are RENUMBERED in cell order (counting sort by cell id, atoms of a cell in ascending original index:
+// histogram -> single-block scan -> placement -> per-cell rank sort, all in this file; no vendor primitive) and the
 // whole model then runs on the spatially sorted atoms - every neighbour of an atom lives in at most 27
 // contiguous index ranges, so (a) the wave-per-atom sweep reads candidate positions coalesced, (b) visiting the
 // ranges in ascending cell id yields rows already sorted by neighbour index (no per-row sort, no atomics,
@@ -13,7 +14,6 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "tn_common.h"
 #include "tn_kernels.h"
@@ -22,24 +22,14 @@ namespace tn {
 
 static inline int cdivc(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-size_t cell_sort_temp_bytes(int64_t n) {
-  // the size query walks rocPRIM's tuning tables (milliseconds on the host): ask once per problem size
-  static thread_local int64_t last_n = -1;
-  static thread_local size_t last_bytes = 0;
-  if (n == last_n) return last_bytes;
-  last_n = n;
-  size_t& bytes = last_bytes;
-  bytes = 0;
-  int* k = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)(n > 0 ? n : 1), 0, 32, (hipStream_t)0);
-  return bytes;
-}
+// scratch of the counting sort: the per-cell cursors (cells <= 8 N + 1 by construction of the grid, launch_cell_phase1)
+size_t cell_sort_temp_bytes(int64_t n) { return (size_t)(8 * (n > 0 ? n : 1) + 2) * sizeof(int); }
 
 // cell id of every atom from its wrapped FRACTIONAL position; iota for the sort values.  Box rows a = (ax,0,0),
 // b = (bx,by,0), c = (cx,cy,cz) (the reference's reduced form, torchmdnet/models/utils.py:206-229; orthorhombic when
 // the off-diagonals vanish): r = sa a + sb b + sc c is solved back to front.
 __global__ void k_cell_assign(const float* __restrict__ pos, const float* __restrict__ box, int N, const int* __restrict__ cgrid,
-                              int* __restrict__ key, int* __restrict__ iota) {
+                              int* __restrict__ key, int* __restrict__ hist) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int ncx = cgrid[0], ncy = cgrid[1], ncz = cgrid[2];
@@ -51,21 +41,81 @@ __global__ void k_cell_assign(const float* __restrict__ pos, const float* __rest
   fy -= floorf(fy);
   fz -= floorf(fz);
   int cx = min((int)(fx * ncx), ncx - 1), cy = min((int)(fy * ncy), ncy - 1), cz = min((int)(fz * ncz), ncz - 1);
-  key[i] = (cx * ncy + cy) * ncz + cz;
-  iota[i] = i;
+  const int c = (cx * ncy + cy) * ncz + cz;
+  key[i] = c;
+  atomicAdd(&hist[c], 1);  // integer counts: the result does not depend on the order of the adds
 }
 
-// cell_start[c] = first sorted position whose cell id >= c (lower bound); c in [0, ncells]
-__global__ void k_cell_bounds(const int* __restrict__ sorted_key, int N, const int* __restrict__ cgrid, int* __restrict__ cell_start) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+// (1) zero the histogram of the live cells (grid sized by the 8 N capacity; the cell count is a device value)
+__global__ void k_fill_cells(const int* __restrict__ cgrid, int* __restrict__ hist) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c <= cgrid[3]) hist[c] = 0;
+}
+// Counting sort, steps 2-4.  (2) exclusive scan of the cell histogram by ONE block (cells ~ N / 12 at liquid density, far
+// below the 8 N capacity): cell_start[c] = first sorted position of cell c, cell_start[ncells] = N; the cursors start there.
+__global__ __launch_bounds__(1024) void k_cell_scan(const int* __restrict__ cgrid, int* __restrict__ hist_cursor,
+                                                   int* __restrict__ cell_start, int N) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
   const int ncells = cgrid[3];
-  if (c > ncells) return;
-  int lo = 0, hi = N;
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (sorted_key[mid] < c) lo = mid + 1; else hi = mid;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < ncells; base += 1024) {
+    const int c = base + tid;
+    const int v = c < ncells ? hist_cursor[c] : 0;
+    int x = v;  // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int excl = carry_s + woff + x - v;
+    if (c < ncells) {
+      cell_start[c] = excl;
+      hist_cursor[c] = excl;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = excl + v;
+    __syncthreads();
   }
-  cell_start[c] = lo;
+  if (tid == 0) cell_start[ncells] = N;
+}
+// (3) placement through the cursors: the order inside a cell is whatever the atomics give ...
+__global__ void k_cell_place(const int* __restrict__ key, int N, int* __restrict__ cursor, int* __restrict__ slot_atom) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  slot_atom[atomicAdd(&cursor[key[i]], 1)] = i;
+}
+// (4) ... and a wave per cell restores ascending original index (rank of each member among the cell's members: cells hold
+// ~12 atoms, so the O(n^2 / 64) ranking is a handful of steps).  The permutation therefore equals a stable sort by cell id:
+// deterministic, independent of the atomics' order.
+__global__ __launch_bounds__(256) void k_cell_rank(const int* __restrict__ cgrid, const int* __restrict__ cell_start,
+                                                   const int* __restrict__ slot_atom, int* __restrict__ perm,
+                                                   int* __restrict__ key_sorted) {
+  const int ncells = cgrid[3];
+  const int lane = threadIdx.x & 63;
+  for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < ncells; c += gridDim.x * 4) {
+    const int s0 = cell_start[c], n = cell_start[c + 1] - s0;
+    for (int a0 = 0; a0 < n; a0 += 64) {
+      const int a = a0 + lane;
+      const int mine = a < n ? slot_atom[s0 + a] : 0x7fffffff;
+      int rank = 0;
+      for (int b0 = 0; b0 < n; b0 += 64) {
+        const int other = b0 + lane < n ? slot_atom[s0 + b0 + lane] : 0x7fffffff;
+        const int m = n - b0 < 64 ? n - b0 : 64;
+        for (int k = 0; k < m; ++k) rank += __shfl(other, k, 64) < mine ? 1 : 0;
+      }
+      if (a < n) {
+        perm[s0 + rank] = mine;
+        key_sorted[s0 + rank] = c;
+      }
+    }
+  }
 }
 
 __global__ void k_permute_pos(const float* __restrict__ pos, const int64_t* __restrict__ batch, const int* __restrict__ perm, int N,
@@ -299,13 +349,13 @@ void launch_cell_phase1(const Graph& g, const float* pos, const int64_t* batch, 
   while ((int64_t)(ncap + 1) * (ncap + 1) * (ncap + 1) <= 8 * (int64_t)N) ++ncap;  // cell_start holds 8 N + 2 entries
   hipLaunchKernelGGL(k_cell_setup, dim3(1), dim3(1024), 0, s, box, pos, N, up, ncap, g.ncx, g.ncy, g.ncz, g.boxd, g.cgrid, g.mstart,
                      g.mend, g.use_cell == 1 ? 1 : 0);
-  hipLaunchKernelGGL(k_cell_assign, dim3(cdivc(N, 256)), dim3(256), 0, s, pos, g.boxd, N, g.cgrid, g.cell_key, g.iota);
-  const int64_t cap = 8 * (int64_t)N + 1;
-  int bits = 1;
-  while (((int64_t)1 << bits) < cap && bits < 31) ++bits;
-  size_t tmp = g.sort_tmp_bytes;
-  (void)rocprim::radix_sort_pairs(g.sort_tmp, tmp, g.cell_key, g.cell_key_sorted, g.iota, g.perm, (size_t)N, 0, (unsigned)bits, s);
-  hipLaunchKernelGGL(k_cell_bounds, dim3(cdivc(cap + 1, 256)), dim3(256), 0, s, g.cell_key_sorted, N, g.cgrid, g.cell_start);
+  int* cursor = reinterpret_cast<int*>(g.sort_tmp);  // [8 N + 2]: histogram, then the placement cursors
+  hipLaunchKernelGGL(k_fill_cells, dim3(cdivc(8 * (int64_t)N + 2, 1024)), dim3(1024), 0, s, g.cgrid, cursor);
+  hipLaunchKernelGGL(k_cell_assign, dim3(cdivc(N, 256)), dim3(256), 0, s, pos, g.boxd, N, g.cgrid, g.cell_key, cursor);
+  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, s, g.cgrid, cursor, g.cell_start, N);
+  hipLaunchKernelGGL(k_cell_place, dim3(cdivc(N, 256)), dim3(256), 0, s, g.cell_key, N, cursor, g.iota);
+  hipLaunchKernelGGL(k_cell_rank, dim3(cdivc(N > 4096 ? N / 8 : 512, 4)), dim3(256), 0, s, g.cgrid, g.cell_start, g.iota, g.perm,
+                     g.cell_key_sorted);
   hipLaunchKernelGGL(k_permute_pos, dim3(cdivc(N, 256)), dim3(256), 0, s, pos, g.use_cell > 1 ? batch : nullptr, g.perm, N, g.pos_s,
                      g.bat_s);
   hipLaunchKernelGGL(k_nbr_cell<false>, dim3(cdivc(N, 4)), dim3(256), 0, s, g, N, lo * lo, up * up, (int)loop);

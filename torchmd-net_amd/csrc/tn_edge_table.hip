@@ -214,7 +214,22 @@ struct InterpArgs {
   float* out[8];        // [P + 1][R]
   float* dout[8];       // [P + 1][R] or null
   int ntab;
+  int out_bf16;         // 1: out / dout are [P + 1][R] bf16 rows (round to nearest even), not fp32
 };
+
+// one 4-channel piece of an output row: 16 bytes of fp32, or 8 bytes of bf16 (the ET's pair rows in reduced-precision storage)
+__device__ __forceinline__ void store_piece(float* base, int64_t elem, float x, float y, float z, float w, int bf16) {
+  if (bf16) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    union { b2 v; uint32_t u; } lo, hi;
+    lo.v = __builtin_convertvector((f2){x, y}, b2);
+    hi.v = __builtin_convertvector((f2){z, w}, b2);
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + elem) = make_uint2(lo.u, hi.u);
+  } else {
+    *reinterpret_cast<float4*>(base + elem) = make_float4(x, y, z, w);
+  }
+}
 
 // Pairs in distance order.  A group of R4 = 3F/4 threads (one float4 column each) walks a RUN of consecutive sorted pairs:
 // consecutive pairs fall into the same or the next grid interval (2e5 pairs over 8192 intervals), so the four table
@@ -242,8 +257,12 @@ __global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const un
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const float* row = a.tab[t] + (int64_t)(T + 1) * 3 * R + 4 * c4;
-        *reinterpret_cast<f4*>(a.out[t] + (int64_t)p * R + 4 * c4) = *reinterpret_cast<const f4*>(row);
-        if (a.dout[t]) *reinterpret_cast<f4*>(a.dout[t] + (int64_t)p * R + 4 * c4) = *reinterpret_cast<const f4*>(row + R);
+        const f4 v0 = *reinterpret_cast<const f4*>(row);
+        store_piece(a.out[t], (int64_t)p * R + 4 * c4, v0.x, v0.y, v0.z, v0.w, a.out_bf16);
+        if (a.dout[t]) {
+          const f4 v1 = *reinterpret_cast<const f4*>(row + R);
+          store_piece(a.dout[t], (int64_t)p * R + 4 * c4, v1.x, v1.y, v1.z, v1.w, a.out_bf16);
+        }
       }
       continue;
     }
@@ -267,8 +286,12 @@ __global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const un
     const float bD = 6.f * t - 6.f * t2, b0 = 3.f * t2 - 4.f * t + 1.f, b1 = 3.f * t2 - 2.f * t;   // slope: bD D + b0 s0 + b1 s1
 #pragma unroll
     for (int tb = 0; tb < NT; ++tb) {
-      *reinterpret_cast<f4*>(a.out[tb] + (int64_t)p * R + 4 * c4) = f0[tb] + (aD * D[tb] + a0 * sl0[tb] + a1 * sl1[tb]);
-      if (a.dout[tb]) *reinterpret_cast<f4*>(a.dout[tb] + (int64_t)p * R + 4 * c4) = bD * D[tb] + b0 * sl0[tb] + b1 * sl1[tb];
+      const f4 v0 = f0[tb] + (aD * D[tb] + a0 * sl0[tb] + a1 * sl1[tb]);
+      store_piece(a.out[tb], (int64_t)p * R + 4 * c4, v0.x, v0.y, v0.z, v0.w, a.out_bf16);
+      if (a.dout[tb]) {
+        const f4 v1 = bD * D[tb] + b0 * sl0[tb] + b1 * sl1[tb];
+        store_piece(a.dout[tb], (int64_t)p * R + 4 * c4, v1.x, v1.y, v1.z, v1.w, a.out_bf16);
+      }
     }
   }
 }
@@ -300,8 +323,12 @@ __global__ __launch_bounds__(256) void k_edge_interp_direct(Graph g, int Pcap, I
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float* row = a.tab[t] + (int64_t)(T + 1) * 3 * R + 4 * c4;
-      *reinterpret_cast<f4*>(a.out[t] + (int64_t)p * R + 4 * c4) = *reinterpret_cast<const f4*>(row);
-      if (a.dout[t]) *reinterpret_cast<f4*>(a.dout[t] + (int64_t)p * R + 4 * c4) = *reinterpret_cast<const f4*>(row + R);
+      const f4 v0 = *reinterpret_cast<const f4*>(row);
+      store_piece(a.out[t], (int64_t)p * R + 4 * c4, v0.x, v0.y, v0.z, v0.w, a.out_bf16);
+      if (a.dout[t]) {
+        const f4 v1 = *reinterpret_cast<const f4*>(row + R);
+        store_piece(a.dout[t], (int64_t)p * R + 4 * c4, v1.x, v1.y, v1.z, v1.w, a.out_bf16);
+      }
     }
     return;
   }
@@ -316,8 +343,12 @@ __global__ __launch_bounds__(256) void k_edge_interp_direct(Graph g, int Pcap, I
     const float* row = a.tab[tb] + (int64_t)k * 3 * R + 4 * c4;
     const f4 f0 = *reinterpret_cast<const f4*>(row), sl0 = *reinterpret_cast<const f4*>(row + R);
     const f4 D = *reinterpret_cast<const f4*>(row + 2 * R), sl1 = *reinterpret_cast<const f4*>(row + 4 * R);
-    *reinterpret_cast<f4*>(a.out[tb] + (int64_t)p * R + 4 * c4) = f0 + (aD * D + a0 * sl0 + a1 * sl1);
-    if (a.dout[tb]) *reinterpret_cast<f4*>(a.dout[tb] + (int64_t)p * R + 4 * c4) = bD * D + b0 * sl0 + b1 * sl1;
+    const f4 v0 = f0 + (aD * D + a0 * sl0 + a1 * sl1);
+    store_piece(a.out[tb], (int64_t)p * R + 4 * c4, v0.x, v0.y, v0.z, v0.w, a.out_bf16);
+    if (a.dout[tb]) {
+      const f4 v1 = bD * D + b0 * sl0 + b1 * sl1;
+      store_piece(a.dout[tb], (int64_t)p * R + 4 * c4, v1.x, v1.y, v1.z, v1.w, a.out_bf16);
+    }
   }
 }
 
@@ -345,7 +376,7 @@ void launch_pair_buckets(const Graph& g, int Pcap, float lo, float up, int T, fl
 // the tables' outputs for all pairs (tables of one row length R per call)
 void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
                         float* const* outs, float* const* douts, const unsigned* keys_s, const int* vals_s, hipStream_t s, float* C,
-                        float* dC) {
+                        float* dC, int out_bf16) {
   const int n = Pcap + 1;
   InterpArgs a{};  // filled per chunk of four tables below: `ntab` is not bounded by the struct's eight slots
   const float h = (up - lo) / (float)T;
@@ -366,6 +397,7 @@ void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int
   for (int t0 = 0; t0 < ntab; t0 += 4) {  // four tables per launch (one launch for TensorNet's L + 1 <= 4)
     a = InterpArgs{};
     a.ntab = ntab - t0 < 4 ? ntab - t0 : 4;
+    a.out_bf16 = out_bf16;
     for (int t = 0; t < a.ntab; ++t) {
       a.tab[t] = tabs[t0 + t];
       a.out[t] = outs[t0 + t];

@@ -17,7 +17,17 @@ struct EtAttnArgs {   // per-layer operands of the attention sweeps
   int F, hd, Wd, dk_off, dv_off;  // *_off = -1: the model has no such projection (factor 1)
   int vector_cutoff;
   int64_t slot_stride;  // reverse target sweep: distance between the per-wave slot arrays of gd2 / gr2 (= 2 (P + 1))
+  int pair_bf16;        // 1: dkv / tkv rows are stored as bf16 (option "pair_rows_bf16"): the sweeps read half the bytes
 };
+
+// element `idx` of a per-pair row array kept in fp32 or, in the reduced-precision storage mode, bf16.  Branch-free on purpose:
+// a (wave-uniform) branch around every load stops the compiler from issuing an edge's loads together, which doubled the
+// sweeps' time (profiles/r03_notes.md); both modes load one aligned dword (two lanes share it in bf16 mode) and select.
+__device__ __forceinline__ float ldpair(const float* base, int64_t idx, int bf16) {
+  const uint32_t w = reinterpret_cast<const uint32_t*>(base)[bf16 ? (idx >> 1) : idx];
+  const uint32_t hi = w & 0xffff0000u, lo = w << 16;
+  return __uint_as_float(bf16 ? ((idx & 1) ? hi : lo) : w);
+}
 
 void launch_et_embed(const int64_t* z, const float* emb, int N, int F, float* x, hipStream_t s);
 void launch_et_nbr_embed(const Graph& g, int N, int F, const int64_t* z, const float* emb, const float* embN, const float* Wn,

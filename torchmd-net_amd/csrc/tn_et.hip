@@ -107,18 +107,18 @@ __global__ void k_et_attn_fwd(Graph g, EtAttnArgs a, float* __restrict__ xagg, f
     const int s = g.col[e], p = g.epair[e];
     const float sg = g.esign[e];
     const float* qs = a.qkv + (int64_t)s * F5 + cc;
-    const float* dkv = a.dkv + (int64_t)p * a.Wd;
+    const int64_t dkv_b = (int64_t)p * a.Wd;
     const float C = a.C[p];
     const float cv = a.vector_cutoff ? C : 1.0f, ca = a.vector_cutoff ? 1.0f : C;
-    const float dk = a.dk_off >= 0 ? dkv[a.dk_off + cc] : 1.0f;
+    const float dk = a.dk_off >= 0 ? ldpair(a.dkv, dkv_b + (a.dk_off + cc), a.pair_bf16) : 1.0f;
     float ak = live ? qt * qs[F] * dk : 0.f;
     ak = head_sum(ak, hd);
     const float A = silu(ak) * ca;
     float dvx = 1.f, dv1 = 1.f, dv2 = 1.f;
     if (a.dv_off >= 0) {
-      dvx = dkv[a.dv_off + cc];
-      dv1 = dkv[a.dv_off + F + cc];
-      dv2 = dkv[a.dv_off + 2 * F + cc];
+      dvx = ldpair(a.dkv, dkv_b + (a.dv_off + cc), a.pair_bf16);
+      dv1 = ldpair(a.dkv, dkv_b + (a.dv_off + F + cc), a.pair_bf16);
+      dv2 = ldpair(a.dkv, dkv_b + (a.dv_off + 2 * F + cc), a.pair_bf16);
     }
     const float sx = qs[2 * F] * cv * dvx, s1 = qs[3 * F] * cv * dv1, s2 = qs[4 * F] * cv * dv2;
     const float* vs = a.vec + (int64_t)s * 3 * F + cc;
@@ -185,11 +185,11 @@ __device__ __forceinline__ void et_fwd_load(const Graph& g, const EtAttnArgs& a,
   o.vxj = qs[2 * F];
   o.v1j = qs[3 * F];
   o.v2j = qs[4 * F];
-  const float* dkv = a.dkv + (int64_t)p * a.Wd + c;
-  o.dk = HAS_DK ? dkv[a.dk_off] : 1.0f;
-  o.dvx = HAS_DV ? dkv[a.dv_off] : 1.0f;
-  o.dv1 = HAS_DV ? dkv[a.dv_off + F] : 1.0f;
-  o.dv2 = HAS_DV ? dkv[a.dv_off + 2 * F] : 1.0f;
+  const int64_t dkv_b = (int64_t)p * a.Wd + c;
+  o.dk = HAS_DK ? ldpair(a.dkv, dkv_b + (a.dk_off), a.pair_bf16) : 1.0f;
+  o.dvx = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off), a.pair_bf16) : 1.0f;
+  o.dv1 = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off + F), a.pair_bf16) : 1.0f;
+  o.dv2 = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off + 2 * F), a.pair_bf16) : 1.0f;
   const float* vs = a.vec + (int64_t)s * 3 * F + c;
   o.vs0 = vs[0];
   o.vs1 = vs[F];
@@ -332,20 +332,20 @@ void launch_et_update_bwd(const float* g_x, const float* g_vec, const float* vp,
 __device__ __forceinline__ EtEdge et_edge(const EtAttnArgs& a, float tq, const float* __restrict__ sq, int p, int cc, bool live,
                                           float& dk, float& dvx, float& dv1, float& dv2) {
   const int F = a.F;
-  const float* dkv = a.dkv + (int64_t)p * a.Wd;
+  const int64_t dkv_b = (int64_t)p * a.Wd;
   const float C = a.C[p];
   EtEdge r;
   r.cv = a.vector_cutoff ? C : 1.0f;
   r.ca = a.vector_cutoff ? 1.0f : C;
-  dk = a.dk_off >= 0 ? dkv[a.dk_off + cc] : 1.0f;
+  dk = a.dk_off >= 0 ? ldpair(a.dkv, dkv_b + (a.dk_off + cc), a.pair_bf16) : 1.0f;
   float ak = live ? tq * sq[F] * dk : 0.f;
   r.a = head_sum(ak, a.hd);
   r.A = silu(r.a) * r.ca;
   dvx = dv1 = dv2 = 1.f;
   if (a.dv_off >= 0) {
-    dvx = dkv[a.dv_off + cc];
-    dv1 = dkv[a.dv_off + F + cc];
-    dv2 = dkv[a.dv_off + 2 * F + cc];
+    dvx = ldpair(a.dkv, dkv_b + (a.dv_off + cc), a.pair_bf16);
+    dv1 = ldpair(a.dkv, dkv_b + (a.dv_off + F + cc), a.pair_bf16);
+    dv2 = ldpair(a.dkv, dkv_b + (a.dv_off + 2 * F + cc), a.pair_bf16);
   }
   r.sx = sq[2 * F] * r.cv * dvx;
   r.s1 = sq[3 * F] * r.cv * dv1;
@@ -390,11 +390,11 @@ __global__ void k_et_attn_bwd_t(Graph g, EtAttnArgs a, const float* __restrict__
       const float g_a = g_A * silu_grad(ed.a) * ed.ca;
       gq += g_a * sq[F] * dk;
       // tangents of dk / dv: d/dd of the pair quantities (forward mode), so g_d needs no per-pair gradient arrays
-      const float* tkv = a.tkv + (int64_t)p * a.Wd;
+      const int64_t tkv_b = (int64_t)p * a.Wd;
       const float vxs = sq[2 * F], v1s = sq[3 * F], v2s = sq[4 * F];
       float gd = 0.f, gcv = 0.f;
-      if (a.dv_off >= 0) gd = ed.cv * (g_sx * vxs * tkv[a.dv_off + cc] + g_s1 * v1s * tkv[a.dv_off + F + cc] + g_s2 * v2s * tkv[a.dv_off + 2 * F + cc]);
-      if (a.dk_off >= 0) gd += g_a * qt * sq[F] * tkv[a.dk_off + cc];
+      if (a.dv_off >= 0) gd = ed.cv * (g_sx * vxs * ldpair(a.tkv, tkv_b + (a.dv_off + cc), a.pair_bf16) + g_s1 * v1s * ldpair(a.tkv, tkv_b + (a.dv_off + F + cc), a.pair_bf16) + g_s2 * v2s * ldpair(a.tkv, tkv_b + (a.dv_off + 2 * F + cc), a.pair_bf16));
+      if (a.dk_off >= 0) gd += g_a * qt * sq[F] * ldpair(a.tkv, tkv_b + (a.dk_off + cc), a.pair_bf16);
       gcv = g_sx * vxs * dvx + g_s1 * v1s * dv1 + g_s2 * v2s * dv2;
       // cutoff factor: on the values (g_cv) or on the attention weight (g_ca = sum_h g_A silu(a); one lane per head adds it)
       const float gca = ((cc % a.hd) == 0) ? g_A * silu(ed.a) : 0.f;
@@ -502,22 +502,22 @@ __global__ void k_et_attn_bwd(Graph g, EtAttnArgs a, const float* __restrict__ g
     const float sg = g.esign[e];
     const float* jq = a.qkv + (int64_t)j * F5 + cc;
     const float qj = jq[0], kj = jq[F], vxj = jq[2 * F], v1j = jq[3 * F], v2j = jq[4 * F];
-    const float* dkv = a.dkv + (int64_t)p * a.Wd;
-    const float* tkv = a.tkv + (int64_t)p * a.Wd;
+    const int64_t dkv_b = (int64_t)p * a.Wd;
+    const int64_t tkv_b = (int64_t)p * a.Wd;
     const float C = a.C[p];
     const float cv = a.vector_cutoff ? C : 1.0f, ca = a.vector_cutoff ? 1.0f : C;
     float dk = 1.f, tk = 0.f, dvx = 1.f, dv1 = 1.f, dv2 = 1.f, tvx = 0.f, tv1 = 0.f, tv2 = 0.f;
     if (a.dk_off >= 0) {
-      dk = dkv[a.dk_off + cc];
-      tk = tkv[a.dk_off + cc];
+      dk = ldpair(a.dkv, dkv_b + (a.dk_off + cc), a.pair_bf16);
+      tk = ldpair(a.tkv, tkv_b + (a.dk_off + cc), a.pair_bf16);
     }
     if (a.dv_off >= 0) {
-      dvx = dkv[a.dv_off + cc];
-      dv1 = dkv[a.dv_off + F + cc];
-      dv2 = dkv[a.dv_off + 2 * F + cc];
-      tvx = tkv[a.dv_off + cc];
-      tv1 = tkv[a.dv_off + F + cc];
-      tv2 = tkv[a.dv_off + 2 * F + cc];
+      dvx = ldpair(a.dkv, dkv_b + (a.dv_off + cc), a.pair_bf16);
+      dv1 = ldpair(a.dkv, dkv_b + (a.dv_off + F + cc), a.pair_bf16);
+      dv2 = ldpair(a.dkv, dkv_b + (a.dv_off + 2 * F + cc), a.pair_bf16);
+      tvx = ldpair(a.tkv, tkv_b + (a.dv_off + cc), a.pair_bf16);
+      tv1 = ldpair(a.tkv, tkv_b + (a.dv_off + F + cc), a.pair_bf16);
+      tv2 = ldpair(a.tkv, tkv_b + (a.dv_off + 2 * F + cc), a.pair_bf16);
     }
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;  // prhat with the edge's sign: rhat(j <- r); rhat(r <- j) is its negative
     if (sg != 0.f) {
@@ -602,16 +602,16 @@ __device__ __forceinline__ void et_bwd_load(const Graph& g, const EtAttnArgs& a,
   o.vxj = jq[2 * F];
   o.v1j = jq[3 * F];
   o.v2j = jq[4 * F];
-  const float* dkv = a.dkv + (int64_t)p * a.Wd + c;
-  const float* tkv = a.tkv + (int64_t)p * a.Wd + c;
-  o.dk = HAS_DK ? dkv[a.dk_off] : 1.f;
-  o.tk = HAS_DK ? tkv[a.dk_off] : 0.f;
-  o.dvx = HAS_DV ? dkv[a.dv_off] : 1.f;
-  o.dv1 = HAS_DV ? dkv[a.dv_off + F] : 1.f;
-  o.dv2 = HAS_DV ? dkv[a.dv_off + 2 * F] : 1.f;
-  o.tvx = HAS_DV ? tkv[a.dv_off] : 0.f;
-  o.tv1 = HAS_DV ? tkv[a.dv_off + F] : 0.f;
-  o.tv2 = HAS_DV ? tkv[a.dv_off + 2 * F] : 0.f;
+  const int64_t dkv_b = (int64_t)p * a.Wd + c;
+  const int64_t tkv_b = (int64_t)p * a.Wd + c;
+  o.dk = HAS_DK ? ldpair(a.dkv, dkv_b + (a.dk_off), a.pair_bf16) : 1.f;
+  o.tk = HAS_DK ? ldpair(a.tkv, tkv_b + (a.dk_off), a.pair_bf16) : 0.f;
+  o.dvx = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off), a.pair_bf16) : 1.f;
+  o.dv1 = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off + F), a.pair_bf16) : 1.f;
+  o.dv2 = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off + 2 * F), a.pair_bf16) : 1.f;
+  o.tvx = HAS_DV ? ldpair(a.tkv, tkv_b + (a.dv_off), a.pair_bf16) : 0.f;
+  o.tv1 = HAS_DV ? ldpair(a.tkv, tkv_b + (a.dv_off + F), a.pair_bf16) : 0.f;
+  o.tv2 = HAS_DV ? ldpair(a.tkv, tkv_b + (a.dv_off + 2 * F), a.pair_bf16) : 0.f;
   const float* vj = a.vec + (int64_t)j * 3 * F + c;
   o.vj0 = vj[0];
   o.vj1 = vj[F];

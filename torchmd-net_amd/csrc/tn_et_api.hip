@@ -430,6 +430,11 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
   const int n_dkv = Wd > 0 ? L : 0;
   const bool use_tab = m->tabs.ok && (int64_t)P1 >= m->tab_min_pairs &&
                        (int)m->tabs.tab.size() == n_dkv + (hp.neighbor_embedding ? 1 : 0) && !m->tabs.tab.empty();
+  // reduced-precision STORAGE of the per-pair filter rows (option "pair_rows_bf16", BASELINE configs[3] "bf16"): dkv / tkv are
+  // written by the table interpolation as bf16 and widened to fp32 when the sweeps load them; every product and sum stays fp32.
+  // Only with the tables (the value + tangent GEMMs write fp32 rows): otherwise the call silently keeps fp32 storage.
+  const int pbf = (m->pair_bf16 && use_tab) ? 1 : 0;
+  const double pB = pbf ? 2.0 : 4.0;  // bytes per stored pair-row element
   if (use_tab) {
     // all per-pair filters from the radial tables: one bucket sort of the pairs, one interpolation launch per row length
     std::vector<const float*> tabs;
@@ -440,10 +445,10 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
       douts.push_back(want_forces ? b.tkv[l] : nullptr);
     }
     const double nt = (double)m->tabs.T + 2;
-    KR(CAT_EDGE_TABLE, (Pd + 1) * (4.0 * Wd * n_dkv * (want_forces ? 2 : 1) + 24) + nt * 12.0 * Wd * n_dkv,
+    KR(CAT_EDGE_TABLE, (Pd + 1) * (pB * Wd * n_dkv * (want_forces ? 2 : 1) + 24) + nt * 12.0 * Wd * n_dkv,
        (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
         n_dkv ? launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, Wd, n_dkv, tabs.data(), outs.data(), douts.data(),
-                                   b.skeys_s, b.svals_s, s, b.C, b.dC)
+                                   b.skeys_s, b.svals_s, s, b.C, b.dC, pbf)
               : (void)0));
     if (hp.neighbor_embedding) {
       const float* t1[1] = {m->tabs.tab[n_dkv]};
@@ -483,10 +488,10 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     EtAttnArgs& a = aa[l];
     a = EtAttnArgs{b.qkv[l], b.vec[l], b.dkv[l], b.tkv[l], b.C, b.dC, F, hd, Wd,
                    (hp.distance_influence & 1) ? 0 : -1, (hp.distance_influence & 2) ? ((hp.distance_influence & 1) ? F : 0) : -1,
-                   hp.vector_cutoff, 2 * (int64_t)P1};
+                   hp.vector_cutoff, 2 * (int64_t)P1, pbf};
     // algorithmic bytes (every distinct tensor once): dkv [P+1, Wd], qkv [N,5F], vec [N,3F] in; xagg [N,F],
     // vagg [N,3F] out; edge indices
-    KR(CAT_MESSAGE, (Pd + 1) * Wd * 4 + Nd * Fd * 4 * 12 + Ed * 12, launch_et_attn_fwd(g, N, a, b.xagg, b.vagg, s));
+    KR(CAT_MESSAGE, (Pd + 1) * Wd * pB + Nd * Fd * 4 * 12 + Ed * 12, launch_et_attn_fwd(g, N, a, b.xagg, b.vagg, s));
     NODE();
     gemm(s, b.xagg, F, q.Wo, F, q.bo, b.o[l], 3 * F, N, 3 * F, F);
     KR(CAT_ELEMENTWISE, Nd * Fd * 4 * 20,
@@ -541,11 +546,11 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
       KR(CAT_ELEMENTWISE, Nd * Fd * 24, launch_et_copy2d(b.g_vec, 3 * F, b.vagg, 3 * F, N, 3 * F, s));
       static const bool two_sweeps = getenv("TMDNET_ET_TWO_SWEEPS") != nullptr;  // developer switch: target / source sweeps apart
       if (two_sweeps) {
-        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * 4 + Nd * Fd * 4 * 17 + Ed * 12 + (Pd + 1) * 32 * nwv, launch_et_attn_bwd_t(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
-        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * 4 + Nd * Fd * 4 * 18 + Ed * 12, launch_et_attn_bwd_s(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, s));
+        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * pB + Nd * Fd * 4 * 17 + Ed * 12 + (Pd + 1) * 32 * nwv, launch_et_attn_bwd_t(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
+        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * pB + Nd * Fd * 4 * 18 + Ed * 12, launch_et_attn_bwd_s(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, s));
       } else {
         // dkv + tkv, qkv, vec, g_xagg, g_vagg in; g_qkv out, g_vec read + written; the (pair, direction) slots of g_d, g_rhat
-        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * 4 + Nd * Fd * 4 * 23 + Ed * 12 + (Pd + 1) * 32 * nwv,
+        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * pB + Nd * Fd * 4 * 23 + Ed * 12 + (Pd + 1) * 32 * nwv,
            launch_et_attn_bwd(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
       }
       gemm(s, b.g_vp, 3 * F, q.WvpT, 3 * F, nullptr, b.g_vec, F, 3 * N, F, 3 * F, GEMM_ACCUM);

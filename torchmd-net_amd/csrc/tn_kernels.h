@@ -168,7 +168,7 @@ void launch_pair_buckets(const Graph& g, int Pcap, float lo, float up, int T, fl
 bool edge_interp_direct(int Pcap);
 void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
                         float* const* outs, float* const* douts, const unsigned* keys_s, const int* vals_s, hipStream_t s, float* C,
-                        float* dC);
+                        float* dC, int out_bf16 = 0);  // out_bf16: rows stored as bf16 (the ET's reduced-precision pair storage)
 void launch_interp_list(const float* tab, const double* dist, int M, int R, int T, float lo, float up, float* out, float* dout,
                         hipStream_t s);
 

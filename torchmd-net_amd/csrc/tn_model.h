@@ -161,6 +161,7 @@ struct tmdnet_model {
   std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
   DevParams P;
   EdgeTables tabs;
+  int pair_bf16 = 0;          // option "pair_rows_bf16" (Equivariant Transformer): per-pair filter rows stored as bf16
   int64_t tab_min_pairs = 1;  // developer / test switch (option "edge_table_min_pairs"): fewer pairs take the value + tangent GEMMs
   bool finalized = false;
   std::string err;

@@ -32,8 +32,24 @@ from torchmdnet_amd.models.utils import _ptr, _require_cuda, _stream_ptr, dtype_
 
 # --------------------------------------------------------------------------------------------------
 def create_model(args, prior_model=None, mean=None, std=None):
-    """Same argument dict as the reference (model.py:21-164).  Supported on the HIP path:
-    model == "tensornet", output_model == "Scalar", precision 32, prior_model in {None, Atomref}."""
+    """Same argument dict as the reference (model.py:21-164); see ``_create_model`` for what the HIP path supports.  One
+    key beyond the reference's: ``pair_storage`` = "fp32" (default) | "bf16" - Equivariant Transformer only: the per-pair
+    distance-filter rows are STORED as bf16 between the kernels (the sweeps that stream them read half the bytes); all
+    arithmetic stays fp32.  That is the "bf16" of BASELINE configs[3]; the reference has no bf16 mode to compare with
+    (models/utils.py:715), so its accuracy is stated against the fp32 oracle (tests/test_gpu_et.py)."""
+    model = _create_model(args, prior_model=prior_model, mean=mean, std=std)
+    storage = str(args.get("pair_storage", "fp32"))
+    if storage not in ("fp32", "bf16"):
+        raise ValueError(f"pair_storage must be 'fp32' or 'bf16', got {storage!r}")
+    if storage == "bf16" and not model._is_et():
+        raise NotImplementedError("pair_storage='bf16' applies to the Equivariant Transformer only")
+    model.pair_storage = storage
+    return model
+
+
+def _create_model(args, prior_model=None, mean=None, std=None):
+    """Supported on the HIP path: model in {"tensornet", "tensornet2", "equivariant-transformer"}, precision 32,
+    prior_model in {None, Atomref}."""
     dtype = dtype_mapping[args["precision"]]
     if "box_vecs" not in args:
         args["box_vecs"] = None
@@ -312,6 +328,7 @@ class TorchMD_Net(nn.Module):
         std = torch.scalar_tensor(1) if std is None else std
         self.register_buffer("std", std.to(dtype=dtype))
         self._engine = _EngineState()
+        self.pair_storage = "fp32"  # "bf16": Equivariant Transformer pair rows in reduced-precision storage (create_model)
         self.static_check = True  # static_shapes mode: poll the overflow flag after every non-captured call
         self.cell_list_min_atoms = 1024  # single periodic systems at least this large use the O(N) cell list
         self.reset_parameters()
@@ -473,6 +490,8 @@ class TorchMD_Net(nn.Module):
         rc = L.tmdnet_finalize_params(handle)
         if rc != _C.OK:
             raise RuntimeError(L.tmdnet_last_error(handle).decode())
+        if getattr(self, "pair_storage", "fp32") == "bf16":
+            L.tmdnet_set_option(handle, b"pair_rows_bf16", 1.0)
         for name, value in getattr(st, "options", {}).items():
             L.tmdnet_set_option(handle, name.encode(), value)
         st.fingerprint = fp
@@ -520,9 +539,10 @@ class TorchMD_Net(nn.Module):
                 q = q.detach().to(device=dev, dtype=torch.float32).contiguous()
                 if q.numel() != n_mol:
                     raise ValueError(f"q must have one entry per molecule ({n_mol}), got {q.numel()}")
-            # neighbour strategy: O(N) cell list for one large periodic system (grid computed on the device from the box of
-            # THIS call: nothing about the box is cached on the host), brute force inside each molecule otherwise
-            auto = box_mode == 1 and n_mol == 1 and n >= self.cell_list_min_atoms
+            # neighbour strategy: O(N) cell list for one large system - periodic (grid computed on the device from the box of
+            # THIS call: nothing about the box is cached on the host) or not (fictitious box around the bounding box, as the
+            # reference's cell strategy, models/utils.py:206-212) -, brute force inside each molecule otherwise
+            auto = box_mode != 2 and n_mol == 1 and n >= self.cell_list_min_atoms
             L.tmdnet_set_cell_grid(st.handle, *((-1, -1, -1) if auto else (0, 0, 0)))
             nbytes = C.c_size_t(0)
             L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
