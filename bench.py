@@ -463,9 +463,11 @@ def main():
         guard = lambda: (id(sta._engine), sta._engine.generation)  # noqa: E731
         ranges = sharded.plan(bs, N_MOL)  # depends on the batch vector only: computed once, outside the timed region
         ses_strong = sharded.prepare(zs, ps, bs, n_mol=N_MOL, ranges=ranges, graph=True, guard=guard)
-        ses_weak = sharded.prepare_local(zw, pw, bw, n_mol=world * N_MOL, mol_lo=rank * N_MOL, atom_lo=rank * N_MOL * N_ATOMS,
-                                         graph=True, guard=guard)
-        sta.check_overflow(int(ses_weak.z_l.shape[0]), N_MOL)  # the replays are unchecked: poll the device-side flag once
+        # weak mode keeps the rank's 256 molecules: at that size a replayed graph buys nothing (2.95 vs 2.93 ms, tools/rank_step_probe.py)
+        # and the dynamic call takes the embedding in the radial basis (the species count is read back with the pair counts), so
+        # the rank step is the N = 1 step + zero-padding + all-reduce on pre-cut tensors and static buffers
+        eager = ShardedEvaluator(lambda zl, pl, bl, boxl, ql, nm: model.energy_and_forces(zl, pl, bl, boxl, ql, nm, want_forces=True))
+        ses_weak = eager.prepare_local(zw, pw, bw, n_mol=world * N_MOL, mol_lo=rank * N_MOL, atom_lo=rank * N_MOL * N_ATOMS, graph=False)
 
         def step_weak():
             e, f, _ = ses_weak.step()
@@ -475,7 +477,9 @@ def main():
             e, f, _ = ses_strong.step()
             return e, f
 
-        rank_step = "HIP-graph replay of the static-shape step (parallel.ShardSession) + one RCCL all-reduce of the energies"
+        sta.check_overflow(ranges[rank][3] - ranges[rank][2], ranges[rank][1] - ranges[rank][0])  # replays are unchecked: poll once
+        rank_step = ("eager two-phase call on the rank's pre-cut shard + one RCCL all-reduce of the zero-padded energy vector" if a.scaling == "weak"
+                     else "HIP-graph replay of the static-shape step (parallel.ShardSession) + one RCCL all-reduce of the energies")
 
     def timed(step, steps, mask):
         if use_dist:

@@ -230,6 +230,8 @@ Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   g.cgrid = c.take<int>(4);
   g.bat_s = c.take<int>(N);
   g.z_c = c.take<int64_t>(N);
+  g.tix = c.take<int>(N);
+  g.tz = c.take<int>(64);
   g.sort_tmp_bytes = cell_sort_temp_bytes(N);
   g.sort_tmp = c.take<char>((int64_t)g.sort_tmp_bytes);
   if (total) *total = c.off;
@@ -256,7 +258,14 @@ void set_cell(Graph& g, const tmdnet_model* m, bool on) {
   g.ncz = explicit_grid ? m->cell_n[2] : 0;
 }
 
-FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, int64_t P, bool bwd, size_t* total) {
+// species count rounded up to 4 / 8 when this call takes the embedding in the radial basis (tn_embed_rb.hip), else 0:
+// dynamic shapes only (the species count is read back with the pair counts), a batch-scale system, at most 8 species
+int rb_ntp(const tmdnet_model* m, int64_t n_atoms, int64_t n_pairs) {
+  if (!m->rb_fwd || m->tn2 || m->et || n_pairs < 0 || n_atoms < m->rb_min_atoms) return 0;
+  return embed_rb_ntp(m->last_nt);
+}
+
+FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, int64_t P, bool bwd, size_t* total, int ntp = 0) {
   Carver c(ws);
   FwdBuffers b{};
   const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden;
@@ -326,6 +335,9 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
     b.g_rhat = c.take<float>(P1 * 3);
     b.g_delta = c.take<float>(P1 * 3);
   }
+  b.mom = c.take<float>(ntp ? embed_rb_moment_elems(N, ntp, (int)K) : 0);
+  b.gmom = c.take<float>(ntp && bwd ? embed_rb_gmoment_elems(N, ntp, (int)K) : 0);
+  b.ps = c.take<float>(ntp ? P1 * 8 : 0);
   if (total) *total = c.off;
   return b;
 }
@@ -559,6 +571,7 @@ int tmdnet_destroy(tmdnet_model* m) {
   delete m->tn2;
   if (m->dev) (void)hipFree(m->dev);
   if (m->dev_sb) (void)hipFree(m->dev_sb);
+  if (m->rb_img) (void)hipFree(m->rb_img);
   delete m;
   return TMDNET_OK;
 }
@@ -850,6 +863,23 @@ int tmdnet_finalize_params(tmdnet_model* m) {
       t2.qweights = D("qweights");
     }
   }
+  {  // embedding in the radial basis: MFMA fragment images of the distance projections (tn_embed_rb.hip)
+    if (m->rb_img) {
+      HIP_TRY(m, hipFree(m->rb_img));
+      m->rb_img = nullptr;
+    }
+    m->rb_fwd = m->rb_rev = nullptr;
+    const char* env = getenv("TMDNET_EMBED_RB");  // developer switch: 0 keeps the per-pair tables for the embedding
+    if (!(env && atoi(env) == 0) && !m->tn2 && embed_rb_shape_ok(F, K)) {
+      const size_t nf = embed_rb_image_elems(F, K, false), nr = embed_rb_image_elems(F, K, true);
+      std::vector<uint16_t> img(nf + nr);
+      embed_rb_images(pk.buf.data() + off.at("Wdp"), pk.buf.data() + off.at("bdp"), F, K, img.data(), img.data() + nf);
+      HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->rb_img), img.size() * sizeof(uint16_t)));
+      HIP_TRY(m, hipMemcpy(m->rb_img, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      m->rb_fwd = m->rb_img;
+      m->rb_rev = m->rb_img + nf;
+    }
+  }
   P.Utab = m->dev + off.at("Utab");
   P.Vtab = m->dev + off.at("Vtab");
   launch_ztables(P.emb, P.emb2_waT, P.emb2_wbT, P.emb2_b, m->hp.max_z, F, m->dev + off.at("Utab"), m->dev + off.at("Vtab"), nullptr);
@@ -868,6 +898,10 @@ int tmdnet_set_option(tmdnet_model* m, const char* name, double value) {
     m->tab_min_pairs = value < 0 ? 0 : (int64_t)value;
     return TMDNET_OK;
   }
+  if (n == "embed_rb_min_atoms") {
+    m->rb_min_atoms = value < 0 ? 0 : (int64_t)value;
+    return TMDNET_OK;
+  }
   if (n == "pair_rows_bf16") {
     if (!m->et) return fail(m, TMDNET_ERR_INVALID, "pair_rows_bf16 applies to the Equivariant Transformer handle only");
     m->pair_bf16 = value != 0.0 ? 1 : 0;
@@ -884,6 +918,9 @@ int tmdnet_get_info(const tmdnet_model* m, const char* name, double* value) {
   else if (n == "edge_table_err_slope") *value = m->tabs.err_slope;
   else if (n == "edge_table_min_pairs") *value = (double)m->tab_min_pairs;
   else if (n == "pair_rows_bf16") *value = (double)m->pair_bf16;
+  else if (n == "embed_rb_min_atoms") *value = (double)m->rb_min_atoms;
+  else if (n == "embed_rb") *value = m->rb_fwd ? 1.0 : 0.0;
+  else if (n == "species_last_build") *value = (double)m->last_nt;
   else return TMDNET_ERR_INVALID;
   return TMDNET_OK;
 }
@@ -935,11 +972,13 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
                                 true, s);
     }
     if (z) launch_prepare_z(g, z, cell ? g.perm : nullptr, (int)n_atoms, m->hp.max_z, s);
+    if (z && m->rb_fwd && n_atoms >= m->rb_min_atoms) launch_type_map(g, (int)n_atoms, m->hp.max_z, s);  // counts[6]
   }
   int counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIP_TRY(m, hipMemcpyAsync(counts, g.counts, sizeof(counts), hipMemcpyDeviceToHost, s));
   HIP_TRY(m, hipStreamSynchronize(s));
   for (int k = 0; k < 8; ++k) counts_host[k] = counts[k];
+  m->last_nt = (z && m->rb_fwd && n_atoms >= m->rb_min_atoms) ? counts[6] : 0;
   if (counts[5])
     return fail(m, TMDNET_ERR_INVALID, "batch index out of range: every entry must be in [0, " + std::to_string(n_mol) + ")");
   if (counts[4])
@@ -999,6 +1038,7 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
     if (z && (cell || !graph_small_ok((int)n_atoms))) launch_prepare_z(g, z, cell ? g.perm : nullptr, (int)n_atoms, m->hp.max_z, s);
   }
   m->lastE = ecap;
+  m->last_nt = 0;  // static shapes: no read-back, the embedding keeps the per-pair tables
   HIP_TRY(m, hipGetLastError());
   return TMDNET_OK;
 }
@@ -1039,7 +1079,7 @@ int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64
   if (n_pairs < 0) n_pairs = ((int64_t)m->hp.max_num_neighbors * n_atoms) / 2 + 1;  // static mode: pair capacity
   if (m->et) return et_forward_workspace_bytes(m, n_atoms, n_mol, n_pairs, want_forces, bytes);
   if (m->tn2) return tn2_forward_workspace_bytes(m, n_atoms, n_mol, n_pairs, n_edges, want_forces, bytes);
-  carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes);
+  carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes, rb_ntp(m, n_atoms, n_pairs));
   return TMDNET_OK;
 }
 
@@ -1086,7 +1126,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   // n_pairs <  0: static mode, grids and workspace sized by the pair capacity, true count read on the device
   const int P = n_pairs >= 0 ? (int)n_pairs : (int)g.pcap, P1 = P + 1;
   size_t need = 0;
-  FwdBuffers b = carve_fwd(ws, hp, n_atoms, n_mol, P, want_forces != 0, &need);
+  const int ntp = rb_ntp(m, n_atoms, n_pairs);  // > 0: embedding in the radial basis (no Q / dQ per pair)
+  FwdBuffers b = carve_fwd(ws, hp, n_atoms, n_mol, P, want_forces != 0, &need, ntp);
   if (need > ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "forward workspace too small: need " + std::to_string(need));
   const DevParams& W = m->P;
   const int o3 = hp.group_o3;
@@ -1126,19 +1167,23 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     const float* tabs[8];
     float* outs[8];
     float* douts[8];
-    tabs[0] = m->tabs.tab[0];
-    outs[0] = b.Q;
-    douts[0] = want_forces ? b.dQ : nullptr;
+    int nt_ = 0;
+    if (!ntp) {  // Q(d) of the embedding: only when the per-pair form runs (the radial-basis form needs no per-pair rows)
+      tabs[nt_] = m->tabs.tab[0];
+      outs[nt_] = b.Q;
+      douts[nt_++] = want_forces ? b.dQ : nullptr;
+    }
     for (int l = 0; l < L; ++l) {
-      tabs[1 + l] = m->tabs.tab[1 + l];
-      outs[1 + l] = b.w[l];
-      douts[1 + l] = want_forces ? b.dw[l] : nullptr;
+      tabs[nt_] = m->tabs.tab[1 + l];
+      outs[nt_] = b.w[l];
+      douts[nt_++] = want_forces ? b.dw[l] : nullptr;
     }
     const double rowB = 12.0 * Fd;
-    KR(CAT_EDGE_TABLE, (Pd + 1) * (rowB * (L + 1) * (want_forces ? 2 : 1) + 24) + (double)(m->tabs.T + 2) * 2 * rowB * (L + 1),
-       (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
-        launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1 + L, tabs, outs, douts, b.skeys_s, b.svals_s, s, b.C,
-                           b.dC)));
+    if (nt_ > 0)
+      KR(CAT_EDGE_TABLE, (Pd + 1) * (rowB * nt_ * (want_forces ? 2 : 1) + 24) + (double)(m->tabs.T + 2) * 2 * rowB * nt_,
+         (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
+          launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, nt_, tabs, outs, douts, b.skeys_s, b.svals_s, s, b.C,
+                             b.dC)));
   } else {
     // ---- radial functions per pair
     RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
@@ -1170,11 +1215,21 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     // ---- embedding
     // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
     EDGE(1);
-    if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);  // distance projections + d/dd
+    if (ntp) {
+    } else if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);  // distance projections + d/dd
     else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
   }
-  KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
-     launch_embed_scatter(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.u0, b.s0n, s));
+  const RadialParams rbp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
+  const double momB = (double)embed_rb_moment_elems(N, ntp ? ntp : 4, K) * 4;
+  if (ntp) {
+    // embedding in the radial basis (tn_embed_rb.hip): moments per (atom, species, component), then the per-atom contraction
+    KR(CAT_SCATTER, E_ * 12 + Pd * 48 + momB,
+       (launch_pair_scalars(g, P, hp.cutoff_lower, hp.cutoff_upper, b.ps, s), launch_embed_moments(g, N, rbp, ntp, b.ps, b.mom, s)));
+    KR(CAT_SCATTER, momB + Nd * 10 * Fd * 4, launch_embed_combine(g, N, F, K, ntp, z, W.Utab, W.Vtab, m->rb_fwd, b.mom, b.u0, b.s0n, s));
+  } else {
+    KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
+       launch_embed_scatter(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.u0, b.s0n, s));
+  }
   KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s));
   NODE();
   gemm(s, b.ln0, F, W.L1, F, W.bL1, b.h1, 2 * F, N, 2 * F, F, GEMM_ACT_SILU, b.a1, 2 * F);
@@ -1251,9 +1306,14 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s));
     tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
-    KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
-       launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s, merged_gd ? b.g_delta : nullptr,
-                            b.gd_slots, L * gd_nw, gd_stride));
+    if (ntp) {
+      KR(CAT_PAIR, Nd * 10 * Fd * 4 + momB, launch_embed_gm(g, N, F, K, ntp, z, W.Utab, W.Vtab, m->rb_rev, W.bdp, b.gA, b.gmom, s));
+      KR(CAT_PAIR, Pd * 40 + momB + Pd * 8 * L * gd_nw,
+         launch_embed_pair_rb(g, P, N, rbp, ntp, b.ps, b.gmom, b.gd, b.g_rhat, s, merged_gd ? b.g_delta : nullptr, b.gd_slots, L * gd_nw, gd_stride));
+    } else
+      KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
+         launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s, merged_gd ? b.g_delta : nullptr,
+                              b.gd_slots, L * gd_nw, gd_stride));
     if (!merged_gd) KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s, nullptr, 0, gd_stride));
     KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
   }

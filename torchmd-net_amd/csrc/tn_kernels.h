@@ -21,7 +21,9 @@ struct Graph {  // device pointers into the graph workspace
   float* pd;     // [Pcap+1] distance (self pair: 0)
   float* pdelta; // [Pcap,3] pos_i - pos_j (+ minimum image)
   float* prhat;  // [Pcap,3] unit vector
-  int* counts;   // [8]: 0 = P, 1 = E, 2 = overflow, 3 = batch unsorted, 4 = z out of range, 5 = batch out of range
+  int* counts;   // [8]: 0 = P, 1 = E, 2 = overflow, 3 = batch unsorted, 4 = z out of range, 5 = batch out of range, 6 = species present
+  int* tix;      // [N]  index of the atom's atomic number among the species present in the batch (k_type_map, tn_embed_rb.hip)
+  int* tz;       // [64] atomic number of each species index
   int64_t ecap, pcap;
   // ---- cell-list path (tn_cell.hip): atoms renumbered in cell order
   int* perm;             // [N] internal index -> caller's atom index
@@ -169,6 +171,22 @@ bool edge_interp_direct(int Pcap);
 void launch_edge_interp(const Graph& g, int Pcap, float lo, float up, int T, int R, int ntab, const float* const* tabs,
                         float* const* outs, float* const* douts, const unsigned* keys_s, const int* vals_s, hipStream_t s, float* C,
                         float* dC, int out_bf16 = 0);  // out_bf16: rows stored as bf16 (the ET's reduced-precision pair storage)
+// ---- embedding in the radial basis (tn_embed_rb.hip; reverse pair kernel in tn_pairgrad.hip)
+void launch_type_map(const Graph& g, int N, int max_z, hipStream_t s);
+bool embed_rb_shape_ok(int F, int K);
+int embed_rb_ntp(int nt);  // species count rounded up to 4 / 8; 0: more than 8 species (the per-pair tables run)
+int64_t embed_rb_moment_elems(int64_t N, int ntp, int K);
+int64_t embed_rb_gmoment_elems(int64_t N, int ntp, int K);
+size_t embed_rb_image_elems(int F, int K, bool reverse);
+void embed_rb_images(const float* Wdp_host, const float* bdp_host, int F, int K, uint16_t* fwd, uint16_t* rev);
+void launch_pair_scalars(const Graph& g, int Pcap, float lo, float up, float* ps, hipStream_t s);  // [P + 1][8]: C, C', C0, C0', u
+void launch_embed_moments(const Graph& g, int N, RadialParams rp, int ntp, const float* ps, float* m, hipStream_t s);
+void launch_embed_combine(const Graph& g, int N, int F, int K, int ntp, const int64_t* z, const float* Utab, const float* Vtab,
+                          const uint16_t* Bimg, const float* m, float* u0, float* s0n, hipStream_t s);
+void launch_embed_gm(const Graph& g, int N, int F, int K, int ntp, const int64_t* z, const float* Utab, const float* Vtab,
+                     const uint16_t* B2img, const float* bdp, const float* gA, float* gm, hipStream_t s);
+void launch_embed_pair_rb(const Graph& g, int Pcap, int N, RadialParams rp, int ntp, const float* ps, const float* gm, float* gd,
+                          float* g_rhat, hipStream_t s, float* g_delta, const float* slots, int n_slots, int64_t slot_stride);
 void launch_interp_list(const float* tab, const double* dist, int M, int R, int T, float lo, float up, float* out, float* dout,
                         hipStream_t s);
 

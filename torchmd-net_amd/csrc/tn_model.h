@@ -72,6 +72,7 @@ struct FwdBuffers {
   int *svals_s, *shist;  // pair ids in that order; bucket counters [T + 2]
   float *g_ao, *g_al, *g_ln, *g_feat, *G, *gD, *gCh, *gMi, *gPn, *gXl, *gd, *gd_slots;
   float *gUX, *g_a2, *g_a1, *g_ln0, *g_s0n, *g_u0l, *gA, *g_rhat, *g_delta;
+  float *mom, *gmom, *ps;  // embedding in the radial basis (tn_embed_rb.hip): moments [N][NTP][10][K + 4], their gradient, pair scalars [P + 1][8]
 };
 
 
@@ -161,6 +162,12 @@ struct tmdnet_model {
   std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
   DevParams P;
   EdgeTables tabs;
+  // embedding in the radial basis (tn_embed_rb.hip): weight fragment images (null: shape not covered / switched off),
+  // species count of the last dynamic graph build (0: unknown -> the per-pair tables run), atom threshold
+  uint16_t* rb_img = nullptr;
+  const uint16_t *rb_fwd = nullptr, *rb_rev = nullptr;
+  int last_nt = 0;
+  int64_t rb_min_atoms = 1024;
   int pair_bf16 = 0;          // option "pair_rows_bf16" (Equivariant Transformer): per-pair filter rows stored as bf16
   int64_t tab_min_pairs = 1;  // developer / test switch (option "edge_table_min_pairs"): fewer pairs take the value + tangent GEMMs
   bool finalized = false;

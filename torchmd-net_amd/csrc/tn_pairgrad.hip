@@ -247,6 +247,98 @@ void launch_embed_pair_gd(const Graph& g, int Pcap, int F, const int64_t* z, con
   }
 }
 
+// ---- embedding in the radial basis (tn_embed_rb.hip): the per-pair part of its reverse pass: gather g_m[i, species(j), :, k] and
+// g_m[j, species(i), :, k] (2 x 10 numbers per radial function k), contract with psi_k(d) = C(d) phi_k(d), psi_k'(d) and the pair
+// geometry, reduce over k.  It is embed_pair_channel with Z1 = Z2 = 1, q0 = q1 = q2 = psi and the cutoff folded into psi:
+// with b[g] = ai[g] + s_g aj[g] (s_g = -1 for the three components odd in rhat)
+//   acc0 += psi' * sum_g b[g] geom_g(r) ,   acc_a += psi * sum_g b[g] d geom_g / d r_a          (33 operations instead of ~110).
+// Two earlier forms - 32 lanes per pair (one radial function per lane), and a wave per atom walking its pairs two at a time -
+// kept 2 pairs per wave in flight and were bound by the latency of their dependent load phases (115 - 160 us at 256 x 64 atoms
+// for 0.5 GB of gathers; profiles/r03_notes.md).
+// K / 8 lanes per pair, EIGHT radial functions per lane (two 16-byte loads per moment row), 16 pairs per
+// wave (K = 32).  Every lane fetches its own pair's record, so there is no shuffle, and the 40 row loads of all 16 pairs are in
+// flight together: the kernel is a gather (0.5 GB at 256 x 64 atoms) and needs that many requests outstanding; that is what makes it fast.
+template <int NTP, int LPP>  // LPP = K / 8 lanes per pair
+__global__ __launch_bounds__(256) void k_embed_pair_rb8(Graph g, RadialParams rp, const float* __restrict__ ps,
+                                                        const float* __restrict__ gm, float* __restrict__ gd,
+                                                        float* __restrict__ g_rhat, float* __restrict__ g_delta,
+                                                        const float* __restrict__ slots, int n_slots, int64_t slot_stride) {
+  constexpr int PPB = 256 / LPP;  // pairs per block
+  constexpr int K = LPP * 8, KP = K + 4;
+  if (g.counts[2]) return;
+  const int P = g.counts[0];
+  const int item = xcd_chunk_act(blockIdx.x, (P + PPB - 1) / PPB);  // grid: pair capacity; items: existing pairs
+  if (item < 0) return;
+  const int p = item * PPB + threadIdx.x / LPP;
+  if (p >= P) return;
+  const int c8 = threadIdx.x % LPP;  // this lane's chunk of eight radial functions
+  const int i = g.pair_i[p], j = g.pair_j[p];
+  const int ti = g.tix[i], tj = g.tix[j];
+  const float r0 = g.prhat[p * 3], r1 = g.prhat[p * 3 + 1], r2 = g.prhat[p * 3 + 2];
+  const float4 sc = *reinterpret_cast<const float4*>(ps + (int64_t)p * 8);  // C, C', C0, C0' (k_pair_scalars)
+  const float c = sc.x, dc = sc.y, c0 = sc.z, dc0 = sc.w;
+  const float u = ps[(int64_t)p * 8 + 4];
+  const float alpha = 5.0f / (rp.up - rp.lo);
+  const float* gi = gm + ((int64_t)i * NTP + tj) * 10 * KP + 8 * c8;
+  const float* gj = gm + ((int64_t)j * NTP + ti) * 10 * KP + 8 * c8;
+  // b[g][k] = ai[g][k] + s_g aj[g][k] for this lane's eight k (rb_pair_channel); lane c8 == 0 also takes the bias moment
+  float b[10][8], bb[10];
+#pragma unroll
+  for (int w = 0; w < 10; ++w) {
+    const float4 a0 = pld4(gi + w * KP), a1 = pld4(gi + w * KP + 4), e0 = pld4(gj + w * KP), e1 = pld4(gj + w * KP + 4);
+    const float sg = (w >= 1 && w <= 3) ? -1.f : 1.f;
+    b[w][0] = a0.x + sg * e0.x; b[w][1] = a0.y + sg * e0.y; b[w][2] = a0.z + sg * e0.z; b[w][3] = a0.w + sg * e0.w;
+    b[w][4] = a1.x + sg * e1.x; b[w][5] = a1.y + sg * e1.y; b[w][6] = a1.z + sg * e1.z; b[w][7] = a1.w + sg * e1.w;
+    bb[w] = c8 == 0 ? gi[w * KP + K] + sg * gj[w * KP + K] : 0.f;  // gi / gj carry the lane offset 8 c8 = 0 here
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  auto add = [&](float psi, float dpsi, float b0, float b1, float b2, float b3, float b4, float b5, float b6, float b7, float b8_,
+                 float b9) {
+    const float h0 = b1 + (2.f * b4 * r0 + b5 * r1 + b6 * r2);
+    const float h1 = b2 + (b5 * r0 + 2.f * b7 * r1 + b8_ * r2);
+    const float h2 = b3 + (b6 * r0 + b8_ * r1 + 2.f * b9 * r2);
+    const float G = b0 + r0 * (b1 + 0.5f * (h0 - b1)) + r1 * (b2 + 0.5f * (h1 - b2)) + r2 * (b3 + 0.5f * (h2 - b3));
+    acc[0] += dpsi * G;
+    acc[1] += psi * h0;
+    acc[2] += psi * h1;
+    acc[3] += psi * h2;
+  };
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int k = 8 * c8 + q;
+    const float mu = rp.means[k], beta = rp.betas[k];
+    const float gk = expf(-beta * (u - mu) * (u - mu));
+    const float phi = c0 * gk, dphi = dc0 * gk + c0 * gk * (-2.0f * beta * (u - mu)) * (-alpha * u);
+    add(c * phi, dc * phi + c * dphi, b[0][q], b[1][q], b[2][q], b[3][q], b[4][q], b[5][q], b[6][q], b[7][q], b[8][q], b[9][q]);
+  }
+  add(c, dc, bb[0], bb[1], bb[2], bb[3], bb[4], bb[5], bb[6], bb[7], bb[8], bb[9]);  // zero except in lane c8 == 0
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = row_sum(acc[q], LPP);
+  if (c8 == 0) {
+    if (g_delta) {
+      pair_finish(g, p, acc[0], acc[1], acc[2], acc[3], r0, r1, r2, slots, n_slots, slot_stride, g_delta);
+    } else {
+      gd[p] += acc[0];
+      g_rhat[p * 3] = acc[1];
+      g_rhat[p * 3 + 1] = acc[2];
+      g_rhat[p * 3 + 2] = acc[3];
+    }
+  }
+}
+void launch_embed_pair_rb(const Graph& g, int Pcap, int N, RadialParams rp, int ntp, const float* ps, const float* gm, float* gd,
+                          float* g_rhat, hipStream_t s, float* g_delta, const float* slots, int n_slots, int64_t slot_stride) {
+  if (Pcap <= 0 || N <= 0) return;
+  const int lpp = rp.K / 8;
+  const dim3 grid(cdivp(Pcap, 256 / lpp)), block(256);
+#define RB_P8(NTP_, LPP_) \
+  hipLaunchKernelGGL((k_embed_pair_rb8<NTP_, LPP_>), grid, block, 0, s, g, rp, ps, gm, gd, g_rhat, g_delta, slots, n_slots, slot_stride)
+  if (ntp == 4 && lpp == 4) RB_P8(4, 4);
+  else if (ntp == 4) RB_P8(4, 8);
+  else if (lpp == 4) RB_P8(8, 4);
+  else RB_P8(8, 8);
+#undef RB_P8
+}
+
 // g_delta = (g_r - (g_r . r) r) / d + g_d r     (reference neighbor_utils.py:11-46; zero for d = 0)
 __global__ void k_geom_gd(Graph g, const float* __restrict__ gd, const float* __restrict__ g_rhat, float* __restrict__ g_delta,
                           const float* __restrict__ slots, int n_slots, int64_t slot_stride) {
