@@ -116,3 +116,22 @@ def test_radial_basis_embedding_periodic_cell_list_and_fallbacks(hip_lib):
     E3, F3 = rb(zc[sel], pc[sel].clone(), bc[sel])
     E4, F4 = old(zc[sel], pc[sel].clone(), bc[sel])
     assert rb.engine_info("species_last_build") == 0 and torch.equal(E3, E4) and torch.equal(F3, F4)
+
+
+def test_radial_basis_embedding_tensornet2(hip_lib):
+    """TensorNet2 shares TensorNet's embedding (tensornet2.py:228-463 -> TensorEmbedding): same switch, same agreement; the
+    Coulomb head and the charge heads sit on top of it unchanged"""
+    args = dict(W.C2_ARGS, model="tensornet2", output_model="ScalarPlusWeightedCoulomb", embedding_dimension=64, q_dim=8,
+                q_weights=[1.0, 0.5, 2.0], max_z=40)
+    rb, old = _pair(args, seed=21)
+    z, pos, batch = W.synthetic_batch(n_mol=40, n_atoms=40, first_seed=900)
+    z = _species(z, 5)
+    q = torch.tensor([float(m % 3 - 1) for m in range(40)])
+    zc, pc, bc, qc = z.cuda(), pos.cuda(), batch.cuda(), q.cuda()
+    E, F = rb(zc, pc, bc, q=qc)
+    assert rb.engine_info("species_last_build") == 5
+    Eo, Fo = old(zc, pc.clone(), bc, q=qc)
+    assert old.engine_info("species_last_build") == 0
+    n = z.shape[0]
+    assert rel_err(rb.debug_tensor("X_embed", (n, 9, 64)), old.debug_tensor("X_embed", (n, 9, 64))) < 5e-6
+    assert rel_err(E, Eo) < 5e-6 and rel_err(F, Fo) < 2e-5, (rel_err(E, Eo), rel_err(F, Fo))

@@ -260,10 +260,12 @@ void set_cell(Graph& g, const tmdnet_model* m, bool on) {
 
 // species count rounded up to 4 / 8 when this call takes the embedding in the radial basis (tn_embed_rb.hip), else 0:
 // dynamic shapes only (the species count is read back with the pair counts), a batch-scale system, at most 8 species
+}  // namespace
 int rb_ntp(const tmdnet_model* m, int64_t n_atoms, int64_t n_pairs) {
-  if (!m->rb_fwd || m->tn2 || m->et || n_pairs < 0 || n_atoms < m->rb_min_atoms) return 0;
+  if (!m->rb_fwd || m->et || n_pairs < 0 || n_atoms < m->rb_min_atoms) return 0;
   return embed_rb_ntp(m->last_nt);
 }
+namespace {
 
 FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, int64_t P, bool bwd, size_t* total, int ntp = 0) {
   Carver c(ws);
@@ -870,7 +872,7 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     }
     m->rb_fwd = m->rb_rev = nullptr;
     const char* env = getenv("TMDNET_EMBED_RB");  // developer switch: 0 keeps the per-pair tables for the embedding
-    if (!(env && atoi(env) == 0) && !m->tn2 && embed_rb_shape_ok(F, K)) {
+    if (!(env && atoi(env) == 0) && embed_rb_shape_ok(F, K)) {
       const size_t nf = embed_rb_image_elems(F, K, false), nr = embed_rb_image_elems(F, K, true);
       std::vector<uint16_t> img(nf + nr);
       embed_rb_images(pk.buf.data() + off.at("Wdp"), pk.buf.data() + off.at("bdp"), F, K, img.data(), img.data() + nf);

@@ -244,6 +244,8 @@ void gemm_dual(hipStream_t s, int kind, const float* A, const float* A2, int64_t
                float* C2, int64_t ldc, int M, int N, int K, const float* rs = nullptr, const float* rs2 = nullptr,
                const uint16_t* Wsb = nullptr);
 Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total);
+// species count rounded up to 4 / 8 when this call takes the embedding in the radial basis (tn_embed_rb.hip), else 0
+int rb_ntp(const tmdnet_model* m, int64_t n_atoms, int64_t n_pairs);
 // the three weight matrices act on the channel axis of the 1 + 3 + 5 irreducible components: one grouped launch, 9 groups
 void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], float* C, int N, int F, int flags = 0, float* pre = nullptr,
                    const float* gates = nullptr);

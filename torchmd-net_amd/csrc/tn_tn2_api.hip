@@ -34,7 +34,7 @@ struct Tn2Buffers {
   float *g_pre3, *g_pre2, *g_pre1, *gCe_slots, *gB, *gCs, *gAp;
 };
 
-Tn2Buffers tn2_carve(void* ws, const tmdnet_model* m, int64_t N, int64_t B, int64_t P, int64_t E, bool bwd, size_t* total) {
+Tn2Buffers tn2_carve(void* ws, const tmdnet_model* m, int64_t N, int64_t B, int64_t P, int64_t E, bool bwd, size_t* total, int ntp) {
   Carver c(ws);
   Tn2Buffers t{};
   FwdBuffers& b = t.b;
@@ -144,6 +144,9 @@ Tn2Buffers tn2_carve(void* ws, const tmdnet_model* m, int64_t N, int64_t B, int6
     t.gCs = c.take<float>(N * F);
     t.gAp = c.take<float>(P1 * F);
   }
+  b.mom = c.take<float>(ntp ? embed_rb_moment_elems(N, ntp, (int)K) : 0);
+  b.gmom = c.take<float>(ntp && bwd ? embed_rb_gmoment_elems(N, ntp, (int)K) : 0);
+  b.ps = c.take<float>(ntp ? P1 * 8 : 0);
   if (total) *total = c.off;
   return t;
 }
@@ -153,7 +156,9 @@ Tn2Buffers tn2_carve(void* ws, const tmdnet_model* m, int64_t N, int64_t B, int6
 int tn2_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int64_t n_edges, int32_t want_forces,
                                 size_t* bytes) {
   if (n_edges < 0) n_edges = (int64_t)m->hp.max_num_neighbors * n_atoms;  // static shapes: the edge capacity
-  tn2_carve(nullptr, m, n_atoms, n_mol, n_pairs, n_edges, want_forces != 0, bytes);
+  const int ntp = rb_ntp(m, n_atoms, n_pairs);
+  if (n_pairs < 0) n_pairs = ((int64_t)m->hp.max_num_neighbors * n_atoms) / 2 + 1;
+  tn2_carve(nullptr, m, n_atoms, n_mol, n_pairs, n_edges, want_forces != 0, bytes, ntp);
   return TMDNET_OK;
 }
 
@@ -169,7 +174,8 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
   const bool static_mode = n_pairs < 0;
   const int64_t E = static_mode ? g.ecap : m->lastE;  // row capacity of the per-edge arrays
   size_t need = 0;
-  Tn2Buffers t = tn2_carve(ws, m, n_atoms, n_mol, P, E, want_forces != 0, &need);
+  const int ntp = rb_ntp(m, n_atoms, n_pairs);  // > 0: embedding in the radial basis (tn_embed_rb.hip), no Q / dQ rows
+  Tn2Buffers t = tn2_carve(ws, m, n_atoms, n_mol, P, E, want_forces != 0, &need, ntp);
   if (need > ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "forward workspace too small: need " + std::to_string(need));
   FwdBuffers& b = t.b;
   const DevParams& W = m->P;
@@ -205,15 +211,17 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
     }
     KR(CAT_EDGE_TABLE, (Pd + 1) * (12 * Fd + 4 * Fd * L) * (bwd ? 2 : 1),
        (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
-        launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1, t0, o0, d0, b.skeys_s, b.svals_s, s, b.C, b.dC),
+        ntp ? (void)0
+            : launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, 1, t0, o0, d0, b.skeys_s, b.svals_s, s, b.C, b.dC),
         L ? launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, F, L, tl.data(), ol.data(), dl.data(), b.skeys_s,
-                               b.svals_s, s, nullptr, nullptr)
+                               b.svals_s, s, ntp ? b.C : nullptr, ntp ? b.dC : nullptr)
           : (void)0));
   } else {
     RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
     KR(CAT_ELEMENTWISE, Pd * (2 * K + 3) * 4, launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s));
     PAIR();
-    if (bwd) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);
+    if (ntp) {
+    } else if (bwd) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);
     else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
     for (int l = 0; l < L; ++l) {
       if (bwd) gemm_dual(s, 0, b.phi, b.dphi, K, T2.layer[l].M1a, W.layer[l].b1, t.Ap[l], t.dAp[l], F, P1, F, K, nullptr, nullptr, nullptr);
@@ -222,7 +230,15 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
   }
 
   // ---- embedding (TensorNet's: tensornet.py:543-619)
-  KR(CAT_SCATTER, Pd * 12 * Fd + Ed * 12 + Nd * 10 * Fd * 4, launch_embed_scatter(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.u0, b.s0n, s));
+  const RadialParams rbp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
+  const double momB = (double)embed_rb_moment_elems(N, ntp ? ntp : 4, K) * 4;
+  if (ntp) {
+    KR(CAT_SCATTER, Ed * 12 + Pd * 48 + momB,
+       (launch_pair_scalars(g, P, hp.cutoff_lower, hp.cutoff_upper, b.ps, s), launch_embed_moments(g, N, rbp, ntp, b.ps, b.mom, s)));
+    KR(CAT_SCATTER, momB + Nd * 10 * Fd * 4, launch_embed_combine(g, N, F, K, ntp, z, W.Utab, W.Vtab, m->rb_fwd, b.mom, b.u0, b.s0n, s));
+  } else {
+    KR(CAT_SCATTER, Pd * 12 * Fd + Ed * 12 + Nd * 10 * Fd * 4, launch_embed_scatter(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.u0, b.s0n, s));
+  }
   KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s));
   NODE();
   gemm(s, b.ln0, F, W.L1, F, W.bL1, b.h1, 2 * F, N, 2 * F, F, GEMM_ACT_SILU, b.a1, 2 * F);
@@ -343,8 +359,12 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
     KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s));
     tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
-    KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
-       launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s));
+    if (ntp) {
+      KR(CAT_PAIR, Nd * 10 * Fd * 4 + momB, launch_embed_gm(g, N, F, K, ntp, z, W.Utab, W.Vtab, m->rb_rev, W.bdp, b.gA, b.gmom, s));
+      KR(CAT_PAIR, Pd * 40 + momB, launch_embed_pair_rb(g, P, N, rbp, ntp, b.ps, b.gmom, b.gd, b.g_rhat, s, nullptr, nullptr, 0, 0));
+    } else
+      KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
+         launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s));
     KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s));
     KR(CAT_ELEMENTWISE, Ed * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
     KR(CAT_ELEMENTWISE, Nd * 24, launch_add_forces(t.fcoul, perm, N, forces, s));
