@@ -1,0 +1,64 @@
+"""-m gpu: every developer switch of the library (`TMDNET_*` environment variables, read once per process) selects a kernel that
+must stay correct - VERDICT r02: "either delete the losing kernel or test it".  The losers of round 2's A/B runs were deleted
+(reverse mode of the LDS-window sweep, tile sweeps, 16-byte row sweeps, two-sweep ET reverse); what is left selects fallbacks that
+other shapes take anyway.  Each combination below runs in a fresh interpreter and checks the reference-generated fixtures
+(tests/golden: C2 batch, tiny model with charges, ET tiny) at the usual 1e-4, plus a static-shape HIP-graph replay."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import os, sys, torch
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "torchmd-net_amd"))
+from torchmdnet_amd import workloads as W
+from torchmdnet_amd.models.model import create_model
+G = os.path.join(ROOT, "tests", "golden")
+def rel(a, b): return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+# C2 model (seed 0) on 64 S-mol64 molecules: the first 4 against the fixture written by the unmodified reference
+g = torch.load(os.path.join(G, "c2_ref.pt"))
+torch.manual_seed(0)
+model = create_model(dict(W.C2_ARGS)).to("cuda")
+z, pos, batch = W.synthetic_batch(n_mol=64)
+E, F = model(z.cuda(), pos.cuda(), batch.cuda())
+n = g["n_mol"]
+assert rel(E[:n].cpu(), g["E"]) < 1e-4 and rel(F[: 64 * n].cpu(), g["F"]) < 1e-4, ("c2", rel(E[:n].cpu(), g["E"]), rel(F[: 64 * n].cpu(), g["F"]))
+# tiny model with charges (small-system kernels) + static shapes + graph replay
+t = torch.load(os.path.join(G, "tiny_ref.pt"))
+for static in (False, True):
+    m = create_model(dict(t["args"], static_shapes=static)); m.load_state_dict(t["state_dict"]); m = m.to("cuda")
+    zc, pc, bc, qc = t["z"].cuda(), t["pos"].cuda(), t["batch"].cuda(), t["q"].cuda()
+    E, F = m(zc, pc, bc, q=qc)
+    assert rel(E.cpu(), t["E"]) < 1e-4 and rel(F.cpu(), t["F"]) < 1e-4, ("tiny", static)
+    if static:
+        r = m.capture(zc, pc, bc, q=qc)
+        E1, F1 = r()
+        assert rel(E1.cpu(), t["E"]) < 1e-4 and rel(F1.cpu(), t["F"]) < 1e-4, "replay"
+# Equivariant Transformer fixture
+e = torch.load(os.path.join(G, "et_tiny_ref.pt"))
+m = create_model(dict(e["args"])); m.load_state_dict(e["state_dict"]); m = m.to("cuda")
+E, F = m(e["z"].cuda(), e["pos"].cuda(), e["batch"].cuda())
+assert rel(E.cpu(), e["E"]) < 1e-4 and rel(F.cpu(), e["F"]) < 1e-4, "et"
+print("SWITCHES_OK")
+"""
+
+COMBOS = {
+    "no-lds-sweep_fp32-mfma_scalar-lanes_direct-gemms": {"TMDNET_NO_MSG_ROWS8": "1", "TMDNET_NO_SPLIT_BF16": "1", "TMDNET_NO_V4": "1",
+                                                        "TMDNET_SCALAR_GRAPH": "1", "TMDNET_EDGE_TABLE": "0"},
+    "pair-form-embedding_separate-pair-gd_no-skinny": {"TMDNET_EMBED_RB": "0", "TMDNET_SEPARATE_PAIR_GD": "1", "TMDNET_NO_SKINNY": "1",
+                                                      "TMDNET_NO_GRAPH_SMALL": "1", "TMDNET_ET_GENERIC_SWEEPS": "1"},
+    "side-stream_table-walk_launch-shapes": {"TMDNET_SIDE_STREAM": "1", "TMDNET_EI_RUN": "3", "TMDNET_EDGE_DIRECT_MAX": "0",
+                                             "TMDNET_SPLIT_ROWS": "0", "TMDNET_GEMM_BPC": "2", "TMDNET_EDGE_TABLE_MIN_PAIRS": "1"},
+}
+
+
+@pytest.mark.parametrize("name", list(COMBOS))
+def test_developer_switch_combination(hip_lib, name):
+    env = dict(os.environ, **COMBOS[name])
+    out = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "SWITCHES_OK" in out.stdout, (name, out.stdout[-500:], out.stderr[-1500:])

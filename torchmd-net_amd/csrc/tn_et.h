@@ -39,10 +39,6 @@ void launch_et_update(const float* x, const float* vec, const float* vp, const f
                       float* vecn, float* vdot, hipStream_t s);
 void launch_et_update_bwd(const float* g_x, const float* g_vec, const float* vp, const float* o, const float* vdot, int N, int F,
                           float* g_o, float* g_vp, hipStream_t s);
-void launch_et_attn_bwd_t(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
-                          float* gd2, float* gr2, hipStream_t s);
-void launch_et_attn_bwd_s(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
-                          float* g_vec, hipStream_t s);
 // both roles of the row atom in one sweep (replaces the two launches above: the per-pair rows are read once per directed edge)
 void launch_et_attn_bwd(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
                         float* g_vec, float* gd2, float* gr2, hipStream_t s);

@@ -353,130 +353,6 @@ __device__ __forceinline__ EtEdge et_edge(const EtAttnArgs& a, float tq, const f
   return r;
 }
 
-// row = target t.  g_q[t,c] ; per edge: g_d and g_rhat (reduced over channels), accumulated into the pair's slot
-// (slot 0: the row atom is the pair's i, slot 1: it is the pair's j; one writer per slot -> deterministic).
-__global__ void k_et_attn_bwd_t(Graph g, EtAttnArgs a, const float* __restrict__ g_xagg, const float* __restrict__ g_vagg,
-                                float* __restrict__ g_qkv, float* __restrict__ gd2, float* __restrict__ gr2) {
-  const int t = xcd_chunk(blockIdx.x, gridDim.x);
-  if (g.counts[2]) return;
-  const int F = a.F, c = threadIdx.x, lane = c & 63, wave = c >> 6;
-  const bool live = c < F;
-  const int cc = live ? c : 0;
-  const int e0 = g.rowptr[t], e1 = g.rowptr[t + 1];
-  const int64_t F5 = 5 * (int64_t)F;
-  const float qt = a.qkv[(int64_t)t * F5 + cc];
-  const float gxa = live ? g_xagg[(int64_t)t * F + cc] : 0.f;
-  const float* gvp = g_vagg + (int64_t)t * 3 * F + cc;
-  const float gv0 = live ? gvp[0] : 0.f, gv1 = live ? gvp[F] : 0.f, gv2 = live ? gvp[2 * F] : 0.f;
-  float gq = 0.f;
-  for (int e = e0; e < e1; ++e) {
-    {
-      const int s = g.col[e], p = g.epair[e];
-      const float sg = g.esign[e];
-      const float* sq = a.qkv + (int64_t)s * F5 + cc;
-      float dk, dvx, dv1, dv2;
-      const EtEdge ed = et_edge(a, qt, sq, p, cc, live, dk, dvx, dv1, dv2);
-      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-      if (sg != 0.f) {
-        r0 = -sg * g.prhat[(int64_t)p * 3];
-        r1 = -sg * g.prhat[(int64_t)p * 3 + 1];
-        r2 = -sg * g.prhat[(int64_t)p * 3 + 2];
-      }
-      const float* vs = a.vec + (int64_t)s * 3 * F + cc;
-      const float g_sx = gxa * ed.A;
-      const float g_A = head_sum(gxa * ed.sx, a.hd);
-      const float g_s1 = gv0 * vs[0] + gv1 * vs[F] + gv2 * vs[2 * F];
-      const float g_s2 = gv0 * r0 + gv1 * r1 + gv2 * r2;
-      const float g_a = g_A * silu_grad(ed.a) * ed.ca;
-      gq += g_a * sq[F] * dk;
-      // tangents of dk / dv: d/dd of the pair quantities (forward mode), so g_d needs no per-pair gradient arrays
-      const int64_t tkv_b = (int64_t)p * a.Wd;
-      const float vxs = sq[2 * F], v1s = sq[3 * F], v2s = sq[4 * F];
-      float gd = 0.f, gcv = 0.f;
-      if (a.dv_off >= 0) gd = ed.cv * (g_sx * vxs * ldpair(a.tkv, tkv_b + (a.dv_off + cc), a.pair_bf16) + g_s1 * v1s * ldpair(a.tkv, tkv_b + (a.dv_off + F + cc), a.pair_bf16) + g_s2 * v2s * ldpair(a.tkv, tkv_b + (a.dv_off + 2 * F + cc), a.pair_bf16));
-      if (a.dk_off >= 0) gd += g_a * qt * sq[F] * ldpair(a.tkv, tkv_b + (a.dk_off + cc), a.pair_bf16);
-      gcv = g_sx * vxs * dvx + g_s1 * v1s * dv1 + g_s2 * v2s * dv2;
-      // cutoff factor: on the values (g_cv) or on the attention weight (g_ca = sum_h g_A silu(a); one lane per head adds it)
-      const float gca = ((cc % a.hd) == 0) ? g_A * silu(ed.a) : 0.f;
-      gd += (a.vector_cutoff ? gcv : gca) * a.dC[p];
-      if (!live) gd = 0.f;
-      // per-edge totals over the channels of THIS wave; every wave owns its slot (wave, pair, direction): one writer per
-      // slot and a fixed order in k_et_pair_combine -> deterministic, no LDS round trip, no barrier
-      const float tot = wave_sum4(gd, live ? gv0 * ed.s2 : 0.f, live ? gv1 * ed.s2 : 0.f, live ? gv2 * ed.s2 : 0.f, lane);
-      if (sg != 0.f && (lane & 15) == 0) {  // self edges: d = 0 and rhat = 0 carry no position dependence
-        const int64_t slot = (int64_t)wave * a.slot_stride + 2 * (int64_t)p + (sg > 0.f ? 0 : 1);
-        const int comp = lane >> 4;
-        if (comp == 0) gd2[slot] = tot;   // plain stores: the slot arrays are per (layer, wave)
-        else gr2[slot * 3 + comp - 1] = tot;
-      }
-    }
-  }
-  if (live) g_qkv[(int64_t)t * F5 + c] = gq;
-}
-void launch_et_attn_bwd_t(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
-                          float* gd2, float* gr2, hipStream_t s) {
-  if (N <= 0) return;
-  hipLaunchKernelGGL(k_et_attn_bwd_t, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, g_xagg, g_vagg, g_qkv, gd2, gr2);
-}
-
-// row = source s: g_k[s], g_vx/v1/v2[s] and g_vec[s] += sum over the targets t of s
-__global__ void k_et_attn_bwd_s(Graph g, EtAttnArgs a, const float* __restrict__ g_xagg, const float* __restrict__ g_vagg,
-                                float* __restrict__ g_qkv, float* __restrict__ g_vec) {
-  const int s = xcd_chunk(blockIdx.x, gridDim.x);
-  if (g.counts[2]) return;
-  const int F = a.F, c = threadIdx.x;
-  const bool live = c < F;
-  const int cc = live ? c : 0;
-  const int e0 = g.rowptr[s], e1 = g.rowptr[s + 1];
-  const int64_t F5 = 5 * (int64_t)F;
-  const float* sq = a.qkv + (int64_t)s * F5 + cc;
-  const float* vs = a.vec + (int64_t)s * 3 * F + cc;
-  const float vs0 = vs[0], vs1 = vs[F], vs2 = vs[2 * F];
-  float gk = 0.f, gvx = 0.f, gv1s = 0.f, gv2s = 0.f, gvec0 = 0.f, gvec1 = 0.f, gvec2 = 0.f;
-  for (int e = e0; e < e1; ++e) {
-    const int t = g.col[e], p = g.epair[e];
-    const float sg = g.esign[e];
-    const float qt = a.qkv[(int64_t)t * F5 + cc];
-    float dk, dvx, dv1, dv2;
-    const EtEdge ed = et_edge(a, qt, sq, p, cc, live, dk, dvx, dv1, dv2);
-    // rhat(t <- s) = (pos_s - pos_t)/d = +esign * prhat when the ROW atom is the source
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    if (sg != 0.f) {
-      r0 = sg * g.prhat[(int64_t)p * 3];
-      r1 = sg * g.prhat[(int64_t)p * 3 + 1];
-      r2 = sg * g.prhat[(int64_t)p * 3 + 2];
-    }
-    const float gxa = live ? g_xagg[(int64_t)t * F + cc] : 0.f;
-    const float* gvp = g_vagg + (int64_t)t * 3 * F + cc;
-    const float gv0 = gvp[0], gv1 = gvp[F], gv2 = gvp[2 * F];
-    const float g_A = head_sum(gxa * ed.sx, a.hd);
-    const float g_a = g_A * silu_grad(ed.a) * ed.ca;
-    gk += g_a * qt * dk;
-    gvx += gxa * ed.A * ed.cv * dvx;
-    gv1s += (gv0 * vs0 + gv1 * vs1 + gv2 * vs2) * ed.cv * dv1;
-    gv2s += (gv0 * r0 + gv1 * r1 + gv2 * r2) * ed.cv * dv2;
-    gvec0 += gv0 * ed.s1;
-    gvec1 += gv1 * ed.s1;
-    gvec2 += gv2 * ed.s1;
-  }
-  if (live) {
-    float* o = g_qkv + (int64_t)s * F5 + c;
-    o[F] = gk;
-    o[2 * F] = gvx;
-    o[3 * F] = gv1s;
-    o[4 * F] = gv2s;
-    float* gv = g_vec + (int64_t)s * 3 * F + c;
-    gv[0] += gvec0;
-    gv[F] += gvec1;
-    gv[2 * F] += gvec2;
-  }
-}
-void launch_et_attn_bwd_s(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
-                          float* g_vec, hipStream_t s) {
-  if (N <= 0) return;
-  hipLaunchKernelGGL(k_et_attn_bwd_s, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec);
-}
-
 // Both roles of the row atom r in ONE sweep (the per-pair rows dkv / tkv are then read once per directed edge instead of
 // twice): as TARGET of the message j -> r (g_q[r], the per-edge scalars g_d, g_rhat) and as SOURCE of the message r -> j
 // (g_k[r], g_v[r], g_vec[r]).  rhat(r <- j) = -esign * prhat, rhat(j <- r) = +esign * prhat.

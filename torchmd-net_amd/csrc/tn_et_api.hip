@@ -544,15 +544,9 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
       gemm(s, b.g_o, 3 * F, q.WoT, 3 * F, nullptr, b.g_xagg, F, N, F, 3 * F);
       // g_vagg = g_vec (read by both sweeps before sweep "s" adds the source terms into it: snapshot in vagg)
       KR(CAT_ELEMENTWISE, Nd * Fd * 24, launch_et_copy2d(b.g_vec, 3 * F, b.vagg, 3 * F, N, 3 * F, s));
-      static const bool two_sweeps = getenv("TMDNET_ET_TWO_SWEEPS") != nullptr;  // developer switch: target / source sweeps apart
-      if (two_sweeps) {
-        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * pB + Nd * Fd * 4 * 17 + Ed * 12 + (Pd + 1) * 32 * nwv, launch_et_attn_bwd_t(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
-        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * pB + Nd * Fd * 4 * 18 + Ed * 12, launch_et_attn_bwd_s(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, s));
-      } else {
-        // dkv + tkv, qkv, vec, g_xagg, g_vagg in; g_qkv out, g_vec read + written; the (pair, direction) slots of g_d, g_rhat
-        KR(CAT_PAIR, 2 * (Pd + 1) * Wd * pB + Nd * Fd * 4 * 23 + Ed * 12 + (Pd + 1) * 32 * nwv,
-           launch_et_attn_bwd(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
-      }
+      // dkv + tkv, qkv, vec, g_xagg, g_vagg in; g_qkv out, g_vec read + written; the (pair, direction) slots of g_d, g_rhat
+      KR(CAT_PAIR, 2 * (Pd + 1) * Wd * pB + Nd * Fd * 4 * 23 + Ed * 12 + (Pd + 1) * 32 * nwv,
+         launch_et_attn_bwd(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
       gemm(s, b.g_vp, 3 * F, q.WvpT, 3 * F, nullptr, b.g_vec, F, 3 * N, F, 3 * F, GEMM_ACCUM);
       gemm(s, b.g_qkv, 5 * F, q.WqkvT, 5 * F, nullptr, b.g_xt, F, N, F, 5 * F);
       KR(CAT_ELEMENTWISE, Nd * Fd * 16, launch_layernorm_bwd(b.g_xt, b.xh[l], b.rstd[l], q.ln_w, N, F, b.g_ln, s));

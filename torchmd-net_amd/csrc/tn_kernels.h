@@ -190,26 +190,12 @@ void launch_embed_pair_rb(const Graph& g, int Pcap, int N, RadialParams rp, int 
 void launch_interp_list(const float* tab, const double* dist, int M, int R, int T, float lo, float up, float* out, float* dout,
                         hipStream_t s);
 
-// ---- pair-major LDS-staged sweeps (tn_message_pair.hip): every per-pair row is read from HBM once per tile
+// ---- LDS-staged forward sweep (tn_message_pair.hip): 8 lanes per row x 16 bytes per lane, the tile's source window in LDS
 bool message_pair_ok(int N, int F);
-int message_pair_slots(int F);
 void launch_message_pair(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
                          int o3, float* Mi, float* Ch, hipStream_t s);
-void launch_message_pair_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi,
-                                    const float* Pn, float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
 
-// ---- LDS-staged tile sweeps (tn_message_tile.hip), selected by launch_message / launch_message_adjoint when message_tile_ok(F)
-bool message_tile_ok(int N, int F);
-void launch_message_tile(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
-                         int o3, float* Mi, float* Ch, hipStream_t s);
-void launch_message_adjoint_tile(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);
-
-// ---- 16-byte-per-lane variants (tn_gather.hip), selected by the launchers above when gather_v4_ok(F)
+// 16-byte-per-lane form of the per-pair kernels (tn_pairgrad.hip)
 bool gather_v4_ok(int F);
-void launch_message_v4(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
-                       int o3, float* Mi, float* Ch, hipStream_t s);
-void launch_message_adjoint_v4(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);
-void launch_embed_scatter_v4(const Graph& g, int N, int F, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
-                             const float* C, float* u0, float* s0n, hipStream_t s);
 
 }  // namespace tn

@@ -414,10 +414,6 @@ static int embed_split_rows() {
   }();
   return v;
 }
-static bool sweep_v4() {
-  static const bool on = getenv("TMDNET_V4_SWEEP") != nullptr;  // developer switch (profiles/r01_notes.md)
-  return on;
-}
 // block = one atom, thread = channel.  I0 = sum W0 ; v = sum W1 r ; T = sum W2 r r^T ; u0 = (I0, v, T - tr(T)/3)
 __global__ void k_embed_scatter(Graph g, int N, int F, const int64_t* __restrict__ z, const float* __restrict__ Utab,
                                 const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ C,
@@ -538,7 +534,6 @@ void launch_embed_scatter(const Graph& g, int N, int F, const int64_t* z, const 
     hipLaunchKernelGGL(k_embed_scatter_split, dim3(N), dim3(kES * F), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
     return;
   }
-  if (sweep_v4() && gather_v4_ok(F)) return launch_embed_scatter_v4(g, N, F, z, Utab, Vtab, Q, C, u0, s0n, s);
   hipLaunchKernelGGL(k_embed_scatter, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, z, Utab, Vtab, Q, C, u0, s0n);
 }
 
@@ -829,8 +824,6 @@ void launch_message(const Graph& g, int N, int F, const float* w, const float* s
   // order has windows of hundreds of rows: there the row kernel with four edges in flight is faster (10 k-atom box:
   // 0.36 -> 0.26 ms per sweep)
   if (g.small_mols && message_pair_ok(N, F)) return launch_message_pair(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
-  if (g.small_mols && message_tile_ok(N, F)) return launch_message_tile(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
-  if (sweep_v4() && gather_v4_ok(F)) return launch_message_v4(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
   hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
 }
 
@@ -918,13 +911,7 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
   for (int c = 0; c < 9; ++c) o[c * F] += acc[c];
 }
 bool message_adjoint_gd_ok(int N, int F) { return F % 64 == 0 && (split_rows_ok(N, F) || (N > kSplitRows && F <= 1024)); }
-// the 16-byte-per-lane layout (tn_message_pair.hip) wins for the forward sweep only: the reverse sweep carries twice the
-// per-lane state (216 VGPRs, one block per CU) and measured 340 vs 307 us at C2 (profiles/r02_notes.md); opt-in
-static bool adjoint_rows8(int N, int F) {
-  static const bool on = getenv("TMDNET_MSG_ROWS8_ADJOINT") != nullptr;
-  return on && !split_rows_ok(N, F) && message_pair_ok(N, F);
-}
-int message_adjoint_gd_waves(int N, int F) { return adjoint_rows8(N, F) ? message_pair_slots(F) : F / 64; }
+int message_adjoint_gd_waves(int N, int F) { return F / 64; }
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
   if (N <= 0) return;
@@ -933,7 +920,6 @@ void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, con
                        slots, slot_stride);
     return;
   }
-  if (adjoint_rows8(N, F)) return launch_message_pair_adjoint_gd(g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, s);
   hipLaunchKernelGGL(k_message_adjoint_gd, dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride);
 }
 
@@ -943,11 +929,6 @@ void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const 
     hipLaunchKernelGGL((k_message_split<1>), dim3(N), dim3(kEG * F), 0, s, g, N, F, w, gMi, nullptr, nullptr, 0, nullptr, gPn);
     return;
   }
-  // the LDS-staged tile sweep is slower for the adjoint (read-modify-write of gPn; 231 vs 204 us at C2,
-  // profiles/r01_notes.md), so it is opt-in here
-  static const bool tile_adj = getenv("TMDNET_MSG_TILE_ADJOINT") != nullptr;
-  if (tile_adj && message_tile_ok(N, F)) return launch_message_adjoint_tile(g, N, F, w, gMi, gPn, s);
-  if (sweep_v4() && gather_v4_ok(F)) return launch_message_adjoint_v4(g, N, F, w, gMi, gPn, s);
   hipLaunchKernelGGL(k_message_adjoint, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, gMi, gPn);
 }
 

@@ -17,9 +17,8 @@
 // deterministic, no atomics.  A tile whose column window is wider than 64 rows (large systems in cell order, ragged
 // molecules straddling the tile) gathers its sources from global memory instead of LDS; the choice is block-uniform.
 //
-// MODE 0: forward message + group product + normalisation -> Mi, Ch
-// MODE 1: reverse: gPn[i] += sum_e w * gMi[j], and the layer's distance-gradient halves
-//         h(i <- j) = sum_f dw[p] . (gMi[j] * Pn[i]) -> slots[channel chunk][2 p + direction]   (see k_message_adjoint_gd)
+// Forward message + group product + normalisation -> Mi, Ch.  (A reverse mode of this layout existed in round 2: 216 VGPRs, one
+// block per CU, 333 - 340 us against 304 for the row kernel k_message_adjoint_gd; removed, profiles/r02_notes.md.)
 #include <cstdlib>
 
 #include "tn_common.h"
@@ -39,20 +38,16 @@ template <> struct VecOf<4> { typedef f4v T; };
 template <> struct VecOf<2> { typedef f2v T; };
 
 __device__ __forceinline__ f4v ldg4(const float* p) { return *reinterpret_cast<const f4v*>(p); }
-__device__ __forceinline__ float hsum(f4v v) { return (v.x + v.y) + (v.z + v.w); }
-__device__ __forceinline__ float hsum(f2v v) { return v.x + v.y; }
 
 // LPR lanes own a row, VW channels per lane (LPR * VW = 32 channels per block).  8 x 4: 512 threads, 16-byte accesses, the
 // fewest instructions per channel - but the reverse sweep's per-lane state (two 9-vectors, weights and their derivatives
 // two edges ahead) is then 216 VGPRs = two waves per SIMD, too few to cover the loads.  16 x 2: 1024 threads, 8-byte
 // accesses, half the state per lane (four waves per SIMD in one block per CU).
-template <int MODE, int LPR, int VW>
+template <int LPR, int VW>
 __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int F, const float* __restrict__ w,
-                                                                const float* __restrict__ dw, const float* __restrict__ src,
-                                                                const float* __restrict__ Pn, const float* __restrict__ q,
+                                                                const float* __restrict__ src, const float* __restrict__ q,
                                                                 const int64_t* __restrict__ batch, int o3,
-                                                                float* __restrict__ Mi, float* __restrict__ out,
-                                                                float* __restrict__ slots, int64_t slot_stride, int nchunks) {
+                                                                float* __restrict__ Mi, float* __restrict__ out, int nchunks) {
   constexpr int MP_FC = VW * LPR, MP_THREADS = 64 * LPR, PIECES = MP_FC / 4;
   typedef typename VecOf<VW>::T vf;
   auto ldv = [](const float* p) { return *reinterpret_cast<const vf*>(p); };
@@ -124,14 +119,9 @@ __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int 
   const bool live = i < r1;
   const int e0 = live ? g.rowptr[i] : 0, e1 = live ? g.rowptr[i + 1] : 0;
   const int grp = lane & ~(LPR - 1);  // first lane of this row's group within the wave
-  vf acc[9], y[9];
+  vf acc[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) acc[c] = y[c] = (vf)(0.f);
-  if (MODE == 1 && live) {
-    const float* yp = Pn + (int64_t)i * F9 + f;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) y[c] = ldv(yp + c * F);
-  }
+  for (int c = 0; c < 9; ++c) acc[c] = (vf)(0.f);
 
   // the 8 rows of a wave advance together: trip count = the longest of them (a row past its end adds zeros)
   int nmax = e1 - e0;
@@ -144,7 +134,7 @@ __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int 
     const int n = min(LPR, nmax - eb);
     for (int k = 0; k < n; k += MP_U) {
       int jj[MP_U], pp[MP_U];
-      vf wv[MP_U][3], dv[MP_U][3];
+      vf wv[MP_U][3];
       float msk[MP_U];
 #pragma unroll
       for (int u = 0; u < MP_U; ++u) {
@@ -157,12 +147,6 @@ __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int 
         wv[u][0] = ldv(wp);
         wv[u][1] = ldv(wp + F);
         wv[u][2] = ldv(wp + 2 * F);
-        if (MODE == 1) {
-          const float* dp = dw + (int64_t)pp[u] * F3 + f;
-          dv[u][0] = ldv(dp);
-          dv[u][1] = ldv(dp + F);
-          dv[u][2] = ldv(dp + 2 * F);
-        }
       }
 #pragma unroll
       for (int u = 0; u < MP_U; ++u) {
@@ -186,29 +170,12 @@ __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int 
         acc[6] += w2 * s9[6];
         acc[7] += w2 * s9[7];
         acc[8] += w2 * s9[8];
-        if (MODE == 1) {
-          const vf hv = dv[u][0] * (s9[0] * y[0]) + dv[u][1] * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
-                         dv[u][2] * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
-          float h = hsum(hv);
-          h = row_sum(h, LPR);  // the row's lanes = its 32 channels in this block
-          const bool valid = msk[u] != 0.f;
-          if (ql == 0 && valid && jj[u] != i)
-            slots[(int64_t)chunk * slot_stride + 2 * (int64_t)pp[u] + (jj[u] < i ? 0 : 1)] = h;
-        }
       }
     }
   }
   if (!live) return;
 
   float* o = out + (int64_t)i * F9 + f;
-  if (MODE == 1) {
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      const vf prev = ldv(o + c * F);
-      *reinterpret_cast<vf*>(o + c * F) = prev + acc[c];
-    }
-    return;
-  }
   vf yy[9];  // the row's own source row; overwritten component by component with the result
   if (staged && i >= lo && i <= hi) {  // the row's own source row is in its window whenever it has a self edge
     const float* yp = win + (i - lo) * (9 * MP_FC) + VW * ql;
@@ -243,40 +210,15 @@ __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int 
   for (int c = 0; c < 9; ++c) *reinterpret_cast<vf*>(o + c * F) = yy[c];
 }
 
-static int env_layout(const char* name, int dflt) {  // 8 (lanes per row, x 4 channels) or 16 (x 2 channels)
-  const char* e = getenv(name);
-  const int x = e ? atoi(e) : dflt;
-  return x == 16 ? 16 : 8;
-}
-
 bool message_pair_ok(int N, int F) {
   static const bool off = getenv("TMDNET_NO_MSG_ROWS8") != nullptr;  // developer switch: one-channel-per-lane sweeps
   if (off || F < MP_FC || F % MP_FC) return false;
   return (int64_t)((N + MP_TA - 1) / MP_TA) * (F / MP_FC) >= 512;
 }
-int message_pair_slots(int F) { return F / MP_FC; }
-
 void launch_message_pair(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
                          int o3, float* Mi, float* Ch, hipStream_t s) {
-  static const int lpr = env_layout("TMDNET_MSG_LPR", 8);
   const int nchunks = F / MP_FC, tiles = (N + MP_TA - 1) / MP_TA;
-  if (lpr == 16)
-    hipLaunchKernelGGL((k_message_rows8<0, 16, 2>), dim3(tiles * nchunks), dim3(1024), 0, s, g, N, F, w, nullptr, src, nullptr, q, batch,
-                       o3, Mi, Ch, nullptr, 0, nchunks);
-  else
-    hipLaunchKernelGGL((k_message_rows8<0, 8, 4>), dim3(tiles * nchunks), dim3(512), 0, s, g, N, F, w, nullptr, src, nullptr, q, batch, o3,
-                       Mi, Ch, nullptr, 0, nchunks);
-}
-void launch_message_pair_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi,
-                                    const float* Pn, float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
-  static const int lpr = env_layout("TMDNET_MSG_LPR_ADJOINT", 16);
-  const int nchunks = F / MP_FC, tiles = (N + MP_TA - 1) / MP_TA;
-  if (lpr == 16)
-    hipLaunchKernelGGL((k_message_rows8<1, 16, 2>), dim3(tiles * nchunks), dim3(1024), 0, s, g, N, F, w, dw, gMi, Pn, nullptr, nullptr, 0,
-                       nullptr, gPn, slots, slot_stride, nchunks);
-  else
-    hipLaunchKernelGGL((k_message_rows8<1, 8, 4>), dim3(tiles * nchunks), dim3(512), 0, s, g, N, F, w, dw, gMi, Pn, nullptr, nullptr, 0,
-                       nullptr, gPn, slots, slot_stride, nchunks);
+  hipLaunchKernelGGL((k_message_rows8<8, 4>), dim3(tiles * nchunks), dim3(512), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, nchunks);
 }
 
 }  // namespace tn

@@ -5,12 +5,22 @@
 //     g_w[p,k,f] = sum_{c in k} gM[i,c,f] P[j,c,f] + gM[j,c,f] P[i,c,f]                   
 // so the reverse pass of the edge side is pure gather + reduce: no edge GEMM, no g_w array in HBM.  Channel sums
 // are wave-level xor-shuffle reductions inside the lanes that own a pair (16 bytes per lane when F allows it).
+#include <cstdlib>
+
 #include "tn_common.h"
 #include "tn_kernels.h"
 
 namespace tn {
 
 static inline int cdivp(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// 16-byte-per-lane form of the per-pair kernels: F % 4 == 0, F / 4 a power of two <= 64 (else one channel per lane)
+bool gather_v4_ok(int F) {
+  static const bool off = getenv("TMDNET_NO_V4") != nullptr;  // developer switch: force the scalar kernels
+  if (off || (F & 3)) return false;
+  const int f4 = F >> 2;
+  return f4 >= 1 && f4 <= 64 && (f4 & (f4 - 1)) == 0;
+}
 static inline int fthreads_p(int F) {
   int t = ((F + 63) / 64) * 64;
   return t > 256 ? 256 : t;
