@@ -46,7 +46,7 @@ SPLIT_PRODUCTS = 6
 # HIP kernels behind each profiled class (rocprofv3 names, profiles/r02_kernel_stats*.csv)
 KERNEL_OF = {"gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_sb1", "message": "k_message_rows8 / k_message_adjoint_gd",
              "edge_table": "k_edge_interp (+ k_pair_cutoff_hist, k_bucket_scan, k_bucket_scatter)",
-             "pair_bwd": "k_embed_pair_gd_v4 / k_geom_gd", "embed_scatter": "k_embed_scatter", "elementwise": "elementwise",
+             "pair_bwd": "k_embed_gm / k_embed_pair_rb8", "embed_scatter": "k_embed_moments / k_embed_combine", "elementwise": "elementwise",
              "graph": "k_nbr_wave / k_scan_counts"}
 
 
@@ -161,12 +161,12 @@ def pmc_kernel_bytes(pmc, cls, label):
     per = pmc.get("_per_kernel_total", {})
     head = label.split(" ")[0].split("(")[0]
     names = {"gemm_dual<2>": ["k_edge_mlp", "k_gemm_dual_sb2<2>"], "gemm_dual<0>": ["k_gemm_dual_sb2<0>"],
-             "launch_message": ["k_message_rows8<0, 8, 4>", "k_message_rows8<0, 16, 2>", "k_message_rows8<0>", "k_message_tile<0, 0>",
-                                "k_message_tile<0>"],
-             "launch_message_adjoint_gd": ["k_message_rows8<1, 16, 2>", "k_message_rows8<1, 8, 4>", "k_message_rows8<1>",
-                                           "k_message_adjoint_gd"],
+             "launch_message": ["k_message_rows8<8, 4>", "k_message"],
+             "launch_message_adjoint_gd": ["k_message_adjoint_gd"],
              "launch_edge_tables": ["k_edge_interp<3>", "k_edge_interp<2>", "k_edge_interp<4>", "k_edge_interp<1>"],
-             "launch_embed_scatter": ["k_embed_scatter"], "launch_embed_pair_gd": ["k_embed_pair_gd_v4"]}.get(head, [])
+             "launch_embed_scatter": ["k_embed_scatter"], "launch_embed_pair_gd": ["k_embed_pair_gd_v4"],
+             "launch_embed_combine": ["k_embed_combine<4, 2>"], "launch_embed_gm": ["k_embed_gm<4, 1, 8>"],
+             "launch_embed_pair_rb": ["k_embed_pair_rb8<4, 4>"]}.get(head, [])
     for n in names:
         if n in per:
             return per[n], n

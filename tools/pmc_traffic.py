@@ -24,7 +24,8 @@ import re
 CLASS_OF = [(r"k_gemm_dual", "gemm_edge"), (r"k_edge_mlp", "gemm_edge"), (r"k_gemm_(nt|skinny|sb1)", "gemm_node"),
             (r"k_message(_tile|_rows8|_adjoint|_adjoint_gd|_split)?(<.*>)?$", "message"),
             (r"k_(edge_interp|pair_cutoff_hist|bucket_scan|bucket_scatter)", "edge_table"),
-            (r"k_(pair_gd|embed_pair_gd|geom_gd)", "pair_bwd"), (r"k_embed_scatter", "embed_scatter")]
+            (r"k_(pair_gd|embed_pair_gd|geom_gd|embed_gm|embed_pair_rb)", "pair_bwd"),
+            (r"k_embed_(scatter|moments|combine)", "embed_scatter")]
 
 
 def read_counter(dirname, counter):
