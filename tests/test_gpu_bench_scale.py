@@ -145,3 +145,49 @@ def test_nonperiodic_30k_atoms_through_the_cell_list(hip_lib):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     Er, Fr = CO.energy_forces(sd, T.hparams_from_args(args), z, pos, batch)
     assert rel_err(Ec.cpu(), Er) < REL and rel_err(Fc.cpu(), Fr) < REL
+
+
+@pytest.mark.parametrize("periodic", [True, False])
+def test_several_large_molecules_through_the_cell_list(hip_lib, periodic):
+    """Three 1536-atom systems that OVERLAP in space (same lattice, different jitter), in one common box or none: the model's
+    cell list bins all atoms in one grid, atoms of different molecules are interleaved in cell order, pairs stay inside a
+    molecule (reference: one `box` for the whole batch, models/utils.py:233-313).  Same numbers as the brute-force sweep inside
+    each molecule, per-molecule energies / charges included; every molecule against the oracle."""
+    from oracle import tensornet_c as CO, tensornet_torch as T
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(4)
+    args = dict(W.TINY_ARGS, max_num_neighbors=96)
+    model = create_model(dict(args)).to("cuda")
+    zs, ps, bs = [], [], []
+    for m in range(3):
+        z, pos, box = W.water_box(n_side=8, spacing=3.1, seed=10 + m)
+        zs.append((z + m) % 19 + 1)
+        ps.append(pos + 0.4 * m)
+        bs.append(torch.full_like(z, m))
+    z, pos, batch = torch.cat(zs), torch.cat(ps), torch.cat(bs)
+    q = torch.tensor([1.0, 0.0, -2.0])
+    kw = dict(box=box.cuda()) if periodic else {}
+    zc, pc, bc = z.cuda(), pos.cuda(), batch.cuda()
+    Ec, Fc = model(zc, pc, bc, q=q.cuda(), **kw)
+    assert model.cell_grid(z.shape[0], 3)[3] == 1, "the cell list ran for several molecules"
+    counts = model._engine.counts[:2]
+    Ec2, Fc2 = model(zc, pc.clone(), bc, q=q.cuda(), **kw)
+    assert torch.equal(Ec, Ec2) and torch.equal(Fc, Fc2)
+    model.cell_list_min_atoms = 10 ** 9
+    Eb, Fb = model(zc, pc.clone(), bc, q=q.cuda(), **kw)
+    assert model.cell_grid(z.shape[0], 3)[3] == 0 and model._engine.counts[:2] == counts
+    assert rel_err(Ec, Eb) < 1e-5 and rel_err(Fc, Fb) < 2e-5
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hp = T.hparams_from_args(args)
+    for m in range(3):
+        sel = batch == m
+        Er, Fr = CO.energy_forces(sd, hp, z[sel], pos[sel], torch.zeros(int(sel.sum()), dtype=torch.long), box=box if periodic else None,
+                                  q=q[m:m + 1])
+        assert rel_err(Ec[m].cpu().reshape(1, 1), Er) < REL and rel_err(Fc[sel.cuda()].cpu(), Fr) < REL, m
+    # an out-of-range molecule index is reported like on the brute-force path
+    model.cell_list_min_atoms = 1024
+    bad = bc.clone()
+    bad[5] = 7
+    with pytest.raises(RuntimeError):
+        model(zc, pc.clone(), bad, q=q.cuda(), num_systems=3, **kw)

@@ -229,6 +229,7 @@ Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   g.boxd = c.take<float>(12);
   g.cgrid = c.take<int>(4);
   g.bat_s = c.take<int>(N);
+  g.bat_c = c.take<int64_t>(N);
   g.z_c = c.take<int64_t>(N);
   g.tix = c.take<int>(N);
   g.tz = c.take<int>(64);
@@ -238,20 +239,22 @@ Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   return g;
 }
 
-// the cell list applies to ONE system: periodic in one box (orthorhombic or reduced triclinic), or non-periodic (box_mode 0:
-// a fictitious orthorhombic box around the bounding box of the positions, as the reference does with a fixed box,
-// models/utils.py:206-212); batches of molecules take the brute-force sweep inside each molecule.
+// the cell list applies to systems that share ONE grid: one system or several molecules, periodic in one common box
+// (orthorhombic or reduced triclinic) or non-periodic (box_mode 0: a fictitious orthorhombic box around the bounding box of
+// ALL positions, as the reference does with a fixed box, models/utils.py:206-212); per-molecule boxes (box_mode 2) have no
+// common grid and take the brute-force sweep inside each molecule.  The host asks for it (tmdnet_set_cell_grid) when the
+// molecules are large on average; several molecules are interleaved in cell order and pairs stay inside a molecule.
 // cell_n < 0: the grid is computed on the device from the current box / bounding box on every call (tn_cell.hip).
 namespace {
 bool cell_applicable(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int box_mode) {
   const int* n = m->cell_n;
-  if (n_mol != 1 || box_mode == 2 || n_atoms < 1) return false;
+  if (n_mol < 1 || box_mode == 2 || n_atoms < 1) return false;
   if (n[0] < 0) return true;
   if (n[0] < 1 || n[1] < 1 || n[2] < 1) return false;
   return (int64_t)n[0] * n[1] * n[2] <= 8 * n_atoms;
 }
-void set_cell(Graph& g, const tmdnet_model* m, bool on) {
-  g.use_cell = on ? 1 : 0;
+void set_cell(Graph& g, const tmdnet_model* m, bool on, int64_t n_mol = 1) {
+  g.use_cell = on ? (n_mol > 1 ? 2 : 1) : 0;
   const bool explicit_grid = m->cell_n[0] > 0;
   g.ncx = explicit_grid ? m->cell_n[0] : 0;
   g.ncy = explicit_grid ? m->cell_n[1] : 0;
@@ -956,8 +959,9 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   if (need > graph_ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "graph workspace too small");
   if (box_mode != 0 && !box) return fail(m, TMDNET_ERR_INVALID, "box_mode != 0 needs a box");
   const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
-  set_cell(g, m, cell);
+  set_cell(g, m, cell, n_mol);
   m->graph_is_cell = cell;
+  m->graph_cell_multi = cell && n_mol > 1;
   m->graph_has_z = z != nullptr;
   m->g_pos = pos;
   m->g_box = box;
@@ -967,7 +971,8 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
     if (cell) {
       launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
-      launch_cell_phase1(g, pos, batch, box_mode == 1 ? box : nullptr, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+      launch_cell_phase1(g, pos, batch, box_mode == 1 ? box : nullptr, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s,
+                         (int)n_mol);
       launch_scan_counts(g, (int)n_atoms, s);
     } else {
       launch_graph_build_phase1(g, pos, batch, box, box_mode, (int)n_atoms, (int)n_mol, m->hp.cutoff_lower, m->hp.cutoff_upper,
@@ -1013,8 +1018,9 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
   if (need > graph_ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "graph workspace too small");
   if (box_mode != 0 && !box) return fail(m, TMDNET_ERR_INVALID, "box_mode != 0 needs a box");
   const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
-  set_cell(g, m, cell);
+  set_cell(g, m, cell, n_mol);
   m->graph_is_cell = cell;
+  m->graph_cell_multi = cell && n_mol > 1;
   m->graph_has_z = z != nullptr;
   m->g_pos = pos;
   m->g_box = box;
@@ -1024,7 +1030,8 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
     ProfScope ps_(s, CAT_GRAPH, 0.0, (double)n_atoms * 20);
     if (cell) {
       launch_fill(reinterpret_cast<float*>(g.counts), 0.f, 8, s);
-      launch_cell_phase1(g, pos, batch, box_mode == 1 ? box : nullptr, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
+      launch_cell_phase1(g, pos, batch, box_mode == 1 ? box : nullptr, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s,
+                         (int)n_mol);
       launch_scan_counts(g, (int)n_atoms, s);
       launch_cell_phase2(g, (int)n_atoms, m->hp.cutoff_lower, m->hp.cutoff_upper, true, s);
       launch_nbr_link_wave(g, (int)n_atoms, s);
@@ -1098,13 +1105,14 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   const int64_t ecap = (int64_t)hp.max_num_neighbors * n_atoms;
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, nullptr);
   if (n_pairs > g.pcap) return fail(m, TMDNET_ERR_INVALID, "n_pairs out of range");
+  if (m->graph_is_cell && m->graph_cell_multi) batch = g.bat_c;  // several molecules renumbered in cell order: their internal batch
   if (m->et) {
     if (q) return fail(m, TMDNET_ERR_INVALID, "the Equivariant Transformer takes no total charge (reference torchmd_et.py:188-196)");
     CurScope cur_(m);
     if (m->graph_has_z) {  // validated + renumbered by the graph phase
       z = g.z_c;
     } else if (m->graph_is_cell) {
-      set_cell(g, m, true);
+      set_cell(g, m, true, n_mol);
       launch_permute_z(g, z, (int)n_atoms, s);
       z = g.z_s;
     }
@@ -1116,12 +1124,12 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     if (m->graph_has_z) {
       z = g.z_c;
     } else if (m->graph_is_cell) {
-      set_cell(g, m, true);
+      set_cell(g, m, true, n_mol);
       launch_permute_z(g, z, (int)n_atoms, s);
       z = g.z_s;
     }
     if (!z) return fail(m, TMDNET_ERR_INVALID, "z is required (here or in tmdnet_build_graph)");
-    if (m->graph_is_cell) set_cell(g, m, true);
+    if (m->graph_is_cell) set_cell(g, m, true, n_mol);
     return tn2_energy_forces(m, s, g, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, q, want_forces, energy, forces);
   }
   // n_pairs >= 0: exact count read back by tmdnet_build_graph (launch grids sized exactly);
@@ -1137,7 +1145,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   CurScope cur_(m);
   const int* perm = nullptr;
   if (m->graph_is_cell) {  // the graph lives in cell order: renumber z here, scatter the forces back at the end
-    set_cell(g, m, true);
+    set_cell(g, m, true, n_mol);
     if (!m->graph_has_z) {
       launch_permute_z(g, z, N, s);
       z = g.z_s;

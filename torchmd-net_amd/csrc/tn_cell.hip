@@ -119,14 +119,24 @@ __global__ __launch_bounds__(256) void k_cell_rank(const int* __restrict__ cgrid
 }
 
 __global__ void k_permute_pos(const float* __restrict__ pos, const int64_t* __restrict__ batch, const int* __restrict__ perm, int N,
-                              float* __restrict__ pos_s, int* __restrict__ bat_s) {
+                              int B, float* __restrict__ pos_s, int* __restrict__ bat_s, int64_t* __restrict__ bat_c,
+                              int* __restrict__ counts) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int o = perm[i];
   pos_s[i * 3] = pos[o * 3];
   pos_s[i * 3 + 1] = pos[o * 3 + 1];
   pos_s[i * 3 + 2] = pos[o * 3 + 2];
-  if (batch) bat_s[i] = (int)batch[o];  // several molecules in one box (neighbour operator only): pairs stay inside a molecule
+  if (batch) {  // several molecules in one box: pairs stay inside a molecule; the molecules are interleaved in cell order, so
+    int64_t b = batch[o];  // the per-molecule kernels take their "unsorted batch" path (counts[3])
+    if (B > 0 && (b < 0 || b >= B)) {
+      counts[5] = 1;
+      b = b < 0 ? 0 : B - 1;
+    }
+    bat_s[i] = (int)b;
+    bat_c[i] = b;
+    if (i == 0) counts[3] = 1;
+  }
 }
 __global__ void k_permute_z(const int64_t* __restrict__ z, const int* __restrict__ perm, int N, int64_t* __restrict__ z_s) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(1024) void k_cell_setup(const float* __restrict__ b
 
 // phase 1: bin + stable sort + permute positions + count ; phase 2: fill (link: launch_nbr_link_wave)
 void launch_cell_phase1(const Graph& g, const float* pos, const int64_t* batch, const float* box, int N, float lo, float up, bool loop,
-                        hipStream_t s) {
+                        hipStream_t s, int B) {
   int ncap = 1;
   while ((int64_t)(ncap + 1) * (ncap + 1) * (ncap + 1) <= 8 * (int64_t)N) ++ncap;  // cell_start holds 8 N + 2 entries
   hipLaunchKernelGGL(k_cell_setup, dim3(1), dim3(1024), 0, s, box, pos, N, up, ncap, g.ncx, g.ncy, g.ncz, g.boxd, g.cgrid, g.mstart,
@@ -356,8 +366,8 @@ void launch_cell_phase1(const Graph& g, const float* pos, const int64_t* batch, 
   hipLaunchKernelGGL(k_cell_place, dim3(cdivc(N, 256)), dim3(256), 0, s, g.cell_key, N, cursor, g.iota);
   hipLaunchKernelGGL(k_cell_rank, dim3(cdivc(N > 4096 ? N / 8 : 512, 4)), dim3(256), 0, s, g.cgrid, g.cell_start, g.iota, g.perm,
                      g.cell_key_sorted);
-  hipLaunchKernelGGL(k_permute_pos, dim3(cdivc(N, 256)), dim3(256), 0, s, pos, g.use_cell > 1 ? batch : nullptr, g.perm, N, g.pos_s,
-                     g.bat_s);
+  hipLaunchKernelGGL(k_permute_pos, dim3(cdivc(N, 256)), dim3(256), 0, s, pos, g.use_cell > 1 ? batch : nullptr, g.perm, N, B, g.pos_s,
+                     g.bat_s, g.bat_c, g.counts);
   hipLaunchKernelGGL(k_nbr_cell<false>, dim3(cdivc(N, 4)), dim3(256), 0, s, g, N, lo * lo, up * up, (int)loop);
 }
 void launch_cell_phase2(const Graph& g, int N, float lo, float up, bool loop, hipStream_t s) {

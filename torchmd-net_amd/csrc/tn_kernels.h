@@ -35,7 +35,8 @@ struct Graph {  // device pointers into the graph workspace
   int64_t* z_s;          // [N] atomic numbers in internal order
   float* boxd;           // [9] device copy of the box (rows a, b, c); fictitious box of a non-periodic cell search
   int* cgrid;            // [4] cells per axis + their product, computed on the device from the current box
-  int* bat_s;            // [N] molecule index per internal atom (several molecules in one box: neighbour operator)
+  int* bat_s;            // [N] molecule index per internal atom (several molecules in one box)
+  int64_t* bat_c;        // [N] the same as int64 (validated): the `batch` the model kernels see when the cell list renumbered several molecules
   int64_t* z_c;          // [N] validated (clamped to [0, max_z)) atomic numbers in internal order (tmdnet_build_graph with z)
   void* sort_tmp;
   size_t sort_tmp_bytes;
@@ -140,7 +141,7 @@ void launch_scan_counts(const Graph& g, int N, hipStream_t s);
 // ---- O(N) cell list for one periodic orthorhombic system (tn_cell.hip)
 size_t cell_sort_temp_bytes(int64_t n);
 void launch_cell_phase1(const Graph& g, const float* pos, const int64_t* batch, const float* box, int N, float lo, float up, bool loop,
-                        hipStream_t s);
+                        hipStream_t s, int B = 0);  // B > 0: validate the molecule indices (several molecules in one box)
 void launch_cell_phase2(const Graph& g, int N, float lo, float up, bool loop, hipStream_t s);
 void launch_permute_z(const Graph& g, const int64_t* z, int N, hipStream_t s);
 // z_c[i] = clamp(z[perm ? perm[i] : i], 0, max_z - 1); counts[4] = 1 when any value was out of range (reference: nn.Embedding raises)

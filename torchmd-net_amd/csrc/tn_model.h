@@ -154,6 +154,7 @@ struct tmdnet_model {
   int64_t lastE = 0;
   int cell_n[3] = {0, 0, 0};  // cell grid set by tmdnet_set_cell_grid (0 = brute force, < 0 = from the box, on the device)
   bool graph_is_cell = false; // last build used the cell list (atoms internally renumbered)
+  bool graph_cell_multi = false;  // ... with several molecules in the common grid (their atoms interleaved: Graph::bat_c)
   bool graph_has_z = false;   // last build validated z into Graph::z_c (internal order)
   std::vector<ParamSpec> specs;
   std::map<std::string, std::vector<float>> host;

@@ -288,7 +288,7 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
   gemm(s, b.x, F, W.O1, F, W.bO1, b.ao, H, N, H, F);
   const float* cpos = m->graph_is_cell ? g.pos_s : m->g_pos;
   const float* cbox = m->graph_is_cell ? g.boxd : m->g_box;
-  const int64_t* cbatch = m->graph_is_cell ? nullptr : batch;
+  const int64_t* cbatch = (m->graph_is_cell && !m->graph_cell_multi) ? nullptr : batch;  // several molecules in cell order: their internal batch
   if (!cpos) return fail(m, TMDNET_ERR_STATE, "TensorNet2 needs the positions of tmdnet_build_graph for its Coulomb head");
   {
     ProfScope ps_(s, CAT_PAIR, 0.0, Nd * (12 + 8.0 * QC), "launch_coulomb");

@@ -542,7 +542,8 @@ class TorchMD_Net(nn.Module):
             # neighbour strategy: O(N) cell list for one large system - periodic (grid computed on the device from the box of
             # THIS call: nothing about the box is cached on the host) or not (fictitious box around the bounding box, as the
             # reference's cell strategy, models/utils.py:206-212) -, brute force inside each molecule otherwise
-            auto = box_mode != 2 and n_mol == 1 and n >= self.cell_list_min_atoms
+            # ... or several LARGE molecules that share the box / the bounding box (interleaved in cell order inside the engine)
+            auto = box_mode != 2 and n_mol >= 1 and n >= self.cell_list_min_atoms * n_mol
             L.tmdnet_set_cell_grid(st.handle, *((-1, -1, -1) if auto else (0, 0, 0)))
             nbytes = C.c_size_t(0)
             L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
