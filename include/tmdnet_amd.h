@@ -106,7 +106,9 @@ int tmdnet_abi_version(void);
  * (SURVEY.md Appendix A), e.g. "representation_model.layers.0.linears_scalar.2.weight", plus
  * "mean", "std" and "atomref".  `data_host` is HOST memory, row-major, `numel` floats; it is copied.
  * tmdnet_finalize_params checks that every tensor is present with the expected size, builds the
- * transposed copies used by the reverse pass and uploads one packed device buffer. */
+ * transposed copies used by the reverse pass and uploads one packed device buffer.  It marks the radial
+ * tables stale: the first tmdnet_energy_forces after it rebuilds them (blocking, NULL stream, tens of ms)
+ * and returns TMDNET_ERR_STATE if its stream is being captured at that moment. */
 int tmdnet_set_param(tmdnet_model* m, const char* name, const float* data_host, int64_t numel);
 int tmdnet_finalize_params(tmdnet_model* m);
 /* number of parameter tensors the model expects; name of the idx-th one and its element count */

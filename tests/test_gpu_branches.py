@@ -507,6 +507,33 @@ def test_custom_ops_opcheck_compile_export(hip_lib, golden_dir):
 
 
 # ------------------------------------------------------------------ (j) radial tables of the per-pair functions
+def test_radial_tables_follow_parameter_edits(hip_lib, golden_dir):
+    """The tables are a function of the radial weights: an upload marks them stale, the next call (or a question about them)
+    rebuilds them - several edits between two calls cost one rebuild, and the results track the new weights exactly as the
+    direct evaluation does."""
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    model = create_model(dict(g["args"]))
+    model.load_state_dict(g["state_dict"])
+    model = model.to("cuda")
+    z, pos, batch, q = g["z"].cuda(), g["pos"].cuda(), g["batch"].cuda(), g["q"].cuda()
+    model.set_engine_option("edge_table_min_pairs", 0)
+    E0, F0 = model(z, pos, batch, q=q)
+    assert rel_err(E0.cpu(), g["E"]) < REL and rel_err(F0.cpu(), g["F"]) < REL
+    with torch.no_grad():  # two edits of radial weights, one of a non-radial one
+        for name, p_ in model.named_parameters():
+            if name.endswith("distance_proj1.weight") or name.endswith("linears_scalar.0.weight"):
+                p_.mul_(1.07)
+        model.representation_model.out_norm.bias.add_(0.01)
+    E1, F1 = model(z, pos, batch, q=q)  # re-upload, tables rebuilt by this call
+    assert model.engine_info("edge_table_T") >= 8192 and model.engine_info("edge_table_err_value") < 1e-6
+    assert rel_err(E1, E0) > 1e-4  # the weights did change the answer
+    model.set_engine_option("edge_table_min_pairs", 10 ** 12)  # same weights through the value + tangent GEMMs
+    E2, F2 = model(z, pos, batch, q=q)
+    assert rel_err(E1, E2) < 2e-6 and rel_err(F1, F2) < 2e-6
+
+
 def test_edge_tables_equal_direct_evaluation(hip_lib, golden_dir):
     """Q(d) and every layer's edge MLP w(d) are functions of the distance alone: tabulated at parameter upload (verified
     there against the direct evaluation at all interval midpoints) and Hermite-interpolated per pair.  The table path must

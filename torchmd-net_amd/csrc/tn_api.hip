@@ -496,6 +496,19 @@ int build_edge_tables(tmdnet_model* m) {
 
 }  // namespace
 
+int ensure_radial_tables(tmdnet_model* m, hipStream_t s) {
+  if (!m->tabs_pending) return TMDNET_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return fail(m, TMDNET_ERR_STATE, "the radial tables are rebuilt after a parameter upload: run one step outside the capture first");
+  HIP_TRY(m, hipStreamSynchronize(nullptr));
+  const int rc = m->et ? et_build_tables(m) : build_edge_tables(m);
+  if (rc != TMDNET_OK) return rc;
+  HIP_TRY(m, hipStreamSynchronize(nullptr));
+  m->tabs_pending = false;
+  return TMDNET_OK;
+}
+
 extern "C" {
 
 const char* tmdnet_version(void) { return "tmdnet_amd 0.3 (gfx950)"; }
@@ -889,9 +902,8 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   P.Vtab = m->dev + off.at("Vtab");
   launch_ztables(P.emb, P.emb2_waT, P.emb2_wbT, P.emb2_b, m->hp.max_z, F, m->dev + off.at("Utab"), m->dev + off.at("Vtab"), nullptr);
   HIP_TRY(m, hipStreamSynchronize(nullptr));
-  const int rc_tab = build_edge_tables(m);
-  if (rc_tab != TMDNET_OK) return rc_tab;
-  HIP_TRY(m, hipStreamSynchronize(nullptr));
+  free_radial_tables(m->tabs);  // rebuilt by the first call that uses them (ensure_radial_tables): fp64 evaluation + refinement,
+  m->tabs_pending = true;      // tens of ms - not paid per parameter edit, and never on a stream that is being captured
   m->finalized = true;
   return TMDNET_OK;
 }
@@ -918,6 +930,8 @@ int tmdnet_set_option(tmdnet_model* m, const char* name, double value) {
 int tmdnet_get_info(const tmdnet_model* m, const char* name, double* value) {
   if (!m || !name || !value) return TMDNET_ERR_INVALID;
   const std::string n(name);
+  if (m->tabs_pending && n.rfind("edge_table_", 0) == 0 && n != "edge_table_min_pairs")  // facts about tables not built yet
+    if (const int rc = ensure_radial_tables(const_cast<tmdnet_model*>(m), nullptr)) return rc;
   if (n == "edge_table_T") *value = m->tabs.ok ? m->tabs.T : 0;
   else if (n == "edge_table_err_value") *value = m->tabs.err_value;
   else if (n == "edge_table_err_slope") *value = m->tabs.err_slope;
@@ -1099,6 +1113,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   if (!m->finalized) return fail(m, TMDNET_ERR_STATE, "parameters not finalised");
   if (want_forces && !forces) return TMDNET_ERR_INVALID;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (const int rc_tab = ensure_radial_tables(m, s)) return rc_tab;
   const tmdnet_hparams& hp = m->hp;
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden;
   const int N = (int)n_atoms, B = (int)n_mol;

@@ -389,20 +389,23 @@ int et_finalize(tmdnet_model* m) {
   P.atomref = hp.has_atomref ? D("atomref") : nullptr;
   P.mean = h["mean"][0];
   P.std = h["std"][0];
-  {  // radial tables (tn_edge_table.hip): every layer's distance filters silu(D phi + b) [Wd] and the neighbour-embedding
-     // filter (D phi + b) C(d) [F] are functions of the pair distance alone (reference torchmd_et.py:375-384, models/utils.py:99-104)
-    HIP_TRY(m, hipStreamSynchronize(nullptr));
-    std::vector<TableSpec> specs;
-    const int Wd = wd_of(hp);
-    if (Wd > 0)
-      for (int l = 0; l < L; ++l) specs.push_back(TableSpec{{TableLayer{P.layer[l].Wdkv, P.layer[l].bdkv, Wd, K, 1}}});
-    if (hp.neighbor_embedding) specs.push_back(TableSpec{{TableLayer{P.Wn, P.bn, F, K, 3}}});
-    const int rc_tab = build_radial_tables(m, m->tabs, specs, P.means, P.betas, K, hp.cutoff_lower, hp.cutoff_upper);
-    if (rc_tab != TMDNET_OK) return rc_tab;
-    HIP_TRY(m, hipStreamSynchronize(nullptr));
-  }
+  free_radial_tables(m->tabs);  // built by the first call that uses them (ensure_radial_tables -> et_build_tables)
+  m->tabs_pending = true;
   m->finalized = true;
   return TMDNET_OK;
+}
+
+// radial tables (tn_edge_table.hip): every layer's distance filters silu(D phi + b) [Wd] and the neighbour-embedding filter
+// (D phi + b) C(d) [F] are functions of the pair distance alone (reference torchmd_et.py:375-384, models/utils.py:99-104)
+int et_build_tables(tmdnet_model* m) {
+  const tmdnet_et_hparams& hp = m->et->hp;
+  const EtParams& P = m->et->P;
+  const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Wd = wd_of(hp);
+  std::vector<TableSpec> specs;
+  if (Wd > 0)
+    for (int l = 0; l < L; ++l) specs.push_back(TableSpec{{TableLayer{P.layer[l].Wdkv, P.layer[l].bdkv, Wd, K, 1}}});
+  if (hp.neighbor_embedding) specs.push_back(TableSpec{{TableLayer{P.Wn, P.bn, F, K, 3}}});
+  return build_radial_tables(m, m->tabs, specs, P.means, P.betas, K, hp.cutoff_lower, hp.cutoff_upper);
 }
 
 int et_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int32_t want_forces,

@@ -170,6 +170,7 @@ struct tmdnet_model {
   int last_nt = 0;
   int64_t rb_min_atoms = 1024;
   int pair_bf16 = 0;          // option "pair_rows_bf16" (Equivariant Transformer): per-pair filter rows stored as bf16
+  bool tabs_pending = false;  // parameters changed since the radial tables were built: rebuilt by the next call that uses them
   int64_t tab_min_pairs = 1;  // developer / test switch (option "edge_table_min_pairs"): fewer pairs take the value + tangent GEMMs
   bool finalized = false;
   std::string err;
@@ -251,6 +252,9 @@ int rb_ntp(const tmdnet_model* m, int64_t n_atoms, int64_t n_pairs);
 void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], float* C, int N, int F, int flags = 0, float* pre = nullptr,
                    const float* gates = nullptr);
 // radial tables (tn_api.hip): fp64 build + midpoint verification; `out.ok` says whether they may be used
+// builds the radial tables if a parameter upload left them pending (blocking, NULL stream); refuses while `s` is being captured
+int ensure_radial_tables(tmdnet_model* m, hipStream_t s);
+int et_build_tables(tmdnet_model* m);  // tn_et_api.hip
 int build_radial_tables(tmdnet_model* m, EdgeTables& out, const std::vector<TableSpec>& specs, const float* means, const float* betas,
                         int K, double lo, double up);
 void free_radial_tables(EdgeTables& t);
