@@ -246,6 +246,25 @@ int64_t tmdnet_debug_split_weight(const float* W_host, int64_t N, int64_t K, uin
 int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float* bias, float* C, int64_t M, int64_t N,
                       int64_t K, int32_t silu, const uint16_t* Wsb);
 
+/* ---- First-order parameter gradients (TensorNet + Scalar head; energy-only training).
+ * Replaces what autograd does in the reference for `loss(E).backward()` over torchmdnet/models/tensornet.py:543-619, 729-814,
+ * 384-398 and output_modules.py:108-117: given d loss / d E_m per molecule, one call evaluates the energies (direct evaluation
+ * of the radial functions, no tables) and the gradient of sum_m grad_energy[m] E_m with respect to every weight, into one flat
+ * device buffer whose layout tmdnet_param_grad_entry enumerates (name, offset and element count; offsets are 64-float
+ * aligned).  Entry names are the engine's: "Wdp"/"bdp" = distance_proj1..3 stacked, "Utab"/"Vtab" = the per-species tables
+ * U[z] = emb(z) Wa^T + b, V[z] = emb(z) Wb^T of emb2([emb(z_i), emb(z_j)]) (chain to emb / emb2 on the caller's side),
+ * "Ue{k}", "L1", "bL1", "L2", "bL2", "ln0_w", "ln0_b" = tensor_embedding linears_tensor / linears_scalar / init_norm,
+ * "l{l}.M{k}", "l{l}.b{k}" = layers.l.linears_scalar.k, "l{l}.Va{k}" / "l{l}.Vb{k}" = layers.l.linears_tensor.k / .(3+k),
+ * "lnr_w", "lnr_b" = out_norm, "Lin", "bLin" = linear, "O1", "bO1", "O2", "bO2" = output_network.layers.0 / .2.
+ * Needs a graph built with the exact pair count (tmdnet_build_graph, no cell list); deterministic; no position gradient. */
+int tmdnet_param_grad_count(tmdnet_model* m);
+const char* tmdnet_param_grad_entry(tmdnet_model* m, int idx, int64_t* offset, int64_t* numel);
+int tmdnet_train_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, size_t* fwd_bytes,
+                                 size_t* train_bytes, int64_t* grad_floats);
+int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, void* train_ws,
+                              size_t train_bytes, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, const int64_t* z,
+                              const int64_t* batch, const float* q, const float* grad_energy, float* energy, float* grads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -265,7 +265,7 @@ void set_cell(Graph& g, const tmdnet_model* m, bool on, int64_t n_mol = 1) {
 // dynamic shapes only (the species count is read back with the pair counts), a batch-scale system, at most 8 species
 }  // namespace
 int rb_ntp(const tmdnet_model* m, int64_t n_atoms, int64_t n_pairs) {
-  if (!m->rb_fwd || m->et || n_pairs < 0 || n_atoms < m->rb_min_atoms) return 0;
+  if (!m->rb_fwd || m->et || m->train || n_pairs < 0 || n_atoms < m->rb_min_atoms) return 0;
   return embed_rb_ntp(m->last_nt);
 }
 namespace {
@@ -1113,7 +1113,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   if (!m->finalized) return fail(m, TMDNET_ERR_STATE, "parameters not finalised");
   if (want_forces && !forces) return TMDNET_ERR_INVALID;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (const int rc_tab = ensure_radial_tables(m, s)) return rc_tab;
+  if (!m->train)  // the parameter-gradient pass evaluates the radial functions directly (its weights change every step)
+    if (const int rc_tab = ensure_radial_tables(m, s)) return rc_tab;
   const tmdnet_hparams& hp = m->hp;
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden;
   const int N = (int)n_atoms, B = (int)n_mol;
@@ -1184,7 +1185,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   auto NODE = [&]() { g_gemm_cat = CAT_GEMM_NODE; g_mdev = nullptr; g_madd = 0; };
 
   // ---- per-pair functions of the distance: Q (embedding) and every layer's w, with their d/dd when forces are wanted
-  const bool use_tab = m->tabs.ok && (int64_t)P1 >= m->tab_min_pairs && (int)m->tabs.tab.size() == 1 + L && L + 1 <= 8;
+  TrainCtx* const tc = m->train;  // parameter gradients wanted: direct evaluation with every pre-activation kept
+  const bool use_tab = !tc && m->tabs.ok && (int64_t)P1 >= m->tab_min_pairs && (int)m->tabs.tab.size() == 1 + L && L + 1 <= 8;
   hipStream_t es = s;
   if (use_tab) {
     // radial tables (tn_edge_table.hip): sort the pairs by distance, one streaming Hermite-interpolation kernel for all
@@ -1216,7 +1218,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     // ---- edge MLPs of all layers: functions of the pair geometry only -> side stream (tn_model.h)
     // only at batch scale: for a small system the cross-queue joins cost more than the overlap gives (graph replay of a
     // 64-atom molecule 0.36 -> 0.40 ms, profiles/r01_notes.md)
-    es = (m->side && L > 0 && P >= 16384) ? m->side : s;
+    es = (m->side && L > 0 && P >= 16384 && !tc) ? m->side : s;
     if (es != s) {
       HIP_TRY(m, hipEventRecord(m->ev_fork, s));
       HIP_TRY(m, hipStreamWaitEvent(es, m->ev_fork, 0));
@@ -1224,7 +1226,12 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     for (int l = 0; l < L; ++l) {
       const LayerP& q_ = W.layer[l];
       EDGE(1);
-      if (want_forces) {
+      if (tc) {  // values only, pre-activations kept for the weight gradients
+        gemm(es, b.phi, K, q_.M1, K, q_.b1, tc->he1[l], F, P1, F, K, GEMM_ACT_SILU, tc->pre1[l], F);
+        gemm(es, tc->he1[l], F, q_.M2, F, q_.b2, tc->he2[l], 2 * F, P1, 2 * F, F, GEMM_ACT_SILU, tc->pre2[l], 2 * F);
+        gemm(es, tc->he2[l], 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, tc->pre3[l], 3 * F,
+             nullptr, 0, b.C);
+      } else if (want_forces) {
         // edge MLP with its distance tangent carried forward (dw/dd): the reverse pass then needs no edge GEMM
         gemm_dual(es, 1, b.phi, b.dphi, K, q_.M1, q_.b1, b.he1, b.te1, F, P1, F, K, nullptr, nullptr, q_.M_sb[0]);
         gemm_dual(es, 1, b.he1, b.te1, F, q_.M2, q_.b2, b.he2, b.te2, 2 * F, P1, 2 * F, F, nullptr, nullptr, q_.M_sb[1]);
@@ -1241,7 +1248,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
     EDGE(1);
     if (ntp) {
-    } else if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);  // distance projections + d/dd
+    } else if (tc) gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
+    else if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);  // distance projections + d/dd
     else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
   }
   const RadialParams rbp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
@@ -1265,13 +1273,16 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     const LayerP& q_ = W.layer[l];
     if (es != s) HIP_TRY(m, hipStreamWaitEvent(s, m->ev_join[l], 0));  // join: w[l] (and dw[l]) are ready
     // X_hat of layer l > 0 was written by the previous layer's update kernel (in place over its own X_hat)
-    if (l == 0) KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], b.Xh, N, F, s));
-    tensor_linear(s, b.Xh, q_.V, b.Pn[l], N, F);
-    KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], b.Ch, s));
-    tensor_linear(s, b.Ch, q_.V + 3, b.D[l], N, F);
+    float* const Xh_l = tc ? tc->Xh[l] : b.Xh;  // kept per layer when parameter gradients are wanted
+    float* const Ch_l = tc ? tc->Ch[l] : b.Ch;
+    float* const Xh_n = tc && l + 1 < L ? tc->Xh[l + 1] : b.Xh;
+    if (l == 0) KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], Xh_l, N, F, s));
+    tensor_linear(s, Xh_l, q_.V, b.Pn[l], N, F);
+    KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s));
+    tensor_linear(s, Ch_l, q_.V + 3, b.D[l], N, F);
     // update fused with the next consumer of the new X: the next layer's normalisation, or the readout invariants
-    KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(b.Xh, b.D[l], q, batch_k, N, F, b.X[l + 1], l + 1 < L ? 1 : 2,
-                                                       l + 1 < L ? b.Xh : b.feat, s));
+    KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(Xh_l, b.D[l], q, batch_k, N, F, b.X[l + 1], l + 1 < L ? 1 : 2,
+                                                       l + 1 < L ? Xh_n : b.feat, s));
   }
   // ---- readout + head + per-molecule sum
   if (L == 0) KR(CAT_ELEMENTWISE, nodeB + Nd * 3 * Fd * 4, launch_readout_feat(b.X[L], N, F, b.feat, s));
@@ -1289,8 +1300,31 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
 
   if (want_forces) {
     NODE();  // g_ao = d energy / d ao came out of the head kernel
+    const RowMap rH = rows_plain(H), rF = rows_plain(F), r2F = rows_plain(2 * F), r3F = rows_plain(3 * F), rK = rows_plain(K);
+    const RowMap rc_[3] = {rows_comp(F, 1), rows_comp(F, 3), rows_comp(F, 5)};  // (atom, component) rows of I / A / S in [N, 9, F]
+    const int c0_[3] = {0, 1, 4}, nc_[3] = {1, 3, 5};
+    // dW[t] (+)= sum over the rows of type t of gOut^T In  (the three weight sets of a 9-component tensor linear)
+    auto tensor_linear_grad = [&](const float* gOut, const float* In, const std::string& key) {
+      for (int t = 0; t < 3; ++t)
+        launch_tn_gemm(s, gOut + (int64_t)c0_[t] * F, rc_[t], In + (int64_t)c0_[t] * F, rc_[t], nullptr, nullptr, N * nc_[t], F, F,
+                       tc->at(key + std::to_string(t)), false, tc->part);
+    };
+    if (tc) {
+      // seeds: every adjoint below is linear in g_ao, so scaling its rows by d loss / d E_mol(i) is all it takes
+      launch_train_seed(b.ao, tc->gE, batch, N, H, W.std, b.g_ao, tc->head, s);
+      launch_colsum(s, tc->head, rows_plain(H + 1), nullptr, rH, nullptr, nullptr, N, H, tc->at("O2"), false, tc->part);
+      launch_colsum(s, tc->head + H, rows_plain(H + 1), nullptr, rH, nullptr, nullptr, N, 1, tc->at("bO2"), false, tc->part);
+      launch_tn_gemm(s, b.g_ao, rH, b.x, rF, nullptr, nullptr, N, H, F, tc->at("O1"), false, tc->part);
+      launch_colsum(s, b.g_ao, rH, nullptr, rH, nullptr, nullptr, N, H, tc->at("bO1"), false, tc->part);
+    }
     gemm(s, b.g_ao, H, W.O1T, H, nullptr, b.g_al, F, N, F, H, GEMM_MUL_DSILU_AUX, nullptr, 0, b.al, F);
     gemm(s, b.g_al, F, W.LinT, F, nullptr, b.g_ln, 3 * F, N, 3 * F, F);
+    if (tc) {
+      launch_tn_gemm(s, b.g_al, rF, b.lnr, r3F, nullptr, nullptr, N, F, 3 * F, tc->at("Lin"), false, tc->part);
+      launch_colsum(s, b.g_al, rF, nullptr, rF, nullptr, nullptr, N, F, tc->at("bLin"), false, tc->part);
+      launch_colsum(s, b.g_ln, r3F, b.xhr, r3F, nullptr, nullptr, N, 3 * F, tc->at("lnr_w"), false, tc->part);
+      launch_colsum(s, b.g_ln, r3F, nullptr, r3F, nullptr, nullptr, N, 3 * F, tc->at("lnr_b"), false, tc->part);
+    }
     if (F % 64 == 0) {
       KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 8, launch_lnbwd_readout_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, F, b.X[L], b.G, s));
     } else {
@@ -1299,7 +1333,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     }
     // zero-fills are kernels, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to
     // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
-    const bool merged_gd = message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD");
+    const bool merged_gd = message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD") && !tc;
     const int gd_nw = message_adjoint_gd_waves(N, F);
     const int64_t gd_stride = 2 * (int64_t)P1;
     if (!merged_gd) launch_fill(b.gd, 0.f, P1, s);  // the per-layer pair kernels accumulate into it
@@ -1307,16 +1341,38 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       const LayerP& q_ = W.layer[l];
       // gD of the layers below the top one comes out of the previous iteration's fused normalisation adjoint
       if (l == L - 1) KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch_k, N, F, b.gD, s));
+      if (tc) tensor_linear_grad(b.gD, tc->Ch[l], "l" + std::to_string(l) + ".V" /* 3..5 */ + std::string("b"));
       tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
       KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch_k, o3, N, F, b.gMi, b.gPn, s));
+      if (tc) {
+        // edge MLP of this layer: g_w per pair (self pair: summed over the atoms), then back through silu(.) C, M3, M2, M1
+        const std::string t_ = "l" + std::to_string(l) + ".";
+        for (int k = 0; k < 3; ++k)
+          launch_colsum(s, b.gMi + (int64_t)c0_[k] * F, rc_[k], b.Pn[l] + (int64_t)c0_[k] * F, rc_[k], nullptr, nullptr, N * nc_[k], F,
+                        tc->self_gw + (int64_t)k * F, false, tc->part);
+        launch_train_gw(g, P, F, b.gMi, b.Pn[l], tc->pre3[l], b.C, tc->self_gw, tc->g3, s);
+        launch_tn_gemm(s, tc->g3, r3F, tc->he2[l], r2F, nullptr, nullptr, P1, 3 * F, 2 * F, tc->at(t_ + "M2"), false, tc->part);
+        launch_colsum(s, tc->g3, r3F, nullptr, r3F, nullptr, nullptr, P1, 3 * F, tc->at(t_ + "b2"), false, tc->part);
+        EDGE(1);
+        launch_transpose(q_.M3, 3 * F, 2 * F, tc->wT, s);  // [2F][3F]: the [N][K] operand of g_he2 = g_pre3 M3
+        gemm(s, tc->g3, 3 * F, tc->wT, 3 * F, nullptr, tc->g2, 2 * F, P1, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, tc->pre2[l], 2 * F);
+        launch_tn_gemm(s, tc->g2, r2F, tc->he1[l], rF, nullptr, nullptr, P1, 2 * F, F, tc->at(t_ + "M1"), false, tc->part);
+        launch_colsum(s, tc->g2, r2F, nullptr, r2F, nullptr, nullptr, P1, 2 * F, tc->at(t_ + "b1"), false, tc->part);
+        launch_transpose(q_.M2, 2 * F, F, tc->wT, s);
+        gemm(s, tc->g2, 2 * F, tc->wT, 2 * F, nullptr, tc->g1, F, P1, F, 2 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, tc->pre1[l], F);
+        launch_tn_gemm(s, tc->g1, rF, b.phi, rK, nullptr, nullptr, P1, F, K, tc->at(t_ + "M0"), false, tc->part);
+        launch_colsum(s, tc->g1, rF, nullptr, rF, nullptr, nullptr, P1, F, tc->at(t_ + "b0"), false, tc->part);
+        NODE();
+      }
       if (merged_gd) {
         KR(CAT_MESSAGE, 2 * wB + idxB + 4 * nodeB + 8 * (Pd + 1) * gd_nw,  // w, dw, gMi, Pn, gPn (read + write), g_d slots
            launch_message_adjoint_gd(g, N, F, b.w[l], b.dw[l], b.gMi, b.Pn[l], b.gPn, b.gd_slots + (int64_t)l * gd_nw * gd_stride,
                                      gd_stride, s));
       } else {
         KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
-        KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));
+        if (!tc) KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));
       }
+      if (tc) tensor_linear_grad(b.gPn, tc->Xh[l], "l" + std::to_string(l) + ".V" /* 0..2 */ + std::string("a"));
       tensor_linear(s, b.gPn, q_.VT, b.gXl, N, F);
       if (l > 0)
         KR(CAT_ELEMENTWISE, 6 * nodeB, launch_norm_bwd_update_bwd(b.X[l], b.gXl, N, F, b.G, b.D[l - 1], q, batch_k, b.gD, s));
@@ -1331,7 +1387,29 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s));
     tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
-    if (ntp) {
+    if (tc) {
+      // embedding: tensor linears, gate MLP, init_norm, then the edge weights W_k = C (U[z_i] + V[z_j]) (Wdp phi + bdp)_k
+      tensor_linear_grad(b.gUX, b.u0, "Ue");
+      launch_tn_gemm(s, b.g_a2, r3F, b.h1, r2F, nullptr, nullptr, N, 3 * F, 2 * F, tc->at("L2"), false, tc->part);
+      launch_colsum(s, b.g_a2, r3F, nullptr, r3F, nullptr, nullptr, N, 3 * F, tc->at("bL2"), false, tc->part);
+      launch_tn_gemm(s, b.g_a1, r2F, b.ln0, rF, nullptr, nullptr, N, 2 * F, F, tc->at("L1"), false, tc->part);
+      launch_colsum(s, b.g_a1, r2F, nullptr, r2F, nullptr, nullptr, N, 2 * F, tc->at("bL1"), false, tc->part);
+      launch_colsum(s, b.g_ln0, rF, b.xh0, rF, nullptr, nullptr, N, F, tc->at("ln0_w"), false, tc->part);
+      launch_colsum(s, b.g_ln0, rF, nullptr, rF, nullptr, nullptr, N, F, tc->at("ln0_b"), false, tc->part);
+      const int64_t dir = (int64_t)P1 * 3 * F;
+      launch_train_embed(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.gA, tc->gq, dir, tc->selfq, tc->gZu, tc->gZv, s);
+      float* dWdp = tc->at("Wdp");
+      float* dbdp = tc->at("bdp");
+      launch_tn_gemm(s, tc->gq, r3F, b.phi, rK, nullptr, nullptr, P, 3 * F, K, dWdp, false, tc->part);
+      launch_tn_gemm(s, tc->gq + dir, r3F, b.phi, rK, nullptr, nullptr, P, 3 * F, K, dWdp, true, tc->part);
+      launch_tn_gemm(s, tc->selfq, rF, b.phi + (int64_t)P * K, rows_plain(0), nullptr, nullptr, N, F, K, dWdp, true, tc->part);  // self pair: I block
+      launch_colsum(s, tc->gq, r3F, nullptr, r3F, nullptr, nullptr, P, 3 * F, dbdp, false, tc->part);
+      launch_colsum(s, tc->gq + dir, r3F, nullptr, r3F, nullptr, nullptr, P, 3 * F, dbdp, true, tc->part);
+      launch_colsum(s, tc->selfq, rF, nullptr, rF, nullptr, nullptr, N, F, dbdp, true, tc->part);
+      launch_onehot(z, N, Z, tc->onehot, s);
+      launch_tn_gemm(s, tc->onehot, rows_plain(Z), tc->gZu, rF, nullptr, nullptr, N, Z, F, tc->at("Utab"), false, tc->part);
+      launch_tn_gemm(s, tc->onehot, rows_plain(Z), tc->gZv, rF, nullptr, nullptr, N, Z, F, tc->at("Vtab"), false, tc->part);
+    } else if (ntp) {
       KR(CAT_PAIR, Nd * 10 * Fd * 4 + momB, launch_embed_gm(g, N, F, K, ntp, z, W.Utab, W.Vtab, m->rb_rev, W.bdp, b.gA, b.gmom, s));
       KR(CAT_PAIR, Pd * 40 + momB + Pd * 8 * L * gd_nw,
          launch_embed_pair_rb(g, P, N, rbp, ntp, b.ps, b.gmom, b.gd, b.g_rhat, s, merged_gd ? b.g_delta : nullptr, b.gd_slots, L * gd_nw, gd_stride));
@@ -1339,8 +1417,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
          launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s, merged_gd ? b.g_delta : nullptr,
                               b.gd_slots, L * gd_nw, gd_stride));
-    if (!merged_gd) KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s, nullptr, 0, gd_stride));
-    KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
+    if (!merged_gd && !tc) KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s, nullptr, 0, gd_stride));
+    if (!tc) KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
   }
   NODE();
   HIP_TRY(m, hipGetLastError());
@@ -1349,6 +1427,125 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   m->lastP = P;
   m->has_last = true;
   return TMDNET_OK;
+}
+
+
+// ------------------------------------------------------------------------------------ parameter gradients (TensorNet + Scalar)
+namespace {
+const std::vector<std::pair<std::string, int64_t>>& train_layout(tmdnet_model* m) {
+  if (!m->train_entries.empty()) return m->train_entries;
+  const int64_t F = m->hp.hidden_channels, K = m->hp.num_rbf, L = m->hp.num_layers, H = m->hp.head_hidden, Z = m->hp.max_z;
+  auto& e = m->train_entries;
+  e = {{"Wdp", 3 * F * K}, {"bdp", 3 * F}, {"Utab", Z * F}, {"Vtab", Z * F}, {"Ue0", F * F}, {"Ue1", F * F}, {"Ue2", F * F},
+       {"L1", 2 * F * F}, {"bL1", 2 * F}, {"L2", 6 * F * F}, {"bL2", 3 * F}, {"ln0_w", F}, {"ln0_b", F}};
+  for (int l = 0; l < L; ++l) {
+    const std::string t = "l" + std::to_string(l) + ".";
+    e.push_back({t + "M0", F * K});
+    e.push_back({t + "b0", F});
+    e.push_back({t + "M1", 2 * F * F});
+    e.push_back({t + "b1", 2 * F});
+    e.push_back({t + "M2", 6 * F * F});
+    e.push_back({t + "b2", 3 * F});
+    for (const char* ab : {"Va", "Vb"})
+      for (int k = 0; k < 3; ++k) e.push_back({t + ab + std::to_string(k), F * F});
+  }
+  for (auto kv : std::vector<std::pair<std::string, int64_t>>{{"lnr_w", 3 * F}, {"lnr_b", 3 * F}, {"Lin", 3 * F * F}, {"bLin", F}, {"O1", H * F},
+                                                               {"bO1", H}, {"O2", H}, {"bO2", 1}})
+    e.push_back(kv);
+  return e;
+}
+int64_t train_grad_floats(tmdnet_model* m) {
+  int64_t n = 0;
+  for (const auto& kv : train_layout(m)) n += (kv.second + 63) & ~int64_t(63);
+  return n;
+}
+// extra activations + scratch of the parameter-gradient pass
+void carve_train(void* ws, tmdnet_model* m, int64_t N, int64_t P, TrainCtx* tc, size_t* total) {
+  const tmdnet_hparams& hp = m->hp;
+  const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, H = hp.head_hidden, Z = hp.max_z, P1 = P + 1, N9 = N * 9 * F;
+  Carver c(ws);
+  TrainCtx t;
+  for (int l = 0; l < L; ++l) {
+    t.pre1.push_back(c.take<float>(P1 * F));
+    t.he1.push_back(c.take<float>(P1 * F));
+    t.pre2.push_back(c.take<float>(P1 * 2 * F));
+    t.he2.push_back(c.take<float>(P1 * 2 * F));
+    t.pre3.push_back(c.take<float>(P1 * 3 * F));
+    t.Ch.push_back(c.take<float>(N9));
+    t.Xh.push_back(c.take<float>(N9));
+  }
+  t.g3 = c.take<float>(P1 * 3 * F);
+  t.g2 = c.take<float>(P1 * 2 * F);
+  t.g1 = c.take<float>(P1 * F);
+  t.self_gw = c.take<float>(3 * F);
+  t.gq = c.take<float>(2 * P1 * 3 * F);
+  t.selfq = c.take<float>(N * F);
+  t.gZu = c.take<float>(N * F);
+  t.gZv = c.take<float>(N * F);
+  t.onehot = c.take<float>(N * Z);
+  t.head = c.take<float>(N * (H + 1));
+  t.wT = c.take<float>(6 * F * F);
+  t.forces = c.take<float>(N * 3);
+  const int64_t big = std::max<int64_t>({6 * F * F, 3 * F * K, Z * F, H * F, 3 * F * F});
+  t.part = c.take<float>((int64_t)train_part_floats((int)std::max<int64_t>(P1, 5 * N), big));
+  (void)K;
+  if (tc) {
+    const float* ge = tc->gE;
+    float* gr = tc->grads;
+    *tc = t;
+    tc->gE = ge;
+    tc->grads = gr;
+  }
+  if (total) *total = c.off;
+}
+}  // namespace
+
+int tmdnet_param_grad_count(tmdnet_model* m) {
+  if (!m || m->et || m->tn2) return 0;
+  return (int)train_layout(m).size();
+}
+const char* tmdnet_param_grad_entry(tmdnet_model* m, int idx, int64_t* offset, int64_t* numel) {
+  if (!m || m->et || m->tn2) return nullptr;
+  const auto& e = train_layout(m);
+  if (idx < 0 || idx >= (int)e.size()) return nullptr;
+  int64_t off = 0;
+  for (int i = 0; i < idx; ++i) off += (e[i].second + 63) & ~int64_t(63);
+  if (offset) *offset = off;
+  if (numel) *numel = e[idx].second;
+  return e[idx].first.c_str();
+}
+int tmdnet_train_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, size_t* fwd_bytes, size_t* train_bytes,
+                                 int64_t* grad_floats) {
+  if (!m || n_atoms < 0 || n_mol < 0 || n_pairs < 0) return TMDNET_ERR_INVALID;
+  if (m->et || m->tn2) return fail(m, TMDNET_ERR_INVALID, "parameter gradients: TensorNet + Scalar only");
+  if (fwd_bytes) carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, true, fwd_bytes, 0);
+  if (train_bytes) carve_train(nullptr, m, n_atoms, n_pairs, nullptr, train_bytes);
+  if (grad_floats) *grad_floats = train_grad_floats(m);
+  return TMDNET_OK;
+}
+int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, void* train_ws, size_t train_bytes,
+                              int64_t n_atoms, int64_t n_mol, int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q,
+                              const float* grad_energy, float* energy, float* grads) {
+  if (!m || !graph_ws || !ws || !train_ws || !grad_energy || !energy || !grads) return TMDNET_ERR_INVALID;
+  if (m->et || m->tn2) return fail(m, TMDNET_ERR_INVALID, "parameter gradients: TensorNet + Scalar only");
+  if (n_pairs < 0) return fail(m, TMDNET_ERR_INVALID, "parameter gradients need the exact pair count (dynamic shapes)");
+  if (m->graph_is_cell) return fail(m, TMDNET_ERR_STATE, "parameter gradients: build the graph without the cell list");
+  TrainCtx tc;
+  tc.gE = grad_energy;
+  tc.grads = grads;
+  size_t need = 0;
+  carve_train(train_ws, m, n_atoms, n_pairs, &tc, &need);
+  if (need > train_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "training workspace too small: need " + std::to_string(need));
+  int64_t off = 0;
+  for (const auto& kv : train_layout(m)) {
+    tc.off[kv.first] = off;
+    off += (kv.second + 63) & ~int64_t(63);
+  }
+  launch_fill(grads, 0.f, off, reinterpret_cast<hipStream_t>(stream));
+  m->train = &tc;
+  const int rc = tmdnet_energy_forces(m, stream, graph_ws, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, q, 1, energy, tc.forces);
+  m->train = nullptr;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------ neighbour operator

@@ -13,6 +13,7 @@
 #include "../../include/tmdnet_amd.h"
 #include "tn_gemm.h"
 #include "tn_kernels.h"
+#include "tn_train.h"
 
 using namespace tn;
 
@@ -136,8 +137,22 @@ struct TableSpec {
   std::vector<TableLayer> chain;  // the last layer's N is the table's row length
 };
 
+// parameter-gradient pass (tmdnet_energy_param_grads): seeds, output and the extra activations the reverse pass keeps per layer
+struct TrainCtx {
+  const float* gE = nullptr;  // [B] d loss / d E_m (device)
+  float* grads = nullptr;     // flat gradient buffer (device), layout = train_layout(m)
+  std::map<std::string, int64_t> off;
+  std::vector<float*> pre1, he1, pre2, he2, pre3, Ch, Xh;  // per layer: edge-MLP pre-/post-activations, group product, normalised X
+  float *g3 = nullptr, *g2 = nullptr, *g1 = nullptr;       // adjoints of the edge-MLP pre-activations [P + 1, 3F / 2F / F]
+  float *self_gw = nullptr, *gq = nullptr, *selfq = nullptr, *gZu = nullptr, *gZv = nullptr, *onehot = nullptr, *head = nullptr;
+  float *part = nullptr, *wT = nullptr, *forces = nullptr;
+  float* at(const std::string& k) const { return grads + off.at(k); }
+};
+
 struct tmdnet_model {
   tmdnet_hparams hp;
+  TrainCtx* train = nullptr;  // non-null while tmdnet_energy_param_grads drives tmdnet_energy_forces
+  std::vector<std::pair<std::string, int64_t>> train_entries;  // gradient buffer layout (name, numel), built on first use
   // optional (TMDNET_SIDE_STREAM=1) second stream + events: the edge MLPs of the interaction layers depend on the pair geometry only, so they are
   // enqueued on `side` (fork after the radial kernel, one join per layer before its message sweep) and run beside the
   // per-atom chain; under HIP-graph capture the fork/join pattern becomes parallel branches of the graph

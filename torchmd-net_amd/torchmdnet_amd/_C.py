@@ -94,6 +94,11 @@ def lib():
     L.tmdnet_debug_split_weight.argtypes = [vp, i64, i64, vp]
     L.tmdnet_debug_split_weight.restype = i64
     L.tmdnet_debug_gemm.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]
+    L.tmdnet_param_grad_count.argtypes = [vp]
+    L.tmdnet_param_grad_entry.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    L.tmdnet_param_grad_entry.restype = C.c_char_p
+    L.tmdnet_train_workspace_bytes.argtypes = [vp, i64, i64, i64, C.POINTER(sz), C.POINTER(sz), C.POINTER(i64)]
+    L.tmdnet_energy_param_grads.argtypes = [vp, vp, vp, vp, sz, vp, sz, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     abi = int(re.search(r"#define\s+TMDNET_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read()).group(1))
     if L.tmdnet_abi_version() != abi:
         raise ImportError(f"{LIB_PATH} has ABI revision {L.tmdnet_abi_version()}, include/tmdnet_amd.h declares {abi}: rebuild")

@@ -304,6 +304,40 @@ class _EngineState:
         self.__init__()
 
 
+class _EnergyParamGrad(torch.autograd.Function):
+    """E(theta) with d/d theta from the engine's parameter-gradient pass (TorchMD_Net.parameter_gradients_of)."""
+
+    @staticmethod
+    def forward(ctx, model, z, pos, batch, box, q, n_mol, *params):
+        energy, _ = model.energy_and_forces(z, pos, batch, box, q, n_mol, want_forces=False)
+        ctx.model, ctx.n_mol, ctx.params = model, n_mol, params
+        ctx.save_for_backward(z, pos, batch, *(t for t in (box, q) if t is not None))
+        ctx.has = (box is not None, q is not None)
+        return energy
+
+    @staticmethod
+    def backward(ctx, g_energy):
+        z, pos, batch, *rest = ctx.saved_tensors
+        box = rest.pop(0) if ctx.has[0] else None
+        q = rest.pop(0) if ctx.has[1] else None
+        _, grads = ctx.model.parameter_gradients_of(z, pos, batch, box, q, ctx.n_mol, g_energy)
+        out = []
+        for p in ctx.params:
+            g = grads.get(p)
+            out.append(None if g is None or not p.requires_grad else g.to(p.dtype).reshape(p.shape))
+        return (None,) * 7 + tuple(out)
+
+
+def _energy_with_parameter_gradients(model, z, pos, batch, box, q, n_mol):
+    if not getattr(model._engine, "train_options", False):
+        # the weights change every step: evaluate the radial functions directly instead of re-tabulating them per step
+        model.set_engine_option("edge_table_min_pairs", 1e15)
+        model.set_engine_option("embed_rb_min_atoms", 1e15)
+        model._engine.train_options = True
+    params = [p for p in model.parameters() if p.requires_grad]
+    return _EnergyParamGrad.apply(model, z, pos, batch, box, q, n_mol, *params)
+
+
 class TorchMD_Net(nn.Module):
     """Representation + output head + priors (reference model.py:451-631), evaluated by one fused HIP schedule."""
 
@@ -331,6 +365,10 @@ class TorchMD_Net(nn.Module):
         self.pair_storage = "fp32"  # "bf16": Equivariant Transformer pair rows in reduced-precision storage (create_model)
         self.static_check = True  # static_shapes mode: poll the overflow flag after every non-captured call
         self.cell_list_min_atoms = 1024  # single periodic systems at least this large use the O(N) cell list
+        # True: `y` carries an autograd graph to the PARAMETERS (energy-only training, TensorNet + Scalar): loss(y).backward()
+        # fills .grad of every weight from the engine's parameter-gradient pass.  The reference needs no switch (autograd
+        # records everything); here the default call stays on the inference schedule (radial tables, no saved activations)
+        self.parameter_gradients = False
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -496,6 +534,95 @@ class TorchMD_Net(nn.Module):
             L.tmdnet_set_option(handle, name.encode(), value)
         st.fingerprint = fp
         return st
+
+    # ---------------------------------------------------------------- parameter gradients (energy-only training)
+    def _grad_targets(self):
+        """engine gradient entry -> parameter(s) it belongs to (reference state-dict layout)"""
+        rm, on = self.representation_model, self.output_model.output_network
+        te = rm.tensor_embedding
+        m = {"Ue%d" % k: te.linears_tensor[k].weight for k in range(3)}
+        m.update({"L1": te.linears_scalar[0].weight, "bL1": te.linears_scalar[0].bias, "L2": te.linears_scalar[1].weight,
+                  "bL2": te.linears_scalar[1].bias, "ln0_w": te.init_norm.weight, "ln0_b": te.init_norm.bias,
+                  "lnr_w": rm.out_norm.weight, "lnr_b": rm.out_norm.bias, "Lin": rm.linear.weight, "bLin": rm.linear.bias,
+                  "O1": on.layers[0].weight, "bO1": on.layers[0].bias, "O2": on.layers[2].weight, "bO2": on.layers[2].bias})
+        for l, layer in enumerate(rm.layers):
+            for k in range(3):
+                m["l%d.M%d" % (l, k)] = layer.linears_scalar[k].weight
+                m["l%d.b%d" % (l, k)] = layer.linears_scalar[k].bias
+                m["l%d.Va%d" % (l, k)] = layer.linears_tensor[k].weight
+                m["l%d.Vb%d" % (l, k)] = layer.linears_tensor[3 + k].weight
+        return m
+
+    def parameter_gradients_of(self, z, pos, batch, box, q, n_mol, grad_energy):
+        """d(sum_m grad_energy[m] E_m)/d theta for every weight of TensorNet + Scalar: (E [n_mol], {parameter: gradient}).
+        One engine call (tmdnet_energy_param_grads): forward with every pre-activation kept, reverse pass with the weight
+        gradients taken where an adjoint meets its input; the species tables' gradients are chained to emb / emb2 here."""
+        if self._is_et() or self._is_tn2():
+            raise NotImplementedError("parameter gradients: TensorNet + Scalar only")
+        L = _C.lib()
+        dev = pos.device
+        with torch.cuda.device(dev):
+            st = self._sync_engine()
+            stream = _stream_ptr(dev)
+            n = int(z.shape[0])
+            p32 = pos.detach().to(torch.float32).contiguous()
+            z = z.contiguous()
+            batch = batch.to(torch.long).contiguous()
+            box_mode = 0
+            if box is not None:
+                box = box.detach().to(device=dev, dtype=torch.float32).contiguous()
+                box_mode = 1 if box.dim() == 2 else 2
+            if q is not None:
+                q = q.detach().to(device=dev, dtype=torch.float32).contiguous()
+            L.tmdnet_set_cell_grid(st.handle, 0, 0, 0)  # brute force inside each molecule (atoms keep their order)
+            nbytes = C.c_size_t(0)
+            L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
+            st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
+            counts = (C.c_int64 * 8)()
+            rc = L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32), _ptr(batch),
+                                      _ptr(z), _ptr(box), box_mode, counts)
+            self._raise_bad_indices(counts, L.tmdnet_last_error(st.handle).decode())
+            if rc != _C.OK:
+                raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
+            n_pairs = int(counts[0])
+            fwd_b, trn_b, gfl = C.c_size_t(0), C.c_size_t(0), C.c_int64(0)
+            rc = L.tmdnet_train_workspace_bytes(st.handle, n, n_mol, n_pairs, C.byref(fwd_b), C.byref(trn_b), C.byref(gfl))
+            if rc != _C.OK:
+                raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
+            st.fwd_ws = self._grow(st.fwd_ws, fwd_b.value, dev)
+            st.train_ws = self._grow(getattr(st, "train_ws", None), trn_b.value, dev)
+            energy = torch.empty(n_mol, dtype=torch.float32, device=dev)
+            flat = torch.empty(gfl.value, dtype=torch.float32, device=dev)
+            ge = grad_energy.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+            assert ge.numel() == n_mol
+            rc = L.tmdnet_energy_param_grads(st.handle, stream, _ptr(st.graph_ws), _ptr(st.fwd_ws), st.fwd_ws.numel(),
+                                             _ptr(st.train_ws), st.train_ws.numel(), n, n_mol, n_pairs, _ptr(z), _ptr(batch), _ptr(q),
+                                             _ptr(ge), _ptr(energy), _ptr(flat))
+            if rc != _C.OK:
+                raise RuntimeError(f"tmdnet_energy_param_grads: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
+            ent = {}
+            for i in range(L.tmdnet_param_grad_count(st.handle)):
+                off, numel = C.c_int64(0), C.c_int64(0)
+                name = L.tmdnet_param_grad_entry(st.handle, i, C.byref(off), C.byref(numel)).decode()
+                ent[name] = flat[off.value: off.value + numel.value]
+            grads = {p: ent[k].view_as(p) for k, p in self._grad_targets().items()}
+            te = self.representation_model.tensor_embedding
+            F = te.emb.weight.shape[1]
+            Wdp, bdp = ent["Wdp"].view(3, F, -1), ent["bdp"].view(3, F)
+            for k, proj in enumerate((te.distance_proj1, te.distance_proj2, te.distance_proj3)):
+                grads[proj.weight], grads[proj.bias] = Wdp[k], bdp[k]
+            # species tables U[z] = emb[z] Wa^T + b, V[z] = emb[z] Wb^T with emb2.weight = [Wa | Wb] (reference tensornet.py:526-541)
+            dU, dV = ent["Utab"].view(-1, F), ent["Vtab"].view(-1, F)
+            emb, w2 = te.emb.weight.detach().float(), te.emb2.weight.detach().float()
+            grads[te.emb.weight] = dU @ w2[:, :F] + dV @ w2[:, F:]
+            grads[te.emb2.weight] = torch.cat([dU.t() @ emb, dV.t() @ emb], dim=1)
+            grads[te.emb2.bias] = dU.sum(0)
+            if self.prior_model is not None:  # Atomref: E_m += sum_i atomref[z_i]
+                for pr in self.prior_model:
+                    if pr.enable:
+                        w = pr.atomref.weight
+                        grads[w] = torch.zeros(w.shape[0], dtype=torch.float32, device=dev).index_add_(0, z, ge[batch]).view_as(w)
+        return energy, grads
 
     def _grow(self, buf, nbytes, device):
         if buf is None or buf.numel() < nbytes or buf.device != device:
@@ -702,6 +829,11 @@ class TorchMD_Net(nn.Module):
             box = rm.distance.box
         want_forces = bool(self.derivative or (pos.requires_grad and torch.is_grad_enabled()))
         _require_cuda(pos, "TorchMD_Net.forward")
+        if self.parameter_gradients and torch.is_grad_enabled():
+            if want_forces:
+                raise NotImplementedError("parameter_gradients=True covers energy-only training: set derivative=False and pass "
+                                          "positions that do not require grad (force-matching needs the second-order pass)")
+            return _energy_with_parameter_gradients(self, z, pos, batch, box, q, n_mol).view(-1, 1), torch.empty(0, device=pos.device)
         if self._engine.op_key is None:
             self._engine.op_key = ops.register_engine(self)
         # one registered torch op (fake + autograd registered, torchmdnet_amd/ops.py): torch.compile / torch.export trace
