@@ -110,6 +110,51 @@ def test_energy_only_training_through_autograd(hip_lib):
     assert (y2.cpu() - Er).abs().max() / Er.abs().max() < REL
 
 
+def _oracle_force_matching_grads(model, args, z, pos, batch, R, ge):
+    """d/d theta of  sum_i R_i . F_i + sum_m ge_m E_m  by double backward over the oracle in fp64"""
+    from oracle import tensornet_torch as T
+
+    sd = {k: v.detach().cpu().double().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    p = pos.double().clone().requires_grad_(True)
+    y = T.energy(sd, T.hparams_from_args(args), z, p, batch)
+    (dy,) = torch.autograd.grad(y.sum(), p, create_graph=True)
+    loss = (-dy * R.double()).sum() + (y.view(-1) * ge.double()).sum()
+    loss.backward()
+    return {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+
+@pytest.mark.parametrize("order,bound", [(2, 2e-3), (4, 1e-3)])
+def test_force_matching_gradients_by_central_difference(hip_lib, order, bound):
+    """derivative=True + parameter_gradients=True: the force output carries a graph to the weights whose backward is a central
+    difference of the exact parameter gradient along d loss / d F.  Against the analytic double backward of the oracle (fp64)
+    the error is dominated by fp32 rounding / step size: bounds stated here, measured values written to gpurun_out/."""
+    import json, os
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.TINY_ARGS, derivative=True)
+    torch.manual_seed(17)
+    model = create_model(dict(args)).to("cuda")
+    model.parameter_gradients = True
+    model.force_gradient_order = order
+    z, pos, batch = _ragged([22, 35, 9], seed=1300)
+    R = torch.randn(pos.shape, generator=torch.Generator().manual_seed(3))
+    ge = torch.tensor([0.7, -1.1, 0.4])
+    y, F = model(z.cuda(), pos.cuda(), batch.cuda())
+    loss = (F * R.cuda()).sum() + (y.view(-1) * ge.cuda()).sum()
+    loss.backward()
+    ref = _oracle_force_matching_grads(model, args, z, pos, batch, R, ge)
+    errs = {}
+    for k, p in model.named_parameters():
+        if k in ref and ref[k].abs().max() > 0:
+            assert p.grad is not None, k
+            errs[k] = (p.grad.cpu().double() - ref[k]).abs().max().item() / ref[k].abs().max().item()
+    worst = max(errs, key=errs.get)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/force_gradient_fd_order{order}.json", "w") as fh:
+        json.dump({"order": order, "step": model.force_gradient_step or (0.02 if order == 4 else 0.005), "worst": [worst, errs[worst]], "errors": errs}, fh, indent=1)
+    assert errs[worst] < bound, (worst, errs[worst])
+
+
 def test_parameter_gradients_refuse_what_they_do_not_cover(hip_lib):
     from torchmdnet_amd.models.model import create_model
 
@@ -117,7 +162,8 @@ def test_parameter_gradients_refuse_what_they_do_not_cover(hip_lib):
     z, pos, batch = _ragged([10], seed=1)
     with pytest.raises(NotImplementedError):
         et.parameter_gradients_of(z.cuda(), pos.cuda(), batch.cuda(), None, None, 1, torch.ones(1).cuda())
-    tn = create_model(dict(W.TINY_ARGS, derivative=True)).to("cuda")
-    tn.parameter_gradients = True
+    tn2 = create_model(dict(W.TINY_ARGS, model="tensornet2", output_model="ScalarPlusWeightedCoulomb", q_dim=4, q_weights=[1.0, 0.5, 2.0],
+                            derivative=False)).to("cuda")
+    tn2.parameter_gradients = True
     with pytest.raises(NotImplementedError):
-        tn(z.cuda(), pos.cuda(), batch.cuda())
+        tn2(z.cuda(), pos.cuda(), batch.cuda(), q=torch.zeros(1).cuda())

@@ -328,14 +328,67 @@ class _EnergyParamGrad(torch.autograd.Function):
         return (None,) * 7 + tuple(out)
 
 
-def _energy_with_parameter_gradients(model, z, pos, batch, box, q, n_mol):
+def _training_options(model):
     if not getattr(model._engine, "train_options", False):
         # the weights change every step: evaluate the radial functions directly instead of re-tabulating them per step
         model.set_engine_option("edge_table_min_pairs", 1e15)
         model.set_engine_option("embed_rb_min_atoms", 1e15)
         model._engine.train_options = True
-    params = [p for p in model.parameters() if p.requires_grad]
-    return _EnergyParamGrad.apply(model, z, pos, batch, box, q, n_mol, *params)
+
+
+class _EnergyForceParamGrad(torch.autograd.Function):
+    """(E, F)(theta): d E / d theta exact (parameter-gradient pass); d (g_F . F) / d theta = - d/d theta of the directional
+    derivative of sum_m E_m along v = g_F, taken as a central difference of the exact parameter gradient at pos +- h v / max|v|
+    (order 2: two extra passes, order 4: four; `model.force_gradient_step` = h in Angstrom, `model.force_gradient_order`).
+    The reference differentiates twice analytically (create_graph=True, model.py:618-628 + the *_bwd_bwd kernels); this is a
+    numerical stand-in with a stated accuracy (tests/test_gpu_train.py), not a parity path."""
+
+    @staticmethod
+    def forward(ctx, model, z, pos, batch, box, q, n_mol, *params):
+        energy, forces = model.energy_and_forces(z, pos, batch, box, q, n_mol, want_forces=True)
+        ctx.model, ctx.n_mol, ctx.params = model, n_mol, params
+        ctx.save_for_backward(z, pos, batch, forces, *(t for t in (box, q) if t is not None))
+        ctx.has = (box is not None, q is not None)
+        return energy, forces
+
+    @staticmethod
+    def backward(ctx, g_energy, g_forces):
+        z, pos, batch, forces, *rest = ctx.saved_tensors
+        box = rest.pop(0) if ctx.has[0] else None
+        q = rest.pop(0) if ctx.has[1] else None
+        model, n_mol = ctx.model, ctx.n_mol
+        total = {}
+
+        def add(grads, w):
+            for p, g in grads.items():
+                total[p] = g * w if p not in total else total[p] + g * w
+
+        if g_energy is not None and bool((g_energy != 0).any()):
+            add(model.parameter_gradients_of(z, pos, batch, box, q, n_mol, g_energy)[1], 1.0)
+        g_pos = None
+        if g_energy is not None:
+            g_pos = -g_energy.reshape(-1)[batch].unsqueeze(1) * forces  # first order in pos (as tmdnet::energy_forces' backward)
+        if g_forces is not None and bool((g_forces != 0).any()):
+            v = g_forces.detach().to(torch.float32)
+            scale = v.abs().max()
+            vh = v / scale
+            order = int(getattr(model, "force_gradient_order", 2))
+            h = getattr(model, "force_gradient_step", None)
+            h = float(h) if h else (0.02 if order >= 4 else 0.005)  # measured optimum of each order (profiles/r03_notes.md)
+            ones = torch.ones(n_mol, dtype=torch.float32, device=pos.device)
+            p0 = pos.detach()
+            G = lambda t: model.parameter_gradients_of(z, p0 + t * vh, batch, box, q, n_mol, ones)[1]
+            if order >= 4:  # (-f(2h) + 8 f(h) - 8 f(-h) + f(-2h)) / 12h
+                for t, w in ((2 * h, -1.0), (h, 8.0), (-h, -8.0), (-2 * h, 1.0)):
+                    add(G(t), -float(scale) * w / (12 * h))
+            else:
+                add(G(h), -float(scale) / (2 * h))
+                add(G(-h), float(scale) / (2 * h))
+        out = []
+        for p in ctx.params:
+            g = total.get(p)
+            out.append(None if g is None or not p.requires_grad else g.to(p.dtype).reshape(p.shape))
+        return (None, None, g_pos, None, None, None, None) + tuple(out)
 
 
 class TorchMD_Net(nn.Module):
@@ -365,10 +418,13 @@ class TorchMD_Net(nn.Module):
         self.pair_storage = "fp32"  # "bf16": Equivariant Transformer pair rows in reduced-precision storage (create_model)
         self.static_check = True  # static_shapes mode: poll the overflow flag after every non-captured call
         self.cell_list_min_atoms = 1024  # single periodic systems at least this large use the O(N) cell list
-        # True: `y` carries an autograd graph to the PARAMETERS (energy-only training, TensorNet + Scalar): loss(y).backward()
-        # fills .grad of every weight from the engine's parameter-gradient pass.  The reference needs no switch (autograd
-        # records everything); here the default call stays on the inference schedule (radial tables, no saved activations)
+        # True: the outputs carry an autograd graph to the PARAMETERS (TensorNet + Scalar): loss(y, F).backward() fills .grad of
+        # every weight - d y / d theta exactly from the engine's parameter-gradient pass, d F / d theta as a central difference
+        # of it along d loss / d F (force matching; step / order below).  The reference needs no switch (autograd records
+        # everything); here the default call stays on the inference schedule (radial tables, no saved activations)
         self.parameter_gradients = False
+        self.force_gradient_step = None  # Angstrom: largest atom displacement of the finite-difference direction (None: 0.005 / 0.02)
+        self.force_gradient_order = 2    # 2: two extra passes ; 4: four (Richardson)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -830,10 +886,14 @@ class TorchMD_Net(nn.Module):
         want_forces = bool(self.derivative or (pos.requires_grad and torch.is_grad_enabled()))
         _require_cuda(pos, "TorchMD_Net.forward")
         if self.parameter_gradients and torch.is_grad_enabled():
-            if want_forces:
-                raise NotImplementedError("parameter_gradients=True covers energy-only training: set derivative=False and pass "
-                                          "positions that do not require grad (force-matching needs the second-order pass)")
-            return _energy_with_parameter_gradients(self, z, pos, batch, box, q, n_mol).view(-1, 1), torch.empty(0, device=pos.device)
+            if self._is_et() or self._is_tn2():
+                raise NotImplementedError("parameter gradients: TensorNet + Scalar only")
+            _training_options(self)
+            params = [p for p in self.parameters() if p.requires_grad]
+            if want_forces:  # force matching: forces carry a (finite-difference) graph to the parameters as well
+                energy, forces = _EnergyForceParamGrad.apply(self, z, pos, batch, box, q, n_mol, *params)
+                return energy.view(-1, 1), (forces if self.derivative else torch.empty(0, device=pos.device))
+            return _EnergyParamGrad.apply(self, z, pos, batch, box, q, n_mol, *params).view(-1, 1), torch.empty(0, device=pos.device)
         if self._engine.op_key is None:
             self._engine.op_key = ops.register_engine(self)
         # one registered torch op (fake + autograd registered, torchmdnet_amd/ops.py): torch.compile / torch.export trace
