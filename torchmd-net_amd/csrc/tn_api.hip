@@ -1113,14 +1113,16 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   if (!m->finalized) return fail(m, TMDNET_ERR_STATE, "parameters not finalised");
   if (want_forces && !forces) return TMDNET_ERR_INVALID;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (!m->train)  // the parameter-gradient pass evaluates the radial functions directly (its weights change every step)
-    if (const int rc_tab = ensure_radial_tables(m, s)) return rc_tab;
   const tmdnet_hparams& hp = m->hp;
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden;
   const int N = (int)n_atoms, B = (int)n_mol;
   const int64_t ecap = (int64_t)hp.max_num_neighbors * n_atoms;
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, nullptr);
   if (n_pairs > g.pcap) return fail(m, TMDNET_ERR_INVALID, "n_pairs out of range");
+  // stale radial tables are rebuilt here, by the first call that would use them (not by the parameter-gradient pass, whose
+  // weights change every step, nor while option "edge_table_min_pairs" keeps this system on the direct evaluation)
+  if (!m->train && (n_pairs >= 0 ? n_pairs : g.pcap) + 1 >= m->tab_min_pairs)
+    if (const int rc_tab = ensure_radial_tables(m, s)) return rc_tab;
   if (m->graph_is_cell && m->graph_cell_multi) batch = g.bat_c;  // several molecules renumbered in cell order: their internal batch
   if (m->et) {
     if (q) return fail(m, TMDNET_ERR_INVALID, "the Equivariant Transformer takes no total charge (reference torchmd_et.py:188-196)");
