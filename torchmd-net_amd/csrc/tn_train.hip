@@ -7,6 +7,8 @@
 // operand layout of that instruction - no LDS, no transposition), split over row slices with a fixed-order reduction of the
 // partial tiles (deterministic, no atomics).  Rows may be the (atom, component) rows of one irreducible type of a [N, 9, F]
 // tensor (RowMap).  These are not on the inference path; they are sized to be correct and reasonably fast, not tuned.
+#include <algorithm>
+
 #include "tn_common.h"
 #include "tn_kernels.h"
 #include "tn_train.h"
@@ -106,7 +108,9 @@ size_t train_part_floats(int R, int64_t out_elems) {
   int64_t slices = (R + 511) / 512;
   if (slices > 128) slices = 128;
   if (slices < 1) slices = 1;
-  return (size_t)(slices * out_elems);
+  const int64_t tn = slices * out_elems;                               // transposed products: <= 128 partial outputs
+  const int64_t cs = ((int64_t)R / 256 + 2) * std::min<int64_t>(out_elems, 4096);  // column sums: one partial row per 256 rows
+  return (size_t)std::max(tn, cs);
 }
 static int slices_of(int R) {
   int s = (R + 511) / 512;
@@ -127,29 +131,43 @@ void launch_tn_gemm(hipStream_t s, const float* A, RowMap ma, const float* B, Ro
 }
 
 // part[slice][c] = sum_{r in slice} A[r][c] * (B ? B[r][c] : 1) * (rs ? rs[r] : 1)
+// block = 64 columns x 4 row lanes over a slice of 256 rows (a thread adds every fourth row, the four lanes are summed in order)
+constexpr int CS_ROWS = 256;
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ A, RowMap ma, const float* __restrict__ B, RowMap mb,
                                                 const float* __restrict__ rs, const int* __restrict__ r_dev, int R, int ncol,
-                                                int rows_per_slice, float* __restrict__ part) {
+                                                float* __restrict__ part) {
+  __shared__ float red[3][64];
   if (r_dev) R = min(R, *r_dev);
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncol) return;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const int slice = blockIdx.y;
-  const int r_lo = slice * rows_per_slice, r_hi = min(R, r_lo + rows_per_slice);
+  const int r_lo = slice * CS_ROWS, r_hi = min(R, r_lo + CS_ROWS);
   float acc = 0.f;
-  for (int r = r_lo; r < r_hi; ++r) {
-    float v = A[row_off(ma, r) + c];
-    if (B) v *= B[row_off(mb, r) + c];
-    if (rs) v *= rs[r];
-    acc += v;
+  if (c < ncol) {
+    for (int r = r_lo + rl; r < r_hi; r += 16) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + 4 * u;
+        const bool ok = rr < r_hi;
+        const int rc = ok ? rr : r_lo;
+        float x = A[row_off(ma, rc) + c];
+        if (B) x *= B[row_off(mb, rc) + c];
+        if (rs) x *= rs[rc];
+        v[u] = ok ? x : 0.f;
+      }
+      acc += (v[0] + v[1]) + (v[2] + v[3]);
+    }
   }
-  part[(int64_t)slice * ncol + c] = acc;
+  if (rl > 0) red[rl - 1][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < ncol) part[(int64_t)slice * ncol + c] = ((acc + red[0][cl]) + red[1][cl]) + red[2][cl];
 }
 void launch_colsum(hipStream_t s, const float* A, RowMap ma, const float* B, RowMap mb, const float* rowscale, const int* r_dev, int R,
                    int ncol, float* out, bool accumulate, float* part) {
   if (ncol <= 0) return;
-  const int slices = R > 0 ? slices_of(R) : 1;
-  const int rps = R > 0 ? (R + slices - 1) / slices : 1;
-  hipLaunchKernelGGL(k_colsum, dim3((ncol + 255) / 256, slices), dim3(256), 0, s, A, ma, B, mb, rowscale, r_dev, R, ncol, rps, part);
+  const int slices = R > 0 ? (R + CS_ROWS - 1) / CS_ROWS : 1;
+  hipLaunchKernelGGL(k_colsum, dim3((ncol + 63) / 64, slices), dim3(256), 0, s, A, ma, B, mb, rowscale, r_dev, R, ncol, part);
   hipLaunchKernelGGL(k_reduce_slices, dim3((ncol + 255) / 256), dim3(256), 0, s, part, slices, (int64_t)ncol, accumulate ? 1 : 0, out);
 }
 
