@@ -313,6 +313,43 @@ def tn2_leg(dev, L, steps=8, warmup=3):
             "roofline": roofline_of(rec, cls, label), "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
 
 
+def training_leg(dev, L, steps=4, warmup=2):
+    """Training steps of the C2 model on the bench batch through the parameter-gradient pass: energy-only
+    (forward + tmdnet_energy_param_grads + SGD step with its parameter re-upload) and energy + forces (two more passes for the
+    difference quotient behind the force gradient).  Not the headline metric: a measured number for SURVEY 8(f)4."""
+    import torch
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    out = {"workload": "C2 model, S-mol64 256 x 64 atoms, one optimizer step (SGD) per step, random-init (seed 0)"}
+    z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS)
+    z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
+    for key, deriv in (("ms_per_step_energy_only", False), ("ms_per_step_energy_and_forces", True)):
+        torch.manual_seed(0)
+        model = create_model(dict(W.C2_ARGS, derivative=deriv)).to(dev)
+        model.parameter_gradients = True
+        opt = torch.optim.SGD(model.parameters(), lr=1e-7)
+
+        def step():
+            opt.zero_grad()
+            y, f = model(z, pos, batch)
+            loss = (y ** 2).mean() + ((f ** 2).mean() if deriv else 0.0)
+            loss.backward()
+            opt.step()
+            return loss
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize(dev)
+        assert torch.isfinite(loss)
+        out[key] = (time.perf_counter() - t0) / steps * 1e3
+    return out
+
+
 def cpu_baseline(args_dict, state_dict, budget_s=25.0):
     """Oracle (oracle/tensornet_torch.py: the reference's pure-PyTorch CPU algorithm, autograd forces; the unmodified
     reference cannot travel to the GPU box) on a bounded sample of the same workload, BASELINE.md section 3 protocol:
@@ -613,7 +650,7 @@ def main():
                 out["md_single_system"] = {"error": repr(exc)}
         if world == 1 and not a.no_aux:
             for key, leg in (("et_c4", et_c4_leg), ("et_c4_bf16", lambda d, l: et_c4_leg(d, l, pair_storage="bf16")),
-                             ("water10k", water10k_leg), ("tensornet2", tn2_leg)):
+                             ("water10k", water10k_leg), ("tensornet2", tn2_leg), ("training_c2", training_leg)):
                 try:
                     out[key] = leg(dev, L)
                 except Exception as exc:  # noqa: BLE001
