@@ -67,6 +67,43 @@ def test_parameter_gradients_match_oracle_autograd(hip_lib, name, extra, sizes, 
     assert torch.equal(E, E2) and all(torch.equal(grads[p], grads2[p]) for p in grads)
 
 
+def test_parameter_gradients_periodic_box_standardisation_atomref(hip_lib):
+    """one periodic (triclinic) box with minimum-image pairs, mean / std standardisation and an Atomref prior: std scales every
+    gradient, the prior's table gets d loss / d atomref[t] = sum of the seeds of the atoms of species t"""
+    from oracle import tensornet_torch as T
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.TINY_ARGS, prior_model="Atomref", prior_args={"max_z": 20}, cutoff_upper=4.0, max_num_neighbors=96)
+    torch.manual_seed(23)
+    model = create_model(dict(args), mean=torch.tensor(1.75), std=torch.tensor(0.375))
+    table = torch.randn(20, 1) * 3.0
+    with torch.no_grad():
+        model.prior_model[0].atomref.weight.copy_(table)
+    model = model.to("cuda")
+    z, pos, box = W.water_box(n_side=3, spacing=3.1)  # 81 atoms, L = 9.3 A > 2 rc
+    z = z % 19 + 1
+    box = box.clone()
+    box[1, 0], box[2, 0], box[2, 1] = 0.9, -0.6, 0.4  # lower-triangular triclinic cell
+    batch = torch.zeros_like(z)
+    ge = torch.tensor([0.8])
+    E, grads = model.parameter_gradients_of(z.cuda(), pos.cuda(), batch.cuda(), box.cuda(), None, 1, ge.cuda())
+    sd = {k: v.detach().cpu().double().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    at = table.double().requires_grad_(True)
+    y = T.energy(sd, T.hparams_from_args(args), z, pos.double(), batch, box=box.double(), atomref=at)
+    (y.view(-1) * ge.double()).sum().backward()
+    assert (E.cpu().double() - y.detach().view(-1)).abs().max() / y.detach().abs().max() < REL
+    by_name = {id(p): k for k, p in model.named_parameters()}
+    bad = {}
+    for p, g in grads.items():
+        key = by_name[id(p)]
+        r = at.grad if key.endswith("atomref.weight") else sd[key].grad
+        err = (g.cpu().double() - r.reshape(g.shape)).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        if not err < REL:
+            bad[key] = err
+    assert not bad, bad
+    assert any(by_name[id(p)].endswith("atomref.weight") for p in grads)
+
+
 def test_energy_only_training_through_autograd(hip_lib):
     """parameter_gradients=True: `loss(y).backward()` fills .grad like the reference's autograd does; a few optimizer steps on
     a toy regression lower the loss, and the inference schedule afterwards evaluates the trained weights"""
