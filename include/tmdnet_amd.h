@@ -256,7 +256,9 @@ int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float*
  * "Ue{k}", "L1", "bL1", "L2", "bL2", "ln0_w", "ln0_b" = tensor_embedding linears_tensor / linears_scalar / init_norm,
  * "l{l}.M{k}", "l{l}.b{k}" = layers.l.linears_scalar.k, "l{l}.Va{k}" / "l{l}.Vb{k}" = layers.l.linears_tensor.k / .(3+k),
  * "lnr_w", "lnr_b" = out_norm, "Lin", "bLin" = linear, "O1", "bO1", "O2", "bO2" = output_network.layers.0 / .2.
- * Needs a graph built with the exact pair count (tmdnet_build_graph, no cell list); deterministic; no position gradient. */
+ * Needs a graph built with the exact pair count (tmdnet_build_graph, no cell list); deterministic; no position gradient.
+ * Two-call form for autograd: grad_energy == NULL runs the forward half only (energies out, activations kept in ws / train_ws),
+ * a later call with energy == NULL and the same other arguments runs the reverse half on those workspaces. */
 int tmdnet_param_grad_count(tmdnet_model* m);
 const char* tmdnet_param_grad_entry(tmdnet_model* m, int idx, int64_t* offset, int64_t* numel);
 int tmdnet_train_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, size_t* fwd_bytes,

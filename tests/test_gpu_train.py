@@ -192,6 +192,33 @@ def test_force_matching_gradients_by_central_difference(hip_lib, order, bound):
     assert errs[worst] < bound, (worst, errs[worst])
 
 
+def test_two_forwards_before_one_backward(hip_lib):
+    """the forward half keeps its activations in the model's workspaces; a second forward (or any other engine call) before the
+    backward takes them away, and the backward of the first then repeats the pass from its inputs: same gradients either way"""
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.TINY_ARGS, derivative=False)
+    torch.manual_seed(31)
+    model = create_model(dict(args)).to("cuda")
+    model.parameter_gradients = True
+    za, pa, ba = _ragged([14, 9], seed=40)
+    zb, pb, bb = _ragged([21, 5, 12], seed=60)
+    ya, _ = model(za.cuda(), pa.cuda(), ba.cuda())
+    yb, _ = model(zb.cuda(), pb.cuda(), bb.cuda())
+    with torch.no_grad():
+        model.parameter_gradients = False
+        model(za.cuda(), pa.cuda(), ba.cuda())  # an inference call in between as well
+        model.parameter_gradients = True
+    (ya.sum() * 0.5 - yb.sum()).backward()
+    got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    _, ra = _oracle_grads(model, args, za, pa, ba, None, torch.full((2,), 0.5))
+    _, rb = _oracle_grads(model, args, zb, pb, bb, None, torch.full((3,), -1.0))
+    for k, g in got.items():
+        r = ra[k] + rb[k]
+        if r.abs().max() > 0:
+            assert (g.cpu().double() - r).abs().max().item() / r.abs().max().item() < REL, k
+
+
 def test_parameter_gradients_refuse_what_they_do_not_cover(hip_lib):
     from torchmdnet_amd.models.model import create_model
 

@@ -1190,117 +1190,122 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   TrainCtx* const tc = m->train;  // parameter gradients wanted: direct evaluation with every pre-activation kept
   const bool use_tab = !tc && m->tabs.ok && (int64_t)P1 >= m->tab_min_pairs && (int)m->tabs.tab.size() == 1 + L && L + 1 <= 8;
   hipStream_t es = s;
-  if (use_tab) {
-    // radial tables (tn_edge_table.hip): sort the pairs by distance, one streaming Hermite-interpolation kernel for all
-    // tables; no basis functions, no pair-row GEMMs in the step
-    const float* tabs[8];
-    float* outs[8];
-    float* douts[8];
-    int nt_ = 0;
-    if (!ntp) {  // Q(d) of the embedding: only when the per-pair form runs (the radial-basis form needs no per-pair rows)
-      tabs[nt_] = m->tabs.tab[0];
-      outs[nt_] = b.Q;
-      douts[nt_++] = want_forces ? b.dQ : nullptr;
-    }
-    for (int l = 0; l < L; ++l) {
-      tabs[nt_] = m->tabs.tab[1 + l];
-      outs[nt_] = b.w[l];
-      douts[nt_++] = want_forces ? b.dw[l] : nullptr;
-    }
-    const double rowB = 12.0 * Fd;
-    if (nt_ > 0)
-      KR(CAT_EDGE_TABLE, (Pd + 1) * (rowB * nt_ * (want_forces ? 2 : 1) + 24) + (double)(m->tabs.T + 2) * 2 * rowB * nt_,
-         (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
-          launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, nt_, tabs, outs, douts, b.skeys_s, b.svals_s, s, b.C,
-                             b.dC)));
-  } else {
-    // ---- radial functions per pair
-    RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
-    KR(CAT_ELEMENTWISE, Pd * (2 * K + 3) * 4, launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s));
-    // ---- edge MLPs of all layers: functions of the pair geometry only -> side stream (tn_model.h)
-    // only at batch scale: for a small system the cross-queue joins cost more than the overlap gives (graph replay of a
-    // 64-atom molecule 0.36 -> 0.40 ms, profiles/r01_notes.md)
-    es = (m->side && L > 0 && P >= 16384 && !tc) ? m->side : s;
-    if (es != s) {
-      HIP_TRY(m, hipEventRecord(m->ev_fork, s));
-      HIP_TRY(m, hipStreamWaitEvent(es, m->ev_fork, 0));
-    }
-    for (int l = 0; l < L; ++l) {
-      const LayerP& q_ = W.layer[l];
-      EDGE(1);
-      if (tc) {  // values only, pre-activations kept for the weight gradients
-        gemm(es, b.phi, K, q_.M1, K, q_.b1, tc->he1[l], F, P1, F, K, GEMM_ACT_SILU, tc->pre1[l], F);
-        gemm(es, tc->he1[l], F, q_.M2, F, q_.b2, tc->he2[l], 2 * F, P1, 2 * F, F, GEMM_ACT_SILU, tc->pre2[l], 2 * F);
-        gemm(es, tc->he2[l], 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, tc->pre3[l], 3 * F,
-             nullptr, 0, b.C);
-      } else if (want_forces) {
-        // edge MLP with its distance tangent carried forward (dw/dd): the reverse pass then needs no edge GEMM
-        gemm_dual(es, 1, b.phi, b.dphi, K, q_.M1, q_.b1, b.he1, b.te1, F, P1, F, K, nullptr, nullptr, q_.M_sb[0]);
-        gemm_dual(es, 1, b.he1, b.te1, F, q_.M2, q_.b2, b.he2, b.te2, 2 * F, P1, 2 * F, F, nullptr, nullptr, q_.M_sb[1]);
-        gemm_dual(es, 2, b.he2, b.te2, 2 * F, q_.M3, q_.b3, b.w[l], b.dw[l], 3 * F, P1, 3 * F, 2 * F, b.C, b.dC, q_.M_sb[2]);
-      } else {
-        gemm(es, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU);
-        gemm(es, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU);
-        gemm(es, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, nullptr, 0, nullptr, 0,
-             b.C);
-      }
-      if (es != s) HIP_TRY(m, hipEventRecord(m->ev_join[l], es));
-    }
-    // ---- embedding
-    // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
-    EDGE(1);
-    if (ntp) {
-    } else if (tc) gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
-    else if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);  // distance projections + d/dd
-    else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
-  }
   const RadialParams rbp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
   const double momB = (double)embed_rb_moment_elems(N, ntp ? ntp : 4, K) * 4;
-  if (ntp) {
-    // embedding in the radial basis (tn_embed_rb.hip): moments per (atom, species, component), then the per-atom contraction
-    KR(CAT_SCATTER, E_ * 12 + Pd * 48 + momB,
-       (launch_pair_scalars(g, P, hp.cutoff_lower, hp.cutoff_upper, b.ps, s), launch_embed_moments(g, N, rbp, ntp, b.ps, b.mom, s)));
-    KR(CAT_SCATTER, momB + Nd * 10 * Fd * 4, launch_embed_combine(g, N, F, K, ntp, z, W.Utab, W.Vtab, m->rb_fwd, b.mom, b.u0, b.s0n, s));
-  } else {
-    KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
-       launch_embed_scatter(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.u0, b.s0n, s));
-  }
-  KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s));
-  NODE();
-  gemm(s, b.ln0, F, W.L1, F, W.bL1, b.h1, 2 * F, N, 2 * F, F, GEMM_ACT_SILU, b.a1, 2 * F);
-  gemm(s, b.h1, 2 * F, W.L2, 2 * F, W.bL2, b.gates, 3 * F, N, 3 * F, 2 * F, GEMM_ACT_SILU, b.a2, 3 * F);
-  tensor_linear(s, b.u0, W.Ue, b.X[0], N, F, GEMM_MUL_AUX, b.UX, b.gates);
-  // ---- interaction layers
-  for (int l = 0; l < L; ++l) {
-    const LayerP& q_ = W.layer[l];
-    if (es != s) HIP_TRY(m, hipStreamWaitEvent(s, m->ev_join[l], 0));  // join: w[l] (and dw[l]) are ready
-    // X_hat of layer l > 0 was written by the previous layer's update kernel (in place over its own X_hat)
-    float* const Xh_l = tc ? tc->Xh[l] : b.Xh;  // kept per layer when parameter gradients are wanted
-    float* const Ch_l = tc ? tc->Ch[l] : b.Ch;
-    float* const Xh_n = tc && l + 1 < L ? tc->Xh[l + 1] : b.Xh;
-    if (l == 0) KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], Xh_l, N, F, s));
-    tensor_linear(s, Xh_l, q_.V, b.Pn[l], N, F);
-    KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s));
-    tensor_linear(s, Ch_l, q_.V + 3, b.D[l], N, F);
-    // update fused with the next consumer of the new X: the next layer's normalisation, or the readout invariants
-    KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(Xh_l, b.D[l], q, batch_k, N, F, b.X[l + 1], l + 1 < L ? 1 : 2,
-                                                       l + 1 < L ? Xh_n : b.feat, s));
-  }
-  // ---- readout + head + per-molecule sum
-  if (L == 0) KR(CAT_ELEMENTWISE, nodeB + Nd * 3 * Fd * 4, launch_readout_feat(b.X[L], N, F, b.feat, s));
-  KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_fwd(b.feat, W.lnr_w, W.lnr_b, N, 3 * F, b.lnr, b.xhr, b.rstdr, s));
-  NODE();
-  gemm(s, b.lnr, 3 * F, W.Lin, 3 * F, W.bLin, b.x, F, N, F, 3 * F, GEMM_ACT_SILU, b.al, F);
-  gemm(s, b.x, F, W.O1, F, W.bO1, b.ao, H, N, H, F);
-  if ((int64_t)N <= 256 * (int64_t)B) {  // small molecules: head + per-molecule sum in one launch (a block walks its molecule)
-    KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_mol_sum(g, b.ao, W.O2, W.bO2, N, B, H, W.std, W.atomref, z, batch, W.mean, energy, s,
-                                                        want_forces ? b.g_ao : nullptr));
-  } else {
-    KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s, want_forces ? b.g_ao : nullptr));
-    KR(CAT_ELEMENTWISE, Nd * 4, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
+  // the parameter-gradient pass may run the two halves as separate calls (TrainCtx::phase): forward with everything kept in the
+  // caller's workspaces, reverse once the seeds d loss / d E are known
+  const bool run_fwd = !tc || tc->phase != 2, run_bwd = !tc || tc->phase != 1;
+  if (run_fwd) {
+    if (use_tab) {
+      // radial tables (tn_edge_table.hip): sort the pairs by distance, one streaming Hermite-interpolation kernel for all
+      // tables; no basis functions, no pair-row GEMMs in the step
+      const float* tabs[8];
+      float* outs[8];
+      float* douts[8];
+      int nt_ = 0;
+      if (!ntp) {  // Q(d) of the embedding: only when the per-pair form runs (the radial-basis form needs no per-pair rows)
+        tabs[nt_] = m->tabs.tab[0];
+        outs[nt_] = b.Q;
+        douts[nt_++] = want_forces ? b.dQ : nullptr;
+      }
+      for (int l = 0; l < L; ++l) {
+        tabs[nt_] = m->tabs.tab[1 + l];
+        outs[nt_] = b.w[l];
+        douts[nt_++] = want_forces ? b.dw[l] : nullptr;
+      }
+      const double rowB = 12.0 * Fd;
+      if (nt_ > 0)
+        KR(CAT_EDGE_TABLE, (Pd + 1) * (rowB * nt_ * (want_forces ? 2 : 1) + 24) + (double)(m->tabs.T + 2) * 2 * rowB * nt_,
+           (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
+            launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, nt_, tabs, outs, douts, b.skeys_s, b.svals_s, s, b.C,
+                               b.dC)));
+    } else {
+      // ---- radial functions per pair
+      RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
+      KR(CAT_ELEMENTWISE, Pd * (2 * K + 3) * 4, launch_radial(g, P, rp, b.phi, b.dphi, b.C, b.dC, s));
+      // ---- edge MLPs of all layers: functions of the pair geometry only -> side stream (tn_model.h)
+      // only at batch scale: for a small system the cross-queue joins cost more than the overlap gives (graph replay of a
+      // 64-atom molecule 0.36 -> 0.40 ms, profiles/r01_notes.md)
+      es = (m->side && L > 0 && P >= 16384 && !tc) ? m->side : s;
+      if (es != s) {
+        HIP_TRY(m, hipEventRecord(m->ev_fork, s));
+        HIP_TRY(m, hipStreamWaitEvent(es, m->ev_fork, 0));
+      }
+      for (int l = 0; l < L; ++l) {
+        const LayerP& q_ = W.layer[l];
+        EDGE(1);
+        if (tc) {  // values only, pre-activations kept for the weight gradients
+          gemm(es, b.phi, K, q_.M1, K, q_.b1, tc->he1[l], F, P1, F, K, GEMM_ACT_SILU, tc->pre1[l], F);
+          gemm(es, tc->he1[l], F, q_.M2, F, q_.b2, tc->he2[l], 2 * F, P1, 2 * F, F, GEMM_ACT_SILU, tc->pre2[l], 2 * F);
+          gemm(es, tc->he2[l], 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, tc->pre3[l], 3 * F,
+               nullptr, 0, b.C);
+        } else if (want_forces) {
+          // edge MLP with its distance tangent carried forward (dw/dd): the reverse pass then needs no edge GEMM
+          gemm_dual(es, 1, b.phi, b.dphi, K, q_.M1, q_.b1, b.he1, b.te1, F, P1, F, K, nullptr, nullptr, q_.M_sb[0]);
+          gemm_dual(es, 1, b.he1, b.te1, F, q_.M2, q_.b2, b.he2, b.te2, 2 * F, P1, 2 * F, F, nullptr, nullptr, q_.M_sb[1]);
+          gemm_dual(es, 2, b.he2, b.te2, 2 * F, q_.M3, q_.b3, b.w[l], b.dw[l], 3 * F, P1, 3 * F, 2 * F, b.C, b.dC, q_.M_sb[2]);
+        } else {
+          gemm(es, b.phi, K, q_.M1, K, q_.b1, b.he1, F, P1, F, K, GEMM_ACT_SILU);
+          gemm(es, b.he1, F, q_.M2, F, q_.b2, b.he2, 2 * F, P1, 2 * F, F, GEMM_ACT_SILU);
+          gemm(es, b.he2, 2 * F, q_.M3, 2 * F, q_.b3, b.w[l], 3 * F, P1, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, nullptr, 0, nullptr, 0,
+               b.C);
+        }
+        if (es != s) HIP_TRY(m, hipEventRecord(m->ev_join[l], es));
+      }
+      // ---- embedding
+      // per-type tables: Zij = emb2([emb(z_i), emb(z_j)]) = U[z_i] + V[z_j]   (reference tensornet.py:526-541)
+      EDGE(1);
+      if (ntp) {
+      } else if (tc) gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
+      else if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);  // distance projections + d/dd
+      else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
+    }
+    if (ntp) {
+      // embedding in the radial basis (tn_embed_rb.hip): moments per (atom, species, component), then the per-atom contraction
+      KR(CAT_SCATTER, E_ * 12 + Pd * 48 + momB,
+         (launch_pair_scalars(g, P, hp.cutoff_lower, hp.cutoff_upper, b.ps, s), launch_embed_moments(g, N, rbp, ntp, b.ps, b.mom, s)));
+      KR(CAT_SCATTER, momB + Nd * 10 * Fd * 4, launch_embed_combine(g, N, F, K, ntp, z, W.Utab, W.Vtab, m->rb_fwd, b.mom, b.u0, b.s0n, s));
+    } else {
+      KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
+         launch_embed_scatter(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.u0, b.s0n, s));
+    }
+    KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s));
+    NODE();
+    gemm(s, b.ln0, F, W.L1, F, W.bL1, b.h1, 2 * F, N, 2 * F, F, GEMM_ACT_SILU, b.a1, 2 * F);
+    gemm(s, b.h1, 2 * F, W.L2, 2 * F, W.bL2, b.gates, 3 * F, N, 3 * F, 2 * F, GEMM_ACT_SILU, b.a2, 3 * F);
+    tensor_linear(s, b.u0, W.Ue, b.X[0], N, F, GEMM_MUL_AUX, b.UX, b.gates);
+    // ---- interaction layers
+    for (int l = 0; l < L; ++l) {
+      const LayerP& q_ = W.layer[l];
+      if (es != s) HIP_TRY(m, hipStreamWaitEvent(s, m->ev_join[l], 0));  // join: w[l] (and dw[l]) are ready
+      // X_hat of layer l > 0 was written by the previous layer's update kernel (in place over its own X_hat)
+      float* const Xh_l = tc ? tc->Xh[l] : b.Xh;  // kept per layer when parameter gradients are wanted
+      float* const Ch_l = tc ? tc->Ch[l] : b.Ch;
+      float* const Xh_n = tc && l + 1 < L ? tc->Xh[l + 1] : b.Xh;
+      if (l == 0) KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], Xh_l, N, F, s));
+      tensor_linear(s, Xh_l, q_.V, b.Pn[l], N, F);
+      KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s));
+      tensor_linear(s, Ch_l, q_.V + 3, b.D[l], N, F);
+      // update fused with the next consumer of the new X: the next layer's normalisation, or the readout invariants
+      KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(Xh_l, b.D[l], q, batch_k, N, F, b.X[l + 1], l + 1 < L ? 1 : 2,
+                                                         l + 1 < L ? Xh_n : b.feat, s));
+    }
+    // ---- readout + head + per-molecule sum
+    if (L == 0) KR(CAT_ELEMENTWISE, nodeB + Nd * 3 * Fd * 4, launch_readout_feat(b.X[L], N, F, b.feat, s));
+    KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_fwd(b.feat, W.lnr_w, W.lnr_b, N, 3 * F, b.lnr, b.xhr, b.rstdr, s));
+    NODE();
+    gemm(s, b.lnr, 3 * F, W.Lin, 3 * F, W.bLin, b.x, F, N, F, 3 * F, GEMM_ACT_SILU, b.al, F);
+    gemm(s, b.x, F, W.O1, F, W.bO1, b.ao, H, N, H, F);
+    if ((int64_t)N <= 256 * (int64_t)B) {  // small molecules: head + per-molecule sum in one launch (a block walks its molecule)
+      KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_mol_sum(g, b.ao, W.O2, W.bO2, N, B, H, W.std, W.atomref, z, batch, W.mean, energy, s,
+                                                          want_forces ? b.g_ao : nullptr));
+    } else {
+      KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s, want_forces ? b.g_ao : nullptr));
+      KR(CAT_ELEMENTWISE, Nd * 4, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
+    }
   }
 
-  if (want_forces) {
+  if (want_forces && run_bwd) {
     NODE();  // g_ao = d energy / d ao came out of the head kernel
     const RowMap rH = rows_plain(H), rF = rows_plain(F), r2F = rows_plain(2 * F), r3F = rows_plain(3 * F), rK = rows_plain(K);
     const RowMap rc_[3] = {rows_comp(F, 1), rows_comp(F, 3), rows_comp(F, 5)};  // (atom, component) rows of I / A / S in [N, 9, F]
@@ -1528,7 +1533,9 @@ int tmdnet_train_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t n_mol
 int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, void* train_ws, size_t train_bytes,
                               int64_t n_atoms, int64_t n_mol, int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q,
                               const float* grad_energy, float* energy, float* grads) {
-  if (!m || !graph_ws || !ws || !train_ws || !grad_energy || !energy || !grads) return TMDNET_ERR_INVALID;
+  // grad_energy == NULL: forward half only (energies out, every activation kept in ws / train_ws); energy == NULL: reverse half
+  // only, on the workspaces a forward-half call with the same arguments left behind; both given: one pass
+  if (!m || !graph_ws || !ws || !train_ws || (!grad_energy && !energy) || (grad_energy && !grads)) return TMDNET_ERR_INVALID;
   if (m->et || m->tn2) return fail(m, TMDNET_ERR_INVALID, "parameter gradients: TensorNet + Scalar only");
   if (n_pairs < 0) return fail(m, TMDNET_ERR_INVALID, "parameter gradients need the exact pair count (dynamic shapes)");
   if (m->graph_is_cell) return fail(m, TMDNET_ERR_STATE, "parameter gradients: build the graph without the cell list");
@@ -1543,9 +1550,11 @@ int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, voi
     tc.off[kv.first] = off;
     off += (kv.second + 63) & ~int64_t(63);
   }
-  launch_fill(grads, 0.f, off, reinterpret_cast<hipStream_t>(stream));
+  tc.phase = !grad_energy ? 1 : (!energy ? 2 : 0);
+  if (grads) launch_fill(grads, 0.f, off, reinterpret_cast<hipStream_t>(stream));
   m->train = &tc;
-  const int rc = tmdnet_energy_forces(m, stream, graph_ws, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, q, 1, energy, tc.forces);
+  float* e_out = energy ? energy : tc.forces;  // reverse half: the energies are not recomputed (scratch pointer, never written)
+  const int rc = tmdnet_energy_forces(m, stream, graph_ws, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, q, 1, e_out, tc.forces);
   m->train = nullptr;
   return rc;
 }

@@ -139,6 +139,7 @@ struct TableSpec {
 
 // parameter-gradient pass (tmdnet_energy_param_grads): seeds, output and the extra activations the reverse pass keeps per layer
 struct TrainCtx {
+  int phase = 0;              // 0: forward + reverse in one call, 1: forward only (activations kept), 2: reverse only
   const float* gE = nullptr;  // [B] d loss / d E_m (device)
   float* grads = nullptr;     // flat gradient buffer (device), layout = train_layout(m)
   std::map<std::string, int64_t> off;

@@ -305,22 +305,18 @@ class _EngineState:
 
 
 class _EnergyParamGrad(torch.autograd.Function):
-    """E(theta) with d/d theta from the engine's parameter-gradient pass (TorchMD_Net.parameter_gradients_of)."""
+    """E(theta) with d/d theta from the engine's parameter-gradient pass: forward half here (activations stay in the model's
+    workspaces), reverse half in backward - or the whole pass again if another call used the workspaces in between."""
 
     @staticmethod
     def forward(ctx, model, z, pos, batch, box, q, n_mol, *params):
-        energy, _ = model.energy_and_forces(z, pos, batch, box, q, n_mol, want_forces=False)
-        ctx.model, ctx.n_mol, ctx.params = model, n_mol, params
-        ctx.save_for_backward(z, pos, batch, *(t for t in (box, q) if t is not None))
-        ctx.has = (box is not None, q is not None)
+        energy, token = model._train_forward(z, pos, batch, box, q, n_mol, keep=True)
+        ctx.model, ctx.token, ctx.params = model, token, params
         return energy
 
     @staticmethod
     def backward(ctx, g_energy):
-        z, pos, batch, *rest = ctx.saved_tensors
-        box = rest.pop(0) if ctx.has[0] else None
-        q = rest.pop(0) if ctx.has[1] else None
-        _, grads = ctx.model.parameter_gradients_of(z, pos, batch, box, q, ctx.n_mol, g_energy)
+        grads = ctx.model._train_backward(ctx.token, g_energy)
         out = []
         for p in ctx.params:
             g = grads.get(p)
@@ -613,6 +609,13 @@ class TorchMD_Net(nn.Module):
         """d(sum_m grad_energy[m] E_m)/d theta for every weight of TensorNet + Scalar: (E [n_mol], {parameter: gradient}).
         One engine call (tmdnet_energy_param_grads): forward with every pre-activation kept, reverse pass with the weight
         gradients taken where an adjoint meets its input; the species tables' gradients are chained to emb / emb2 here."""
+        energy, token = self._train_forward(z, pos, batch, box, q, n_mol, keep=False)
+        return energy, self._train_backward(token, grad_energy)
+
+    def _train_forward(self, z, pos, batch, box, q, n_mol, keep=True):
+        """Forward half of the parameter-gradient pass.  keep=True: the activations stay in the model's workspaces and the
+        returned token lets `_train_backward` run the reverse half on them - unless another engine call used the workspaces
+        in between (the token's epoch no longer matches), in which case the pass is repeated from the inputs."""
         if self._is_et() or self._is_tn2():
             raise NotImplementedError("parameter gradients: TensorNet + Scalar only")
         L = _C.lib()
@@ -648,14 +651,40 @@ class TorchMD_Net(nn.Module):
             st.fwd_ws = self._grow(st.fwd_ws, fwd_b.value, dev)
             st.train_ws = self._grow(getattr(st, "train_ws", None), trn_b.value, dev)
             energy = torch.empty(n_mol, dtype=torch.float32, device=dev)
-            flat = torch.empty(gfl.value, dtype=torch.float32, device=dev)
+            token = dict(z=z, pos=p32, batch=batch, box=box, q=q, n=n, n_mol=n_mol, n_pairs=n_pairs, grad_floats=gfl.value, dev=dev,
+                         handle=st.handle.value, epoch=None, energy=energy)
+            if keep:
+                rc = L.tmdnet_energy_param_grads(st.handle, stream, _ptr(st.graph_ws), _ptr(st.fwd_ws), st.fwd_ws.numel(),
+                                                 _ptr(st.train_ws), st.train_ws.numel(), n, n_mol, n_pairs, _ptr(z), _ptr(batch), _ptr(q),
+                                                 None, _ptr(energy), None)
+                if rc != _C.OK:
+                    raise RuntimeError(f"tmdnet_energy_param_grads: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
+                st.ws_epoch = getattr(st, "ws_epoch", 0) + 1
+                token["epoch"] = st.ws_epoch
+        return energy, token
+
+    def _train_backward(self, token, grad_energy):
+        L = _C.lib()
+        dev = token["dev"]
+        z, batch, q, n, n_mol, n_pairs = token["z"], token["batch"], token["q"], token["n"], token["n_mol"], token["n_pairs"]
+        with torch.cuda.device(dev):
+            st = self._engine
+            stream = _stream_ptr(dev)
             ge = grad_energy.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
             assert ge.numel() == n_mol
+            flat = torch.empty(token["grad_floats"], dtype=torch.float32, device=dev)
+            kept = (token["epoch"] is not None and getattr(st, "ws_epoch", 0) == token["epoch"] and st.handle is not None
+                    and st.handle.value == token["handle"])
+            if not kept:  # the workspaces were reused (or never filled): rebuild the graph and run both halves
+                _, fresh = self._train_forward(z, token["pos"], batch, token["box"], q, n_mol, keep=False)
+                st = self._engine
+                n_pairs = fresh["n_pairs"]
             rc = L.tmdnet_energy_param_grads(st.handle, stream, _ptr(st.graph_ws), _ptr(st.fwd_ws), st.fwd_ws.numel(),
                                              _ptr(st.train_ws), st.train_ws.numel(), n, n_mol, n_pairs, _ptr(z), _ptr(batch), _ptr(q),
-                                             _ptr(ge), _ptr(energy), _ptr(flat))
+                                             _ptr(ge), None if kept else _ptr(token["energy"]), _ptr(flat))
             if rc != _C.OK:
                 raise RuntimeError(f"tmdnet_energy_param_grads: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
+            st.ws_epoch = getattr(st, "ws_epoch", 0) + 1
             ent = {}
             for i in range(L.tmdnet_param_grad_count(st.handle)):
                 off, numel = C.c_int64(0), C.c_int64(0)
@@ -678,7 +707,7 @@ class TorchMD_Net(nn.Module):
                     if pr.enable:
                         w = pr.atomref.weight
                         grads[w] = torch.zeros(w.shape[0], dtype=torch.float32, device=dev).index_add_(0, z, ge[batch]).view_as(w)
-        return energy, grads
+        return grads
 
     def _grow(self, buf, nbytes, device):
         if buf is None or buf.numel() < nbytes or buf.device != device:
@@ -754,6 +783,7 @@ class TorchMD_Net(nn.Module):
             st.fwd_ws = self._grow(st.fwd_ws, nbytes.value, dev)
             energy = torch.empty(n_mol, dtype=torch.float32, device=dev)
             forces = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_forces else None
+            st.ws_epoch = getattr(st, "ws_epoch", 0) + 1  # the workspaces of a pending parameter-gradient pass are gone
             rc = L.tmdnet_energy_forces(st.handle, stream, _ptr(st.graph_ws), _ptr(st.fwd_ws), st.fwd_ws.numel(), n, n_mol,
                                         n_pairs, _ptr(z), _ptr(batch), _ptr(q), int(want_forces), _ptr(energy), _ptr(forces))
             if rc != _C.OK:
