@@ -35,6 +35,7 @@ def _oracle_grads(model, args, z, pos, batch, q, ge, dtype=torch.float64):
     ("so3", dict(equivariance_invariance_group="SO(3)"), [9, 21, 14], False),
     ("wide", dict(embedding_dimension=128, num_rbf=32, num_layers=2), [40, 33, 64], True),
     ("one-layer-lower-cutoff", dict(num_layers=1, cutoff_lower=0.8, cutoff_upper=4.5), [25, 12], False),
+    ("odd-widths", dict(embedding_dimension=64, num_rbf=50, max_z=100, num_layers=3), [64, 64, 37, 64, 2], True),
 ])
 def test_parameter_gradients_match_oracle_autograd(hip_lib, name, extra, sizes, charges):
     from torchmdnet_amd.models.model import create_model
