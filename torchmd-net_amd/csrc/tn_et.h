@@ -44,6 +44,13 @@ void launch_et_attn_bwd(const Graph& g, int N, const EtAttnArgs& a, const float*
                         float* g_vec, float* gd2, float* gr2, hipStream_t s);
 void launch_et_pair_combine(const Graph& g, int Pcap, const float* gd2, const float* gr2, int nw, int64_t stride,
                             const float* gd_extra, float* gd, float* g_rhat, hipStream_t s);
+// parameter gradients: adjoints of the per-pair filter rows and of the neighbour embedding
+void launch_et_train_filter(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* slots,
+                            int64_t dir_stride, float* self_rows, hipStream_t s);
+void launch_et_train_gpre(const Graph& g, int P, int Wd, const float* slots, int64_t dir_stride, const float* self_sum, const float* pre,
+                          float* g_pre, hipStream_t s);
+void launch_et_train_nbr(const Graph& g, int N, int F, const int64_t* z, const float* embN, const float* Wn, const float* g_xcat,
+                         float* slots, int64_t dir_stride, float* gEN, hipStream_t s);
 int et_sweep_waves(int F);  // waves per block of the attention sweeps = partial-sum slots per pair direction
 void launch_et_cat_norm(const float* xsrc, int Fx, const float* u, int ldu, int Fn, int N, float* hcat, hipStream_t s);
 void launch_et_norm_bwd(const float* g_n, int ldg, const float* u, int ldu, int Fn, int N, float* g_u, int ldgu, hipStream_t s);

@@ -741,4 +741,108 @@ void launch_et_add(const float* in, float* out, int64_t n, hipStream_t s) {
 
 int et_sweep_waves(int F) { return bthreads(F) / 64; }
 
+
+// ---------------------------------------------------------------------------------------------- parameter gradients
+// Adjoint of the per-pair filter rows dkv[p] = silu(dk_proj phi) | silu(dv_proj phi) from the attention sweep: every directed
+// edge t <- s contributes once, as the TARGET role of k_et_attn_bwd (same arithmetic):
+//   g_dk = g_a q_t k_s ; g_dvx = cv g_sx vx_s ; g_dv1 = cv g_s1 v1_s ; g_dv2 = cv g_s2 v2_s
+// The two directed edges of a pair share the row: slots[direction][p][Wd]; the self pair's row is shared by every atom's self
+// edge: self_rows[t][Wd], summed over the atoms afterwards.  Block = target atom, thread = channel.
+__global__ void k_et_train_filter(Graph g, EtAttnArgs a, const float* __restrict__ g_xagg, const float* __restrict__ g_vagg,
+                                  float* __restrict__ slots, int64_t dir_stride, float* __restrict__ self_rows) {
+  const int r = blockIdx.x;
+  if (g.counts[2]) return;
+  const int F = a.F, c = threadIdx.x;
+  const bool live = c < F;
+  const int cc = live ? c : 0;
+  const int e0 = g.rowptr[r], e1 = g.rowptr[r + 1];
+  const int64_t F5 = 5 * (int64_t)F;
+  const float qr = a.qkv[(int64_t)r * F5 + cc];
+  const float gxr = live ? g_xagg[(int64_t)r * F + cc] : 0.f;
+  const float* gvr = g_vagg + (int64_t)r * 3 * F + cc;
+  const float gr0 = live ? gvr[0] : 0.f, gr1 = live ? gvr[F] : 0.f, gr2_ = live ? gvr[2 * F] : 0.f;
+  for (int e = e0; e < e1; ++e) {
+    const int j = g.col[e], p = g.epair[e];
+    const float sg = g.esign[e];
+    const float* jq = a.qkv + (int64_t)j * F5 + cc;
+    const float kj = jq[F], vxj = jq[2 * F], v1j = jq[3 * F], v2j = jq[4 * F];
+    const int64_t dkv_b = (int64_t)p * a.Wd;
+    const float C = a.C[p];
+    const float cv = a.vector_cutoff ? C : 1.0f, ca = a.vector_cutoff ? 1.0f : C;
+    const float dk = a.dk_off >= 0 ? a.dkv[dkv_b + a.dk_off + cc] : 1.f;
+    const float dvx = a.dv_off >= 0 ? a.dkv[dkv_b + a.dv_off + cc] : 1.f;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (sg != 0.f) {
+      p0 = sg * g.prhat[(int64_t)p * 3];
+      p1 = sg * g.prhat[(int64_t)p * 3 + 1];
+      p2 = sg * g.prhat[(int64_t)p * 3 + 2];
+    }
+    const float at = head_sum(live ? qr * kj * dk : 0.f, a.hd);
+    const float A = silu(at) * ca;
+    const float sx = vxj * cv * dvx;
+    const float* vj = a.vec + (int64_t)j * 3 * F + cc;
+    const float g_sx = gxr * A;
+    const float g_A = head_sum(gxr * sx, a.hd);
+    const float g_s1 = gr0 * vj[0] + gr1 * vj[F] + gr2_ * vj[2 * F];
+    const float g_s2 = -(gr0 * p0 + gr1 * p1 + gr2_ * p2);
+    const float g_a = g_A * silu_grad(at) * ca;
+    if (!live) continue;
+    float* row = sg != 0.f ? slots + (sg > 0.f ? 0 : dir_stride) + dkv_b : self_rows + (int64_t)r * a.Wd;
+    if (a.dk_off >= 0) row[a.dk_off + c] = g_a * qr * kj;
+    if (a.dv_off >= 0) {
+      row[a.dv_off + c] = cv * g_sx * vxj;
+      row[a.dv_off + F + c] = cv * g_s1 * v1j;
+      row[a.dv_off + 2 * F + c] = cv * g_s2 * v2j;
+    }
+  }
+}
+void launch_et_train_filter(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* slots,
+                            int64_t dir_stride, float* self_rows, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_train_filter, dim3(N), dim3(((a.F + 63) / 64) * 64), 0, s, g, a, g_xagg, g_vagg, slots, dir_stride, self_rows);
+}
+
+// g_pre[p] = (slot0[p] + slot1[p]) silu'(pre[p]) for the pairs, (sum of the atoms' self rows) silu'(pre[P]) for the self pair
+__global__ void k_et_train_gpre(Graph g, int Pcap, int Wd, const float* __restrict__ slots, int64_t dir_stride,
+                                const float* __restrict__ self_sum, const float* __restrict__ pre, float* __restrict__ g_pre) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int P = g.counts[0];
+  if (idx >= (int64_t)(P + 1) * Wd || idx >= (int64_t)(Pcap + 1) * Wd) return;
+  const int p = (int)(idx / Wd), c = (int)(idx - (int64_t)p * Wd);
+  const float gsum = p == P ? self_sum[c] : slots[idx] + slots[dir_stride + idx];
+  g_pre[idx] = gsum * silu_grad(pre[idx]);
+}
+void launch_et_train_gpre(const Graph& g, int P, int Wd, const float* slots, int64_t dir_stride, const float* self_sum, const float* pre,
+                          float* g_pre, hipStream_t s) {
+  const int64_t n = (int64_t)(P + 1) * Wd;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_et_train_gpre, dim3((unsigned)cdiv_(n, 256)), dim3(256), 0, s, g, P, Wd, slots, dir_stride, self_sum, pre, g_pre);
+}
+
+// neighbour embedding nbr[i] = sum_{j != i} Wn[p] embN[z_j]: adjoint of the filter rows per direction (g_nbr[i] embN[z_j]) and of
+// embN through the reverse edges (gEN[i] = sum_j g_nbr[j] Wn[p]: atom i is the source of the edge j <- i)
+__global__ void k_et_train_nbr(Graph g, int N, int F, const int64_t* __restrict__ z, const float* __restrict__ embN,
+                               const float* __restrict__ Wn, const float* __restrict__ g_xcat, float* __restrict__ slots,
+                               int64_t dir_stride, float* __restrict__ gEN) {
+  const int i = blockIdx.x;
+  if (g.counts[2]) return;
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  for (int c = threadIdx.x; c < F; c += blockDim.x) {
+    const float gi = g_xcat[(int64_t)i * 2 * F + F + c];
+    float acc = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int j = g.col[e], p = g.epair[e];
+      if (j == i) continue;
+      slots[(g.esign[e] > 0.f ? 0 : dir_stride) + (int64_t)p * F + c] = gi * embN[z[j] * F + c];
+      acc += g_xcat[(int64_t)j * 2 * F + F + c] * Wn[(int64_t)p * F + c];
+    }
+    gEN[(int64_t)i * F + c] = acc;
+  }
+}
+void launch_et_train_nbr(const Graph& g, int N, int F, const int64_t* z, const float* embN, const float* Wn, const float* g_xcat,
+                         float* slots, int64_t dir_stride, float* gEN, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_train_nbr, dim3(N), dim3(bthreads(F)), 0, s, g, N, F, z, embN, Wn, g_xcat, slots, dir_stride, gEN);
+}
+
 }  // namespace tn

@@ -408,6 +408,62 @@ int et_build_tables(tmdnet_model* m) {
   return build_radial_tables(m, m->tabs, specs, P.means, P.betas, K, hp.cutoff_lower, hp.cutoff_upper);
 }
 
+// parameter-gradient pass: gradient buffer layout and the extra buffers
+std::vector<std::pair<std::string, int64_t>> et_train_layout(const tmdnet_model* m) {
+  const tmdnet_et_hparams& hp = m->et->hp;
+  const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, F2 = F / 2, Wd = wd_of(hp), U = F + F2;
+  std::vector<std::pair<std::string, int64_t>> e = {{"emb", Z * F}};
+  if (hp.neighbor_embedding)
+    for (auto kv : std::vector<std::pair<std::string, int64_t>>{{"embN", Z * F}, {"Wn", F * K}, {"bn", F}, {"Wc", 2 * F * F}, {"bc", F}})
+      e.push_back(kv);
+  for (int l = 0; l < L; ++l) {
+    const std::string t = "l" + std::to_string(l) + ".";
+    for (auto kv : std::vector<std::pair<std::string, int64_t>>{{"ln_w", F}, {"ln_b", F}, {"Wqkv", 5 * F * F}, {"bqkv", 5 * F}, {"Wvp", 3 * F * F},
+                                                                 {"Wo", 3 * F * F}, {"bo", 3 * F}})
+      e.push_back({t + kv.first, kv.second});
+    if (Wd > 0) {
+      e.push_back({t + "Wdkv", Wd * K});
+      e.push_back({t + "bdkv", Wd});
+    }
+  }
+  for (auto kv : std::vector<std::pair<std::string, int64_t>>{{"lno_w", F}, {"lno_b", F}, {"W1u", U * F}, {"Wm1", 2 * F * F}, {"bm1", F},
+                                                               {"Wm2", F * F}, {"bm2", F}, {"W21", F2 * F2}, {"Wn1", F2 * F}, {"bn1", F2},
+                                                               {"Wn2", F2}, {"bn2", 1}})
+    e.push_back(kv);
+  return e;
+}
+void et_carve_train(void* ws, const tmdnet_model* m, int64_t N, int64_t P, TrainCtx* tc, size_t* total) {
+  const tmdnet_et_hparams& hp = m->et->hp;
+  const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, F2 = F / 2, P1 = P + 1;
+  const int64_t Wd = std::max<int64_t>(wd_of(hp), F);
+  Carver c(ws);
+  TrainCtx t;
+  for (int l = 0; l < L; ++l) {
+    t.pre3.push_back(c.take<float>(P1 * Wd));  // pre-activations of the filter rows
+    t.Ch.push_back(c.take<float>(N * F));      // xagg of the layer
+  }
+  t.g3 = c.take<float>(P1 * Wd);
+  t.gq = c.take<float>(2 * P1 * Wd);
+  t.selfq = c.take<float>(N * Wd);
+  t.self_gw = c.take<float>(Wd);
+  t.gZu = c.take<float>(N * F);
+  t.onehot = c.take<float>(N * Z);
+  t.head = c.take<float>(N * (F2 + 1));
+  t.forces = c.take<float>(N * 3);
+  const int64_t big = std::max<int64_t>({5 * F * F, Wd * K, Z * F, 2 * F * F});
+  t.part = c.take<float>((int64_t)train_part_floats((int)std::max<int64_t>(P1, 3 * N), big));
+  if (tc) {
+    const float* ge = tc->gE;
+    float* gr = tc->grads;
+    const int ph = tc->phase;
+    *tc = t;
+    tc->gE = ge;
+    tc->grads = gr;
+    tc->phase = ph;
+  }
+  if (total) *total = c.off;
+}
+
 int et_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int32_t want_forces,
                                size_t* bytes) {
   et_carve(nullptr, m->et->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes);
@@ -431,7 +487,8 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
 
   // ---------------- forward
   const int n_dkv = Wd > 0 ? L : 0;
-  const bool use_tab = m->tabs.ok && (int64_t)P1 >= m->tab_min_pairs &&
+  TrainCtx* const tc = m->train;  // parameter gradients: direct filters with their pre-activations kept, fp32 rows
+  const bool use_tab = !tc && m->tabs.ok && (int64_t)P1 >= m->tab_min_pairs &&
                        (int)m->tabs.tab.size() == n_dkv + (hp.neighbor_embedding ? 1 : 0) && !m->tabs.tab.empty();
   // reduced-precision STORAGE of the per-pair filter rows (option "pair_rows_bf16", BASELINE configs[3] "bf16"): dkv / tkv are
   // written by the table interpolation as bf16 and widened to fp32 when the sweeps load them; every product and sum stays fp32.
@@ -467,7 +524,7 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
   if (hp.neighbor_embedding) {
     EDGE(1);
     if (use_tab) {
-    } else if (want_forces) gemm_dual(s, 3, b.phi, b.dphi, K, W.Wn, W.bn, b.Wn, b.dWn, F, P1, F, K, b.C, b.dC, W.Wn_sb);
+    } else if (want_forces && !tc) gemm_dual(s, 3, b.phi, b.dphi, K, W.Wn, W.bn, b.Wn, b.dWn, F, P1, F, K, b.C, b.dC, W.Wn_sb);
     else gemm(s, b.phi, K, W.Wn, K, W.bn, b.Wn, F, P1, F, K, GEMM_ROWSCALE, nullptr, 0, nullptr, 0, b.C);  // energies only: no tangents
     KR(CAT_SCATTER, Ed * Fd * 8, launch_et_nbr_embed(g, N, F, z, W.emb, W.embN, b.Wn, b.xcat, s));
     NODE();
@@ -485,7 +542,8 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     gemm(s, b.vec[l], F, q.Wvp, F, nullptr, b.vp[l], 3 * F, 3 * N, 3 * F, F);
     if (Wd > 0 && !use_tab) {
       EDGE(1);
-      if (want_forces) gemm_dual(s, 1, b.phi, b.dphi, K, q.Wdkv, q.bdkv, b.dkv[l], b.tkv[l], Wd, P1, Wd, K, nullptr, nullptr, q.Wdkv_sb);
+      if (tc) gemm(s, b.phi, K, q.Wdkv, K, q.bdkv, b.dkv[l], Wd, P1, Wd, K, GEMM_ACT_SILU, tc->pre3[l], Wd);  // pre-activation kept
+      else if (want_forces) gemm_dual(s, 1, b.phi, b.dphi, K, q.Wdkv, q.bdkv, b.dkv[l], b.tkv[l], Wd, P1, Wd, K, nullptr, nullptr, q.Wdkv_sb);
       else gemm(s, b.phi, K, q.Wdkv, K, q.bdkv, b.dkv[l], Wd, P1, Wd, K, GEMM_ACT_SILU);
     }
     EtAttnArgs& a = aa[l];
@@ -494,9 +552,10 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
                    hp.vector_cutoff, 2 * (int64_t)P1, pbf};
     // algorithmic bytes (every distinct tensor once): dkv [P+1, Wd], qkv [N,5F], vec [N,3F] in; xagg [N,F],
     // vagg [N,3F] out; edge indices
-    KR(CAT_MESSAGE, (Pd + 1) * Wd * pB + Nd * Fd * 4 * 12 + Ed * 12, launch_et_attn_fwd(g, N, a, b.xagg, b.vagg, s));
+    float* const xagg_l = tc ? tc->Ch[l] : b.xagg;  // kept per layer when parameter gradients are wanted
+    KR(CAT_MESSAGE, (Pd + 1) * Wd * pB + Nd * Fd * 4 * 12 + Ed * 12, launch_et_attn_fwd(g, N, a, xagg_l, b.vagg, s));
     NODE();
-    gemm(s, b.xagg, F, q.Wo, F, q.bo, b.o[l], 3 * F, N, 3 * F, F);
+    gemm(s, xagg_l, F, q.Wo, F, q.bo, b.o[l], 3 * F, N, 3 * F, F);
     KR(CAT_ELEMENTWISE, Nd * Fd * 4 * 20,
        launch_et_update(b.x[l], b.vec[l], b.vp[l], b.o[l], b.vagg, N, F, b.x[l + 1], b.vec[l + 1], b.vdot[l], s));
   }
@@ -523,17 +582,48 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
   // ---------------- reverse (oracle/et_adjoint.py)
   if (want_forces) {
     NODE();
+    // parameter gradients: dW (+)= g_out^T in, db = colsum(g_out) wherever an adjoint meets its layer's input (tn_train.hip)
+    auto RP = [](int64_t ld) { return rows_plain(ld); };
+    auto dW = [&](const char* key, const float* gOut, int64_t ldg, const float* In, int64_t ldi, int R, int Nout, int Kin,
+                  const float* rs = nullptr, bool acc = false) {
+      launch_tn_gemm(s, gOut, RP(ldg), In, RP(ldi), rs, nullptr, R, Nout, Kin, tc->at(key), acc, tc->part);
+    };
+    auto dB = [&](const char* key, const float* gOut, int64_t ldg, int R, int ncol, const float* mul = nullptr, int64_t ldm = 0,
+                  const float* rs = nullptr, bool acc = false) {
+      launch_colsum(s, gOut, RP(ldg), mul, RP(ldm), rs, nullptr, R, ncol, tc->at(key), acc, tc->part);
+    };
+    if (tc) {
+      launch_train_seed(b.pre2, tc->gE, batch, N, F2, W.std, b.g_pre2, tc->head, s);  // rows of g_pre2 scaled by d loss / d E_mol
+      dB("Wn2", tc->head, F2 + 1, N, F2);
+      dB("bn2", tc->head + F2, F2 + 1, N, 1);
+      dW("Wn1", b.g_pre2, F2, b.hcat2, F, N, F2, F);
+      dB("bn1", b.g_pre2, F2, N, F2);
+    }
     gemm(s, b.g_pre2, F2, W.Wn1T, F2, nullptr, b.g_h2, F, N, F, F2);                       // (g_xs | g_n2)
     KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_et_norm_bwd(b.g_h2 + F2, F, b.w1, F2, F2, N, b.g_w1, F2, s));
+    if (tc) dW("W21", b.g_w1, F2, b.vq, F2, 3 * N, F2, F2);
     gemm(s, b.g_w1, F2, W.W21T, F2, nullptr, b.g_vq, F2, 3 * N, F2, F2);
     KR(CAT_ELEMENTWISE, Nd * Fd * 20,
        launch_et_head_mid_bwd(b.y, b.u12 + F, U, b.g_h2, b.g_vq, F2, N, b.g_y, b.g_u12 + F, U, s));
+    if (tc) {
+      dW("Wm2", b.g_y, F, b.m1, F, N, F, F);
+      dB("bm2", b.g_y, F, N, F);
+    }
     gemm(s, b.g_y, F, W.Wm2T, F, nullptr, b.g_m1, F, N, F, F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.pre1, F);
+    if (tc) {
+      dW("Wm1", b.g_m1, F, b.hcat, 2 * F, N, F, 2 * F);
+      dB("bm1", b.g_m1, F, N, F);
+    }
     gemm(s, b.g_m1, F, W.Wm1T, F, nullptr, b.g_h1, 2 * F, N, 2 * F, F);                    // (g_xf | g_n1)
     KR(CAT_ELEMENTWISE, Nd * Fd * 24, launch_et_norm_bwd(b.g_h1 + F, 2 * F, b.u12, U, F, N, b.g_u12, U, s));
+    if (tc) dW("W1u", b.g_u12, U, b.vec[L], F, 3 * N, U, F);
     gemm(s, b.g_u12, U, W.W1uT, U, nullptr, b.g_vec, F, 3 * N, F, U);
     // LayerNorm adjoint of out_norm: its input gradient is the first F columns of g_h1 (row stride 2F) -> compact copy
     KR(CAT_ELEMENTWISE, Nd * Fd * 8, launch_et_copy2d(b.g_h1, 2 * F, b.g_xf, F, N, F, s));
+    if (tc) {
+      dB("lno_w", b.g_xf, F, N, F, b.xfh, F);
+      dB("lno_b", b.g_xf, F, N, F);
+    }
     KR(CAT_ELEMENTWISE, Nd * Fd * 16, launch_layernorm_bwd(b.g_xf, b.xfh, b.rstdf, W.lno_w, N, F, b.g_x, s));
     const int nwv = et_sweep_waves(F);
     const int64_t sstride = 2 * (int64_t)P1;   // one slot array: [pair][direction]
@@ -544,24 +634,66 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
       NODE();
       KR(CAT_ELEMENTWISE, Nd * Fd * 4 * 28,
          launch_et_update_bwd(b.g_x, b.g_vec, b.vp[l], b.o[l], b.vdot[l], N, F, b.g_o, b.g_vp, s));
+      const std::string t_ = "l" + std::to_string(l) + ".";
+      if (tc) {
+        dW((t_ + "Wo").c_str(), b.g_o, 3 * F, tc->Ch[l], F, N, 3 * F, F);
+        dB((t_ + "bo").c_str(), b.g_o, 3 * F, N, 3 * F);
+        dW((t_ + "Wvp").c_str(), b.g_vp, 3 * F, b.vec[l], F, 3 * N, 3 * F, F);
+      }
       gemm(s, b.g_o, 3 * F, q.WoT, 3 * F, nullptr, b.g_xagg, F, N, F, 3 * F);
       // g_vagg = g_vec (read by both sweeps before sweep "s" adds the source terms into it: snapshot in vagg)
       KR(CAT_ELEMENTWISE, Nd * Fd * 24, launch_et_copy2d(b.g_vec, 3 * F, b.vagg, 3 * F, N, 3 * F, s));
       // dkv + tkv, qkv, vec, g_xagg, g_vagg in; g_qkv out, g_vec read + written; the (pair, direction) slots of g_d, g_rhat
       KR(CAT_PAIR, 2 * (Pd + 1) * Wd * pB + Nd * Fd * 4 * 23 + Ed * 12 + (Pd + 1) * 32 * nwv,
          launch_et_attn_bwd(g, N, aa[l], b.g_xagg, b.vagg, b.g_qkv, b.g_vec, b.gd2 + sstride * nwv * l, b.gr2 + 3 * sstride * nwv * l, s));
+      if (tc) {
+        if (Wd > 0) {  // filter rows: adjoint per directed edge -> per pair (self pair: summed over the atoms) -> dk_proj / dv_proj
+          const int64_t dir = (int64_t)P1 * Wd;
+          launch_et_train_filter(g, N, aa[l], b.g_xagg, b.vagg, tc->gq, dir, tc->selfq, s);
+          launch_colsum(s, tc->selfq, RP(Wd), nullptr, RP(Wd), nullptr, nullptr, N, Wd, tc->self_gw, false, tc->part);
+          launch_et_train_gpre(g, P, Wd, tc->gq, dir, tc->self_gw, tc->pre3[l], tc->g3, s);
+          dW((t_ + "Wdkv").c_str(), tc->g3, Wd, b.phi, K, P1, Wd, K);
+          dB((t_ + "bdkv").c_str(), tc->g3, Wd, P1, Wd);
+        }
+        dW((t_ + "Wqkv").c_str(), b.g_qkv, 5 * F, b.xt[l], F, N, 5 * F, F);
+        dB((t_ + "bqkv").c_str(), b.g_qkv, 5 * F, N, 5 * F);
+      }
       gemm(s, b.g_vp, 3 * F, q.WvpT, 3 * F, nullptr, b.g_vec, F, 3 * N, F, 3 * F, GEMM_ACCUM);
       gemm(s, b.g_qkv, 5 * F, q.WqkvT, 5 * F, nullptr, b.g_xt, F, N, F, 5 * F);
+      if (tc) {
+        dB((t_ + "ln_w").c_str(), b.g_xt, F, N, F, b.xh[l], F);
+        dB((t_ + "ln_b").c_str(), b.g_xt, F, N, F);
+      }
       KR(CAT_ELEMENTWISE, Nd * Fd * 16, launch_layernorm_bwd(b.g_xt, b.xh[l], b.rstd[l], q.ln_w, N, F, b.g_ln, s));
       KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_et_add(b.g_ln, b.g_x, (int64_t)N * F, s));
     }
     if (hp.neighbor_embedding) {
       gemm(s, b.g_x, F, W.WcT, F, nullptr, b.g_xcat, 2 * F, N, 2 * F, F);
-      KR(CAT_PAIR, Pd * Fd * 12, launch_et_nbr_embed_bwd(g, P, F, z, W.embN, b.g_xcat, b.dWn, gd_emb, s));
+      if (!tc) KR(CAT_PAIR, Pd * Fd * 12, launch_et_nbr_embed_bwd(g, P, F, z, W.embN, b.g_xcat, b.dWn, gd_emb, s));
     }
-    KR(CAT_PAIR, Pd * 48, launch_et_pair_combine(g, P, b.gd2, b.gr2, nwv * L, sstride, gd_emb, b.gd, b.g_rhat, s));
-    KR(CAT_PAIR, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s));
-    KR(CAT_PAIR, Ed * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
+    if (tc) {
+      const int Z = hp.max_z;
+      launch_onehot(z, N, Z, tc->onehot, s);
+      if (hp.neighbor_embedding) {
+        dW("Wc", b.g_x, F, b.xcat, 2 * F, N, F, 2 * F);
+        dB("bc", b.g_x, F, N, F);
+        dW("emb", tc->onehot, Z, b.g_xcat, 2 * F, N, Z, F);  // first half of g_xcat
+        const int64_t dir = (int64_t)P1 * F;
+        launch_et_train_nbr(g, N, F, z, W.embN, b.Wn, b.g_xcat, tc->gq, dir, tc->gZu, s);
+        dW("embN", tc->onehot, Z, tc->gZu, F, N, Z, F);
+        // Wn[p] = (distance_proj phi + b) C(d): both direction halves, rows scaled by the cutoff
+        dW("Wn", tc->gq, F, b.phi, K, P, F, K, b.C);
+        dW("Wn", tc->gq + dir, F, b.phi, K, P, F, K, b.C, true);
+        dB("bn", tc->gq, F, P, F, nullptr, 0, b.C);
+        dB("bn", tc->gq + dir, F, P, F, nullptr, 0, b.C, true);
+      } else {
+        dW("emb", tc->onehot, Z, b.g_x, F, N, Z, F);
+      }
+    } else {
+      KR(CAT_PAIR, Pd * 48, launch_et_pair_combine(g, P, b.gd2, b.gr2, nwv * L, sstride, gd_emb, b.gd, b.g_rhat, s));
+      KR(CAT_PAIR, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s));
+      KR(CAT_PAIR, Ed * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
+    }
   }
   m->et->last = b;
   m->et->lastN = N;

@@ -271,6 +271,8 @@ void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], floa
 // builds the radial tables if a parameter upload left them pending (blocking, NULL stream); refuses while `s` is being captured
 int ensure_radial_tables(tmdnet_model* m, hipStream_t s);
 int et_build_tables(tmdnet_model* m);  // tn_et_api.hip
+std::vector<std::pair<std::string, int64_t>> et_train_layout(const tmdnet_model* m);
+void et_carve_train(void* ws, const tmdnet_model* m, int64_t N, int64_t P, TrainCtx* tc, size_t* total);
 int build_radial_tables(tmdnet_model* m, EdgeTables& out, const std::vector<TableSpec>& specs, const float* means, const float* betas,
                         int K, double lo, double up);
 void free_radial_tables(EdgeTables& t);

@@ -310,7 +310,11 @@ class _EnergyParamGrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, z, pos, batch, box, q, n_mol, *params):
-        energy, token = model._train_forward(z, pos, batch, box, q, n_mol, keep=True)
+        if model._is_et():  # one-call form: energies from the inference schedule here, the whole pass in backward
+            energy, _ = model.energy_and_forces(z, pos, batch, box, q, n_mol, want_forces=False)
+            _, token = model._train_forward(z, pos, batch, box, q, n_mol, keep=False)
+        else:
+            energy, token = model._train_forward(z, pos, batch, box, q, n_mol, keep=True)
         ctx.model, ctx.token, ctx.params = model, token, params
         return energy
 
@@ -616,8 +620,10 @@ class TorchMD_Net(nn.Module):
         """Forward half of the parameter-gradient pass.  keep=True: the activations stay in the model's workspaces and the
         returned token lets `_train_backward` run the reverse half on them - unless another engine call used the workspaces
         in between (the token's epoch no longer matches), in which case the pass is repeated from the inputs."""
-        if self._is_et() or self._is_tn2():
-            raise NotImplementedError("parameter gradients: TensorNet + Scalar only")
+        if self._is_tn2():
+            raise NotImplementedError("parameter gradients: TensorNet and the Equivariant Transformer only")
+        if self._is_et():
+            keep, q = False, None  # one-call form only; TorchMD_ET.forward ignores q
         L = _C.lib()
         dev = pos.device
         with torch.cuda.device(dev):
@@ -690,23 +696,77 @@ class TorchMD_Net(nn.Module):
                 off, numel = C.c_int64(0), C.c_int64(0)
                 name = L.tmdnet_param_grad_entry(st.handle, i, C.byref(off), C.byref(numel)).decode()
                 ent[name] = flat[off.value: off.value + numel.value]
-            grads = {p: ent[k].view_as(p) for k, p in self._grad_targets().items()}
-            te = self.representation_model.tensor_embedding
-            F = te.emb.weight.shape[1]
-            Wdp, bdp = ent["Wdp"].view(3, F, -1), ent["bdp"].view(3, F)
-            for k, proj in enumerate((te.distance_proj1, te.distance_proj2, te.distance_proj3)):
-                grads[proj.weight], grads[proj.bias] = Wdp[k], bdp[k]
-            # species tables U[z] = emb[z] Wa^T + b, V[z] = emb[z] Wb^T with emb2.weight = [Wa | Wb] (reference tensornet.py:526-541)
-            dU, dV = ent["Utab"].view(-1, F), ent["Vtab"].view(-1, F)
-            emb, w2 = te.emb.weight.detach().float(), te.emb2.weight.detach().float()
-            grads[te.emb.weight] = dU @ w2[:, :F] + dV @ w2[:, F:]
-            grads[te.emb2.weight] = torch.cat([dU.t() @ emb, dV.t() @ emb], dim=1)
-            grads[te.emb2.bias] = dU.sum(0)
+            grads = self._et_grads(ent) if self._is_et() else self._tensornet_grads(ent)
             if self.prior_model is not None:  # Atomref: E_m += sum_i atomref[z_i]
                 for pr in self.prior_model:
                     if pr.enable:
                         w = pr.atomref.weight
                         grads[w] = torch.zeros(w.shape[0], dtype=torch.float32, device=dev).index_add_(0, z, ge[batch]).view_as(w)
+        return grads
+
+    def _tensornet_grads(self, ent):
+        grads = {p: ent[k].view_as(p) for k, p in self._grad_targets().items()}
+        te = self.representation_model.tensor_embedding
+        F = te.emb.weight.shape[1]
+        Wdp, bdp = ent["Wdp"].view(3, F, -1), ent["bdp"].view(3, F)
+        for k, proj in enumerate((te.distance_proj1, te.distance_proj2, te.distance_proj3)):
+            grads[proj.weight], grads[proj.bias] = Wdp[k], bdp[k]
+        # species tables U[z] = emb[z] Wa^T + b, V[z] = emb[z] Wb^T with emb2.weight = [Wa | Wb] (reference tensornet.py:526-541)
+        dU, dV = ent["Utab"].view(-1, F), ent["Vtab"].view(-1, F)
+        emb, w2 = te.emb.weight.detach().float(), te.emb2.weight.detach().float()
+        grads[te.emb.weight] = dU @ w2[:, :F] + dV @ w2[:, F:]
+        grads[te.emb2.weight] = torch.cat([dU.t() @ emb, dV.t() @ emb], dim=1)
+        grads[te.emb2.bias] = dU.sum(0)
+        return grads
+
+    def _et_grads(self, ent):
+        """engine entries -> Equivariant Transformer parameters (packing of csrc/tn_et_api.hip et_finalize: q | k | v stacked, the
+        value-type rows regrouped from the reference's per-head [H][3][hd] order to thirds [3][F])"""
+        rm, on = self.representation_model, self.output_model.output_network
+        F, hd = rm.hidden_channels, rm.hidden_channels // rm.num_heads
+        c = torch.arange(F)
+        src = torch.cat([(c // hd) * 3 * hd + t * hd + c % hd for t in range(3)])  # state-dict row of engine row t * F + c
+
+        def unthirds(g):  # engine rows [3F, ...] -> state-dict order
+            out = torch.empty_like(g)
+            out[src.to(g.device)] = g
+            return out
+
+        grads = {rm.embedding.weight: ent["emb"].view_as(rm.embedding.weight), rm.out_norm.weight: ent["lno_w"],
+                 rm.out_norm.bias: ent["lno_b"]}
+        ne = rm.neighbor_embedding
+        if ne is not None:
+            grads.update({ne.embedding.weight: ent["embN"].view_as(ne.embedding.weight), ne.distance_proj.weight: ent["Wn"].view(F, -1),
+                          ne.distance_proj.bias: ent["bn"], ne.combine.weight: ent["Wc"].view(F, 2 * F), ne.combine.bias: ent["bc"]})
+        for l, al in enumerate(rm.attention_layers):
+            t = "l%d." % l
+            W, b = ent[t + "Wqkv"].view(5 * F, F), ent[t + "bqkv"]
+            grads.update({al.layernorm.weight: ent[t + "ln_w"], al.layernorm.bias: ent[t + "ln_b"], al.q_proj.weight: W[:F],
+                          al.q_proj.bias: b[:F], al.k_proj.weight: W[F:2 * F], al.k_proj.bias: b[F:2 * F],
+                          al.v_proj.weight: unthirds(W[2 * F:]), al.v_proj.bias: unthirds(b[2 * F:]),
+                          al.vec_proj.weight: ent[t + "Wvp"].view(3 * F, F), al.o_proj.weight: ent[t + "Wo"].view(3 * F, F),
+                          al.o_proj.bias: ent[t + "bo"]})
+            if al.dk_proj is not None or al.dv_proj is not None:
+                Wd, bd = ent[t + "Wdkv"], ent[t + "bdkv"]
+                Wd = Wd.view(bd.numel(), -1)
+                o = 0
+                if al.dk_proj is not None:
+                    grads[al.dk_proj.weight], grads[al.dk_proj.bias] = Wd[:F], bd[:F]
+                    o = F
+                if al.dv_proj is not None:
+                    grads[al.dv_proj.weight], grads[al.dv_proj.bias] = unthirds(Wd[o:o + 3 * F]), unthirds(bd[o:o + 3 * F])
+        F2 = F // 2
+        b0, b1 = on[0], on[1]
+        W1u = ent["W1u"].view(F + F2, F)
+        w2 = torch.zeros_like(b1.update_net.layers[2].weight, dtype=torch.float32)
+        w2[0] = ent["Wn2"]
+        bb2 = torch.zeros_like(b1.update_net.layers[2].bias, dtype=torch.float32)
+        bb2[0] = ent["bn2"][0]
+        grads.update({b0.vec1_proj.weight: W1u[:F], b0.vec2_proj.weight: W1u[F:], b0.update_net.layers[0].weight: ent["Wm1"].view(F, 2 * F),
+                      b0.update_net.layers[0].bias: ent["bm1"], b0.update_net.layers[2].weight: ent["Wm2"].view(F, F),
+                      b0.update_net.layers[2].bias: ent["bm2"], b1.vec1_proj.weight: ent["W21"].view(F2, F2),
+                      b1.update_net.layers[0].weight: ent["Wn1"].view(F2, F), b1.update_net.layers[0].bias: ent["bn1"],
+                      b1.update_net.layers[2].weight: w2, b1.update_net.layers[2].bias: bb2})
         return grads
 
     def _grow(self, buf, nbytes, device):
@@ -916,8 +976,8 @@ class TorchMD_Net(nn.Module):
         want_forces = bool(self.derivative or (pos.requires_grad and torch.is_grad_enabled()))
         _require_cuda(pos, "TorchMD_Net.forward")
         if self.parameter_gradients and torch.is_grad_enabled():
-            if self._is_et() or self._is_tn2():
-                raise NotImplementedError("parameter gradients: TensorNet + Scalar only")
+            if self._is_tn2():
+                raise NotImplementedError("parameter gradients: TensorNet and the Equivariant Transformer only")
             _training_options(self)
             params = [p for p in self.parameters() if p.requires_grad]
             if want_forces:  # force matching: forces carry a (finite-difference) graph to the parameters as well
