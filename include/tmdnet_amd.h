@@ -246,7 +246,7 @@ int64_t tmdnet_debug_split_weight(const float* W_host, int64_t N, int64_t K, uin
 int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float* bias, float* C, int64_t M, int64_t N,
                       int64_t K, int32_t silu, const uint16_t* Wsb);
 
-/* ---- First-order parameter gradients (TensorNet + Scalar head, Equivariant Transformer + EquivariantScalar; energy-only training).
+/* ---- First-order parameter gradients (TensorNet, TensorNet2 and Equivariant Transformer handles; energy-only training).
  * Replaces what autograd does in the reference for `loss(E).backward()` over torchmdnet/models/tensornet.py:543-619, 729-814,
  * 384-398 and output_modules.py:108-117: given d loss / d E_m per molecule, one call evaluates the energies (direct evaluation
  * of the radial functions, no tables) and the gradient of sum_m grad_energy[m] E_m with respect to every weight, into one flat
@@ -256,6 +256,7 @@ int tmdnet_debug_gemm(void* stream, const float* A, const float* W, const float*
  * "Ue{k}", "L1", "bL1", "L2", "bL2", "ln0_w", "ln0_b" = tensor_embedding linears_tensor / linears_scalar / init_norm,
  * "l{l}.M{k}", "l{l}.b{k}" = layers.l.linears_scalar.k, "l{l}.Va{k}" / "l{l}.Vb{k}" = layers.l.linears_tensor.k / .(3+k),
  * "lnr_w", "lnr_b" = out_norm, "Lin", "bLin" = linear, "O1", "bO1", "O2", "bO2" = output_network.layers.0 / .2.
+ * TensorNet2 handles add "l{l}.M0b" / "l{l}.M0c" (charge blocks of linears_scalar.0) and "cp{h}.ln_w", "cp{h}.W1" ... (ChargePredict).
  * Equivariant Transformer handles enumerate their own entries ("emb", "embN", "Wn", "bn", "Wc", "bc", "l{l}.ln_w", "l{l}.Wqkv" =
  * q | k | v rows as packed by the engine, "l{l}.Wvp", "l{l}.Wo", "l{l}.Wdkv" = dk_proj | dv_proj, "lno_w", "W1u", "Wm1", "Wm2", "W21",
  * "Wn1", "Wn2", ...; torchmdnet_amd/models/model.py::_et_grads maps them back) and take the one-call form only.

@@ -1442,6 +1442,7 @@ namespace {
 const std::vector<std::pair<std::string, int64_t>>& train_layout(tmdnet_model* m) {
   if (!m->train_entries.empty()) return m->train_entries;
   if (m->et) return m->train_entries = et_train_layout(m);
+  if (m->tn2) return m->train_entries = tn2_train_layout(m);
   const int64_t F = m->hp.hidden_channels, K = m->hp.num_rbf, L = m->hp.num_layers, H = m->hp.head_hidden, Z = m->hp.max_z;
   auto& e = m->train_entries;
   e = {{"Wdp", 3 * F * K}, {"bdp", 3 * F}, {"Utab", Z * F}, {"Vtab", Z * F}, {"Ue0", F * F}, {"Ue1", F * F}, {"Ue2", F * F},
@@ -1509,11 +1510,11 @@ void carve_train(void* ws, tmdnet_model* m, int64_t N, int64_t P, TrainCtx* tc, 
 }  // namespace
 
 int tmdnet_param_grad_count(tmdnet_model* m) {
-  if (!m || m->tn2) return 0;
+  if (!m) return 0;
   return (int)train_layout(m).size();
 }
 const char* tmdnet_param_grad_entry(tmdnet_model* m, int idx, int64_t* offset, int64_t* numel) {
-  if (!m || m->tn2) return nullptr;
+  if (!m) return nullptr;
   const auto& e = train_layout(m);
   if (idx < 0 || idx >= (int)e.size()) return nullptr;
   int64_t off = 0;
@@ -1525,7 +1526,13 @@ const char* tmdnet_param_grad_entry(tmdnet_model* m, int idx, int64_t* offset, i
 int tmdnet_train_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, size_t* fwd_bytes, size_t* train_bytes,
                                  int64_t* grad_floats) {
   if (!m || n_atoms < 0 || n_mol < 0 || n_pairs < 0) return TMDNET_ERR_INVALID;
-  if (m->tn2) return fail(m, TMDNET_ERR_INVALID, "parameter gradients: TensorNet and the Equivariant Transformer only");
+  if (m->tn2) {  // per-edge arrays: every pair in both directions + one self edge per atom
+    const int64_t n_edges = std::max<int64_t>(m->lastE, 2 * n_pairs + n_atoms);
+    if (fwd_bytes) tn2_forward_workspace_bytes(m, n_atoms, n_mol, n_pairs, n_edges, 1, fwd_bytes);  // covers the per-pair embedding too
+    if (train_bytes) tn2_carve_train(nullptr, m, n_atoms, n_pairs, n_edges, nullptr, train_bytes);
+    if (grad_floats) *grad_floats = train_grad_floats(m);
+    return TMDNET_OK;
+  }
   if (m->et) {
     if (fwd_bytes) et_forward_workspace_bytes(m, n_atoms, n_mol, n_pairs, 1, fwd_bytes);
     if (train_bytes) et_carve_train(nullptr, m, n_atoms, n_pairs, nullptr, train_bytes);
@@ -1543,8 +1550,7 @@ int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, voi
   // grad_energy == NULL: forward half only (energies out, every activation kept in ws / train_ws); energy == NULL: reverse half
   // only, on the workspaces a forward-half call with the same arguments left behind; both given: one pass
   if (!m || !graph_ws || !ws || !train_ws || (!grad_energy && !energy) || (grad_energy && !grads)) return TMDNET_ERR_INVALID;
-  if (m->tn2) return fail(m, TMDNET_ERR_INVALID, "parameter gradients: TensorNet and the Equivariant Transformer only");
-  if (m->et && (!grad_energy || !energy)) return fail(m, TMDNET_ERR_INVALID, "the two-call form is built for TensorNet only");
+  if ((m->et || m->tn2) && (!grad_energy || !energy)) return fail(m, TMDNET_ERR_INVALID, "the two-call form is built for TensorNet only");
   if (n_pairs < 0) return fail(m, TMDNET_ERR_INVALID, "parameter gradients need the exact pair count (dynamic shapes)");
   if (m->graph_is_cell) return fail(m, TMDNET_ERR_STATE, "parameter gradients: build the graph without the cell list");
   TrainCtx tc;
@@ -1552,6 +1558,7 @@ int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, voi
   tc.grads = grads;
   size_t need = 0;
   if (m->et) et_carve_train(train_ws, m, n_atoms, n_pairs, &tc, &need);
+  else if (m->tn2) tn2_carve_train(train_ws, m, n_atoms, n_pairs, std::max<int64_t>(m->lastE, 2 * n_pairs + n_atoms), &tc, &need);
   else carve_train(train_ws, m, n_atoms, n_pairs, &tc, &need);
   if (need > train_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "training workspace too small: need " + std::to_string(need));
   int64_t off = 0;

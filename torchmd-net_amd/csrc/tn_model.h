@@ -273,6 +273,8 @@ int ensure_radial_tables(tmdnet_model* m, hipStream_t s);
 int et_build_tables(tmdnet_model* m);  // tn_et_api.hip
 std::vector<std::pair<std::string, int64_t>> et_train_layout(const tmdnet_model* m);
 void et_carve_train(void* ws, const tmdnet_model* m, int64_t N, int64_t P, TrainCtx* tc, size_t* total);
+std::vector<std::pair<std::string, int64_t>> tn2_train_layout(const tmdnet_model* m);  // tn_tn2_api.hip
+void tn2_carve_train(void* ws, const tmdnet_model* m, int64_t N, int64_t P, int64_t E, TrainCtx* tc, size_t* total);
 int build_radial_tables(tmdnet_model* m, EdgeTables& out, const std::vector<TableSpec>& specs, const float* means, const float* betas,
                         int K, double lo, double up);
 void free_radial_tables(EdgeTables& t);

@@ -37,6 +37,8 @@ void launch_tn2_head_energy(const float* ao, const float* O2, const float* bO2, 
 void launch_add_forces(const float* fc, const int* perm, int N, float* forces, hipStream_t s);
 void launch_add(const float* x, float* y, int64_t n, hipStream_t s);
 void launch_slice_cols(const float* src, int ld, int off, int rows, int cols, float* dst, hipStream_t s);
+void launch_scale_rows(float* x, const float* r, float mul, int rows, int cols, hipStream_t s);
+void launch_tn2_self_rows(const Graph& g, int N, int F, const float* rows, float* out, hipStream_t s);
 void launch_put_cols(const float* src, int rows, int cols, float* dst, int ld, int off, hipStream_t s);
 
 }  // namespace tn

@@ -513,4 +513,30 @@ void launch_put_cols(const float* src, int rows, int cols, float* dst, int ld, i
   hipLaunchKernelGGL(k_put_cols, dim3(cdiv2((int64_t)rows * cols, 256)), dim3(256), 0, s, src, rows, cols, dst, ld, off);
 }
 
+
+// ---- parameter gradients
+// x[i, :] *= r[i] * mul
+__global__ void k_scale_rows(float* __restrict__ x, const float* __restrict__ r, float mul, int rows, int cols) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)rows * cols) return;
+  x[idx] *= r[idx / cols] * mul;
+}
+void launch_scale_rows(float* x, const float* r, float mul, int rows, int cols, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return;
+  hipLaunchKernelGGL(k_scale_rows, dim3(cdiv2((int64_t)rows * cols, 256)), dim3(256), 0, s, x, r, mul, rows, cols);
+}
+// out[i, :] = rows[e, :] of atom i's self edge (every atom has one: the pair list carries self loops); zeros if it has none
+__global__ void k_tn2_self_rows(Graph g, int N, int F, const float* __restrict__ rows, float* __restrict__ out) {
+  const int i = blockIdx.x;
+  if (g.counts[2]) return;
+  int es = -1;
+  for (int e = g.rowptr[i]; e < g.rowptr[i + 1]; ++e)
+    if (g.col[e] == i) es = e;
+  for (int f = threadIdx.x; f < F; f += blockDim.x) out[(int64_t)i * F + f] = es >= 0 ? rows[(int64_t)es * F + f] : 0.f;
+}
+void launch_tn2_self_rows(const Graph& g, int N, int F, const float* rows, float* out, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_tn2_self_rows, dim3(N), dim3(((F + 63) / 64) * 64 > 256 ? 256 : ((F + 63) / 64) * 64), 0, s, g, N, F, rows, out);
+}
+
 }  // namespace tn

@@ -153,6 +153,63 @@ Tn2Buffers tn2_carve(void* ws, const tmdnet_model* m, int64_t N, int64_t B, int6
 
 }  // namespace
 
+// parameter-gradient pass: gradient buffer layout and the extra buffers of a TensorNet2 handle
+std::vector<std::pair<std::string, int64_t>> tn2_train_layout(const tmdnet_model* m) {
+  const int64_t F = m->hp.hidden_channels, K = m->hp.num_rbf, L = m->hp.num_layers, H = m->hp.head_hidden, Z = m->hp.max_z,
+                qd = m->tn2->hp.q_dim;
+  std::vector<std::pair<std::string, int64_t>> e = {{"Wdp", 3 * F * K}, {"bdp", 3 * F}, {"Utab", Z * F}, {"Vtab", Z * F}, {"Ue0", F * F},
+                                                    {"Ue1", F * F}, {"Ue2", F * F}, {"L1", 2 * F * F}, {"bL1", 2 * F}, {"L2", 6 * F * F},
+                                                    {"bL2", 3 * F}, {"ln0_w", F}, {"ln0_b", F}};
+  for (int l = 0; l < L; ++l) {
+    const std::string t = "l" + std::to_string(l) + ".";
+    for (auto kv : std::vector<std::pair<std::string, int64_t>>{{"M0", F * K}, {"M0b", F * qd}, {"M0c", F * qd}, {"b0", F}, {"M1", 2 * F * F},
+                                                                 {"b1", 2 * F}, {"M2", 6 * F * F}, {"b2", 3 * F}})
+      e.push_back({t + kv.first, kv.second});
+    for (const char* ab : {"Va", "Vb"})
+      for (int k = 0; k < 3; ++k) e.push_back({t + ab + std::to_string(k), F * F});
+  }
+  for (int h = 0; h <= L; ++h) {
+    const std::string c = "cp" + std::to_string(h) + ".";
+    for (auto kv : std::vector<std::pair<std::string, int64_t>>{{"ln_w", 3 * F}, {"ln_b", 3 * F}, {"W1", 3 * F * F}, {"b1", F}, {"W2", F * F},
+                                                                 {"b2", F}, {"W3", 2 * qd * F}, {"b3", 2 * qd}})
+      e.push_back({c + kv.first, kv.second});
+  }
+  for (auto kv : std::vector<std::pair<std::string, int64_t>>{{"lnr_w", 3 * F}, {"lnr_b", 3 * F}, {"Lin", 3 * F * F}, {"bLin", F}, {"O1", H * F},
+                                                               {"bO1", H}, {"O2", H}, {"bO2", 1}})
+    e.push_back(kv);
+  return e;
+}
+void tn2_carve_train(void* ws, const tmdnet_model* m, int64_t N, int64_t P, int64_t E, TrainCtx* tc, size_t* total) {
+  const int64_t F = m->hp.hidden_channels, K = m->hp.num_rbf, L = m->hp.num_layers, H = m->hp.head_hidden, Z = m->hp.max_z, P1 = P + 1,
+                N9 = N * 9 * F;
+  Carver c(ws);
+  TrainCtx t;
+  for (int l = 0; l < L; ++l) {
+    t.Ch.push_back(c.take<float>(N9));
+    t.Xh.push_back(c.take<float>(N9));
+  }
+  t.g1 = c.take<float>(N * F);  // self-edge rows of g_pre1
+  t.gq = c.take<float>(2 * P1 * 3 * F);
+  t.selfq = c.take<float>(N * F);
+  t.gZu = c.take<float>(N * F);
+  t.gZv = c.take<float>(N * F);
+  t.onehot = c.take<float>(N * Z);
+  t.head = c.take<float>(N * (H + 1));
+  t.forces = c.take<float>(N * 3);
+  const int64_t big = std::max<int64_t>({6 * F * F, 3 * F * K, Z * F, H * F, 3 * F * F});
+  t.part = c.take<float>((int64_t)train_part_floats((int)std::max<int64_t>({P1, 5 * N, E}), big));
+  if (tc) {
+    const float* ge = tc->gE;
+    float* gr = tc->grads;
+    const int ph = tc->phase;
+    *tc = t;
+    tc->gE = ge;
+    tc->grads = gr;
+    tc->phase = ph;
+  }
+  if (total) *total = c.off;
+}
+
 int tn2_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int64_t n_edges, int32_t want_forces,
                                 size_t* bytes) {
   if (n_edges < 0) n_edges = (int64_t)m->hp.max_num_neighbors * n_atoms;  // static shapes: the edge capacity
@@ -197,7 +254,8 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
   gR.epair = t.erev;
 
   // ---- per-pair functions of the distance: Q (embedding) and the pair block of every layer's first edge-MLP layer
-  const bool use_tab = m->tabs.ok && (int64_t)P1 >= m->tab_min_pairs && (int)m->tabs.tab.size() == 1 + L;
+  TrainCtx* const tc = m->train;  // parameter gradients: direct radial functions, per-layer X_hat / group product kept
+  const bool use_tab = !tc && m->tabs.ok && (int64_t)P1 >= m->tab_min_pairs && (int)m->tabs.tab.size() == 1 + L;
   if (use_tab) {
     const float* t0[1] = {m->tabs.tab[0]};
     float* o0[1] = {b.Q};
@@ -271,12 +329,14 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
     gemm(s, t.he1[l], F, q_.M2, F, q_.b2, t.he2[l], 2 * F, Erows, 2 * F, F, GEMM_ACT_SILU, t.pre2[l], 2 * F);
     gemm(s, t.he2[l], 2 * F, q_.M3, 2 * F, q_.b3, t.we[l], 3 * F, Erows, 3 * F, 2 * F, GEMM_ACT_SILU | GEMM_ROWSCALE, t.pre3[l], 3 * F,
          nullptr, 0, t.Ce[l]);
-    KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], b.Xh, N, F, s));
-    tensor_linear(s, b.Xh, q_.V, b.Pn[l], N, F);
-    KR(CAT_MESSAGE, Ed * (12 * Fd + 12) + 3 * nodeB, launch_message(gE, N, F, t.we[l], b.Pn[l], nullptr, nullptr, o3, b.Mi[l], b.Ch, s));
-    tensor_linear(s, b.Ch, q_.V + 3, b.D[l], N, F);
+    float* const Xh_l = tc ? tc->Xh[l] : b.Xh;
+    float* const Ch_l = tc ? tc->Ch[l] : b.Ch;
+    KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], Xh_l, N, F, s));
+    tensor_linear(s, Xh_l, q_.V, b.Pn[l], N, F);
+    KR(CAT_MESSAGE, Ed * (12 * Fd + 12) + 3 * nodeB, launch_message(gE, N, F, t.we[l], b.Pn[l], nullptr, nullptr, o3, b.Mi[l], Ch_l, s));
+    tensor_linear(s, Ch_l, q_.V + 3, b.D[l], N, F);
     // X_new = X_hat + dX + dX dX (no charge factor, tensornet2.py:624); the readout invariants come with the last layer
-    KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(b.Xh, b.D[l], nullptr, nullptr, N, F, b.X[l + 1], l + 1 < L ? 0 : 2, b.feat, s));
+    KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(Xh_l, b.D[l], nullptr, nullptr, N, F, b.X[l + 1], l + 1 < L ? 0 : 2, b.feat, s));
     charge_predict(l + 1);
   }
 
@@ -303,8 +363,37 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
     // ---- head + readout adjoints (TensorNet's)
     KR(CAT_ELEMENTWISE, Nd * H * 8, launch_head_bwd(b.ao, W.O2, N, H, W.std, b.g_ao, s));
     NODE();
+    // parameter gradients: dW (+)= g_out^T in, db = colsum(g_out) wherever an adjoint meets its layer's input (tn_train.hip)
+    auto RP = [](int64_t ld) { return rows_plain(ld); };
+    auto dW = [&](const std::string& key, const float* gOut, int64_t ldg, const float* In, int64_t ldi, int R, int Nout, int Kin,
+                  bool acc = false) { launch_tn_gemm(s, gOut, RP(ldg), In, RP(ldi), nullptr, nullptr, R, Nout, Kin, tc->at(key), acc, tc->part); };
+    auto dB = [&](const std::string& key, const float* gOut, int64_t ldg, int R, int ncol, const float* mul = nullptr, int64_t ldm = 0,
+                  bool acc = false) { launch_colsum(s, gOut, RP(ldg), mul, RP(ldm), nullptr, nullptr, R, ncol, tc->at(key), acc, tc->part); };
+    const RowMap rc_[3] = {rows_comp(F, 1), rows_comp(F, 3), rows_comp(F, 5)};
+    const int c0_[3] = {0, 1, 4}, nc_[3] = {1, 3, 5};
+    auto tensor_linear_grad = [&](const float* gOut, const float* In, const std::string& key) {
+      for (int k = 0; k < 3; ++k)
+        launch_tn_gemm(s, gOut + (int64_t)c0_[k] * F, rc_[k], In + (int64_t)c0_[k] * F, rc_[k], nullptr, nullptr, N * nc_[k], F, F,
+                       tc->at(key + std::to_string(k)), false, tc->part);
+    };
+    if (tc) {
+      // seeds d loss / d E_mol(i): rows of g_ao and of the Coulomb charge gradient; everything below is linear in the two
+      launch_train_seed(b.ao, tc->gE, batch, N, H, W.std, b.g_ao, tc->head, s);
+      launch_slice_cols(tc->head, H + 1, H, N, 1, tc->selfq, s);                     // s_i = seed * std
+      launch_scale_rows(t.g_q, tc->selfq, 1.0f / W.std, N, QC, s);                   // g_q was computed with seed 1
+      dB("O2", tc->head, H + 1, N, H);
+      dB("bO2", tc->head + H, H + 1, N, 1);
+      dW("O1", b.g_ao, H, b.x, F, N, H, F);
+      dB("bO1", b.g_ao, H, N, H);
+    }
     gemm(s, b.g_ao, H, W.O1T, H, nullptr, b.g_al, F, N, F, H, GEMM_MUL_DSILU_AUX, nullptr, 0, b.al, F);
     gemm(s, b.g_al, F, W.LinT, F, nullptr, b.g_ln, 3 * F, N, 3 * F, F);
+    if (tc) {
+      dW("Lin", b.g_al, F, b.lnr, 3 * F, N, F, 3 * F);
+      dB("bLin", b.g_al, F, N, F);
+      dB("lnr_w", b.g_ln, 3 * F, N, 3 * F, b.xhr, 3 * F);
+      dB("lnr_b", b.g_ln, 3 * F, N, 3 * F);
+    }
     KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, 3 * F, b.g_feat, s));
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 4, launch_readout_bwd(b.X[L], b.g_feat, N, F, b.G, s));
     launch_fill(b.gd, 0.f, P1, s);
@@ -314,9 +403,26 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
       const CpParams& cp = T2.cp[l];
       KR(CAT_ELEMENTWISE, Nd * qd * 16, launch_qeq_bwd(g, t.outq[l], batch, N, B, qd, t.FuQ[l], t.g_c, t.g_outq, s));
       NODE();
+      const std::string c_ = "cp" + std::to_string(l) + ".";
+      if (tc) {
+        dW(c_ + "W3", t.g_outq, 2 * qd, t.h2q[l], F, N, 2 * qd, F);
+        dB(c_ + "b3", t.g_outq, 2 * qd, N, 2 * qd);
+      }
       gemm(s, t.g_outq, 2 * qd, cp.W3T, 2 * qd, nullptr, t.g_h2q, F, N, F, 2 * qd, GEMM_MUL_DSILU_AUX, nullptr, 0, t.a2q[l], F);
+      if (tc) {
+        dW(c_ + "W2", t.g_h2q, F, t.h1q[l], F, N, F, F);
+        dB(c_ + "b2", t.g_h2q, F, N, F);
+      }
       gemm(s, t.g_h2q, F, cp.W2T, F, nullptr, t.g_h1q, F, N, F, F, GEMM_MUL_DSILU_AUX, nullptr, 0, t.a1q[l], F);
+      if (tc) {
+        dW(c_ + "W1", t.g_h1q, F, t.lnq[l], 3 * F, N, F, 3 * F);
+        dB(c_ + "b1", t.g_h1q, F, N, F);
+      }
       gemm(s, t.g_h1q, F, cp.W1T, F, nullptr, t.g_lnq, 3 * F, N, 3 * F, F);
+      if (tc) {
+        dB(c_ + "ln_w", t.g_lnq, 3 * F, N, 3 * F, t.xhq[l], 3 * F);
+        dB(c_ + "ln_b", t.g_lnq, 3 * F, N, 3 * F);
+      }
       KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_bwd(t.g_lnq, t.xhq[l], t.rstdq[l], cp.ln_w, N, 3 * F, t.g_featq, s));
       KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 4, launch_cp_feat_bwd(b.X[l], t.g_featq, N, F, b.G, s));
     };
@@ -330,6 +436,8 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
       const Tn2LayerP& q2 = T2.layer[l];
       // G = gradient wrt X[l + 1]
       KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], nullptr, nullptr, N, F, b.gD, s));
+      const std::string t_ = "l" + std::to_string(l) + ".";
+      if (tc) tensor_linear_grad(b.gD, tc->Ch[l], t_ + "Vb");
       tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
       KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], nullptr, nullptr, o3, N, F, b.gMi, b.gPn, s));
       // per-edge weight gradient -> g_pre3, cutoff gradient slots; then the transposed sweep with w[erev[e]]
@@ -337,9 +445,27 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
          launch_tn2_edge_gw(g, N, F, b.gMi, b.Pn[l], t.pre3[l], t.Ce[l], t.g_pre3, t.gCe_slots, E, s));
       KR(CAT_MESSAGE, Ed * (12 * Fd + 12) + 3 * nodeB, launch_message_adjoint(gR, N, F, t.we[l], b.gMi, b.gPn, s));
       EDGE();
+      if (tc) {
+        dW(t_ + "M2", t.g_pre3, 3 * F, t.he2[l], 2 * F, Erows, 3 * F, 2 * F);
+        dB(t_ + "b2", t.g_pre3, 3 * F, Erows, 3 * F);
+      }
       gemm(s, t.g_pre3, 3 * F, q2.M3T, 3 * F, nullptr, t.g_pre2, 2 * F, Erows, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, t.pre2[l], 2 * F);
+      if (tc) {
+        dW(t_ + "M1", t.g_pre2, 2 * F, t.he1[l], F, Erows, 2 * F, F);
+        dB(t_ + "b1", t.g_pre2, 2 * F, Erows, 2 * F);
+      }
       gemm(s, t.g_pre2, 2 * F, q2.M2T, 2 * F, nullptr, t.g_pre1, F, Erows, F, 2 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, t.pre1[l], F);
       KR(CAT_PAIR, Ed * Fd * 8 + Nd * Fd * 8 + Pd * Fd * 4, launch_tn2_edge_reduce(g, N, F, t.g_pre1, t.erev, t.gB, t.gCs, t.gAp, s));
+      if (tc) {
+        // first layer pre1[e] = (M1a phi + b1)[pair] + (M1b c)[target] + (M1c c)[source]: pair rows (the self pair's row is the sum
+        // over the atoms' self edges), target / source atom rows
+        launch_tn2_self_rows(g, N, F, t.g_pre1, tc->g1, s);
+        launch_colsum(s, tc->g1, RP(F), nullptr, RP(F), nullptr, nullptr, N, F, t.gAp + (int64_t)P * F, false, tc->part);
+        dW(t_ + "M0", t.gAp, F, b.phi, K, P1, F, K);
+        dB(t_ + "b0", t.gAp, F, P1, F);
+        dW(t_ + "M0b", t.gB, F, t.chg[l], qd, N, F, qd);
+        dW(t_ + "M0c", t.gCs, F, t.chg[l], qd, N, F, qd);
+      }
       KR(CAT_PAIR, Pd * Fd * 8, launch_tn2_pair_gd(g, P, F, t.gAp, t.dAp[l], t.gCe_slots, tn2_gw_slots(F), E, t.pair_edge, t.erev, b.dC, b.gd, s));
       // charges of head l enter this layer's edge MLP: g_c = Coulomb slice l + gB M1b + gCs M1c
       coulomb_slice(l);
@@ -347,6 +473,7 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
       gemm(s, t.gB, F, q2.M1bT, F, nullptr, t.g_c, qd, N, qd, F, GEMM_ACCUM);
       gemm(s, t.gCs, F, q2.M1cT, F, nullptr, t.g_c, qd, N, qd, F, GEMM_ACCUM);
       // node chain down to X[l]
+      if (tc) tensor_linear_grad(b.gPn, tc->Xh[l], t_ + "Va");
       tensor_linear(s, b.gPn, q_.VT, b.gXl, N, F);
       KR(CAT_ELEMENTWISE, 4 * nodeB, launch_norm_bwd(b.X[l], b.gXl, N, F, b.G, s));  // reads the residual G, writes the gradient wrt X[l]
       charge_predict_bwd(l);
@@ -359,15 +486,37 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
     KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s));
     tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
-    if (ntp) {
+    if (tc) {  // the embedding is TensorNet's: same products as in tn_api.hip
+      tensor_linear_grad(b.gUX, b.u0, "Ue");
+      dW("L2", b.g_a2, 3 * F, b.h1, 2 * F, N, 3 * F, 2 * F);
+      dB("bL2", b.g_a2, 3 * F, N, 3 * F);
+      dW("L1", b.g_a1, 2 * F, b.ln0, F, N, 2 * F, F);
+      dB("bL1", b.g_a1, 2 * F, N, 2 * F);
+      dB("ln0_w", b.g_ln0, F, N, F, b.xh0, F);
+      dB("ln0_b", b.g_ln0, F, N, F);
+      const int64_t dir = (int64_t)P1 * 3 * F;
+      const int Z = hp.max_z;
+      launch_train_embed(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.gA, tc->gq, dir, tc->selfq, tc->gZu, tc->gZv, s);
+      dW("Wdp", tc->gq, 3 * F, b.phi, K, P, 3 * F, K);
+      dW("Wdp", tc->gq + dir, 3 * F, b.phi, K, P, 3 * F, K, true);
+      launch_tn_gemm(s, tc->selfq, RP(F), b.phi + (int64_t)P * K, RP(0), nullptr, nullptr, N, F, K, tc->at("Wdp"), true, tc->part);
+      dB("bdp", tc->gq, 3 * F, P, 3 * F);
+      dB("bdp", tc->gq + dir, 3 * F, P, 3 * F, nullptr, 0, true);
+      dB("bdp", tc->selfq, F, N, F, nullptr, 0, true);
+      launch_onehot(z, N, Z, tc->onehot, s);
+      dW("Utab", tc->onehot, Z, tc->gZu, F, N, Z, F);
+      dW("Vtab", tc->onehot, Z, tc->gZv, F, N, Z, F);
+    } else if (ntp) {
       KR(CAT_PAIR, Nd * 10 * Fd * 4 + momB, launch_embed_gm(g, N, F, K, ntp, z, W.Utab, W.Vtab, m->rb_rev, W.bdp, b.gA, b.gmom, s));
       KR(CAT_PAIR, Pd * 40 + momB, launch_embed_pair_rb(g, P, N, rbp, ntp, b.ps, b.gmom, b.gd, b.g_rhat, s, nullptr, nullptr, 0, 0));
     } else
       KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
          launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s));
-    KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s));
-    KR(CAT_ELEMENTWISE, Ed * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
-    KR(CAT_ELEMENTWISE, Nd * 24, launch_add_forces(t.fcoul, perm, N, forces, s));
+    if (!tc) {
+      KR(CAT_ELEMENTWISE, Pd * 40, launch_geom_gd(g, P, b.gd, b.g_rhat, b.g_delta, s));
+      KR(CAT_ELEMENTWISE, Ed * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
+      KR(CAT_ELEMENTWISE, Nd * 24, launch_add_forces(t.fcoul, perm, N, forces, s));
+    }
   }
   NODE();
   HIP_TRY(m, hipGetLastError());

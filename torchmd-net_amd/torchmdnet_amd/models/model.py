@@ -310,7 +310,7 @@ class _EnergyParamGrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, z, pos, batch, box, q, n_mol, *params):
-        if model._is_et():  # one-call form: energies from the inference schedule here, the whole pass in backward
+        if model._is_et() or model._is_tn2():  # one-call form: energies from the inference schedule here, the whole pass in backward
             energy, _ = model.energy_and_forces(z, pos, batch, box, q, n_mol, want_forces=False)
             _, token = model._train_forward(z, pos, batch, box, q, n_mol, keep=False)
         else:
@@ -621,7 +621,7 @@ class TorchMD_Net(nn.Module):
         returned token lets `_train_backward` run the reverse half on them - unless another engine call used the workspaces
         in between (the token's epoch no longer matches), in which case the pass is repeated from the inputs."""
         if self._is_tn2():
-            raise NotImplementedError("parameter gradients: TensorNet and the Equivariant Transformer only")
+            keep = False  # one-call form only
         if self._is_et():
             keep, q = False, None  # one-call form only; TorchMD_ET.forward ignores q
         L = _C.lib()
@@ -696,7 +696,7 @@ class TorchMD_Net(nn.Module):
                 off, numel = C.c_int64(0), C.c_int64(0)
                 name = L.tmdnet_param_grad_entry(st.handle, i, C.byref(off), C.byref(numel)).decode()
                 ent[name] = flat[off.value: off.value + numel.value]
-            grads = self._et_grads(ent) if self._is_et() else self._tensornet_grads(ent)
+            grads = self._et_grads(ent) if self._is_et() else (self._tn2_grads(ent) if self._is_tn2() else self._tensornet_grads(ent))
             if self.prior_model is not None:  # Atomref: E_m += sum_i atomref[z_i]
                 for pr in self.prior_model:
                     if pr.enable:
@@ -704,8 +704,8 @@ class TorchMD_Net(nn.Module):
                         grads[w] = torch.zeros(w.shape[0], dtype=torch.float32, device=dev).index_add_(0, z, ge[batch]).view_as(w)
         return grads
 
-    def _tensornet_grads(self, ent):
-        grads = {p: ent[k].view_as(p) for k, p in self._grad_targets().items()}
+    def _tensornet_grads(self, ent, skip=()):
+        grads = {p: ent[k].view_as(p) for k, p in self._grad_targets().items() if not k.endswith(skip)}
         te = self.representation_model.tensor_embedding
         F = te.emb.weight.shape[1]
         Wdp, bdp = ent["Wdp"].view(3, F, -1), ent["bdp"].view(3, F)
@@ -717,6 +717,25 @@ class TorchMD_Net(nn.Module):
         grads[te.emb.weight] = dU @ w2[:, :F] + dV @ w2[:, F:]
         grads[te.emb2.weight] = torch.cat([dU.t() @ emb, dV.t() @ emb], dim=1)
         grads[te.emb2.bias] = dU.sum(0)
+        return grads
+
+    def _tn2_grads(self, ent):
+        """TensorNet2: TensorNet's entries, the first edge-MLP layer as its three column blocks [pair | target charges | source
+        charges] (reference tensornet2.py:536-560), and the ChargePredict heads (:49-157)"""
+        rm = self.representation_model
+        grads = self._tensornet_grads(ent, skip=("M0",))
+        for l, layer in enumerate(rm.layers):
+            t = "l%d." % l
+            w = layer.linears_scalar[0].weight
+            F = w.shape[0]
+            grads[w] = torch.cat([ent[t + "M0"].view(F, -1), ent[t + "M0b"].view(F, -1), ent[t + "M0c"].view(F, -1)], dim=1)
+        heads = [rm.charge_predict_0] + list(rm.charge_predicts)
+        for h, cp in enumerate(heads):
+            c = "cp%d." % h
+            mlp = cp.q_mlp.layers
+            for key, prm in (("ln_w", cp.q_norm.weight), ("ln_b", cp.q_norm.bias), ("W1", mlp[0].weight), ("b1", mlp[0].bias),
+                             ("W2", mlp[2].weight), ("b2", mlp[2].bias), ("W3", mlp[4].weight), ("b3", mlp[4].bias)):
+                grads[prm] = ent[c + key].view_as(prm)
         return grads
 
     def _et_grads(self, ent):
@@ -976,8 +995,6 @@ class TorchMD_Net(nn.Module):
         want_forces = bool(self.derivative or (pos.requires_grad and torch.is_grad_enabled()))
         _require_cuda(pos, "TorchMD_Net.forward")
         if self.parameter_gradients and torch.is_grad_enabled():
-            if self._is_tn2():
-                raise NotImplementedError("parameter gradients: TensorNet and the Equivariant Transformer only")
             _training_options(self)
             params = [p for p in self.parameters() if p.requires_grad]
             if want_forces:  # force matching: forces carry a (finite-difference) graph to the parameters as well
