@@ -125,13 +125,16 @@ __global__ __launch_bounds__(256, 3) void k_gemm_sb1(GemmArgs a, int tiles_m, in
   bf16x8 bf[2][3];                                                                                         \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int p = 0; p < 3; ++p) bf[j][p] =   \
       *reinterpret_cast<const bf16x8*>(cur + fob + p * SB2_PLANE + j * 1024);                              \
-  bf16x8 af[3];
+  bf16x8 af[2][3];
 #define SB1_AF(i) \
-  _Pragma("unroll") for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(cur + foa + p * SB2_PLANE + (i) * 1024);
-#define SB1_MMA(i, pa_, pb_)                                                                        \
-  acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa_], bf[0][pb_], acc[i][0], 0, 0, 0); \
-  acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa_], bf[1][pb_], acc[i][1], 0, 0, 0);
-#define SB1_GROUP(i) SB1_MMA(i, 0, 2) SB1_MMA(i, 2, 0) SB1_MMA(i, 1, 1) SB1_MMA(i, 0, 1) SB1_MMA(i, 1, 0) SB1_MMA(i, 0, 0)
+  _Pragma("unroll") for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(cur + foa + p * SB2_PLANE + (i) * 1024);
+// one product of the split on all four accumulators of the wave: consecutive MFMAs never touch the same accumulator, and an
+// accumulator is revisited after four issues (the six products of a k-step in the order of k_gemm_sb: 02 20 11 01 10 00)
+#define SB1_MMA4(pa_, pb_)                                                                          \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[0][pb_], acc[0][0], 0, 0, 0); \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[0][1], 0, 0, 0); \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[1][0], 0, 0, 0); \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[1][1], 0, 0, 0);
 
     // steady state: chunk kt+1 is in the registers; branch-free body (the chunk index of the next loads is clamped)
     for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -141,44 +144,36 @@ __global__ __launch_bounds__(256, 3) void k_gemm_sb1(GemmArgs a, int tiles_m, in
       SB1_LOAD_B()
       uint4 h, m, l;
       SB1_AF(0)
-      SB1_MMA(0, 0, 2)
+      SB1_AF(1)
+      SB1_MMA4(0, 2)
       split2(a0.x, a0.y, h.x, m.x, l.x);
-      SB1_MMA(0, 2, 0)
       split2(a0.z, a0.w, h.y, m.y, l.y);
-      SB1_MMA(0, 1, 1)
+      SB1_MMA4(2, 0)
       split2(a1.x, a1.y, h.z, m.z, l.z);
-      SB1_MMA(0, 0, 1)
       split2(a1.z, a1.w, h.w, m.w, l.w);
-      SB1_MMA(0, 1, 0)
+      SB1_MMA4(1, 1)
       *reinterpret_cast<uint4*>(nxt + 0 * SB2_PLANE + soff) = h;
       *reinterpret_cast<uint4*>(nxt + 1 * SB2_PLANE + soff) = m;
       *reinterpret_cast<uint4*>(nxt + 2 * SB2_PLANE + soff) = l;
-      SB1_MMA(0, 0, 0)
-      SB1_AF(1)
-      SB1_MMA(1, 0, 2)
+      SB1_MMA4(0, 1)
       *reinterpret_cast<uint4*>(nxt + 3 * SB2_PLANE + soff) = w0;
       *reinterpret_cast<uint4*>(nxt + 4 * SB2_PLANE + soff) = w1;
       *reinterpret_cast<uint4*>(nxt + 5 * SB2_PLANE + soff) = w2;
-      SB1_MMA(1, 2, 0)
-      SB1_MMA(1, 1, 1)
+      SB1_MMA4(1, 0)
       SB1_FETCH(kf)
-      SB1_MMA(1, 0, 1)
-      SB1_MMA(1, 1, 0)
-      SB1_MMA(1, 0, 0)
+      SB1_MMA4(0, 0)
       __syncthreads();
     }
     {  // last chunk: multiply only
       const unsigned char* cur = smem + ((nk - 1) & 1) * SB1_STAGE;
       SB1_LOAD_B()
       SB1_AF(0)
-      SB1_GROUP(0)
       SB1_AF(1)
-      SB1_GROUP(1)
+      SB1_MMA4(0, 2) SB1_MMA4(2, 0) SB1_MMA4(1, 1) SB1_MMA4(0, 1) SB1_MMA4(1, 0) SB1_MMA4(0, 0)
     }
 #undef SB1_LOAD_B
 #undef SB1_AF
-#undef SB1_MMA
-#undef SB1_GROUP
+#undef SB1_MMA4
 #undef SB1_FETCH
 
     // epilogue through wave-private LDS (4 KB per wave): 16 bytes per lane, 8 rows x 128 contiguous bytes per access
