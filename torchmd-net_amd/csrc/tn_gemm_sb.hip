@@ -106,18 +106,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dual_sb2(GemmArgs a, int tiles_
   const int fob = 6 * SB2_PLANE + (2 * rb_ + (kh ^ (((rb_ + 4) >> 3) & 1))) * 16;
 
 #define SB2_AF(v, i)                                                                                     \
-  _Pragma("unroll") for (int p = 0; p < 3; ++p) af[p] =                                                  \
+  _Pragma("unroll") for (int p = 0; p < 3; ++p) af[i][p] =                                               \
       *reinterpret_cast<const bf16x8*>(cur + foa + ((v) * 3 + p) * SB2_PLANE + (i) * 1024);
-#define SB2_MMA(v, i, pa_, pb_)                                                                            \
-  acc[v][i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa_], bf[0][pb_], acc[v][i][0], 0, 0, 0); \
-  acc[v][i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa_], bf[1][pb_], acc[v][i][1], 0, 0, 0);
-#define SB2_GROUP(v, i) \
-  SB2_MMA(v, i, 0, 2) SB2_MMA(v, i, 2, 0) SB2_MMA(v, i, 1, 1) SB2_MMA(v, i, 0, 1) SB2_MMA(v, i, 1, 0) SB2_MMA(v, i, 0, 0)
+// one split product on the four accumulators of a half (value or tangent): an accumulator is revisited after four MFMAs
+// (products per accumulator in the order 02 20 11 01 10 00, as before: same bits)
+#define SB2_MMA4(v, pa_, pb_)                                                                                  \
+  acc[v][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[0][pb_], acc[v][0][0], 0, 0, 0);     \
+  acc[v][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][pa_], bf[1][pb_], acc[v][0][1], 0, 0, 0);     \
+  acc[v][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[0][pb_], acc[v][1][0], 0, 0, 0);     \
+  acc[v][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][pa_], bf[1][pb_], acc[v][1][1], 0, 0, 0);
+#define SB2_HALF(v) SB2_MMA4(v, 0, 2) SB2_MMA4(v, 2, 0) SB2_MMA4(v, 1, 1) SB2_MMA4(v, 0, 1) SB2_MMA4(v, 1, 0) SB2_MMA4(v, 0, 0)
 #define SB2_LOAD_B()                                                                                               \
   bf16x8 bf[2][3];                                                                                                 \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int p = 0; p < 3; ++p) bf[j][p] =           \
       *reinterpret_cast<const bf16x8*>(cur + fob + p * SB2_PLANE + j * 1024);                                      \
-  bf16x8 af[3];
+  bf16x8 af[2][3];
 
   // steady state: chunk kt+1 is in the registers, branch-free body (the chunk index of the next loads is clamped)
   for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -127,62 +130,53 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dual_sb2(GemmArgs a, int tiles_
     SB2_LOAD_B()
     // ---- first half: value rows (the loads of chunk kt+1 land meanwhile)
     SB2_AF(0, 0)
-    SB2_GROUP(0, 0)
     SB2_AF(0, 1)
-    SB2_GROUP(0, 1)
+    SB2_HALF(0)
     __builtin_amdgcn_sched_barrier(0);
     // ---- second half: tangent rows, interleaved with the split of chunk kt+1 and the loads of chunk kt+2
     uint4 h, m, l;
     SB2_AF(1, 0)
-    SB2_MMA(1, 0, 0, 2)
+    SB2_AF(1, 1)
+    SB2_MMA4(1, 0, 2)
     split2(a0.x, a0.y, h.x, m.x, l.x);
-    SB2_MMA(1, 0, 2, 0)
     split2(a0.z, a0.w, h.y, m.y, l.y);
-    SB2_MMA(1, 0, 1, 1)
+    SB2_MMA4(1, 2, 0)
     split2(a1.x, a1.y, h.z, m.z, l.z);
-    SB2_MMA(1, 0, 0, 1)
     split2(a1.z, a1.w, h.w, m.w, l.w);
-    SB2_MMA(1, 0, 1, 0)
     *reinterpret_cast<uint4*>(nxt + 0 * SB2_PLANE + soff) = h;
     *reinterpret_cast<uint4*>(nxt + 1 * SB2_PLANE + soff) = m;
     *reinterpret_cast<uint4*>(nxt + 2 * SB2_PLANE + soff) = l;
-    SB2_MMA(1, 0, 0, 0)
-    SB2_AF(1, 1)
+    SB2_MMA4(1, 1, 1)
     split2(t0.x, t0.y, h.x, m.x, l.x);
-    SB2_MMA(1, 1, 0, 2)
     split2(t0.z, t0.w, h.y, m.y, l.y);
-    SB2_MMA(1, 1, 2, 0)
+    SB2_MMA4(1, 0, 1)
     split2(t1.x, t1.y, h.z, m.z, l.z);
-    SB2_MMA(1, 1, 1, 1)
     split2(t1.z, t1.w, h.w, m.w, l.w);
-    SB2_MMA(1, 1, 0, 1)
     *reinterpret_cast<uint4*>(nxt + 3 * SB2_PLANE + soff) = h;
     *reinterpret_cast<uint4*>(nxt + 4 * SB2_PLANE + soff) = m;
     *reinterpret_cast<uint4*>(nxt + 5 * SB2_PLANE + soff) = l;
+    SB2_MMA4(1, 1, 0)
     *reinterpret_cast<uint4*>(nxt + 6 * SB2_PLANE + soff) = w0;
     *reinterpret_cast<uint4*>(nxt + 7 * SB2_PLANE + soff) = w1;
     *reinterpret_cast<uint4*>(nxt + 8 * SB2_PLANE + soff) = w2;
-    SB2_MMA(1, 1, 1, 0)
     SB2_FETCH(kf)
-    SB2_MMA(1, 1, 0, 0)
+    SB2_MMA4(1, 0, 0)
     __syncthreads();
   }
   {  // last chunk: multiply only
     const unsigned char* cur = smem + ((nk - 1) & 1) * SB2_STAGE;
     SB2_LOAD_B()
     SB2_AF(0, 0)
-    SB2_GROUP(0, 0)
     SB2_AF(0, 1)
-    SB2_GROUP(0, 1)
+    SB2_HALF(0)
     SB2_AF(1, 0)
-    SB2_GROUP(1, 0)
     SB2_AF(1, 1)
-    SB2_GROUP(1, 1)
+    SB2_HALF(1)
   }
 #undef SB2_LOAD_B
 #undef SB2_AF
-#undef SB2_MMA
-#undef SB2_GROUP
+#undef SB2_MMA4
+#undef SB2_HALF
 #undef SB2_FETCH
   // Epilogue.  A lane owns one column of each 32x32 accumulator block, so direct stores are 4 bytes per lane and the
   // 128 store instructions per lane clog the CU's vector-memory queue (the co-resident block's loads wait behind
