@@ -175,7 +175,13 @@ template <int HD>
 __device__ __forceinline__ float head_sum_t(float v, int hd) {  // HD = 16 / 8 / 4: compile-time width (no branches)
   return HD > 0 ? row_sum(v, HD) : head_sum(v, hd);
 }
-template <bool HAS_DK, bool HAS_DV>
+// pair-row element with the storage mode known at compile time: the fp32 default is a plain load (the run-time select of ldpair
+// costs four VALU instructions per value: a fifth of the sweeps' instruction count)
+template <bool BF>
+__device__ __forceinline__ float ldpair_t(const float* base, int64_t idx) {
+  return BF ? ldpair(base, idx, 1) : base[idx];
+}
+template <bool HAS_DK, bool HAS_DV, bool BF>
 __device__ __forceinline__ void et_fwd_load(const Graph& g, const EtAttnArgs& a, const EtIdx& ix, int c, EtFwdIn& o) {
   const int F = a.F;
   const int s = ix.j, p = ix.p;
@@ -186,10 +192,10 @@ __device__ __forceinline__ void et_fwd_load(const Graph& g, const EtAttnArgs& a,
   o.v1j = qs[3 * F];
   o.v2j = qs[4 * F];
   const int64_t dkv_b = (int64_t)p * a.Wd + c;
-  o.dk = HAS_DK ? ldpair(a.dkv, dkv_b + (a.dk_off), a.pair_bf16) : 1.0f;
-  o.dvx = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off), a.pair_bf16) : 1.0f;
-  o.dv1 = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off + F), a.pair_bf16) : 1.0f;
-  o.dv2 = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off + 2 * F), a.pair_bf16) : 1.0f;
+  o.dk = HAS_DK ? ldpair_t<BF>(a.dkv, dkv_b + (a.dk_off)) : 1.0f;
+  o.dvx = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off)) : 1.0f;
+  o.dv1 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + F)) : 1.0f;
+  o.dv2 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + 2 * F)) : 1.0f;
   const float* vs = a.vec + (int64_t)s * 3 * F + c;
   o.vs0 = vs[0];
   o.vs1 = vs[F];
@@ -200,7 +206,7 @@ __device__ __forceinline__ void et_fwd_load(const Graph& g, const EtAttnArgs& a,
   o.r1 = sg != 0.f ? -sg * h1 : 0.f;
   o.r2 = sg != 0.f ? -sg * h2 : 0.f;
 }
-template <bool HAS_DK, bool HAS_DV, bool VCUT, int HD>
+template <bool HAS_DK, bool HAS_DV, bool VCUT, int HD, bool BF>
 __global__ void k_et_attn_fwd_p(Graph g, EtAttnArgs a, float* __restrict__ xagg, float* __restrict__ vagg) {
   const int t = xcd_chunk(blockIdx.x, gridDim.x);
   if (g.counts[2]) return;
@@ -223,10 +229,10 @@ __global__ void k_et_attn_fwd_p(Graph g, EtAttnArgs a, float* __restrict__ xagg,
   int e = e0;
   for (; e + 4 <= e1; e += 4) {
     EtFwdIn a0, a1, a2, a3;
-    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e, e0, e1, rot)), c, a0);
-    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e + 1, e0, e1, rot)), c, a1);
-    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e + 2, e0, e1, rot)), c, a2);
-    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e + 3, e0, e1, rot)), c, a3);
+    et_fwd_load<HAS_DK, HAS_DV, BF>(g, a, et_idx(g, et_rot(e, e0, e1, rot)), c, a0);
+    et_fwd_load<HAS_DK, HAS_DV, BF>(g, a, et_idx(g, et_rot(e + 1, e0, e1, rot)), c, a1);
+    et_fwd_load<HAS_DK, HAS_DV, BF>(g, a, et_idx(g, et_rot(e + 2, e0, e1, rot)), c, a2);
+    et_fwd_load<HAS_DK, HAS_DV, BF>(g, a, et_idx(g, et_rot(e + 3, e0, e1, rot)), c, a3);
     add(a0);
     add(a1);
     add(a2);
@@ -234,7 +240,7 @@ __global__ void k_et_attn_fwd_p(Graph g, EtAttnArgs a, float* __restrict__ xagg,
   }
   for (; e < e1; ++e) {
     EtFwdIn a0;
-    et_fwd_load<HAS_DK, HAS_DV>(g, a, et_idx(g, et_rot(e, e0, e1, rot)), c, a0);
+    et_fwd_load<HAS_DK, HAS_DV, BF>(g, a, et_idx(g, et_rot(e, e0, e1, rot)), c, a0);
     add(a0);
   }
   xagg[(int64_t)t * F + c] = xa;
@@ -251,9 +257,15 @@ void launch_et_attn_fwd(const Graph& g, int N, const EtAttnArgs& a, float* xagg,
   if (N <= 0) return;
   if (et_pipelined_ok(a)) {
     const dim3 grid(N), block(a.F);
-#define ET_FWD(DK, DV, VC)                                                                                     \
-  if (a.hd == 16) hipLaunchKernelGGL((k_et_attn_fwd_p<DK, DV, VC, 16>), grid, block, 0, s, g, a, xagg, vagg); \
-  else hipLaunchKernelGGL((k_et_attn_fwd_p<DK, DV, VC, 0>), grid, block, 0, s, g, a, xagg, vagg)
+#define ET_FWD2(DK, DV, VC, BF)                                                                                    \
+  if (a.hd == 16) hipLaunchKernelGGL((k_et_attn_fwd_p<DK, DV, VC, 16, BF>), grid, block, 0, s, g, a, xagg, vagg); \
+  else hipLaunchKernelGGL((k_et_attn_fwd_p<DK, DV, VC, 0, BF>), grid, block, 0, s, g, a, xagg, vagg)
+#define ET_FWD(DK, DV, VC)              \
+  if (a.pair_bf16) {                    \
+    ET_FWD2(DK, DV, VC, true);          \
+  } else {                              \
+    ET_FWD2(DK, DV, VC, false);         \
+  }
     const int key = (a.dk_off >= 0 ? 4 : 0) | (a.dv_off >= 0 ? 2 : 0) | (a.vector_cutoff ? 1 : 0);
     switch (key) {
       case 0: ET_FWD(false, false, false); break;
@@ -266,6 +278,7 @@ void launch_et_attn_fwd(const Graph& g, int N, const EtAttnArgs& a, float* xagg,
       default: ET_FWD(true, true, true); break;
     }
 #undef ET_FWD
+#undef ET_FWD2
     return;
   }
   hipLaunchKernelGGL(k_et_attn_fwd, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, xagg, vagg);
@@ -464,7 +477,7 @@ struct EtBwdIn {
   float qj, kj, vxj, v1j, v2j, dk, tk, dvx, dv1, dv2, tvx, tv1, tv2, vj0, vj1, vj2, gxj, gj0, gj1, gj2, C, dC, p0, p1, p2, sg;
   int p;
 };
-template <bool HAS_DK, bool HAS_DV>
+template <bool HAS_DK, bool HAS_DV, bool BF>
 __device__ __forceinline__ void et_bwd_load(const Graph& g, const EtAttnArgs& a, const float* __restrict__ g_xagg,
                                             const float* __restrict__ g_vagg, const EtIdx& ix, int c, EtBwdIn& o) {
   const int F = a.F;
@@ -480,14 +493,14 @@ __device__ __forceinline__ void et_bwd_load(const Graph& g, const EtAttnArgs& a,
   o.v2j = jq[4 * F];
   const int64_t dkv_b = (int64_t)p * a.Wd + c;
   const int64_t tkv_b = (int64_t)p * a.Wd + c;
-  o.dk = HAS_DK ? ldpair(a.dkv, dkv_b + (a.dk_off), a.pair_bf16) : 1.f;
-  o.tk = HAS_DK ? ldpair(a.tkv, tkv_b + (a.dk_off), a.pair_bf16) : 0.f;
-  o.dvx = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off), a.pair_bf16) : 1.f;
-  o.dv1 = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off + F), a.pair_bf16) : 1.f;
-  o.dv2 = HAS_DV ? ldpair(a.dkv, dkv_b + (a.dv_off + 2 * F), a.pair_bf16) : 1.f;
-  o.tvx = HAS_DV ? ldpair(a.tkv, tkv_b + (a.dv_off), a.pair_bf16) : 0.f;
-  o.tv1 = HAS_DV ? ldpair(a.tkv, tkv_b + (a.dv_off + F), a.pair_bf16) : 0.f;
-  o.tv2 = HAS_DV ? ldpair(a.tkv, tkv_b + (a.dv_off + 2 * F), a.pair_bf16) : 0.f;
+  o.dk = HAS_DK ? ldpair_t<BF>(a.dkv, dkv_b + (a.dk_off)) : 1.f;
+  o.tk = HAS_DK ? ldpair_t<BF>(a.tkv, tkv_b + (a.dk_off)) : 0.f;
+  o.dvx = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off)) : 1.f;
+  o.dv1 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + F)) : 1.f;
+  o.dv2 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + 2 * F)) : 1.f;
+  o.tvx = HAS_DV ? ldpair_t<BF>(a.tkv, tkv_b + (a.dv_off)) : 0.f;
+  o.tv1 = HAS_DV ? ldpair_t<BF>(a.tkv, tkv_b + (a.dv_off + F)) : 0.f;
+  o.tv2 = HAS_DV ? ldpair_t<BF>(a.tkv, tkv_b + (a.dv_off + 2 * F)) : 0.f;
   const float* vj = a.vec + (int64_t)j * 3 * F + c;
   o.vj0 = vj[0];
   o.vj1 = vj[F];
@@ -505,7 +518,7 @@ __device__ __forceinline__ void et_bwd_load(const Graph& g, const EtAttnArgs& a,
   o.p2 = sg != 0.f ? sg * h2 : 0.f;
 }
 // k_et_attn_bwd (both roles of the row atom in one sweep), pipelined: same arithmetic in the same order
-template <bool HAS_DK, bool HAS_DV, bool VCUT, int HD>
+template <bool HAS_DK, bool HAS_DV, bool VCUT, int HD, bool BF>
 __global__ void k_et_attn_bwd_p(Graph g, EtAttnArgs a, const float* __restrict__ g_xagg, const float* __restrict__ g_vagg,
                                 float* __restrict__ g_qkv, float* __restrict__ g_vec, float* __restrict__ gd2,
                                 float* __restrict__ gr2) {
@@ -527,12 +540,12 @@ __global__ void k_et_attn_bwd_p(Graph g, EtAttnArgs a, const float* __restrict__
   EtIdx in = {0, 0, 0.f}, inn;
   const int rot = et_rot_start(g.col, e0, e1, r);
   if (e0 < e1) {
-    et_bwd_load<HAS_DK, HAS_DV>(g, a, g_xagg, g_vagg, et_idx(g, et_rot(e0, e0, e1, rot)), c, u);
+    et_bwd_load<HAS_DK, HAS_DV, BF>(g, a, g_xagg, g_vagg, et_idx(g, et_rot(e0, e0, e1, rot)), c, u);
     in = et_idx(g, et_rot(e0 + 1 < e1 ? e0 + 1 : e0, e0, e1, rot));
   }
   for (int e = e0; e < e1; ++e) {
     inn = et_idx(g, et_rot(e + 2 < e1 ? e + 2 : e1 - 1, e0, e1, rot));
-    et_bwd_load<HAS_DK, HAS_DV>(g, a, g_xagg, g_vagg, in, c, nxt);
+    et_bwd_load<HAS_DK, HAS_DV, BF>(g, a, g_xagg, g_vagg, in, c, nxt);
     in = inn;
     const float cv = VCUT ? u.C : 1.0f, ca = VCUT ? 1.0f : u.C;
     // ---- role TARGET: message j -> r
@@ -591,11 +604,17 @@ void launch_et_attn_bwd(const Graph& g, int N, const EtAttnArgs& a, const float*
   if (N <= 0) return;
   if (et_pipelined_ok(a)) {
     const dim3 grid(N), block(a.F);
-#define ET_BWD(DK, DV, VC)                                                                                                   \
-  if (a.hd == 16)                                                                                                           \
-    hipLaunchKernelGGL((k_et_attn_bwd_p<DK, DV, VC, 16>), grid, block, 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2); \
-  else                                                                                                                      \
-    hipLaunchKernelGGL((k_et_attn_bwd_p<DK, DV, VC, 0>), grid, block, 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2)
+#define ET_BWD2(DK, DV, VC, BF)                                                                                                  \
+  if (a.hd == 16)                                                                                                               \
+    hipLaunchKernelGGL((k_et_attn_bwd_p<DK, DV, VC, 16, BF>), grid, block, 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2); \
+  else                                                                                                                          \
+    hipLaunchKernelGGL((k_et_attn_bwd_p<DK, DV, VC, 0, BF>), grid, block, 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2)
+#define ET_BWD(DK, DV, VC)      \
+  if (a.pair_bf16) {            \
+    ET_BWD2(DK, DV, VC, true);  \
+  } else {                      \
+    ET_BWD2(DK, DV, VC, false); \
+  }
     const int key = (a.dk_off >= 0 ? 4 : 0) | (a.dv_off >= 0 ? 2 : 0) | (a.vector_cutoff ? 1 : 0);
     switch (key) {
       case 0: ET_BWD(false, false, false); break;
@@ -608,6 +627,7 @@ void launch_et_attn_bwd(const Graph& g, int N, const EtAttnArgs& a, const float*
       default: ET_BWD(true, true, true); break;
     }
 #undef ET_BWD
+#undef ET_BWD2
     return;
   }
   hipLaunchKernelGGL(k_et_attn_bwd, dim3(N), dim3(bthreads(a.F)), 0, s, g, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2);
