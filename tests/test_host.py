@@ -336,3 +336,47 @@ def test_tensornet2_host_mirror_matches_reference_init_and_keys(hip_lib):
         hip_lib.tmdnet_destroy(handle)
     with pytest.raises(NotImplementedError):
         create_model(dict(args, output_model="Scalar"))
+
+
+def test_parameter_gradient_entries_map_back_to_state_dict_rows():
+    """torchmdnet_amd/models/model.py::_et_grads undoes the engine's packing (csrc/tn_et_api.hip `thirds`: value-type rows from the
+    reference's per-head [H][3][hd] order to thirds [3][F]); with entries that carry their own engine row index every state-dict
+    row must come back in place.  No GPU: the entries are made up here."""
+    import torch
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.ET_TINY_ARGS)
+    model = create_model(dict(args))
+    rm = model.representation_model
+    F, hd, K = rm.hidden_channels, rm.hidden_channels // rm.num_heads, args["num_rbf"]
+    Z, F2 = rm.embedding.weight.shape[0], F // 2
+
+    def thirds_src(dst_row):  # state-dict row of engine row t * F + c (the C++ packer, restated)
+        t, c = divmod(dst_row, F)
+        return (c // hd) * 3 * hd + t * hd + c % hd
+
+    ent = {"emb": torch.zeros(Z * F), "embN": torch.zeros(Z * F), "Wn": torch.zeros(F * K), "bn": torch.zeros(F), "Wc": torch.zeros(2 * F * F),
+           "bc": torch.zeros(F), "lno_w": torch.zeros(F), "lno_b": torch.zeros(F), "W1u": torch.zeros((F + F2) * F), "Wm1": torch.zeros(2 * F * F),
+           "bm1": torch.zeros(F), "Wm2": torch.zeros(F * F), "bm2": torch.zeros(F), "W21": torch.zeros(F2 * F2), "Wn1": torch.zeros(F2 * F),
+           "bn1": torch.zeros(F2), "Wn2": torch.arange(F2, dtype=torch.float32), "bn2": torch.tensor([7.0])}
+    for l in range(args["num_layers"]):
+        t = "l%d." % l
+        ent.update({t + "ln_w": torch.zeros(F), t + "ln_b": torch.zeros(F), t + "Wvp": torch.zeros(3 * F * F), t + "Wo": torch.zeros(3 * F * F),
+                    t + "bo": torch.zeros(3 * F)})
+        ent[t + "bqkv"] = torch.arange(5 * F, dtype=torch.float32)                      # value = engine row
+        ent[t + "Wqkv"] = torch.arange(5 * F, dtype=torch.float32).repeat_interleave(F)
+        ent[t + "bdkv"] = torch.arange(4 * F, dtype=torch.float32)
+        ent[t + "Wdkv"] = torch.arange(4 * F, dtype=torch.float32).repeat_interleave(K)
+    grads = model._et_grads(ent)
+    al = rm.attention_layers[0]
+    assert torch.equal(grads[al.q_proj.bias], torch.arange(F, dtype=torch.float32))
+    assert torch.equal(grads[al.k_proj.bias], torch.arange(F, 2 * F, dtype=torch.float32))
+    gv, gdv = grads[al.v_proj.bias], grads[al.dv_proj.bias]
+    for dst in range(3 * F):
+        assert gv[thirds_src(dst)] == 2 * F + dst and gdv[thirds_src(dst)] == F + dst
+    assert torch.equal(grads[al.v_proj.weight][:, 0], gv) and torch.equal(grads[al.dk_proj.bias], torch.arange(F, dtype=torch.float32))
+    last = model.output_model.output_network[1].update_net.layers[2]
+    assert torch.equal(grads[last.weight][0], torch.arange(F2, dtype=torch.float32)) and grads[last.weight][1].abs().max() == 0
+    assert grads[last.bias][0] == 7.0 and grads[last.bias][1] == 0.0
+    assert set(id(p) for p in grads) <= set(id(p) for p in model.parameters())
