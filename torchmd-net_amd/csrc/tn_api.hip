@@ -733,11 +733,16 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   put("Utab", std::vector<float>((size_t)m->hp.max_z * F, 0.f));
   put("Vtab", std::vector<float>((size_t)m->hp.max_z * F, 0.f));
 
-  if (m->dev) {
+  // device buffers are kept across uploads of the same size (a training loop re-uploads every step: hipFree / hipMalloc are
+  // device-wide synchronisations)
+  if (m->dev && m->dev_cap < pk.buf.size()) {
     HIP_TRY(m, hipFree(m->dev));
     m->dev = nullptr;
   }
-  HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev), pk.buf.size() * sizeof(float)));
+  if (!m->dev) {
+    HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev), pk.buf.size() * sizeof(float)));
+    m->dev_cap = pk.buf.size();
+  }
   HIP_TRY(m, hipMemcpy(m->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice));
   auto D = [&](const std::string& key) -> const float* { return m->dev + off.at(key); };
   DevParams& P = m->P;
@@ -847,11 +852,14 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     add_sb("LinT", 3 * F, F);
     add_sb("O1", H, F);
     add_sb("O1T", F, H);
-    if (m->dev_sb) {
+    if (m->dev_sb && m->dev_sb_cap < sb.size()) {
       HIP_TRY(m, hipFree(m->dev_sb));
       m->dev_sb = nullptr;
     }
-    HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev_sb), sb.size() * sizeof(uint16_t)));
+    if (!m->dev_sb) {
+      HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev_sb), sb.size() * sizeof(uint16_t)));
+      m->dev_sb_cap = sb.size();
+    }
     HIP_TRY(m, hipMemcpy(m->dev_sb, sb.data(), sb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     m->sb_of.clear();
     for (const auto& im : imgs) m->sb_of[m->dev + off.at(im.key)] = m->dev_sb + im.o;
@@ -882,17 +890,20 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     }
   }
   {  // embedding in the radial basis: MFMA fragment images of the distance projections (tn_embed_rb.hip)
-    if (m->rb_img) {
-      HIP_TRY(m, hipFree(m->rb_img));
-      m->rb_img = nullptr;
-    }
     m->rb_fwd = m->rb_rev = nullptr;
     const char* env = getenv("TMDNET_EMBED_RB");  // developer switch: 0 keeps the per-pair tables for the embedding
     if (!(env && atoi(env) == 0) && embed_rb_shape_ok(F, K)) {
       const size_t nf = embed_rb_image_elems(F, K, false), nr = embed_rb_image_elems(F, K, true);
       std::vector<uint16_t> img(nf + nr);
       embed_rb_images(pk.buf.data() + off.at("Wdp"), pk.buf.data() + off.at("bdp"), F, K, img.data(), img.data() + nf);
-      HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->rb_img), img.size() * sizeof(uint16_t)));
+      if (m->rb_img && m->rb_cap < img.size()) {
+        HIP_TRY(m, hipFree(m->rb_img));
+        m->rb_img = nullptr;
+      }
+      if (!m->rb_img) {
+        HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->rb_img), img.size() * sizeof(uint16_t)));
+        m->rb_cap = img.size();
+      }
       HIP_TRY(m, hipMemcpy(m->rb_img, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
       m->rb_fwd = m->rb_img;
       m->rb_rev = m->rb_img + nf;

@@ -175,6 +175,7 @@ struct tmdnet_model {
   std::vector<ParamSpec> specs;
   std::map<std::string, std::vector<float>> host;
   float* dev = nullptr;  // packed parameters
+  size_t dev_cap = 0, dev_sb_cap = 0, rb_cap = 0;  // element capacities of dev / dev_sb / rb_img (kept across re-uploads)
   uint16_t* dev_sb = nullptr;  // split-bf16 weight tile images
   std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
   DevParams P;

@@ -552,21 +552,20 @@ class TorchMD_Net(nn.Module):
         if st.handle is not None and st.fingerprint == fp:
             return st
         L = _C.lib()
-        st.release()
-        st.generation += 1
-        handle = C.c_void_p()
-        if self._is_et():
-            hp = self._et_hparams()
-            rc = L.tmdnet_create_et(C.byref(hp), C.byref(handle))
-        elif self._is_tn2():
-            hp = self._tn2_hparams()
-            rc = L.tmdnet_create_tn2(C.byref(hp), C.byref(handle))
-        else:
-            hp = self._hparams()
-            rc = L.tmdnet_create(C.byref(hp), C.byref(handle))
-        if rc != _C.OK:
-            raise RuntimeError(f"tmdnet_create failed with code {rc}")
-        st.handle = handle
+        hp = self._et_hparams() if self._is_et() else (self._tn2_hparams() if self._is_tn2() else self._hparams())
+        hp_key = (type(hp).__name__, bytes(hp))
+        st.generation += 1  # captured replays of the previous weights are stale either way
+        if st.handle is None or getattr(st, "hp_key", None) != hp_key:
+            st.release()
+            handle = C.c_void_p()
+            create = L.tmdnet_create_et if self._is_et() else (L.tmdnet_create_tn2 if self._is_tn2() else L.tmdnet_create)
+            rc = create(C.byref(hp), C.byref(handle))
+            if rc != _C.OK:
+                raise RuntimeError(f"tmdnet_create failed with code {rc}")
+            st.handle, st.hp_key = handle, hp_key
+        # else: same architecture, new weights (training loop): the handle and its device buffers are kept, the parameters
+        # are re-uploaded below (hipFree / hipMalloc per step would each be a device-wide synchronisation)
+        handle = st.handle
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         table = self._atomref_table()
         if table is not None:
