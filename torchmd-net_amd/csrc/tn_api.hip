@@ -799,13 +799,11 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   {  // split-bf16 tile images (tn_gemm_sb.hip / tn_gemm_sb1.hip) of every GEMM weight, keyed by its fp32 device copy
     struct Img { std::string key; int64_t n, k; size_t o; };
     std::vector<Img> imgs;
-    std::vector<uint16_t> sb;
+    size_t sb_elems = 0;  // the images are made on the device from the uploaded fp32 copies (the host loop cost 4 - 6 ms per upload)
     auto add_sb = [&](const std::string& key, int64_t n, int64_t k) {  // packed matrix `key` is [n][k] row-major
       if ((k & 15) || (n & 3)) return;  // shapes the split kernels do not take stay on the fp32-MFMA kernels
-      const size_t o = sb.size();
-      sb.resize(o + split_weight_elems(n, k));
-      split_weight_tiles(pk.buf.data() + off.at(key), n, k, sb.data() + o);
-      imgs.push_back({key, n, k, o});
+      imgs.push_back({key, n, k, sb_elems});
+      sb_elems += split_weight_elems(n, k);
     };
     add_sb("Wdp", 3 * F, K);
     for (int k = 0; k < 3; ++k) {
@@ -852,15 +850,15 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     add_sb("LinT", 3 * F, F);
     add_sb("O1", H, F);
     add_sb("O1T", F, H);
-    if (m->dev_sb && m->dev_sb_cap < sb.size()) {
+    if (m->dev_sb && m->dev_sb_cap < sb_elems) {
       HIP_TRY(m, hipFree(m->dev_sb));
       m->dev_sb = nullptr;
     }
     if (!m->dev_sb) {
-      HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev_sb), sb.size() * sizeof(uint16_t)));
-      m->dev_sb_cap = sb.size();
+      HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev_sb), sb_elems * sizeof(uint16_t)));
+      m->dev_sb_cap = sb_elems;
     }
-    HIP_TRY(m, hipMemcpy(m->dev_sb, sb.data(), sb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    for (const auto& im : imgs) launch_split_weight_tiles(m->dev + off.at(im.key), im.n, im.k, m->dev_sb + im.o, nullptr);
     m->sb_of.clear();
     for (const auto& im : imgs) m->sb_of[m->dev + off.at(im.key)] = m->dev_sb + im.o;
     auto sb_or_null = [&](const float* w) -> const uint16_t* {

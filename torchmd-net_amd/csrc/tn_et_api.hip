@@ -311,26 +311,32 @@ int et_finalize(tmdnet_model* m) {
   put("bn2", h[O1 + "update_net.layers.2.bias"]);
   if (hp.has_atomref) put("atomref", h["atomref"]);
 
-  if (m->dev) {
+  if (m->dev && m->dev_cap < pk.buf.size()) {
     HIP_TRY(m, hipFree(m->dev));
     m->dev = nullptr;
   }
-  HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev), pk.buf.size() * sizeof(float)));
+  if (!m->dev) {
+    HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev), pk.buf.size() * sizeof(float)));
+    m->dev_cap = pk.buf.size();
+  }
   HIP_TRY(m, hipMemcpy(m->dev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice));
   {  // split-bf16 tile images of every GEMM weight
-    std::vector<uint16_t> sb;
-    std::vector<size_t> so;
+    std::vector<size_t> so;  // made on the device from the uploaded fp32 copies
+    size_t sb_elems = 0;
     for (const auto& im : imgs) {
-      so.push_back(sb.size());
-      sb.resize(sb.size() + split_weight_elems(im.n, im.k));
-      split_weight_tiles(pk.buf.data() + off.at(im.key), im.n, im.k, sb.data() + so.back());
+      so.push_back(sb_elems);
+      sb_elems += split_weight_elems(im.n, im.k);
     }
-    if (m->dev_sb) {
+    if (m->dev_sb && m->dev_sb_cap < sb_elems) {
       HIP_TRY(m, hipFree(m->dev_sb));
       m->dev_sb = nullptr;
     }
-    HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev_sb), sb.size() * sizeof(uint16_t)));
-    HIP_TRY(m, hipMemcpy(m->dev_sb, sb.data(), sb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    if (!m->dev_sb) {
+      HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->dev_sb), sb_elems * sizeof(uint16_t)));
+      m->dev_sb_cap = sb_elems;
+    }
+    for (size_t i = 0; i < imgs.size(); ++i)
+      launch_split_weight_tiles(m->dev + off.at(imgs[i].key), imgs[i].n, imgs[i].k, m->dev_sb + so[i], nullptr);
     m->sb_of.clear();
     for (size_t i = 0; i < imgs.size(); ++i) m->sb_of[m->dev + off.at(imgs[i].key)] = m->dev_sb + so[i];
   }
@@ -389,6 +395,7 @@ int et_finalize(tmdnet_model* m) {
   P.atomref = hp.has_atomref ? D("atomref") : nullptr;
   P.mean = h["mean"][0];
   P.std = h["std"][0];
+  HIP_TRY(m, hipStreamSynchronize(nullptr));  // the weight images are made by kernels on the NULL stream
   free_radial_tables(m->tabs);  // built by the first call that uses them (ensure_radial_tables -> et_build_tables)
   m->tabs_pending = true;
   m->finalized = true;

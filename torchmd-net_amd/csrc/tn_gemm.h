@@ -60,5 +60,6 @@ bool gemm_sb1_ok(const GemmArgs& args);
 int launch_gemm_sb1(const GemmArgs& args, hipStream_t stream);
 size_t split_weight_elems(int64_t N, int64_t K);                                   // uint16 elements of the tile image
 void split_weight_tiles(const float* W_host, int64_t N, int64_t K, uint16_t* out_host);
+void launch_split_weight_tiles(const float* W_dev, int64_t N, int64_t K, uint16_t* out_dev, hipStream_t s);  // same image, on the device
 
 }  // namespace tn

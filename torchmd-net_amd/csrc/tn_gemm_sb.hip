@@ -293,4 +293,30 @@ void split_weight_tiles(const float* W, int64_t N, int64_t K, uint16_t* out) {
     }
 }
 
+
+// the same tile image from a weight that already sits in device memory (parameter upload: tn_api.hip / tn_et_api.hip); one thread
+// per pair of consecutive k, rounding as split2 = bf16_rne at every level
+__global__ void k_split_weight_tiles(const float* __restrict__ W, int N, int K, int nk, uint16_t* __restrict__ out, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int kp = (int)(idx & 7), r = (int)((idx >> 3) & 127);
+  const int64_t tc = idx >> 10;  // tile * nk + chunk
+  const int c = (int)(tc % nk);
+  const int64_t t = tc / nk;
+  const int64_t n = t * 128 + r;
+  const int kk = c * 16 + 2 * kp;
+  const float x0 = (n < N && kk < K) ? W[n * K + kk] : 0.f, x1 = (n < N && kk + 1 < K) ? W[n * K + kk + 1] : 0.f;
+  uint32_t h, m, l;
+  split2(x0, x1, h, m, l);
+  uint32_t* blk = reinterpret_cast<uint32_t*>(out + tc * 3 * 128 * 16);
+  blk[(0 * 128 + r) * 8 + kp] = h;
+  blk[(1 * 128 + r) * 8 + kp] = m;
+  blk[(2 * 128 + r) * 8 + kp] = l;
+}
+void launch_split_weight_tiles(const float* W_dev, int64_t N, int64_t K, uint16_t* out_dev, hipStream_t s) {
+  const int64_t tn = (N + 127) / 128, nk = (K + 15) / 16, total = tn * nk * 128 * 8;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(k_split_weight_tiles, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W_dev, (int)N, (int)K, (int)nk, out_dev, total);
+}
+
 }  // namespace tn
