@@ -176,10 +176,12 @@ __device__ __forceinline__ float head_sum_t(float v, int hd) {  // HD = 16 / 8 /
   return HD > 0 ? row_sum(v, HD) : head_sum(v, hd);
 }
 // pair-row element with the storage mode known at compile time: the fp32 default is a plain load (the run-time select of ldpair
-// costs four VALU instructions per value: a fifth of the sweeps' instruction count)
+// costs four VALU instructions per value: a fifth of the sweeps' instruction count; ET-SPICE step 11.0 -> 10.6 ms).  The bf16
+// instantiation keeps ldpair's run-time form ON PURPOSE: with the flag folded to a constant the same sweep was 0.5 ms per step
+// SLOWER (A/B on one box: 9.85 vs 10.39 ms) - the compiler then schedules the unpacking differently.
 template <bool BF>
-__device__ __forceinline__ float ldpair_t(const float* base, int64_t idx) {
-  return BF ? ldpair(base, idx, 1) : base[idx];
+__device__ __forceinline__ float ldpair_t(const float* base, int64_t idx, int rt_bf16) {
+  return BF ? ldpair(base, idx, rt_bf16) : base[idx];
 }
 template <bool HAS_DK, bool HAS_DV, bool BF>
 __device__ __forceinline__ void et_fwd_load(const Graph& g, const EtAttnArgs& a, const EtIdx& ix, int c, EtFwdIn& o) {
@@ -192,10 +194,10 @@ __device__ __forceinline__ void et_fwd_load(const Graph& g, const EtAttnArgs& a,
   o.v1j = qs[3 * F];
   o.v2j = qs[4 * F];
   const int64_t dkv_b = (int64_t)p * a.Wd + c;
-  o.dk = HAS_DK ? ldpair_t<BF>(a.dkv, dkv_b + (a.dk_off)) : 1.0f;
-  o.dvx = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off)) : 1.0f;
-  o.dv1 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + F)) : 1.0f;
-  o.dv2 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + 2 * F)) : 1.0f;
+  o.dk = HAS_DK ? ldpair_t<BF>(a.dkv, dkv_b + (a.dk_off), a.pair_bf16) : 1.0f;
+  o.dvx = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off), a.pair_bf16) : 1.0f;
+  o.dv1 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + F), a.pair_bf16) : 1.0f;
+  o.dv2 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + 2 * F), a.pair_bf16) : 1.0f;
   const float* vs = a.vec + (int64_t)s * 3 * F + c;
   o.vs0 = vs[0];
   o.vs1 = vs[F];
@@ -493,14 +495,14 @@ __device__ __forceinline__ void et_bwd_load(const Graph& g, const EtAttnArgs& a,
   o.v2j = jq[4 * F];
   const int64_t dkv_b = (int64_t)p * a.Wd + c;
   const int64_t tkv_b = (int64_t)p * a.Wd + c;
-  o.dk = HAS_DK ? ldpair_t<BF>(a.dkv, dkv_b + (a.dk_off)) : 1.f;
-  o.tk = HAS_DK ? ldpair_t<BF>(a.tkv, tkv_b + (a.dk_off)) : 0.f;
-  o.dvx = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off)) : 1.f;
-  o.dv1 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + F)) : 1.f;
-  o.dv2 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + 2 * F)) : 1.f;
-  o.tvx = HAS_DV ? ldpair_t<BF>(a.tkv, tkv_b + (a.dv_off)) : 0.f;
-  o.tv1 = HAS_DV ? ldpair_t<BF>(a.tkv, tkv_b + (a.dv_off + F)) : 0.f;
-  o.tv2 = HAS_DV ? ldpair_t<BF>(a.tkv, tkv_b + (a.dv_off + 2 * F)) : 0.f;
+  o.dk = HAS_DK ? ldpair_t<BF>(a.dkv, dkv_b + (a.dk_off), a.pair_bf16) : 1.f;
+  o.tk = HAS_DK ? ldpair_t<BF>(a.tkv, tkv_b + (a.dk_off), a.pair_bf16) : 0.f;
+  o.dvx = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off), a.pair_bf16) : 1.f;
+  o.dv1 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + F), a.pair_bf16) : 1.f;
+  o.dv2 = HAS_DV ? ldpair_t<BF>(a.dkv, dkv_b + (a.dv_off + 2 * F), a.pair_bf16) : 1.f;
+  o.tvx = HAS_DV ? ldpair_t<BF>(a.tkv, tkv_b + (a.dv_off), a.pair_bf16) : 0.f;
+  o.tv1 = HAS_DV ? ldpair_t<BF>(a.tkv, tkv_b + (a.dv_off + F), a.pair_bf16) : 0.f;
+  o.tv2 = HAS_DV ? ldpair_t<BF>(a.tkv, tkv_b + (a.dv_off + 2 * F), a.pair_bf16) : 0.f;
   const float* vj = a.vec + (int64_t)j * 3 * F + c;
   o.vj0 = vj[0];
   o.vj1 = vj[F];
