@@ -1350,7 +1350,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     // zero-fills are kernels, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to
     // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
     const bool merged_gd = message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD") && !tc;
-    const int gd_nw = message_adjoint_gd_waves(N, F);
+    const int gd_nw = message_adjoint_gd_waves(g, N, F);
     const int64_t gd_stride = 2 * (int64_t)P1;
     if (!merged_gd) launch_fill(b.gd, 0.f, P1, s);  // the per-layer pair kernels accumulate into it
     for (int l = L - 1; l >= 0; --l) {

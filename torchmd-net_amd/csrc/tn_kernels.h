@@ -88,7 +88,7 @@ void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const 
 // adjoint sweep + the layer's per-pair distance gradient in one pass (replaces launch_message_adjoint + launch_pair_gd when
 // message_adjoint_gd_ok): partial sums go to slots[wave][2 * pair + direction], summed by launch_geom_gd
 bool message_adjoint_gd_ok(int N, int F);
-int message_adjoint_gd_waves(int N, int F);  // number of slot arrays the sweep writes per layer
+int message_adjoint_gd_waves(const Graph& g, int N, int F);  // number of slot arrays the sweep writes per layer
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
 // next = 0: plain; 1: nxt = X_hat of the new X (next layer's k_norm_x); 2: nxt = readout invariants of the new X
@@ -195,6 +195,11 @@ void launch_interp_list(const float* tab, const double* dist, int M, int R, int 
 bool message_pair_ok(int N, int F);
 void launch_message_pair(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
                          int o3, float* Mi, float* Ch, hipStream_t s);
+
+// reverse sweep in the same layout (adjoint + distance-gradient halves); slot arrays: one per 32-channel chunk
+bool message_adjoint_pair_ok(const Graph& g, int N, int F);
+void launch_message_adjoint_pair(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
+                                 float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
 
 // 16-byte-per-lane form of the per-pair kernels (tn_pairgrad.hip)
 bool gather_v4_ok(int F);
