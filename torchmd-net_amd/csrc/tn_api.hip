@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "tn_model.h"
+#include "tn_tlin9.h"
 
 using namespace tn;
 
@@ -196,6 +197,22 @@ void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], floa
   launch_gemm(a, s);
 }
 
+
+// fused form (tn_tlin9.hip): the weights' fragment-major images must exist (F % 32 == 0); `tensors` = [N, 9, F] tensors the
+// launch reads or writes (algorithmic bytes of the profile record)
+bool tlin9_images(const float* const W3[3]) {
+  if (!g_cur) return false;
+  for (int t = 0; t < 3; ++t)
+    if (g_cur->fm_of.find(W3[t]) == g_cur->fm_of.end()) return false;
+  return true;
+}
+void tlin9(hipStream_t s, int pro, int epi, const float* const W3[3], Tl9Args a, double tensors, const char* what) {
+  for (int t = 0; t < 3; ++t) a.Wfm[t] = g_cur->fm_of.at(W3[t]);
+  char lab[64];
+  std::snprintf(lab, sizeof(lab), "tlin9 %s 9x%dx%dx%d", what, a.N, a.F, a.F);
+  ProfScope ps_(s, CAT_GEMM_NODE, 2.0 * 9 * a.N * (double)a.F * a.F, 4.0 * (tensors * 9.0 * a.N * a.F + 3.0 * a.F * a.F), lab);
+  launch_tlin9(a, pro, epi, s);
+}
 
 Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total) {
   Carver c(ws);
@@ -850,6 +867,22 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     add_sb("LinT", 3 * F, F);
     add_sb("O1", H, F);
     add_sb("O1T", F, H);
+    // fragment-major images of the 9-component tensor linears' weights (tn_tlin9.hip), same buffer
+    std::vector<Img> fms;
+    auto add_fm = [&](const std::string& key) {
+      if (F % 32) return;
+      fms.push_back({key, F, F, sb_elems});
+      sb_elems += split_weight_fm_elems(F, F);
+    };
+    for (int k = 0; k < 3; ++k) {
+      add_fm("Ue" + std::to_string(k));
+      add_fm("UeT" + std::to_string(k));
+    }
+    for (int l = 0; l < L; ++l)
+      for (int k = 0; k < 6; ++k) {
+        add_fm("l" + std::to_string(l) + ".V" + std::to_string(k));
+        add_fm("l" + std::to_string(l) + ".VT" + std::to_string(k));
+      }
     if (m->dev_sb && m->dev_sb_cap < sb_elems) {
       HIP_TRY(m, hipFree(m->dev_sb));
       m->dev_sb = nullptr;
@@ -859,8 +892,11 @@ int tmdnet_finalize_params(tmdnet_model* m) {
       m->dev_sb_cap = sb_elems;
     }
     for (const auto& im : imgs) launch_split_weight_tiles(m->dev + off.at(im.key), im.n, im.k, m->dev_sb + im.o, nullptr);
+    for (const auto& im : fms) launch_split_weight_fm(m->dev + off.at(im.key), im.n, im.k, m->dev_sb + im.o, nullptr);
     m->sb_of.clear();
+    m->fm_of.clear();
     for (const auto& im : imgs) m->sb_of[m->dev + off.at(im.key)] = m->dev_sb + im.o;
+    for (const auto& im : fms) m->fm_of[m->dev + off.at(im.key)] = m->dev_sb + im.o;
     auto sb_or_null = [&](const float* w) -> const uint16_t* {
       auto it = m->sb_of.find(w);
       return it == m->sb_of.end() ? nullptr : it->second;
@@ -1282,7 +1318,15 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     NODE();
     gemm(s, b.ln0, F, W.L1, F, W.bL1, b.h1, 2 * F, N, 2 * F, F, GEMM_ACT_SILU, b.a1, 2 * F);
     gemm(s, b.h1, 2 * F, W.L2, 2 * F, W.bL2, b.gates, 3 * F, N, 3 * F, 2 * F, GEMM_ACT_SILU, b.a2, 3 * F);
-    tensor_linear(s, b.u0, W.Ue, b.X[0], N, F, GEMM_MUL_AUX, b.UX, b.gates);
+    // fused 9-component tensor linears (tn_tlin9.hip) at batch scale; the parameter-gradient pass keeps the unfused schedule,
+    // whose intermediates (X_hat, C_hat, g_D, g_C_hat per layer) are operands of its weight-gradient products
+    const bool t9 = !tc && tlin9_ok(N, F) && tlin9_images(W.Ue) && tlin9_images(W.UeT) && (L == 0 || tlin9_images(W.layer[0].V));
+    if (t9) {
+      Tl9Args ta{};
+      ta.A = b.u0; ta.C = b.X[0]; ta.o1 = b.UX; ta.e3 = b.gates; ta.N = N; ta.F = F;
+      tlin9(s, TL9_PRO_PLAIN, TL9_EPI_MULGATE, W.Ue, ta, 3.0 + 1.0 / 3.0, "gate");
+    } else
+      tensor_linear(s, b.u0, W.Ue, b.X[0], N, F, GEMM_MUL_AUX, b.UX, b.gates);
     // ---- interaction layers
     for (int l = 0; l < L; ++l) {
       const LayerP& q_ = W.layer[l];
@@ -1291,6 +1335,19 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       float* const Xh_l = tc ? tc->Xh[l] : b.Xh;  // kept per layer when parameter gradients are wanted
       float* const Ch_l = tc ? tc->Ch[l] : b.Ch;
       float* const Xh_n = tc && l + 1 < L ? tc->Xh[l + 1] : b.Xh;
+      if (t9) {
+        // X / (||X||^2 + 1) while the rows are staged; X_hat is never stored (the update recomputes it from X)
+        Tl9Args ta{};
+        ta.A = b.X[l]; ta.C = b.Pn[l]; ta.N = N; ta.F = F;
+        tlin9(s, TL9_PRO_NORM, TL9_EPI_PLAIN, q_.V, ta, 2.0, "norm");
+        KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s));
+        // dX = linear(C_hat), then X_new = X_hat + dX + kappa dX.dX (and the readout invariants after the last layer) in the epilogue
+        Tl9Args tb{};
+        tb.A = Ch_l; tb.C = b.D[l]; tb.e0 = b.X[l]; tb.o1 = b.X[l + 1]; tb.o2 = b.feat; tb.want_feat = l + 1 == L; tb.kap = q;
+        tb.N = N; tb.F = F;
+        tlin9(s, TL9_PRO_PLAIN, TL9_EPI_UPDATE, q_.V + 3, tb, 4.0 + (l + 1 == L ? 1.0 / 3.0 : 0.0), "update");
+        continue;
+      }
       if (l == 0) KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], Xh_l, N, F, s));
       tensor_linear(s, Xh_l, q_.V, b.Pn[l], N, F);
       KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s));
@@ -1350,16 +1407,26 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     // zero-fills are kernels, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to
     // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
     const bool merged_gd = message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD") && !tc;
+    const bool t9r = !tc && L > 0 && tlin9_ok(N, F) && tlin9_images(W.UeT) && tlin9_images(W.layer[0].VT);
     const int gd_nw = message_adjoint_gd_waves(g, N, F);
     const int64_t gd_stride = 2 * (int64_t)P1;
     if (!merged_gd) launch_fill(b.gd, 0.f, P1, s);  // the per-layer pair kernels accumulate into it
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];
+      if (t9r) {
+        // update adjoint while G is staged, transposed linear, adjoint of the group product in the epilogue: g_D and g_C_hat
+        // never reach memory
+        Tl9Args ta{};
+        ta.A = b.G; ta.A2 = b.D[l]; ta.C = b.gMi; ta.o1 = b.gPn; ta.e0 = b.Pn[l]; ta.e1 = b.Mi[l]; ta.kap = q; ta.o3 = o3;
+        ta.N = N; ta.F = F;
+        tlin9(s, TL9_PRO_UPDBWD, TL9_EPI_MSGBWD, q_.VT + 3, ta, 6.0, "updbwd+msgbwd");
+      } else {
       // gD of the layers below the top one comes out of the previous iteration's fused normalisation adjoint
       if (l == L - 1) KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch_k, N, F, b.gD, s));
       if (tc) tensor_linear_grad(b.gD, tc->Ch[l], "l" + std::to_string(l) + ".V" /* 3..5 */ + std::string("b"));
       tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
       KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch_k, o3, N, F, b.gMi, b.gPn, s));
+      }
       if (tc) {
         // edge MLP of this layer: g_w per pair (self pair: summed over the atoms), then back through silu(.) C, M3, M2, M1
         const std::string t_ = "l" + std::to_string(l) + ".";
@@ -1388,6 +1455,20 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
         if (!tc) KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));
       }
+      if (t9r) {
+        // transposed linear + normalisation adjoint (incoming: the residual stream's G) in the epilogue; layer 0 goes on through
+        // the embedding's gate adjoint there
+        Tl9Args ta{};
+        ta.A = b.gPn; ta.e0 = b.X[l]; ta.e1 = b.G; ta.N = N; ta.F = F;
+        if (l > 0) {
+          ta.C = b.G;
+          tlin9(s, TL9_PRO_PLAIN, TL9_EPI_NORMBWD, q_.VT, ta, 4.0, "normbwd");
+        } else {
+          ta.C = b.gUX; ta.o1 = b.g_a2; ta.e2 = b.UX; ta.e3 = b.gates; ta.e4 = b.a2;
+          tlin9(s, TL9_PRO_PLAIN, TL9_EPI_NORMBWD_GATE, q_.VT, ta, 5.0 + 1.0, "normbwd+gate");
+        }
+        continue;
+      }
       if (tc) tensor_linear_grad(b.gPn, tc->Xh[l], "l" + std::to_string(l) + ".V" /* 0..2 */ + std::string("a"));
       tensor_linear(s, b.gPn, q_.VT, b.gXl, N, F);
       if (l > 0)
@@ -1401,8 +1482,14 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     gemm(s, b.g_a2, 3 * F, W.L2T, 3 * F, nullptr, b.g_a1, 2 * F, N, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.a1, 2 * F);
     gemm(s, b.g_a1, 2 * F, W.L1T, 2 * F, nullptr, b.g_ln0, F, N, F, 2 * F);
     KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s));
-    tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
-    KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
+    if (!tc && tlin9_ok(N, F) && tlin9_images(W.UeT)) {
+      Tl9Args ta{};
+      ta.A = b.gUX; ta.e0 = b.u0; ta.e1 = b.g_s0n; ta.o1 = b.gA; ta.N = N; ta.F = F;
+      tlin9(s, TL9_PRO_PLAIN, TL9_EPI_EMBBWD, W.UeT, ta, 2.0 + 11.0 / 9.0, "embbwd");
+    } else {
+      tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
+      KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
+    }
     if (tc) {
       // embedding: tensor linears, gate MLP, init_norm, then the edge weights W_k = C (U[z_i] + V[z_j]) (Wdp phi + bdp)_k
       tensor_linear_grad(b.gUX, b.u0, "Ue");

@@ -178,6 +178,7 @@ struct tmdnet_model {
   size_t dev_cap = 0, dev_sb_cap = 0, rb_cap = 0;  // element capacities of dev / dev_sb / rb_img (kept across re-uploads)
   uint16_t* dev_sb = nullptr;  // split-bf16 weight tile images
   std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
+  std::unordered_map<const float*, const uint16_t*> fm_of;  // fp32 device weight -> its fragment-major split image (tn_tlin9.hip)
   DevParams P;
   EdgeTables tabs;
   // embedding in the radial basis (tn_embed_rb.hip): weight fragment images (null: shape not covered / switched off),
