@@ -1414,12 +1414,12 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];
       if (t9r) {
-        // update adjoint while G is staged, transposed linear, adjoint of the group product in the epilogue: g_D and g_C_hat
-        // never reach memory
+        // update adjoint while G is staged (g_D never reaches memory), transposed linear; the adjoint of the group product stays a
+        // kernel of its own: in the epilogue its 3x3 temporaries spilled and the fused launch lost to the pair (180 vs 77 + 62 us)
         Tl9Args ta{};
-        ta.A = b.G; ta.A2 = b.D[l]; ta.C = b.gMi; ta.o1 = b.gPn; ta.e0 = b.Pn[l]; ta.e1 = b.Mi[l]; ta.kap = q; ta.o3 = o3;
-        ta.N = N; ta.F = F;
-        tlin9(s, TL9_PRO_UPDBWD, TL9_EPI_MSGBWD, q_.VT + 3, ta, 6.0, "updbwd+msgbwd");
+        ta.A = b.G; ta.A2 = b.D[l]; ta.kap = q; ta.N = N; ta.F = F; ta.C = b.gCh;
+        tlin9(s, TL9_PRO_UPDBWD, TL9_EPI_PLAIN, q_.VT + 3, ta, 3.0, "updbwd");
+        KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch_k, o3, N, F, b.gMi, b.gPn, s));
       } else {
       // gD of the layers below the top one comes out of the previous iteration's fused normalisation adjoint
       if (l == L - 1) KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch_k, N, F, b.gD, s));

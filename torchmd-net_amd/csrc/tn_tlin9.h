@@ -16,7 +16,6 @@ enum Tl9Epi : int {
   TL9_EPI_PLAIN = 0,      // C = acc
   TL9_EPI_MULGATE,        // o1 = acc ; C = acc * gates[atom, type(c), n]                       (embedding, tensornet.py:595-617)
   TL9_EPI_UPDATE,         // C = acc (= dX) ; o1 = X_hat + dX + kappa dX.dX with X_hat = e0 / (||e0||^2 + 1) ; o2 = invariants of o1
-  TL9_EPI_MSGBWD,         // adjoint of (Y = e0, M = e1) -> C_hat given g_C_hat = acc: C = g_M, o1 = g_Y         (k_message_bwd_node)
   TL9_EPI_NORMBWD,        // C = normalisation adjoint of X = e0 with incoming e1 + acc                            (k_norm_bwd<0>)
   TL9_EPI_NORMBWD_GATE,   // the same, then the embedding gate adjoint: C = g_UX, o1 = g_a2 (e2 = UX, e3 = gates, e4 = a2)
   TL9_EPI_EMBBWD,         // o1[atom, 10, n] = embedding atom adjoint of acc + dquad(e0) e1[atom, n]               (k_embed_bwd_atom)

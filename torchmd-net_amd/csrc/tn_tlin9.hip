@@ -6,19 +6,23 @@
 // tn_gemm_sb1.hip treats the nine components as nine independent row panels, so everything that couples the components of one
 // atom - X / (||X||^2 + 1), X_hat + dX + dX.dX, the adjoint of the group product, the normalisation adjoint - ran as separate
 // elementwise launches around it, each a round trip of [N, 9, F] tensors through HBM (0.58 ms of a 2.86 ms step in round 3).
-// Here a block owns 32 ATOMS x all 9 components x 128 output channels:
-//   * staging (prologue): a thread holds the nine components of (atom, 4 input channels), so the per-(atom, channel) algebra
-//     runs in registers while the chunk is split into its three bf16 planes on the way to LDS; wave pairs take turns (chunk
-//     q is staged by pair q mod 4 and requested four chunks ahead), so the staging VALU of one wave runs beside the MFMAs of
-//     the wave it shares a SIMD with;
+// Here a block (8 waves, one per CU, persistent over its tiles) owns 32 ATOMS x all 9 components x 128 output channels:
+//   * staging (prologue): a thread holds the nine components of (atom, 2 input channels) of a DOUBLE chunk (32 channels = one
+//     128-byte line per row), so the per-(atom, channel) algebra runs in registers while the pair is split into its three bf16
+//     planes on the way to LDS; two register slots keep the next two double chunks in flight;
 //   * product: exact 3-way bf16 split, six MFMA products per fp32 product (tn_gemm_sb.hip); waves 0-3 own components 0-3,
 //     waves 4-7 components 4-8, each for one 32-column block: an accumulator row block = the 32 atoms of one component, so the
 //     nine components of (atom, column) sit at the same lane and element of nine accumulators.  Weights never touch LDS:
-//     their fragment-major image (split_weight_fm) is read straight into MFMA operand registers, one chunk ahead;
-//   * epilogue: 16 atoms at a time go through LDS into (atom, 4 columns)-per-lane order - nine components in one lane, 16-byte
-//     global accesses, 512 contiguous bytes per (atom, component) and wave - the extra operands of the fused neighbour were
-//     requested before the dump.
-// One block of 8 waves per CU (129 KB of LDS), persistent over its tiles; the chunk pipeline runs across tile boundaries.
+//     their fragment-major image (split_weight_fm) is read straight into MFMA operand registers, one chunk ahead, every
+//     fragment by exactly one wave;
+//   * the two wave classes run the steps of a double chunk in rotated order (stage - multiply / multiply - stage), as two
+//     separate loops: the staging of one wave of a SIMD runs beside the products of the other;
+//   * epilogue: 8 atoms at a time go through LDS (aliasing two free chunk buffers) into (atom, 2 columns)-per-lane order - nine
+//     components in one lane, a wave = one atom = 512 contiguous bytes per component - the extra operands of the fused neighbour
+//     were requested before the dump.
+// Measured (C2, 9 x 16384 x 128 x 128, profiles/r04_notes.md): 50 us for the plain product (the grouped GEMM: 47), 70 us with the
+// update in the epilogue (was 47 + 43), 73 us with the normalisation adjoint (was 47 + 74).  What the kernel is NOT: a
+// streaming kernel - memory-only it runs at 5.1 TB/s, products-only in 23 us, together in 50: see the notes for the timeline.
 #include <cstdlib>
 
 #include "tn_common.h"
@@ -30,7 +34,7 @@ namespace tn {
 constexpr int T9_RA = 32;                  // atoms per tile
 constexpr int T9_PLANE = 9 * T9_RA * 32;   // one bf16 plane of a [288 rows][16 k] chunk
 constexpr int T9_STAGE = 3 * T9_PLANE;     // 27 648 B
-constexpr int T9_EG = 16;                  // atoms per epilogue group
+constexpr int T9_EG = 8;                   // atoms per epilogue group
 constexpr int T9_NT = 128;                 // output channels per block
 
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -40,6 +44,9 @@ __device__ __forceinline__ void st2(float* p, f2v v) { *reinterpret_cast<f2v*>(p
 // (one offset register for all nine components instead of a 64-bit address pair each)
 __device__ __forceinline__ f2v ldu2(const float* ubase, unsigned off) {
   return *reinterpret_cast<const f2v*>(reinterpret_cast<const char*>(ubase) + (size_t)(off * 4u));
+}
+__device__ __forceinline__ float ldu1(const float* ubase, unsigned off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + (size_t)(off * 4u));
 }
 __device__ __forceinline__ void stu2(float* ubase, unsigned off, f2v v) {
   *reinterpret_cast<f2v*>(reinterpret_cast<char*>(ubase) + (size_t)(off * 4u)) = v;
@@ -66,33 +73,6 @@ __device__ __forceinline__ void t9_update(const float x[9], const float d[9], fl
   const M3 Xf = add(add(compose(xh), dX), scale(matmul(dX, dX), kap));
   decompose(Xf, o);
 }
-__device__ __forceinline__ void t9_msg_bwd(const float gc[9], const float y[9], const float m[9], float kap, int o3, float gM9[9],
-                                           float gY9[9]) {
-  const M3 Y = compose(y), M = compose(m);
-  const M3 Cm = o3 ? scale(add(matmul(Y, M), matmul(M, Y)), kap) : scale(matmul(Y, M), 2.0f);
-  float uc[9];
-  decompose(Cm, uc);
-  const float inv = 1.0f / (frob2(Cm) + 1.0f);
-  float dot = 0.f, guc[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) {
-    dot += gc[c] * uc[c];
-    guc[c] = gc[c] * inv;
-  }
-  const float g_t = -dot * inv * inv;
-  const M3 gCm = add(decompose_T(guc), scale(Cm, 2.0f * g_t));
-  const M3 Yt = transpose(Y), Mt = transpose(M);
-  M3 gY, gM;
-  if (o3) {
-    gY = scale(add(matmul(gCm, Mt), matmul(Mt, gCm)), kap);
-    gM = scale(add(matmul(Yt, gCm), matmul(gCm, Yt)), kap);
-  } else {
-    gY = scale(matmul(gCm, Mt), 2.0f);
-    gM = scale(matmul(Yt, gCm), 2.0f);
-  }
-  compose_T(gM, gM9);
-  compose_T(gY, gY9);
-}
 __device__ __forceinline__ void t9_norm_bwd(const float u[9], float gx[9] /* in: G + g_lin, out: new G */) {
   float dq[9];
   dquad(u, dq);
@@ -107,84 +87,100 @@ __device__ __forceinline__ void t9_norm_bwd(const float u[9], float gx[9] /* in:
 
 template <int N_> struct IC { static constexpr int value = N_; };
 
+// Why the loop looks the way it does (measured, profiles/r04_notes.md):
+//  * one instruction stream for all waves and NO branch around a global load in the steady state: at the join of a wave-uniform
+//    branch that issued loads hipcc merges the outstanding-load counters and waits vmcnt(0), which drained the prefetch every
+//    chunk (first version: wave pairs took turns staging, 2.6 TB/s);
+//  * a thread requests FULL 128-byte lines: two consecutive 16-channel chunks of a row are one line, and requesting the halves
+//    one iteration apart parks the second request behind the first one's miss in the vector L1 (TCP_PENDING_STALL 55 % of the
+//    kernel, second version: 1.3 TB/s).  So the unit of the pipeline is a DOUBLE chunk (32 input channels): 16 lanes x 8 bytes
+//    per (atom, component), a lane's two channels are one bf16 pair of the LDS image (no lane exchange);
+//  * vmcnt counts in order: the wait for the next chunk's weights (L2 hits, needed at once) also waits for every older request,
+//    so the input prefetch is at most one double chunk deep whatever the ring size - two ring slots.
 template <int PRO, int EPI>
 __global__ __launch_bounds__(512, 2) void k_tlin9(Tl9Args a, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) unsigned char sA[2 * T9_STAGE];
-  __shared__ __attribute__((aligned(16))) float sE[T9_EG * 9 * T9_NT];
+  // four chunk buffers: double chunk d lives in buffers 2 (d & 1), 2 (d & 1) + 1; the epilogue's transposition buffer aliases
+  // the two buffers of a tile's last double chunk (free by then; the other two already hold the next tile's first double chunk)
+  __shared__ __attribute__((aligned(16))) unsigned char sA[4 * T9_STAGE];
+  float* const sE = reinterpret_cast<float*>(sA + 2 * T9_STAGE);  // [8 atoms][9][128 columns] = 36 864 B <= 2 stages
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave & 3, wc = wave >> 2;
-  // staging role: the waves of one half (0-3 / 4-7; a SIMD hosts one wave of each) stage alternate chunks, a thread holds the
-  // nine components of (atom, 2 of the chunk's 16 input channels)
-  const int su = tid & 255, sa = su >> 3, skp = su & 7;
-  const int N = a.N, F = a.F, nk = F >> 4, NB = F >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // scalar: the class branches below become s_cbranch
+  const int wn = wave & 3, wc = wave >> 2;  // NOT the scalar copy: with a scalar class branch hipcc merges the two product blocks and indexes the accumulators through scratch
+  const int sa = tid >> 4, skp = tid & 15;  // staging role: atom of the tile, pair of the double chunk's 32 input channels
+  const int N = a.N, F = a.F, nd = F >> 5, NB = F >> 5;  // nd: double chunks per tile (even: F % 128 == 0 -> multiple of 4)
   const int F9 = 9 * F;
   const int total = tiles_m * tiles_n;
   if ((int)blockIdx.x >= total) return;
   const int my_tiles = (total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
-  const int nq = my_tiles * nk;  // chunks of this block, numbered across its tiles
+  const int ndt = my_tiles * nd;  // double chunks of this block, numbered across its tiles
 
-  auto tile_of = [&](int ts, int& m0, int& n0) __attribute__((always_inline)) {  // column tiles of one atom tile are consecutive (they share the input rows)
+  auto tile_of = [&](int ts, int& m0, int& n0) __attribute__((always_inline)) {  // column tiles of one atom tile are consecutive
     const int t = (int)blockIdx.x + ts * (int)gridDim.x;
     const int tn_ = t % tiles_n;
     m0 = (t / tiles_n) * T9_RA;
     n0 = tn_ * T9_NT;
   };
 
-  // ---------------------------------------------------------------- staging: global -> registers -> (algebra, split) -> LDS
-  f2v sr[9];
-  f2v sr2[PRO == TL9_PRO_UPDBWD ? 9 : 1];
-  float s_kap = 1.0f;
-  auto load_chunk = [&](int qq) __attribute__((always_inline)) {
-    const int ts = qq / nk, kt = qq - ts * nk;
+  // ---------------------------------------------------------------- staging: global -> register ring -> (algebra, split) -> LDS
+  f2v sr[2][9];
+  f2v sr2[2][9];  // second operand (TL9_PRO_UPDBWD only; dead otherwise)
+  float s_kap[2];
+  auto load_dbl = [&](auto S_, int dd) __attribute__((always_inline)) {
+    constexpr int S = decltype(S_)::value;
+    dd = dd < ndt ? dd : ndt - 1;  // past the end: re-request the last one (no branch around loads)
+    const int ts = dd / nd, kd = dd - ts * nd;
     int m0, n0;
     tile_of(ts, m0, n0);
     int n = m0 + sa;
     if (n >= N) n = N - 1;  // rows past the end: any valid row (their outputs are not stored)
-    if (PRO == TL9_PRO_UPDBWD) s_kap = a.kap ? a.kap[n] : 1.0f;
+    if (PRO == TL9_PRO_UPDBWD) s_kap[S] = a.kap ? a.kap[n] : 1.0f;
     const unsigned voff = (unsigned)((n - m0) * F9 + skp * 2);
-    const float* p = a.A + (int64_t)m0 * F9 + kt * 16;  // wave-uniform
+    const float* p = a.A + (int64_t)m0 * F9 + kd * 32;  // wave-uniform
 #pragma unroll
-    for (int c = 0; c < 9; ++c) sr[c] = ldu2(p + c * F, voff);
+    for (int c = 0; c < 9; ++c) sr[S][c] = ldu2(p + c * F, voff);
     if (PRO == TL9_PRO_UPDBWD) {
-      const float* p2 = a.A2 + (int64_t)m0 * F9 + kt * 16;
+      const float* p2 = a.A2 + (int64_t)m0 * F9 + kd * 32;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) sr2[c] = ldu2(p2 + c * F, voff);
+      for (int c = 0; c < 9; ++c) sr2[S][c] = ldu2(p2 + c * F, voff);
     }
   };
-  auto stage_chunk = [&](int qq) __attribute__((always_inline)) {
-    unsigned char* buf = sA + (qq & 1) * T9_STAGE;
+  // lanes with skp < 8 hold channels of the double chunk's first chunk, the others of its second: two of the four buffers
+  const int st_off = (skp >> 3) * T9_STAGE + (skp & 3) * 4;
+  const int st_h = (skp >> 2) & 1;
+  auto stage_dbl = [&](auto S_) __attribute__((always_inline)) {  // ring slot S = double chunk parity = buffer pair
+    constexpr int S = decltype(S_)::value;
+    unsigned char* buf = sA + 2 * S * T9_STAGE + st_off;
     if (PRO == TL9_PRO_NORM) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        __builtin_amdgcn_sched_barrier(0);  // one column at a time: interleaving the two doubles the live 3x3 temporaries
+        __builtin_amdgcn_sched_barrier(0);  // one channel at a time: interleaving the two doubles the live temporaries
         float u[9];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) u[c] = sr[c][j];
+        for (int c = 0; c < 9; ++c) u[c] = sr[S][c][j];
         t9_norm(u);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) sr[c][j] = u[c];
+        for (int c = 0; c < 9; ++c) sr[S][c][j] = u[c];
       }
     } else if (PRO == TL9_PRO_UPDBWD) {
-      const float kap = s_kap;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        __builtin_amdgcn_sched_barrier(0);  // one column at a time: interleaving the two doubles the live 3x3 temporaries
+        __builtin_amdgcn_sched_barrier(0);
         float gg[9], d[9], o[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-          gg[c] = sr[c][j];
-          d[c] = sr2[c][j];
+          gg[c] = sr[S][c][j];
+          d[c] = sr2[S][c][j];
         }
-        t9_update_bwd(gg, d, kap, o);
+        t9_update_bwd(gg, d, s_kap[S], o);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) sr[c][j] = o[c];
+        for (int c = 0; c < 9; ++c) sr[S][c][j] = o[c];
       }
     }
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
       uint32_t h, m, l;
-      split2(sr[c][0], sr[c][1], h, m, l);
-      const int off = sb_piece(c * T9_RA + sa, skp >> 2) + (skp & 3) * 4;
+      split2(sr[S][c][0], sr[S][c][1], h, m, l);
+      const int off = sb_piece(c * T9_RA + sa, st_h);
       *reinterpret_cast<uint32_t*>(buf + 0 * T9_PLANE + off) = h;
       *reinterpret_cast<uint32_t*>(buf + 1 * T9_PLANE + off) = m;
       *reinterpret_cast<uint32_t*>(buf + 2 * T9_PLANE + off) = l;
@@ -192,28 +188,64 @@ __global__ __launch_bounds__(512, 2) void k_tlin9(Tl9Args a, int tiles_m, int ti
   };
 
   // ---------------------------------------------------------------- weights: fragment-major image -> operand registers
-  // wave (wn, wc = 0): components 0..3 = types 0, 1, 1, 1 ; (wn, wc = 1): components 4..8 = type 2
-  bf16x8 bfr[2][2][3];  // [buffer][slot][plane]; slot 0: type 0 (wc 0) / type 2 (wc 1), slot 1: type 1 (wc 0)
+  // wave (wn, wc = 0): components 0..3 (types 0, 1) ; (wn, wc = 1): components 4..8 (type 2 only).  The two classes run separate
+  // loops (below), so their request counts may differ: every weight fragment is read by exactly one wave of the block
+  bf16x8 bfr[2][2][3];  // [chunk parity][slot][plane]; slot 0: type 0 (wc 0) / type 2 (wc 1), slot 1: type 1 (wc 0 only)
   const uint16_t* const wsl0 = a.Wfm[wc == 0 ? 0 : 2] + lane * 8;
   const uint16_t* const wsl1 = a.Wfm[1] + lane * 8;
-  auto wofs = [&](int kt, int nb, int p) __attribute__((always_inline)) { return (((int64_t)kt * NB + nb) * 3 + p) * 512; };
+  auto load_b = [&](auto PB_, auto WC_, int kt, int n0) __attribute__((always_inline)) {  // weights of chunk kt (16 channels), column tile n0
+    constexpr int PB = decltype(PB_)::value, WC = decltype(WC_)::value;
+    const int64_t o = ((int64_t)kt * NB + (n0 >> 5) + wn) * 3 * 512;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      bfr[PB][0][p] = *reinterpret_cast<const bf16x8*>(wsl0 + o + p * 512);
+      if (WC == 0) bfr[PB][1][p] = *reinterpret_cast<const bf16x8*>(wsl1 + o + p * 512);
+    }
+  };
 
   floatx16 acc[5];
+  auto mma_chunk = [&](auto PB_, auto WC_, const unsigned char* cur) __attribute__((always_inline)) {
+    constexpr int PB = decltype(PB_)::value, WC = decltype(WC_)::value;
+#define T9_MMA(ci, slot, pa_, pb_) \
+  acc[ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ci][pa_], bfr[PB][slot][pb_], acc[ci], 0, 0, 0);
+#define T9_AF(ci, comp) \
+  _Pragma("unroll") for (int p = 0; p < 3; ++p) af[ci][p] = *reinterpret_cast<const bf16x8*>(cur + p * T9_PLANE + (comp) * (T9_RA * 32));
+    if (WC == 0) {
+      bf16x8 af[4][3];
+      T9_AF(0, 0) T9_AF(1, 1) T9_AF(2, 2) T9_AF(3, 3)
+      T9_MMA(0, 0, 0, 2) T9_MMA(1, 1, 0, 2) T9_MMA(2, 1, 0, 2) T9_MMA(3, 1, 0, 2)
+      T9_MMA(0, 0, 2, 0) T9_MMA(1, 1, 2, 0) T9_MMA(2, 1, 2, 0) T9_MMA(3, 1, 2, 0)
+      T9_MMA(0, 0, 1, 1) T9_MMA(1, 1, 1, 1) T9_MMA(2, 1, 1, 1) T9_MMA(3, 1, 1, 1)
+      T9_MMA(0, 0, 0, 1) T9_MMA(1, 1, 0, 1) T9_MMA(2, 1, 0, 1) T9_MMA(3, 1, 0, 1)
+      T9_MMA(0, 0, 1, 0) T9_MMA(1, 1, 1, 0) T9_MMA(2, 1, 1, 0) T9_MMA(3, 1, 1, 0)
+      T9_MMA(0, 0, 0, 0) T9_MMA(1, 1, 0, 0) T9_MMA(2, 1, 0, 0) T9_MMA(3, 1, 0, 0)
+    } else {
+      bf16x8 af[5][3];
+      T9_AF(0, 4) T9_AF(1, 5) T9_AF(2, 6) T9_AF(3, 7) T9_AF(4, 8)
+      T9_MMA(0, 0, 0, 2) T9_MMA(1, 0, 0, 2) T9_MMA(2, 0, 0, 2) T9_MMA(3, 0, 0, 2) T9_MMA(4, 0, 0, 2)
+      T9_MMA(0, 0, 2, 0) T9_MMA(1, 0, 2, 0) T9_MMA(2, 0, 2, 0) T9_MMA(3, 0, 2, 0) T9_MMA(4, 0, 2, 0)
+      T9_MMA(0, 0, 1, 1) T9_MMA(1, 0, 1, 1) T9_MMA(2, 0, 1, 1) T9_MMA(3, 0, 1, 1) T9_MMA(4, 0, 1, 1)
+      T9_MMA(0, 0, 0, 1) T9_MMA(1, 0, 0, 1) T9_MMA(2, 0, 0, 1) T9_MMA(3, 0, 0, 1) T9_MMA(4, 0, 0, 1)
+      T9_MMA(0, 0, 1, 0) T9_MMA(1, 0, 1, 0) T9_MMA(2, 0, 1, 0) T9_MMA(3, 0, 1, 0) T9_MMA(4, 0, 1, 0)
+      T9_MMA(0, 0, 0, 0) T9_MMA(1, 0, 0, 0) T9_MMA(2, 0, 0, 0) T9_MMA(3, 0, 0, 0) T9_MMA(4, 0, 0, 0)
+    }
+#undef T9_MMA
+#undef T9_AF
+  };
 
-  // ---------------------------------------------------------------- epilogue: 16 atoms per group, 8 per pass (a wave = one atom)
+  // ---------------------------------------------------------------- epilogue: 8 atoms per group (a wave = one atom)
   const unsigned cp2 = 2 * (tid & 63);
-  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int F3 = 3 * F;
-  f2v x0[9], x1[(EPI == TL9_EPI_MSGBWD || EPI == TL9_EPI_NORMBWD || EPI == TL9_EPI_NORMBWD_GATE) ? 9 : 1], gt[3];
+  f2v x0[9], x1[(EPI == TL9_EPI_NORMBWD || EPI == TL9_EPI_NORMBWD_GATE) ? 9 : 1], gt[3];
   auto epi_loads = [&](int n, int n0) __attribute__((always_inline)) {  // operands of the fused neighbour for (atom n, 2 columns)
     const bool ok = n < N;
     const int64_t rowu = (int64_t)(ok ? n : 0) * F9 + n0;  // wave-uniform (a wave = one atom); lanes add cp2
-    if (EPI == TL9_EPI_UPDATE || EPI == TL9_EPI_MSGBWD || EPI == TL9_EPI_NORMBWD || EPI == TL9_EPI_NORMBWD_GATE ||
+    if (EPI == TL9_EPI_UPDATE || EPI == TL9_EPI_NORMBWD || EPI == TL9_EPI_NORMBWD_GATE ||
         EPI == TL9_EPI_EMBBWD) {
 #pragma unroll
       for (int c = 0; c < 9; ++c) x0[c] = ldu2(a.e0 + rowu + c * F, cp2);
     }
-    if (EPI == TL9_EPI_MSGBWD || EPI == TL9_EPI_NORMBWD || EPI == TL9_EPI_NORMBWD_GATE) {
+    if (EPI == TL9_EPI_NORMBWD || EPI == TL9_EPI_NORMBWD_GATE) {
 #pragma unroll
       for (int c = 0; c < 9; ++c) x1[c] = ldu2(a.e1 + rowu + c * F, cp2);
     }
@@ -272,31 +304,6 @@ __global__ __launch_bounds__(512, 2) void k_tlin9(Tl9Args a, int tiles_m, int ti
         if (a.want_feat) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) stu2(a.o2 + (int64_t)n * F3 + n0 + k * F, cp2, ft[k]);
-        }
-      }
-    } else if (EPI == TL9_EPI_MSGBWD) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        __builtin_amdgcn_sched_barrier(0);  // one column at a time: interleaving the two doubles the live 3x3 temporaries
-        float gc[9], y[9], m[9], gM9[9], gY9[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-          gc[c] = v[c][j];
-          y[c] = x0[c][j];
-          m[c] = x1[c][j];
-        }
-        t9_msg_bwd(gc, y, m, kap, a.o3, gM9, gY9);
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-          v[c][j] = gM9[c];
-          x0[c][j] = gY9[c];
-        }
-      }
-      if (ok) {
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-          stu2(a.C + rowu + c * F, cp2, v[c]);
-          stu2(a.o1 + rowu + c * F, cp2, x0[c]);
         }
       }
     } else if (EPI == TL9_EPI_NORMBWD || EPI == TL9_EPI_NORMBWD_GATE) {
@@ -372,129 +379,93 @@ __global__ __launch_bounds__(512, 2) void k_tlin9(Tl9Args a, int tiles_m, int ti
   };
   auto epi_group = [&](auto G_, int m0, int n0) __attribute__((always_inline)) {
     constexpr int G = decltype(G_)::value;
-    const int nA = m0 + T9_EG * G + wave_u, nB = nA + 8;
-    epi_loads(nA, n0);  // requested before the dump so that their latency is covered by it
-    {  // accumulators of this group's 16 atoms -> LDS [atom][component][128 columns]
-      float* dst = sE + 32 * wn + (lane & 31) + (4 * (lane >> 5) * 9 + (wc ? 4 : 0)) * T9_NT;
+    const int n = m0 + T9_EG * G + wave_u;
+    epi_loads(n, n0);  // requested before the dump so that their latency is covered by it
+    {  // accumulators of this group's 8 atoms -> LDS [atom][component][128 columns]
+      float* dst = sE + 32 * wn + (lane & 31) + (4 * (lane >> 5) * 9) * T9_NT;
       // one code path for both wave classes (the fifth accumulator of waves 0-3 is idle): a branch per class made the compiler
       // index the accumulators through scratch memory
 #pragma unroll
       for (int ci = 0; ci < 5; ++ci) {
         if (ci < 4 || wc) {
+          const int comp = (wc ? 4 : 0) + ci;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) dst[(((e & 3) + 8 * (e >> 2)) * 9 + ci) * T9_NT] = acc[ci][8 * G + e];
+          for (int e = 0; e < 4; ++e) dst[(e * 9 + comp) * T9_NT] = acc[ci][4 * G + e];
         }
       }
     }
     __syncthreads();
-    epi_pass(nA, n0, wave_u);
-    __builtin_amdgcn_sched_barrier(0);  // the second pass's requests reuse the first one's registers: do not hoist them
-    epi_loads(nB, n0);
-    epi_pass(nB, n0, wave_u + 8);
-    __builtin_amdgcn_sched_barrier(0);
-    if (G == 0) __syncthreads();  // the second group's dump overwrites the buffer
+    epi_pass(n, n0, wave_u);
+    __syncthreads();  // the next group's dump (or the next tile's staging) overwrites the buffer
   };
 
   // ---------------------------------------------------------------- pipeline start-up
-  const int half = wave >> 2;  // chunk q is staged by half q & 1 and requested two chunks earlier
-  if (half < nq) load_chunk(half);
-  if (half == 0) {
-    stage_chunk(0);
-    if (2 < nq) load_chunk(2);
-  }
-  {
-    int m0, n0;
-    tile_of(0, m0, n0);
-    const int nb = (n0 >> 5) + wn;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      bfr[0][0][p] = *reinterpret_cast<const bf16x8*>(wsl0 + wofs(0, nb, p));
-      if (wc == 0) bfr[0][1][p] = *reinterpret_cast<const bf16x8*>(wsl1 + wofs(0, nb, p));
-    }
+  load_dbl(IC<0>{}, 0);
+  load_dbl(IC<1>{}, 1);
+  stage_dbl(IC<0>{});
+  load_dbl(IC<0>{}, 2);
+  int m0c, n0c;
+  tile_of(0, m0c, n0c);
+  if (wave < 4) {
+    load_b(IC<0>{}, IC<0>{}, 0, n0c);
+    load_b(IC<1>{}, IC<0>{}, 1, n0c);
+  } else {
+    load_b(IC<0>{}, IC<1>{}, 0, n0c);
+    load_b(IC<1>{}, IC<1>{}, 1, n0c);
   }
   __syncthreads();
 
-  int kt = 0, ts = 0, m0c, n0c, q = 0;
-  tile_of(0, m0c, n0c);
+  int d = 0;  // double chunk being multiplied
 
-  // one chunk: (1) weights of the next chunk, (2) this half's staging turn, (3) the products, (4) barrier or epilogue
-  auto body = [&](auto PB_) __attribute__((always_inline)) {
-    constexpr int PB = decltype(PB_)::value;
-    if (kt == 0) {
+  // One double chunk = {S: the next one staged from its ring slot, L: the one after requested into that slot, M0 / M1: the two
+  // chunks' products, each followed by the request for the weights two chunks on}, then a barrier.  The waves of the two halves
+  // of the block (a SIMD hosts one wave of each) run the SAME steps in ROTATED order - S L M0 M1 and M0 M1 S L - as two separate
+  // loops: while one wave of a SIMD stages (VALU, LDS writes, waits for its requests) the other one keeps the matrix pipe busy;
+  // with one order for all waves every wave was in the same phase between two barriers and the phases added up (ablation: 23 us
+  // of compute + 27 us of memory = 50 us).  Separate loops, not a branch inside one loop: no join of paths with different
+  // outstanding requests per iteration (see the note at the top of the kernel).  No branch around a global load in either.
+  auto dbl = [&](auto S_, auto ROT_, int kd, int n0_next) __attribute__((always_inline)) {
+    constexpr int S = decltype(S_)::value, ROT = decltype(ROT_)::value;
+    if (!ROT) {
+      stage_dbl(IC<S ^ 1>{});
+      load_dbl(IC<S ^ 1>{}, d + 3);
+    }
+    const unsigned char* cur = sA + 2 * S * T9_STAGE + sb_piece(lane & 31, lane >> 5);
+    const bool wrap = kd + 1 == nd;  // the weights two chunks on belong to the next tile's first double chunk
+    const int k2 = wrap ? 0 : 2 * kd + 2, n2 = wrap ? n0_next : n0c;
+    mma_chunk(IC<0>{}, ROT_, cur);
+    load_b(IC<0>{}, ROT_, k2, n2);
+    mma_chunk(IC<1>{}, ROT_, cur + T9_STAGE);
+    load_b(IC<1>{}, ROT_, k2 + 1, n2);
+    if (ROT) {
+      stage_dbl(IC<S ^ 1>{});
+      load_dbl(IC<S ^ 1>{}, d + 3);
+    }
+    __syncthreads();
+    ++d;
+  };
+  auto run = [&](auto ROT_) __attribute__((always_inline)) {
+    for (int ts = 0; ts < my_tiles; ++ts) {
+      int m0n = m0c, n0n = n0c;
+      if (ts + 1 < my_tiles) tile_of(ts + 1, m0n, n0n);
 #pragma unroll
       for (int ci = 0; ci < 5; ++ci)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[ci][e] = 0.f;
-    }
-    auto load_b_next = [&]() __attribute__((always_inline)) {  // weights of chunk q + 1 -> the other operand buffer
-      int ktn = kt + 1, n0n = n0c;
-      if (ktn == nk) {
-        ktn = 0;
-        int m0n;
-        tile_of(ts + 1, m0n, n0n);
+      for (int kd = 0; kd < nd; kd += 2) {
+        dbl(IC<0>{}, ROT_, kd, n0n);
+        dbl(IC<1>{}, ROT_, kd + 1, n0n);
       }
-      const int nbn = (n0n >> 5) + wn;
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        bfr[PB ^ 1][0][p] = *reinterpret_cast<const bf16x8*>(wsl0 + wofs(ktn, nbn, p));
-        if (wc == 0) bfr[PB ^ 1][1][p] = *reinterpret_cast<const bf16x8*>(wsl1 + wofs(ktn, nbn, p));
-      }
-    };
-    const bool last_of_tile = kt + 1 == nk;
-    if (q + 1 < nq) {
-      // before a tile's epilogue the request waits until the epilogue is done (its registers are needed there)
-      if (!last_of_tile) load_b_next();
-      if (half == ((q + 1) & 1)) {
-        stage_chunk(q + 1);
-        if (q + 3 < nq) load_chunk(q + 3);
-      }
-    }
-    const unsigned char* cur = sA + (q & 1) * T9_STAGE + sb_piece(lane & 31, lane >> 5);
-#define T9_MMA(ci, slot, pa_, pb_) \
-  acc[ci] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ci][pa_], bfr[PB][slot][pb_], acc[ci], 0, 0, 0);
-    if (wc == 0) {
-      bf16x8 af[4][3];
-#pragma unroll
-      for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) af[ci][p] = *reinterpret_cast<const bf16x8*>(cur + p * T9_PLANE + ci * (T9_RA * 32));
-      T9_MMA(0, 0, 0, 2) T9_MMA(1, 1, 0, 2) T9_MMA(2, 1, 0, 2) T9_MMA(3, 1, 0, 2)
-      T9_MMA(0, 0, 2, 0) T9_MMA(1, 1, 2, 0) T9_MMA(2, 1, 2, 0) T9_MMA(3, 1, 2, 0)
-      T9_MMA(0, 0, 1, 1) T9_MMA(1, 1, 1, 1) T9_MMA(2, 1, 1, 1) T9_MMA(3, 1, 1, 1)
-      T9_MMA(0, 0, 0, 1) T9_MMA(1, 1, 0, 1) T9_MMA(2, 1, 0, 1) T9_MMA(3, 1, 0, 1)
-      T9_MMA(0, 0, 1, 0) T9_MMA(1, 1, 1, 0) T9_MMA(2, 1, 1, 0) T9_MMA(3, 1, 1, 0)
-      T9_MMA(0, 0, 0, 0) T9_MMA(1, 1, 0, 0) T9_MMA(2, 1, 0, 0) T9_MMA(3, 1, 0, 0)
-    } else {
-      bf16x8 af[5][3];
-#pragma unroll
-      for (int ci = 0; ci < 5; ++ci)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) af[ci][p] = *reinterpret_cast<const bf16x8*>(cur + p * T9_PLANE + (4 + ci) * (T9_RA * 32));
-      T9_MMA(0, 0, 0, 2) T9_MMA(1, 0, 0, 2) T9_MMA(2, 0, 0, 2) T9_MMA(3, 0, 0, 2) T9_MMA(4, 0, 0, 2)
-      T9_MMA(0, 0, 2, 0) T9_MMA(1, 0, 2, 0) T9_MMA(2, 0, 2, 0) T9_MMA(3, 0, 2, 0) T9_MMA(4, 0, 2, 0)
-      T9_MMA(0, 0, 1, 1) T9_MMA(1, 0, 1, 1) T9_MMA(2, 0, 1, 1) T9_MMA(3, 0, 1, 1) T9_MMA(4, 0, 1, 1)
-      T9_MMA(0, 0, 0, 1) T9_MMA(1, 0, 0, 1) T9_MMA(2, 0, 0, 1) T9_MMA(3, 0, 0, 1) T9_MMA(4, 0, 0, 1)
-      T9_MMA(0, 0, 1, 0) T9_MMA(1, 0, 1, 0) T9_MMA(2, 0, 1, 0) T9_MMA(3, 0, 1, 0) T9_MMA(4, 0, 1, 0)
-      T9_MMA(0, 0, 0, 0) T9_MMA(1, 0, 0, 0) T9_MMA(2, 0, 0, 0) T9_MMA(3, 0, 0, 0) T9_MMA(4, 0, 0, 0)
-    }
-#undef T9_MMA
-    __syncthreads();
-    if (last_of_tile) {
       epi_group(IC<0>{}, m0c, n0c);
       epi_group(IC<1>{}, m0c, n0c);
-      if (q + 1 < nq) load_b_next();
-      kt = 0;
-      ++ts;
-      if (ts < my_tiles) tile_of(ts, m0c, n0c);
-    } else {
-      ++kt;
+      epi_group(IC<2>{}, m0c, n0c);
+      epi_group(IC<3>{}, m0c, n0c);
+      m0c = m0n;
+      n0c = n0n;
     }
-    ++q;
   };
-  while (q < nq) {  // nk is even: chunks come in (even, odd) pairs, so the weight double buffer is indexed statically
-    body(IC<0>{});
-    body(IC<1>{});
-  }
+  if (wave < 4) run(IC<0>{});
+  else run(IC<1>{});
 }
 
 // ------------------------------------------------------------------------------------------------ weight image
@@ -523,7 +494,8 @@ void launch_split_weight_fm(const float* W_dev, int64_t n, int64_t k, uint16_t* 
 bool tlin9_ok(int N, int F) {
   static const bool off = getenv("TMDNET_NO_TLIN9") != nullptr || getenv("TMDNET_NO_SPLIT_BF16") != nullptr;  // developer switches
   // batch scale only: below ~128 tiles the launch does not fill the chip and the split-K kernels of the small-system path win
-  return !off && F >= T9_NT && F % T9_NT == 0 && (int64_t)((N + T9_RA - 1) / T9_RA) * (F / T9_NT) >= 128;
+  return !off && F >= T9_NT && F % T9_NT == 0 &&  // (F % 128 == 0: the chunk count is a multiple of 4)
+         (int64_t)((N + T9_RA - 1) / T9_RA) * (F / T9_NT) >= 128;
 }
 
 int launch_tlin9(const Tl9Args& a, int pro, int epi, hipStream_t s) {
@@ -540,7 +512,7 @@ int launch_tlin9(const Tl9Args& a, int pro, int epi, hipStream_t s) {
   else if (pro == TL9_PRO_PLAIN && epi == TL9_EPI_PLAIN) T9_LAUNCH(TL9_PRO_PLAIN, TL9_EPI_PLAIN);
   else if (pro == TL9_PRO_PLAIN && epi == TL9_EPI_MULGATE) T9_LAUNCH(TL9_PRO_PLAIN, TL9_EPI_MULGATE);
   else if (pro == TL9_PRO_PLAIN && epi == TL9_EPI_UPDATE) T9_LAUNCH(TL9_PRO_PLAIN, TL9_EPI_UPDATE);
-  else if (pro == TL9_PRO_UPDBWD && epi == TL9_EPI_MSGBWD) T9_LAUNCH(TL9_PRO_UPDBWD, TL9_EPI_MSGBWD);
+  else if (pro == TL9_PRO_UPDBWD && epi == TL9_EPI_PLAIN) T9_LAUNCH(TL9_PRO_UPDBWD, TL9_EPI_PLAIN);
   else if (pro == TL9_PRO_PLAIN && epi == TL9_EPI_NORMBWD) T9_LAUNCH(TL9_PRO_PLAIN, TL9_EPI_NORMBWD);
   else if (pro == TL9_PRO_PLAIN && epi == TL9_EPI_NORMBWD_GATE) T9_LAUNCH(TL9_PRO_PLAIN, TL9_EPI_NORMBWD_GATE);
   else if (pro == TL9_PRO_PLAIN && epi == TL9_EPI_EMBBWD) T9_LAUNCH(TL9_PRO_PLAIN, TL9_EPI_EMBBWD);
