@@ -183,7 +183,10 @@ int tmdnet_graph_cell_grid(tmdnet_model* m, void* stream, void* graph_ws, int64_
  * `z` may be NULL when tmdnet_build_graph[_static] received (and validated) it.
  * Must be called after tmdnet_build_graph on the same graph_ws (which holds the pair geometry);
  * n_pairs = counts_host[0] of that call (or -1 after tmdnet_build_graph_static).  Enqueues only: no
- * synchronisation, no allocation. */
+ * synchronisation, no allocation.  The handle remembers per graph_ws address what it was last built as (cell list or
+ * not, validated z, species count): builds on several workspaces may be interleaved with their evaluations.
+ * tmdnet_forward_workspace_bytes does not depend on which build came last (the species-dependent buffers are sized for
+ * their largest padding). */
 int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, int64_t n_edges,
                                    int32_t want_forces, size_t* bytes);
 int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms,

@@ -198,6 +198,20 @@ void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], floa
 }
 
 
+// per-workspace record of the last graph build (tn_model.h GraphRecord)
+void remember_graph(tmdnet_model* m, const void* graph_ws) {
+  m->graph_rec[graph_ws] = tmdnet_model::GraphRecord{m->graph_is_cell, m->graph_cell_multi, m->graph_has_z, m->last_nt, m->lastE};
+}
+void recall_graph(tmdnet_model* m, const void* graph_ws) {
+  auto it = m->graph_rec.find(graph_ws);
+  if (it == m->graph_rec.end()) return;  // never built through this handle: the fields keep the last build's values
+  m->graph_is_cell = it->second.is_cell;
+  m->graph_cell_multi = it->second.cell_multi;
+  m->graph_has_z = it->second.has_z;
+  m->last_nt = it->second.nt;
+  m->lastE = it->second.lastE;
+}
+
 // fused form (tn_tlin9.hip): the weights' fragment-major images must exist (F % 32 == 0); `tensors` = [N, 9, F] tensors the
 // launch reads or writes (algorithmic bytes of the profile record)
 bool tlin9_images(const float* const W3[3]) {
@@ -1045,6 +1059,8 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   HIP_TRY(m, hipStreamSynchronize(s));
   for (int k = 0; k < 8; ++k) counts_host[k] = counts[k];
   m->last_nt = (z && m->rb_fwd && n_atoms >= m->rb_min_atoms) ? counts[6] : 0;
+  m->lastE = counts[1];
+  remember_graph(m, graph_ws);
   if (counts[5])
     return fail(m, TMDNET_ERR_INVALID, "batch index out of range: every entry must be in [0, " + std::to_string(n_mol) + ")");
   if (counts[4])
@@ -1107,6 +1123,7 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
   }
   m->lastE = ecap;
   m->last_nt = 0;  // static shapes: no read-back, the embedding keeps the per-pair tables
+  remember_graph(m, graph_ws);
   HIP_TRY(m, hipGetLastError());
   return TMDNET_OK;
 }
@@ -1127,6 +1144,7 @@ int tmdnet_graph_counts(tmdnet_model* m, void* stream, void* graph_ws, int64_t n
 
 int tmdnet_graph_cell_grid(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t grid_host[4]) {
   if (!m || !graph_ws || !grid_host) return TMDNET_ERR_INVALID;
+  recall_graph(m, graph_ws);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, (int64_t)m->hp.max_num_neighbors * n_atoms, nullptr);
   int grid[4] = {0, 0, 0, 0};
@@ -1147,7 +1165,10 @@ int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64
   if (n_pairs < 0) n_pairs = ((int64_t)m->hp.max_num_neighbors * n_atoms) / 2 + 1;  // static mode: pair capacity
   if (m->et) return et_forward_workspace_bytes(m, n_atoms, n_mol, n_pairs, want_forces, bytes);
   if (m->tn2) return tn2_forward_workspace_bytes(m, n_atoms, n_mol, n_pairs, n_edges, want_forces, bytes);
-  carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes, rb_ntp(m, n_atoms, n_pairs));
+  // the radial-basis embedding's buffers depend on the species count of the graph the call will run on: sized for the
+  // largest padding (8) whenever that path can be taken, so the answer does not depend on which build came last
+  const bool rb_possible = m->rb_fwd && !m->et && !m->train && n_pairs >= 0 && n_atoms >= m->rb_min_atoms;
+  carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes, rb_possible ? 8 : 0);
   return TMDNET_OK;
 }
 
@@ -1157,6 +1178,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   if (!m || !graph_ws || !ws || !energy) return TMDNET_ERR_INVALID;
   if (!m->finalized) return fail(m, TMDNET_ERR_STATE, "parameters not finalised");
   if (want_forces && !forces) return TMDNET_ERR_INVALID;
+  recall_graph(m, graph_ws);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const tmdnet_hparams& hp = m->hp;
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden;
@@ -1646,6 +1668,7 @@ int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, voi
   // grad_energy == NULL: forward half only (energies out, every activation kept in ws / train_ws); energy == NULL: reverse half
   // only, on the workspaces a forward-half call with the same arguments left behind; both given: one pass
   if (!m || !graph_ws || !ws || !train_ws || (!grad_energy && !energy) || (grad_energy && !grads)) return TMDNET_ERR_INVALID;
+  recall_graph(m, graph_ws);
   if ((m->et || m->tn2) && (!grad_energy || !energy)) return fail(m, TMDNET_ERR_INVALID, "the two-call form is built for TensorNet only");
   if (n_pairs < 0) return fail(m, TMDNET_ERR_INVALID, "parameter gradients need the exact pair count (dynamic shapes)");
   if (m->graph_is_cell) return fail(m, TMDNET_ERR_STATE, "parameter gradients: build the graph without the cell list");

@@ -196,11 +196,6 @@ bool message_pair_ok(int N, int F);
 void launch_message_pair(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
                          int o3, float* Mi, float* Ch, hipStream_t s);
 
-// reverse sweep in the same layout (adjoint + distance-gradient halves); slot arrays: one per 32-channel chunk
-bool message_adjoint_pair_ok(const Graph& g, int N, int F);
-void launch_message_adjoint_pair(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
-                                 float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
-
 // 16-byte-per-lane form of the per-pair kernels (tn_pairgrad.hip)
 bool gather_v4_ok(int F);
 

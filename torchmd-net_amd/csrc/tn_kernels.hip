@@ -911,9 +911,7 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
   for (int c = 0; c < 9; ++c) o[c * F] += acc[c];
 }
 bool message_adjoint_gd_ok(int N, int F) { return F % 64 == 0 && (split_rows_ok(N, F) || (N > kSplitRows && F <= 1024)); }
-int message_adjoint_gd_waves(const Graph& g, int N, int F) {
-  return (!split_rows_ok(N, F) && message_adjoint_pair_ok(g, N, F)) ? F / 32 : F / 64;  // tile sweep: one slot array per 32-channel chunk
-}
+int message_adjoint_gd_waves(const Graph& g, int N, int F) { return F / 64; }
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
   if (N <= 0) return;
@@ -922,8 +920,6 @@ void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, con
                        slots, slot_stride);
     return;
   }
-  // batches of small molecules: LDS-staged tile sweep with 16 bytes per lane (tn_message_pair.hip)
-  if (message_adjoint_pair_ok(g, N, F)) return launch_message_adjoint_pair(g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, s);
   hipLaunchKernelGGL(k_message_adjoint_gd, dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride);
 }
 

@@ -17,8 +17,9 @@
 // deterministic, no atomics.  A tile whose column window is wider than 64 rows (large systems in cell order, ragged
 // molecules straddling the tile) gathers its sources from global memory instead of LDS; the choice is block-uniform.
 //
-// Forward message + group product + normalisation -> Mi, Ch.  (A reverse mode of this layout existed in round 2: 216 VGPRs, one
-// block per CU, 333 - 340 us against 304 for the row kernel k_message_adjoint_gd; removed, profiles/r02_notes.md.)
+// Forward message + group product + normalisation -> Mi, Ch.  (A reverse mode of this layout existed in round 2 and again, with the symmetric
+// walk order, in round 4: 216 VGPRs, one block per CU, 325 us against 283 for the row kernel k_message_adjoint_gd; removed,
+// profiles/r04_notes.md, profiles/r04_experiments/.)
 #include <cstdlib>
 
 #include "tn_common.h"
@@ -74,7 +75,7 @@ template <int LPR, int VW>
 __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int F, const float* __restrict__ w,
                                                                 const float* __restrict__ src, const float* __restrict__ q,
                                                                 const int64_t* __restrict__ batch, int o3,
-                                                                float* __restrict__ Mi, float* __restrict__ out, int nchunks, int norot) {
+                                                                float* __restrict__ Mi, float* __restrict__ out, int nchunks) {
   constexpr int MP_FC = VW * LPR, MP_THREADS = 64 * LPR, PIECES = MP_FC / 4;
   typedef typename VecOf<VW>::T vf;
   auto ldv = [](const float* p) { return *reinterpret_cast<const vf*>(p); };
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int 
   const bool live = i < r1;
   const int e0 = live ? g.rowptr[i] : 0, e1 = live ? g.rowptr[i + 1] : 0;
   const int grp = lane & ~(LPR - 1);  // first lane of this row's group within the wave
-  const int len = e1 - e0, rot = norot ? 0 : row_rotation<LPR>(g, i, e0, len, ql);
+  const int len = e1 - e0, rot = row_rotation<LPR>(g, i, e0, len, ql);
   vf acc[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) acc[c] = (vf)(0.f);
@@ -238,188 +239,6 @@ __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int 
   for (int c = 0; c < 9; ++c) *reinterpret_cast<vf*>(o + c * F) = yy[c];
 }
 
-// Reverse sweep in the same tile layout (round 4): the adjoint of the message sum,  gPn[i] += sum_e w[p] * gMi[col(e)],  and the
-// layer's distance-gradient halves  h(i <- j) = sum_{k,f} dw[p,k,f] * sum_{c in k} gMi[j,c,f] * Pn[i,c,f]  (see
-// k_message_adjoint_gd, tn_kernels.hip).  A block owns 64 rows x 32 channels; the gMi rows of its column window sit in LDS,
-// the row's own Pn row in registers; per edge a lane loads six 16-byte pieces (w, dw) and reads nine from LDS.  The 8 lanes of
-// a row reduce their channel products with three DPP steps and lane 0 of the group writes the slot (channel chunk, pair,
-// direction): one writer per slot, summed in fixed order by the pair kernel of the embedding.  With the symmetric walk order
-// both reads of a pair's (w, dw) rows fall within a few trips of each other; round 2's version of this kernel walked the rows in
-// list order and lost to the one-block-per-atom kernel (333 vs 304 us) because every second read missed L2.
-template <int U>
-__global__ __launch_bounds__(512) void k_message_adjoint_rows8(Graph g, int N, int F, const float* __restrict__ w,
-                                                               const float* __restrict__ dw, const float* __restrict__ gMi,
-                                                               const float* __restrict__ Pn, float* __restrict__ gPn,
-                                                               float* __restrict__ slots, int64_t slot_stride, int nchunks, int norot) {
-  constexpr int LPR = 8, VW = 4, FC = 32, THREADS = 512, PIECES = FC / 4;
-  __shared__ __attribute__((aligned(16))) float win[MP_W * 9 * FC];
-  __shared__ int s_lo[THREADS / 64], s_hi[THREADS / 64];
-  if (g.counts[2]) return;
-  const int b = xcd_chunk(blockIdx.x, gridDim.x);
-  const int tile = b / nchunks, chunk = b - tile * nchunks;
-  const int r0 = tile * MP_TA, r1 = min(N, r0 + MP_TA);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int F9 = 9 * F, F3 = 3 * F, c0 = chunk * FC;
-
-  int lo = 0x7fffffff, hi = -1;
-  if (tid < r1 - r0) {
-    const int e0 = g.rowptr[r0 + tid], e1 = g.rowptr[r0 + tid + 1];
-    if (e1 > e0) {
-      lo = g.col[e0];
-      hi = g.col[e1 - 1];
-    }
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    lo = min(lo, __shfl_xor(lo, off, 64));
-    hi = max(hi, __shfl_xor(hi, off, 64));
-  }
-  if (lane == 0) {
-    s_lo[wave] = lo;
-    s_hi[wave] = hi;
-  }
-  __syncthreads();
-  lo = s_lo[0];
-  hi = s_hi[0];
-#pragma unroll
-  for (int k = 1; k < THREADS / 64; ++k) {
-    lo = min(lo, s_lo[k]);
-    hi = max(hi, s_hi[k]);
-  }
-  const int wn = hi - lo + 1;
-  const bool staged = hi >= lo && wn <= MP_W;  // block-uniform
-
-  const int i = r0 + tid / LPR, ql = tid & (LPR - 1), f = c0 + VW * ql;
-  const bool live = i < r1;
-  const int e0 = live ? g.rowptr[i] : 0, e1 = live ? g.rowptr[i + 1] : 0;
-  const int grp = lane & ~(LPR - 1);
-  const int len = e1 - e0;
-  f4v y[9];  // the row's own Pn row
-  {
-    const float* yp = Pn + (int64_t)(live ? i : r0) * F9 + f;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) y[c] = ldg4(yp + c * F);
-  }
-  if (staged) {
-    const int pieces = wn * 9 * PIECES;
-    constexpr int NIT = (MP_W * 9 * PIECES + THREADS - 1) / THREADS;
-    f4v tmp[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const int idx = tid + k * THREADS;
-      if (idx < pieces) {
-        const int rc = idx / PIECES, f4 = (idx % PIECES) << 2;
-        const int row = rc / 9, c = rc - row * 9;
-        tmp[k] = ldg4(gMi + (int64_t)(lo + row) * F9 + c * F + c0 + f4);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      const int idx = tid + k * THREADS;
-      if (idx < pieces) {
-        const int rc = idx / PIECES, f4 = (idx % PIECES) << 2;
-        *reinterpret_cast<f4v*>(&win[rc * FC + f4]) = tmp[k];
-      }
-    }
-  }
-  const int rot = norot ? 0 : row_rotation<LPR>(g, i, e0, len, ql);
-  __syncthreads();
-
-  f4v acc[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) acc[c] = (f4v)(0.f);
-  int nmax = len;
-#pragma unroll
-  for (int off = LPR; off <= 32; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
-  float* const slot_base = slots + (int64_t)chunk * slot_stride;
-
-  for (int eb = 0; eb < nmax; eb += LPR) {
-    const int me = walk_edge(e0, len, rot, eb + ql);
-    int myc = 0, myp = 0, mys = -1;
-    if (len > 0) {
-      myc = g.col[me];
-      myp = g.epair[me];
-      const float sg = g.esign[me];
-      mys = (sg != 0.f && eb + ql < len) ? 2 * myp + (sg > 0.f ? 0 : 1) : -1;  // self edge / past the end: no slot
-    }
-    const int n = min(LPR, nmax - eb);
-    for (int k = 0; k < n; k += U) {
-      int jj[U], ss[U];
-      f4v wv[U][3], dv[U][3];
-      float msk[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool valid = eb + k + u < len;
-        const int srcl = grp + min(k + u, LPR - 1);
-        jj[u] = __shfl(myc, srcl, 64);
-        const int pp = __shfl(myp, srcl, 64);
-        ss[u] = (k + u < LPR) ? __shfl(mys, srcl, 64) : -1;
-        msk[u] = valid ? 1.0f : 0.0f;
-        const float* wp = w + (int64_t)pp * F3 + f;
-        const float* dp = dw + (int64_t)pp * F3 + f;
-        wv[u][0] = ldg4(wp);
-        wv[u][1] = ldg4(wp + F);
-        wv[u][2] = ldg4(wp + 2 * F);
-        dv[u][0] = ldg4(dp);
-        dv[u][1] = ldg4(dp + F);
-        dv[u][2] = ldg4(dp + 2 * F);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        f4v s9[9];
-        if (staged) {
-          const float* sp = win + (jj[u] - lo) * (9 * FC) + VW * ql;
-#pragma unroll
-          for (int c = 0; c < 9; ++c) s9[c] = *reinterpret_cast<const f4v*>(sp + c * FC);
-        } else {
-          const float* sp = gMi + (int64_t)jj[u] * F9 + f;
-#pragma unroll
-          for (int c = 0; c < 9; ++c) s9[c] = ldg4(sp + c * F);
-        }
-        const f4v w0 = wv[u][0] * msk[u], w1 = wv[u][1] * msk[u], w2 = wv[u][2] * msk[u];
-        acc[0] += w0 * s9[0];
-        acc[1] += w1 * s9[1];
-        acc[2] += w1 * s9[2];
-        acc[3] += w1 * s9[3];
-        acc[4] += w2 * s9[4];
-        acc[5] += w2 * s9[5];
-        acc[6] += w2 * s9[6];
-        acc[7] += w2 * s9[7];
-        acc[8] += w2 * s9[8];
-        const f4v hv = dv[u][0] * (s9[0] * y[0]) + dv[u][1] * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
-                       dv[u][2] * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
-        const float h = row_sum((hv[0] + hv[1]) + (hv[2] + hv[3]), LPR);
-        if (ql == 0 && ss[u] >= 0) slot_base[ss[u]] = h;
-      }
-    }
-  }
-  if (!live) return;
-  float* o = gPn + (int64_t)i * F9 + f;
-#pragma unroll
-  for (int c = 0; c < 9; ++c) {
-    f4v* op = reinterpret_cast<f4v*>(o + c * F);
-    *op = *op + acc[c];
-  }
-}
-
-static int msg_norot() {  // TEMPORARY A/B switch (round 4 measurement)
-  static const int v = getenv("TMDNET_MSG_NOROT") ? 1 : 0;
-  return v;
-}
-bool message_adjoint_pair_ok(const Graph& g, int N, int F) {
-  static const bool off2 = getenv("TMDNET_NO_ADJ_ROWS8") != nullptr;  // TEMPORARY A/B switch
-  if (off2) return false;
-  static const bool off = getenv("TMDNET_NO_MSG_ROWS8") != nullptr;  // developer switch: one-channel-per-lane sweeps
-  if (off || !g.small_mols || F < MP_FC || F % MP_FC) return false;
-  return (int64_t)((N + MP_TA - 1) / MP_TA) * (F / MP_FC) >= 512;
-}
-void launch_message_adjoint_pair(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
-                                 float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
-  const int nchunks = F / MP_FC, tiles = (N + MP_TA - 1) / MP_TA;
-  hipLaunchKernelGGL((k_message_adjoint_rows8<2>), dim3(tiles * nchunks), dim3(512), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots,
-                     slot_stride, nchunks, msg_norot());
-}
-
 bool message_pair_ok(int N, int F) {
   static const bool off = getenv("TMDNET_NO_MSG_ROWS8") != nullptr;  // developer switch: one-channel-per-lane sweeps
   if (off || F < MP_FC || F % MP_FC) return false;
@@ -428,7 +247,7 @@ bool message_pair_ok(int N, int F) {
 void launch_message_pair(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch,
                          int o3, float* Mi, float* Ch, hipStream_t s) {
   const int nchunks = F / MP_FC, tiles = (N + MP_TA - 1) / MP_TA;
-  hipLaunchKernelGGL((k_message_rows8<8, 4>), dim3(tiles * nchunks), dim3(512), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, nchunks, msg_norot());
+  hipLaunchKernelGGL((k_message_rows8<8, 4>), dim3(tiles * nchunks), dim3(512), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, nchunks);
 }
 
 }  // namespace tn

@@ -172,6 +172,10 @@ struct tmdnet_model {
   bool graph_is_cell = false; // last build used the cell list (atoms internally renumbered)
   bool graph_cell_multi = false;  // ... with several molecules in the common grid (their atoms interleaved: Graph::bat_c)
   bool graph_has_z = false;   // last build validated z into Graph::z_c (internal order)
+  // what each graph workspace was last built as (host side, keyed by its address): a call that takes a workspace restores the four
+  // fields above / last_nt from its record, so builds on several workspaces may be interleaved with their evaluations
+  struct GraphRecord { bool is_cell, cell_multi, has_z; int nt; int64_t lastE; };
+  std::unordered_map<const void*, GraphRecord> graph_rec;
   std::vector<ParamSpec> specs;
   std::map<std::string, std::vector<float>> host;
   float* dev = nullptr;  // packed parameters
