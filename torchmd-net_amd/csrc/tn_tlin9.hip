@@ -494,6 +494,7 @@ void launch_split_weight_fm(const float* W_dev, int64_t n, int64_t k, uint16_t* 
 bool tlin9_ok(int N, int F) {
   static const bool off = getenv("TMDNET_NO_TLIN9") != nullptr || getenv("TMDNET_NO_SPLIT_BF16") != nullptr;  // developer switches
   // batch scale only: below ~128 tiles the launch does not fill the chip and the split-K kernels of the small-system path win
+  // (measured with the threshold at 1: 64 atoms 0.233 -> 0.391 ms per replayed step, 2048 atoms 0.65 -> 0.74, 4096 atoms equal)
   return !off && F >= T9_NT && F % T9_NT == 0 &&  // (F % 128 == 0: the chunk count is a multiple of 4)
          (int64_t)((N + T9_RA - 1) / T9_RA) * (F / T9_NT) >= 128;
 }
