@@ -99,7 +99,7 @@ const char* tmdnet_version(void);
 /* ABI revision of this header: bumped whenever an exported signature or struct layout changes (3: `z` in
  * tmdnet_build_graph[_static], `strategy` in tmdnet_neighbor_pairs).  A binding compares its compile-time
  * TMDNET_ABI_VERSION with the loaded library's tmdnet_abi_version() before its first call. */
-#define TMDNET_ABI_VERSION 3
+#define TMDNET_ABI_VERSION 4
 int tmdnet_abi_version(void);
 
 /* Parameters are addressed by the reference's state-dict keys without the "model." prefix
@@ -111,6 +111,16 @@ int tmdnet_abi_version(void);
  * and returns TMDNET_ERR_STATE if its stream is being captured at that moment. */
 int tmdnet_set_param(tmdnet_model* m, const char* name, const float* data_host, int64_t numel);
 int tmdnet_finalize_params(tmdnet_model* m);
+/* Device-side parameter update (training loops; TensorNet and TensorNet2): `dev_ptrs[c]` is the fp32, contiguous DEVICE copy of
+ * state-dict tensor `names[c]` (any subset; "mean" / "std" excluded - they are host-read kernel arguments).  Needs one
+ * tmdnet_set_param + tmdnet_finalize_params round first (shapes, layout, host-built images).  Enqueues on `stream`: one gather
+ * kernel rewrites the packed parameter buffer from the caller's tensors (the mapping is learnt once by running the packing on
+ * index tags), then the split-bf16 images and the per-species tables are rebuilt by kernels; nothing crosses PCIe except a
+ * pointer table, no synchronisation.  The caller's tensors must stay valid until the stream reaches this point.  Afterwards
+ * the radial tables are stale (rebuilt by the first call that uses them) and the radial-basis embedding stays off until the
+ * next full tmdnet_finalize_params (its weight images are made on the host).  Evaluations that used the handle on OTHER
+ * streams must have finished (same rule as tmdnet_finalize_params, which additionally blocks the host). */
+int tmdnet_update_params_device(tmdnet_model* m, void* stream, int32_t count, const char* const* names, const float* const* dev_ptrs);
 /* number of parameter tensors the model expects; name of the idx-th one and its element count */
 int tmdnet_num_params(const tmdnet_model* m);
 const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel);

@@ -263,8 +263,11 @@ def test_force_matching_gradients_by_central_difference(hip_lib, order, bound):
     R = torch.randn(pos.shape, generator=torch.Generator().manual_seed(3))
     ge = torch.tensor([0.7, -1.1, 0.4])
     y, F = model(z.cuda(), pos.cuda(), batch.cuda())
+    # the training step's inference-schedule call ran without the radial tables, and the switches are back afterwards
+    assert model.engine_info("edge_table_min_pairs") < 1e9 and model.engine_info("embed_rb_min_atoms") < 1e9
     loss = (F * R.cuda()).sum() + (y.view(-1) * ge.cuda()).sum()
     loss.backward()
+    assert model.engine_info("edge_table_min_pairs") < 1e9
     ref = _oracle_force_matching_grads(model, args, z, pos, batch, R, ge)
     errs = {}
     for k, p in model.named_parameters():
@@ -343,3 +346,55 @@ def test_two_forwards_before_one_backward(hip_lib):
         r = ra[k] + rb[k]
         if r.abs().max() > 0:
             assert (g.cpu().double() - r).abs().max().item() / r.abs().max().item() < REL, k
+
+
+@pytest.mark.parametrize("arch", ["tensornet", "tensornet2"])
+def test_parameter_update_stays_on_the_device(hip_lib, arch):
+    """An in-place optimizer step on CUDA parameters reaches the engine through tmdnet_update_params_device (a gather kernel
+    from the caller's tensors + the image kernels; nothing but a pointer table crosses PCIe): the result must be BIT-IDENTICAL to
+    a fresh handle that uploaded the same weights through the host."""
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.TINY_ARGS, embedding_dimension=64, num_rbf=16, num_layers=2)
+    if arch == "tensornet2":
+        args.update(model="tensornet2", output_model="ScalarPlusWeightedCoulomb", q_dim=4, q_weights=[1.0, 0.5, 2.0])
+    torch.manual_seed(3)
+    model = create_model(dict(args)).to("cuda")
+    z, pos, batch = (t.cuda() for t in _ragged([17, 30, 9], seed=77))
+    q = torch.tensor([0.0, 1.0, -1.0]).cuda() if arch == "tensornet2" else None
+    kw = dict(q=q) if q is not None else {}
+    model(z, pos, batch, **kw)  # full upload
+    assert model._engine.device_updates == 0
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for step in range(3):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.01 * torch.randn(p.shape, device="cuda", generator=g) * p.abs().mean())
+        E, F = model(z, pos, batch, **kw)
+        assert model._engine.device_updates == step + 1
+    fresh = create_model(dict(args)).to("cuda")
+    fresh.load_state_dict(model.state_dict())
+    Er, Fr = fresh(z, pos, batch, **kw)
+    assert fresh._engine.device_updates == 0
+    assert torch.equal(E, Er) and torch.equal(F, Fr)
+    # a value the host reads (std) falls back to the full upload, and so does a replaced tensor object
+    with torch.no_grad():
+        model.std.mul_(2.0)
+    n = model._engine.device_updates
+    E2, _ = model(z, pos, batch, **kw)
+    assert model._engine.device_updates == n and not torch.equal(E2, E)
+
+
+def test_force_loss_with_position_gradient_is_refused(hip_lib):
+    """d loss / d pos THROUGH the forces is a second derivative in the positions, which this engine does not build: asking for
+    it raises instead of silently returning the first-order part."""
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(2)
+    model = create_model(dict(W.TINY_ARGS, derivative=True)).to("cuda")
+    model.parameter_gradients = True
+    z, pos, batch = (t.cuda() for t in _ragged([12, 20], seed=4))
+    pos = pos.clone().requires_grad_(True)
+    y, F = model(z, pos, batch)
+    with pytest.raises(NotImplementedError):
+        (F ** 2).sum().backward()

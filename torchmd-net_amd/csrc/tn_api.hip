@@ -7,6 +7,7 @@
 // reverse pass that replaces torch.autograd.grad (model.py:618-628).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -620,6 +621,9 @@ int tmdnet_destroy(tmdnet_model* m) {
   delete m->tn2;
   if (m->dev) (void)hipFree(m->dev);
   if (m->dev_sb) (void)hipFree(m->dev_sb);
+  if (m->upd_tid) (void)hipFree(m->upd_tid);
+  if (m->upd_ofs) (void)hipFree(m->upd_ofs);
+  if (m->upd_ptrs) (void)hipFree(m->upd_ptrs);
   if (m->rb_img) (void)hipFree(m->rb_img);
   delete m;
   return TMDNET_OK;
@@ -650,16 +654,14 @@ int tmdnet_set_param(tmdnet_model* m, const char* name, const float* data_host, 
   return fail(m, TMDNET_ERR_INVALID, std::string("unknown parameter: ") + name);
 }
 
-int tmdnet_finalize_params(tmdnet_model* m) {
-  if (!m) return TMDNET_ERR_INVALID;
-  if (m->et) return et_finalize(m);
-  for (const auto& sp : m->specs)
-    if (!m->host.count(sp.name)) return fail(m, TMDNET_ERR_STATE, "missing parameter: " + sp.name);
+// Packing of the state dict into the engine's parameter buffer: copies, transposes, column blocks, concatenations - pure data
+// movement, no arithmetic (the device-side update below relies on that: it runs this once on index tags to learn where every
+// packed element comes from).
+static void pack_tensornet_params(tmdnet_model* m, std::map<std::string, std::vector<float>>& h, Packer& pk,
+                                  std::map<std::string, size_t>& off) {
   const int F = m->hp.hidden_channels, K = m->hp.num_rbf, L = m->hp.num_layers, H = m->hp.head_hidden;
+  (void)H;
   const std::string R = "representation_model.", T = R + "tensor_embedding.", O = "output_model.output_network.layers.";
-  auto& h = m->host;
-  Packer pk;
-  std::map<std::string, size_t> off;
   auto put = [&](const std::string& key, const std::vector<float>& v) { off[key] = pk.add(v); };
   auto putT = [&](const std::string& key, const std::vector<float>& v, int64_t r, int64_t c) { off[key] = pk.add_T(v, r, c); };
   put("means", h[R + "distance_expansion.means"]);
@@ -764,6 +766,19 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   put("Utab", std::vector<float>((size_t)m->hp.max_z * F, 0.f));
   put("Vtab", std::vector<float>((size_t)m->hp.max_z * F, 0.f));
 
+}
+
+int tmdnet_finalize_params(tmdnet_model* m) {
+  if (!m) return TMDNET_ERR_INVALID;
+  if (m->et) return et_finalize(m);
+  for (const auto& sp : m->specs)
+    if (!m->host.count(sp.name)) return fail(m, TMDNET_ERR_STATE, "missing parameter: " + sp.name);
+  const int F = m->hp.hidden_channels, K = m->hp.num_rbf, L = m->hp.num_layers, H = m->hp.head_hidden;
+  const std::string R = "representation_model.", T = R + "tensor_embedding.", O = "output_model.output_network.layers.";
+  auto& h = m->host;
+  Packer pk;
+  std::map<std::string, size_t> off;
+  pack_tensornet_params(m, h, pk, off);
   // device buffers are kept across uploads of the same size (a training loop re-uploads every step: hipFree / hipMalloc are
   // device-wide synchronisations)
   if (m->dev && m->dev_cap < pk.buf.size()) {
@@ -907,6 +922,10 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     }
     for (const auto& im : imgs) launch_split_weight_tiles(m->dev + off.at(im.key), im.n, im.k, m->dev_sb + im.o, nullptr);
     for (const auto& im : fms) launch_split_weight_fm(m->dev + off.at(im.key), im.n, im.k, m->dev_sb + im.o, nullptr);
+    m->image_jobs.clear();
+    for (const auto& im : imgs) m->image_jobs.push_back({off.at(im.key), im.n, im.k, im.o, 0});
+    for (const auto& im : fms) m->image_jobs.push_back({off.at(im.key), im.n, im.k, im.o, 1});
+    m->packed_elems = pk.buf.size();
     m->sb_of.clear();
     m->fm_of.clear();
     for (const auto& im : imgs) m->sb_of[m->dev + off.at(im.key)] = m->dev_sb + im.o;
@@ -964,6 +983,86 @@ int tmdnet_finalize_params(tmdnet_model* m) {
   free_radial_tables(m->tabs);  // rebuilt by the first call that uses them (ensure_radial_tables): fp64 evaluation + refinement,
   m->tabs_pending = true;      // tens of ms - not paid per parameter edit, and never on a stream that is being captured
   m->finalized = true;
+  return TMDNET_OK;
+}
+
+// ---- device-side parameter update (training loops): the optimizer's tensors already live on the GPU
+__global__ void k_param_gather(float* __restrict__ dst, const int32_t* __restrict__ tid, const int32_t* __restrict__ ofs,
+                               const float* const* __restrict__ ptrs, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = tid[i];
+  if (t < 0) return;
+  const float* p = ptrs[t];
+  if (p) dst[i] = p[ofs[i]];
+}
+
+int tmdnet_update_params_device(tmdnet_model* m, void* stream, int32_t count, const char* const* names, const float* const* dev_ptrs) {
+  if (!m || count < 0 || (count > 0 && (!names || !dev_ptrs))) return TMDNET_ERR_INVALID;
+  if (m->et) return fail(m, TMDNET_ERR_STATE, "device-side parameter update: not built for the Equivariant Transformer");
+  if (!m->finalized || !m->dev || !m->packed_elems)
+    return fail(m, TMDNET_ERR_STATE, "device-side parameter update needs one tmdnet_finalize_params first");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t ns = m->specs.size();
+  if (!m->upd_ready) {
+    // where does every packed element come from?  Run the packing on INDEX TAGS (bit patterns; the packing only moves data)
+    std::map<std::string, std::vector<float>> tags;
+    std::vector<int64_t> base(ns + 1, 0);
+    for (size_t i = 0; i < ns; ++i) base[i + 1] = base[i] + m->specs[i].rows * m->specs[i].cols;
+    if (base[ns] + 1 >= (int64_t)0x7f000000) return fail(m, TMDNET_ERR_STATE, "device-side parameter update: model too large for the tag pass");
+    for (size_t i = 0; i < ns; ++i) {
+      std::vector<float>& v = tags[m->specs[i].name];
+      v.resize((size_t)(base[i + 1] - base[i]));
+      for (size_t j = 0; j < v.size(); ++j) {
+        const uint32_t tag = (uint32_t)(base[i] + (int64_t)j + 1);  // 0 = "no source"
+        std::memcpy(&v[j], &tag, 4);
+      }
+    }
+    Packer pk;
+    std::map<std::string, size_t> off;
+    pack_tensornet_params(m, tags, pk, off);
+    if (pk.buf.size() != m->packed_elems) return fail(m, TMDNET_ERR_STATE, "device-side parameter update: layout mismatch");
+    std::vector<int32_t> tid(pk.buf.size(), -1), ofs(pk.buf.size(), 0);
+    for (size_t i = 0; i < pk.buf.size(); ++i) {
+      uint32_t tag;
+      std::memcpy(&tag, &pk.buf[i], 4);
+      if (!tag || (int64_t)tag > base[ns]) continue;
+      const int64_t g = (int64_t)tag - 1;
+      const size_t t = (size_t)(std::upper_bound(base.begin(), base.end(), g) - base.begin()) - 1;
+      tid[i] = (int32_t)t;
+      ofs[i] = (int32_t)(g - base[t]);
+    }
+    HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->upd_tid), tid.size() * sizeof(int32_t)));
+    HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->upd_ofs), ofs.size() * sizeof(int32_t)));
+    HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->upd_ptrs), ns * sizeof(float*)));
+    HIP_TRY(m, hipMemcpy(m->upd_tid, tid.data(), tid.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(m, hipMemcpy(m->upd_ofs, ofs.data(), ofs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    m->upd_ready = true;
+  }
+  std::vector<const float*> ptrs(ns, nullptr);
+  for (int32_t c = 0; c < count; ++c) {
+    size_t i = 0;
+    for (; i < ns; ++i)
+      if (m->specs[i].name == names[c]) break;
+    if (i == ns) return fail(m, TMDNET_ERR_INVALID, std::string("unknown parameter: ") + names[c]);
+    if (m->specs[i].name == "mean" || m->specs[i].name == "std")
+      return fail(m, TMDNET_ERR_INVALID, "mean / std are kernel arguments read on the host: update them through tmdnet_set_param");
+    ptrs[i] = dev_ptrs[c];
+  }
+  // the pointer table travels through the stream too (pageable host memory: the copy is staged before the call returns)
+  HIP_TRY(m, hipMemcpyAsync(m->upd_ptrs, ptrs.data(), ns * sizeof(float*), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_param_gather, dim3((unsigned)((m->packed_elems + 255) / 256)), dim3(256), 0, s, m->dev, m->upd_tid, m->upd_ofs,
+                     m->upd_ptrs, (int64_t)m->packed_elems);
+  for (const auto& j : m->image_jobs) {
+    if (j.fm) launch_split_weight_fm(m->dev + j.src_off, j.n, j.k, m->dev_sb + j.dst_off, s);
+    else launch_split_weight_tiles(m->dev + j.src_off, j.n, j.k, m->dev_sb + j.dst_off, s);
+  }
+  const int F = m->hp.hidden_channels;
+  launch_ztables(m->P.emb, m->P.emb2_waT, m->P.emb2_wbT, m->P.emb2_b, m->hp.max_z, F, const_cast<float*>(m->P.Utab),
+                 const_cast<float*>(m->P.Vtab), s);
+  m->tabs_pending = true;           // radial tables: rebuilt by the first call that uses them
+  m->rb_fwd = m->rb_rev = nullptr;  // the radial-basis embedding's images are made on the host: off until the next full upload
+  HIP_TRY(m, hipGetLastError());
   return TMDNET_OK;
 }
 

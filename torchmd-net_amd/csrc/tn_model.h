@@ -183,6 +183,15 @@ struct tmdnet_model {
   uint16_t* dev_sb = nullptr;  // split-bf16 weight tile images
   std::unordered_map<const float*, const uint16_t*> sb_of;  // fp32 device weight -> its split image
   std::unordered_map<const float*, const uint16_t*> fm_of;  // fp32 device weight -> its fragment-major split image (tn_tlin9.hip)
+  // device-side parameter update (tmdnet_update_params_device): the derived images to rebuild and, built on first use, where every
+  // element of the packed buffer comes from (state-dict tensor, offset)
+  struct ImageJob { size_t src_off; int64_t n, k; size_t dst_off; int fm; };
+  std::vector<ImageJob> image_jobs;
+  size_t packed_elems = 0;
+  int32_t* upd_tid = nullptr;   // [packed_elems] index into specs (-1: no source: zero fill / derived table)
+  int32_t* upd_ofs = nullptr;   // [packed_elems]
+  const float** upd_ptrs = nullptr;  // [specs.size()] device table of the caller's tensors for one update
+  bool upd_ready = false;
   DevParams P;
   EdgeTables tabs;
   // embedding in the radial basis (tn_embed_rb.hip): weight fragment images (null: shape not covered / switched off),

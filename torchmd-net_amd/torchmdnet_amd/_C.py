@@ -67,6 +67,7 @@ def lib():
     L.tmdnet_version.restype = C.c_char_p
     L.tmdnet_set_param.argtypes = [vp, C.c_char_p, vp, i64]
     L.tmdnet_finalize_params.argtypes = [vp]
+    L.tmdnet_update_params_device.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(vp)]
     L.tmdnet_num_params.argtypes = [vp]
     L.tmdnet_param_name.argtypes = [vp, C.c_int, C.POINTER(i64)]
     L.tmdnet_param_name.restype = C.c_char_p

@@ -282,6 +282,9 @@ class _EngineState:
         self.counts = None
         self.op_key = None   # key of the owning module in torchmdnet_amd.ops' registry (custom-op calls carry it)
         self.generation = 0  # bumped whenever the handle or a workspace is re-created: captured graphs of older generations are stale
+        self.uploaded_fp = None   # fingerprint of the last FULL upload / device update (tmdnet_update_params_device)
+        self.slot_keys = None     # state-dict key of every fingerprinted tensor
+        self.device_updates = 0   # parameter updates that stayed on the GPU
 
     def release(self):
         if self.handle is not None:
@@ -328,12 +331,37 @@ class _EnergyParamGrad(torch.autograd.Function):
         return (None,) * 7 + tuple(out)
 
 
-def _training_options(model):
-    if not getattr(model._engine, "train_options", False):
-        # the weights change every step: evaluate the radial functions directly instead of re-tabulating them per step
-        model.set_engine_option("edge_table_min_pairs", 1e15)
-        model.set_engine_option("embed_rb_min_atoms", 1e15)
-        model._engine.train_options = True
+class _direct_radial_functions:
+    """Scope in which the engine evaluates the radial functions directly (no radial tables, no radial-basis embedding): the
+    inference-schedule calls INSIDE a training step - the weights change every step, re-tabulating would cost ~100 ms each.
+    The previous values are restored on exit, so later validation / MD calls on the same module keep the benchmarked schedule
+    (round 3 set the options once and for all)."""
+
+    NAMES = ("edge_table_min_pairs", "embed_rb_min_atoms")
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        m, L = self.model, _C.lib()
+        st = m._sync_engine()
+        self.saved_options = dict(getattr(st, "options", {}))
+        self.saved = {}
+        for n in self.NAMES:
+            v = C.c_double()
+            L.tmdnet_get_info(st.handle, n.encode(), C.byref(v))
+            self.saved[n] = v.value
+            L.tmdnet_set_option(st.handle, n.encode(), 1e15)
+        st.options = dict(self.saved_options, **{n: 1e15 for n in self.NAMES})  # a re-upload inside the scope keeps them
+        return self
+
+    def __exit__(self, *exc):
+        st = self.model._engine
+        st.options = self.saved_options
+        if st.handle is not None:
+            for n, v in self.saved.items():
+                _C.lib().tmdnet_set_option(st.handle, n.encode(), v)
+        return False
 
 
 class _EnergyForceParamGrad(torch.autograd.Function):
@@ -345,7 +373,8 @@ class _EnergyForceParamGrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, z, pos, batch, box, q, n_mol, *params):
-        energy, forces = model.energy_and_forces(z, pos, batch, box, q, n_mol, want_forces=True)
+        with _direct_radial_functions(model):
+            energy, forces = model.energy_and_forces(z, pos, batch, box, q, n_mol, want_forces=True)
         ctx.model, ctx.n_mol, ctx.params = model, n_mol, params
         ctx.save_for_backward(z, pos, batch, forces, *(t for t in (box, q) if t is not None))
         ctx.has = (box is not None, q is not None)
@@ -369,6 +398,10 @@ class _EnergyForceParamGrad(torch.autograd.Function):
         if g_energy is not None:
             g_pos = -g_energy.reshape(-1)[batch].unsqueeze(1) * forces  # first order in pos (as tmdnet::energy_forces' backward)
         if g_forces is not None and bool((g_forces != 0).any()):
+            if ctx.needs_input_grad[2] and getattr(model, "_user_pos_grad", False):
+                raise NotImplementedError(
+                    "d loss / d pos through the forces (a second derivative in the positions) is not built: the force output carries "
+                    "a graph to the PARAMETERS only; detach pos or take the position gradient from an energy-only loss")
             v = g_forces.detach().to(torch.float32)
             scale = v.abs().max()
             vh = v / scale
@@ -567,6 +600,8 @@ class TorchMD_Net(nn.Module):
         # are re-uploaded below (hipFree / hipMalloc per step would each be a device-wide synchronisation)
         handle = st.handle
         sd = {k: v.detach() for k, v in self.state_dict().items()}
+        if self._update_engine_on_device(st, sd, fp):
+            return st
         table = self._atomref_table()
         if table is not None:
             sd["atomref"] = table
@@ -588,7 +623,51 @@ class TorchMD_Net(nn.Module):
         for name, value in getattr(st, "options", {}).items():
             L.tmdnet_set_option(handle, name.encode(), value)
         st.fingerprint = fp
+        # state for the device-side update of the next training step: the fingerprint this upload corresponds to and the
+        # state-dict key of every fingerprinted tensor (None: not in the state dict)
+        st.uploaded_fp = fp
+        by_id = {id(v): k for k, v in self.state_dict(keep_vars=True).items()}
+        st.slot_keys = [by_id.get(id(t)) for _, _, t in st.tensors[0]]
         return st
+
+    def _update_engine_on_device(self, st, sd, fp):
+        """Training loops: same handle, same tensors, new values on the GPU -> ``tmdnet_update_params_device`` rewrites the
+        engine's parameter buffer from the optimizer's tensors with a gather kernel (no host round trip of the weights, no
+        synchronisation).  Taken when the full upload happened once with the same tensor objects, every tensor is a
+        contiguous fp32 CUDA tensor, and nothing the host reads (mean, std, the Atomref table) changed."""
+        if getattr(st, "uploaded_fp", None) is None or self._is_et() or not getattr(self, "device_parameter_update", True):
+            return False
+        old = st.uploaded_fp
+        if len(old) != len(fp) or old[0] != fp[0]:
+            return False
+        slots = st.tensors[0]
+        names, ptrs = [], []
+        keys = st.slot_keys
+        if keys is None or len(keys) != len(slots):
+            return False
+        for (name, (_, _, t)), o, n in zip(zip(keys, slots), old[1:], fp[1:]):
+            if o == n:
+                continue
+            if o[1] != n[1] or name in ("mean", "std") or name is None or name.startswith("prior_model"):
+                return False  # storage moved, or a tensor the host reads: full upload
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                return False
+            names.append(name.encode())
+            ptrs.append(t.data_ptr())
+        if self.prior_model is not None and old[len(slots) + 1:] != fp[len(slots) + 1:]:
+            return False
+        if not names:
+            return False
+        L = _C.lib()
+        arr_n = (C.c_char_p * len(names))(*names)
+        arr_p = (C.c_void_p * len(ptrs))(*ptrs)
+        rc = L.tmdnet_update_params_device(st.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream), len(names), arr_n, arr_p)
+        if rc != _C.OK:
+            return False  # e.g. a parameter the engine does not know by that name: the full upload reports it
+        st.fingerprint = fp
+        st.uploaded_fp = fp
+        st.device_updates += 1
+        return True
 
     # ---------------------------------------------------------------- parameter gradients (energy-only training)
     def _grad_targets(self):
@@ -976,6 +1055,7 @@ class TorchMD_Net(nn.Module):
         if pos.dtype != torch.float32:
             raise NotImplementedError("torchmdnet_amd computes in fp32; cast positions to float32")
         if self.derivative:
+            self._user_pos_grad = bool(pos.requires_grad)  # did the CALLER ask for d / d pos? (see _EnergyForceParamGrad)
             pos.requires_grad_(True)  # reference side effect (model.py:584-585)
         if num_systems is not None:
             n_mol = int(num_systems)
@@ -994,7 +1074,6 @@ class TorchMD_Net(nn.Module):
         want_forces = bool(self.derivative or (pos.requires_grad and torch.is_grad_enabled()))
         _require_cuda(pos, "TorchMD_Net.forward")
         if self.parameter_gradients and torch.is_grad_enabled():
-            _training_options(self)
             params = [p for p in self.parameters() if p.requires_grad]
             if want_forces:  # force matching: forces carry a (finite-difference) graph to the parameters as well
                 energy, forces = _EnergyForceParamGrad.apply(self, z, pos, batch, box, q, n_mol, *params)
