@@ -167,10 +167,45 @@ def pmc_kernel_bytes(pmc, cls, label):
              "launch_embed_scatter": ["k_embed_scatter"], "launch_embed_pair_gd": ["k_embed_pair_gd_v4"],
              "launch_embed_combine": ["k_embed_combine<4, 2>"], "launch_embed_gm": ["k_embed_gm<4, 1, 8>"],
              "launch_embed_pair_rb": ["k_embed_pair_rb8<4, 4>"]}.get(head, [])
+    if head == "tlin9":  # "tlin9 <variant> 9xNxFxF": the template instance of the variant (tn_tlin9.hip: <prologue, epilogue>)
+        names = {"norm": ["k_tlin9<1, 0>"], "update": ["k_tlin9<0, 2>"], "updbwd": ["k_tlin9<2, 0>"], "normbwd": ["k_tlin9<0, 3>"],
+                 "normbwd+gate": ["k_tlin9<0, 4>"], "embbwd": ["k_tlin9<0, 5>"], "gate": ["k_tlin9<0, 1>"]}.get(label.split(" ")[1], [])
     for n in names:
         if n in per:
             return per[n], n
     return None, None
+
+
+def load_pmc_aux():
+    """PMC summary of the auxiliary legs (tools/profile_round.sh: the same two passes over `bench.py --aux-only`)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_aux.json")))
+    except Exception:
+        return {}
+
+
+def aux_traffic(prefixes):
+    """(bytes per launch, kernel name, summary) of the first kernel of the aux summary whose name starts with one of `prefixes`
+    (the heaviest one when several template instances match), or None."""
+    pmc = load_pmc_aux()
+    per = pmc.get("_per_kernel_total", {})
+    for pre in prefixes:
+        hits = [(v, k) for k, v in per.items() if k.startswith(pre)]
+        if hits:
+            v, k = max(hits)
+            return (v, k, pmc)
+    return None
+
+
+def with_aux_traffic(roof, prefixes):
+    hit = aux_traffic(prefixes)
+    if hit:
+        roof["traffic"] = hit[0]
+        roof["traffic_ratio"] = hit[0] / max(roof.get("algorithmic_bytes_per_launch", 0.0), 1.0)
+        src = traffic_source(hit[2], hit[1])
+        src["file"] = "profiles/pmc_traffic_aux.json"
+        roof["traffic_source"] = src
+    return roof
 
 
 def traffic_source(pmc, kernel_name):
@@ -259,7 +294,10 @@ def et_c4_leg(dev, L, steps=8, warmup=3, pair_storage="fp32"):
             "ms_per_step": dt * 1e3, "molecules_per_s": N_MOL / dt,
             "dtype": "f32 (bf16 MFMA, exact 3-way split)" if pair_storage == "fp32" else
                      "f32 arithmetic, per-pair filter rows stored as bf16 (pair_storage='bf16': <= 2e-3 rel. vs the fp32 oracle, tests/test_gpu_et.py)",
-            "pairs": model._engine.counts[0], "roofline": roofline_of(rec, cls, label, note_kernel=ET_KERNEL_OF.get(cls)),
+            "pairs": model._engine.counts[0],
+            "roofline": with_aux_traffic(roofline_of(rec, cls, label, note_kernel=ET_KERNEL_OF.get(cls)),
+                                         [ET_KERNEL_OF.get(cls, "k_et_attn_bwd") + ("_p<1" if pair_storage == "bf16" else "_p<0"),
+                                          ET_KERNEL_OF.get(cls, "k_et_attn_bwd")]),
             "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
 
 
@@ -288,7 +326,12 @@ def water10k_leg(dev, L, steps=8, warmup=3, dt_fs=1.0):
                         "cell-list neighbours rebuilt every step, E+F",
             "atoms": n, "pairs": model._engine.counts[0], "cell_grid": grid[:3], "cell_list": bool(grid[3]),
             "ms_per_step": dt * 1e3, "ns_per_day": 86400.0 / dt * dt_fs * 1e-6, "dt_fs": dt_fs,
-            "roofline": roofline_of(rec, cls, label), "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
+            "roofline": with_aux_traffic(roofline_of(rec, cls, label), [AUX_KERNEL_PREFIX.get(label.split("(")[0].split(" ")[0], "k_message_adjoint_gd")]),
+            "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
+
+
+AUX_KERNEL_PREFIX = {"launch_message_adjoint_gd": "k_message_adjoint_gd", "launch_message": "k_message", "gemm": "k_gemm_sb1",
+                     "gemm_dual<1>": "k_gemm_dual_sb2<1>", "gemm_dual<2>": "k_gemm_dual_sb2<2>", "tensor_linear": "k_gemm_sb1<0>"}
 
 
 def tn2_leg(dev, L, steps=8, warmup=3):
@@ -310,7 +353,8 @@ def tn2_leg(dev, L, steps=8, warmup=3):
     return {"workload": "TensorNet2 + ScalarPlusWeightedCoulomb F=128 L=2 K=32 q_dim=16 rc=5.0 (all-to-all Coulomb), S-mol64 256 x 64 atoms, "
                         "E+F, random-init (seed 0)",
             "ms_per_step": dt * 1e3, "molecules_per_s": N_MOL / dt, "pairs": model._engine.counts[0],
-            "roofline": roofline_of(rec, cls, label), "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
+            "roofline": with_aux_traffic(roofline_of(rec, cls, label), [AUX_KERNEL_PREFIX.get(label.split("(")[0].split(" ")[0], "k_gemm_sb1")]),
+            "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
 
 
 def training_leg(dev, L, steps=4, warmup=2):
@@ -438,6 +482,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-md", action="store_true", help="skip the HIP-graph latency leg (rocprofv3 --pmc cannot trace graph replays)")
     ap.add_argument("--no-aux", action="store_true", help="skip the configs[3] / configs[4] legs (profiling runs)")
+    ap.add_argument("--aux-only", action="store_true",
+                    help="run ONLY the auxiliary legs (ET, water box, TensorNet2) and print their line: the target of the rocprofv3 passes of tools/profile_round.sh that give these legs their kernel stats and PMC traffic")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-class / per-kernel timing table to this file")
     a = ap.parse_args()
 
@@ -471,6 +517,17 @@ def main():
     from torchmdnet_amd.parallel import ShardedEvaluator
 
     L = _C.lib()
+    if a.aux_only:  # the profiling target of the auxiliary legs: same legs, same sizes, nothing else in the process
+        out = {"aux_only": True}
+        for key, leg in (("et_c4", et_c4_leg), ("et_c4_bf16", lambda d, l, **kw: et_c4_leg(d, l, pair_storage="bf16", **kw)),
+                         ("water10k", water10k_leg), ("tensornet2", tn2_leg)):
+            out[key] = leg(dev, L, steps=a.steps, warmup=a.warmup)
+        if a.breakdown:
+            os.makedirs(os.path.dirname(os.path.abspath(a.breakdown)), exist_ok=True)
+            with open(a.breakdown, "w") as fh:
+                json.dump({"aux_legs": AUX_GROUPS}, fh, indent=1)
+        print(json.dumps(out), flush=True)
+        return
     torch.manual_seed(0)
     args_dict = dict(W.C2_ARGS)
     model = create_model(dict(args_dict)).to(dev)

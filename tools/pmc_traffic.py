@@ -21,7 +21,7 @@ import re
 
 # kernel (rocprofv3 short name, template instance kept) -> profiled class of the library (tn_model.h ProfCat).  Exact
 # patterns: `k_message_bwd_node` is an elementwise kernel, not a sweep.
-CLASS_OF = [(r"k_gemm_dual", "gemm_edge"), (r"k_edge_mlp", "gemm_edge"), (r"k_gemm_(nt|skinny|sb1)", "gemm_node"),
+CLASS_OF = [(r"k_gemm_dual", "gemm_edge"), (r"k_edge_mlp", "gemm_edge"), (r"k_gemm_(nt|skinny|sb1)", "gemm_node"), (r"k_tlin9", "gemm_node"),
             (r"k_message(_tile|_rows8|_adjoint|_adjoint_gd|_split)?(<.*>)?$", "message"),
             (r"k_(edge_interp|pair_cutoff_hist|bucket_scan|bucket_scatter)", "edge_table"),
             (r"k_(pair_gd|embed_pair_gd|geom_gd|embed_gm|embed_pair_rb)", "pair_bwd"),
@@ -74,7 +74,7 @@ def main():
     res["_per_kernel"] = kernels
     res["_per_kernel_total"] = {k: v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for k, v in kernels.items()}
     res["_meta"] = {"git_commit": os.environ.get("GIT_COMMIT"), "recipe": "tools/profile_round.sh (two rocprofv3 --pmc passes: FETCH_SIZE, WRITE_SIZE)",
-                    "bench_command": "python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-md --no-aux"}
+                    "bench_command": sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-md --no-aux"}
     res["_note"] = "bytes per launch; reads = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), writes = WRITE_SIZE KiB x 1024"
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)

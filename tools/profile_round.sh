@@ -11,6 +11,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- py
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_rd -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-md --no-aux > $R/gpurun_out/pmc_rd.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_wr -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-md --no-aux > $R/gpurun_out/pmc_wr.log 2>&1
 python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_rd $R/gpurun_out/pmc_wr $R/gpurun_out/pmc_traffic.json
+# the auxiliary legs (ET configs[3] in both storage modes, 10k-atom water box, TensorNet2): kernel stats + the same two PMC passes
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_aux -- python $R/bench.py --aux-only --steps 3 --warmup 2 > $R/gpurun_out/prof_aux.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_rd_aux -- python $R/bench.py --aux-only --steps 1 --warmup 1 > $R/gpurun_out/pmc_rd_aux.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_wr_aux -- python $R/bench.py --aux-only --steps 1 --warmup 1 > $R/gpurun_out/pmc_wr_aux.log 2>&1
+python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_rd_aux $R/gpurun_out/pmc_wr_aux $R/gpurun_out/pmc_traffic_aux.json "python bench.py --aux-only --steps 1 --warmup 1"
+find $R/gpurun_out/pmc_rd_aux $R/gpurun_out/pmc_wr_aux -name '*.csv' -size +4M -delete
+find $R/gpurun_out/prof_aux -name '*kernel_trace.csv' -size +8M -delete
 # keep only the summaries (counter CSVs of every dispatch are large)
 find $R/gpurun_out/pmc_rd $R/gpurun_out/pmc_wr -name '*.csv' -size +4M -delete
 find $R/gpurun_out/prof -name '*kernel_trace.csv' -size +8M -delete

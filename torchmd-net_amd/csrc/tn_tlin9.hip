@@ -491,21 +491,31 @@ void launch_split_weight_fm(const float* W_dev, int64_t n, int64_t k, uint16_t* 
   hipLaunchKernelGGL(k_split_weight_fm, dim3((total + 255) / 256), dim3(256), 0, s, W_dev, (int)n, (int)k, out_dev);
 }
 
-bool tlin9_ok(int N, int F) {
-  static const bool off = getenv("TMDNET_NO_TLIN9") != nullptr || getenv("TMDNET_NO_SPLIT_BF16") != nullptr;  // developer switches
-  // batch scale only: below ~128 tiles the launch does not fill the chip and the split-K kernels of the small-system path win
-  // (measured with the threshold at 1: 64 atoms 0.233 -> 0.391 ms per replayed step, 2048 atoms 0.65 -> 0.74, 4096 atoms equal)
-  return !off && F >= T9_NT && F % T9_NT == 0 &&  // (F % 128 == 0: the chunk count is a multiple of 4)
-         (int64_t)((N + T9_RA - 1) / T9_RA) * (F / T9_NT) >= 128;
-}
-
-int launch_tlin9(const Tl9Args& a, int pro, int epi, hipStream_t s) {
-  const int tiles_m = (a.N + T9_RA - 1) / T9_RA, tiles_n = a.F / T9_NT;
+static int t9_num_cu() {
   static const int n_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n;
   }();
+  return n_cu;
+}
+
+bool tlin9_ok(int N, int F) {
+  static const bool off = getenv("TMDNET_NO_TLIN9") != nullptr || getenv("TMDNET_NO_SPLIT_BF16") != nullptr;  // developer switches
+  if (off || F < T9_NT || F % T9_NT) return false;  // (F % 128 == 0: the double-chunk count per tile is even)
+  // batch scale only: below ~128 tiles the launch does not fill the chip and the split-K kernels of the small-system path win
+  // (measured with the threshold at 1: 64 atoms 0.233 -> 0.391 ms per replayed step, 2048 atoms 0.65 -> 0.74, 4096 atoms equal)
+  const int64_t tiles = (int64_t)((N + T9_RA - 1) / T9_RA) * (F / T9_NT);
+  if (tiles < 128) return false;
+  // one persistent block per CU: the launch takes ceil(tiles / CUs) tile times, so a mostly empty last round is paid in full
+  // (10 125 atoms = 317 tiles on 256 CUs: two rounds for 1.24 rounds of work, the water box stepped 3.02 -> 3.16 ms)
+  const int64_t n_cu = t9_num_cu(), rounds = (tiles + n_cu - 1) / n_cu;
+  return tiles <= n_cu || 5 * tiles >= 4 * rounds * n_cu;
+}
+
+int launch_tlin9(const Tl9Args& a, int pro, int epi, hipStream_t s) {
+  const int tiles_m = (a.N + T9_RA - 1) / T9_RA, tiles_n = a.F / T9_NT;
+  const int n_cu = t9_num_cu();
   const int total = tiles_m * tiles_n;
   const dim3 grid(total < n_cu ? total : n_cu), block(512);  // persistent: one block per CU
 #define T9_LAUNCH(P, E) hipLaunchKernelGGL((k_tlin9<P, E>), grid, block, 0, s, a, tiles_m, tiles_n)
