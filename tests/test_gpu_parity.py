@@ -1,8 +1,11 @@
 """-m gpu: parity of the HIP path (through the C ABI) with the oracle and the committed golden vectors.
 
-Tolerance: BASELINE north_star -> energies and forces within 1e-4 relative (fp32), measured as
-max|delta| / max|reference| per tensor.  The reference's own golden-vector test uses atol=rtol=1e-5
-(tests/test_model.py:322-329); that tighter bar is applied to the golden case as well."""
+Tolerance: BASELINE north_star -> energies and forces within 1e-4 relative (fp32).  THE METRIC of `rel_err` (used by every
+`-m gpu` parity test of this repo) is the MAX-NORM relative error per tensor, max|delta| / max|reference| - looser than the
+reference's element-wise `assert_close` for entries much smaller than the largest one (measured values are 1e-7 ... 1e-6, so the
+difference does not matter today; it is stated so that nobody reads the bound as element-wise).  Two cases carry the
+element-wise form too: the reference's own golden vector at its atol = rtol = 1e-5 (tests/test_model.py:322-329) and the C2
+fixture at rtol = 1e-4, atol = 1e-4 max|reference| (test_c2_vs_reference_fixture)."""
 import os
 
 import pytest
@@ -91,6 +94,10 @@ def test_c2_vs_reference_fixture(hip_lib, golden_dir):
     E, F = model(z.cuda(), pos.cuda(), batch.cuda())
     assert rel_err(E.cpu(), g["E"]) < REL
     assert rel_err(F.cpu(), g["F"]) < REL
+    # element-wise as well: every entry within rtol of its reference value, entries near zero within 1e-4 of
+    # the tensor's largest one
+    torch.testing.assert_close(E.cpu().view(-1), g["E"].view(-1), rtol=REL, atol=REL * g["E"].abs().max().item())
+    torch.testing.assert_close(F.cpu(), g["F"], rtol=REL, atol=REL * g["F"].abs().max().item())
 
 
 def test_c2_vs_oracle_and_properties(hip_lib):

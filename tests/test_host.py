@@ -380,3 +380,22 @@ def test_parameter_gradient_entries_map_back_to_state_dict_rows():
     assert torch.equal(grads[last.weight][0], torch.arange(F2, dtype=torch.float32)) and grads[last.weight][1].abs().max() == 0
     assert grads[last.bias][0] == 7.0 and grads[last.bias][1] == 0.0
     assert set(id(p) for p in grads) <= set(id(p) for p in model.parameters())
+
+
+def test_every_developer_switch_is_listed_for_the_gpu_switch_tests():
+    """tests/test_gpu_switches.py runs every TMDNET_* environment switch on its own: a switch added to the library without an
+    entry there fails HERE (CPU), so no kernel variant can hide behind an untested switch."""
+    import glob, re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for path in glob.glob(os.path.join(root, "torchmd-net_amd", "csrc", "*")) + glob.glob(os.path.join(root, "torchmd-net_amd", "torchmdnet_amd", "**", "*.py"), recursive=True):
+        found |= set(re.findall(r'getenv\("(TMDNET_[A-Z0-9_]+)"\)|environ(?:\.get)?\(?\[?"(TMDNET_[A-Z0-9_]+)"', open(path).read())) 
+    names = {a or b for a, b in found}
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sw", os.path.join(root, "tests", "test_gpu_switches.py"))
+    sw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sw)
+    missing = names - set(sw.SWITCHES) - sw.NOT_KERNEL_SWITCHES
+    assert not missing, f"switches without a GPU test: {sorted(missing)}"
+    assert set(sw.SWITCHES) <= names, f"stale entries: {sorted(set(sw.SWITCHES) - names)}"
