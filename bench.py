@@ -136,7 +136,8 @@ def roofline_mfma_of(rec, label, pmc=None):
     split = not os.environ.get("TMDNET_NO_SPLIT_BF16")
     fl, by = rec["flops"] / launches, rec["bytes"] / launches
     peak = PEAK["mfma_bf16_tflops"] / SPLIT_PRODUCTS if split else PEAK["mfma_f32_tflops"]
-    out = {"bound": "mfma", "kernel": f"k_gemm_sb1 [{label}]" + (" (v_mfma_f32_32x32x16_bf16 x6 per fp32 product)" if split else ""),
+    kname = "k_tlin9" if label.startswith("tlin9") else "k_gemm_sb1"
+    out = {"bound": "mfma", "kernel": f"{kname} [{label}]" + (" (v_mfma_f32_32x32x16_bf16 x6 per fp32 product)" if split else ""),
            "achieved": fl / avg_s / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / peak,
            "executed_bf16_tflops": (SPLIT_PRODUCTS if split else 1) * fl / avg_s / 1e12,
            "executed_frac_of_bf16_peak": (SPLIT_PRODUCTS * fl / avg_s / 1e12 / PEAK["mfma_bf16_tflops"]) if split else None,
@@ -678,8 +679,13 @@ def main():
         }
         out["config"]["rank_step"] = rank_step
         if gemm_rec:
-            out["roofline_mfma"] = roofline_mfma_of(gemm_rec, gemm_label, pmc=(pmc.get("_per_kernel_total", {}).get("k_gemm_sb1<0>"), "k_gemm_sb1<0>", pmc)
-                                                    if gemm_label.startswith("tensor_linear") else None)
+            if gemm_label.startswith("tlin9"):
+                gb, gk = pmc_kernel_bytes(pmc, "gemm_node", gemm_label)
+                gpmc = (gb, gk, pmc) if gb is not None else None
+            else:
+                gpmc = ((pmc.get("_per_kernel_total", {}).get("k_gemm_sb1<0>"), "k_gemm_sb1<0>", pmc)
+                        if gemm_label.startswith("tensor_linear") else None)
+            out["roofline_mfma"] = roofline_mfma_of(gemm_rec, gemm_label, pmc=gpmc)
         if use_dist:
             out["ranks_seen_by_rccl"] = dist.get_world_size()
             out["rccl"] = {"backend": dist.get_backend(), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
