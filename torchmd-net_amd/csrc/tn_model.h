@@ -282,6 +282,10 @@ int rb_ntp(const tmdnet_model* m, int64_t n_atoms, int64_t n_pairs);
 // the three weight matrices act on the channel axis of the 1 + 3 + 5 irreducible components: one grouped launch, 9 groups
 void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], float* C, int N, int F, int flags = 0, float* pre = nullptr,
                    const float* gates = nullptr);
+// fused form of the 9-component tensor linears (tn_tlin9.hip) and whether the three weights have their fragment-major images
+namespace tn { struct Tl9Args; }
+bool tlin9_images(const float* const W3[3]);
+void tlin9(hipStream_t s, int pro, int epi, const float* const W3[3], tn::Tl9Args a, double tensors, const char* what);
 // radial tables (tn_api.hip): fp64 build + midpoint verification; `out.ok` says whether they may be used
 // builds the radial tables if a parameter upload left them pending (blocking, NULL stream); refuses while `s` is being captured
 int ensure_radial_tables(tmdnet_model* m, hipStream_t s);

@@ -19,6 +19,7 @@
 
 #include "tn_model.h"
 #include "tn_tn2.h"
+#include "tn_tlin9.h"
 
 using namespace tn;
 
@@ -301,7 +302,15 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
   NODE();
   gemm(s, b.ln0, F, W.L1, F, W.bL1, b.h1, 2 * F, N, 2 * F, F, GEMM_ACT_SILU, b.a1, 2 * F);
   gemm(s, b.h1, 2 * F, W.L2, 2 * F, W.bL2, b.gates, 3 * F, N, 3 * F, 2 * F, GEMM_ACT_SILU, b.a2, 3 * F);
-  tensor_linear(s, b.u0, W.Ue, b.X[0], N, F, GEMM_MUL_AUX, b.UX, b.gates);
+  // fused 9-component tensor linears at batch scale (tn_tlin9.hip, as in tn_api.hip); the parameter-gradient pass keeps the
+  // unfused schedule (its weight-gradient products read the intermediates)
+  const bool t9 = !tc && tlin9_ok(N, F) && tlin9_images(W.Ue) && tlin9_images(W.UeT) && (L == 0 || (tlin9_images(W.layer[0].V) && tlin9_images(W.layer[0].VT)));
+  if (t9) {
+    Tl9Args ta{};
+    ta.A = b.u0; ta.C = b.X[0]; ta.o1 = b.UX; ta.e3 = b.gates; ta.N = N; ta.F = F;
+    tlin9(s, TL9_PRO_PLAIN, TL9_EPI_MULGATE, W.Ue, ta, 3.0 + 1.0 / 3.0, "gate");
+  } else
+    tensor_linear(s, b.u0, W.Ue, b.X[0], N, F, GEMM_MUL_AUX, b.UX, b.gates);
 
   // ---- ChargePredict head l on X[l] (tensornet2.py:139-157)
   auto charge_predict = [&](int l) {
@@ -331,12 +340,22 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
          nullptr, 0, t.Ce[l]);
     float* const Xh_l = tc ? tc->Xh[l] : b.Xh;
     float* const Ch_l = tc ? tc->Ch[l] : b.Ch;
+    if (t9) {
+      Tl9Args ta{};
+      ta.A = b.X[l]; ta.C = b.Pn[l]; ta.N = N; ta.F = F;
+      tlin9(s, TL9_PRO_NORM, TL9_EPI_PLAIN, q_.V, ta, 2.0, "norm");
+      KR(CAT_MESSAGE, Ed * (12 * Fd + 12) + 3 * nodeB, launch_message(gE, N, F, t.we[l], b.Pn[l], nullptr, nullptr, o3, b.Mi[l], Ch_l, s));
+      Tl9Args tb{};
+      tb.A = Ch_l; tb.C = b.D[l]; tb.e0 = b.X[l]; tb.o1 = b.X[l + 1]; tb.o2 = b.feat; tb.want_feat = l + 1 == L; tb.N = N; tb.F = F;
+      tlin9(s, TL9_PRO_PLAIN, TL9_EPI_UPDATE, q_.V + 3, tb, 4.0 + (l + 1 == L ? 1.0 / 3.0 : 0.0), "update");
+    } else {
     KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], Xh_l, N, F, s));
     tensor_linear(s, Xh_l, q_.V, b.Pn[l], N, F);
     KR(CAT_MESSAGE, Ed * (12 * Fd + 12) + 3 * nodeB, launch_message(gE, N, F, t.we[l], b.Pn[l], nullptr, nullptr, o3, b.Mi[l], Ch_l, s));
     tensor_linear(s, Ch_l, q_.V + 3, b.D[l], N, F);
     // X_new = X_hat + dX + dX dX (no charge factor, tensornet2.py:624); the readout invariants come with the last layer
     KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(Xh_l, b.D[l], nullptr, nullptr, N, F, b.X[l + 1], l + 1 < L ? 0 : 2, b.feat, s));
+    }
     charge_predict(l + 1);
   }
 
@@ -435,10 +454,16 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
       const LayerP& q_ = W.layer[l];
       const Tn2LayerP& q2 = T2.layer[l];
       // G = gradient wrt X[l + 1]
-      KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], nullptr, nullptr, N, F, b.gD, s));
       const std::string t_ = "l" + std::to_string(l) + ".";
+      if (t9) {
+        Tl9Args ta{};
+        ta.A = b.G; ta.A2 = b.D[l]; ta.N = N; ta.F = F; ta.C = b.gCh;
+        tlin9(s, TL9_PRO_UPDBWD, TL9_EPI_PLAIN, q_.VT + 3, ta, 3.0, "updbwd");
+      } else {
+      KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], nullptr, nullptr, N, F, b.gD, s));
       if (tc) tensor_linear_grad(b.gD, tc->Ch[l], t_ + "Vb");
       tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
+      }
       KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], nullptr, nullptr, o3, N, F, b.gMi, b.gPn, s));
       // per-edge weight gradient -> g_pre3, cutoff gradient slots; then the transposed sweep with w[erev[e]]
       KR(CAT_PAIR, Ed * (24 * Fd + 12) + 2 * nodeB,
@@ -473,9 +498,15 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
       gemm(s, t.gB, F, q2.M1bT, F, nullptr, t.g_c, qd, N, qd, F, GEMM_ACCUM);
       gemm(s, t.gCs, F, q2.M1cT, F, nullptr, t.g_c, qd, N, qd, F, GEMM_ACCUM);
       // node chain down to X[l]
+      if (t9) {
+        Tl9Args ta{};
+        ta.A = b.gPn; ta.e0 = b.X[l]; ta.e1 = b.G; ta.C = b.G; ta.N = N; ta.F = F;
+        tlin9(s, TL9_PRO_PLAIN, TL9_EPI_NORMBWD, q_.VT, ta, 4.0, "normbwd");
+      } else {
       if (tc) tensor_linear_grad(b.gPn, tc->Xh[l], t_ + "Va");
       tensor_linear(s, b.gPn, q_.VT, b.gXl, N, F);
       KR(CAT_ELEMENTWISE, 4 * nodeB, launch_norm_bwd(b.X[l], b.gXl, N, F, b.G, s));  // reads the residual G, writes the gradient wrt X[l]
+      }
       charge_predict_bwd(l);
     }
     // ---- embedding adjoint (TensorNet's)
@@ -484,8 +515,14 @@ int tn2_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g0, void* ws,
     gemm(s, b.g_a2, 3 * F, W.L2T, 3 * F, nullptr, b.g_a1, 2 * F, N, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.a1, 2 * F);
     gemm(s, b.g_a1, 2 * F, W.L1T, 2 * F, nullptr, b.g_ln0, F, N, F, 2 * F);
     KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s));
+    if (t9) {
+      Tl9Args ta{};
+      ta.A = b.gUX; ta.e0 = b.u0; ta.e1 = b.g_s0n; ta.o1 = b.gA; ta.N = N; ta.F = F;
+      tlin9(s, TL9_PRO_PLAIN, TL9_EPI_EMBBWD, W.UeT, ta, 2.0 + 11.0 / 9.0, "embbwd");
+    } else {
     tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
     KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
+    }
     if (tc) {  // the embedding is TensorNet's: same products as in tn_api.hip
       tensor_linear_grad(b.gUX, b.u0, "Ue");
       dW("L2", b.g_a2, 3 * F, b.h1, 2 * F, N, 3 * F, 2 * F);
