@@ -191,7 +191,8 @@ def aux_traffic(prefixes):
     pmc = load_pmc_aux()
     per = pmc.get("_per_kernel_total", {})
     for pre in prefixes:
-        hits = [(v, k) for k, v in per.items() if k.startswith(pre)]
+        pre, suf = pre if isinstance(pre, tuple) else (pre, "")  # (prefix, suffix): e.g. the storage mode is the LAST template argument
+        hits = [(v, k) for k, v in per.items() if k.startswith(pre) and k.endswith(suf)]
         if hits:
             v, k = max(hits)
             return (v, k, pmc)
@@ -297,8 +298,7 @@ def et_c4_leg(dev, L, steps=8, warmup=3, pair_storage="fp32"):
                      "f32 arithmetic, per-pair filter rows stored as bf16 (pair_storage='bf16': <= 2e-3 rel. vs the fp32 oracle, tests/test_gpu_et.py)",
             "pairs": model._engine.counts[0],
             "roofline": with_aux_traffic(roofline_of(rec, cls, label, note_kernel=ET_KERNEL_OF.get(cls)),
-                                         [ET_KERNEL_OF.get(cls, "k_et_attn_bwd") + ("_p<1" if pair_storage == "bf16" else "_p<0"),
-                                          ET_KERNEL_OF.get(cls, "k_et_attn_bwd")]),
+                                         [(ET_KERNEL_OF.get(cls, "k_et_attn_bwd") + "_p<", "true>" if pair_storage == "bf16" else "false>")]),
             "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
 
 

@@ -398,10 +398,15 @@ class _EnergyForceParamGrad(torch.autograd.Function):
         if g_energy is not None:
             g_pos = -g_energy.reshape(-1)[batch].unsqueeze(1) * forces  # first order in pos (as tmdnet::energy_forces' backward)
         if g_forces is not None and bool((g_forces != 0).any()):
-            if ctx.needs_input_grad[2] and getattr(model, "_user_pos_grad", False):
-                raise NotImplementedError(
-                    "d loss / d pos through the forces (a second derivative in the positions) is not built: the force output carries "
-                    "a graph to the PARAMETERS only; detach pos or take the position gradient from an energy-only loss")
+            if ctx.needs_input_grad[2] and not getattr(model, "_warned_pos_grad", False):
+                # pos always requires grad here (the reference's side effect, model.py:584-585), so this cannot tell a caller who
+                # wants d loss / d pos from one who does not: say it once instead of silently returning a truncated gradient
+                import warnings
+
+                warnings.warn("torchmdnet_amd: pos.grad of a loss that depends on the FORCES holds only the energy term's part "
+                              "(-g_E F): the second derivative in the positions is not built; the force output carries a graph "
+                              "to the parameters only", stacklevel=2)
+                model._warned_pos_grad = True
             v = g_forces.detach().to(torch.float32)
             scale = v.abs().max()
             vh = v / scale
@@ -1055,7 +1060,6 @@ class TorchMD_Net(nn.Module):
         if pos.dtype != torch.float32:
             raise NotImplementedError("torchmdnet_amd computes in fp32; cast positions to float32")
         if self.derivative:
-            self._user_pos_grad = bool(pos.requires_grad)  # did the CALLER ask for d / d pos? (see _EnergyForceParamGrad)
             pos.requires_grad_(True)  # reference side effect (model.py:584-585)
         if num_systems is not None:
             n_mol = int(num_systems)
