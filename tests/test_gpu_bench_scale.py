@@ -191,3 +191,42 @@ def test_several_large_molecules_through_the_cell_list(hip_lib, periodic):
     bad[5] = 7
     with pytest.raises(RuntimeError):
         model(zc, pc.clone(), bad, q=q.cuda(), num_systems=3, **kw)
+
+
+def test_fused_tensor_linears_with_charges_ragged_partial_tile_vs_oracle(hip_lib):
+    """The fused tensor linears (csrc/tn_tlin9.hip) at a size that engages them (>= 128 tiles of 32 atoms) on a batch that is NOT
+    the benchmark's: ragged molecules (tile boundaries inside molecules, a partial last tile), total charges (the charge factor
+    enters the update epilogue and the update-adjoint prologue, reference tensornet.py:789, 812), O(3) and SO(3) products.  Sampled
+    molecules against the torch oracle (molecules are independent), all molecules against the unfused schedule of a second handle
+    is not possible in one process (the switch is read once) - tests/test_gpu_switches.py runs the unfused schedule on fixtures."""
+    from oracle import tensornet_torch as T
+    from torchmdnet_amd.models.model import create_model
+
+    for group in ("O(3)", "SO(3)"):
+        args = dict(W.C2_ARGS, equivariance_invariance_group=group)
+        torch.manual_seed(5)
+        model = create_model(dict(args)).to("cuda")
+        sizes = [64 - (m % 7) for m in range(90)]  # 5 490 atoms = 172 tiles (one round), last tile partial
+        zs, ps, bs = [], [], []
+        for m, n in enumerate(sizes):
+            zz, pp = W.synthetic_molecule(9000 + m, n_atoms=n)
+            zs.append(torch.from_numpy(zz)); ps.append(torch.from_numpy(pp)); bs.append(torch.full((n,), m, dtype=torch.long))
+        z, pos, batch = torch.cat(zs), torch.cat(ps), torch.cat(bs)
+        assert z.shape[0] % 32 != 0
+        q = torch.tensor([float(m % 3 - 1) for m in range(len(sizes))])
+        E, F = model(z.cuda(), pos.cuda(), batch.cuda(), q=q.cuda())
+        E2, F2 = model(z.cuda(), pos.cuda(), batch.cuda(), q=q.cuda())
+        assert torch.equal(E, E2) and torch.equal(F, F2)  # deterministic
+        sd = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+        hp = T.hparams_from_args(args)
+        off = [0]
+        for n in sizes:
+            off.append(off[-1] + n)
+        for m in (0, 37, 89):
+            sl = slice(off[m], off[m + 1])
+            Er, Fr = T.energy_and_forces(sd, hp, z[sl], pos[sl].double(), torch.zeros(sizes[m], dtype=torch.long), q=q[m:m + 1].double())
+            assert abs(E[m].item() - Er.item()) / max(abs(Er.item()), 1e-12) < REL, (group, m)
+            assert rel_err(F[sl].cpu().double(), Fr) < REL, (group, m)
+        # zero net force per molecule (pairwise forces): every molecule, not only the sampled ones
+        net = torch.zeros(len(sizes), 3, device="cuda").index_add_(0, batch.cuda(), F)
+        assert net.abs().max().item() < 1e-3 * F.abs().max().item()
