@@ -427,3 +427,99 @@ def test_randomised_small_systems_vs_oracle(hip_lib, golden_dir):
                                       box=None if box is None else box[m], q=None if q is None else q[m:m + 1])
             assert abs(E[m].item() - Eo.item()) < 1e-4 * max(1.0, abs(Eo.item())), (case, m)
             assert (F[sel.cuda()].cpu() - Fo).abs().max().item() < 1e-4 * max(1.0, Fo.abs().max().item()), (case, m)
+
+
+@pytest.mark.parametrize("F,L,group", [(64, 1, "O(3)"), (64, 3, "SO(3)"), (128, 2, "O(3)")])
+def test_fused_small_system_kernels_vs_oracle(hip_lib, F, L, group):
+    """The per-atom phase kernels of small systems (csrc/tn_small.hip: hidden width 64 or 128, <= 512 atoms, >= 1 layer) over
+    the same awkward corners as the randomised sweep - single atoms, isolated atoms, ragged and unsorted molecules,
+    triclinic boxes, total charges - plus the energy-only call and the static-shape replay; oracle = the scalar C
+    transliteration (oracle/tensornet_c.c), fp32 bound 1e-4 relative to the largest entry."""
+    import numpy as np
+    from oracle import tensornet_c as CO, tensornet_torch as T
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.C2_ARGS, embedding_dimension=F, num_layers=L, num_rbf=16, equivariance_invariance_group=group, max_z=20,
+                max_num_neighbors=64)
+    torch.manual_seed(5)
+    model = create_model(dict(args)).to("cuda")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hp = T.hparams_from_args(args)
+    e_only = _model_from_sd(dict(args, derivative=False), sd)
+    rng = np.random.default_rng(77 + F + L)
+    for case in range(10):
+        n_mol = int(rng.integers(1, 5))
+        sizes = [int(rng.integers(1, 20)) for _ in range(n_mol)]
+        spread = float(rng.choice([1.5, 3.0, 9.0]))
+        pos = np.concatenate([rng.uniform(0, spread * max(s, 2) ** (1 / 3), size=(s, 3)) for s in sizes]).astype(np.float32)
+        z = rng.integers(1, 20, size=sum(sizes))
+        batch = np.repeat(np.arange(n_mol), sizes)
+        box = None
+        if case % 3 == 1:
+            box = torch.tensor([[[12.0 + m, 0, 0], [0.5, 12.5, 0], [-0.4, 0.7, 13.0]] for m in range(n_mol)], dtype=torch.float32)
+        q = torch.tensor(rng.integers(-2, 3, size=n_mol), dtype=torch.float32) if case % 4 == 2 else None
+        if case % 5 == 4 and n_mol > 1:
+            perm = rng.permutation(len(z))
+            pos, z, batch = pos[perm], z[perm], batch[perm]
+        zt, pt, bt = torch.from_numpy(z), torch.from_numpy(pos), torch.from_numpy(batch)
+        kw = dict(box=None if box is None else box.cuda(), q=None if q is None else q.cuda())
+        E, Fo = model(zt.cuda(), pt.cuda(), bt.cuda(), **kw)
+        E0 = e_only(zt.cuda(), pt.cuda(), bt.cuda(), **kw)[0]
+        assert torch.equal(E0.reshape(-1), E.reshape(-1)), case  # the same forward kernels with and without the reverse half
+        for m in range(n_mol):
+            sel = bt == m
+            Eo, Fr = CO.energy_forces(sd, hp, zt[sel], pt[sel], torch.zeros(int(sel.sum()), dtype=torch.long),
+                                      box=None if box is None else box[m], q=None if q is None else q[m:m + 1])
+            assert abs(E[m].item() - Eo.item()) < 1e-4 * max(1.0, abs(Eo.item())), (case, m)
+            assert (Fo[sel.cuda()].cpu() - Fr).abs().max().item() < 1e-4 * max(1.0, Fr.abs().max().item()), (case, m)
+    # one 64-atom molecule, static shapes + replay (the MD stepping path) against the dynamic call
+    z, pos, batch = (t.cuda() for t in W.synthetic_batch(n_mol=1, n_atoms=64))
+    z = z % 19 + 1
+    Ed, Fd = model(z, pos, batch)
+    sm = _model_from_sd(dict(args, static_shapes=True), sd)
+    replay = sm.capture(z, pos, batch)
+    for _ in range(2):
+        Es, Fs = replay(pos)
+    assert torch.equal(Es.reshape(-1), Ed.reshape(-1)) and torch.equal(Fs, Fd)
+    # ... and it is these kernels that ran (per-launch records of the C ABI's profiler)
+    import ctypes as C
+    import bench
+    from torchmdnet_amd import _C
+    lib = _C.lib()
+    bench.profile_begin(model, lib)
+    model(z, pos, batch)
+    _, groups = bench.profile_records(model, lib, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    labels = " ".join(label for (_, label) in groups)
+    assert "launch_small_embed" in labels and "launch_small_layer" in labels and "launch_small_rev" in labels, labels
+    assert "tensor_linear" not in labels and "launch_message(" not in labels, labels
+
+
+def test_fused_small_system_kernels_equal_the_unfused_schedule(hip_lib, tmp_path):
+    """Same model, same 64-atom molecule (with a total charge), fused per-atom kernels vs the general schedule (developer switch
+    TMDNET_SMALL_FUSED_MAX=0, read once per process: a child process).  Both are fp32; they differ by summation order only."""
+    import subprocess
+    import sys
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    script = (
+        "import sys, torch\n"
+        "sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/torchmd-net_amd')\n"
+        "from torchmdnet_amd import workloads as W\n"
+        "from torchmdnet_amd.models.model import create_model\n"
+        "torch.manual_seed(0)\n"
+        "m = create_model(dict(W.C2_ARGS)).cuda()\n"
+        "z, pos, batch = (t.cuda() for t in W.synthetic_batch(n_mol=2, n_atoms=64))\n"
+        "E, F = m(z, pos, batch, q=torch.tensor([1.0, -2.0], device='cuda'))\n"
+        "torch.save({'E': E.cpu(), 'F': F.cpu()}, sys.argv[2])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, env in (("fused", {}), ("unfused", {"TMDNET_SMALL_FUSED_MAX": "0"})):
+        path = str(tmp_path / (name + ".pt"))
+        r = subprocess.run([sys.executable, "-c", script, root, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs[name] = torch.load(path)
+    assert rel_err(outs["fused"]["E"], outs["unfused"]["E"]) < 1e-5
+    assert rel_err(outs["fused"]["F"], outs["unfused"]["F"]) < 1e-5
+    assert not torch.equal(outs["fused"]["F"], outs["unfused"]["F"])  # the switch did select another schedule

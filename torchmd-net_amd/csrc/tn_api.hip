@@ -19,6 +19,7 @@
 
 #include "tn_model.h"
 #include "tn_tlin9.h"
+#include "tn_small.h"
 
 using namespace tn;
 
@@ -1361,6 +1362,9 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   // the parameter-gradient pass may run the two halves as separate calls (TrainCtx::phase): forward with everything kept in the
   // caller's workspaces, reverse once the seeds d loss / d E are known
   const bool run_fwd = !tc || tc->phase != 2, run_bwd = !tc || tc->phase != 1;
+  // the slots of the merged distance gradient are what the fused reverse sweeps write: both or neither
+  const bool fused_small = !tc && !ntp && small_fused_ok(N, F, H, L) &&
+                           (!want_forces || (message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD")));
   if (run_fwd) {
     if (use_tab) {
       // radial tables (tn_edge_table.hip): sort the pairs by distance, one streaming Hermite-interpolation kernel for all
@@ -1426,6 +1430,39 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       else if (want_forces) gemm_dual(s, 0, b.phi, b.dphi, K, W.Wdp, W.bdp, b.Q, b.dQ, 3 * F, P1, 3 * F, K, nullptr, nullptr, W.Wdp_sb);  // distance projections + d/dd
       else gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
     }
+    if (fused_small) {
+      // small systems: the node side of the step as 1 + L (+ L) per-atom kernels cut at the neighbour sweeps (tn_small.hip)
+      SmallEmbedArgs ea{};
+      ea.g = g; ea.N = N; ea.F = F; ea.L = L; ea.z = z;
+      ea.Utab = W.Utab; ea.Vtab = W.Vtab; ea.Q = b.Q; ea.C = b.C;
+      ea.ln0_w = W.ln0_w; ea.ln0_b = W.ln0_b; ea.L1T = W.L1T; ea.bL1 = W.bL1; ea.L2T = W.L2T; ea.bL2 = W.bL2;
+      for (int t = 0; t < 3; ++t) {
+        ea.UeT[t] = W.UeT[t];
+        ea.V0T[t] = W.layer[0].VT[t];
+      }
+      ea.u0 = b.u0; ea.xh0 = b.xh0; ea.rstd0 = b.rstd0; ea.a1 = b.a1; ea.a2 = b.a2; ea.gates = b.gates; ea.UX = b.UX; ea.X0 = b.X[0];
+      ea.Pn0 = b.Pn[0];
+      KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + 5 * nodeB, launch_small_embed(ea, s));
+      for (int l = 0; l < L; ++l) {
+        const LayerP& q_ = W.layer[l];
+        const bool last = l + 1 == L;
+        SmallLayerArgs la{};
+        la.g = g; la.N = N; la.F = F; la.H = H; la.o3 = o3; la.want_forces = want_forces ? 1 : 0; la.z = z; la.kap = q;
+        la.w = b.w[l]; la.Pn = b.Pn[l]; la.X = b.X[l]; la.Mi = b.Mi[l]; la.D = b.D[l]; la.Xn = b.X[l + 1];
+        for (int t = 0; t < 3; ++t) {
+          la.VbT[t] = q_.VT[3 + t];
+          la.Vb[t] = q_.V[3 + t];
+          if (!last) la.VnT[t] = W.layer[l + 1].VT[t];
+        }
+        if (!last) la.Pn_next = b.Pn[l + 1];
+        la.lnr_w = W.lnr_w; la.lnr_b = W.lnr_b; la.LinT = W.LinT; la.bLin = W.bLin; la.O1T = W.O1T; la.bO1 = W.bO1; la.O2 = W.O2;
+        la.bO2 = W.bO2; la.atomref = W.atomref; la.Lin = W.Lin; la.O1 = W.O1; la.std_ = W.std;
+        la.xhr = b.xhr; la.rstdr = b.rstdr; la.al = b.al; la.x = b.x; la.ea = b.ea;
+        if (want_forces) { la.G = b.G; la.gMi = b.gMi; la.gPn = b.gPn; }
+        KR(CAT_MESSAGE, wB + idxB + 6 * nodeB, launch_small_layer(la, last, s));
+      }
+      if (!want_forces) KR(CAT_ELEMENTWISE, Nd * 4, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
+    } else {
     if (ntp) {
       // embedding in the radial basis (tn_embed_rb.hip): moments per (atom, species, component), then the per-atom contraction
       KR(CAT_SCATTER, E_ * 12 + Pd * 48 + momB,
@@ -1490,9 +1527,37 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s, want_forces ? b.g_ao : nullptr));
       KR(CAT_ELEMENTWISE, Nd * 4, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
     }
+    }  // !fused_small
   }
 
-  if (want_forces && run_bwd) {
+  if (want_forces && run_bwd && fused_small) {
+    const int gd_nw = message_adjoint_gd_waves(g, N, F);
+    const int64_t gd_stride = 2 * (int64_t)P1;
+    for (int l = L - 1; l >= 0; --l) {
+      const LayerP& q_ = W.layer[l];
+      // the adjoint sweep reads its neighbours' gMi while the same launch writes the layer below's: two buffers in turn
+      float* const gMi_in = ((L - 1 - l) & 1) ? b.gCh : b.gMi;
+      float* const gMi_out = ((L - 1 - l) & 1) ? b.gMi : b.gCh;
+      SmallRevArgs ra{};
+      ra.g = g; ra.N = N; ra.F = F; ra.B = B; ra.o3 = o3; ra.first = l == 0; ra.kap = q;
+      ra.w = b.w[l]; ra.dw = b.dw[l]; ra.gMi_in = gMi_in; ra.Pn = b.Pn[l]; ra.X = b.X[l];
+      ra.gPn = b.gPn; ra.G = b.G; ra.slots = b.gd_slots + (int64_t)l * gd_nw * gd_stride; ra.slot_stride = gd_stride;
+      for (int t = 0; t < 3; ++t) {
+        ra.Va[t] = q_.V[t];
+        ra.Ue[t] = W.Ue[t];
+        if (l > 0) ra.Vb_prev[t] = W.layer[l - 1].V[3 + t];
+      }
+      if (l > 0) { ra.D_prev = b.D[l - 1]; ra.Pn_prev = b.Pn[l - 1]; ra.Mi_prev = b.Mi[l - 1]; ra.gMi_out = gMi_out; }
+      ra.UX = b.UX; ra.gates = b.gates; ra.a2 = b.a2; ra.a1 = b.a1; ra.L2 = W.L2; ra.L1 = W.L1; ra.xh0 = b.xh0; ra.rstd0 = b.rstd0;
+      ra.ln0_w = W.ln0_w; ra.u0 = b.u0; ra.gA = b.gA;
+      if (l == L - 1) { ra.ea = b.ea; ra.batch = batch; ra.mean = W.mean; ra.energy = energy; }
+      KR(CAT_MESSAGE, 2 * wB + idxB + 6 * nodeB + 8 * (Pd + 1) * gd_nw, launch_small_rev(ra, s));
+    }
+    KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
+       launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s, b.g_delta, b.gd_slots, L * gd_nw,
+                            gd_stride));
+    KR(CAT_ELEMENTWISE, E_ * 8 + Nd * 12, launch_force_gather(g, N, b.g_delta, perm, forces, s));
+  } else if (want_forces && run_bwd) {
     NODE();  // g_ao = d energy / d ao came out of the head kernel
     const RowMap rH = rows_plain(H), rF = rows_plain(F), r2F = rows_plain(2 * F), r3F = rows_plain(3 * F), rK = rows_plain(K);
     const RowMap rc_[3] = {rows_comp(F, 1), rows_comp(F, 3), rows_comp(F, 5)};  // (atom, component) rows of I / A / S in [N, 9, F]
