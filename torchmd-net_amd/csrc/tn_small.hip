@@ -40,7 +40,7 @@ struct Blk {
 
 struct SmallLds {
   float part[SM_G * 10 * SM_FMAX];  // partial sums [group][component][channel] (sweeps: 9 or 10 components) / [k-group][output]
-  float xs[9 * SM_FMAX];            // input of a tensor linear [component][channel]
+  float xs[10 * SM_FMAX];           // input of a tensor linear [component][channel]; reduced partial sums
   float va[3 * SM_FMAX], vb[3 * SM_FMAX], vc[3 * SM_FMAX];  // vectors of the MLP chains
 };
 
@@ -53,86 +53,155 @@ __device__ __forceinline__ void st9(float* __restrict__ p, int F, const float u[
   for (int c = 0; c < 9; ++c) p[c * F] = u[c];
 }
 
-// ---- nine-component linear of the vector in xs: every thread its share of the input channels; the sums of the groups meet in part.
-// All 3 KQ weight loads of a thread are requested before the first multiply (they come from L2: the chain was 4 round trips
-// with the loop unrolled by four, 2.4 us per product).
+// ---- nine-component linear: every thread its share KQ = F / 8 of the input channels; the sums of the groups meet in part.
+// Weights come from L2 and a block streams all 3 F^2 of them through its CU's miss path (~4 us per product, in-kernel
+// timestamps): they are REQUESTED early (tlin_issue: 3 KQ registers) - before the sweep, or before group 0's 3x3 algebra - and
+// multiplied once the input vector is in xs (tlin_finish).
 template <int KQ>
-__device__ __forceinline__ void tlin_partial_k(const float* __restrict__ W0, const float* __restrict__ W1, const float* __restrict__ W2,
-                                               const SmallLds& L, float* part, const Blk& b) {
-  const int F = b.F, k0 = b.g * KQ;
+struct TlinW {
   float w0[KQ], w1[KQ], w2[KQ];
+};
+template <int KQ>
+__device__ __forceinline__ void tlin_issue(const float* const W[3], const Blk& b, TlinW<KQ>& t) {
+  const int F = b.F, k0 = b.g * KQ;
 #pragma unroll
   for (int k = 0; k < KQ; ++k) {
-    w0[k] = W0[(k0 + k) * F + b.f];
-    w1[k] = W1[(k0 + k) * F + b.f];
-    w2[k] = W2[(k0 + k) * F + b.f];
+    t.w0[k] = W[0][(k0 + k) * F + b.f];
+    t.w1[k] = W[1][(k0 + k) * F + b.f];
+    t.w2[k] = W[2][(k0 + k) * F + b.f];
   }
+}
+// sum of the groups' partial sums, every thread of the block calls (one barrier inside): group g adds up component g (groups 0
+// and 1 also components 8 and 9) into xs, group 0 then picks up its NC values.  Group 0 alone reading all 8 NC partials kept 72
+// LDS results in registers next to its 3x3 algebra (30 registers spilled at the 128-register limit of a 1024-thread block).
+template <int NC>
+__device__ __forceinline__ void part_reduce(SmallLds& L, const Blk& b, float out[NC]) {
+  const int F = b.F;
+  for (int c = b.g; c < NC; c += SM_G) {
+    float s = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < SM_G; ++gg) s += L.part[(gg * NC + c) * F + b.f];
+    L.xs[c * F + b.f] = s;
+  }
+  __syncthreads();
+  if (b.g == 0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) out[c] = L.xs[c * F + b.f];
+  }
+}
+// xs <- u (group 0), barrier, partial products, barrier, group 0: out = sum.  Leaves xs / part free after the caller's next barrier.
+template <int KQ>
+__device__ __forceinline__ void tlin_finish(const TlinW<KQ>& t, const float u[9], SmallLds& L, const Blk& b, float out[9]) {
+  const int F = b.F, k0 = b.g * KQ;
+  if (b.g == 0) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) L.xs[c * F + b.f] = u[c];
+  }
+  __syncthreads();
   float acc[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) acc[c] = 0.f;
 #pragma unroll
   for (int k = 0; k < KQ; ++k) {
-    acc[0] += w0[k] * L.xs[k0 + k];
-    acc[1] += w1[k] * L.xs[F + k0 + k];
-    acc[2] += w1[k] * L.xs[2 * F + k0 + k];
-    acc[3] += w1[k] * L.xs[3 * F + k0 + k];
-    acc[4] += w2[k] * L.xs[4 * F + k0 + k];
-    acc[5] += w2[k] * L.xs[5 * F + k0 + k];
-    acc[6] += w2[k] * L.xs[6 * F + k0 + k];
-    acc[7] += w2[k] * L.xs[7 * F + k0 + k];
-    acc[8] += w2[k] * L.xs[8 * F + k0 + k];
+    acc[0] += t.w0[k] * L.xs[k0 + k];
+    acc[1] += t.w1[k] * L.xs[F + k0 + k];
+    acc[2] += t.w1[k] * L.xs[2 * F + k0 + k];
+    acc[3] += t.w1[k] * L.xs[3 * F + k0 + k];
+    acc[4] += t.w2[k] * L.xs[4 * F + k0 + k];
+    acc[5] += t.w2[k] * L.xs[5 * F + k0 + k];
+    acc[6] += t.w2[k] * L.xs[6 * F + k0 + k];
+    acc[7] += t.w2[k] * L.xs[7 * F + k0 + k];
+    acc[8] += t.w2[k] * L.xs[8 * F + k0 + k];
   }
 #pragma unroll
-  for (int c = 0; c < 9; ++c) part[(b.g * 9 + c) * F + b.f] = acc[c];
+  for (int c = 0; c < 9; ++c) L.part[(b.g * 9 + c) * F + b.f] = acc[c];
+  __syncthreads();
+  part_reduce<9>(L, b, out);
 }
-__device__ __forceinline__ void tlin_partial(const float* __restrict__ W0, const float* __restrict__ W1, const float* __restrict__ W2,
-                                             const SmallLds& L, float* part, const Blk& b) {
-  if (b.F == 128) tlin_partial_k<128 / SM_G>(W0, W1, W2, L, part, b);
-  else tlin_partial_k<64 / SM_G>(W0, W1, W2, L, part, b);
-}
-template <int NC>
-__device__ __forceinline__ void part_sum(const float* part, const Blk& b, float out[NC]) {  // group 0
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    float s = 0.f;
-#pragma unroll
-    for (int gg = 0; gg < SM_G; ++gg) s += part[(gg * NC + c) * b.F + b.f];
-    out[c] = s;
-  }
-}
-// xs <- u (group 0), barrier, partial products, barrier, group 0: out = sum.  Leaves xs / part free after the caller's next barrier.
-__device__ __forceinline__ void tlin(const float* const W[3], const float u[9], SmallLds& L, const Blk& b, float out[9]) {
+
+// the same with the weights requested only now (after the barrier: the compiler must not move 3 KQ loads into the caller's algebra)
+template <int KQ>
+__device__ __forceinline__ void tlin_now(const float* const W[3], const float u[9], SmallLds& L, const Blk& b, float out[9]) {
+  const int F = b.F, k0 = b.g * KQ;
   if (b.g == 0) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) L.xs[c * b.F + b.f] = u[c];
+    for (int c = 0; c < 9; ++c) L.xs[c * F + b.f] = u[c];
   }
   __syncthreads();
-  tlin_partial(W[0], W[1], W[2], L, L.part, b);
+  TlinW<KQ> t;
+  tlin_issue<KQ>(W, b, t);
+  float acc[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) {
+    acc[0] += t.w0[k] * L.xs[k0 + k];
+    acc[1] += t.w1[k] * L.xs[F + k0 + k];
+    acc[2] += t.w1[k] * L.xs[2 * F + k0 + k];
+    acc[3] += t.w1[k] * L.xs[3 * F + k0 + k];
+    acc[4] += t.w2[k] * L.xs[4 * F + k0 + k];
+    acc[5] += t.w2[k] * L.xs[5 * F + k0 + k];
+    acc[6] += t.w2[k] * L.xs[6 * F + k0 + k];
+    acc[7] += t.w2[k] * L.xs[7 * F + k0 + k];
+    acc[8] += t.w2[k] * L.xs[8 * F + k0 + k];
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) L.part[(b.g * 9 + c) * F + b.f] = acc[c];
   __syncthreads();
-  if (b.g == 0) part_sum<9>(L.part, b, out);
+  part_reduce<9>(L, b, out);
 }
 
 // ---- y[n] = bias[n] + sum_k WT[k, n] x[k]  (x, y in LDS; every thread of the block calls; y is visible on return).  Nout % 4 == 0.
 // A thread owns four consecutive outputs (one 16-byte weight load per input channel) and a slice of the input channels; up to
 // sixteen slices, their sums added in a fixed order.  Eight loads in flight per thread.
 constexpr int SM_MV_KG = 16;
-__device__ __forceinline__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* x, int K, int Nout,
-                                       float* part, float* y, const Blk& b) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct MvW {
+  f4 w[8];
+};
+// the slice of the input channels thread tid multiplies: [k0, k1)
+__device__ __forceinline__ bool mv_slice(int K, int Nout, const Blk& b, int& c4, int& q, int& k0, int& k1) {
   const int n4 = Nout >> 2;
   const int kg = min(b.T / n4, SM_MV_KG);
-  const int q = b.tid / n4, c4 = b.tid - q * n4;
-  if (q < kg) {
-    const int kq = (K + kg - 1) / kg, k0 = q * kq, k1 = min(K, k0 + kq);
+  q = b.tid / n4;
+  c4 = b.tid - q * n4;
+  const int kq = (K + kg - 1) / kg;
+  k0 = q * kq;
+  k1 = min(K, k0 + kq);
+  return q < kg;
+}
+// request the first eight weight rows of the thread's slice ahead of time (while the input vector is still being made)
+__device__ __forceinline__ void mv_issue(const float* __restrict__ WT, int K, int Nout, const Blk& b, MvW& t) {
+  int c4, q, k0, k1;
+  if (!mv_slice(K, Nout, b, c4, q, k0, k1)) return;
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (k0 + u < k1) t.w[u] = *reinterpret_cast<const f4*>(WT + (int64_t)(k0 + u) * Nout + 4 * c4);
+}
+template <bool PRE>
+__device__ __forceinline__ void matvec_(const float* __restrict__ WT, const float* __restrict__ bias, const float* x, int K, int Nout,
+                                        float* part, float* y, const Blk& b, const MvW* pre) {
+  int c4, q, k0, k1;
+  const bool on = mv_slice(K, Nout, b, c4, q, k0, k1);
+  const int kg = min(b.T / (Nout >> 2), SM_MV_KG);
+  if (on) {
     f4 acc = (f4)(0.f);
     int k = k0;
-    for (; k + 8 <= k1; k += 8) {
+    if (PRE) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < k1) acc += pre->w[u] * x[k0 + u];
+      k = min(k1, k0 + 8);
+    }
+#pragma unroll 1
+    for (; k + 8 <= k1; k += 8) {  // one chunk of eight requests at a time (unrolled, the chunks' loads pile up in registers)
       f4 wv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const f4*>(WT + (int64_t)(k + u) * Nout + 4 * c4);
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += wv[u] * x[k + u];
     }
+#pragma unroll 1
     for (; k < k1; ++k) acc += *reinterpret_cast<const f4*>(WT + (int64_t)k * Nout + 4 * c4) * x[k];
     *reinterpret_cast<f4*>(part + q * Nout + 4 * c4) = acc;
   }
@@ -143,6 +212,14 @@ __device__ __forceinline__ void matvec(const float* __restrict__ WT, const float
     y[b.tid] = s;
   }
   __syncthreads();
+}
+__device__ __forceinline__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* x, int K, int Nout,
+                                       float* part, float* y, const Blk& b) {
+  matvec_<false>(WT, bias, x, K, Nout, part, y, b, nullptr);
+}
+__device__ __forceinline__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* x, int K, int Nout,
+                                       float* part, float* y, const Blk& b, const MvW& pre) {
+  matvec_<true>(WT, bias, x, K, Nout, part, y, b, &pre);
 }
 
 // LayerNorm statistics of v[0..R) (LDS), computed by every wave for itself: no barrier
@@ -301,13 +378,17 @@ __device__ __forceinline__ void sweep(const Graph& g, int i, const float* __rest
 }  // namespace
 
 // =====================================================================================================================
-__global__ __launch_bounds__(1024) void k_small_embed(SmallEmbedArgs a) {
+template <int F>
+__global__ __launch_bounds__(SM_G * F) void k_small_embed(SmallEmbedArgs a) {
+  constexpr int KQ = F / SM_G;
   __shared__ SmallLds L;
   const Graph& g = a.g;
   if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
-  const int i = blockIdx.x, F = a.F, F3 = 3 * F;
-  Blk b{F, (int)threadIdx.x / F, (int)threadIdx.x % F, (int)threadIdx.x, (int)blockDim.x};
+  const int i = blockIdx.x, F3 = 3 * F;
+  Blk b{F, (int)threadIdx.x / F, (int)threadIdx.x % F, (int)threadIdx.x, SM_G * F};
   const int f = b.f;
+  MvW mw;
+  mv_issue(a.L1T, F, 2 * F, b, mw);  // the gate MLP's first weights travel while the row is swept
 
   // ---- embedding scatter (k_embed_scatter_split): I0 = sum W0 ; v = sum W1 r ; T = sum W2 r r^T
   {
@@ -339,9 +420,10 @@ __global__ __launch_bounds__(1024) void k_small_embed(SmallEmbedArgs a) {
   }
   __syncthreads();
   float u[9];
+  float s10[10];
+  part_reduce<10>(L, b, s10);
   if (b.g == 0) {
-    float s[10];
-    part_sum<10>(L.part, b, s);
+    const float* s = s10;
     const float tr3 = (s[4] + s[7] + s[9]) * (1.0f / 3.0f);
     u[0] = s[0]; u[1] = s[1]; u[2] = s[2]; u[3] = s[3];
     u[4] = s[4] - tr3; u[5] = s[5]; u[6] = s[6]; u[7] = s[7] - tr3; u[8] = s[8];
@@ -361,7 +443,7 @@ __global__ __launch_bounds__(1024) void k_small_embed(SmallEmbedArgs a) {
     }
   }
   __syncthreads();
-  matvec(a.L1T, a.bL1, L.vb, F, 2 * F, L.part, L.va, b);
+  matvec(a.L1T, a.bL1, L.vb, F, 2 * F, L.part, L.va, b, mw);
   if (b.tid < 2 * F) {
     const float v = L.va[b.tid];
     a.a1[(int64_t)i * 2 * F + b.tid] = v;
@@ -378,7 +460,9 @@ __global__ __launch_bounds__(1024) void k_small_embed(SmallEmbedArgs a) {
   }
   // ---- tensor linear, gates -> X0 (the barrier inside tlin publishes vb as well)
   float ux[9];
-  tlin(a.UeT, u, L, b, ux);
+  TlinW<KQ> tw;
+  tlin_now<KQ>(a.UeT, u, L, b, ux);
+  if (a.L > 0) tlin_issue<KQ>(a.V0T, b, tw);  // requested before group 0 turns to its 3x3 algebra
   float x0[9];
   if (b.g == 0) {
     st9(a.UX + (int64_t)i * 9 * F + f, F, ux);
@@ -395,36 +479,43 @@ __global__ __launch_bounds__(1024) void k_small_embed(SmallEmbedArgs a) {
   }
   __syncthreads();  // part was read by group 0 just now
   float pn[9];
-  tlin(a.V0T, x0, L, b, pn);
+  tlin_finish<KQ>(tw, x0, L, b, pn);
   if (b.g == 0) st9(a.Pn0 + (int64_t)i * 9 * F + f, F, pn);
 }
 
 // =====================================================================================================================
-template <int LAST>
-__global__ __launch_bounds__(1024) void k_small_layer(SmallLayerArgs a) {
+template <int F, int LAST>
+__global__ __launch_bounds__(SM_G * F) void k_small_layer(SmallLayerArgs a) {
+  constexpr int KQ = F / SM_G;
   __shared__ SmallLds L;
   const Graph& g = a.g;
   if (g.counts[2]) return;
-  const int i = blockIdx.x, F = a.F;
-  Blk b{F, (int)threadIdx.x / F, (int)threadIdx.x % F, (int)threadIdx.x, (int)blockDim.x};
+  const int i = blockIdx.x;
+  Blk b{F, (int)threadIdx.x / F, (int)threadIdx.x % F, (int)threadIdx.x, SM_G * F};
   const int f = b.f;
   const int64_t row9 = (int64_t)i * 9 * F + f;
   const float kap = a.kap ? a.kap[i] : 1.0f;
   const float none[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  TlinW<KQ> tw;
+  if (!LAST) tlin_issue<KQ>(a.VbT, b, tw);  // the second linear's weights travel while the row is swept (last layer: the kernel is
+                                            // at its register limit with the readout chain; requested where they are used)
 
   sweep<0>(g, i, a.w, nullptr, a.Pn, none, nullptr, 0, L.part, b);
   __syncthreads();
   float ch[9];
+  float m[9];
+  part_reduce<9>(L, b, m);
   if (b.g == 0) {
-    float y[9], m[9];
-    part_sum<9>(L.part, b, m);
+    float y[9];
     st9(a.Mi + row9, F, m);
     ld9(a.Pn + row9, F, y);
     group_product(y, m, a.o3, kap, ch);
   }
   __syncthreads();
   float d[9];
-  tlin(a.VbT, ch, L, b, d);
+  if (LAST) tlin_now<KQ>(a.VbT, ch, L, b, d);
+  else tlin_finish<KQ>(tw, ch, L, b, d);
+  if (!LAST) tlin_issue<KQ>(a.VnT, b, tw);
   float xn[9];
   if (b.g == 0) {
     st9(a.D + row9, F, d);
@@ -447,7 +538,7 @@ __global__ __launch_bounds__(1024) void k_small_layer(SmallLayerArgs a) {
     }
     __syncthreads();
     float pn[9];
-    tlin(a.VnT, xh, L, b, pn);
+    tlin_finish<KQ>(tw, xh, L, b, pn);
     if (b.g == 0) st9(a.Pn_next + row9, F, pn);
     return;
   }
@@ -514,7 +605,7 @@ __global__ __launch_bounds__(1024) void k_small_layer(SmallLayerArgs a) {
     }
     __syncthreads();
     float gch[9];
-    tlin(a.Vb, gD, L, b, gch);
+    tlin_now<KQ>(a.Vb, gD, L, b, gch);
     if (b.g == 0) {
       float y[9], m[9], gm[9], gy[9];  // reloaded (this thread stored m above): keeping them live across the readout spilled
       ld9(a.Pn + row9, F, y);
@@ -527,12 +618,14 @@ __global__ __launch_bounds__(1024) void k_small_layer(SmallLayerArgs a) {
 }
 
 // =====================================================================================================================
-__global__ __launch_bounds__(1024) void k_small_rev(SmallRevArgs a) {
+template <int F>
+__global__ __launch_bounds__(SM_G * F) void k_small_rev(SmallRevArgs a) {
+  constexpr int KQ = F / SM_G;
   __shared__ SmallLds L;
   const Graph& g = a.g;
   if (g.counts[2]) return;
-  const int i = blockIdx.x, F = a.F;
-  Blk b{F, (int)threadIdx.x / F, (int)threadIdx.x % F, (int)threadIdx.x, (int)blockDim.x};
+  const int i = blockIdx.x;
+  Blk b{F, (int)threadIdx.x / F, (int)threadIdx.x % F, (int)threadIdx.x, SM_G * F};
   const int f = b.f;
   const int64_t row9 = (int64_t)i * 9 * F + f;
   const float kap = a.kap ? a.kap[i] : 1.0f;
@@ -555,16 +648,16 @@ __global__ __launch_bounds__(1024) void k_small_rev(SmallRevArgs a) {
   sweep<2>(g, i, a.w, a.dw, a.gMi_in, y, a.slots, a.slot_stride, L.part, b);
   __syncthreads();
   float gp[9];
+  float s[9];
+  part_reduce<9>(L, b, s);
   if (b.g == 0) {
-    float s[9];
-    part_sum<9>(L.part, b, s);
     ld9(a.gPn + row9, F, gp);
 #pragma unroll
     for (int c = 0; c < 9; ++c) gp[c] += s[c];
   }
   __syncthreads();
   float gxl[9];
-  tlin(a.Va, gp, L, b, gxl);
+  tlin_now<KQ>(a.Va, gp, L, b, gxl);
   // normalisation adjoint with the residual stream's G (k_norm_bwd)
   float gx[9];
   if (b.g == 0) {
@@ -593,7 +686,7 @@ __global__ __launch_bounds__(1024) void k_small_rev(SmallRevArgs a) {
     }
     __syncthreads();
     float gch[9];
-    tlin(a.Vb_prev, gD, L, b, gch);
+    tlin_now<KQ>(a.Vb_prev, gD, L, b, gch);
     if (b.g == 0) {
       float yp[9], mp[9], gm[9], gy[9];
       ld9(a.Pn_prev + row9, F, yp);
@@ -631,7 +724,7 @@ __global__ __launch_bounds__(1024) void k_small_rev(SmallRevArgs a) {
   if (b.g == 0) gs0 = (L.va[f] * a.ln0_w[f] - s1 - a.xh0[(int64_t)i * F + f] * s2) * a.rstd0[i];
   __syncthreads();
   float gl[9];
-  tlin(a.Ue, gux, L, b, gl);
+  tlin_now<KQ>(a.Ue, gux, L, b, gl);
   if (b.g == 0) {
     float u[9], dq[9];
     ld9(a.u0 + row9, F, u);
@@ -662,14 +755,21 @@ bool small_fused_ok(int N, int F, int H, int L) {
   return N > 0 && N <= max_atoms && L >= 1 && (F == 64 || F == 128) && H >= 4 && H % 4 == 0 && H <= 3 * F;
 }
 void launch_small_embed(const SmallEmbedArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_small_embed, dim3(a.N), dim3(SM_G * a.F), 0, s, a);
+  if (a.F == 128) hipLaunchKernelGGL((k_small_embed<128>), dim3(a.N), dim3(SM_G * 128), 0, s, a);
+  else hipLaunchKernelGGL((k_small_embed<64>), dim3(a.N), dim3(SM_G * 64), 0, s, a);
 }
 void launch_small_layer(const SmallLayerArgs& a, bool last, hipStream_t s) {
-  if (last) hipLaunchKernelGGL((k_small_layer<1>), dim3(a.N), dim3(SM_G * a.F), 0, s, a);
-  else hipLaunchKernelGGL((k_small_layer<0>), dim3(a.N), dim3(SM_G * a.F), 0, s, a);
+  if (a.F == 128) {
+    if (last) hipLaunchKernelGGL((k_small_layer<128, 1>), dim3(a.N), dim3(SM_G * 128), 0, s, a);
+    else hipLaunchKernelGGL((k_small_layer<128, 0>), dim3(a.N), dim3(SM_G * 128), 0, s, a);
+  } else {
+    if (last) hipLaunchKernelGGL((k_small_layer<64, 1>), dim3(a.N), dim3(SM_G * 64), 0, s, a);
+    else hipLaunchKernelGGL((k_small_layer<64, 0>), dim3(a.N), dim3(SM_G * 64), 0, s, a);
+  }
 }
 void launch_small_rev(const SmallRevArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_small_rev, dim3(a.N), dim3(SM_G * a.F), 0, s, a);
+  if (a.F == 128) hipLaunchKernelGGL((k_small_rev<128>), dim3(a.N), dim3(SM_G * 128), 0, s, a);
+  else hipLaunchKernelGGL((k_small_rev<64>), dim3(a.N), dim3(SM_G * 64), 0, s, a);
 }
 
 }  // namespace tn
