@@ -99,7 +99,7 @@ const char* tmdnet_version(void);
 /* ABI revision of this header: bumped whenever an exported signature or struct layout changes (3: `z` in
  * tmdnet_build_graph[_static], `strategy` in tmdnet_neighbor_pairs).  A binding compares its compile-time
  * TMDNET_ABI_VERSION with the loaded library's tmdnet_abi_version() before its first call. */
-#define TMDNET_ABI_VERSION 4
+#define TMDNET_ABI_VERSION 5
 int tmdnet_abi_version(void);
 
 /* Parameters are addressed by the reference's state-dict keys without the "model." prefix
@@ -166,6 +166,15 @@ int tmdnet_graph_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t
  * Any grid gives the same pair set as brute force (axes with fewer than 3 cells visit each cell once); atoms are
  * renumbered in cell order internally and forces are returned in the caller's order. */
 int tmdnet_set_cell_grid(tmdnet_model* m, int32_t ncx, int32_t ncy, int32_t ncz);
+
+/* Per-atom weights of the energy sum (ABI 5): E_mol = sum_i w_i e_i + mean, and the forces are minus the gradient of THAT sum.
+ * `weights_dev` is a device vector of n_atoms floats in the caller's atom order (read by every later tmdnet_energy_forces on this
+ * handle until it is reset with NULL; it must stay valid for as long as a captured HIP graph replays the call).  This is what a
+ * domain decomposition of one large system needs (parallel.SpatialEvaluator): a rank evaluates its owned atoms (w = 1) inside a
+ * halo of ghost copies (w = 0), and the ranks' forces add up to the whole system's.  The reference has no such argument: its
+ * multi-GPU story stops at data parallelism over molecules.  TensorNet only (ET / TensorNet2 and the
+ * parameter-gradient pass refuse a handle with weights set). */
+int tmdnet_set_atom_weights(tmdnet_model* m, const float* weights_dev);
 int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms, int64_t n_mol,
                        const float* pos, const int64_t* batch, const int64_t* z, const float* box, int32_t box_mode,
                        int64_t counts_host[8]);

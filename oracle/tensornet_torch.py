@@ -229,7 +229,9 @@ def tensornet_representation(sd: Dict[str, Tensor], hp: dict, z: Tensor, pos: Te
 # TorchMD_Net.forward with the Scalar head: torchmdnet/models/model.py:530-631,
 # output_modules.py:43-117, models/utils.py:552-580, priors/atomref.py:93-96
 # ----------------------------------------------------------------------------------------------
-def energy(sd, hp, z, pos, batch, box=None, q=None, num_systems=None, atomref=None):
+def energy(sd, hp, z, pos, batch, box=None, q=None, num_systems=None, atomref=None, atom_weights=None):
+    """``atom_weights`` is NOT a reference argument: it restates include/tmdnet_amd.h's tmdnet_set_atom_weights (E = sum_i w_i e_i)
+    so that the domain-decomposition tests have a checker for the weighted sum."""
     x = tensornet_representation(sd, hp, z, pos, batch, box, q)
     O = "output_model.output_network.layers."
     h = Fn.silu(lin(x, sd, O + "0"))
@@ -241,15 +243,17 @@ def energy(sd, hp, z, pos, batch, box=None, q=None, num_systems=None, atomref=No
     e = e * sd.get("std", torch.ones((), dtype=e.dtype))  # model.py:594-595
     if atomref is not None:  # priors/atomref.py:93-96
         e = e + atomref[z]
+    if atom_weights is not None:
+        e = e * atom_weights.to(e.dtype).reshape(-1, 1)
     nmol = int(batch.max()) + 1 if num_systems is None else num_systems
     y = torch.zeros(nmol, 1, dtype=e.dtype).index_add(0, batch, e)  # output_modules.py:43-73
     return y + sd.get("mean", torch.zeros((), dtype=e.dtype))  # model.py:606-607
 
 
-def energy_and_forces(sd, hp, z, pos, batch, box=None, q=None, num_systems=None, atomref=None):
+def energy_and_forces(sd, hp, z, pos, batch, box=None, q=None, num_systems=None, atomref=None, atom_weights=None):
     """model.py:584-628: y, -dy with dy = grad(sum y, pos)."""
     pos = pos.detach().clone().requires_grad_(True)
-    y = energy(sd, hp, z, pos, batch, box, q, num_systems, atomref)
+    y = energy(sd, hp, z, pos, batch, box, q, num_systems, atomref, atom_weights)
     (dy,) = torch.autograd.grad([y], [pos], grad_outputs=[torch.ones_like(y)])
     return y.detach(), -dy
 

@@ -89,3 +89,82 @@ def test_sharded_evaluator_gloo_world2(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert open(tmp_path / f"ok{r}").read() == "1"
+
+
+def _periodic_system(n, lengths, seed):
+    g = torch.Generator().manual_seed(seed)
+    pos = torch.rand(n, 3, generator=g) * torch.tensor(lengths)
+    z = torch.randint(1, 9, (n,), generator=g)
+    return z, pos, torch.diag(torch.tensor(lengths))
+
+
+def _spatial_setup():
+    from oracle import tensornet_torch as T
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.TINY_ARGS, num_layers=1, cutoff_upper=2.5, embedding_dimension=16, num_rbf=8)
+    torch.manual_seed(3)
+    model = create_model(dict(args))
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    sd["mean"] = torch.tensor(0.75)  # every rank's sum contains the per-molecule offset once: the evaluator must not add it twice
+    hp = T.hparams_from_args(args)
+
+    def compute(zl, pl, boxl, wl):
+        return T.energy_and_forces(sd, hp, zl, pl, torch.zeros_like(zl), box=boxl, atom_weights=wl)
+
+    return T, sd, hp, compute, args
+
+
+def test_spatial_decomposition_single_process_equals_the_whole_system():
+    """Slab decomposition with deep halo (parallel.SpatialEvaluator), the ranks evaluated one after the other: the sum of the ranks'
+    energies and forces is the undecomposed periodic system's, for slabs wider and narrower than the halo (self images)."""
+    from torchmdnet_amd.parallel import SpatialEvaluator
+
+    T, sd, hp, compute, args = _spatial_setup()
+    for lengths, n in (([17.0, 6.0, 5.5], 70), ([9.0, 5.5, 6.5], 45)):
+        z, pos, box = _periodic_system(n, lengths, seed=len(lengths) + n)
+        Er, Fr = T.energy_and_forces(sd, hp, z, pos, torch.zeros_like(z), box=box)
+        for world in (2, 3):
+            ev = SpatialEvaluator(compute, args["cutoff_upper"], args["num_layers"], energy_offset=0.75)
+            E, F, n_local = torch.zeros(1), torch.zeros(n, 3), 0
+            for r in range(world):
+                e, f = ev.contribution(z, pos, box, r, world)
+                E, F = E + e, F + f
+                n_local += ev.local_system(pos, box, r, world)[0].numel()
+            E = E + 0.75
+            assert n_local > n  # there is a halo
+            assert abs(float(E) - float(Er)) < 1e-5 * max(1.0, abs(float(Er))), (lengths, world)
+            assert (F - Fr).abs().max().item() < 1e-5 * max(1.0, Fr.abs().max().item()), (lengths, world)
+
+
+def _spatial_worker(rank, world, port, tmpdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "torchmd-net_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from torchmdnet_amd.parallel import SpatialEvaluator
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, sd, hp, compute, args = _spatial_setup()
+    z, pos, box = _periodic_system(64, [16.0, 6.0, 5.5], seed=9)
+    ev = SpatialEvaluator(compute, args["cutoff_upper"], args["num_layers"], energy_offset=0.75)
+    E, F = ev.evaluate(z, pos, box)
+    Er, Fr = T.energy_and_forces(sd, hp, z, pos, torch.zeros_like(z), box=box)
+    ok = abs(float(E) - float(Er)) < 1e-5 * max(1.0, abs(float(Er))) and (F - Fr).abs().max().item() < 1e-5 * max(1.0, Fr.abs().max().item())
+    ok = ok and 0 < ev.local_system(pos, box, rank, world)[3] < 64  # this rank owns a proper part of the atoms
+    with open(os.path.join(tmpdir, f"sp{rank}"), "w") as fh:
+        fh.write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_spatial_decomposition_gloo_world2(tmp_path):
+    """One periodic system, two processes, one all-reduce of forces + energy (the N > 1 path of parallel.SpatialEvaluator)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_spatial_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"sp{r}").read() == "1"

@@ -1242,6 +1242,12 @@ int tmdnet_graph_counts(tmdnet_model* m, void* stream, void* graph_ws, int64_t n
   return counts[2] ? TMDNET_ERR_OVERFLOW : TMDNET_OK;
 }
 
+int tmdnet_set_atom_weights(tmdnet_model* m, const float* weights_dev) {
+  if (!m) return TMDNET_ERR_INVALID;
+  m->atom_w = weights_dev;
+  return TMDNET_OK;
+}
+
 int tmdnet_graph_cell_grid(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t grid_host[4]) {
   if (!m || !graph_ws || !grid_host) return TMDNET_ERR_INVALID;
   recall_graph(m, graph_ws);
@@ -1291,6 +1297,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   if (!m->train && (n_pairs >= 0 ? n_pairs : g.pcap) + 1 >= m->tab_min_pairs)
     if (const int rc_tab = ensure_radial_tables(m, s)) return rc_tab;
   if (m->graph_is_cell && m->graph_cell_multi) batch = g.bat_c;  // several molecules renumbered in cell order: their internal batch
+  if (m->atom_w && (m->et || m->tn2 || m->train))
+    return fail(m, TMDNET_ERR_INVALID, "atom weights (tmdnet_set_atom_weights) are implemented for TensorNet inference only");
   if (m->et) {
     if (q) return fail(m, TMDNET_ERR_INVALID, "the Equivariant Transformer takes no total charge (reference torchmd_et.py:188-196)");
     CurScope cur_(m);
@@ -1447,7 +1455,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         const LayerP& q_ = W.layer[l];
         const bool last = l + 1 == L;
         SmallLayerArgs la{};
-        la.g = g; la.N = N; la.F = F; la.H = H; la.o3 = o3; la.want_forces = want_forces ? 1 : 0; la.z = z; la.kap = q;
+        la.g = g; la.N = N; la.F = F; la.H = H; la.o3 = o3; la.want_forces = want_forces ? 1 : 0; la.z = z; la.kap = q; la.atom_w = m->atom_w; la.perm = perm;
         la.w = b.w[l]; la.Pn = b.Pn[l]; la.X = b.X[l]; la.Mi = b.Mi[l]; la.D = b.D[l]; la.Xn = b.X[l + 1];
         for (int t = 0; t < 3; ++t) {
           la.VbT[t] = q_.VT[3 + t];
@@ -1522,9 +1530,10 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     gemm(s, b.x, F, W.O1, F, W.bO1, b.ao, H, N, H, F);
     if ((int64_t)N <= 256 * (int64_t)B) {  // small molecules: head + per-molecule sum in one launch (a block walks its molecule)
       KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_mol_sum(g, b.ao, W.O2, W.bO2, N, B, H, W.std, W.atomref, z, batch, W.mean, energy, s,
-                                                          want_forces ? b.g_ao : nullptr));
+                                                          want_forces ? b.g_ao : nullptr, m->atom_w, perm));
     } else {
-      KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s, want_forces ? b.g_ao : nullptr));
+      KR(CAT_ELEMENTWISE, Nd * H * 4,
+         launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s, want_forces ? b.g_ao : nullptr, m->atom_w, perm));
       KR(CAT_ELEMENTWISE, Nd * 4, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
     }
     }  // !fused_small

@@ -97,7 +97,8 @@ void launch_layer_update(const float* Xh, const float* D, const float* q, const 
 // ---- readout (reference tensornet.py:384-398, output_modules.py:43-117, model.py:591-607)
 void launch_readout_feat(const float* X, int N, int F, float* feat, hipStream_t s);
 void launch_head_energy(const float* ao, const float* O2, const float* bO2, int N, int H, float std, const float* atomref,
-                        const int64_t* z, float* ea, hipStream_t s, float* g_ao = nullptr);  // g_ao: also d e / d ao (launch_head_bwd)
+                        const int64_t* z, float* ea, hipStream_t s, float* g_ao = nullptr,  // g_ao: also d e / d ao (launch_head_bwd)
+                        const float* atom_w = nullptr, const int* perm = nullptr);  // weights of the energy sum, caller's order
 void launch_mol_sum(const Graph& g, const float* ea, const int64_t* batch, int N, int B, float mean, float* energy, hipStream_t s);
 
 // ---- reverse pass
@@ -117,7 +118,7 @@ void launch_lnbwd_readout_bwd(const float* g, const float* xhat, const float* rs
                               float* G, hipStream_t s);
 void launch_head_mol_sum(const Graph& g, const float* ao, const float* O2, const float* bO2, int N, int B, int H, float std,
                          const float* atomref, const int64_t* z, const int64_t* batch, float mean, float* energy, hipStream_t s,
-                         float* g_ao = nullptr);
+                         float* g_ao = nullptr, const float* atom_w = nullptr, const int* perm = nullptr);
 void launch_embed_gate_bwd(const float* G, const float* UX, const float* gates, const float* a2, int N, int F, float* gUX, float* g_a2,
                            hipStream_t s);
 void launch_embed_bwd_atom(const float* g_u0_lin, const float* u0, const float* g_s0n, int N, int F, float* gA, hipStream_t s);

@@ -997,27 +997,29 @@ void launch_readout_feat(const float* X, int N, int F, float* feat, hipStream_t 
 __global__ __launch_bounds__(256) void k_head_energy(const float* __restrict__ ao, const float* __restrict__ O2,
                                                      const float* __restrict__ bO2, int N, int H, float std,
                                                      const float* __restrict__ atomref, const int64_t* __restrict__ z,
-                                                     float* __restrict__ ea, float* __restrict__ g_ao) {
+                                                     float* __restrict__ ea, float* __restrict__ g_ao,
+                                                     const float* __restrict__ aw, const int* __restrict__ perm) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
+  const float wgt = aw ? aw[perm ? perm[n] : n] : 1.0f;  // weight of this atom in the energy sum (tmdnet_set_atom_weights)
   float s = 0.f;
   for (int k = lane; k < H; k += 64) {
     const float a = ao[(int64_t)n * H + k], o = O2[k];
     s += silu(a) * o;
-    if (g_ao) g_ao[(int64_t)n * H + k] = std * o * silu_grad(a);  // d energy / d ao (k_head_bwd), while the row is in registers
+    if (g_ao) g_ao[(int64_t)n * H + k] = wgt * std * o * silu_grad(a);  // d energy / d ao (k_head_bwd), while the row is in registers
   }
   s = wave_sum(s);
   if (lane == 0) {
     float e = (s + bO2[0]) * std;
     if (atomref) e += atomref[z[n]];
-    ea[n] = e;
+    ea[n] = wgt * e;
   }
 }
 void launch_head_energy(const float* ao, const float* O2, const float* bO2, int N, int H, float std, const float* atomref,
-                        const int64_t* z, float* ea, hipStream_t s, float* g_ao) {
+                        const int64_t* z, float* ea, hipStream_t s, float* g_ao, const float* aw, const int* perm) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(k_head_energy, dim3(cdiv(N, 4)), dim3(256), 0, s, ao, O2, bO2, N, H, std, atomref, z, ea, g_ao);
+  hipLaunchKernelGGL(k_head_energy, dim3(cdiv(N, 4)), dim3(256), 0, s, ao, O2, bO2, N, H, std, atomref, z, ea, g_ao, aw, perm);
 }
 
 // per-molecule sum (reference output_modules.py:43-73): one block per molecule, fixed order (deterministic).
@@ -1050,7 +1052,8 @@ __global__ __launch_bounds__(1024) void k_head_mol_sum(Graph g, const float* __r
                                                       const float* __restrict__ bO2, int N, int H, float std,
                                                       const float* __restrict__ atomref, const int64_t* __restrict__ z,
                                                       const int64_t* __restrict__ batch, float mean, float* __restrict__ energy,
-                                                      float* __restrict__ g_ao) {
+                                                      float* __restrict__ g_ao, const float* __restrict__ aw,
+                                                      const int* __restrict__ perm) {
   __shared__ float part[16];
   const int m = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool sorted = !g.counts[3];
@@ -1058,16 +1061,17 @@ __global__ __launch_bounds__(1024) void k_head_mol_sum(Graph g, const float* __r
   float acc = 0.f;  // lane 0 of each wave: sum over its atoms, fixed order
   for (int n = i0 + wave; n < i1; n += 16) {
     if (!sorted && batch[n] != m) continue;
+    const float wgt = aw ? aw[perm ? perm[n] : n] : 1.0f;
     float s = 0.f;
     for (int k = lane; k < H; k += 64) {
       const float a = ao[(int64_t)n * H + k], o = O2[k];
       s += silu(a) * o;
-      if (g_ao) g_ao[(int64_t)n * H + k] = std * o * silu_grad(a);
+      if (g_ao) g_ao[(int64_t)n * H + k] = wgt * std * o * silu_grad(a);
     }
     s = wave_sum(s);
     float e = (s + bO2[0]) * std;
     if (atomref) e += atomref[z[n]];
-    acc += e;
+    acc += wgt * e;
   }
   if (lane == 0) part[wave] = acc;
   __syncthreads();
@@ -1079,9 +1083,10 @@ __global__ __launch_bounds__(1024) void k_head_mol_sum(Graph g, const float* __r
 }
 void launch_head_mol_sum(const Graph& g, const float* ao, const float* O2, const float* bO2, int N, int B, int H, float std,
                          const float* atomref, const int64_t* z, const int64_t* batch, float mean, float* energy, hipStream_t s,
-                         float* g_ao) {
+                         float* g_ao, const float* aw, const int* perm) {
   if (B <= 0) return;
-  hipLaunchKernelGGL(k_head_mol_sum, dim3(B), dim3(1024), 0, s, g, ao, O2, bO2, N, H, std, atomref, z, batch, mean, energy, g_ao);
+  hipLaunchKernelGGL(k_head_mol_sum, dim3(B), dim3(1024), 0, s, g, ao, O2, bO2, N, H, std, atomref, z, batch, mean, energy, g_ao, aw,
+                     perm);
 }
 
 // LayerNorm adjoint of the readout row [3F] followed by the adjoint of the invariants (k_readout_bwd): with F % 64 == 0 the

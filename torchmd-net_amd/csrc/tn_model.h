@@ -151,6 +151,7 @@ struct TrainCtx {
 };
 
 struct tmdnet_model {
+  const float* atom_w = nullptr;  // per-atom weights of the energy sum (tmdnet_set_atom_weights), caller's atom order
   tmdnet_hparams hp;
   TrainCtx* train = nullptr;  // non-null while tmdnet_energy_param_grads drives tmdnet_energy_forces
   std::vector<std::pair<std::string, int64_t>> train_entries;  // gradient buffer layout (name, numel), built on first use

@@ -31,6 +31,8 @@ struct SmallLayerArgs {  // message sweep -> group product -> linear -> update (
   int N, F, H, o3, want_forces;
   const int64_t* z;
   const float* kap;  // per-atom charge factor or null
+  const float* atom_w;  // weights of the energy sum or null
+  const int* perm;  // internal -> caller's atom index (cell order) or null
   const float *w, *Pn, *X;
   float *Mi, *D, *Xn;
   const float* VbT[3];  // this layer's second linear, transposed

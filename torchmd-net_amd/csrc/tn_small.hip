@@ -570,6 +570,7 @@ __global__ __launch_bounds__(SM_G * F) void k_small_layer(SmallLayerArgs a) {
     }
     __syncthreads();
     matvec(a.O1T, a.bO1, L.va, F, a.H, L.part, L.vb, b);  // vb[0..H) = ao
+    const float wgt = a.atom_w ? a.atom_w[a.perm ? a.perm[i] : i] : 1.0f;  // weight of this atom in the energy sum
     if (b.tid < 64) {
       float s = 0.f;
       for (int k = b.tid; k < a.H; k += 64) s += silu(L.vb[k]) * a.O2[k];
@@ -577,13 +578,13 @@ __global__ __launch_bounds__(SM_G * F) void k_small_layer(SmallLayerArgs a) {
       if (b.tid == 0) {
         float e = (s + a.bO2[0]) * a.std_;
         if (a.atomref) e += a.atomref[a.z[i]];
-        a.ea[i] = e;
+        a.ea[i] = wgt * e;
       }
     }
     if (!a.want_forces) return;
     // ---- reverse: head, MLP, LayerNorm, invariants -> G = d E / d X[L]
     __syncthreads();
-    if (b.tid < a.H) L.va[b.tid] = a.std_ * a.O2[b.tid] * silu_grad(L.vb[b.tid]);  // g_ao
+    if (b.tid < a.H) L.va[b.tid] = wgt * a.std_ * a.O2[b.tid] * silu_grad(L.vb[b.tid]);  // g_ao
     __syncthreads();
     matvec(a.O1, nullptr, L.va, a.H, F, L.part, L.vb, b);  // vb[0..F) = g_ao O1
     if (b.tid < F) L.vb[b.tid] *= silu_grad(L.vc[b.tid]);  // g_al

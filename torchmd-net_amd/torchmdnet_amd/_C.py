@@ -76,6 +76,7 @@ def lib():
     L.tmdnet_graph_workspace_bytes.argtypes = [vp, i64, i64, C.POINTER(sz)]
     L.tmdnet_build_graph.argtypes = [vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, i32, C.POINTER(i64)]
     L.tmdnet_set_cell_grid.argtypes = [vp, i32, i32, i32]
+    L.tmdnet_set_atom_weights.argtypes = [vp, vp]
     L.tmdnet_build_graph_static.argtypes = [vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, i32]
     L.tmdnet_graph_counts.argtypes = [vp, vp, vp, i64, i64, C.POINTER(i64)]
     L.tmdnet_graph_cell_grid.argtypes = [vp, vp, vp, i64, i64, C.POINTER(i64)]

@@ -885,8 +885,10 @@ class TorchMD_Net(nn.Module):
         if t.dtype not in dtypes:
             raise TypeError(f"torchmdnet_amd: `{name}` must have dtype {' or '.join(str(d) for d in dtypes)}, got {t.dtype}")
 
-    def energy_and_forces(self, z, pos, batch, box, q, n_mol, want_forces=True) -> Tuple[Tensor, Optional[Tensor]]:
-        """Raw engine call: returns (E [n_mol], F [N,3] or None), both fp32 on ``pos.device``."""
+    def energy_and_forces(self, z, pos, batch, box, q, n_mol, want_forces=True, atom_weights=None) -> Tuple[Tensor, Optional[Tensor]]:
+        """Raw engine call: returns (E [n_mol], F [N,3] or None), both fp32 on ``pos.device``.  ``atom_weights`` ([N] fp32, this
+        framework's extension for domain decomposition, parallel.SpatialEvaluator): E_mol = sum_i w_i e_i + mean and F = -dE/dpos
+        of that sum (TensorNet only)."""
         _require_cuda(pos, "TorchMD_Net.forward")
         L = _C.lib()
         dev = pos.device
@@ -946,8 +948,16 @@ class TorchMD_Net(nn.Module):
             energy = torch.empty(n_mol, dtype=torch.float32, device=dev)
             forces = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_forces else None
             st.ws_epoch = getattr(st, "ws_epoch", 0) + 1  # the workspaces of a pending parameter-gradient pass are gone
+            if atom_weights is not None:
+                atom_weights = atom_weights.detach().to(device=dev, dtype=torch.float32).contiguous()
+                if atom_weights.numel() != n:
+                    raise ValueError(f"atom_weights must have one entry per atom ({n}), got {atom_weights.numel()}")
+            L.tmdnet_set_atom_weights(st.handle, _ptr(atom_weights))
+            st.atom_weights = atom_weights  # a captured graph replays the call: the vector has to outlive it
             rc = L.tmdnet_energy_forces(st.handle, stream, _ptr(st.graph_ws), _ptr(st.fwd_ws), st.fwd_ws.numel(), n, n_mol,
                                         n_pairs, _ptr(z), _ptr(batch), _ptr(q), int(want_forces), _ptr(energy), _ptr(forces))
+            if atom_weights is not None:
+                L.tmdnet_set_atom_weights(st.handle, None)
             if rc != _C.OK:
                 raise RuntimeError(f"tmdnet_energy_forces: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
             if static and self.static_check and not torch.cuda.is_current_stream_capturing():

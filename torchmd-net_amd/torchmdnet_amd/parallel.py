@@ -165,3 +165,85 @@ class ShardSession:
         if dist.is_initialized():  # also at world size 1: the collective path is the same code on every node size
             dist.all_reduce(self.energy, op=dist.ReduceOp.SUM, group=self.ev.group)
         return self.energy, self.f_loc, (self.a_lo, self.a_hi)
+
+
+class SpatialEvaluator:
+    """ONE large periodic system over the ranks (last paragraph; the reference has no counterpart: a
+    system must fit one GPU there).  First executable step of the spatial decomposition: slabs along one axis of an
+    orthorhombic box, DEEP halo, no exchange inside the step.
+
+    The energy of an atom depends on the positions within (num_layers + 1) * cutoff_upper of it: one cutoff for the
+    embedding's neighbour sum and one per interaction layer (reference tensornet.py:543-619, 757-806).  A rank therefore takes
+    the atoms of its slab (weight 1 in the energy sum) plus every periodic image within that distance of the slab as ghost copies
+    (weight 0), evaluates this local system as an ordinary periodic system - the local box is the slab + both halos + more than
+    one cutoff of vacuum along the slab axis, so the images of the local box do not see each other; the other two axes keep the
+    box's own periodicity - and gets E_r = sum of its owned atoms' energies and -dE_r/d(pos) on owned atoms AND ghosts
+    (``tmdnet_set_atom_weights``).  The forces of the whole system are the sum over ranks and copies, so the only collective is
+    ONE all-reduce of [3N + 1] floats per step (forces + energy); positions are replicated like every other input.  The price
+    is the redundant evaluation of the halo: it pays when the slab is wide against 2 (L + 1) rc (30 Angstrom for the C2
+    model); the per-layer halo exchange that removes the redundancy is the next step.
+
+    ``compute(z_l, pos_l, box_l, w_l) -> (E [1], F_l [n_l, 3])`` is injected (the engine on a GPU, the oracle in the CPU tests);
+    ``energy_offset`` is the model's per-molecule ``mean``, which every rank's E contains once."""
+
+    def __init__(self, compute: Callable, cutoff_upper: float, num_layers: int, group: Optional[dist.ProcessGroup] = None,
+                 axis: Optional[int] = None, energy_offset: float = 0.0):
+        self.compute, self.group, self.axis = compute, group, axis
+        self.cutoff = float(cutoff_upper)
+        self.halo = (int(num_layers) + 1) * float(cutoff_upper)
+        self.energy_offset = float(energy_offset)
+
+    def local_system(self, pos: torch.Tensor, box: torch.Tensor, rank: int, world: int):
+        """-> (gidx [n_l] global index of every local atom, owned atoms first; pos_l [n_l, 3]; box_l [3, 3]; n_owned)."""
+        if box.dim() != 2 or bool((box - torch.diag(torch.diagonal(box))).abs().max() > 0):
+            raise ValueError("SpatialEvaluator: one orthorhombic box [3, 3] (diagonal) for the whole system")
+        lengths = torch.diagonal(box)
+        a = int(torch.argmax(lengths)) if self.axis is None else int(self.axis)
+        La = float(lengths[a])
+        if world == 1:
+            return torch.arange(pos.shape[0], device=pos.device), pos, box, pos.shape[0]
+        h, w = self.halo, La / world
+        if h > La:
+            raise ValueError(f"halo {h:g} exceeds the box length {La:g} along the slab axis: more than one image per atom")
+        x0 = rank * w
+        x = torch.remainder(pos[:, a], La)
+        s = torch.clamp(torch.floor(x / w).long(), max=world - 1)  # slab of every atom (x == La rounds into the last one)
+        owned = s == rank
+        dlo = torch.remainder(x0 - x, La)          # distance below the slab's lower face (periodic)
+        dhi = torch.remainder(x - (x0 + w), La)    # distance above its upper face
+        # owned atoms have dlo in (La - w, La] and dhi in [La - w, La): they enter a halo only as periodic images of themselves
+        lo = (dlo > 0) & (dlo <= h)
+        hi = dhi < h
+        i_own = torch.nonzero(owned).flatten()
+        i_lo = torch.nonzero(lo).flatten()
+        i_hi = torch.nonzero(hi).flatten()
+        gidx = torch.cat([i_own, i_lo, i_hi])
+        pos_l = pos[gidx].clone()
+        xa = torch.cat([x[i_own] - x0 + h, h - dlo[i_lo], h + w + dhi[i_hi]])
+        pos_l[:, a] = xa
+        box_l = box.clone()
+        box_l[a, a] = w + 2 * h + 1.05 * self.cutoff + 1e-3
+        return gidx, pos_l, box_l, int(i_own.numel())
+
+    def contribution(self, z, pos, box, rank: int, world: int):
+        """This rank's term of the sums: (E_r - offset [1], forces scattered to the global atom order [N, 3])."""
+        gidx, pos_l, box_l, n_own = self.local_system(pos, box, rank, world)
+        forces = torch.zeros((pos.shape[0], 3), dtype=torch.float32, device=pos.device)
+        if n_own == 0:
+            return torch.zeros(1, dtype=torch.float32, device=pos.device), forces
+        w_l = torch.zeros(gidx.numel(), dtype=torch.float32, device=pos.device)
+        w_l[:n_own] = 1.0
+        e, f_l = self.compute(z[gidx], pos_l, box_l, w_l)
+        forces.index_add_(0, gidx, f_l.to(torch.float32))
+        return e.reshape(1).to(torch.float32) - self.energy_offset, forces
+
+    def evaluate(self, z, pos, box) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Every rank calls with the full (replicated) system; returns (E [1], F [N, 3]) of the whole system on every rank."""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        e, forces = self.contribution(z, pos, box, rank, world)
+        if world > 1:
+            buf = torch.cat([forces.reshape(-1), e])
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            forces, e = buf[:-1].reshape(-1, 3), buf[-1:]
+        return e + self.energy_offset, forces
