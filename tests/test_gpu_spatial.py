@@ -66,10 +66,56 @@ def test_spatial_decomposition_c2_water_box_cell_list(hip_lib):
     ev = _evaluator(model, args)
     E, F, n_local = _decomposed(ev, z, pos, box, 2)
     assert min(n_local) > 1024  # the local systems take the cell list
-    # fp32 bound of north_star (1e-4): the local systems hold the atoms at translated coordinates, so every distance is rounded
-    # differently from the whole system's (measured: 2e-5 of the largest force component)
-    assert abs(float(E) - float(Ew)) < 1e-4 * max(1.0, abs(float(Ew)))
-    assert (F - Fw).abs().max().item() < 1e-4 * max(1.0, Fw.abs().max().item())
+    # the local systems number their atoms differently (other summation orders): measured 3e-6 of the largest force component
+    assert abs(float(E) - float(Ew)) < 1e-5 * max(1.0, abs(float(Ew)))
+    assert (F - Fw).abs().max().item() < 1e-5 * max(1.0, Fw.abs().max().item())
     # weights really select: all-zero weights give the bare offset and no forces
     e0, f0 = model.energy_and_forces(z, pos, batch, box, None, 1, True, atom_weights=torch.zeros(z.shape[0], device="cuda"))
     assert abs(float(e0) - float(model.mean)) < 1e-6 and float(f0.abs().max()) == 0.0
+
+
+def _two_rank_worker(rank, world, port, tmpdir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "torchmd-net_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = dict(W.C2_ARGS)
+    torch.manual_seed(0)
+    model = create_model(dict(args)).cuda()
+    z, pos, box = (t.cuda() for t in W.water_box(n_side=15))
+    ev = _evaluator(model, args)
+    E, F = ev.evaluate(z, pos, box)  # every rank: its slab + halo on the GPU, then ONE all-reduce of forces + energy
+    n_own = ev.local_system(pos, box, rank, world)[3]
+    torch.save({"E": E.cpu(), "F": F.cpu(), "n_own": n_own}, os.path.join(tmpdir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_processes_sharing_the_gpu_equal_one(hip_lib, tmp_path):
+    """The protocol end to end: two processes, one GPU, gloo with the device buffer staged through the host
+    (RCCL refuses two ranks on one device), 10 125-atom periodic water box with the C2 model: the 2-rank result is the 1-rank
+    result up to the summation order of fp32 (1e-5 of the largest force component; the energy to 1e-6)."""
+    import socket
+    import torch.multiprocessing as mp
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    torch.manual_seed(0)
+    model = create_model(dict(W.C2_ARGS)).cuda()
+    z, pos, box = (t.cuda() for t in W.water_box(n_side=15))
+    Ew, Fw = model.energy_and_forces(z, pos, torch.zeros_like(z), box, None, 1, True)
+    outs = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    assert outs[0]["n_own"] + outs[1]["n_own"] == z.shape[0] and min(o["n_own"] for o in outs) > 0
+    assert torch.equal(outs[0]["E"], outs[1]["E"]) and torch.equal(outs[0]["F"], outs[1]["F"])  # every rank holds the result
+    assert abs(float(outs[0]["E"]) - float(Ew)) < 1e-6 * max(1.0, abs(float(Ew)))
+    assert (outs[0]["F"] - Fw.cpu()).abs().max().item() < 1e-5 * max(1.0, Fw.abs().max().item())

@@ -219,10 +219,13 @@ class SpatialEvaluator:
         i_hi = torch.nonzero(hi).flatten()
         gidx = torch.cat([i_own, i_lo, i_hi])
         pos_l = pos[gidx].clone()
-        xa = torch.cat([x[i_own] - x0 + h, h - dlo[i_lo], h + w + dhi[i_hi]])
+        # local coordinate along the slab axis = the atom's own (wrapped) coordinate, or its periodic image one box length away:
+        # no translation, so the distances inside the local system are rounded like the whole system's wherever they can be
+        x1 = x0 + w
+        xa = torch.cat([x[i_own], torch.where(x[i_lo] < x0, x[i_lo], x[i_lo] - La), torch.where(x[i_hi] >= x1, x[i_hi], x[i_hi] + La)])
         pos_l[:, a] = xa
         box_l = box.clone()
-        box_l[a, a] = w + 2 * h + 1.05 * self.cutoff + 1e-3
+        box_l[a, a] = w + 2 * h + 1.05 * self.cutoff + 1e-3  # [x0 - h, x1 + h) plus more than one cutoff of vacuum
         return gidx, pos_l, box_l, int(i_own.numel())
 
     def contribution(self, z, pos, box, rank: int, world: int):
@@ -244,6 +247,11 @@ class SpatialEvaluator:
         e, forces = self.contribution(z, pos, box, rank, world)
         if world > 1:
             buf = torch.cat([forces.reshape(-1), e])
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            if buf.is_cuda and dist.get_backend(self.group) == "gloo":  # tests: two processes on one GPU (RCCL refuses that)
+                host = buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                buf = host.to(buf.device)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
             forces, e = buf[:-1].reshape(-1, 3), buf[-1:]
         return e + self.energy_offset, forces
