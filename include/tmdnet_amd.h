@@ -136,7 +136,13 @@ const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel);
  * Options: "edge_table_min_pairs"; "pair_rows_bf16" (Equivariant Transformer handle only; 1: the per-pair distance-filter
  * rows silu(dk_proj phi) | silu(dv_proj phi) and their d/dd - reference torchmd_et.py:375-415 - are written by the table
  * interpolation as bf16 and widened when the attention sweeps load them; products and sums stay fp32; default 0).  Info: "edge_table_T" (0 = off), "edge_table_err_value", "edge_table_err_slope"
- * (measured at the midpoints), "edge_table_min_pairs". */
+ * (measured at the midpoints), "edge_table_min_pairs".
+ * "recompute_pair_rows" (TensorNet handle; default 0): 1 = the message sweeps interpolate a layer's per-pair row from its table
+ * themselves (12 table loads per edge instead of 3, or 6 in the reverse sweep) and the rows w^l, d w^l / dd, the distance
+ * projections' rows and the direct evaluation's activations get NO workspace: tmdnet_forward_workspace_bytes drops from
+ * ~12.6 KB to ~0.1 KB per pair, which is what lets a 10^6-atom periodic box fit one 288 GB device.  Same arithmetic as the stored
+ * rows (one definition, csrc/tn_interp.h): energies and forces are bit-identical.  Needs the tables (verified, not switched
+ * off); tmdnet_energy_forces reports TMDNET_ERR_STATE otherwise. */
 int tmdnet_set_option(tmdnet_model* m, const char* name, double value);
 int tmdnet_get_info(const tmdnet_model* m, const char* name, double* value);
 

@@ -230,3 +230,59 @@ def test_fused_tensor_linears_with_charges_ragged_partial_tile_vs_oracle(hip_lib
         # zero net force per molecule (pairwise forces): every molecule, not only the sampled ones
         net = torch.zeros(len(sizes), 3, device="cuda").index_add_(0, batch.cuda(), F)
         assert net.abs().max().item() < 1e-3 * F.abs().max().item()
+
+
+def test_recompute_pair_rows_is_bit_identical_and_drops_the_pair_workspace(hip_lib):
+    """Option "recompute_pair_rows" (VERDICT r03 item 6): the sweeps of a large system interpolate the per-pair rows from the radial
+    tables themselves; same arithmetic (csrc/tn_interp.h) -> energies and forces equal the stored-row path bit for bit, and the
+    forward workspace shrinks by the per-pair rows (10 125-atom periodic water box, C2 model)."""
+    import ctypes as C
+    from torchmdnet_amd import _C, workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(0)
+    model = create_model(dict(W.C2_ARGS)).cuda()
+    z, pos, box = (t.cuda() for t in W.water_box(n_side=15))
+    batch = torch.zeros_like(z)
+    E0, F0 = model.energy_and_forces(z, pos, batch, box, None, 1, True)
+    e0 = model.energy_and_forces(z, pos, batch, box, None, 1, False)[0]
+    n, (n_pairs, n_edges, _) = int(z.shape[0]), model._engine.counts
+    lib, nb = _C.lib(), C.c_size_t(0)
+    lib.tmdnet_forward_workspace_bytes(model._engine.handle, n, 1, n_pairs, n_edges, 1, C.byref(nb))
+    stored = nb.value
+    model.set_engine_option("recompute_pair_rows", 1)
+    E1, F1 = model.energy_and_forces(z, pos, batch, box, None, 1, True)
+    e1 = model.energy_and_forces(z, pos, batch, box, None, 1, False)[0]
+    lib.tmdnet_forward_workspace_bytes(model._engine.handle, n, 1, n_pairs, n_edges, 1, C.byref(nb))
+    assert torch.equal(E0, E1) and torch.equal(F0, F1) and torch.equal(e0, e1)
+    assert nb.value < 0.45 * stored, (nb.value, stored)  # ~12.6 KB per pair gone; the per-atom tensors remain
+    model.set_engine_option("recompute_pair_rows", 0)
+    E2, F2 = model.energy_and_forces(z, pos, batch, box, None, 1, True)
+    assert torch.equal(E0, E2) and torch.equal(F0, F2)
+
+
+def test_quarter_million_atom_box_pair_set_and_determinism(hip_lib):
+    """273 375-atom periodic water box: the cell list's pair set is the brute-force pair set, the step is reproducible bit for bit
+    and translation-invariant.  This configuration holds a pair within one ulp of the cutoff; the count and the fill pass of the
+    row once disagreed about it (their copies of |delta|^2 were contracted differently), the row got one entry too many, a real
+    neighbour fell off its end and ~50 atoms had forces off by 10 % (round 4; csrc/tn_common.h pair_geometry is the fix)."""
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    z, pos, box = (t.cuda() for t in W.water_box(n_side=45))
+    batch, n = torch.zeros_like(z), z.shape[0]
+    keys = []
+    for strategy in (0, 1):  # brute force, cell list
+        nb, _, ds, npairs = torch.ops.tmdnet.neighbor_pairs(pos, batch, box, 0.0, 5.0, 9_000_000, False, False, strategy, 1)
+        k = int(npairs.reshape(-1)[0])
+        assert float(ds[:k].max()) <= 5.0  # |delta|^2 < 25 decides; its square root may round to 5
+        keys.append(torch.sort(nb[0, :k] * n + nb[1, :k]).values)
+    assert torch.equal(keys[0], keys[1])
+    torch.manual_seed(0)
+    model = create_model(dict(W.C2_ARGS, max_num_neighbors=96)).cuda()
+    E, F = model(z, pos, batch, box=box)
+    E1, F1 = model(z, pos, batch, box=box)
+    assert torch.equal(E, E1) and torch.equal(F, F1)
+    E2, F2 = model(z, pos + torch.tensor([1.234, -2.5, 7.7], device="cuda"), batch, box=box)
+    assert abs(float(E2) - float(E)) < 1e-5 * abs(float(E))
+    assert (F2 - F).abs().max().item() < 1e-3 * F.abs().max().item()

@@ -20,6 +20,7 @@
 #include "tn_model.h"
 #include "tn_tlin9.h"
 #include "tn_small.h"
+#include "tn_interp.h"
 
 using namespace tn;
 
@@ -303,16 +304,19 @@ int rb_ntp(const tmdnet_model* m, int64_t n_atoms, int64_t n_pairs) {
 }
 namespace {
 
-FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, int64_t P, bool bwd, size_t* total, int ntp = 0) {
+// lean: 1 = no direct-evaluation buffers (phi, the edge MLP's activations and tangents), 2 = no Q / dQ rows (embedding in the
+// radial basis), 4 = no w / dw rows (the sweeps interpolate them) - what option "recompute_pair_rows" drops: 12.6 -> 0.1 KB per pair
+FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, int64_t P, bool bwd, size_t* total, int ntp = 0,
+                     int lean = 0) {
   Carver c(ws);
   FwdBuffers b{};
   const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden;
   const int64_t P1 = P + 1, N9 = N * 9 * F;
-  b.phi = c.take<float>(P1 * K);
-  b.dphi = c.take<float>(P1 * K);
+  b.phi = c.take<float>((lean & 1) ? 0 : P1 * K);
+  b.dphi = c.take<float>((lean & 1) ? 0 : P1 * K);
   b.C = c.take<float>(P1);
   b.dC = c.take<float>(P1);
-  b.Q = c.take<float>(P1 * 3 * F);
+  b.Q = c.take<float>((lean & 2) ? 0 : P1 * 3 * F);
   b.u0 = c.take<float>(N9);
   b.s0n = c.take<float>(N * F);
   b.ln0 = c.take<float>(N * F);
@@ -325,17 +329,17 @@ FwdBuffers carve_fwd(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t B, i
   b.UX = c.take<float>(N9);
   for (int l = 0; l <= L; ++l) b.X.push_back(c.take<float>(N9));
   for (int l = 0; l < L; ++l) {
-    b.w.push_back(c.take<float>(P1 * 3 * F));
-    b.dw.push_back(c.take<float>(bwd ? P1 * 3 * F : 0));
+    b.w.push_back(c.take<float>((lean & 4) ? 0 : P1 * 3 * F));
+    b.dw.push_back(c.take<float>(bwd && !(lean & 4) ? P1 * 3 * F : 0));
     b.Pn.push_back(c.take<float>(N9));
     b.Mi.push_back(c.take<float>(N9));
     b.D.push_back(c.take<float>(N9));
   }
-  b.he1 = c.take<float>(P1 * F);
-  b.he2 = c.take<float>(P1 * 2 * F);
-  b.te1 = c.take<float>(bwd ? P1 * F : 0);
-  b.te2 = c.take<float>(bwd ? P1 * 2 * F : 0);
-  b.dQ = c.take<float>(bwd ? P1 * 3 * F : 0);
+  b.he1 = c.take<float>((lean & 1) ? 0 : P1 * F);
+  b.he2 = c.take<float>((lean & 1) ? 0 : P1 * 2 * F);
+  b.te1 = c.take<float>(bwd && !(lean & 1) ? P1 * F : 0);
+  b.te2 = c.take<float>(bwd && !(lean & 1) ? P1 * 2 * F : 0);
+  b.dQ = c.take<float>(bwd && !(lean & 2) ? P1 * 3 * F : 0);
   b.Xh = c.take<float>(N9);
   b.Ch = c.take<float>(N9);
   b.feat = c.take<float>(N * 3 * F);
@@ -1083,6 +1087,11 @@ int tmdnet_set_option(tmdnet_model* m, const char* name, double value) {
     m->pair_bf16 = value != 0.0 ? 1 : 0;
     return TMDNET_OK;
   }
+  if (n == "recompute_pair_rows") {
+    if (m->et || m->tn2) return fail(m, TMDNET_ERR_INVALID, "recompute_pair_rows applies to the TensorNet handle only");
+    m->recompute_rows = value != 0.0;
+    return TMDNET_OK;
+  }
   return fail(m, TMDNET_ERR_INVALID, "unknown option: " + n);
 }
 
@@ -1097,6 +1106,7 @@ int tmdnet_get_info(const tmdnet_model* m, const char* name, double* value) {
   else if (n == "edge_table_min_pairs") *value = (double)m->tab_min_pairs;
   else if (n == "pair_rows_bf16") *value = (double)m->pair_bf16;
   else if (n == "embed_rb_min_atoms") *value = (double)m->rb_min_atoms;
+  else if (n == "recompute_pair_rows") *value = m->recompute_rows ? 1.0 : 0.0;
   else if (n == "embed_rb") *value = m->rb_fwd ? 1.0 : 0.0;
   else if (n == "species_last_build") *value = (double)m->last_nt;
   else return TMDNET_ERR_INVALID;
@@ -1274,7 +1284,8 @@ int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64
   // the radial-basis embedding's buffers depend on the species count of the graph the call will run on: sized for the
   // largest padding (8) whenever that path can be taken, so the answer does not depend on which build came last
   const bool rb_possible = m->rb_fwd && !m->et && !m->train && n_pairs >= 0 && n_atoms >= m->rb_min_atoms;
-  carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes, rb_possible ? 8 : 0);
+  carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes, rb_possible ? 8 : 0,
+            m->recompute_rows ? (rb_possible ? 7 : 5) : 0);
   return TMDNET_OK;
 }
 
@@ -1330,7 +1341,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   const int P = n_pairs >= 0 ? (int)n_pairs : (int)g.pcap, P1 = P + 1;
   size_t need = 0;
   const int ntp = rb_ntp(m, n_atoms, n_pairs);  // > 0: embedding in the radial basis (no Q / dQ per pair)
-  FwdBuffers b = carve_fwd(ws, hp, n_atoms, n_mol, P, want_forces != 0, &need, ntp);
+  const bool recompute = m->recompute_rows;
+  FwdBuffers b = carve_fwd(ws, hp, n_atoms, n_mol, P, want_forces != 0, &need, ntp, recompute ? (ntp ? 7 : 5) : 0);
   if (need > ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "forward workspace too small: need " + std::to_string(need));
   const DevParams& W = m->P;
   const int o3 = hp.group_o3;
@@ -1371,7 +1383,15 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   // caller's workspaces, reverse once the seeds d loss / d E are known
   const bool run_fwd = !tc || tc->phase != 2, run_bwd = !tc || tc->phase != 1;
   // the slots of the merged distance gradient are what the fused reverse sweeps write: both or neither
-  const bool fused_small = !tc && !ntp && small_fused_ok(N, F, H, L) &&
+  if (recompute && (!use_tab || (want_forces && !(message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD")))))
+    return fail(m, TMDNET_ERR_STATE, "option recompute_pair_rows needs the radial tables (verified, not switched off) and the merged "
+                                     "distance gradient; TensorNet inference only");
+  PairRowTable rts[8];
+  for (int l = 0; l < L && recompute; ++l) {
+    const float h_ = (hp.cutoff_upper - hp.cutoff_lower) / (float)m->tabs.T;  // the expressions of launch_edge_interp
+    rts[l] = PairRowTable{m->tabs.tab[1 + l], g.pd, g.counts, hp.cutoff_lower, h_, 1.0f / h_, m->tabs.T};
+  }
+  const bool fused_small = !tc && !ntp && !recompute && small_fused_ok(N, F, H, L) &&
                            (!want_forces || (message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD")));
   if (run_fwd) {
     if (use_tab) {
@@ -1386,7 +1406,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         outs[nt_] = b.Q;
         douts[nt_++] = want_forces ? b.dQ : nullptr;
       }
-      for (int l = 0; l < L; ++l) {
+      for (int l = 0; l < L && !recompute; ++l) {  // recompute: no per-pair rows of the layers (the sweeps interpolate)
         tabs[nt_] = m->tabs.tab[1 + l];
         outs[nt_] = b.w[l];
         douts[nt_++] = want_forces ? b.dw[l] : nullptr;
@@ -1506,7 +1526,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         Tl9Args ta{};
         ta.A = b.X[l]; ta.C = b.Pn[l]; ta.N = N; ta.F = F;
         tlin9(s, TL9_PRO_NORM, TL9_EPI_PLAIN, q_.V, ta, 2.0, "norm");
-        KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s));
+        KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s, recompute ? &rts[l] : nullptr));
         // dX = linear(C_hat), then X_new = X_hat + dX + kappa dX.dX (and the readout invariants after the last layer) in the epilogue
         Tl9Args tb{};
         tb.A = Ch_l; tb.C = b.D[l]; tb.e0 = b.X[l]; tb.o1 = b.X[l + 1]; tb.o2 = b.feat; tb.want_feat = l + 1 == L; tb.kap = q;
@@ -1516,7 +1536,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       }
       if (l == 0) KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], Xh_l, N, F, s));
       tensor_linear(s, Xh_l, q_.V, b.Pn[l], N, F);
-      KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s));
+      KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s, recompute ? &rts[l] : nullptr));
       tensor_linear(s, Ch_l, q_.V + 3, b.D[l], N, F);
       // update fused with the next consumer of the new X: the next layer's normalisation, or the readout invariants
       KR(CAT_ELEMENTWISE, 4 * nodeB, launch_layer_update(Xh_l, b.D[l], q, batch_k, N, F, b.X[l + 1], l + 1 < L ? 1 : 2,
@@ -1645,7 +1665,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       if (merged_gd) {
         KR(CAT_MESSAGE, 2 * wB + idxB + 4 * nodeB + 8 * (Pd + 1) * gd_nw,  // w, dw, gMi, Pn, gPn (read + write), g_d slots
            launch_message_adjoint_gd(g, N, F, b.w[l], b.dw[l], b.gMi, b.Pn[l], b.gPn, b.gd_slots + (int64_t)l * gd_nw * gd_stride,
-                                     gd_stride, s));
+                                     gd_stride, s, recompute ? &rts[l] : nullptr));
       } else {
         KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
         if (!tc) KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));

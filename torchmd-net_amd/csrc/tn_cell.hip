@@ -165,16 +165,7 @@ void launch_prepare_z(const Graph& g, const int64_t* z, const int* perm, int N, 
 // kernels (tn_graph_wave.hip) so that both strategies produce bit-identical deltas
 __device__ __forceinline__ float cell_d2(const float* __restrict__ pos, int hi, int lo, const float* __restrict__ box, float& dx,
                                          float& dy, float& dz) {
-  dx = pos[hi * 3 + 0] - pos[lo * 3 + 0];
-  dy = pos[hi * 3 + 1] - pos[lo * 3 + 1];
-  dz = pos[hi * 3 + 2] - pos[lo * 3 + 2];
-  const float s3 = roundf(dz / box[8]);
-  dx -= s3 * box[6]; dy -= s3 * box[7]; dz -= s3 * box[8];
-  const float s2 = roundf(dy / box[4]);
-  dx -= s2 * box[3]; dy -= s2 * box[4];
-  const float s1 = roundf(dx / box[0]);
-  dx -= s1 * box[0];
-  return dx * dx + dy * dy + dz * dz;
+  return pair_geometry(pos, hi, lo, box, dx, dy, dz);  // tn_common.h: the one definition
 }
 
 // wave per (cell-sorted) atom: sort the 27 neighbour cell ids, sweep their atom ranges in ascending order.

@@ -19,6 +19,33 @@ struct M3 {  // 3x3 matrix in registers
   float a[3][3];
 };
 
+// Canonical pair geometry: delta = pos[hi] - pos[lo] (+ triclinic minimum image, z -> y -> x; reference neighbors_brute.py:112-135,
+// models/utils.py:206-229), returns |delta|^2.  ONE definition for every kernel that decides "is this a pair" - the count and the
+// fill pass of a row, the two rows of a pair, brute force and cell list - with contraction off and the fused multiply-adds
+// spelled out: left to the compiler, a*b+c was contracted differently in the count and the fill instantiation, and a pair within one
+// ulp of the cutoff (about one per 3e5 atoms of water) was counted by one pass and not the other - the row then held one entry
+// too many and a real neighbour fell off its end (round 4: wrong forces on ~50 atoms of a 273 375-atom box).
+__device__ __forceinline__ float pair_geometry(const float* __restrict__ pos, int hi, int lo, const float* __restrict__ box, float& dx,
+                                               float& dy, float& dz) {
+#pragma clang fp contract(off)
+  dx = pos[hi * 3 + 0] - pos[lo * 3 + 0];
+  dy = pos[hi * 3 + 1] - pos[lo * 3 + 1];
+  dz = pos[hi * 3 + 2] - pos[lo * 3 + 2];
+  if (box) {
+    const float s3 = -roundf(dz / box[8]);
+    dx = __builtin_fmaf(s3, box[6], dx);
+    dy = __builtin_fmaf(s3, box[7], dy);
+    dz = __builtin_fmaf(s3, box[8], dz);
+    const float s2 = -roundf(dy / box[4]);
+    dx = __builtin_fmaf(s2, box[3], dx);
+    dy = __builtin_fmaf(s2, box[4], dy);
+    const float s1 = -roundf(dx / box[0]);
+    dx = __builtin_fmaf(s1, box[0], dx);
+  }
+  const float xx = dx * dx;
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, xx));
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float silu_grad(float x) {

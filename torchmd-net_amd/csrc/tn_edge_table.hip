@@ -29,6 +29,7 @@
 
 #include "tn_common.h"
 #include "tn_kernels.h"
+#include "tn_interp.h"
 
 namespace tn {
 
@@ -267,9 +268,8 @@ __global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const un
       continue;
     }
     const float d = __uint_as_float(key);  // the key holds all 32 bits of the distance
-    const float x = (d - lo) * inv_h;
-    int k = (int)x;
-    k = k < 0 ? 0 : (k > T - 1 ? T - 1 : k);
+    const InterpCoef ic = interp_coef(d, lo, h, inv_h, T);  // tn_interp.h: the one definition of this arithmetic
+    const int k = ic.k;
     if (k != kcur) {
       kcur = k;
 #pragma unroll
@@ -281,17 +281,16 @@ __global__ __launch_bounds__(256) void k_edge_interp(Graph g, int Pcap, const un
         sl1[t] = *reinterpret_cast<const f4*>(row + 4 * R);
       }
     }
-    const float t = x - (float)k, t2 = t * t, t3 = t2 * t;
-    const float aD = (3.f * t2 - 2.f * t3) * h, a0 = (t3 - 2.f * t2 + t) * h, a1 = (t3 - t2) * h;  // value: f0 + aD D + a0 s0 + a1 s1
-    const float bD = 6.f * t - 6.f * t2, b0 = 3.f * t2 - 4.f * t + 1.f, b1 = 3.f * t2 - 2.f * t;   // slope: bD D + b0 s0 + b1 s1
 #pragma unroll
     for (int tb = 0; tb < NT; ++tb) {
-      const f4 v0 = f0[tb] + (aD * D[tb] + a0 * sl0[tb] + a1 * sl1[tb]);
-      store_piece(a.out[tb], (int64_t)p * R + 4 * c4, v0.x, v0.y, v0.z, v0.w, a.out_bf16);
-      if (a.dout[tb]) {
-        const f4 v1 = bD * D[tb] + b0 * sl0[tb] + b1 * sl1[tb];
-        store_piece(a.dout[tb], (int64_t)p * R + 4 * c4, v1.x, v1.y, v1.z, v1.w, a.out_bf16);
+      f4 v0, v1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v0[j] = interp_value(f0[tb][j], sl0[tb][j], D[tb][j], sl1[tb][j], ic);
+        v1[j] = interp_slope(sl0[tb][j], D[tb][j], sl1[tb][j], ic);
       }
+      store_piece(a.out[tb], (int64_t)p * R + 4 * c4, v0.x, v0.y, v0.z, v0.w, a.out_bf16);
+      if (a.dout[tb]) store_piece(a.dout[tb], (int64_t)p * R + 4 * c4, v1.x, v1.y, v1.z, v1.w, a.out_bf16);
     }
   }
 }
@@ -332,23 +331,20 @@ __global__ __launch_bounds__(256) void k_edge_interp_direct(Graph g, int Pcap, I
     }
     return;
   }
-  const float x = (d - lo) * inv_h;
-  int k = (int)x;
-  k = k < 0 ? 0 : (k > T - 1 ? T - 1 : k);
-  const float t = x - (float)k, t2 = t * t, t3 = t2 * t;
-  const float aD = (3.f * t2 - 2.f * t3) * h, a0 = (t3 - 2.f * t2 + t) * h, a1 = (t3 - t2) * h;
-  const float bD = 6.f * t - 6.f * t2, b0 = 3.f * t2 - 4.f * t + 1.f, b1 = 3.f * t2 - 2.f * t;
+  const InterpCoef ic = interp_coef(d, lo, h, inv_h, T);
 #pragma unroll
   for (int tb = 0; tb < NT; ++tb) {
-    const float* row = a.tab[tb] + (int64_t)k * 3 * R + 4 * c4;
+    const float* row = a.tab[tb] + (int64_t)ic.k * 3 * R + 4 * c4;
     const f4 f0 = *reinterpret_cast<const f4*>(row), sl0 = *reinterpret_cast<const f4*>(row + R);
     const f4 D = *reinterpret_cast<const f4*>(row + 2 * R), sl1 = *reinterpret_cast<const f4*>(row + 4 * R);
-    const f4 v0 = f0 + (aD * D + a0 * sl0 + a1 * sl1);
-    store_piece(a.out[tb], (int64_t)p * R + 4 * c4, v0.x, v0.y, v0.z, v0.w, a.out_bf16);
-    if (a.dout[tb]) {
-      const f4 v1 = bD * D + b0 * sl0 + b1 * sl1;
-      store_piece(a.dout[tb], (int64_t)p * R + 4 * c4, v1.x, v1.y, v1.z, v1.w, a.out_bf16);
+    f4 v0, v1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v0[j] = interp_value(f0[j], sl0[j], D[j], sl1[j], ic);
+      v1[j] = interp_slope(sl0[j], D[j], sl1[j], ic);
     }
+    store_piece(a.out[tb], (int64_t)p * R + 4 * c4, v0.x, v0.y, v0.z, v0.w, a.out_bf16);
+    if (a.dout[tb]) store_piece(a.dout[tb], (int64_t)p * R + 4 * c4, v1.x, v1.y, v1.z, v1.w, a.out_bf16);
   }
 }
 
@@ -419,16 +415,11 @@ __global__ void k_interp_list(const float* __restrict__ tab, const double* __res
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)M * R) return;
   const int m = (int)(idx / R), c = (int)(idx - (int64_t)m * R);
-  const float x = ((float)dist[m] - lo) * inv_h;
-  int k = (int)x;
-  k = k < 0 ? 0 : (k > T - 1 ? T - 1 : k);
-  const float t = x - (float)k, t2 = t * t, t3 = t2 * t;
-  const float aD = (3.f * t2 - 2.f * t3) * h, a0 = (t3 - 2.f * t2 + t) * h, a1 = (t3 - t2) * h;
-  const float bD = 6.f * t - 6.f * t2, b0 = 3.f * t2 - 4.f * t + 1.f, b1 = 3.f * t2 - 2.f * t;
-  const float* row = tab + (int64_t)k * 3 * R + c;
+  const InterpCoef ic = interp_coef((float)dist[m], lo, h, inv_h, T);
+  const float* row = tab + (int64_t)ic.k * 3 * R + c;
   const float f0 = row[0], s0 = row[R], D = row[2 * R], s1 = row[4 * R];
-  out[idx] = f0 + (aD * D + a0 * s0 + a1 * s1);
-  dout[idx] = bD * D + b0 * s0 + b1 * s1;
+  out[idx] = interp_value(f0, s0, D, s1, ic);
+  dout[idx] = interp_slope(s0, D, s1, ic);
 }
 void launch_interp_list(const float* tab, const double* dist, int M, int R, int T, float lo, float up, float* out, float* dout,
                         hipStream_t s) {

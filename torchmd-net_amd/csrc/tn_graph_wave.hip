@@ -16,18 +16,7 @@ static inline int cdivw(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float pair_d2(const float* __restrict__ pos, int hi, int lo, const float* __restrict__ box, float& dx,
                                          float& dy, float& dz) {
-  dx = pos[hi * 3 + 0] - pos[lo * 3 + 0];
-  dy = pos[hi * 3 + 1] - pos[lo * 3 + 1];
-  dz = pos[hi * 3 + 2] - pos[lo * 3 + 2];
-  if (box) {  // triclinic minimum image, z -> y -> x
-    float s3 = roundf(dz / box[8]);
-    dx -= s3 * box[6]; dy -= s3 * box[7]; dz -= s3 * box[8];
-    float s2 = roundf(dy / box[4]);
-    dx -= s2 * box[3]; dy -= s2 * box[4];
-    float s1 = roundf(dx / box[0]);
-    dx -= s1 * box[0];
-  }
-  return dx * dx + dy * dy + dz * dz;
+  return pair_geometry(pos, hi, lo, box, dx, dy, dz);  // tn_common.h: the one definition
 }
 
 // one atom's row, by one wave: count pass (FILL = false: nlow, ntot) or fill pass (FILL = true: col / epair / esign and the

@@ -82,15 +82,16 @@ void launch_layernorm_bwd(const float* g, const float* xhat, const float* rstd, 
 // ---- interaction layer (reference tensornet.py:729-814, 622-679)
 void launch_norm_x(const float* X, float* Xh, int N, int F, hipStream_t s);
 // mode 0: forward message + O(3)/SO(3) product + normalisation -> Mi, Ch ; mode 1: dst[i] += sum_e w * src[j] (adjoint)
+struct PairRowTable;  // tn_interp.h: a layer's radial table for sweeps that evaluate the per-pair rows themselves
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
-                    float* Mi, float* Ch, hipStream_t s);
+                    float* Mi, float* Ch, hipStream_t s, const PairRowTable* rt = nullptr);
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);
 // adjoint sweep + the layer's per-pair distance gradient in one pass (replaces launch_message_adjoint + launch_pair_gd when
 // message_adjoint_gd_ok): partial sums go to slots[wave][2 * pair + direction], summed by launch_geom_gd
 bool message_adjoint_gd_ok(int N, int F);
 int message_adjoint_gd_waves(const Graph& g, int N, int F);  // number of slot arrays the sweep writes per layer
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
-                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
+                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt = nullptr);
 // next = 0: plain; 1: nxt = X_hat of the new X (next layer's k_norm_x); 2: nxt = readout invariants of the new X
 void launch_layer_update(const float* Xh, const float* D, const float* q, const int64_t* batch, int N, int F, float* Xn, int next,
                          float* nxt, hipStream_t s);

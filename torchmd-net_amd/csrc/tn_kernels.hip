@@ -4,6 +4,7 @@
 // scalars are wave-uniform (scalar loads).  Segmented sums over CSR rows are done in registers by
 // the thread that owns (atom, channel): no atomics, deterministic results.
 #include "tn_kernels.h"
+#include "tn_interp.h"
 
 #include <cstdlib>
 
@@ -43,21 +44,7 @@ __global__ void k_mol_ranges(const int64_t* __restrict__ batch, int N, int B, in
 // reference neighbors_brute.py:112-135).  Both atoms of a pair evaluate the identical expression.
 __device__ __forceinline__ float pair_delta(const float* __restrict__ pos, int hi, int lo, const float* __restrict__ box,
                                             float& dx, float& dy, float& dz) {
-  dx = pos[hi * 3 + 0] - pos[lo * 3 + 0];
-  dy = pos[hi * 3 + 1] - pos[lo * 3 + 1];
-  dz = pos[hi * 3 + 2] - pos[lo * 3 + 2];
-  if (box) {
-    float s3 = roundf(dz / box[8]);
-    dx -= s3 * box[6];
-    dy -= s3 * box[7];
-    dz -= s3 * box[8];
-    float s2 = roundf(dy / box[4]);
-    dx -= s2 * box[3];
-    dy -= s2 * box[4];
-    float s1 = roundf(dx / box[0]);
-    dx -= s1 * box[0];
-  }
-  return dx * dx + dy * dy + dz * dz;
+  return pair_geometry(pos, hi, lo, box, dx, dy, dz);  // tn_common.h: the one definition
 }
 
 __device__ __forceinline__ void cand_range(const int* mstart, const int* mend, const int* counts, int64_t b, int N, int& j0,
@@ -629,8 +616,11 @@ void launch_norm_x(const float* X, float* Xh, int N, int F, hipStream_t s) {
 }
 
 // CSR segmented gather-sum: acc[c] = sum_{e in row(i)} w[pair(e), type(c), f] * src[col(e), c, f]
+// RC: the per-pair rows are not stored; each is interpolated from the layer's radial table here (tn_interp.h, option
+// "recompute_pair_rows": 12 table loads per edge instead of 3 row loads, 6 KB of workspace per pair saved)
+template <bool RC = false>
 __device__ __forceinline__ void csr_gather(const Graph& g, int i, int F, int f, const float* __restrict__ w,
-                                           const float* __restrict__ src, float acc[9]) {
+                                           const float* __restrict__ src, float acc[9], const PairRowTable* rt = nullptr) {
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   const int F3 = 3 * F, F9 = 9 * F;
 #pragma unroll
@@ -640,24 +630,32 @@ __device__ __forceinline__ void csr_gather(const Graph& g, int i, int F, int f, 
   };
   auto load = [&](int e, In& o) {
     const int j = g.col[e], p = g.epair[e];
-    const float* wp = w + (int64_t)p * F3 + f;
     const float* sp = src + (int64_t)j * F9 + f;
-    o.w0 = wp[0];
-    o.w1 = wp[F];
-    o.w2 = wp[2 * F];
+    if (RC) {
+      float w3[3], unused[3];
+      pair_row_eval<false>(*rt, p, F3, F, f, w3, unused);
+      o.w0 = w3[0];
+      o.w1 = w3[1];
+      o.w2 = w3[2];
+    } else {
+      const float* wp = w + (int64_t)p * F3 + f;
+      o.w0 = wp[0];
+      o.w1 = wp[F];
+      o.w2 = wp[2 * F];
+    }
 #pragma unroll
     for (int c = 0; c < 9; ++c) o.s[c] = sp[c * F];
   };
-  auto add = [&](const In& o) {
-    acc[0] += o.w0 * o.s[0];
-    acc[1] += o.w1 * o.s[1];
-    acc[2] += o.w1 * o.s[2];
-    acc[3] += o.w1 * o.s[3];
-    acc[4] += o.w2 * o.s[4];
-    acc[5] += o.w2 * o.s[5];
-    acc[6] += o.w2 * o.s[6];
-    acc[7] += o.w2 * o.s[7];
-    acc[8] += o.w2 * o.s[8];
+  auto add = [&](const In& o) {  // explicit fused multiply-adds: both instantiations (stored / interpolated rows) round alike
+    acc[0] = __fmaf_rn(o.w0, o.s[0], acc[0]);
+    acc[1] = __fmaf_rn(o.w1, o.s[1], acc[1]);
+    acc[2] = __fmaf_rn(o.w1, o.s[2], acc[2]);
+    acc[3] = __fmaf_rn(o.w1, o.s[3], acc[3]);
+    acc[4] = __fmaf_rn(o.w2, o.s[4], acc[4]);
+    acc[5] = __fmaf_rn(o.w2, o.s[5], acc[5]);
+    acc[6] = __fmaf_rn(o.w2, o.s[6], acc[6]);
+    acc[7] = __fmaf_rn(o.w2, o.s[7], acc[7]);
+    acc[8] = __fmaf_rn(o.w2, o.s[8], acc[8]);
   };
   int e = e0;
   for (; e + 4 <= e1; e += 4) {  // four edges' rows requested together, accumulated in list order
@@ -679,15 +677,16 @@ __device__ __forceinline__ void csr_gather(const Graph& g, int i, int F, int f, 
 }
 
 // message passing + group product + normalisation (reference tensornet.py:757-806)
+template <bool RC>
 __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ Pn,
                           const float* __restrict__ q, const int64_t* __restrict__ batch, int o3, float* __restrict__ Mi,
-                          float* __restrict__ Ch) {
+                          float* __restrict__ Ch, PairRowTable rt) {
   const int i = xcd_chunk(blockIdx.x, gridDim.x);
   if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
   const float kap = kappa_of(q, batch, i);
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
     float m[9], y[9];
-    csr_gather(g, i, F, f, w, Pn, m);
+    csr_gather<RC>(g, i, F, f, w, Pn, m, &rt);
     load9(Pn + (int64_t)i * 9 * F + f, F, y);
     store9(Mi + (int64_t)i * 9 * F + f, F, m);
     const M3 Y = compose(y), M = compose(m);
@@ -814,8 +813,12 @@ __global__ __launch_bounds__(1024) void k_message_split(Graph g, int N, int F, c
 static bool split_rows_ok(int N, int F) { return N <= kSplitRows && F <= 128 && F % 64 == 0; }
 
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
-                    float* Mi, float* Ch, hipStream_t s) {
+                    float* Mi, float* Ch, hipStream_t s, const PairRowTable* rt) {
   if (N <= 0) return;
+  if (rt) {  // rows evaluated from the table inside the sweep
+    hipLaunchKernelGGL((k_message<true>), dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, *rt);
+    return;
+  }
   if (split_rows_ok(N, F)) {
     hipLaunchKernelGGL((k_message_split<0>), dim3(N), dim3(kEG * F), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
     return;
@@ -824,7 +827,7 @@ void launch_message(const Graph& g, int N, int F, const float* w, const float* s
   // order has windows of hundreds of rows: there the row kernel with four edges in flight is faster (10 k-atom box:
   // 0.36 -> 0.26 ms per sweep)
   if (g.small_mols && message_pair_ok(N, F)) return launch_message_pair(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
-  hipLaunchKernelGGL(k_message, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch);
+  hipLaunchKernelGGL((k_message<false>), dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, PairRowTable{});
 }
 
 // adjoint of the message sum: the graph and the edge weights are symmetric, so the transpose sweep is the
@@ -846,9 +849,10 @@ __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict
 // and g_d[p] = h(i <- j) + h(j <- i) (tn_pairgrad.hip); gMi[j] is loaded for the adjoint anyway and Pn[i] is the row's own,
 // so the separate per-pair kernel (a 4-row gather per pair) disappears.  The per-edge channel sum of a wave goes to its
 // own slot (wave, pair, direction): one writer per slot, summed in fixed order by k_geom_gd -> deterministic.
+template <bool RC>
 __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ dw,
                                      const float* __restrict__ gMi, const float* __restrict__ Pn, float* __restrict__ gPn,
-                                     float* __restrict__ slots, int64_t slot_stride) {
+                                     float* __restrict__ slots, int64_t slot_stride, PairRowTable rt) {
   const int i = xcd_chunk(blockIdx.x, gridDim.x);
   if (g.counts[2]) return;
   const int f = threadIdx.x, lane = f & 63, wave = f >> 6;  // blockDim.x == F (multiple of 64)
@@ -863,25 +867,37 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
   auto edge = [&](int e, float& h, int& slot_idx) {
     const int j = g.col[e], p = g.epair[e];
     const float sg = g.esign[e];
-    const float* wp = w + (int64_t)p * F3 + f;
-    const float* dp = dw + (int64_t)p * F3 + f;
     const float* sp = gMi + (int64_t)j * F9 + f;
-    const float w0 = wp[0], w1 = wp[F], w2 = wp[2 * F];
-    const float d0 = dp[0], d1 = dp[F], d2 = dp[2 * F];
+    float w3[3], d3[3];
+    if (RC) {
+      pair_row_eval<true>(rt, p, F3, F, f, w3, d3);
+    } else {
+      const float* wp = w + (int64_t)p * F3 + f;
+      const float* dp = dw + (int64_t)p * F3 + f;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        w3[t] = wp[t * F];
+        d3[t] = dp[t * F];
+      }
+    }
+    const float w0 = w3[0], w1 = w3[1], w2 = w3[2];
+    const float d0 = d3[0], d1 = d3[1], d2 = d3[2];
     float s9[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) s9[c] = sp[c * F];
-    acc[0] += w0 * s9[0];
-    acc[1] += w1 * s9[1];
-    acc[2] += w1 * s9[2];
-    acc[3] += w1 * s9[3];
-    acc[4] += w2 * s9[4];
-    acc[5] += w2 * s9[5];
-    acc[6] += w2 * s9[6];
-    acc[7] += w2 * s9[7];
-    acc[8] += w2 * s9[8];
-    h = d0 * (s9[0] * y[0]) + d1 * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
-        d2 * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
+    // explicit fused multiply-adds: both instantiations (stored / interpolated rows) round alike
+    acc[0] = __fmaf_rn(w0, s9[0], acc[0]);
+    acc[1] = __fmaf_rn(w1, s9[1], acc[1]);
+    acc[2] = __fmaf_rn(w1, s9[2], acc[2]);
+    acc[3] = __fmaf_rn(w1, s9[3], acc[3]);
+    acc[4] = __fmaf_rn(w2, s9[4], acc[4]);
+    acc[5] = __fmaf_rn(w2, s9[5], acc[5]);
+    acc[6] = __fmaf_rn(w2, s9[6], acc[6]);
+    acc[7] = __fmaf_rn(w2, s9[7], acc[7]);
+    acc[8] = __fmaf_rn(w2, s9[8], acc[8]);
+    const float tA = __fmaf_rn(s9[3], y[3], __fmaf_rn(s9[2], y[2], __fmul_rn(s9[1], y[1])));
+    const float tS = __fmaf_rn(s9[8], y[8], __fmaf_rn(s9[7], y[7], __fmaf_rn(s9[6], y[6], __fmaf_rn(s9[5], y[5], __fmul_rn(s9[4], y[4])))));
+    h = __fmaf_rn(d2, tS, __fmaf_rn(d1, tA, __fmul_rn(d0, __fmul_rn(s9[0], y[0]))));
     slot_idx = sg != 0.f ? 2 * p + (sg > 0.f ? 0 : 1) : -1;  // self edge: no slot
   };
   int e = e0;
@@ -913,14 +929,19 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
 bool message_adjoint_gd_ok(int N, int F) { return F % 64 == 0 && (split_rows_ok(N, F) || (N > kSplitRows && F <= 1024)); }
 int message_adjoint_gd_waves(const Graph& g, int N, int F) { return F / 64; }
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
-                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
+                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt) {
   if (N <= 0) return;
+  if (rt) {
+    hipLaunchKernelGGL((k_message_adjoint_gd<true>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, *rt);
+    return;
+  }
   if (split_rows_ok(N, F)) {
     hipLaunchKernelGGL((k_message_split<2>), dim3(N), dim3(kEG * F), 0, s, g, N, F, w, gMi, dw, nullptr, 0, const_cast<float*>(Pn), gPn,
                        slots, slot_stride);
     return;
   }
-  hipLaunchKernelGGL(k_message_adjoint_gd, dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride);
+  hipLaunchKernelGGL((k_message_adjoint_gd<false>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride,
+                     PairRowTable{});
 }
 
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {

@@ -151,6 +151,7 @@ struct TrainCtx {
 };
 
 struct tmdnet_model {
+  bool recompute_rows = false;  // option "recompute_pair_rows": the sweeps interpolate the per-pair rows themselves (no w / dw workspace)
   const float* atom_w = nullptr;  // per-atom weights of the energy sum (tmdnet_set_atom_weights), caller's atom order
   tmdnet_hparams hp;
   TrainCtx* train = nullptr;  // non-null while tmdnet_energy_param_grads drives tmdnet_energy_forces
