@@ -100,7 +100,7 @@ def roofline_of(rec, cls, label, pmc=None, note_kernel=None):
     """rec: summed ms / flops / bytes / launches of one kernel (or class).  MFMA-bound when it carries FLOPs."""
     launches = max(rec["launches"], 1)
     avg_s = rec["ms"] * 1e-3 / launches
-    kernel = note_kernel or KERNEL_OF.get(cls, cls)
+    kernel = note_kernel or ("k_tlin9" if label.startswith("tlin9") else KERNEL_OF.get(cls, cls))
     if rec["flops"] > 0:
         ach = rec["flops"] / launches / avg_s / 1e12
         split = not os.environ.get("TMDNET_NO_SPLIT_BF16")
@@ -162,8 +162,8 @@ def pmc_kernel_bytes(pmc, cls, label):
     per = pmc.get("_per_kernel_total", {})
     head = label.split(" ")[0].split("(")[0]
     names = {"gemm_dual<2>": ["k_edge_mlp", "k_gemm_dual_sb2<2>"], "gemm_dual<0>": ["k_gemm_dual_sb2<0>"],
-             "launch_message": ["k_message_rows8<8, 4>", "k_message"],
-             "launch_message_adjoint_gd": ["k_message_adjoint_gd"],
+             "launch_message": ["k_message_rows8<8, 4>", "k_message<false>", "k_message<true>", "k_message"],
+             "launch_message_adjoint_gd": ["k_message_adjoint_gd<false>", "k_message_adjoint_gd<true>", "k_message_adjoint_gd"],
              "launch_edge_tables": ["k_edge_interp<3>", "k_edge_interp<2>", "k_edge_interp<4>", "k_edge_interp<1>"],
              "launch_embed_scatter": ["k_embed_scatter"], "launch_embed_pair_gd": ["k_embed_pair_gd_v4"],
              "launch_embed_combine": ["k_embed_combine<4, 2>"], "launch_embed_gm": ["k_embed_gm<4, 1, 8>"],
@@ -331,7 +331,7 @@ def water10k_leg(dev, L, steps=8, warmup=3, dt_fs=1.0):
             "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
 
 
-AUX_KERNEL_PREFIX = {"launch_message_adjoint_gd": "k_message_adjoint_gd", "launch_message": "k_message", "gemm": "k_gemm_sb1",
+AUX_KERNEL_PREFIX = {"launch_message_adjoint_gd": "k_message_adjoint_gd", "launch_message": "k_message<", "gemm": "k_gemm_sb1",
                      "gemm_dual<1>": "k_gemm_dual_sb2<1>", "gemm_dual<2>": "k_gemm_dual_sb2<2>", "tensor_linear": "k_gemm_sb1<0>"}
 
 
