@@ -1284,8 +1284,10 @@ int tmdnet_forward_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64
   // the radial-basis embedding's buffers depend on the species count of the graph the call will run on: sized for the
   // largest padding (8) whenever that path can be taken, so the answer does not depend on which build came last
   const bool rb_possible = m->rb_fwd && !m->et && !m->train && n_pairs >= 0 && n_atoms >= m->rb_min_atoms;
+  // recompute_pair_rows: the Q / dQ rows go only when the graph this handle built last takes the radial-basis embedding (its
+  // species count is known by now: tmdnet_build_graph precedes this query); otherwise they stay in the plan
   carve_fwd(nullptr, m->hp, n_atoms, n_mol, n_pairs, want_forces != 0, bytes, rb_possible ? 8 : 0,
-            m->recompute_rows ? (rb_possible ? 7 : 5) : 0);
+            m->recompute_rows ? (rb_possible && rb_ntp(m, n_atoms, n_pairs) > 0 ? 7 : 5) : 0);
   return TMDNET_OK;
 }
 
