@@ -496,8 +496,9 @@ def test_fused_small_system_kernels_vs_oracle(hip_lib, F, L, group):
 
 
 def test_fused_small_system_kernels_equal_the_unfused_schedule(hip_lib, tmp_path):
-    """Same model, same 64-atom molecule (with a total charge), fused per-atom kernels vs the general schedule (developer switch
-    TMDNET_SMALL_FUSED_MAX=0, read once per process: a child process).  Both are fp32; they differ by summation order only."""
+    """Same model, the same batches (with total charges), per-atom phase kernels - one atom per block at 128 atoms, four per block at
+    768 - vs the general schedule (developer switches TMDNET_SMALL_FUSED_MAX=0 TMDNET_MID_FUSED_MAX=0, read once per process: a
+    child process).  Both are fp32; they differ by summation order only."""
     import subprocess
     import sys
     from torchmdnet_amd import workloads as W
@@ -510,16 +511,59 @@ def test_fused_small_system_kernels_equal_the_unfused_schedule(hip_lib, tmp_path
         "from torchmdnet_amd.models.model import create_model\n"
         "torch.manual_seed(0)\n"
         "m = create_model(dict(W.C2_ARGS)).cuda()\n"
-        "z, pos, batch = (t.cuda() for t in W.synthetic_batch(n_mol=2, n_atoms=64))\n"
-        "E, F = m(z, pos, batch, q=torch.tensor([1.0, -2.0], device='cuda'))\n"
-        "torch.save({'E': E.cpu(), 'F': F.cpu()}, sys.argv[2])\n")
+        "out = {}\n"
+        "for n_mol in (2, 12):\n"  # 128 atoms: one atom per block (tn_small.hip); 768 atoms: four per block (tn_mid.hip)
+        "    z, pos, batch = (t.cuda() for t in W.synthetic_batch(n_mol=n_mol, n_atoms=64))\n"
+        "    q = torch.arange(n_mol, device='cuda', dtype=torch.float32) - 2.0\n"
+        "    E, F = m(z, pos, batch, q=q)\n"
+        "    out[n_mol] = {'E': E.cpu(), 'F': F.cpu()}\n"
+        "torch.save(out, sys.argv[2])\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for name, env in (("fused", {}), ("unfused", {"TMDNET_SMALL_FUSED_MAX": "0"})):
+    for name, env in (("fused", {}), ("unfused", {"TMDNET_SMALL_FUSED_MAX": "0", "TMDNET_MID_FUSED_MAX": "0"})):
         path = str(tmp_path / (name + ".pt"))
         r = subprocess.run([sys.executable, "-c", script, root, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-1500:]
         outs[name] = torch.load(path)
-    assert rel_err(outs["fused"]["E"], outs["unfused"]["E"]) < 1e-5
-    assert rel_err(outs["fused"]["F"], outs["unfused"]["F"]) < 1e-5
-    assert not torch.equal(outs["fused"]["F"], outs["unfused"]["F"])  # the switch did select another schedule
+    for n_mol in (2, 12):
+        assert rel_err(outs["fused"][n_mol]["E"], outs["unfused"][n_mol]["E"]) < 1e-5
+        assert rel_err(outs["fused"][n_mol]["F"], outs["unfused"][n_mol]["F"]) < 1e-5
+        assert not torch.equal(outs["fused"][n_mol]["F"], outs["unfused"][n_mol]["F"])  # the switches did select another schedule
+
+
+@pytest.mark.parametrize("F,L,group", [(64, 1, "SO(3)"), (128, 2, "O(3)")])
+def test_four_atoms_per_block_phase_kernels_vs_oracle(hip_lib, F, L, group):
+    """csrc/tn_mid.hip (513 .. 1 024 atoms): three molecules of 201 atoms - 603 is not a multiple of four: the last block holds three
+    atoms - with total charges, and one periodic 600-atom system; oracle = tensornet_torch, fp32 bound 1e-4."""
+    import ctypes as C
+    import bench
+    from oracle import tensornet_torch as T
+    from torchmdnet_amd import _C, workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.C2_ARGS, embedding_dimension=F, num_layers=L, num_rbf=16, equivariance_invariance_group=group, max_z=20)
+    torch.manual_seed(7)
+    model = create_model(dict(args)).to("cuda")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hp = T.hparams_from_args(args)
+    z, pos, batch = W.synthetic_batch(n_mol=3, n_atoms=201, first_seed=900)
+    z = z % 19 + 1
+    q = torch.tensor([1.0, 0.0, -2.0])
+    lib = _C.lib()
+    E, Fo = model(z.cuda(), pos.cuda(), batch.cuda(), q=q.cuda())  # (the first call creates the engine handle the profiler hangs on)
+    bench.profile_begin(model, lib)
+    model(z.cuda(), pos.cuda(), batch.cuda(), q=q.cuda())
+    _, groups = bench.profile_records(model, lib, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    labels = " ".join(label for (_, label) in groups)
+    assert "launch_mid_embed" in labels and "launch_mid_layer" in labels and "launch_mid_rev" in labels, labels
+    Er, Fr = T.energy_and_forces(sd, hp, z, pos, batch, q=q)
+    assert rel_err(E.cpu(), Er) < REL and rel_err(Fo.cpu(), Fr) < REL
+    e_only = _model_from_sd(dict(args, derivative=False), sd)
+    # energy-only call: the same forward kernels; the molecule sums are taken by another kernel in another (fixed) order
+    assert rel_err(e_only(z.cuda(), pos.cuda(), batch.cuda(), q=q.cuda())[0].reshape(-1), E.reshape(-1)) < 1e-6
+    zb, pb, box = W.water_box(n_side=6)  # 648 atoms, 18.6 A box, brute force with minimum image
+    zb, pb = zb[:600], pb[:600]
+    bb = torch.zeros_like(zb)
+    Eb, Fb = model(zb.cuda(), pb.cuda(), bb.cuda(), box=box.cuda())
+    Ebr, Fbr = T.energy_and_forces(sd, hp, zb, pb, bb, box=box)
+    assert rel_err(Eb.cpu(), Ebr) < REL and rel_err(Fb.cpu(), Fbr) < REL

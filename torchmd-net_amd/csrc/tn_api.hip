@@ -1393,7 +1393,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     const float h_ = (hp.cutoff_upper - hp.cutoff_lower) / (float)m->tabs.T;  // the expressions of launch_edge_interp
     rts[l] = PairRowTable{m->tabs.tab[1 + l], g.pd, g.counts, hp.cutoff_lower, h_, 1.0f / h_, m->tabs.T};
   }
-  const bool fused_small = !tc && !ntp && !recompute && small_fused_ok(N, F, H, L) &&
+  const bool use_mid = !small_fused_ok(N, F, H, L);  // 513 .. 1 024 atoms: four atoms per block (tn_mid.hip)
+  const bool fused_small = !tc && !ntp && !recompute && (small_fused_ok(N, F, H, L) || mid_fused_ok(N, F, H, L)) &&
                            (!want_forces || (message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD")));
   if (run_fwd) {
     if (use_tab) {
@@ -1472,7 +1473,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       }
       ea.u0 = b.u0; ea.xh0 = b.xh0; ea.rstd0 = b.rstd0; ea.a1 = b.a1; ea.a2 = b.a2; ea.gates = b.gates; ea.UX = b.UX; ea.X0 = b.X[0];
       ea.Pn0 = b.Pn[0];
-      KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + 5 * nodeB, launch_small_embed(ea, s));
+      KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + 5 * nodeB, (use_mid ? launch_mid_embed(ea, s) : launch_small_embed(ea, s)));
       for (int l = 0; l < L; ++l) {
         const LayerP& q_ = W.layer[l];
         const bool last = l + 1 == L;
@@ -1489,7 +1490,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         la.bO2 = W.bO2; la.atomref = W.atomref; la.Lin = W.Lin; la.O1 = W.O1; la.std_ = W.std;
         la.xhr = b.xhr; la.rstdr = b.rstdr; la.al = b.al; la.x = b.x; la.ea = b.ea;
         if (want_forces) { la.G = b.G; la.gMi = b.gMi; la.gPn = b.gPn; }
-        KR(CAT_MESSAGE, wB + idxB + 6 * nodeB, launch_small_layer(la, last, s));
+        KR(CAT_MESSAGE, wB + idxB + 6 * nodeB, (use_mid ? launch_mid_layer(la, last, s) : launch_small_layer(la, last, s)));
       }
       if (!want_forces) KR(CAT_ELEMENTWISE, Nd * 4, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
     } else {
@@ -1582,7 +1583,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       ra.UX = b.UX; ra.gates = b.gates; ra.a2 = b.a2; ra.a1 = b.a1; ra.L2 = W.L2; ra.L1 = W.L1; ra.xh0 = b.xh0; ra.rstd0 = b.rstd0;
       ra.ln0_w = W.ln0_w; ra.u0 = b.u0; ra.gA = b.gA;
       if (l == L - 1) { ra.ea = b.ea; ra.batch = batch; ra.mean = W.mean; ra.energy = energy; }
-      KR(CAT_MESSAGE, 2 * wB + idxB + 6 * nodeB + 8 * (Pd + 1) * gd_nw, launch_small_rev(ra, s));
+      KR(CAT_MESSAGE, 2 * wB + idxB + 6 * nodeB + 8 * (Pd + 1) * gd_nw, (use_mid ? launch_mid_rev(ra, s) : launch_small_rev(ra, s)));
     }
     KR(CAT_PAIR, Pd * (24 * Fd + 24) + Nd * 10 * Fd * 4,
        launch_embed_pair_gd(g, P, F, z, W.Utab, W.Vtab, b.Q, b.dQ, b.C, b.dC, b.gA, b.gd, b.g_rhat, s, b.g_delta, b.gd_slots, L * gd_nw,

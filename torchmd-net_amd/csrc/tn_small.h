@@ -71,6 +71,11 @@ struct SmallRevArgs {  // adjoint sweep (+ distance-gradient slots) -> linear^T 
 };
 
 bool small_fused_ok(int N, int F, int H, int L);
+// four atoms per block (tn_mid.hip): same argument structs, same cut of the step; systems of 513 .. 1 024 atoms
+bool mid_fused_ok(int N, int F, int H, int L);
+void launch_mid_embed(const SmallEmbedArgs& a, hipStream_t s);
+void launch_mid_layer(const SmallLayerArgs& a, bool last, hipStream_t s);
+void launch_mid_rev(const SmallRevArgs& a, hipStream_t s);
 void launch_small_embed(const SmallEmbedArgs& a, hipStream_t s);
 void launch_small_layer(const SmallLayerArgs& a, bool last, hipStream_t s);
 void launch_small_rev(const SmallRevArgs& a, hipStream_t s);

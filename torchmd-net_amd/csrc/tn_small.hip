@@ -27,50 +27,18 @@
 
 #include "tn_common.h"
 #include "tn_small.h"
+#include "tn_small_dev.h"
 
 namespace tn {
 
 namespace {
 
-constexpr int SM_G = 8;        // thread groups per block
-constexpr int SM_FMAX = 128;   // channels
-struct Blk {
-  int F, g, f, tid, T;
-};
-
-struct SmallLds {
+struct __attribute__((aligned(16))) SmallLds {
   float part[SM_G * 10 * SM_FMAX];  // partial sums [group][component][channel] (sweeps: 9 or 10 components) / [k-group][output]
   float xs[10 * SM_FMAX];           // input of a tensor linear [component][channel]; reduced partial sums
   float va[3 * SM_FMAX], vb[3 * SM_FMAX], vc[3 * SM_FMAX];  // vectors of the MLP chains
 };
 
-__device__ __forceinline__ void ld9(const float* __restrict__ p, int F, float u[9]) {
-#pragma unroll
-  for (int c = 0; c < 9; ++c) u[c] = p[c * F];
-}
-__device__ __forceinline__ void st9(float* __restrict__ p, int F, const float u[9]) {
-#pragma unroll
-  for (int c = 0; c < 9; ++c) p[c * F] = u[c];
-}
-
-// ---- nine-component linear: every thread its share KQ = F / 8 of the input channels; the sums of the groups meet in part.
-// Weights come from L2 and a block streams all 3 F^2 of them through its CU's miss path (~4 us per product, in-kernel
-// timestamps): they are REQUESTED early (tlin_issue: 3 KQ registers) - before the sweep, or before group 0's 3x3 algebra - and
-// multiplied once the input vector is in xs (tlin_finish).
-template <int KQ>
-struct TlinW {
-  float w0[KQ], w1[KQ], w2[KQ];
-};
-template <int KQ>
-__device__ __forceinline__ void tlin_issue(const float* const W[3], const Blk& b, TlinW<KQ>& t) {
-  const int F = b.F, k0 = b.g * KQ;
-#pragma unroll
-  for (int k = 0; k < KQ; ++k) {
-    t.w0[k] = W[0][(k0 + k) * F + b.f];
-    t.w1[k] = W[1][(k0 + k) * F + b.f];
-    t.w2[k] = W[2][(k0 + k) * F + b.f];
-  }
-}
 // sum of the groups' partial sums, every thread of the block calls (one barrier inside): group g adds up component g (groups 0
 // and 1 also components 8 and 9) into xs, group 0 then picks up its NC values.  Group 0 alone reading all 8 NC partials kept 72
 // LDS results in registers next to its 3x3 algebra (30 registers spilled at the 128-register limit of a 1024-thread block).
@@ -99,20 +67,7 @@ __device__ __forceinline__ void tlin_finish(const TlinW<KQ>& t, const float u[9]
   }
   __syncthreads();
   float acc[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) acc[c] = 0.f;
-#pragma unroll
-  for (int k = 0; k < KQ; ++k) {
-    acc[0] += t.w0[k] * L.xs[k0 + k];
-    acc[1] += t.w1[k] * L.xs[F + k0 + k];
-    acc[2] += t.w1[k] * L.xs[2 * F + k0 + k];
-    acc[3] += t.w1[k] * L.xs[3 * F + k0 + k];
-    acc[4] += t.w2[k] * L.xs[4 * F + k0 + k];
-    acc[5] += t.w2[k] * L.xs[5 * F + k0 + k];
-    acc[6] += t.w2[k] * L.xs[6 * F + k0 + k];
-    acc[7] += t.w2[k] * L.xs[7 * F + k0 + k];
-    acc[8] += t.w2[k] * L.xs[8 * F + k0 + k];
-  }
+  tlin_fma<KQ>(t, L.xs, F, k0, acc);
 #pragma unroll
   for (int c = 0; c < 9; ++c) L.part[(b.g * 9 + c) * F + b.f] = acc[c];
   __syncthreads();
@@ -131,20 +86,7 @@ __device__ __forceinline__ void tlin_now(const float* const W[3], const float u[
   TlinW<KQ> t;
   tlin_issue<KQ>(W, b, t);
   float acc[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) acc[c] = 0.f;
-#pragma unroll
-  for (int k = 0; k < KQ; ++k) {
-    acc[0] += t.w0[k] * L.xs[k0 + k];
-    acc[1] += t.w1[k] * L.xs[F + k0 + k];
-    acc[2] += t.w1[k] * L.xs[2 * F + k0 + k];
-    acc[3] += t.w1[k] * L.xs[3 * F + k0 + k];
-    acc[4] += t.w2[k] * L.xs[4 * F + k0 + k];
-    acc[5] += t.w2[k] * L.xs[5 * F + k0 + k];
-    acc[6] += t.w2[k] * L.xs[6 * F + k0 + k];
-    acc[7] += t.w2[k] * L.xs[7 * F + k0 + k];
-    acc[8] += t.w2[k] * L.xs[8 * F + k0 + k];
-  }
+  tlin_fma<KQ>(t, L.xs, F, k0, acc);
 #pragma unroll
   for (int c = 0; c < 9; ++c) L.part[(b.g * 9 + c) * F + b.f] = acc[c];
   __syncthreads();
@@ -154,43 +96,17 @@ __device__ __forceinline__ void tlin_now(const float* const W[3], const float u[
 // ---- y[n] = bias[n] + sum_k WT[k, n] x[k]  (x, y in LDS; every thread of the block calls; y is visible on return).  Nout % 4 == 0.
 // A thread owns four consecutive outputs (one 16-byte weight load per input channel) and a slice of the input channels; up to
 // sixteen slices, their sums added in a fixed order.  Eight loads in flight per thread.
-constexpr int SM_MV_KG = 16;
-typedef float f4 __attribute__((ext_vector_type(4)));
-struct MvW {
-  f4 w[8];
-};
-// the slice of the input channels thread tid multiplies: [k0, k1)
-__device__ __forceinline__ bool mv_slice(int K, int Nout, const Blk& b, int& c4, int& q, int& k0, int& k1) {
-  const int n4 = Nout >> 2;
-  const int kg = min(b.T / n4, SM_MV_KG);
-  q = b.tid / n4;
-  c4 = b.tid - q * n4;
-  const int kq = (K + kg - 1) / kg;
-  k0 = q * kq;
-  k1 = min(K, k0 + kq);
-  return q < kg;
-}
-// request the first eight weight rows of the thread's slice ahead of time (while the input vector is still being made)
-__device__ __forceinline__ void mv_issue(const float* __restrict__ WT, int K, int Nout, const Blk& b, MvW& t) {
-  int c4, q, k0, k1;
-  if (!mv_slice(K, Nout, b, c4, q, k0, k1)) return;
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-    if (k0 + u < k1) t.w[u] = *reinterpret_cast<const f4*>(WT + (int64_t)(k0 + u) * Nout + 4 * c4);
-}
 template <bool PRE>
 __device__ __forceinline__ void matvec_(const float* __restrict__ WT, const float* __restrict__ bias, const float* x, int K, int Nout,
                                         float* part, float* y, const Blk& b, const MvW* pre) {
   int c4, q, k0, k1;
-  const bool on = mv_slice(K, Nout, b, c4, q, k0, k1);
-  const int kg = min(b.T / (Nout >> 2), SM_MV_KG);
-  if (on) {
-    f4 acc = (f4)(0.f);
+  const int kg = mv_slice(K, Nout, b, c4, q, k0, k1);  // slices in use
+  if (q < kg) {
+    f4 acc[1] = {(f4)(0.f)};
     int k = k0;
-    if (PRE) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (k0 + u < k1) acc += pre->w[u] * x[k0 + u];
+    if (PRE) {  // the first eight rows were requested ahead
+      mv_fma4<1>(pre->w, x, 0, k0, acc);
+      if (k0 + 4 < k1) mv_fma4<1>(pre->w + 4, x, 0, k0 + 4, acc);
       k = min(k1, k0 + 8);
     }
 #pragma unroll 1
@@ -198,12 +114,16 @@ __device__ __forceinline__ void matvec_(const float* __restrict__ WT, const floa
       f4 wv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const f4*>(WT + (int64_t)(k + u) * Nout + 4 * c4);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += wv[u] * x[k + u];
+      mv_fma4<1>(wv, x, 0, k, acc);
+      mv_fma4<1>(wv + 4, x, 0, k + 4, acc);
     }
-#pragma unroll 1
-    for (; k < k1; ++k) acc += *reinterpret_cast<const f4*>(WT + (int64_t)k * Nout + 4 * c4) * x[k];
-    *reinterpret_cast<f4*>(part + q * Nout + 4 * c4) = acc;
+    if (k < k1) {  // one more piece of four
+      f4 wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const f4*>(WT + (int64_t)(k + u) * Nout + 4 * c4);
+      mv_fma4<1>(wv, x, 0, k, acc);
+    }
+    *reinterpret_cast<f4*>(part + q * Nout + 4 * c4) = acc[0];
   }
   __syncthreads();
   if (b.tid < Nout) {
@@ -220,78 +140,6 @@ __device__ __forceinline__ void matvec(const float* __restrict__ WT, const float
 __device__ __forceinline__ void matvec(const float* __restrict__ WT, const float* __restrict__ bias, const float* x, int K, int Nout,
                                        float* part, float* y, const Blk& b, const MvW& pre) {
   matvec_<true>(WT, bias, x, K, Nout, part, y, b, &pre);
-}
-
-// LayerNorm statistics of v[0..R) (LDS), computed by every wave for itself: no barrier
-__device__ __forceinline__ void row_stats(const float* v, int R, float& mean, float& rs) {
-  const int lane = threadIdx.x & 63;
-  float s = 0.f;
-  for (int k = lane; k < R; k += 64) s += v[k];
-  mean = wave_sum(s) / R;
-  float var = 0.f;
-  for (int k = lane; k < R; k += 64) {
-    const float d = v[k] - mean;
-    var += d * d;
-  }
-  rs = 1.0f / sqrtf(wave_sum(var) / R + 1e-5f);
-}
-// LayerNorm adjoint sums of g (LDS) against the stored normalised row xh (global) and the weight w: s1 = mean(g w), s2 = mean(g w xh)
-__device__ __forceinline__ void lnbwd_stats(const float* g, const float* __restrict__ xh, const float* __restrict__ w, int R, float& s1,
-                                            float& s2) {
-  const int lane = threadIdx.x & 63;
-  float a = 0.f, c = 0.f;
-  for (int k = lane; k < R; k += 64) {
-    const float gw = g[k] * w[k];
-    a += gw;
-    c += gw * xh[k];
-  }
-  s1 = wave_sum(a) / R;
-  s2 = wave_sum(c) / R;
-}
-
-// group product + normalisation (reference tensornet.py:800-806): C_hat from Y = Pn[i], M = message
-__device__ __forceinline__ void group_product(const float y[9], const float m[9], int o3, float kap, float ch[9]) {
-  const M3 Y = compose(y), M = compose(m);
-  const M3 Cm = o3 ? scale(add(matmul(Y, M), matmul(M, Y)), kap) : scale(matmul(Y, M), 2.0f);
-  decompose(Cm, ch);
-  const float inv = 1.0f / (frob2(Cm) + 1.0f);
-#pragma unroll
-  for (int c = 0; c < 9; ++c) ch[c] *= inv;
-}
-// its adjoint (k_message_bwd_node)
-__device__ __forceinline__ void group_product_bwd(const float gc[9], const float y[9], const float m[9], int o3, float kap, float gm[9],
-                                                  float gy[9]) {
-  const M3 Y = compose(y), M = compose(m);
-  const M3 Cm = o3 ? scale(add(matmul(Y, M), matmul(M, Y)), kap) : scale(matmul(Y, M), 2.0f);
-  float uc[9];
-  decompose(Cm, uc);
-  const float inv = 1.0f / (frob2(Cm) + 1.0f);
-  float dot = 0.f, guc[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) {
-    dot += gc[c] * uc[c];
-    guc[c] = gc[c] * inv;
-  }
-  const float g_t = -dot * inv * inv;
-  const M3 gCm = add(decompose_T(guc), scale(Cm, 2.0f * g_t));
-  const M3 Yt = transpose(Y), Mt = transpose(M);
-  M3 gY, gM;
-  if (o3) {
-    gY = scale(add(matmul(gCm, Mt), matmul(Mt, gCm)), kap);
-    gM = scale(add(matmul(Yt, gCm), matmul(gCm, Yt)), kap);
-  } else {
-    gY = scale(matmul(gCm, Mt), 2.0f);
-    gM = scale(matmul(Yt, gCm), 2.0f);
-  }
-  compose_T(gM, gm);
-  compose_T(gY, gy);
-}
-// g_D = compose^T(Gf + kappa (Gf dX^T + dX^T Gf)), Gf = dec^T(G)   (k_update_bwd)
-__device__ __forceinline__ void update_bwd(const float gg[9], const float d[9], float kap, float o[9]) {
-  const M3 Gf = decompose_T(gg);
-  const M3 dXt = transpose(compose(d));
-  const M3 gdx = add(Gf, scale(add(matmul(Gf, dXt), matmul(dXt, Gf)), kap));
-  compose_T(gdx, o);
 }
 
 // message sweep of row i by the block's groups (k_message_split): acc = sum_e w[pair, type(c)] * src[col, c]; MODE 2 also the
