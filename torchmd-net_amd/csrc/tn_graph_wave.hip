@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void k_nbr_link_wave(Graph g, int N) {
 // barriers (the arrays are written and read through global memory by the same CU: a barrier orders them).  Same row
 // functions as the general kernels: identical graph.
 constexpr int GS_MAX_ATOMS = 256;
+constexpr int GS_ECAP = 16384;  // adjacency entries kept in LDS (64 KB): 256 atoms x 64 neighbours
 __global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __restrict__ pos, const int64_t* __restrict__ batch,
                                                       const float* __restrict__ box, int box_mode, int N, int B, float lo2, float up2,
                                                       int loop, const int64_t* __restrict__ z, int max_z) {
@@ -141,6 +142,11 @@ __global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __re
   __shared__ int s_rowptr[GS_MAX_ATOMS + 1], s_pairptr[GS_MAX_ATOMS + 1], s_counts[8], c_low[4], c_tot[4];
   __shared__ float s_pos[3 * GS_MAX_ATOMS];
   __shared__ int64_t s_batch[GS_MAX_ATOMS];
+  // the neighbour columns too (when the capacity fits): the link phase finds the pair id of every upper neighbour by a binary
+  // search in the partner's row - five to six DEPENDENT reads per edge, which were round trips to L2 for data this block had
+  // written a moment ago (in-kernel share: most of the kernel's 14 us at 64 atoms)
+  __shared__ int s_col[GS_ECAP];
+  const bool col_lds = g.ecap <= GS_ECAP;  // uniform
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool mol_lds = B <= GS_MAX_ATOMS;  // more molecule slots than atoms (empty molecules): ranges stay in global memory
   Graph gl = g;
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __re
     gl.mstart = s_mstart;
     gl.mend = s_mend;
   }
+  if (col_lds) gl.col = s_col;
   for (int k = tid; k < 3 * N; k += 1024) s_pos[k] = pos[k];
   if (tid < N) s_batch[tid] = batch[tid];
   for (int i = tid; i < B; i += 1024) gl.mstart[i] = gl.mend[i] = 0;  // k_graph_reset
@@ -233,6 +240,11 @@ __global__ __launch_bounds__(1024) void k_graph_small(Graph g, const float* __re
     for (int i = wave; i < N; i += 16) nbr_wave_row<true>(gl, s_pos, s_batch, box, box_mode, N, B, lo2, up2, loop, i, lane);
     __syncthreads();
     for (int i = wave; i < N; i += 16) nbr_link_row(gl, i, lane);
+    if (col_lds) {
+      __syncthreads();
+      const int E = s_counts[1];
+      for (int e = tid; e < E; e += 1024) g.col[e] = s_col[e];
+    }
   }
   // the global copies the later kernels (and the host, for the flags) read
   if (tid <= N) {
