@@ -44,7 +44,7 @@ N_MOL, N_ATOMS = 256, 64
 PEAK = {"mfma_f32_tflops": 157.3, "mfma_bf16_tflops": 2500.0, "hbm_gbs": 8000.0}
 SPLIT_PRODUCTS = 6
 # HIP kernels behind each profiled class (rocprofv3 names, profiles/r02_kernel_stats*.csv)
-KERNEL_OF = {"gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_sb1", "message": "k_message_rows8 / k_message_adjoint_gd",
+KERNEL_OF = {"gemm_edge": "k_gemm_dual_sb2", "gemm_node": "k_gemm_sb1", "message": "k_message_rows8 / k_message_adjoint_rows8",
              "edge_table": "k_edge_interp (+ k_pair_cutoff_hist, k_bucket_scan, k_bucket_scatter)",
              "pair_bwd": "k_embed_gm / k_embed_pair_rb8", "embed_scatter": "k_embed_moments / k_embed_combine", "elementwise": "elementwise",
              "graph": "k_nbr_wave / k_scan_counts"}
@@ -171,7 +171,7 @@ def pmc_kernel_bytes(pmc, cls, label):
     head = label.split(" ")[0].split("(")[0]
     names = {"gemm_dual<2>": ["k_edge_mlp", "k_gemm_dual_sb2<2>"], "gemm_dual<0>": ["k_gemm_dual_sb2<0>"],
              "launch_message": ["k_message_rows8<8, 4>", "k_message<false>", "k_message<true>", "k_message"],
-             "launch_message_adjoint_gd": ["k_message_adjoint_gd<false>", "k_message_adjoint_gd<true>", "k_message_adjoint_gd"],
+             "launch_message_adjoint_gd": ["k_message_adjoint_rows8", "k_message_adjoint_gd<false>", "k_message_adjoint_gd<true>", "k_message_adjoint_gd"],
              "launch_edge_tables": ["k_edge_interp<3>", "k_edge_interp<2>", "k_edge_interp<4>", "k_edge_interp<1>"],
              "launch_embed_scatter": ["k_embed_scatter"], "launch_embed_pair_gd": ["k_embed_pair_gd_v4"],
              "launch_embed_combine": ["k_embed_combine<4, 2>"], "launch_embed_gm": ["k_embed_gm<4, 1, 8>"],

@@ -65,7 +65,8 @@ SWITCHES = {"TMDNET_NO_MSG_ROWS8": "1", "TMDNET_NO_SPLIT_BF16": "1", "TMDNET_NO_
             "TMDNET_EMBED_RB": "0", "TMDNET_SEPARATE_PAIR_GD": "1", "TMDNET_NO_SKINNY": "1", "TMDNET_NO_GRAPH_SMALL": "1",
             "TMDNET_ET_GENERIC_SWEEPS": "1", "TMDNET_SIDE_STREAM": "1", "TMDNET_EI_RUN": "3", "TMDNET_EDGE_DIRECT_MAX": "0",
             "TMDNET_SPLIT_ROWS": "0", "TMDNET_GEMM_BPC": "2", "TMDNET_EDGE_TABLE_MIN_PAIRS": "100000000", "TMDNET_NO_TLIN9": "1",
-            "TMDNET_MSG_NOBALANCE": "1", "TMDNET_SMALL_FUSED_MAX": "0", "TMDNET_MID_FUSED_MAX": "0"}
+            "TMDNET_MSG_NOBALANCE": "1", "TMDNET_SMALL_FUSED_MAX": "0", "TMDNET_MID_FUSED_MAX": "0",
+            "TMDNET_NO_ADJ_ROWS8": "1"}
 NOT_KERNEL_SWITCHES = {"TMDNET_DEBUG", "TMDNET_REFERENCE_ROOT"}  # error-message verbosity; location of the reference for CPU tests
 COMBOS.update({k.lower(): {k: v} for k, v in SWITCHES.items()})
 

@@ -1563,7 +1563,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   }
 
   if (want_forces && run_bwd && fused_small) {
-    const int gd_nw = message_adjoint_gd_waves(g, N, F);
+    const int gd_nw = message_adjoint_gd_waves(g, N, F, recompute);
     const int64_t gd_stride = 2 * (int64_t)P1;
     for (int l = L - 1; l >= 0; --l) {
       const LayerP& q_ = W.layer[l];
@@ -1626,7 +1626,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
     const bool merged_gd = message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD") && !tc;
     const bool t9r = !tc && L > 0 && tlin9_ok(N, F) && tlin9_images(W.UeT) && tlin9_images(W.layer[0].VT);
-    const int gd_nw = message_adjoint_gd_waves(g, N, F);
+    const int gd_nw = message_adjoint_gd_waves(g, N, F, recompute);
     const int64_t gd_stride = 2 * (int64_t)P1;
     if (!merged_gd) launch_fill(b.gd, 0.f, P1, s);  // the per-layer pair kernels accumulate into it
     for (int l = L - 1; l >= 0; --l) {

@@ -89,7 +89,10 @@ void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const 
 // adjoint sweep + the layer's per-pair distance gradient in one pass (replaces launch_message_adjoint + launch_pair_gd when
 // message_adjoint_gd_ok): partial sums go to slots[wave][2 * pair + direction], summed by launch_geom_gd
 bool message_adjoint_gd_ok(int N, int F);
-int message_adjoint_gd_waves(const Graph& g, int N, int F);  // number of slot arrays the sweep writes per layer
+int message_adjoint_gd_waves(const Graph& g, int N, int F, bool rows_from_table = false);  // slot arrays the sweep writes per layer
+bool message_adjoint_pair_ok(const Graph& g, int N, int F);  // tn_message_pair.hip: the reverse sweep in the tile layout
+void launch_message_adjoint_pair(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
+                                 float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt = nullptr);
 // next = 0: plain; 1: nxt = X_hat of the new X (next layer's k_norm_x); 2: nxt = readout invariants of the new X

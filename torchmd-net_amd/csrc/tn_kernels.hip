@@ -927,7 +927,10 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
   for (int c = 0; c < 9; ++c) o[c * F] += acc[c];
 }
 bool message_adjoint_gd_ok(int N, int F) { return F % 64 == 0 && (split_rows_ok(N, F) || (N > kSplitRows && F <= 1024)); }
-int message_adjoint_gd_waves(const Graph& g, int N, int F) { return F / 64; }
+// slot arrays per layer: one per wave of the row kernel's block (F / 64), or one per 32-channel chunk of the tile kernel
+int message_adjoint_gd_waves(const Graph& g, int N, int F, bool rows_from_table) {
+  return (!rows_from_table && !split_rows_ok(N, F) && message_adjoint_pair_ok(g, N, F)) ? F / 32 : F / 64;
+}
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt) {
   if (N <= 0) return;
@@ -940,6 +943,8 @@ void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, con
                        slots, slot_stride);
     return;
   }
+  // batches of small molecules: the tile kernel (tn_message_pair.hip: gMi window and adjacency slice in LDS, balanced rows)
+  if (message_adjoint_pair_ok(g, N, F)) return launch_message_adjoint_pair(g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, s);
   hipLaunchKernelGGL((k_message_adjoint_gd<false>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride,
                      PairRowTable{});
 }

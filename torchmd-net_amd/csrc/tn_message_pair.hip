@@ -406,6 +406,280 @@ __global__ __launch_bounds__(64 * LPR) void k_message_rows8(Graph g, int N, int 
   for (int c = 0; c < 9; ++c) *reinterpret_cast<vf*>(o + c * F) = yy[c];
 }
 
+// Reverse sweep in the same tile layout with the same two devices (adjacency slice in LDS, balanced rows): the adjoint of the
+// message sum,  gPn[i] += sum_e w[p] * gMi[col(e)],  and the layer's distance-gradient halves
+// h(i <- j) = sum_{k,f} dw[p,k,f] * sum_{c in k} gMi[j,c,f] * Pn[i,c,f]  (k_message_adjoint_gd, tn_kernels.hip).  The gMi rows of
+// the tile's column window sit in LDS, the Pn row of the row being walked in registers (a helper group holds the LONG row's Pn
+// while it walks that row's tail, then its own); per edge a lane loads six 16-byte pieces (w, dw) and reads nine from LDS; the 8
+// lanes of a row reduce their channel products and lane 0 writes the slot (channel chunk, pair, direction): one writer per slot,
+// summed in fixed order by the embedding's pair kernel.  Tiles whose window or adjacency slice does not fit LDS are not taken by
+// this kernel at all (message_adjoint_pair_ok looks at the batch; the row kernel serves them).
+__global__ __launch_bounds__(512) void k_message_adjoint_rows8(Graph g, int N, int F, const float* __restrict__ w,
+                                                               const float* __restrict__ dw, const float* __restrict__ gMi,
+                                                               const float* __restrict__ Pn, float* __restrict__ gPn,
+                                                               float* __restrict__ slots, int64_t slot_stride, int nchunks) {
+  constexpr int LPR = 8, VW = 4, FC = 32, THREADS = 512, PIECES = FC / 4, U = 2;
+  typedef f4v vf;
+  auto ldv = [](const float* p) { return *reinterpret_cast<const vf*>(p); };
+  __shared__ __attribute__((aligned(16))) float win[MP_W * 9 * FC];
+  __shared__ __attribute__((aligned(16))) float s_help[(MP_TA / 2) * 9 * FC];
+  __shared__ int s_col[MP_E], s_pair[MP_E];
+  __shared__ int s_lo[THREADS / 64], s_hi[THREADS / 64], s_rp[MP_TA], s_len[MP_TA], s_rank[MP_TA], s_byrank[MP_TA];
+  if (g.counts[2]) return;
+  const int b = xcd_chunk(blockIdx.x, gridDim.x);
+  const int tile = b / nchunks, chunk = b - tile * nchunks;
+  const int r0 = tile * MP_TA, r1 = min(N, r0 + MP_TA);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int F9 = 9 * F, F3 = 3 * F, c0 = chunk * FC;
+
+  const int eT0 = g.rowptr[r0], nE = g.rowptr[r1] - eT0;
+  const bool csr_lds = nE <= MP_E;  // block-uniform
+  int lo = 0x7fffffff, hi = -1;
+  {
+    int cbuf[MP_E / THREADS], pbuf[MP_E / THREADS];
+    if (csr_lds) {
+#pragma unroll
+      for (int k = 0; k < MP_E / THREADS; ++k) {
+        const int idx = tid + k * THREADS;
+        if (idx < nE) {
+          cbuf[k] = g.col[eT0 + idx];
+          pbuf[k] = g.epair[eT0 + idx];
+        }
+      }
+    }
+    if (tid < MP_TA) {
+      const int rr = min(r0 + tid, r1);
+      const int a0 = g.rowptr[rr], a1 = g.rowptr[min(rr + 1, r1)];
+      s_rp[tid] = a0 - eT0;
+      s_len[tid] = a1 - a0;
+      if (a1 > a0) {
+        lo = g.col[a0];
+        hi = g.col[a1 - 1];
+      }
+    }
+    if (csr_lds) {
+#pragma unroll
+      for (int k = 0; k < MP_E / THREADS; ++k) {
+        const int idx = tid + k * THREADS;
+        if (idx < nE) {
+          s_col[idx] = cbuf[k];
+          s_pair[idx] = pbuf[k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off, 64));
+    hi = max(hi, __shfl_xor(hi, off, 64));
+  }
+  if (lane == 0) {
+    s_lo[wave] = lo;
+    s_hi[wave] = hi;
+  }
+  __syncthreads();
+  lo = s_lo[0];
+  hi = s_hi[0];
+#pragma unroll
+  for (int k = 1; k < THREADS / 64; ++k) {
+    lo = min(lo, s_lo[k]);
+    hi = max(hi, s_hi[k]);
+  }
+  const int wn = hi - lo + 1;
+  const bool staged = hi >= lo && wn <= MP_W;  // block-uniform
+  {
+    const int pieces = staged ? wn * 9 * PIECES : 0;
+    constexpr int NIT = (MP_W * 9 * PIECES + THREADS - 1) / THREADS;
+    f4v tmp[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = tid + k * THREADS;
+      if (idx < pieces) {
+        const int rc = idx / PIECES, f4 = (idx % PIECES) << 2;
+        const int row = rc / 9, c = rc - row * 9;
+        tmp[k] = ldg4(gMi + (int64_t)(lo + row) * F9 + c * F + c0 + f4);
+      }
+    }
+    if (tid < MP_TA) {
+      const int mylen = s_len[tid];
+      int rank = 0;
+      for (int r = 0; r < MP_TA; ++r) {
+        const int l = s_len[r];
+        rank += (l > mylen || (l == mylen && r < tid)) ? 1 : 0;
+      }
+      s_rank[tid] = rank;
+      s_byrank[rank] = tid;
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = tid + k * THREADS;
+      if (idx < pieces) {
+        const int rc = idx / PIECES, f4 = (idx % PIECES) << 2;
+        *reinterpret_cast<f4v*>(&win[rc * FC + f4]) = tmp[k];
+      }
+    }
+    __syncthreads();
+  }
+
+  const int rl = tid / LPR, i = r0 + rl, ql = tid & (LPR - 1), f = c0 + VW * ql;
+  const bool live = i < r1;
+  vf acc[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) acc[c] = (vf)(0.f);
+  int help_slot = -1;
+  float* const slot_base = slots + (int64_t)chunk * slot_stride;
+
+  // segments: A = the tail of the partner's (long) row, walked first; B = the own row (or its head, when this row is a long one)
+  const int rank = s_rank[rl], partner = s_byrank[MP_TA - 1 - rank];
+  const int mylen = s_len[rl], plen = s_len[partner];
+  int baseA = 0, lenA = 0, rowA = r0, baseB = s_rp[rl], lenB = mylen, slotA = 0;
+  if (csr_lds) {
+    if (rank < MP_TA / 2) {
+      const int h = ((mylen - plen) / 2) & ~(U - 1);
+      lenB = mylen - h;
+      if (h > 0) help_slot = rank;
+    } else {
+      const int h = ((plen - mylen) / 2) & ~(U - 1);
+      lenA = h;
+      baseA = s_rp[partner] + plen - h;
+      rowA = r0 + partner;
+      slotA = MP_TA - 1 - rank;
+    }
+  }
+  auto seg_rot = [&](int base, int len, int row) __attribute__((always_inline)) {
+    unsigned best = 0xffffffffu;
+    if (csr_lds)
+      for (int pos = ql; pos < len; pos += LPR) best = min(best, ((unsigned)((row + s_col[base + pos]) & 63) << 16) | (unsigned)pos);
+    else
+      for (int pos = ql; pos < len; pos += LPR) best = min(best, ((unsigned)((row + g.col[eT0 + base + pos]) & 63) << 16) | (unsigned)pos);
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) best = min(best, (unsigned)__shfl_xor((int)best, off, 64));
+    return len > 0 ? (int)(best & 0xffffu) : 0;
+  };
+  const int rotA = seg_rot(baseA, lenA, rowA), rotB = seg_rot(baseB, lenB, i);
+  const int ntrip = lenA + lenB;
+  int nmax = ntrip;
+#pragma unroll
+  for (int off = LPR; off <= 32; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+
+  // (column, pair id) of trip t: LDS broadcast read (or, for a slice that did not fit, a global read)
+  auto idx_of = [&](int t, int& j, int& p) __attribute__((always_inline)) {
+    const bool inA = t < lenA;
+    const int tt = inA ? t : t - lenA, L = inA ? lenA : lenB;
+    int pos = (inA ? rotA : rotB) + min(tt, L - 1);
+    if (pos >= L) pos -= L;
+    const int entry = L > 0 ? (inA ? baseA : baseB) + pos : 0;
+    if (csr_lds) {
+      j = s_col[entry];
+      p = s_pair[entry];
+    } else {
+      j = nE > 0 ? g.col[eT0 + entry] : 0;
+      p = nE > 0 ? g.epair[eT0 + entry] : 0;
+    }
+  };
+  vf y[9];  // Pn row of the row being walked
+  auto load_y = [&](int row) __attribute__((always_inline)) {
+    const float* yp = Pn + (int64_t)min(row, N - 1) * F9 + f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) y[c] = ldv(yp + c * F);
+  };
+  auto park = [&]() __attribute__((always_inline)) {
+    float* hp = s_help + slotA * (9 * FC) + VW * ql;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      *reinterpret_cast<vf*>(hp + c * FC) = acc[c];
+      acc[c] = (vf)(0.f);
+    }
+    load_y(i);
+  };
+  bool parked = lenA == 0;
+  load_y(parked ? i : rowA);
+  int jn[U], pn[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) idx_of(u, jn[u], pn[u]);
+  for (int t = 0; t < nmax; t += U) {
+    if (!parked && t == lenA) {  // lenA is a multiple of U
+      park();
+      parked = true;
+    }
+    const int row_now = t < lenA ? rowA : i;
+    int jj[U], pp[U];
+    vf wv[U][3], dv[U][3];
+    float msk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      jj[u] = jn[u];
+      pp[u] = pn[u];
+      msk[u] = (t + u < ntrip) ? 1.0f : 0.0f;
+      const float* wp = w + (int64_t)pn[u] * F3 + f;
+      const float* dp = dw + (int64_t)pn[u] * F3 + f;
+      wv[u][0] = ldv(wp);
+      wv[u][1] = ldv(wp + F);
+      wv[u][2] = ldv(wp + 2 * F);
+      dv[u][0] = ldv(dp);
+      dv[u][1] = ldv(dp + F);
+      dv[u][2] = ldv(dp + 2 * F);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) idx_of(t + U + u, jn[u], pn[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      vf s9[9];
+      if (staged) {
+        const float* sp = win + (jj[u] - lo) * (9 * FC) + VW * ql;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) s9[c] = ldv(sp + c * FC);
+      } else {
+        const float* sp = gMi + (int64_t)jj[u] * F9 + f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) s9[c] = ldv(sp + c * F);
+      }
+      const vf w0 = wv[u][0] * msk[u], w1 = wv[u][1] * msk[u], w2 = wv[u][2] * msk[u];
+      acc[0] += w0 * s9[0];
+      acc[1] += w1 * s9[1];
+      acc[2] += w1 * s9[2];
+      acc[3] += w1 * s9[3];
+      acc[4] += w2 * s9[4];
+      acc[5] += w2 * s9[5];
+      acc[6] += w2 * s9[6];
+      acc[7] += w2 * s9[7];
+      acc[8] += w2 * s9[8];
+      const vf hv = dv[u][0] * (s9[0] * y[0]) + dv[u][1] * (s9[1] * y[1] + s9[2] * y[2] + s9[3] * y[3]) +
+                    dv[u][2] * (s9[4] * y[4] + s9[5] * y[5] + s9[6] * y[6] + s9[7] * y[7] + s9[8] * y[8]);
+      const float h = row_sum((hv[0] + hv[1]) + (hv[2] + hv[3]), LPR);
+      // slot (pair, direction): direction 0 when the walked row is the pair's i (its neighbour has the smaller index); self edge: none
+      if (ql == 0 && t + u < ntrip && jj[u] != row_now) slot_base[2 * pp[u] + (jj[u] < row_now ? 0 : 1)] = h;
+    }
+  }
+  if (!parked) park();  // a helper whose own row is empty
+  __syncthreads();      // the parked sums are complete
+  if (!live) return;
+  if (help_slot >= 0) {
+    const float* hp = s_help + help_slot * (9 * FC) + VW * ql;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] += ldv(hp + c * FC);
+  }
+  float* o = gPn + (int64_t)i * F9 + f;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    vf* op = reinterpret_cast<vf*>(o + c * F);
+    *op = *op + acc[c];
+  }
+}
+
+bool message_adjoint_pair_ok(const Graph& g, int N, int F) {
+  static const bool off2 = getenv("TMDNET_NO_ADJ_ROWS8") != nullptr;  // developer switch: the row kernel k_message_adjoint_gd
+  static const bool off = getenv("TMDNET_NO_MSG_ROWS8") != nullptr;   // developer switch: one-channel-per-lane sweeps
+  if (off || off2 || !g.small_mols || F < MP_FC || F % MP_FC) return false;
+  return (int64_t)((N + MP_TA - 1) / MP_TA) * (F / MP_FC) >= 512;
+}
+void launch_message_adjoint_pair(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
+                                 float* gPn, float* slots, int64_t slot_stride, hipStream_t s) {
+  const int nchunks = F / MP_FC, tiles = (N + MP_TA - 1) / MP_TA;
+  hipLaunchKernelGGL(k_message_adjoint_rows8, dim3(tiles * nchunks), dim3(512), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride,
+                     nchunks);
+}
+
 bool message_pair_ok(int N, int F) {
   static const bool off = getenv("TMDNET_NO_MSG_ROWS8") != nullptr;  // developer switch: one-channel-per-lane sweeps
   if (off || F < MP_FC || F % MP_FC) return false;
