@@ -168,3 +168,32 @@ def test_spatial_decomposition_gloo_world2(tmp_path):
     mp.spawn(_spatial_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert open(tmp_path / f"sp{r}").read() == "1"
+
+
+def test_spatial_evaluator_argument_checks_and_single_rank():
+    """Host logic of parallel.SpatialEvaluator: a triclinic box and a halo longer than the box are refused; world size 1 hands the whole
+    system through with unit weights; every atom is owned by exactly one slab and the slabs' halos hold periodic images only within
+    (num_layers + 1) cutoffs of the slab."""
+    from torchmdnet_amd.parallel import SpatialEvaluator
+
+    z, pos, box = _periodic_system(200, [20.0, 8.0, 9.0], seed=1)
+    ev = SpatialEvaluator(lambda *a: None, cutoff_upper=2.0, num_layers=1)
+    with pytest.raises(ValueError):
+        ev.local_system(pos, box + torch.tensor([[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.0, 0.0, 0.0]]), 0, 2)
+    with pytest.raises(ValueError):
+        SpatialEvaluator(lambda *a: None, cutoff_upper=8.0, num_layers=2).local_system(pos, box, 0, 2)  # halo 24 A > the 20 A box
+    g, p, b, n = ev.local_system(pos, box, 0, 1)
+    assert n == 200 and torch.equal(p, pos) and torch.equal(b, box)
+    owned = torch.zeros(200, dtype=torch.long)
+    for r in range(4):
+        gidx, pos_l, box_l, n_own = ev.local_system(pos, box, r, 4)
+        owned[gidx[:n_own]] += 1
+        x0, w, h = r * 5.0, 5.0, ev.halo
+        xa = pos_l[:, 0]
+        assert bool(((xa[:n_own] >= x0) & (xa[:n_own] < x0 + w)).all())
+        assert bool(((xa[n_own:] >= x0 - h - 1e-5) & (xa[n_own:] < x0 + w + h + 1e-5)).all())
+        assert float(box_l[0, 0]) > w + 2 * h + ev.cutoff  # more than one cutoff of vacuum between the images of the local box
+        # a ghost is a periodic image of its atom
+        d = torch.remainder(pos_l[n_own:, 0] - pos[gidx[n_own:], 0] + 10.0, 20.0) - 10.0
+        assert float(d.abs().max()) < 1e-4
+    assert bool((owned == 1).all())

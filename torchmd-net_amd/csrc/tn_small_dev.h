@@ -44,8 +44,8 @@ __device__ __forceinline__ void tlin_issue(const float* const W[3], const Blk& b
 }
 
 // acc[c] = sum_k w_type(c)[k] * x[c][k0 + k]: the input vector sits in LDS as [9][F]; every lane of a wave reads the same address
-// (k0 depends on the group only), so the reads are issue-bound - 16-byte reads: 9 KQ / 4 instructions instead of 9 KQ (in-kernel
-// timestamps: the tensor linear of one atom 4.0 -> see profiles/r04_notes.md section 7)
+// (k0 depends on the group only), so these reads are bound by instruction issue, not by LDS bandwidth: as 16-byte reads they are
+// 9 KQ / 4 instructions instead of 9 KQ (the 64-atom step went 0.137 -> 0.130 ms with this alone, profiles/r04_notes.md section 7)
 template <int KQ>
 __device__ __forceinline__ void tlin_fma(const TlinW<KQ>& t, const float* x /* LDS, 16-byte aligned */, int F, int k0, float acc[9]) {
   typedef float v4 __attribute__((ext_vector_type(4)));
