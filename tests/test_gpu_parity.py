@@ -561,6 +561,15 @@ def test_four_atoms_per_block_phase_kernels_vs_oracle(hip_lib, F, L, group):
     e_only = _model_from_sd(dict(args, derivative=False), sd)
     # energy-only call: the same forward kernels; the molecule sums are taken by another kernel in another (fixed) order
     assert rel_err(e_only(z.cuda(), pos.cuda(), batch.cuda(), q=q.cuda())[0].reshape(-1), E.reshape(-1)) < 1e-6
+    # static shapes + HIP-graph replay (the MD stepping path) against the dynamic call: same kernels, same bits.  The inputs of
+    # capture() are temporaries ON PURPOSE: the graph must not depend on the caller keeping them (round 4: it did - z, batch and q
+    # were recorded by pointer and this replay read reused memory)
+    sm = _model_from_sd(dict(args, static_shapes=True, max_num_neighbors=64), sd)
+    replay = sm.capture(z.cuda(), pos.cuda(), batch.to(torch.int32).cuda(), q=q.double().cuda())
+    junk = [torch.full((4096,), 7, dtype=torch.long, device="cuda") for _ in range(8)]  # lands in whatever was freed
+    for _ in range(2):
+        Es, Fs = replay(pos.cuda())
+    assert torch.equal(Es.reshape(-1), E.reshape(-1)) and torch.equal(Fs, Fo)
     zb, pb, box = W.water_box(n_side=6)  # 648 atoms, 18.6 A box, brute force with minimum image
     zb, pb = zb[:600], pb[:600]
     bb = torch.zeros_like(zb)
