@@ -121,11 +121,13 @@ class ShardSession:
         sl_a = slice(None) if local else slice(a_lo, a_hi)  # local: the inputs already are this rank's rows
         sl_m = slice(None) if local else slice(m_lo, m_hi)
         self.local = local
-        self.z_l = z[sl_a].contiguous()
-        self.pos_l = pos[sl_a].detach().clone().contiguous()
-        self.batch_l = (batch[sl_a] - m_lo).contiguous()
-        self.q_l = None if q is None else q[sl_m].contiguous()
-        self.box_l = box if (box is None or box.dim() == 2) else box[sl_m].contiguous()
+        # in the dtypes the engine takes: a captured graph records the pointers of exactly these tensors (a conversion inside the
+        # compute callable would hand the graph a temporary)
+        self.z_l = z[sl_a].to(torch.long).contiguous()
+        self.pos_l = pos[sl_a].detach().to(torch.float32).clone().contiguous()
+        self.batch_l = (batch[sl_a] - m_lo).to(torch.long).contiguous()
+        self.q_l = None if q is None else q[sl_m].detach().to(torch.float32).contiguous()
+        self.box_l = None if box is None else (box if box.dim() == 2 else box[sl_m]).detach().to(torch.float32).contiguous()
         self.f_loc = torch.zeros((a_hi - a_lo, 3), dtype=torch.float32, device=dev)
         self.graph, self.guard, self._token = None, guard, None
         if graph and m_hi > m_lo:
