@@ -126,8 +126,8 @@ class ShardSession:
         self.z_l = z[sl_a].to(torch.long).contiguous()
         self.pos_l = pos[sl_a].detach().to(torch.float32).clone().contiguous()
         self.batch_l = (batch[sl_a] - m_lo).to(torch.long).contiguous()
-        self.q_l = None if q is None else q[sl_m].detach().to(torch.float32).contiguous()
-        self.box_l = None if box is None else (box if box.dim() == 2 else box[sl_m]).detach().to(torch.float32).contiguous()
+        self.q_l = None if q is None else q[sl_m].detach().to(device=dev, dtype=torch.float32).contiguous()
+        self.box_l = None if box is None else (box if box.dim() == 2 else box[sl_m]).detach().to(device=dev, dtype=torch.float32).contiguous()
         self.f_loc = torch.zeros((a_hi - a_lo, 3), dtype=torch.float32, device=dev)
         self.graph, self.guard, self._token = None, guard, None
         if graph and m_hi > m_lo:
