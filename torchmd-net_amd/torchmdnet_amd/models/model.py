@@ -1023,13 +1023,15 @@ class TorchMD_Net(nn.Module):
         rm = self.representation_model
         if box is None and rm.distance.use_periodic:
             box = rm.distance.box
-        # the graph records raw device pointers of EVERY input: the caller's z / batch / box / q (or the converted temporaries
-        # energy_and_forces would make of them) may be freed and reused before a replay - own copies in the dtypes the engine takes
+        # the graph records raw device pointers of EVERY input.  They are brought to the device / dtype the engine takes HERE (inside
+        # energy_and_forces a conversion would be a temporary) and the replay closure keeps them alive: before round 4 a caller that
+        # passed temporaries (z.cuda(), an int32 batch, ...) replayed over freed memory.  A tensor that needs no conversion stays the
+        # caller's own object, so in-place updates remain visible to the graph - a barostat scaling `box` between replays.
         dev = pos.device
-        z = z.detach().to(device=dev, dtype=torch.long).clone().contiguous()
-        batch = batch.detach().to(device=dev, dtype=torch.long).clone().contiguous()
-        box = None if box is None else box.detach().to(device=dev, dtype=torch.float32).clone().contiguous()
-        q = None if q is None else q.detach().to(device=dev, dtype=torch.float32).clone().contiguous()
+        z = z.detach().to(device=dev, dtype=torch.long).contiguous()
+        batch = batch.detach().to(device=dev, dtype=torch.long).contiguous()
+        box = None if box is None else box.detach().to(device=dev, dtype=torch.float32).contiguous()
+        q = None if q is None else q.detach().to(device=dev, dtype=torch.float32).contiguous()
         side = torch.cuda.Stream(device=pos.device)
         side.wait_stream(torch.cuda.current_stream(pos.device))
         with torch.cuda.stream(side):
@@ -1054,7 +1056,7 @@ class TorchMD_Net(nn.Module):
             return s_e.view(-1, 1), s_f
 
         replay.graph = graph
-        replay.inputs = (z, batch, box, q)  # kept alive for as long as the graph can be replayed
+        replay.inputs = (z, batch, box, q)  # what the graph reads, kept alive for as long as it can be replayed
         replay.pos = s_pos  # the positions the graph reads: write them in place and call replay() to skip the copy
         replay.n_atoms, replay.n_mol = int(z.shape[0]), n_mol
         return replay
