@@ -286,3 +286,33 @@ def test_quarter_million_atom_box_pair_set_and_determinism(hip_lib):
     E2, F2 = model(z, pos + torch.tensor([1.234, -2.5, 7.7], device="cuda"), batch, box=box)
     assert abs(float(E2) - float(E)) < 1e-5 * abs(float(E))
     assert (F2 - F).abs().max().item() < 1e-3 * F.abs().max().item()
+
+
+def test_thousands_of_tiny_molecules_through_the_batch_kernels(hip_lib):
+    """3 000 molecules of 1 .. 9 atoms (C2 model): the batch-scale kernels on rows that are mostly one or two entries long - tiles whose
+    column window spans a dozen molecules, balanced walks whose helper segments are empty, single atoms (self edge only).  A sample
+    of molecules against the oracle, and every molecule's forces sum to zero."""
+    import numpy as np
+    from oracle import tensornet_torch as T
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(0)
+    model = create_model(dict(W.C2_ARGS)).cuda()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hp = T.hparams_from_args(W.C2_ARGS)
+    rng = np.random.default_rng(11)
+    sizes = rng.integers(1, 10, size=3000)
+    pos = np.concatenate([rng.uniform(0, 1.6 * max(s, 2) ** (1 / 3), size=(s, 3)) for s in sizes]).astype(np.float32)
+    z = torch.from_numpy(rng.choice([1, 6, 7, 8], size=int(sizes.sum())))
+    batch = torch.from_numpy(np.repeat(np.arange(3000), sizes))
+    pos = torch.from_numpy(pos)
+    E, F = model(z.cuda(), pos.cuda(), batch.cuda())
+    assert torch.isfinite(E).all() and torch.isfinite(F).all()
+    net = torch.zeros(3000, 3, device="cuda").index_add_(0, batch.cuda(), F)
+    assert net.abs().max().item() < 1e-4 * max(1.0, F.abs().max().item())
+    for m in (0, 1, 2, 1499, 2999):
+        sel = batch == m
+        Eo, Fo = T.energy_and_forces(sd, hp, z[sel], pos[sel], torch.zeros(int(sel.sum()), dtype=torch.long))
+        assert abs(E[m].item() - Eo.item()) < 1e-4 * max(1.0, abs(Eo.item())), m
+        assert (F[sel.cuda()].cpu() - Fo).abs().max().item() < 1e-4 * max(1.0, Fo.abs().max().item()), m
