@@ -717,6 +717,12 @@ static void pack_tensornet_params(tmdnet_model* m, std::map<std::string, std::ve
       put(t + "V" + std::to_string(k), h[Lp + "linears_tensor." + std::to_string(k) + ".weight"]);
       putT(t + "VT" + std::to_string(k), h[Lp + "linears_tensor." + std::to_string(k) + ".weight"], F, F);
     }
+    if (!m->tn2) {  // transposes of the edge MLP's second and third layer: the data-gradient products of the parameter-gradient
+      // pass (g_he1 = g_pre2 M2, g_he2 = g_pre3 M3) then run on the split-bf16 kernels like every other product (they were
+      // transposed on the fly, without a split image: fp32 matrix pipe, 1.6 ms per step at C2)
+      putT(t + "M2T", h[Lp + "linears_scalar.1.weight"], 2 * F, F);
+      putT(t + "M3T", h[Lp + "linears_scalar.2.weight"], 3 * F, 2 * F);
+    }
   }
   if (m->tn2) {  // TensorNet2: column blocks of linears_scalar.0, transposes for the reverse pass, ChargePredict heads
     const int qd = m->tn2->hp.q_dim, K1 = K + 2 * qd;
@@ -829,6 +835,8 @@ int tmdnet_finalize_params(tmdnet_model* m) {
     q.b2 = D(t + "b1");
     q.M3 = D(t + "M2");
     q.b3 = D(t + "b2");
+    q.M2T = m->tn2 ? nullptr : D(t + "M2T");
+    q.M3T = m->tn2 ? nullptr : D(t + "M3T");
     for (int k = 0; k < 6; ++k) {
       q.V[k] = D(t + "V" + std::to_string(k));
       q.VT[k] = D(t + "VT" + std::to_string(k));
@@ -870,6 +878,10 @@ int tmdnet_finalize_params(tmdnet_model* m) {
       add_sb(t + "M0", F, m->tn2 ? K + 2 * m->tn2->hp.q_dim : K);
       add_sb(t + "M1", 2 * F, F);
       add_sb(t + "M2", 3 * F, 2 * F);
+      if (!m->tn2) {
+        add_sb(t + "M2T", F, 2 * F);
+        add_sb(t + "M3T", 2 * F, 3 * F);
+      }
       for (int k = 0; k < 6; ++k) {
         add_sb(t + "V" + std::to_string(k), F, F);
         add_sb(t + "VT" + std::to_string(k), F, F);
@@ -1655,12 +1667,11 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         launch_tn_gemm(s, tc->g3, r3F, tc->he2[l], r2F, nullptr, nullptr, P1, 3 * F, 2 * F, tc->at(t_ + "M2"), false, tc->part);
         launch_colsum(s, tc->g3, r3F, nullptr, r3F, nullptr, nullptr, P1, 3 * F, tc->at(t_ + "b2"), false, tc->part);
         EDGE(1);
-        launch_transpose(q_.M3, 3 * F, 2 * F, tc->wT, s);  // [2F][3F]: the [N][K] operand of g_he2 = g_pre3 M3
-        gemm(s, tc->g3, 3 * F, tc->wT, 3 * F, nullptr, tc->g2, 2 * F, P1, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, tc->pre2[l], 2 * F);
+        // g_he2 = g_pre3 M3: the [N][K] operand is M3^T [2F][3F], kept with its split image (tmdnet_finalize_params)
+        gemm(s, tc->g3, 3 * F, q_.M3T, 3 * F, nullptr, tc->g2, 2 * F, P1, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, tc->pre2[l], 2 * F);
         launch_tn_gemm(s, tc->g2, r2F, tc->he1[l], rF, nullptr, nullptr, P1, 2 * F, F, tc->at(t_ + "M1"), false, tc->part);
         launch_colsum(s, tc->g2, r2F, nullptr, r2F, nullptr, nullptr, P1, 2 * F, tc->at(t_ + "b1"), false, tc->part);
-        launch_transpose(q_.M2, 2 * F, F, tc->wT, s);
-        gemm(s, tc->g2, 2 * F, tc->wT, 2 * F, nullptr, tc->g1, F, P1, F, 2 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, tc->pre1[l], F);
+        gemm(s, tc->g2, 2 * F, q_.M2T, 2 * F, nullptr, tc->g1, F, P1, F, 2 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, tc->pre1[l], F);
         launch_tn_gemm(s, tc->g1, rF, b.phi, rK, nullptr, nullptr, P1, F, K, tc->at(t_ + "M0"), false, tc->part);
         launch_colsum(s, tc->g1, rF, nullptr, rF, nullptr, nullptr, P1, F, tc->at(t_ + "b0"), false, tc->part);
         NODE();

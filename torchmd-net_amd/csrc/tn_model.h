@@ -20,6 +20,7 @@ using namespace tn;
 
 struct LayerP {
   const float *M1, *b1, *M2, *b2, *M3, *b3;
+  const float *M2T, *M3T;  // transposes of M2, M3 (TensorNet: the parameter-gradient pass's data-gradient products)
   const float* V[6];
   const float* VT[6];
   const uint16_t* M_sb[3];  // split-bf16 tile images of M1..M3 (tn_gemm_sb.hip)
