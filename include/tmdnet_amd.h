@@ -142,7 +142,9 @@ const char* tmdnet_param_name(const tmdnet_model* m, int idx, int64_t* numel);
  * projections' rows and the direct evaluation's activations get NO workspace: tmdnet_forward_workspace_bytes drops from
  * ~12.6 KB to ~0.1 KB per pair, which is what lets a 10^6-atom periodic box fit one 288 GB device.  Same arithmetic as the stored
  * rows (one definition, csrc/tn_interp.h): energies and forces are bit-identical.  Needs the tables (verified, not switched
- * off); tmdnet_energy_forces reports TMDNET_ERR_STATE otherwise. */
+ * off); tmdnet_energy_forces reports TMDNET_ERR_STATE otherwise.  tmdnet_forward_workspace_bytes plans for the embedding form
+ * of the graph this handle built LAST (query it after tmdnet_build_graph of the same system, as the Python host does); a plan made
+ * for another graph is refused with TMDNET_ERR_WORKSPACE, never overrun. */
 int tmdnet_set_option(tmdnet_model* m, const char* name, double value);
 int tmdnet_get_info(const tmdnet_model* m, const char* name, double* value);
 
