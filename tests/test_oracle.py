@@ -232,3 +232,58 @@ def test_tensornet2_oracle_matches_reference_fixture(golden_dir, fixture):
     # fp32 evaluation agrees with the reference's fp32 run to rounding
     E, F = T2.energy_and_forces(g["state_dict"], hp, g["z"], g["pos"], g["batch"], box=g["box"], q=g["q"])
     assert (E - g["E"]).abs().max() < 2e-5 * g["E"].abs().max() and (F - g["F"]).abs().max() < 2e-5 * g["F"].abs().max()
+
+
+# ---------------------------------------------------------------------------------------------- second-order pass (force matching)
+from oracle import tensornet_second_order as S2  # noqa: E402
+
+
+def _autograd_force_term(sd, hp, z, pos, batch, v, q=None, box=None):
+    """d/d theta and d/d pos of  s = v . d(sum E)/d pos  by differentiating the autograd oracle twice (what the reference does:
+    model.py:618-628 with create_graph=True)."""
+    keys = [k for k, t in sd.items() if t.dtype == pos.dtype and t.dim() > 0 and "distance" not in k and "prior" not in k]
+    sdg = {k: (t.clone().requires_grad_(True) if k in keys else t) for k, t in sd.items()}
+    p = pos.clone().requires_grad_(True)
+    E = T.energy(sdg, hp, z, p, batch, box=box, q=q)
+    (gp,) = torch.autograd.grad(E.sum(), p, create_graph=True)
+    s = (gp * v).sum()
+    grads = torch.autograd.grad(s, [sdg[k] for k in keys] + [p], allow_unused=True)
+    return s.detach(), {k: (torch.zeros_like(sd[k]) if g is None else g) for k, g in zip(keys, grads[:-1])}, grads[-1]
+
+
+@pytest.mark.parametrize("extra,use_q", [({}, True), (dict(equivariance_invariance_group="SO(3)"), False), (dict(cutoff_lower=1.2), True)])
+def test_hand_second_order_pass_equals_autograd_of_autograd(tiny, extra, use_q):
+    """oracle/tensornet_second_order.py (the specification of the engine's analytic force-matching pass) against the reference's
+    way of getting the same numbers - two nested autograd passes - in fp64: every parameter, and H v in the positions."""
+    sd64 = T.cast_state_dict(tiny["state_dict"], torch.float64)
+    hp = dict(T.hparams_from_args(tiny["args"]), **extra)
+    z, pos, batch = tiny["z"], tiny["pos"].double(), tiny["batch"]
+    q = tiny["q"].double() if use_q else None
+    v = torch.randn(pos.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    s, ref, Hv = _autograd_force_term(sd64, hp, z, pos, batch, v, q=q)
+    out = S2.force_term(sd64, hp, z, pos, batch, v, q=q)
+    assert abs(out["s"].item() - s.item()) < 1e-12 * max(1.0, abs(s.item()))
+    assert abs(out["s"].item() + (v * out["F"]).sum().item()) < 1e-12  # s = - v . F
+    assert rel_err(out["Hv"], Hv) < 1e-11
+    mine = S2.state_dict_grads(out["ent"], sd64, hp)
+    assert set(ref) <= set(mine)
+    for k, r in ref.items():
+        if r.abs().max() > 0:
+            assert rel_err(mine[k].reshape(r.shape), r) < 1e-10, k
+        else:
+            assert mine[k].abs().max() < 1e-12, k
+
+
+def test_hand_second_order_pass_periodic(tiny, golden_dir):
+    f = torch.load(os.path.join(golden_dir, "tiny_pbc_ref.pt"))
+    sd64 = T.cast_state_dict(tiny["state_dict"], torch.float64)
+    hp = T.hparams_from_args(tiny["args"])
+    z, pos, batch, box = f["z"], f["pos"].double(), f["batch"], f["box"].double()
+    v = torch.randn(pos.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+    s, ref, Hv = _autograd_force_term(sd64, hp, z, pos, batch, v, box=box)
+    out = S2.force_term(sd64, hp, z, pos, batch, v, box=box)
+    assert abs(out["s"].item() - s.item()) < 1e-12 * max(1.0, abs(s.item())) and rel_err(out["Hv"], Hv) < 1e-11
+    mine = S2.state_dict_grads(out["ent"], sd64, hp)
+    for k, r in ref.items():
+        if r.abs().max() > 0:
+            assert rel_err(mine[k].reshape(r.shape), r) < 1e-10, k
