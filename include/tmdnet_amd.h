@@ -99,7 +99,7 @@ const char* tmdnet_version(void);
 /* ABI revision of this header: bumped whenever an exported signature or struct layout changes (3: `z` in
  * tmdnet_build_graph[_static], `strategy` in tmdnet_neighbor_pairs).  A binding compares its compile-time
  * TMDNET_ABI_VERSION with the loaded library's tmdnet_abi_version() before its first call. */
-#define TMDNET_ABI_VERSION 5
+#define TMDNET_ABI_VERSION 6
 int tmdnet_abi_version(void);
 
 /* Parameters are addressed by the reference's state-dict keys without the "model." prefix
@@ -300,6 +300,24 @@ int tmdnet_train_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t n_mol
 int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, void* train_ws,
                               size_t train_bytes, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, const int64_t* z,
                               const int64_t* batch, const float* q, const float* grad_energy, float* energy, float* grads);
+
+/* Second-order pass of force-matching training (TensorNet + Scalar): the gradient, with respect to every weight, of
+ *     s(theta) = v . d(sum_m E_m)/d pos = - v . F          v [n_atoms, 3] = d loss / d F  (device, caller's atom order)
+ * so that d loss / d theta through the forces is  - grads.  Replaces the reference's second autograd pass over its own graph
+ * (torchmdnet/models/model.py:618-628, create_graph = self.training) and the *_bwd_bwd kernels behind it
+ * (torchmdnet/extensions/warp_ops/tensornet_mp.py:538-548 and siblings).  Analytic: the forward-mode tangent, along v, of the
+ * forward + reverse program (no difference quotient); one self-contained pass that evaluates the radial functions directly and
+ * keeps its own activations in `ws` (tmdnet_force_param_workspace_bytes: about 0.75 KB per atom-channel plus 0.2 KB per
+ * pair-channel).  `grads` has the layout of tmdnet_energy_param_grads (tmdnet_param_grad_entry; d s / d bO2 = 0).  Needs a graph
+ * built with the exact pair count and without the cell list; `z` may be NULL when tmdnet_build_graph saw it; deterministic. */
+int tmdnet_force_param_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, size_t* bytes);
+int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms,
+                             int64_t n_mol, int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q, const float* v,
+                             float* grads);
+/* Developer / test hook: copies one intermediate of the LAST tmdnet_force_param_grads call on this handle (same thread, workspace
+ * untouched since) into `out` (device); names are the buffer names of csrc/tn_hvp_api.hip ("u0_t", "l0.Mi_t", "g_Pn", ...).
+ * out == NULL: returns the element count instead of a status. */
+int tmdnet_hvp_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* out, int64_t numel);
 
 #ifdef __cplusplus
 }

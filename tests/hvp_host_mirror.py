@@ -1,0 +1,286 @@
+"""TEST INFRASTRUCTURE ONLY: the schedule of the engine's analytic second-order pass (torchmd-net_amd/csrc/tn_hvp_api.hip), launch
+by launch, on the CPU: the per-element kernels are the SAME bodies (csrc/tn_hvp_math.h, compiled host-only into
+oracle/_build/libhvp_host.so from tests/hvp_host.hip), the dense products the engine takes through its GEMM launchers are torch
+matmuls here.  tests/test_hvp_host.py compares the result with oracle/tensornet_second_order.py: that checks the kernel arithmetic
+and the order / operands of the schedule without a GPU.  The names of the buffers are the names of tn_hvp_api.hip."""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+import torch.nn.functional as Fn
+
+from oracle import tensornet_adjoint as A
+from oracle import tensornet_second_order as S2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(ROOT, "oracle", "_build", "libhvp_host.so")
+        src = [os.path.join(ROOT, "tests", "hvp_host.hip"), os.path.join(ROOT, "torchmd-net_amd", "csrc", "tn_hvp_math.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+            os.makedirs(os.path.dirname(so), exist_ok=True)
+            subprocess.check_call(["hipcc", "-x", "hip", "--cuda-host-only", "-O1", "-fPIC", "-shared", src[0], "-o", so])
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def _arg(a):
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, torch.Tensor):
+        assert a.is_contiguous(), "harness operands must be contiguous"
+        return C.c_void_p(a.data_ptr())
+    if isinstance(a, float):
+        return C.c_float(a)
+    return a
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    fn.restype = None
+    fn(*[_arg(a) for a in args])
+
+
+def f32(*shape):
+    return torch.full(shape, float("nan"), dtype=torch.float32)  # NaN-filled: an element a kernel forgets to write shows up
+
+
+def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
+    """-> {engine entry name: d s / d entry} in fp32, by the engine's schedule."""
+    R = "representation_model."
+    T = R + "tensor_embedding."
+    O = "output_model.output_network.layers."
+    sd = {k: (t.float() if t.is_floating_point() else t) for k, t in sd.items()}
+    F, L, K = hp["hidden_channels"], hp["num_layers"], hp["num_rbf"]
+    lo, up = float(hp["cutoff_lower"]), float(hp["cutoff_upper"])
+    o3 = int(hp.get("equivariance_invariance_group", "O(3)") == "O(3)")
+    g = A.build_graph(pos.float(), batch, lo, up, None if box is None else box.float())
+    N, P = g["n"], g["P"]
+    P1 = P + 1
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    rowptr, col, epair, esign = i32(g["rowptr"]), i32(g["cols"]), i32(g["epair"]), g["esign"].float().contiguous()
+    pair_i, pair_j = i32(g["pi"]), i32(g["pj"])
+    pd = torch.cat([g["d"].float(), torch.zeros(1)]).contiguous()
+    prhat = g["rhat"].float().contiguous()
+    z = z.to(torch.int64).contiguous()
+    v = v.float().contiguous()
+    kap = None if q is None else (1 + 0.1 * q.float()[batch]).contiguous()
+    H = sd[O + "0.weight"].shape[0]
+    std = float(sd["std"]) if "std" in sd else 1.0
+
+    # dense products of the engine: gemm(A, W, bias) = A W^T + bias ; tensor linears ; weight-gradient products
+    gemm = lambda a, W, b=None: (a @ W.t() + (0 if b is None else b)).contiguous()
+    gemmT = lambda a, W: (a @ W).contiguous()  # the engine passes the stored transpose W^T to gemm()
+    tlin = lambda u, Ws, tr=False: A.tensor_linear(u, Ws, tr).contiguous()
+    tn_gemm = lambda a, b: a.t() @ b  # out[n][k] = sum_r a[r][n] b[r][k]
+    C0, NC = (0, 1, 4), (1, 3, 5)
+
+    def tlin_grad(g_out, inp):
+        return [sum(g_out[:, c].t() @ inp[:, c] for c in range(C0[k], C0[k] + NC[k])) for k in range(3)]
+
+    ent = {}
+    # ---- radial functions per pair (launch_radial) and the tangent of the geometry
+    phi, dphi = A.rbf_and_grad(pd, sd[R + "distance_expansion.means"], sd[R + "distance_expansion.betas"], lo, up)
+    Cc, dC = A.cutoff_and_grad(pd, lo, up)
+    phi, dphi, Cc, dC = phi.contiguous(), dphi.contiguous(), Cc.contiguous(), dC.contiguous()
+    d_t, rhat_t, phi_t, C_t = f32(P1), f32(P1, 3), f32(P1, K), f32(P1)
+    call("hh_pair_tangent", P, K, pair_i, pair_j, prhat, pd, v, dphi, dC, d_t, rhat_t, phi_t, C_t)
+
+    # ---- embedding, forward
+    Wdp = torch.cat([sd[T + f"distance_proj{k}.weight"] for k in (1, 2, 3)], 0)
+    bdp = torch.cat([sd[T + f"distance_proj{k}.bias"] for k in (1, 2, 3)], 0)
+    W2 = sd[T + "emb2.weight"]
+    Utab = (sd[T + "emb.weight"] @ W2[:, :F].t() + sd[T + "emb2.bias"]).contiguous()
+    Vtab = (sd[T + "emb.weight"] @ W2[:, F:].t()).contiguous()
+    Q, Q_t = gemm(phi, Wdp, bdp), gemm(phi_t, Wdp)
+    u0, u0_t, s0n, s0n_t = f32(N, 9, F), f32(N, 9, F), f32(N, F), f32(N, F)
+    call("hh_embed_scatter_dual", N, F, P, rowptr, col, epair, esign, z, Utab, Vtab, Q, Q_t, Cc, C_t, prhat, rhat_t, u0, u0_t, s0n, s0n_t)
+    ln0_w, ln0_b = sd[T + "init_norm.weight"].contiguous(), sd[T + "init_norm.bias"].contiguous()
+    ln0, xh0, rstd0, ln0_t, xh0_t, rstd0_t = f32(N, F), f32(N, F), f32(N), f32(N, F), f32(N, F), f32(N)
+    call("hh_ln_dual", N, F, s0n, s0n_t, ln0_w, ln0_b, ln0, xh0, rstd0, ln0_t, xh0_t, rstd0_t)
+    L1, bL1 = sd[T + "linears_scalar.0.weight"], sd[T + "linears_scalar.0.bias"]
+    L2, bL2 = sd[T + "linears_scalar.1.weight"], sd[T + "linears_scalar.1.bias"]
+    a1 = gemm(ln0, L1, bL1)
+    h1 = Fn.silu(a1)
+    a1_t = gemm(ln0_t, L1)
+    h1_t = f32(N, 2 * F)
+    call("hh_silu_tangent", C.c_int64(a1.numel()), a1, a1_t, h1_t)
+    a2 = gemm(h1, L2, bL2)
+    gates = Fn.silu(a2)
+    a2_t = gemm(h1_t, L2)
+    gates_t = f32(N, 3 * F)
+    call("hh_silu_tangent", C.c_int64(a2.numel()), a2, a2_t, gates_t)
+    Ue = [sd[T + f"linears_tensor.{k}.weight"] for k in range(3)]
+    UX, UX_t = tlin(u0, Ue), tlin(u0_t, Ue)
+    X, X_t = [f32(N, 9, F)], [f32(N, 9, F)]
+    call("hh_gate_mul_dual", N, F, UX, UX_t, gates, gates_t, X[0], X_t[0])
+
+    # ---- interaction layers, forward
+    lay = []
+    for l in range(L):
+        Lp = R + f"layers.{l}."
+        M = [sd[Lp + f"linears_scalar.{k}.weight"] for k in range(3)]
+        bM = [sd[Lp + f"linears_scalar.{k}.bias"] for k in range(3)]
+        V = [sd[Lp + f"linears_tensor.{k}.weight"] for k in range(6)]
+        c = dict(M=M, V=V)
+        c["pre1"] = gemm(phi, M[0], bM[0])
+        c["he1"] = Fn.silu(c["pre1"])
+        c["e1_t"] = gemm(phi_t, M[0])
+        c["he1_t"] = f32(P1, F)
+        call("hh_silu_tangent", C.c_int64(P1 * F), c["pre1"], c["e1_t"], c["he1_t"])
+        c["pre2"] = gemm(c["he1"], M[1], bM[1])
+        c["he2"] = Fn.silu(c["pre2"])
+        c["e2_t"] = gemm(c["he1_t"], M[1])
+        c["he2_t"] = f32(P1, 2 * F)
+        call("hh_silu_tangent", C.c_int64(P1 * 2 * F), c["pre2"], c["e2_t"], c["he2_t"])
+        c["pre3"] = gemm(c["he2"], M[2], bM[2])
+        c["e3_t"] = gemm(c["he2_t"], M[2])
+        c["w"], c["w_t"] = f32(P1, 3 * F), f32(P1, 3 * F)
+        call("hh_w_dual", C.c_int64(P1), 3 * F, c["pre3"], c["e3_t"], Cc, C_t, c["w"], c["w_t"])
+        c["Xh"], c["Xh_t"] = f32(N, 9, F), f32(N, 9, F)
+        call("hh_norm_dual", N, F, X[l], X_t[l], c["Xh"], c["Xh_t"])
+        c["Pn"], c["Pn_t"] = tlin(c["Xh"], V[0:3]), tlin(c["Xh_t"], V[0:3])
+        c["Mi"], c["Mi_t"] = f32(N, 9, F), f32(N, 9, F)
+        call("hh_sweep2", N, F, rowptr, col, epair, c["w"], c["Pn"], None, None, None, c["Mi"])
+        call("hh_sweep2", N, F, rowptr, col, epair, c["w"], c["Pn_t"], c["w_t"], c["Pn"], None, c["Mi_t"])
+        c["Ch"], c["Ch_t"] = f32(N, 9, F), f32(N, 9, F)
+        call("hh_group_dual", N, F, c["Pn"], c["Pn_t"], c["Mi"], c["Mi_t"], kap, o3, c["Ch"], c["Ch_t"])
+        c["D"], c["D_t"] = tlin(c["Ch"], V[3:6]), tlin(c["Ch_t"], V[3:6])
+        X.append(f32(N, 9, F))
+        X_t.append(f32(N, 9, F))
+        call("hh_update_dual", N, F, c["Xh"], c["Xh_t"], c["D"], c["D_t"], kap, X[l + 1], X_t[l + 1])
+        lay.append(c)
+
+    # ---- readout and head, forward
+    feat, feat_t = f32(N, 3 * F), f32(N, 3 * F)
+    call("hh_feat_dual", N, F, X[L], X_t[L], feat, feat_t)
+    lnr_w, lnr_b = sd[R + "out_norm.weight"].contiguous(), sd[R + "out_norm.bias"].contiguous()
+    lnr, xhr, rstdr, lnr_t, xhr_t, rstdr_t = f32(N, 3 * F), f32(N, 3 * F), f32(N), f32(N, 3 * F), f32(N, 3 * F), f32(N)
+    call("hh_ln_dual", N, 3 * F, feat, feat_t, lnr_w, lnr_b, lnr, xhr, rstdr, lnr_t, xhr_t, rstdr_t)
+    Lin, bLin = sd[R + "linear.weight"], sd[R + "linear.bias"]
+    O1, bO1, O2 = sd[O + "0.weight"], sd[O + "0.bias"], sd[O + "2.weight"].reshape(-1).contiguous()
+    al = gemm(lnr, Lin, bLin)
+    x = Fn.silu(al)
+    al_t = gemm(lnr_t, Lin)
+    x_t = f32(N, F)
+    call("hh_silu_tangent", C.c_int64(N * F), al, al_t, x_t)
+    ao, ao_t = gemm(x, O1, bO1), gemm(x_t, O1)
+    g_ao, g_ao_t, headv = f32(N, H), f32(N, H), f32(N, H)
+    call("hh_head_dual", C.c_int64(N * H), H, ao, ao_t, O2, std, g_ao, g_ao_t, headv)
+    s_val = (headv * O2).sum()
+
+    # ---- reverse pass with tangents
+    ent["O2"], ent["bO2"] = headv.sum(0, keepdim=True), torch.zeros(1)
+    ent["O1"], ent["bO1"] = tn_gemm(g_ao_t, x) + tn_gemm(g_ao, x_t), g_ao_t.sum(0)
+    g_x, g_x_t = gemmT(g_ao, O1), gemmT(g_ao_t, O1)
+    g_al, g_al_t = f32(N, F), f32(N, F)
+    call("hh_dsilu_dual", C.c_int64(N * F), g_x, g_x_t, al, al_t, g_al, g_al_t)
+    ent["Lin"], ent["bLin"] = tn_gemm(g_al_t, lnr) + tn_gemm(g_al, lnr_t), g_al_t.sum(0)
+    g_ln, g_ln_t = gemmT(g_al, Lin), gemmT(g_al_t, Lin)
+    ent["lnr_w"], ent["lnr_b"] = (g_ln_t * xhr).sum(0) + (g_ln * xhr_t).sum(0), g_ln_t.sum(0)
+    g_feat, g_feat_t = f32(N, 3 * F), f32(N, 3 * F)
+    call("hh_lnbwd_dual", N, 3 * F, g_ln, g_ln_t, xhr, xhr_t, rstdr, rstdr_t, lnr_w, g_feat, g_feat_t)
+    G, G_t = f32(N, 9, F), f32(N, 9, F)
+    call("hh_readout_bwd_dual", N, F, X[L], X_t[L], g_feat, g_feat_t, G, G_t)
+    for l in reversed(range(L)):
+        c = lay[l]
+        V, M = c["V"], c["M"]
+        g_D, g_D_t = f32(N, 9, F), f32(N, 9, F)
+        call("hh_update_bwd_dual", N, F, G, G_t, c["D"], c["D_t"], kap, g_D, g_D_t)
+        for k, (a_, b_) in enumerate(zip(tlin_grad(g_D_t, c["Ch"]), tlin_grad(g_D, c["Ch_t"]))):
+            ent[f"l{l}.Vb{k}"] = a_ + b_
+        g_Ch, g_Ch_t = tlin(g_D, V[3:6], True), tlin(g_D_t, V[3:6], True)
+        g_Mi, g_Mi_t, g_PnY, g_PnY_t = f32(N, 9, F), f32(N, 9, F), f32(N, 9, F), f32(N, 9, F)
+        call("hh_group_bwd_dual", N, F, g_Ch, g_Ch_t, c["Pn"], c["Pn_t"], c["Mi"], c["Mi_t"], kap, o3, g_Mi, g_Mi_t, g_PnY, g_PnY_t)
+        g_Pn, g_Pn_t = f32(N, 9, F), f32(N, 9, F)
+        call("hh_sweep2", N, F, rowptr, col, epair, c["w"], g_Mi, None, None, g_PnY, g_Pn)
+        call("hh_sweep2", N, F, rowptr, col, epair, c["w"], g_Mi_t, c["w_t"], g_Mi, g_PnY_t, g_Pn_t)
+        # self pair: column sums over the atoms, per irreducible type (launch_colsum over the (atom, component) rows)
+        self_gw = S2.tsum(g_Mi * c["Pn"]).sum(0).reshape(3 * F).contiguous()
+        self_gw_t = (S2.tsum(g_Mi_t * c["Pn"]).sum(0) + S2.tsum(g_Mi * c["Pn_t"]).sum(0)).reshape(3 * F).contiguous()
+        g3, g3_t = f32(P1, 3 * F), f32(P1, 3 * F)
+        call("hh_pair_gw_dual", P, F, pair_i, pair_j, g_Mi, g_Mi_t, c["Pn"], c["Pn_t"], self_gw, self_gw_t, c["pre3"], c["e3_t"], Cc, C_t,
+             g3, g3_t)
+        ent[f"l{l}.M2"], ent[f"l{l}.b2"] = tn_gemm(g3_t, c["he2"]) + tn_gemm(g3, c["he2_t"]), g3_t.sum(0)
+        gh2, gh2_t = gemmT(g3, M[2]), gemmT(g3_t, M[2])
+        g2, g2_t = f32(P1, 2 * F), f32(P1, 2 * F)
+        call("hh_dsilu_dual", C.c_int64(P1 * 2 * F), gh2, gh2_t, c["pre2"], c["e2_t"], g2, g2_t)
+        ent[f"l{l}.M1"], ent[f"l{l}.b1"] = tn_gemm(g2_t, c["he1"]) + tn_gemm(g2, c["he1_t"]), g2_t.sum(0)
+        gh1, gh1_t = gemmT(g2, M[1]), gemmT(g2_t, M[1])
+        g1, g1_t = f32(P1, F), f32(P1, F)
+        call("hh_dsilu_dual", C.c_int64(P1 * F), gh1, gh1_t, c["pre1"], c["e1_t"], g1, g1_t)
+        ent[f"l{l}.M0"], ent[f"l{l}.b0"] = tn_gemm(g1_t, phi) + tn_gemm(g1, phi_t), g1_t.sum(0)
+        for k, (a_, b_) in enumerate(zip(tlin_grad(g_Pn_t, c["Xh"]), tlin_grad(g_Pn, c["Xh_t"]))):
+            ent[f"l{l}.Va{k}"] = a_ + b_
+        gXl, gXl_t = tlin(g_Pn, V[0:3], True), tlin(g_Pn_t, V[0:3], True)
+        Gn, Gn_t = f32(N, 9, F), f32(N, 9, F)
+        call("hh_norm_bwd_dual", N, F, X[l], X_t[l], G, G_t, gXl, gXl_t, Gn, Gn_t)
+        G, G_t = Gn, Gn_t
+
+    # ---- embedding adjoint
+    g_UX, g_UX_t, g_a2, g_a2_t = f32(N, 9, F), f32(N, 9, F), f32(N, 3 * F), f32(N, 3 * F)
+    call("hh_gate_bwd_dual", N, F, G, G_t, UX, UX_t, gates, gates_t, a2, a2_t, g_UX, g_UX_t, g_a2, g_a2_t)
+    ent["L2"], ent["bL2"] = tn_gemm(g_a2_t, h1) + tn_gemm(g_a2, h1_t), g_a2_t.sum(0)
+    g_h1, g_h1_t = gemmT(g_a2, L2), gemmT(g_a2_t, L2)
+    g_a1, g_a1_t = f32(N, 2 * F), f32(N, 2 * F)
+    call("hh_dsilu_dual", C.c_int64(N * 2 * F), g_h1, g_h1_t, a1, a1_t, g_a1, g_a1_t)
+    ent["L1"], ent["bL1"] = tn_gemm(g_a1_t, ln0) + tn_gemm(g_a1, ln0_t), g_a1_t.sum(0)
+    g_ln0, g_ln0_t = gemmT(g_a1, L1), gemmT(g_a1_t, L1)
+    ent["ln0_w"], ent["ln0_b"] = (g_ln0_t * xh0).sum(0) + (g_ln0 * xh0_t).sum(0), g_ln0_t.sum(0)
+    g_s0n, g_s0n_t = f32(N, F), f32(N, F)
+    call("hh_lnbwd_dual", N, F, g_ln0, g_ln0_t, xh0, xh0_t, rstd0, rstd0_t, ln0_w, g_s0n, g_s0n_t)
+    for k, (a_, b_) in enumerate(zip(tlin_grad(g_UX_t, u0), tlin_grad(g_UX, u0_t))):
+        ent[f"Ue{k}"] = a_ + b_
+    g_u0l, g_u0l_t = tlin(g_UX, Ue, True), tlin(g_UX_t, Ue, True)
+    gA, gA_t = f32(N, 10, F), f32(N, 10, F)
+    call("hh_embed_bwd_atom_dual", N, F, g_u0l, g_u0l_t, u0, u0_t, g_s0n, g_s0n_t, gA, gA_t)
+    dir_ = P1 * 3 * F
+    gq, gq_t = f32(2, P1, 3 * F), f32(2, P1, 3 * F)
+    selfq, selfq_t, gZu_t, gZv_t = f32(N, F), f32(N, F), f32(N, F), f32(N, F)
+    call("hh_embed_edge_dual", N, F, P, rowptr, col, epair, esign, z, Utab, Vtab, Q, Q_t, Cc, C_t, prhat, rhat_t, gA, gA_t, gq, gq_t,
+         C.c_int64(dir_), selfq, selfq_t, gZu_t, gZv_t)
+    dW = tn_gemm(gq_t[0, :P], phi[:P]) + tn_gemm(gq_t[1, :P], phi[:P]) + tn_gemm(gq[0, :P], phi_t[:P]) + tn_gemm(gq[1, :P], phi_t[:P])
+    dW[:F] += selfq_t.sum(0)[:, None] * phi[P][None, :]
+    db = gq_t[0, :P].sum(0) + gq_t[1, :P].sum(0)
+    db[:F] += selfq_t.sum(0)
+    ent["Wdp"], ent["bdp"] = dW, db
+    nz = sd[T + "emb.weight"].shape[0]
+    onehot = Fn.one_hot(z, nz).float()
+    ent["Utab"], ent["Vtab"] = tn_gemm(onehot, gZu_t), tn_gemm(onehot, gZv_t)
+    # every buffer under the name it has in csrc/tn_hvp_api.hip (tmdnet_hvp_debug_tensor); reverse-sweep scratch: its last use (layer 0)
+    loc = locals()
+    names = ("phi dphi d_t rhat_t phi_t C_t Q Q_t u0 u0_t s0n s0n_t ln0 xh0 rstd0 ln0_t xh0_t rstd0_t a1 h1 a1_t h1_t a2 gates a2_t gates_t "
+             "UX UX_t feat feat_t lnr xhr rstdr lnr_t xhr_t rstdr_t al x al_t x_t ao ao_t g_ao g_ao_t headv g_x g_x_t g_al g_al_t g_ln g_ln_t "
+             "g_feat g_feat_t g_UX g_UX_t g_a2 g_a2_t g_h1 g_h1_t g_a1 g_a1_t g_ln0 g_ln0_t g_s0n g_s0n_t gA gA_t gq gq_t selfq selfq_t "
+             "gZu_t gZv_t").split()
+    bufs = {k: loc[k] for k in names}
+    bufs.update(C=Cc, dC=dC, g_u0l=g_u0l, g_u0l_t=g_u0l_t, G_emb=G, G_emb_t=G_t)
+    if L > 0:
+        bufs.update({k: loc[k] for k in "g_D g_D_t g_Ch g_Ch_t g_Mi g_Mi_t g_PnY g_PnY_t g_Pn g_Pn_t self_gw self_gw_t g3 g3_t gh2 gh2_t g2 "
+                                        "g2_t gh1 gh1_t g1 g1_t".split()})
+        bufs.update(gXl=gXl, gXl_t=gXl_t)
+    for l in range(L + 1):
+        bufs[f"X{l}"], bufs[f"X_t{l}"] = X[l], X_t[l]
+    for l, c in enumerate(lay):
+        for k in "pre1 he1 e1_t he1_t pre2 he2 e2_t he2_t pre3 e3_t w w_t Xh Xh_t Pn Pn_t Mi Mi_t Ch Ch_t D D_t".split():
+            bufs[f"l{l}.{k}"] = c[k]
+    # schedule order of the names (the first mismatching one names the launch that went wrong)
+    order = ["phi", "dphi", "C", "dC", "d_t", "rhat_t", "phi_t", "C_t", "Q", "Q_t", "u0", "u0_t", "s0n", "s0n_t", "ln0", "xh0", "rstd0", "ln0_t",
+             "xh0_t", "rstd0_t", "a1", "h1", "a1_t", "h1_t", "a2", "gates", "a2_t", "gates_t", "UX", "UX_t", "X0", "X_t0"]
+    for l in range(L):
+        order += [f"l{l}.{k}" for k in "pre1 he1 e1_t he1_t pre2 he2 e2_t he2_t pre3 e3_t w w_t Xh Xh_t Pn Pn_t Mi Mi_t Ch Ch_t D D_t".split()]
+        order += [f"X{l + 1}", f"X_t{l + 1}"]
+    order += ["feat", "feat_t", "lnr", "xhr", "rstdr", "lnr_t", "xhr_t", "rstdr_t", "al", "x", "al_t", "x_t", "ao", "ao_t", "g_ao", "g_ao_t", "headv",
+              "g_x", "g_x_t", "g_al", "g_al_t", "g_ln", "g_ln_t", "g_feat", "g_feat_t"]
+    if L > 0:
+        order += ["g_D", "g_D_t", "g_Ch", "g_Ch_t", "g_Mi", "g_Mi_t", "g_PnY", "g_PnY_t", "g_Pn", "g_Pn_t", "self_gw", "self_gw_t", "g3", "g3_t",
+                  "gh2", "gh2_t", "g2", "g2_t", "gh1", "gh1_t", "g1", "g1_t", "gXl", "gXl_t"]
+    order += ["G_emb", "G_emb_t", "g_UX", "g_UX_t", "g_a2", "g_a2_t", "g_h1", "g_h1_t", "g_a1", "g_a1_t", "g_ln0", "g_ln0_t", "g_s0n", "g_s0n_t",
+              "g_u0l", "g_u0l_t", "gA", "gA_t", "gq", "gq_t", "selfq", "selfq_t", "gZu_t", "gZv_t"]
+    assert set(order) == set(bufs), set(order) ^ set(bufs)
+    return dict(ent=ent, s=s_val, bufs=bufs, order=order, P=P)

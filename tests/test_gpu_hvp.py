@@ -1,0 +1,137 @@
+"""-m gpu: the analytic second-order pass of force-matching training (tmdnet_force_param_grads, csrc/tn_hvp*.hip) through the C
+ABI against its specification oracle/tensornet_second_order.py in fp64 (pinned to autograd-of-autograd, tests/test_oracle.py) - what
+the reference computes with its second autograd pass (model.py:618-628, create_graph=True).  Bound: the north-star 1e-4 relative to
+each tensor's largest entry.  Every case also walks the engine's intermediates (tmdnet_hvp_debug_tensor) against the host run of the
+same kernel bodies (tests/hvp_host_mirror.py) and writes the table to gpurun_out/: the first mismatching name is the launch to
+look at."""
+import ctypes as C
+import json
+import os
+
+import pytest
+import torch
+
+from torchmdnet_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def _ragged(sizes, seed):
+    zs, ps, bs = [], [], []
+    for m, n in enumerate(sizes):
+        zz, pp = W.synthetic_molecule(seed + m, n_atoms=n)
+        zs.append(torch.from_numpy(zz))
+        ps.append(torch.from_numpy(pp))
+        bs.append(torch.full((n,), m, dtype=torch.long))
+    return torch.cat(zs), torch.cat(ps), torch.cat(bs)
+
+
+def _walk_buffers(model, sd, hp, z, pos, batch, v, q):
+    """engine intermediates vs the host run of the same bodies, in schedule order: [(name, rel err)]"""
+    from tests import hvp_host_mirror as HM
+    from torchmdnet_amd import _C
+
+    mir = HM.force_term_mirror(sd, hp, z, pos, batch, v, q=q)
+    L, st = _C.lib(), model._engine
+    rows = []
+    for name in mir["order"]:
+        ref = mir["bufs"][name]
+        n = L.tmdnet_hvp_debug_tensor(st.handle, None, name.encode(), None, 0)
+        if n != ref.numel():
+            rows.append((name, f"size {n} != {ref.numel()}"))
+            continue
+        out = torch.empty(ref.numel(), dtype=torch.float32, device="cuda")
+        rc = L.tmdnet_hvp_debug_tensor(st.handle, None, name.encode(), C.c_void_p(out.data_ptr()), out.numel())
+        assert rc == 0, L.tmdnet_last_error(st.handle).decode()
+        torch.cuda.synchronize()
+        o, r = out.cpu(), ref.reshape(-1)
+        if name in ("gq", "gq_t"):  # the self-pair rows of the two direction blocks are never written (nor read)
+            P1 = mir["P"] + 1
+            keep = torch.ones(2, P1, ref.numel() // (2 * P1), dtype=torch.bool)
+            keep[:, P1 - 1] = False
+            o, r = o[keep.reshape(-1)], r[keep.reshape(-1)]
+        err = (o - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        rows.append((name, err if torch.isfinite(o).all() else float("inf")))
+    return rows
+
+
+@pytest.mark.parametrize("name,extra,sizes,charges", [
+    ("tiny-o3-charges", dict(), [18, 30, 4, 11, 1], True),
+    ("so3", dict(equivariance_invariance_group="SO(3)"), [9, 21, 14], False),
+    ("wide", dict(embedding_dimension=128, num_rbf=32, num_layers=2), [40, 33, 64], True),
+    ("one-layer-lower-cutoff", dict(num_layers=1, cutoff_lower=0.8, cutoff_upper=4.5), [25, 12], False),
+    ("odd-widths", dict(embedding_dimension=64, num_rbf=50, max_z=100, num_layers=3), [64, 64, 37, 64, 2], True),
+])
+def test_analytic_force_term_gradients_match_specification(hip_lib, name, extra, sizes, charges):
+    from oracle import tensornet_second_order as S2
+    from oracle import tensornet_torch as T
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.TINY_ARGS, **extra)
+    torch.manual_seed(11)
+    model = create_model(dict(args)).to("cuda")
+    z, pos, batch = _ragged(sizes, seed=700)
+    B = len(sizes)
+    q = torch.tensor([float(m % 3 - 1) for m in range(B)]) if charges else None
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(5))
+    grads = model.force_term_parameter_gradients(z.cuda(), pos.cuda(), batch.cuda(), None, None if q is None else q.cuda(), B, v.cuda())
+    torch.cuda.synchronize()
+    sd = {k: t.detach().cpu() for k, t in model.state_dict().items()}
+    hp = T.hparams_from_args(args)
+    rows = _walk_buffers(model, sd, hp, z, pos, batch, v, q)
+    sd64 = T.cast_state_dict(sd, torch.float64)
+    ref = S2.force_term(sd64, hp, z, pos.double(), batch, v.double(), q=None if q is None else q.double())
+    refg = S2.state_dict_grads(ref["ent"], sd64, hp)
+    by_name = {id(p): k for k, p in model.named_parameters()}
+    errs = {}
+    for p, g in grads.items():
+        key = by_name[id(p)]
+        r = refg[key].reshape(g.shape)
+        scale = r.abs().max().item()
+        errs[key] = (g.cpu().double() - r).abs().max().item() / scale if scale > 0 else g.abs().max().item()
+    # s = - v . F: the same number from the engine's O2 gradient (d s / d O2 . O2 = s) and from the specification
+    O2 = model.output_model.output_network.layers[2].weight
+    s_engine = (grads[O2].cpu().double().reshape(-1) * O2.detach().cpu().double().reshape(-1)).sum().item()
+    first_bad = next(((n, e) for n, e in rows if not (isinstance(e, float) and e < 1e-3)), None)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/hvp_{name}.json", "w") as fh:
+        json.dump({"case": name, "s_engine": s_engine, "s_spec": ref["s"].item(), "worst_param": max(errs.items(), key=lambda kv: kv[1]),
+                   "param_errors": errs, "first_bad_buffer": first_bad, "buffers": rows}, fh, indent=1)
+    assert first_bad is None, first_bad
+    assert abs(s_engine - ref["s"].item()) < REL * max(1.0, abs(ref["s"].item()))
+    missing = {k for k, t in refg.items() if t.abs().max() > 0} - set(errs)
+    assert not missing, missing
+    bad = {k: e for k, e in errs.items() if not e < REL}
+    assert not bad, bad
+
+
+def test_force_matching_backward_takes_the_analytic_pass(hip_lib):
+    """derivative=True + parameter_gradients=True with force_gradient_order = 0: loss(E, F).backward() fills the weights' .grad
+    with the energy term's exact gradient plus the analytic force term, against the double backward of the oracle in fp64 at the
+    first-order pass's bound (the difference-quotient orders stay at 1e-3 / 2e-3, test_gpu_train.py)."""
+    from tests.test_gpu_train import _oracle_force_matching_grads
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.TINY_ARGS, derivative=True)
+    torch.manual_seed(17)
+    model = create_model(dict(args)).to("cuda")
+    model.parameter_gradients = True
+    model.force_gradient_order = 0
+    z, pos, batch = _ragged([22, 35, 9], seed=1300)
+    R = torch.randn(pos.shape, generator=torch.Generator().manual_seed(3))
+    ge = torch.tensor([0.7, -1.1, 0.4])
+    y, F = model(z.cuda(), pos.cuda(), batch.cuda())
+    loss = (F * R.cuda()).sum() + (y.view(-1) * ge.cuda()).sum()
+    loss.backward()
+    ref = _oracle_force_matching_grads(model, args, z, pos, batch, R, ge)
+    errs = {}
+    for k, p in model.named_parameters():
+        if k in ref and ref[k].abs().max() > 0:
+            assert p.grad is not None, k
+            errs[k] = (p.grad.cpu().double() - ref[k]).abs().max().item() / ref[k].abs().max().item()
+    worst = max(errs, key=errs.get)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/force_gradient_analytic.json", "w") as fh:
+        json.dump({"worst": [worst, errs[worst]], "errors": errs}, fh, indent=1)
+    assert errs[worst] < REL, (worst, errs[worst])

@@ -1,0 +1,45 @@
+"""The analytic second-order pass of the engine, checked without a GPU: the per-element bodies the HIP kernels run
+(csrc/tn_hvp_math.h, compiled host-only) in the engine's schedule (tests/hvp_host_mirror.py) against the specification
+oracle/tensornet_second_order.py in fp64 (itself pinned to autograd-of-autograd, tests/test_oracle.py)."""
+import os
+import shutil
+
+import pytest
+import torch
+
+from oracle import tensornet_second_order as S2
+from oracle import tensornet_torch as T
+
+pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+
+
+def _check(sd, hp, z, pos, batch, v, q=None, box=None, tol=2e-5):
+    from tests import hvp_host_mirror as HM
+
+    sd64 = T.cast_state_dict(sd, torch.float64)
+    ref = S2.force_term(sd64, hp, z, pos.double(), batch, v.double(), q=None if q is None else q.double(),
+                        box=None if box is None else box.double())
+    out = HM.force_term_mirror(sd, hp, z, pos, batch, v, q=q, box=box)
+    assert abs(out["s"].item() - ref["s"].item()) < tol * max(1.0, abs(ref["s"].item()))
+    assert set(out["ent"]) == set(ref["ent"])
+    for k, r in ref["ent"].items():
+        o = out["ent"][k].double().reshape(r.shape)
+        assert torch.isfinite(o).all(), k
+        scale = max(r.abs().max().item(), 1e-6)
+        assert (o - r).abs().max().item() < tol * scale, (k, (o - r).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("extra,use_q", [({}, True), (dict(equivariance_invariance_group="SO(3)"), False), (dict(cutoff_lower=1.2), True)])
+def test_kernel_bodies_in_engine_schedule_match_specification(golden_dir, extra, use_q):
+    tiny = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    hp = dict(T.hparams_from_args(tiny["args"]), **extra)
+    v = torch.randn(tiny["pos"].shape, generator=torch.Generator().manual_seed(3))
+    _check(tiny["state_dict"], hp, tiny["z"], tiny["pos"], tiny["batch"], v, q=tiny["q"] if use_q else None)
+
+
+def test_kernel_bodies_periodic_box(golden_dir):
+    tiny = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    f = torch.load(os.path.join(golden_dir, "tiny_pbc_ref.pt"))
+    hp = T.hparams_from_args(tiny["args"])
+    v = torch.randn(f["pos"].shape, generator=torch.Generator().manual_seed(5))
+    _check(tiny["state_dict"], hp, f["z"], f["pos"], f["batch"], v, box=f["box"])

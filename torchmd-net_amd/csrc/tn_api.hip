@@ -1834,6 +1834,8 @@ void carve_train(void* ws, tmdnet_model* m, int64_t N, int64_t P, TrainCtx* tc, 
 }
 }  // namespace
 
+extern "C++" const std::vector<std::pair<std::string, int64_t>>& param_grad_layout(tmdnet_model* m) { return train_layout(m); }
+
 int tmdnet_param_grad_count(tmdnet_model* m) {
   if (!m) return 0;
   return (int)train_layout(m).size();

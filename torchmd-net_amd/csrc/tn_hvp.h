@@ -1,0 +1,60 @@
+// Launchers of the analytic second-order pass (tn_hvp.hip; arithmetic in tn_hvp_math.h, schedule in tn_hvp_api.hip).
+// "_t" = tangent along the direction v in the positions; node tensors [N][9][F], pair rows [P + 1][...], self pair at row P.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tn_kernels.h"
+
+namespace tn {
+namespace hvp {
+
+void launch_pair_tangent(const Graph& g, int P, int K, const float* v, const float* dphi, const float* dC, float* d_t, float* rhat_t,
+                         float* phi_t, float* C_t, hipStream_t s);
+void launch_embed_scatter_dual(const Graph& g, int N, int F, int P, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                               const float* Q_t, const float* C, const float* C_t, const float* rhat_t, float* u0, float* u0_t, float* s0n,
+                               float* s0n_t, hipStream_t s);
+void launch_ln_dual(int R, int W, const float* x, const float* x_t, const float* w, const float* b, float* y, float* xh, float* rstd,
+                    float* y_t, float* xh_t, float* rstd_t, hipStream_t s);
+void launch_lnbwd_dual(int R, int W, const float* g, const float* g_t, const float* xh, const float* xh_t, const float* rstd,
+                       const float* rstd_t, const float* w, float* o, float* o_t, hipStream_t s);
+void launch_silu_tangent(int64_t n, const float* a, const float* a_t, float* h_t, hipStream_t s);
+void launch_dsilu_dual(int64_t n, const float* g, const float* g_t, const float* a, const float* a_t, float* o, float* o_t, hipStream_t s);
+void launch_gate_mul_dual(int N, int F, const float* UX, const float* UX_t, const float* gates, const float* gates_t, float* X, float* X_t,
+                          hipStream_t s);
+void launch_w_dual(int64_t rows, int F3, const float* e3, const float* e3_t, const float* C, const float* C_t, float* w, float* w_t,
+                   hipStream_t s);
+void launch_norm_dual(int N, int F, const float* X, const float* X_t, float* Xh, float* Xh_t, hipStream_t s);
+void launch_sweep2(const Graph& g, int N, int F, const float* wA, const float* srcA, const float* wB, const float* srcB, const float* init,
+                   float* out, hipStream_t s);
+void launch_group_dual(int N, int F, const float* Pn, const float* Pn_t, const float* Mi, const float* Mi_t, const float* kap, int o3,
+                       float* Ch, float* Ch_t, hipStream_t s);
+void launch_update_dual(int N, int F, const float* Xh, const float* Xh_t, const float* D, const float* D_t, const float* kap, float* Xn,
+                        float* Xn_t, hipStream_t s);
+void launch_feat_dual(int N, int F, const float* X, const float* X_t, float* feat, float* feat_t, hipStream_t s);
+void launch_head_dual(int N, int H, const float* ao, const float* ao_t, const float* O2, float std_, float* g_ao, float* g_ao_t,
+                      float* headv, hipStream_t s);
+void launch_readout_bwd_dual(int N, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G,
+                             float* G_t, hipStream_t s);
+void launch_update_bwd_dual(int N, int F, const float* G, const float* G_t, const float* D, const float* D_t, const float* kap, float* g_D,
+                            float* g_D_t, hipStream_t s);
+void launch_group_bwd_dual(int N, int F, const float* g_Ch, const float* g_Ch_t, const float* Pn, const float* Pn_t, const float* Mi,
+                           const float* Mi_t, const float* kap, int o3, float* g_Mi, float* g_Mi_t, float* g_PnY, float* g_PnY_t,
+                           hipStream_t s);
+void launch_pair_gw_dual(const Graph& g, int P, int F, const float* g_Mi, const float* g_Mi_t, const float* Pn, const float* Pn_t,
+                         const float* self_gw, const float* self_gw_t, const float* e3, const float* e3_t, const float* C, const float* C_t,
+                         float* g_e3, float* g_e3_t, hipStream_t s);
+void launch_norm_bwd_dual(int N, int F, const float* X, const float* X_t, const float* G, const float* G_t, const float* gL,
+                          const float* gL_t, float* Gn, float* Gn_t, hipStream_t s);
+void launch_gate_bwd_dual(int N, int F, const float* G, const float* G_t, const float* UX, const float* UX_t, const float* gates,
+                          const float* gates_t, const float* a2, const float* a2_t, float* g_UX, float* g_UX_t, float* g_a2, float* g_a2_t,
+                          hipStream_t s);
+void launch_embed_bwd_atom_dual(int N, int F, const float* gL, const float* gL_t, const float* u0, const float* u0_t, const float* g_s0n,
+                                const float* g_s0n_t, float* gA, float* gA_t, hipStream_t s);
+void launch_embed_edge_dual(const Graph& g, int N, int F, int P, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                            const float* Q_t, const float* C, const float* C_t, const float* rhat_t, const float* gA, const float* gA_t,
+                            float* gq, float* gq_t, int64_t dir_stride, float* selfq, float* selfq_t, float* gZu_t, float* gZv_t,
+                            hipStream_t s);
+
+}  // namespace hvp
+}  // namespace tn

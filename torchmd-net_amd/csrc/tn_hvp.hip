@@ -1,0 +1,254 @@
+// Kernels of the analytic second-order pass of force-matching training on TensorNet (gfx950):
+//     d/d theta of  s = v . d(sum_m E_m)/d pos          (reference: autograd twice, model.py:618-628; warp_ops/*_bwd_bwd)
+// The arithmetic of every kernel is one function of tn_hvp_math.h (one logical thread = one (atom, channel), pair-row element or
+// LayerNorm row), specified by oracle/tensornet_second_order.py and checked against it on the host (tests/test_hvp_host.py);
+// here is only the index arithmetic: consecutive lanes take consecutive channels (coalesced rows of the [N][9][F] tensors,
+// wave-uniform neighbour loops for F >= 64).  This pass belongs to the training path, not to the inference step: it is written to
+// be exact and simple - one launch per statement group of the specification - not tuned.
+#include "tn_hvp.h"
+
+#include "tn_hvp_math.h"
+
+namespace tn {
+namespace hvp {
+
+namespace {
+constexpr int TB = 256;
+inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); }
+#define NF_INDEX                                                           \
+  const int64_t idx_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     \
+  if (idx_ >= (int64_t)N * F) return;                                      \
+  const int n = (int)(idx_ / F), f = (int)(idx_ - (int64_t)n * F);
+
+__global__ __launch_bounds__(TB) void k_pair_tangent(Graph g, int P, int K, const float* __restrict__ v, const float* __restrict__ dphi,
+                               const float* __restrict__ dC, float* __restrict__ d_t, float* __restrict__ rhat_t, float* __restrict__ phi_t,
+                               float* __restrict__ C_t) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > P) return;
+  pair_tangent(p, P, K, g.pair_i, g.pair_j, g.prhat, g.pd, v, dphi, dC, d_t, rhat_t, phi_t, C_t);
+}
+__global__ __launch_bounds__(TB) void k_embed_scatter_dual(Graph g, int N, int F, int P, const int64_t* __restrict__ z, const float* __restrict__ Utab,
+                                     const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ Q_t,
+                                     const float* __restrict__ C, const float* __restrict__ C_t, const float* __restrict__ rhat_t,
+                                     float* __restrict__ u0, float* __restrict__ u0_t, float* __restrict__ s0n, float* __restrict__ s0n_t) {
+  NF_INDEX
+  embed_scatter_dual(n, f, F, P, g.rowptr, g.col, g.epair, g.esign, z, Utab, Vtab, Q, Q_t, C, C_t, g.prhat, rhat_t, u0, u0_t, s0n, s0n_t);
+}
+__global__ __launch_bounds__(TB) void k_ln_dual(int R, int W, const float* __restrict__ x, const float* __restrict__ x_t, const float* __restrict__ w,
+                          const float* __restrict__ b, float* __restrict__ y, float* __restrict__ xh, float* __restrict__ rstd,
+                          float* __restrict__ y_t, float* __restrict__ xh_t, float* __restrict__ rstd_t) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < R) ln_dual(r, W, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
+}
+__global__ __launch_bounds__(TB) void k_lnbwd_dual(int R, int W, const float* __restrict__ g, const float* __restrict__ g_t, const float* __restrict__ xh,
+                             const float* __restrict__ xh_t, const float* __restrict__ rstd, const float* __restrict__ rstd_t,
+                             const float* __restrict__ w, float* __restrict__ o, float* __restrict__ o_t) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < R) lnbwd_dual(r, W, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
+}
+__global__ __launch_bounds__(TB) void k_silu_tangent(int64_t n, const float* __restrict__ a, const float* __restrict__ a_t, float* __restrict__ h_t) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) silu_tangent(i, a, a_t, h_t);
+}
+__global__ __launch_bounds__(TB) void k_dsilu_dual(int64_t n, const float* __restrict__ g, const float* __restrict__ g_t, const float* __restrict__ a,
+                             const float* __restrict__ a_t, float* __restrict__ o, float* __restrict__ o_t) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dsilu_dual(i, g, g_t, a, a_t, o, o_t);
+}
+__global__ __launch_bounds__(TB) void k_gate_mul_dual(int N, int F, const float* __restrict__ UX, const float* __restrict__ UX_t, const float* __restrict__ gates,
+                                const float* __restrict__ gates_t, float* __restrict__ X, float* __restrict__ X_t) {
+  NF_INDEX
+  gate_mul_dual(n, f, F, UX, UX_t, gates, gates_t, X, X_t);
+}
+__global__ __launch_bounds__(TB) void k_w_dual(int64_t total, int F3, const float* __restrict__ e3, const float* __restrict__ e3_t, const float* __restrict__ C,
+                         const float* __restrict__ C_t, float* __restrict__ w, float* __restrict__ w_t) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) w_dual(i, F3, e3, e3_t, C, C_t, w, w_t);
+}
+__global__ __launch_bounds__(TB) void k_norm_dual(int N, int F, const float* __restrict__ X, const float* __restrict__ X_t, float* __restrict__ Xh,
+                            float* __restrict__ Xh_t) {
+  NF_INDEX
+  norm_dual(n, f, F, X, X_t, Xh, Xh_t);
+}
+__global__ __launch_bounds__(TB) void k_sweep2(Graph g, int N, int F, const float* __restrict__ wA, const float* __restrict__ srcA, const float* __restrict__ wB,
+                         const float* __restrict__ srcB, const float* __restrict__ init, float* __restrict__ out) {
+  NF_INDEX
+  sweep2(n, f, F, g.rowptr, g.col, g.epair, wA, srcA, wB, srcB, init, out);
+}
+__global__ __launch_bounds__(TB) void k_group_dual(int N, int F, const float* __restrict__ Pn, const float* __restrict__ Pn_t, const float* __restrict__ Mi,
+                             const float* __restrict__ Mi_t, const float* __restrict__ kap, int o3, float* __restrict__ Ch,
+                             float* __restrict__ Ch_t) {
+  NF_INDEX
+  group_dual(n, f, F, Pn, Pn_t, Mi, Mi_t, kap, o3, Ch, Ch_t);
+}
+__global__ __launch_bounds__(TB) void k_update_dual(int N, int F, const float* __restrict__ Xh, const float* __restrict__ Xh_t, const float* __restrict__ D,
+                              const float* __restrict__ D_t, const float* __restrict__ kap, float* __restrict__ Xn,
+                              float* __restrict__ Xn_t) {
+  NF_INDEX
+  update_dual(n, f, F, Xh, Xh_t, D, D_t, kap, Xn, Xn_t);
+}
+__global__ __launch_bounds__(TB) void k_feat_dual(int N, int F, const float* __restrict__ X, const float* __restrict__ X_t, float* __restrict__ feat,
+                            float* __restrict__ feat_t) {
+  NF_INDEX
+  feat_dual(n, f, F, X, X_t, feat, feat_t);
+}
+__global__ __launch_bounds__(TB) void k_head_dual(int64_t total, int H, const float* __restrict__ ao, const float* __restrict__ ao_t, const float* __restrict__ O2,
+                            float std_, float* __restrict__ g_ao, float* __restrict__ g_ao_t, float* __restrict__ headv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) head_dual(i, H, ao, ao_t, O2, std_, g_ao, g_ao_t, headv);
+}
+__global__ __launch_bounds__(TB) void k_readout_bwd_dual(int N, int F, const float* __restrict__ X, const float* __restrict__ X_t,
+                                   const float* __restrict__ g_feat, const float* __restrict__ g_feat_t, float* __restrict__ G,
+                                   float* __restrict__ G_t) {
+  NF_INDEX
+  readout_bwd_dual(n, f, F, X, X_t, g_feat, g_feat_t, G, G_t);
+}
+__global__ __launch_bounds__(TB) void k_update_bwd_dual(int N, int F, const float* __restrict__ G, const float* __restrict__ G_t, const float* __restrict__ D,
+                                  const float* __restrict__ D_t, const float* __restrict__ kap, float* __restrict__ g_D,
+                                  float* __restrict__ g_D_t) {
+  NF_INDEX
+  update_bwd_dual(n, f, F, G, G_t, D, D_t, kap, g_D, g_D_t);
+}
+__global__ __launch_bounds__(TB) void k_group_bwd_dual(int N, int F, const float* __restrict__ g_Ch, const float* __restrict__ g_Ch_t,
+                                 const float* __restrict__ Pn, const float* __restrict__ Pn_t, const float* __restrict__ Mi,
+                                 const float* __restrict__ Mi_t, const float* __restrict__ kap, int o3, float* __restrict__ g_Mi,
+                                 float* __restrict__ g_Mi_t, float* __restrict__ g_PnY, float* __restrict__ g_PnY_t) {
+  NF_INDEX
+  group_bwd_dual(n, f, F, g_Ch, g_Ch_t, Pn, Pn_t, Mi, Mi_t, kap, o3, g_Mi, g_Mi_t, g_PnY, g_PnY_t);
+}
+__global__ __launch_bounds__(TB) void k_pair_gw_dual(Graph g, int P, int F, const float* __restrict__ g_Mi, const float* __restrict__ g_Mi_t,
+                               const float* __restrict__ Pn, const float* __restrict__ Pn_t, const float* __restrict__ self_gw,
+                               const float* __restrict__ self_gw_t, const float* __restrict__ e3, const float* __restrict__ e3_t,
+                               const float* __restrict__ C, const float* __restrict__ C_t, float* __restrict__ g_e3,
+                               float* __restrict__ g_e3_t) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)(P + 1) * F) pair_gw_dual(i, P, F, g.pair_i, g.pair_j, g_Mi, g_Mi_t, Pn, Pn_t, self_gw, self_gw_t, e3, e3_t, C, C_t, g_e3, g_e3_t);
+}
+__global__ __launch_bounds__(TB) void k_norm_bwd_dual(int N, int F, const float* __restrict__ X, const float* __restrict__ X_t, const float* __restrict__ G,
+                                const float* __restrict__ G_t, const float* __restrict__ gL, const float* __restrict__ gL_t,
+                                float* __restrict__ Gn, float* __restrict__ Gn_t) {
+  NF_INDEX
+  norm_bwd_dual(n, f, F, X, X_t, G, G_t, gL, gL_t, Gn, Gn_t);
+}
+__global__ __launch_bounds__(TB) void k_gate_bwd_dual(int N, int F, const float* __restrict__ G, const float* __restrict__ G_t, const float* __restrict__ UX,
+                                const float* __restrict__ UX_t, const float* __restrict__ gates, const float* __restrict__ gates_t,
+                                const float* __restrict__ a2, const float* __restrict__ a2_t, float* __restrict__ g_UX,
+                                float* __restrict__ g_UX_t, float* __restrict__ g_a2, float* __restrict__ g_a2_t) {
+  NF_INDEX
+  gate_bwd_dual(n, f, F, G, G_t, UX, UX_t, gates, gates_t, a2, a2_t, g_UX, g_UX_t, g_a2, g_a2_t);
+}
+__global__ __launch_bounds__(TB) void k_embed_bwd_atom_dual(int N, int F, const float* __restrict__ gL, const float* __restrict__ gL_t,
+                                      const float* __restrict__ u0, const float* __restrict__ u0_t, const float* __restrict__ g_s0n,
+                                      const float* __restrict__ g_s0n_t, float* __restrict__ gA, float* __restrict__ gA_t) {
+  NF_INDEX
+  embed_bwd_atom_dual(n, f, F, gL, gL_t, u0, u0_t, g_s0n, g_s0n_t, gA, gA_t);
+}
+__global__ __launch_bounds__(TB) void k_embed_edge_dual(Graph g, int N, int F, int P, const int64_t* __restrict__ z, const float* __restrict__ Utab,
+                                  const float* __restrict__ Vtab, const float* __restrict__ Q, const float* __restrict__ Q_t,
+                                  const float* __restrict__ C, const float* __restrict__ C_t, const float* __restrict__ rhat_t,
+                                  const float* __restrict__ gA, const float* __restrict__ gA_t, float* __restrict__ gq,
+                                  float* __restrict__ gq_t, int64_t dir_stride, float* __restrict__ selfq, float* __restrict__ selfq_t,
+                                  float* __restrict__ gZu_t, float* __restrict__ gZv_t) {
+  NF_INDEX
+  embed_edge_dual(n, f, F, P, g.rowptr, g.col, g.epair, g.esign, z, Utab, Vtab, Q, Q_t, C, C_t, g.prhat, rhat_t, gA, gA_t, gq, gq_t,
+                  dir_stride, selfq, selfq_t, gZu_t, gZv_t);
+}
+}  // namespace
+
+#define LAUNCH(kernel, count, ...)                                                            \
+  do {                                                                                        \
+    if ((count) > 0) hipLaunchKernelGGL(kernel, grid_for(count), dim3(TB), 0, s, __VA_ARGS__); \
+  } while (0)
+
+void launch_pair_tangent(const Graph& g, int P, int K, const float* v, const float* dphi, const float* dC, float* d_t, float* rhat_t,
+                         float* phi_t, float* C_t, hipStream_t s) {
+  LAUNCH(k_pair_tangent, (int64_t)P + 1, g, P, K, v, dphi, dC, d_t, rhat_t, phi_t, C_t);
+}
+void launch_embed_scatter_dual(const Graph& g, int N, int F, int P, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                               const float* Q_t, const float* C, const float* C_t, const float* rhat_t, float* u0, float* u0_t, float* s0n,
+                               float* s0n_t, hipStream_t s) {
+  LAUNCH(k_embed_scatter_dual, (int64_t)N * F, g, N, F, P, z, Utab, Vtab, Q, Q_t, C, C_t, rhat_t, u0, u0_t, s0n, s0n_t);
+}
+void launch_ln_dual(int R, int W, const float* x, const float* x_t, const float* w, const float* b, float* y, float* xh, float* rstd,
+                    float* y_t, float* xh_t, float* rstd_t, hipStream_t s) {
+  LAUNCH(k_ln_dual, (int64_t)R, R, W, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
+}
+void launch_lnbwd_dual(int R, int W, const float* g, const float* g_t, const float* xh, const float* xh_t, const float* rstd,
+                       const float* rstd_t, const float* w, float* o, float* o_t, hipStream_t s) {
+  LAUNCH(k_lnbwd_dual, (int64_t)R, R, W, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
+}
+void launch_silu_tangent(int64_t n, const float* a, const float* a_t, float* h_t, hipStream_t s) { LAUNCH(k_silu_tangent, n, n, a, a_t, h_t); }
+void launch_dsilu_dual(int64_t n, const float* g, const float* g_t, const float* a, const float* a_t, float* o, float* o_t, hipStream_t s) {
+  LAUNCH(k_dsilu_dual, n, n, g, g_t, a, a_t, o, o_t);
+}
+void launch_gate_mul_dual(int N, int F, const float* UX, const float* UX_t, const float* gates, const float* gates_t, float* X, float* X_t,
+                          hipStream_t s) {
+  LAUNCH(k_gate_mul_dual, (int64_t)N * F, N, F, UX, UX_t, gates, gates_t, X, X_t);
+}
+void launch_w_dual(int64_t rows, int F3, const float* e3, const float* e3_t, const float* C, const float* C_t, float* w, float* w_t,
+                   hipStream_t s) {
+  LAUNCH(k_w_dual, rows * F3, rows * F3, F3, e3, e3_t, C, C_t, w, w_t);
+}
+void launch_norm_dual(int N, int F, const float* X, const float* X_t, float* Xh, float* Xh_t, hipStream_t s) {
+  LAUNCH(k_norm_dual, (int64_t)N * F, N, F, X, X_t, Xh, Xh_t);
+}
+void launch_sweep2(const Graph& g, int N, int F, const float* wA, const float* srcA, const float* wB, const float* srcB, const float* init,
+                   float* out, hipStream_t s) {
+  LAUNCH(k_sweep2, (int64_t)N * F, g, N, F, wA, srcA, wB, srcB, init, out);
+}
+void launch_group_dual(int N, int F, const float* Pn, const float* Pn_t, const float* Mi, const float* Mi_t, const float* kap, int o3,
+                       float* Ch, float* Ch_t, hipStream_t s) {
+  LAUNCH(k_group_dual, (int64_t)N * F, N, F, Pn, Pn_t, Mi, Mi_t, kap, o3, Ch, Ch_t);
+}
+void launch_update_dual(int N, int F, const float* Xh, const float* Xh_t, const float* D, const float* D_t, const float* kap, float* Xn,
+                        float* Xn_t, hipStream_t s) {
+  LAUNCH(k_update_dual, (int64_t)N * F, N, F, Xh, Xh_t, D, D_t, kap, Xn, Xn_t);
+}
+void launch_feat_dual(int N, int F, const float* X, const float* X_t, float* feat, float* feat_t, hipStream_t s) {
+  LAUNCH(k_feat_dual, (int64_t)N * F, N, F, X, X_t, feat, feat_t);
+}
+void launch_head_dual(int N, int H, const float* ao, const float* ao_t, const float* O2, float std_, float* g_ao, float* g_ao_t,
+                      float* headv, hipStream_t s) {
+  LAUNCH(k_head_dual, (int64_t)N * H, (int64_t)N * H, H, ao, ao_t, O2, std_, g_ao, g_ao_t, headv);
+}
+void launch_readout_bwd_dual(int N, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G,
+                             float* G_t, hipStream_t s) {
+  LAUNCH(k_readout_bwd_dual, (int64_t)N * F, N, F, X, X_t, g_feat, g_feat_t, G, G_t);
+}
+void launch_update_bwd_dual(int N, int F, const float* G, const float* G_t, const float* D, const float* D_t, const float* kap, float* g_D,
+                            float* g_D_t, hipStream_t s) {
+  LAUNCH(k_update_bwd_dual, (int64_t)N * F, N, F, G, G_t, D, D_t, kap, g_D, g_D_t);
+}
+void launch_group_bwd_dual(int N, int F, const float* g_Ch, const float* g_Ch_t, const float* Pn, const float* Pn_t, const float* Mi,
+                           const float* Mi_t, const float* kap, int o3, float* g_Mi, float* g_Mi_t, float* g_PnY, float* g_PnY_t,
+                           hipStream_t s) {
+  LAUNCH(k_group_bwd_dual, (int64_t)N * F, N, F, g_Ch, g_Ch_t, Pn, Pn_t, Mi, Mi_t, kap, o3, g_Mi, g_Mi_t, g_PnY, g_PnY_t);
+}
+void launch_pair_gw_dual(const Graph& g, int P, int F, const float* g_Mi, const float* g_Mi_t, const float* Pn, const float* Pn_t,
+                         const float* self_gw, const float* self_gw_t, const float* e3, const float* e3_t, const float* C, const float* C_t,
+                         float* g_e3, float* g_e3_t, hipStream_t s) {
+  LAUNCH(k_pair_gw_dual, (int64_t)(P + 1) * F, g, P, F, g_Mi, g_Mi_t, Pn, Pn_t, self_gw, self_gw_t, e3, e3_t, C, C_t, g_e3, g_e3_t);
+}
+void launch_norm_bwd_dual(int N, int F, const float* X, const float* X_t, const float* G, const float* G_t, const float* gL,
+                          const float* gL_t, float* Gn, float* Gn_t, hipStream_t s) {
+  LAUNCH(k_norm_bwd_dual, (int64_t)N * F, N, F, X, X_t, G, G_t, gL, gL_t, Gn, Gn_t);
+}
+void launch_gate_bwd_dual(int N, int F, const float* G, const float* G_t, const float* UX, const float* UX_t, const float* gates,
+                          const float* gates_t, const float* a2, const float* a2_t, float* g_UX, float* g_UX_t, float* g_a2, float* g_a2_t,
+                          hipStream_t s) {
+  LAUNCH(k_gate_bwd_dual, (int64_t)N * F, N, F, G, G_t, UX, UX_t, gates, gates_t, a2, a2_t, g_UX, g_UX_t, g_a2, g_a2_t);
+}
+void launch_embed_bwd_atom_dual(int N, int F, const float* gL, const float* gL_t, const float* u0, const float* u0_t, const float* g_s0n,
+                                const float* g_s0n_t, float* gA, float* gA_t, hipStream_t s) {
+  LAUNCH(k_embed_bwd_atom_dual, (int64_t)N * F, N, F, gL, gL_t, u0, u0_t, g_s0n, g_s0n_t, gA, gA_t);
+}
+void launch_embed_edge_dual(const Graph& g, int N, int F, int P, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                            const float* Q_t, const float* C, const float* C_t, const float* rhat_t, const float* gA, const float* gA_t,
+                            float* gq, float* gq_t, int64_t dir_stride, float* selfq, float* selfq_t, float* gZu_t, float* gZv_t,
+                            hipStream_t s) {
+  LAUNCH(k_embed_edge_dual, (int64_t)N * F, g, N, F, P, z, Utab, Vtab, Q, Q_t, C, C_t, rhat_t, gA, gA_t, gq, gq_t, dir_stride, selfq,
+         selfq_t, gZu_t, gZv_t);
+}
+
+}  // namespace hvp
+}  // namespace tn

@@ -280,6 +280,10 @@ void gemm_dual(hipStream_t s, int kind, const float* A, const float* A2, int64_t
                float* C2, int64_t ldc, int M, int N, int K, const float* rs = nullptr, const float* rs2 = nullptr,
                const uint16_t* Wsb = nullptr);
 Graph carve_graph(void* ws, int64_t N, int64_t B, int64_t ecap, size_t* total);
+// restores the per-workspace record of the last graph build (is_cell / has_z / species count) into the handle
+void recall_graph(tmdnet_model* m, const void* graph_ws);
+// (name, numel) of every entry of the flat parameter-gradient buffer (tmdnet_param_grad_entry); entries are 64-float aligned
+const std::vector<std::pair<std::string, int64_t>>& param_grad_layout(tmdnet_model* m);
 // species count rounded up to 4 / 8 when this call takes the embedding in the radial basis (tn_embed_rb.hip), else 0
 int rb_ntp(const tmdnet_model* m, int64_t n_atoms, int64_t n_pairs);
 // the three weight matrices act on the channel axis of the 1 + 3 + 5 irreducible components: one grouped launch, 9 groups

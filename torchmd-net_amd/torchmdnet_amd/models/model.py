@@ -408,20 +408,24 @@ class _EnergyForceParamGrad(torch.autograd.Function):
                               "to the parameters only", stacklevel=2)
                 model._warned_pos_grad = True
             v = g_forces.detach().to(torch.float32)
-            scale = v.abs().max()
-            vh = v / scale
             order = int(getattr(model, "force_gradient_order", 2))
-            h = getattr(model, "force_gradient_step", None)
-            h = float(h) if h else (0.02 if order >= 4 else 0.005)  # measured optimum of each order (profiles/r03_notes.md)
-            ones = torch.ones(n_mol, dtype=torch.float32, device=pos.device)
-            p0 = pos.detach()
-            G = lambda t: model.parameter_gradients_of(z, p0 + t * vh, batch, box, q, n_mol, ones)[1]
-            if order >= 4:  # (-f(2h) + 8 f(h) - 8 f(-h) + f(-2h)) / 12h
-                for t, w in ((2 * h, -1.0), (h, 8.0), (-h, -8.0), (-2 * h, 1.0)):
-                    add(G(t), -float(scale) * w / (12 * h))
+            if order == 0 and not (model._is_et() or model._is_tn2()):
+                # analytic second-order pass (TensorNet + Scalar): d (g_F . F) / d theta = - d/d theta [ g_F . d sum_m E_m / d pos ]
+                add(model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v), -1.0)
             else:
-                add(G(h), -float(scale) / (2 * h))
-                add(G(-h), float(scale) / (2 * h))
+                scale = v.abs().max()
+                vh = v / scale
+                h = getattr(model, "force_gradient_step", None)
+                h = float(h) if h else (0.02 if order >= 4 else 0.005)  # measured optimum of each order (profiles/r03_notes.md)
+                ones = torch.ones(n_mol, dtype=torch.float32, device=pos.device)
+                p0 = pos.detach()
+                G = lambda t: model.parameter_gradients_of(z, p0 + t * vh, batch, box, q, n_mol, ones)[1]
+                if order >= 4:  # (-f(2h) + 8 f(h) - 8 f(-h) + f(-2h)) / 12h
+                    for t, w in ((2 * h, -1.0), (h, 8.0), (-h, -8.0), (-2 * h, 1.0)):
+                        add(G(t), -float(scale) * w / (12 * h))
+                else:
+                    add(G(h), -float(scale) / (2 * h))
+                    add(G(-h), float(scale) / (2 * h))
         out = []
         for p in ctx.params:
             g = total.get(p)
@@ -698,6 +702,60 @@ class TorchMD_Net(nn.Module):
         gradients taken where an adjoint meets its input; the species tables' gradients are chained to emb / emb2 here."""
         energy, token = self._train_forward(z, pos, batch, box, q, n_mol, keep=False)
         return energy, self._train_backward(token, grad_energy)
+
+    def force_term_parameter_gradients(self, z, pos, batch, box, q, n_mol, v):
+        """d s / d theta of  s = v . d(sum_m E_m)/d pos = - v . F  for every weight of TensorNet + Scalar, analytically
+        (tmdnet_force_param_grads: the tangent, along v, of the engine's forward + reverse program - what the reference gets from
+        its second autograd pass, model.py:618-628 with create_graph=True).  -> {parameter: gradient}; d loss / d theta through
+        the forces is MINUS this with v = d loss / d F."""
+        if self._is_et() or self._is_tn2():
+            raise NotImplementedError("the analytic second-order pass is built for TensorNet + Scalar")
+        L = _C.lib()
+        dev = pos.device
+        with torch.cuda.device(dev):
+            st = self._sync_engine()
+            stream = _stream_ptr(dev)
+            n = int(z.shape[0])
+            p32 = pos.detach().to(torch.float32).contiguous()
+            v32 = v.detach().to(device=dev, dtype=torch.float32).contiguous()
+            assert v32.shape == p32.shape
+            z = z.contiguous()
+            batch = batch.to(torch.long).contiguous()
+            box_mode = 0
+            if box is not None:
+                box = box.detach().to(device=dev, dtype=torch.float32).contiguous()
+                box_mode = 1 if box.dim() == 2 else 2
+            if q is not None:
+                q = q.detach().to(device=dev, dtype=torch.float32).contiguous()
+            L.tmdnet_set_cell_grid(st.handle, 0, 0, 0)  # brute force inside each molecule (atoms keep their order)
+            nbytes = C.c_size_t(0)
+            L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
+            st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
+            counts = (C.c_int64 * 8)()
+            rc = L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32), _ptr(batch),
+                                      _ptr(z), _ptr(box), box_mode, counts)
+            self._raise_bad_indices(counts, L.tmdnet_last_error(st.handle).decode())
+            if rc != _C.OK:
+                raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
+            n_pairs = int(counts[0])
+            hb = C.c_size_t(0)
+            if L.tmdnet_force_param_workspace_bytes(st.handle, n, n_mol, n_pairs, C.byref(hb)) != _C.OK:
+                raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
+            st.hvp_ws = self._grow(getattr(st, "hvp_ws", None), hb.value, dev)
+            gfl = C.c_int64(0)
+            L.tmdnet_train_workspace_bytes(st.handle, n, n_mol, n_pairs, None, None, C.byref(gfl))
+            flat = torch.empty(gfl.value, dtype=torch.float32, device=dev)
+            rc = L.tmdnet_force_param_grads(st.handle, stream, _ptr(st.graph_ws), _ptr(st.hvp_ws), st.hvp_ws.numel(), n, n_mol, n_pairs,
+                                            _ptr(z), _ptr(batch), _ptr(q), _ptr(v32), _ptr(flat))
+            if rc != _C.OK:
+                raise RuntimeError(f"tmdnet_force_param_grads: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
+            st.ws_epoch = getattr(st, "ws_epoch", 0) + 1  # the graph workspace was rebuilt: a kept forward half is stale
+            ent = {}
+            for i in range(L.tmdnet_param_grad_count(st.handle)):
+                off, numel = C.c_int64(0), C.c_int64(0)
+                name = L.tmdnet_param_grad_entry(st.handle, i, C.byref(off), C.byref(numel)).decode()
+                ent[name] = flat[off.value: off.value + numel.value]
+            return self._tensornet_grads(ent)
 
     def _train_forward(self, z, pos, batch, box, q, n_mol, keep=True):
         """Forward half of the parameter-gradient pass.  keep=True: the activations stay in the model's workspaces and the
