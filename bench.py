@@ -368,8 +368,8 @@ def tn2_leg(dev, L, steps=8, warmup=3):
 
 def training_leg(dev, L, steps=4, warmup=2):
     """Training steps of the C2 model on the bench batch through the parameter-gradient pass: energy-only
-    (forward + tmdnet_energy_param_grads + SGD step with its parameter re-upload) and energy + forces (two more passes for the
-    difference quotient behind the force gradient).  Not the headline metric: a measured number for SURVEY 8(f)4."""
+    (forward + tmdnet_energy_param_grads + SGD step with its parameter re-upload) and energy + forces (plus the analytic
+    second-order pass tmdnet_force_param_grads behind the force gradient; the round-3 difference quotient timed beside it).  Not the headline metric: a measured number for SURVEY 8(f)4."""
     import torch
     from torchmdnet_amd import workloads as W
     from torchmdnet_amd.models.model import create_model
@@ -377,10 +377,12 @@ def training_leg(dev, L, steps=4, warmup=2):
     out = {"workload": "C2 model, S-mol64 256 x 64 atoms, one optimizer step (SGD) per step, random-init (seed 0)"}
     z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS)
     z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
-    for key, deriv in (("ms_per_step_energy_only", False), ("ms_per_step_energy_and_forces", True)):
+    for key, deriv, order in (("ms_per_step_energy_only", False, 0), ("ms_per_step_energy_and_forces", True, 0),
+                              ("ms_per_step_energy_and_forces_difference_quotient", True, 2)):
         torch.manual_seed(0)
         model = create_model(dict(W.C2_ARGS, derivative=deriv)).to(dev)
         model.parameter_gradients = True
+        model.force_gradient_order = order  # 0: analytic second-order pass (the default); 2: central difference, two extra passes
         opt = torch.optim.SGD(model.parameters(), lr=1e-7)
 
         def step():

@@ -44,11 +44,6 @@ void hh_norm_dual(int N, int F, const float* X, const float* X_t, float* Xh, flo
   for (int n = 0; n < N; ++n)
     for (int f = 0; f < F; ++f) norm_dual(n, f, F, X, X_t, Xh, Xh_t);
 }
-void hh_sweep2(int N, int F, const int* rowptr, const int* col, const int* epair, const float* wA, const float* srcA, const float* wB,
-               const float* srcB, const float* init, float* out) {
-  for (int n = 0; n < N; ++n)
-    for (int f = 0; f < F; ++f) sweep2(n, f, F, rowptr, col, epair, wA, srcA, wB, srcB, init, out);
-}
 void hh_group_dual(int N, int F, const float* Pn, const float* Pn_t, const float* Mi, const float* Mi_t, const float* kap, int o3,
                    float* Ch, float* Ch_t) {
   for (int n = 0; n < N; ++n)

@@ -78,6 +78,8 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     gemmT = lambda a, W: (a @ W).contiguous()  # the engine passes the stored transpose W^T to gemm()
     tlin = lambda u, Ws, tr=False: A.tensor_linear(u, Ws, tr).contiguous()
     tn_gemm = lambda a, b: a.t() @ b  # out[n][k] = sum_r a[r][n] b[r][k]
+    # the engine's plain CSR sweep (launch_message_adjoint): out[i, c] = sum_{e in row i} w[pair(e), type(c)] src[col(e), c]
+    sweep = lambda w_, src: A.csr_gather_sum(g, src, w_.view(P1, 3, F)).contiguous()
     C0, NC = (0, 1, 4), (1, 3, 5)
 
     def tlin_grad(g_out, inp):
@@ -145,9 +147,8 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
         c["Xh"], c["Xh_t"] = f32(N, 9, F), f32(N, 9, F)
         call("hh_norm_dual", N, F, X[l], X_t[l], c["Xh"], c["Xh_t"])
         c["Pn"], c["Pn_t"] = tlin(c["Xh"], V[0:3]), tlin(c["Xh_t"], V[0:3])
-        c["Mi"], c["Mi_t"] = f32(N, 9, F), f32(N, 9, F)
-        call("hh_sweep2", N, F, rowptr, col, epair, c["w"], c["Pn"], None, None, None, c["Mi"])
-        call("hh_sweep2", N, F, rowptr, col, epair, c["w"], c["Pn_t"], c["w_t"], c["Pn"], None, c["Mi_t"])
+        c["Mi"] = sweep(c["w"], c["Pn"])
+        c["Mi_t"] = sweep(c["w"], c["Pn_t"]) + sweep(c["w_t"], c["Pn"])
         c["Ch"], c["Ch_t"] = f32(N, 9, F), f32(N, 9, F)
         call("hh_group_dual", N, F, c["Pn"], c["Pn_t"], c["Mi"], c["Mi_t"], kap, o3, c["Ch"], c["Ch_t"])
         c["D"], c["D_t"] = tlin(c["Ch"], V[3:6]), tlin(c["Ch_t"], V[3:6])
@@ -197,9 +198,8 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
         g_Ch, g_Ch_t = tlin(g_D, V[3:6], True), tlin(g_D_t, V[3:6], True)
         g_Mi, g_Mi_t, g_PnY, g_PnY_t = f32(N, 9, F), f32(N, 9, F), f32(N, 9, F), f32(N, 9, F)
         call("hh_group_bwd_dual", N, F, g_Ch, g_Ch_t, c["Pn"], c["Pn_t"], c["Mi"], c["Mi_t"], kap, o3, g_Mi, g_Mi_t, g_PnY, g_PnY_t)
-        g_Pn, g_Pn_t = f32(N, 9, F), f32(N, 9, F)
-        call("hh_sweep2", N, F, rowptr, col, epair, c["w"], g_Mi, None, None, g_PnY, g_Pn)
-        call("hh_sweep2", N, F, rowptr, col, epair, c["w"], g_Mi_t, c["w_t"], g_Mi, g_PnY_t, g_Pn_t)
+        g_Pn = g_PnY + sweep(c["w"], g_Mi)
+        g_Pn_t = g_PnY_t + sweep(c["w"], g_Mi_t) + sweep(c["w_t"], g_Mi)
         # self pair: column sums over the atoms, per irreducible type (launch_colsum over the (atom, component) rows)
         self_gw = S2.tsum(g_Mi * c["Pn"]).sum(0).reshape(3 * F).contiguous()
         self_gw_t = (S2.tsum(g_Mi_t * c["Pn"]).sum(0) + S2.tsum(g_Mi * c["Pn_t"]).sum(0)).reshape(3 * F).contiguous()
@@ -261,7 +261,7 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     bufs = {k: loc[k] for k in names}
     bufs.update(C=Cc, dC=dC, g_u0l=g_u0l, g_u0l_t=g_u0l_t, G_emb=G, G_emb_t=G_t)
     if L > 0:
-        bufs.update({k: loc[k] for k in "g_D g_D_t g_Ch g_Ch_t g_Mi g_Mi_t g_PnY g_PnY_t g_Pn g_Pn_t self_gw self_gw_t g3 g3_t gh2 gh2_t g2 "
+        bufs.update({k: loc[k] for k in "g_D g_D_t g_Ch g_Ch_t g_Mi g_Mi_t g_Pn g_Pn_t self_gw self_gw_t g3 g3_t gh2 gh2_t g2 "
                                         "g2_t gh1 gh1_t g1 g1_t".split()})
         bufs.update(gXl=gXl, gXl_t=gXl_t)
     for l in range(L + 1):
@@ -278,7 +278,7 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     order += ["feat", "feat_t", "lnr", "xhr", "rstdr", "lnr_t", "xhr_t", "rstdr_t", "al", "x", "al_t", "x_t", "ao", "ao_t", "g_ao", "g_ao_t", "headv",
               "g_x", "g_x_t", "g_al", "g_al_t", "g_ln", "g_ln_t", "g_feat", "g_feat_t"]
     if L > 0:
-        order += ["g_D", "g_D_t", "g_Ch", "g_Ch_t", "g_Mi", "g_Mi_t", "g_PnY", "g_PnY_t", "g_Pn", "g_Pn_t", "self_gw", "self_gw_t", "g3", "g3_t",
+        order += ["g_D", "g_D_t", "g_Ch", "g_Ch_t", "g_Mi", "g_Mi_t", "g_Pn", "g_Pn_t", "self_gw", "self_gw_t", "g3", "g3_t",
                   "gh2", "gh2_t", "g2", "g2_t", "gh1", "gh1_t", "g1", "g1_t", "gXl", "gXl_t"]
     order += ["G_emb", "G_emb_t", "g_UX", "g_UX_t", "g_a2", "g_a2_t", "g_h1", "g_h1_t", "g_a1", "g_a1_t", "g_ln0", "g_ln0_t", "g_s0n", "g_s0n_t",
               "g_u0l", "g_u0l_t", "gA", "gA_t", "gq", "gq_t", "selfq", "selfq_t", "gZu_t", "gZv_t"]

@@ -25,8 +25,6 @@ void launch_gate_mul_dual(int N, int F, const float* UX, const float* UX_t, cons
 void launch_w_dual(int64_t rows, int F3, const float* e3, const float* e3_t, const float* C, const float* C_t, float* w, float* w_t,
                    hipStream_t s);
 void launch_norm_dual(int N, int F, const float* X, const float* X_t, float* Xh, float* Xh_t, hipStream_t s);
-void launch_sweep2(const Graph& g, int N, int F, const float* wA, const float* srcA, const float* wB, const float* srcB, const float* init,
-                   float* out, hipStream_t s);
 void launch_group_dual(int N, int F, const float* Pn, const float* Pn_t, const float* Mi, const float* Mi_t, const float* kap, int o3,
                        float* Ch, float* Ch_t, hipStream_t s);
 void launch_update_dual(int N, int F, const float* Xh, const float* Xh_t, const float* D, const float* D_t, const float* kap, float* Xn,

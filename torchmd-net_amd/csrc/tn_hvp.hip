@@ -70,11 +70,6 @@ __global__ __launch_bounds__(TB) void k_norm_dual(int N, int F, const float* __r
   NF_INDEX
   norm_dual(n, f, F, X, X_t, Xh, Xh_t);
 }
-__global__ __launch_bounds__(TB) void k_sweep2(Graph g, int N, int F, const float* __restrict__ wA, const float* __restrict__ srcA, const float* __restrict__ wB,
-                         const float* __restrict__ srcB, const float* __restrict__ init, float* __restrict__ out) {
-  NF_INDEX
-  sweep2(n, f, F, g.rowptr, g.col, g.epair, wA, srcA, wB, srcB, init, out);
-}
 __global__ __launch_bounds__(TB) void k_group_dual(int N, int F, const float* __restrict__ Pn, const float* __restrict__ Pn_t, const float* __restrict__ Mi,
                              const float* __restrict__ Mi_t, const float* __restrict__ kap, int o3, float* __restrict__ Ch,
                              float* __restrict__ Ch_t) {
@@ -191,10 +186,6 @@ void launch_w_dual(int64_t rows, int F3, const float* e3, const float* e3_t, con
 }
 void launch_norm_dual(int N, int F, const float* X, const float* X_t, float* Xh, float* Xh_t, hipStream_t s) {
   LAUNCH(k_norm_dual, (int64_t)N * F, N, F, X, X_t, Xh, Xh_t);
-}
-void launch_sweep2(const Graph& g, int N, int F, const float* wA, const float* srcA, const float* wB, const float* srcB, const float* init,
-                   float* out, hipStream_t s) {
-  LAUNCH(k_sweep2, (int64_t)N * F, g, N, F, wA, srcA, wB, srcB, init, out);
 }
 void launch_group_dual(int N, int F, const float* Pn, const float* Pn_t, const float* Mi, const float* Mi_t, const float* kap, int o3,
                        float* Ch, float* Ch_t, hipStream_t s) {

@@ -8,7 +8,8 @@
 // through the reverse sweep, and takes every weight gradient as  g_y_t^T x + g_y^T x_t  where the first-order pass takes
 // g_y^T x.  Statement by statement it is oracle/tensornet_second_order.py (pinned to autograd-of-autograd in fp64);
 // launch by launch it is tests/hvp_host_mirror.py, which runs the same kernel bodies on the host.  Dense products go through the
-// engine's GEMM launchers (gemm / tensor_linear / launch_tn_gemm / launch_colsum), everything else is a kernel of tn_hvp.hip.
+// engine's GEMM launchers (gemm / tensor_linear / launch_tn_gemm / launch_colsum), the neighbour sums through its plain CSR
+// sweep (launch_message_adjoint), everything else is a kernel of tn_hvp.hip.
 // The gradient buffer has the layout of tmdnet_energy_param_grads (tmdnet_param_grad_entry).
 #include <algorithm>
 #include <string>
@@ -34,7 +35,7 @@ struct HvpBuffers {
   float *feat, *feat_t, *lnr, *xhr, *rstdr, *lnr_t, *xhr_t, *rstdr_t, *al, *x, *al_t, *x_t, *ao, *ao_t, *g_ao, *g_ao_t, *headv;
   // reverse sweep (reused layer after layer)
   float *g_x, *g_x_t, *g_al, *g_al_t, *g_ln, *g_ln_t, *g_feat, *g_feat_t, *G, *G_t, *Gn, *Gn_t;
-  float *g_D, *g_D_t, *g_Ch, *g_Ch_t, *g_Mi, *g_Mi_t, *g_PnY, *g_PnY_t, *g_Pn, *g_Pn_t, *gXl, *gXl_t;
+  float *g_D, *g_D_t, *g_Ch, *g_Ch_t, *g_Mi, *g_Mi_t, *g_Pn, *g_Pn_t, *gXl, *gXl_t;
   float *self_gw, *self_gw_t, *g3, *g3_t, *gh2, *gh2_t, *g2, *g2_t, *gh1, *gh1_t, *g1, *g1_t;
   float *g_UX, *g_UX_t, *g_a2, *g_a2_t, *g_h1, *g_h1_t, *g_a1, *g_a1_t, *g_ln0, *g_ln0_t, *g_s0n, *g_s0n_t, *g_u0l, *g_u0l_t;
   float *gA, *gA_t, *gq, *gq_t, *selfq, *selfq_t, *gZu_t, *gZv_t, *onehot, *part;
@@ -72,7 +73,7 @@ HvpBuffers carve_hvp(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t P, s
   b.g_x = f(NF); b.g_x_t = f(NF); b.g_al = f(NF); b.g_al_t = f(NF);
   b.g_ln = f(3 * NF); b.g_ln_t = f(3 * NF); b.g_feat = f(3 * NF); b.g_feat_t = f(3 * NF);
   b.G = f(N9); b.G_t = f(N9); b.Gn = f(N9); b.Gn_t = f(N9);
-  b.g_D = f(N9); b.g_D_t = f(N9); b.g_Ch = f(N9); b.g_Ch_t = f(N9); b.g_Mi = f(N9); b.g_Mi_t = f(N9); b.g_PnY = f(N9); b.g_PnY_t = f(N9);
+  b.g_D = f(N9); b.g_D_t = f(N9); b.g_Ch = f(N9); b.g_Ch_t = f(N9); b.g_Mi = f(N9); b.g_Mi_t = f(N9);
   b.g_Pn = f(N9); b.g_Pn_t = f(N9); b.gXl = f(N9); b.gXl_t = f(N9);
   b.self_gw = f(3 * F); b.self_gw_t = f(3 * F);
   b.g3 = f(P1 * 3 * F); b.g3_t = f(P1 * 3 * F); b.gh2 = f(P1 * 2 * F); b.gh2_t = f(P1 * 2 * F); b.g2 = f(P1 * 2 * F); b.g2_t = f(P1 * 2 * F);
@@ -111,7 +112,7 @@ int tmdnet_hvp_debug_tensor(tmdnet_model* m, void* stream, const char* name, flo
   T_(feat, 3 * NF); T_(feat_t, 3 * NF); T_(lnr, 3 * NF); T_(xhr, 3 * NF); T_(rstdr, N); T_(lnr_t, 3 * NF); T_(xhr_t, 3 * NF); T_(rstdr_t, N);
   T_(al, NF); T_(x, NF); T_(al_t, NF); T_(x_t, NF); T_(ao, N * H); T_(ao_t, N * H); T_(g_ao, N * H); T_(g_ao_t, N * H); T_(headv, N * H);
   T_(g_x, NF); T_(g_x_t, NF); T_(g_al, NF); T_(g_al_t, NF); T_(g_ln, 3 * NF); T_(g_ln_t, 3 * NF); T_(g_feat, 3 * NF); T_(g_feat_t, 3 * NF);
-  T_(g_D, N9); T_(g_D_t, N9); T_(g_Ch, N9); T_(g_Ch_t, N9); T_(g_Mi, N9); T_(g_Mi_t, N9); T_(g_PnY, N9); T_(g_PnY_t, N9); T_(g_Pn, N9);
+  T_(g_D, N9); T_(g_D_t, N9); T_(g_Ch, N9); T_(g_Ch_t, N9); T_(g_Mi, N9); T_(g_Mi_t, N9); T_(g_Pn, N9);
   T_(g_Pn_t, N9); T_(gXl, N9); T_(gXl_t, N9); T_(self_gw, 3 * F); T_(self_gw_t, 3 * F); T_(g3, P1 * 3 * F); T_(g3_t, P1 * 3 * F);
   T_(gh2, P1 * 2 * F); T_(gh2_t, P1 * 2 * F); T_(g2, P1 * 2 * F); T_(g2_t, P1 * 2 * F); T_(gh1, P1 * F); T_(gh1_t, P1 * F); T_(g1, P1 * F);
   T_(g1_t, P1 * F); T_(g_UX, N9); T_(g_UX_t, N9); T_(g_a2, 3 * NF); T_(g_a2_t, 3 * NF); T_(g_h1, 2 * NF); T_(g_h1_t, 2 * NF);
@@ -164,6 +165,7 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
   const tmdnet_hparams& hp = m->hp;
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden, o3 = hp.group_o3;
   const int N = (int)n_atoms, B = (int)n_mol, P = (int)n_pairs, P1 = P + 1;
+  const int64_t N9 = (int64_t)N * 9 * F;
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, (int64_t)hp.max_num_neighbors * n_atoms, nullptr);
   if (n_pairs > g.pcap) return fail(m, TMDNET_ERR_INVALID, "n_pairs out of range");
   size_t need = 0;
@@ -252,8 +254,12 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
     hvp::launch_norm_dual(N, F, b.X[l], b.X_t[l], y.Xh, y.Xh_t, s);
     tensor_linear(s, y.Xh, q_.V, y.Pn, N, F);
     tensor_linear(s, y.Xh_t, q_.V, y.Pn_t, N, F);
-    hvp::launch_sweep2(g, N, F, y.w, y.Pn, nullptr, nullptr, nullptr, y.Mi, s);
-    hvp::launch_sweep2(g, N, F, y.w, y.Pn_t, y.w_t, y.Pn, nullptr, y.Mi_t, s);
+    // neighbour sums through the engine's plain sweep (out += sum_e w[pair(e)] src[col(e)]): Mi_t = sweep(w, Pn_t) + sweep(w_t, Pn)
+    launch_fill(y.Mi, 0.f, N9, s);
+    launch_message_adjoint(g, N, F, y.w, y.Pn, y.Mi, s);
+    launch_fill(y.Mi_t, 0.f, N9, s);
+    launch_message_adjoint(g, N, F, y.w, y.Pn_t, y.Mi_t, s);
+    launch_message_adjoint(g, N, F, y.w_t, y.Pn, y.Mi_t, s);
     hvp::launch_group_dual(N, F, y.Pn, y.Pn_t, y.Mi, y.Mi_t, kap, o3, y.Ch, y.Ch_t, s);
     tensor_linear(s, y.Ch, q_.V + 3, y.D, N, F);
     tensor_linear(s, y.Ch_t, q_.V + 3, y.D_t, N, F);
@@ -293,9 +299,11 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
     tensor_linear_grad(b.g_D, b.g_D_t, y.Ch, y.Ch_t, t_ + "Vb");
     tensor_linear(s, b.g_D, q_.VT + 3, b.g_Ch, N, F);
     tensor_linear(s, b.g_D_t, q_.VT + 3, b.g_Ch_t, N, F);
-    hvp::launch_group_bwd_dual(N, F, b.g_Ch, b.g_Ch_t, y.Pn, y.Pn_t, y.Mi, y.Mi_t, kap, o3, b.g_Mi, b.g_Mi_t, b.g_PnY, b.g_PnY_t, s);
-    hvp::launch_sweep2(g, N, F, y.w, b.g_Mi, nullptr, nullptr, b.g_PnY, b.g_Pn, s);
-    hvp::launch_sweep2(g, N, F, y.w, b.g_Mi_t, y.w_t, b.g_Mi, b.g_PnY_t, b.g_Pn_t, s);
+    // g_Pn = compose_T(g_Y) (written by the group-product adjoint) + sweep(w, g_Mi); the tangent adds sweep(w_t, g_Mi)
+    hvp::launch_group_bwd_dual(N, F, b.g_Ch, b.g_Ch_t, y.Pn, y.Pn_t, y.Mi, y.Mi_t, kap, o3, b.g_Mi, b.g_Mi_t, b.g_Pn, b.g_Pn_t, s);
+    launch_message_adjoint(g, N, F, y.w, b.g_Mi, b.g_Pn, s);
+    launch_message_adjoint(g, N, F, y.w, b.g_Mi_t, b.g_Pn_t, s);
+    launch_message_adjoint(g, N, F, y.w_t, b.g_Mi, b.g_Pn_t, s);
     // edge MLP: g_w per pair (self pair: summed over the atoms, per irreducible type), back through silu(.) C, M3, M2, M1
     for (int k = 0; k < 3; ++k) {
       const int64_t o = (int64_t)c0_[k] * F;

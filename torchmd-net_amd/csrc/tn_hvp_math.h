@@ -328,22 +328,6 @@ HVP_FN void norm_dual(int n, int f, int F, const float* X, const float* X_t, flo
   st9(Xh + o, F, h);
   st9(Xh_t + o, F, ht);
 }
-// out[i, c] = init[i, c] + sum_{e in row i} ( wA[p, type(c)] srcA[j, c] + wB[p, type(c)] srcB[j, c] )       (wB / init may be null)
-HVP_FN void sweep2(int i, int f, int F, const int* rowptr, const int* col, const int* epair, const float* wA, const float* srcA,
-                   const float* wB, const float* srcB, const float* init, float* out) {
-  const int F3 = 3 * F, F9 = 9 * F;
-  float acc[9];
-  for (int c = 0; c < 9; ++c) acc[c] = init ? init[(int64_t)i * F9 + c * F + f] : 0.f;
-  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-    const int j = col[e], p = epair[e];
-    for (int c = 0; c < 9; ++c) {
-      float t = wA[(int64_t)p * F3 + type_of(c) * F + f] * srcA[(int64_t)j * F9 + c * F + f];
-      if (wB) t += wB[(int64_t)p * F3 + type_of(c) * F + f] * srcB[(int64_t)j * F9 + c * F + f];
-      acc[c] += t;
-    }
-  }
-  st9(out + (int64_t)i * F9 + f, F, acc);
-}
 
 // ------------------------------------------------------------------------------------------------ group product
 // Cm = kappa (Y Mf + Mf Y)  [O(3)]  or  2 Y Mf  [SO(3)] and its tangent     (reference tensornet.py:42-51, 789)

@@ -120,10 +120,13 @@ static int slices_of(int R) {
 void launch_tn_gemm(hipStream_t s, const float* A, RowMap ma, const float* B, RowMap mb, const float* rowscale, const int* r_dev, int R,
                     int Nout, int Kin, float* out, bool accumulate, float* part) {
   if (Nout <= 0 || Kin <= 0) return;
-  const int slices = R > 0 ? slices_of(R) : 1;
+  const int tiles_n = (Nout + 63) / 64, tiles_k = (Kin + 63) / 64;
+  // row slices: at most slices_of(R) (>= 512 rows each), and no more than it takes to put about four blocks on every CU - a large
+  // output (24 tiles of the 3F x 2F edge-MLP weight) then writes and re-reads 42 partial outputs instead of 128
+  int slices = R > 0 ? slices_of(R) : 1;
+  slices = std::max(1, std::min(slices, std::max(8, 1024 / (tiles_n * tiles_k))));
   int rps = R > 0 ? (R + slices - 1) / slices : 1;
   rps = (rps + 1) & ~1;  // pairs of rows
-  const int tiles_n = (Nout + 63) / 64, tiles_k = (Kin + 63) / 64;
   hipLaunchKernelGGL(k_tn_gemm, dim3(tiles_n * tiles_k, slices), dim3(256), 0, s, A, ma, B, mb, rowscale, r_dev, R, Nout, Kin, tiles_k, rps,
                      part);
   const int64_t n = (int64_t)Nout * Kin;
