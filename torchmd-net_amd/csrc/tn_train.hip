@@ -8,6 +8,7 @@
 // partial tiles (deterministic, no atomics).  Rows may be the (atom, component) rows of one irreducible type of a [N, 9, F]
 // tensor (RowMap).  These are not on the inference path; they are sized to be correct and reasonably fast, not tuned.
 #include <algorithm>
+#include <cstdlib>
 
 #include "tn_common.h"
 #include "tn_kernels.h"
@@ -104,33 +105,133 @@ __global__ void k_reduce_slices(const float* __restrict__ part, int slices, int6
   out[i] = s;
 }
 
+// few outputs, many slices (a column sum over the pair rows: 384 outputs x 757 slices; one thread per output would walk them one
+// after the other, ~95 us of load latency): 16 threads share an output, fixed order inside the thread and across the 16
+__global__ __launch_bounds__(256) void k_reduce_slices_wide(const float* __restrict__ part, int slices, int64_t n, int accumulate,
+                                                            float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int e = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + e;
+  float s = 0.f;
+  if (i < n)
+    for (int k = lane; k < slices; k += 16) s += part[(int64_t)k * n + i];
+  red[lane][e] = s;
+  __syncthreads();
+  if (lane == 0 && i < n) {
+    float t = accumulate ? out[i] : 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][e];
+    out[i] = t;
+  }
+}
+static void reduce_slices(hipStream_t s, const float* part, int slices, int64_t n, bool accumulate, float* out) {
+  if (slices >= 32 && n <= 16384)
+    hipLaunchKernelGGL(k_reduce_slices_wide, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, part, slices, n, accumulate ? 1 : 0, out);
+  else
+    hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, slices, n, accumulate ? 1 : 0, out);
+}
+
+// 128 x 128 output tile per WAVE (sixteen 32 x 32 accumulators), every wave its own row range and its own partial output: per pair
+// of rows a wave loads 4 + 4 operand values for 16 matrix instructions, where the 64 x 64 kernel loads 2 + 2 for 4 - half the
+// operand traffic per flop, no LDS, no barrier.  For the pair-row products of the edge MLP (3F x 2F, 2F x F with F = 128).
+// Nout, Kin multiples of 128, plain row maps, no row scale.
+__global__ __launch_bounds__(256) void k_tn_gemm128(const float* __restrict__ A, RowMap ma, const float* __restrict__ B, RowMap mb,
+                                                    const int* __restrict__ r_dev, int R, int Nout, int Kin,
+                                                    int tiles_k, int rows_per_wave, float* __restrict__ part) {
+  if (r_dev) R = min(R, *r_dev);
+  const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = blockIdx.y * 4 + wave;
+  const int tn_ = tile / tiles_k, tk = tile - tn_ * tiles_k;
+  const int n0 = tn_ * 128, k0 = tk * 128;
+  const int kk = lane >> 5, cl = lane & 31;
+  const int r_lo = sub * rows_per_wave, r_hi = min(R, r_lo + rows_per_wave);
+  floatx16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // two pairs of rows per trip: 16 loads, 32 matrix instructions; the next trip's operands are requested before this trip's matrix
+  // instructions issue (one wave per SIMD: nobody else hides the load latency)
+  auto load = [&](int r, float (&a)[2][4], float (&b)[2][4]) {  // no branch around a load: rows past the end are clamped and masked
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rr = r + 2 * u + kk;
+      const int rc = min(rr, r_hi - 1);
+      const float* pa = A + (int64_t)rc * ma.ld + n0 + cl;
+      const float* pb = B + (int64_t)rc * mb.ld + k0 + cl;
+      const float sc = rr < r_hi ? 1.f : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[u][i] = pa[32 * i] * sc;
+        b[u][i] = pb[32 * i];
+      }
+    }
+  };
+  float a[2][4], b[2][4], an[2][4], bn[2][4];
+  if (r_lo < r_hi) load(r_lo, a, b);
+  for (int r = r_lo; r < r_hi; r += 4) {
+    load(r + 4, an, bn);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[u][i] = an[u][i];
+        b[u][i] = bn[u][i];
+      }
+  }
+  float* o = part + (int64_t)sub * Nout * Kin;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kk, k = k0 + 32 * j + cl;
+        o[(int64_t)n * Kin + k] = acc[i][j][e];
+      }
+}
+
+// partial outputs one product may write: 128, or 512 for outputs of at most 32 768 elements (launch_tn_gemm and the sizing below agree)
+static int max_partials(int64_t out_elems) { return out_elems <= 32768 ? 512 : 128; }
+
 size_t train_part_floats(int R, int64_t out_elems) {
-  int64_t slices = (R + 511) / 512;
-  if (slices > 128) slices = 128;
-  if (slices < 1) slices = 1;
-  const int64_t tn = slices * out_elems;                               // transposed products: <= 128 partial outputs
+  const int64_t tn = std::max<int64_t>(128 * out_elems, 512 * std::min<int64_t>(out_elems, 32768));  // transposed products: max_partials()
   const int64_t cs = ((int64_t)R / 256 + 2) * std::min<int64_t>(out_elems, 4096);  // column sums: one partial row per 256 rows
   return (size_t)std::max(tn, cs);
-}
-static int slices_of(int R) {
-  int s = (R + 511) / 512;
-  return s > 128 ? 128 : (s < 1 ? 1 : s);
 }
 
 void launch_tn_gemm(hipStream_t s, const float* A, RowMap ma, const float* B, RowMap mb, const float* rowscale, const int* r_dev, int R,
                     int Nout, int Kin, float* out, bool accumulate, float* part) {
   if (Nout <= 0 || Kin <= 0) return;
+  const int64_t n = (int64_t)Nout * Kin;
+  if (Nout % 128 == 0 && Kin % 128 == 0 && n >= 2 * 128 * 128 && R >= 4096 && ma.reps == 1 && mb.reps == 1 && !rowscale) {
+    // one 128 x 128 tile per wave: about 1 500 waves when the partial-output budget allows it
+    const int tiles = (Nout / 128) * (Kin / 128);
+    int slices = std::max(1, std::min({max_partials(n) / 4, (1536 + 4 * tiles - 1) / (4 * tiles), R / 512}));
+    int rpw = (R + 4 * slices - 1) / (4 * slices);
+    rpw = (rpw + 1) & ~1;  // pairs of rows
+    hipLaunchKernelGGL(k_tn_gemm128, dim3(tiles, slices), dim3(256), 0, s, A, ma, B, mb, r_dev, R, Nout, Kin, Kin / 128, rpw, part);
+    reduce_slices(s, part, 4 * slices, n, accumulate, out);
+    return;
+  }
   const int tiles_n = (Nout + 63) / 64, tiles_k = (Kin + 63) / 64;
-  // row slices: at most slices_of(R) (>= 512 rows each), and no more than it takes to put about four blocks on every CU - a large
-  // output (24 tiles of the 3F x 2F edge-MLP weight) then writes and re-reads 42 partial outputs instead of 128
-  int slices = R > 0 ? slices_of(R) : 1;
+  // row slices of >= 256 rows: as many as it takes to put about four blocks on every CU, within the partial-output budget (a 128 x 32
+  // output - two tiles - gets 512 slices, the 3F x 2F output of 24 tiles 42)
+  int slices = R > 0 ? std::max(1, std::min(max_partials(n), (R + 255) / 256)) : 1;
   slices = std::max(1, std::min(slices, std::max(8, 1024 / (tiles_n * tiles_k))));
   int rps = R > 0 ? (R + slices - 1) / slices : 1;
   rps = (rps + 1) & ~1;  // pairs of rows
   hipLaunchKernelGGL(k_tn_gemm, dim3(tiles_n * tiles_k, slices), dim3(256), 0, s, A, ma, B, mb, rowscale, r_dev, R, Nout, Kin, tiles_k, rps,
                      part);
-  const int64_t n = (int64_t)Nout * Kin;
-  hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, slices, n, accumulate ? 1 : 0, out);
+  reduce_slices(s, part, slices, n, accumulate, out);
 }
 
 // part[slice][c] = sum_{r in slice} A[r][c] * (B ? B[r][c] : 1) * (rs ? rs[r] : 1)
@@ -171,7 +272,7 @@ void launch_colsum(hipStream_t s, const float* A, RowMap ma, const float* B, Row
   if (ncol <= 0) return;
   const int slices = R > 0 ? (R + CS_ROWS - 1) / CS_ROWS : 1;
   hipLaunchKernelGGL(k_colsum, dim3((ncol + 63) / 64, slices), dim3(256), 0, s, A, ma, B, mb, rowscale, r_dev, R, ncol, part);
-  hipLaunchKernelGGL(k_reduce_slices, dim3((ncol + 255) / 256), dim3(256), 0, s, part, slices, (int64_t)ncol, accumulate ? 1 : 0, out);
+  reduce_slices(s, part, slices, (int64_t)ncol, accumulate, out);
 }
 
 // g_ao[i, :] *= gE[mol(i)]  (the seed of molecule m's energy in the loss); head[i, 0..H) = silu(ao) s_i, head[i, H] = s_i with
