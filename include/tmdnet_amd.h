@@ -309,11 +309,13 @@ int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, voi
  * forward + reverse program (no difference quotient); one self-contained pass that evaluates the radial functions directly and
  * keeps its own activations in `ws` (tmdnet_force_param_workspace_bytes: about 0.75 KB per atom-channel plus 0.2 KB per
  * pair-channel).  `grads` has the layout of tmdnet_energy_param_grads (tmdnet_param_grad_entry; d s / d bO2 = 0).  Needs a graph
- * built with the exact pair count and without the cell list; `z` may be NULL when tmdnet_build_graph saw it; deterministic. */
+ * built with the exact pair count and without the cell list; `z` may be NULL when tmdnet_build_graph saw it; deterministic.
+ * `hv` (device, [n_atoms, 3], or NULL): d s / d pos = H v, the Hessian of the summed energy applied to v - the position gradient
+ * of a loss that depends on the forces is  - H (d loss / d F)  (the reference gets it from the same second autograd pass). */
 int tmdnet_force_param_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, size_t* bytes);
 int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms,
                              int64_t n_mol, int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q, const float* v,
-                             float* grads);
+                             float* grads, float* hv);
 /* Developer / test hook: copies one intermediate of the LAST tmdnet_force_param_grads call on this handle (same thread, workspace
  * untouched since) into `out` (device); names are the buffer names of csrc/tn_hvp_api.hip ("u0_t", "l0.Mi_t", "g_Pn", ...).
  * out == NULL: returns the element count instead of a status. */

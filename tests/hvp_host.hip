@@ -78,9 +78,9 @@ void hh_group_bwd_dual(int N, int F, const float* g_Ch, const float* g_Ch_t, con
 }
 void hh_pair_gw_dual(int P, int F, const int* pi, const int* pj, const float* g_Mi, const float* g_Mi_t, const float* Pn,
                      const float* Pn_t, const float* self_gw, const float* self_gw_t, const float* e3, const float* e3_t, const float* C,
-                     const float* C_t, float* g_e3, float* g_e3_t) {
+                     const float* C_t, float* g_e3, float* g_e3_t, float* gcp, float* gcp_t) {
   for (int64_t i = 0; i < (int64_t)(P + 1) * F; ++i)
-    pair_gw_dual(i, P, F, pi, pj, g_Mi, g_Mi_t, Pn, Pn_t, self_gw, self_gw_t, e3, e3_t, C, C_t, g_e3, g_e3_t);
+    pair_gw_dual(i, P, F, pi, pj, g_Mi, g_Mi_t, Pn, Pn_t, self_gw, self_gw_t, e3, e3_t, C, C_t, g_e3, g_e3_t, gcp, gcp_t);
 }
 void hh_norm_bwd_dual(int N, int F, const float* X, const float* X_t, const float* G, const float* G_t, const float* gL, const float* gL_t,
                       float* Gn, float* Gn_t) {
@@ -105,6 +105,28 @@ void hh_embed_edge_dual(int N, int F, int P, const int* rowptr, const int* col, 
     for (int f = 0; f < F; ++f)
       embed_edge_dual(i, f, F, P, rowptr, col, epair, esign, z, Utab, Vtab, Q, Q_t, C, C_t, prhat, rhat_t, gA, gA_t, gq, gq_t, dir_stride,
                       selfq, selfq_t, gZu_t, gZv_t);
+}
+void hh_radial2(int P, int K, const float* pd, const float* means, const float* betas, float lo, float up, float* d2phi, float* d2C) {
+  for (int64_t i = 0; i < (int64_t)(P + 1) * K; ++i) radial2(i, P, K, pd, means, betas, lo, up, d2phi, d2C);
+}
+void hh_pair_rowdot(int rows, int W, const float* x, const float* x_t, const float* y, const float* y2, const float* d_t, int accumulate,
+                    float* out, float* out_t) {
+  for (int p = 0; p < rows; ++p) pair_rowdot(p, W, x, x_t, y, y2, d_t, accumulate, out, out_t);
+}
+void hh_edge_geom_dual(int E, int N, int F, int P, const int* rowptr, const int* col, const int* epair, const float* esign, const int64_t* z,
+                       const float* Utab, const float* Vtab, const float* Q, const float* Q_t, const float* C, const float* C_t,
+                       const float* prhat, const float* rhat_t, const float* gA, const float* gA_t, float* ec, float* ec_t,
+                       int64_t dir_stride) {
+  for (int e = 0; e < E; ++e)
+    edge_geom_dual(e, N, F, P, rowptr, col, epair, esign, z, Utab, Vtab, Q, Q_t, C, C_t, prhat, rhat_t, gA, gA_t, ec, ec_t, dir_stride);
+}
+void hh_geom_dual(int P, const float* pd, const float* prhat, const float* d_t, const float* rhat_t, const float* dC, const float* d2C,
+                  const float* gC, const float* gC_t, const float* gphid, const float* gphid_t, const float* ec, const float* ec_t,
+                  int64_t dir_stride, float* gdel, float* gdel_t) {
+  for (int p = 0; p < P; ++p) geom_dual(p, P, pd, prhat, d_t, rhat_t, dC, d2C, gC, gC_t, gphid, gphid_t, ec, ec_t, dir_stride, gdel, gdel_t);
+}
+void hh_pair_to_atom(int N, int P, const int* rowptr, const int* epair, const float* esign, const float* g, float* out) {
+  for (int i = 0; i < N; ++i) pair_to_atom(i, P, rowptr, epair, esign, g, out);
 }
 
 }  // extern "C"

@@ -92,6 +92,11 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     phi, dphi, Cc, dC = phi.contiguous(), dphi.contiguous(), Cc.contiguous(), dC.contiguous()
     d_t, rhat_t, phi_t, C_t = f32(P1), f32(P1, 3), f32(P1, K), f32(P1)
     call("hh_pair_tangent", P, K, pair_i, pair_j, prhat, pd, v, dphi, dC, d_t, rhat_t, phi_t, C_t)
+    # position gradient H v: second derivatives of the radial functions, per-pair accumulators of the distance gradient
+    means, betas = sd[R + "distance_expansion.means"].contiguous(), sd[R + "distance_expansion.betas"].contiguous()
+    d2phi, d2C = f32(P1, K), f32(P1)
+    call("hh_radial2", P, K, pd, means, betas, lo, up, d2phi, d2C)
+    gC, gC_t, gphid, gphid_t = torch.zeros(P1), torch.zeros(P1), torch.zeros(P1), torch.zeros(P1)
 
     # ---- embedding, forward
     Wdp = torch.cat([sd[T + f"distance_proj{k}.weight"] for k in (1, 2, 3)], 0)
@@ -204,8 +209,10 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
         self_gw = S2.tsum(g_Mi * c["Pn"]).sum(0).reshape(3 * F).contiguous()
         self_gw_t = (S2.tsum(g_Mi_t * c["Pn"]).sum(0) + S2.tsum(g_Mi * c["Pn_t"]).sum(0)).reshape(3 * F).contiguous()
         g3, g3_t = f32(P1, 3 * F), f32(P1, 3 * F)
+        gcp, gcp_t = f32(P1, F), f32(P1, F)
         call("hh_pair_gw_dual", P, F, pair_i, pair_j, g_Mi, g_Mi_t, c["Pn"], c["Pn_t"], self_gw, self_gw_t, c["pre3"], c["e3_t"], Cc, C_t,
-             g3, g3_t)
+             g3, g3_t, gcp, gcp_t)
+        call("hh_pair_rowdot", P1, F, gcp, gcp_t, None, None, d_t, 1, gC, gC_t)  # g_C[p] += sum g_w silu(e3)
         ent[f"l{l}.M2"], ent[f"l{l}.b2"] = tn_gemm(g3_t, c["he2"]) + tn_gemm(g3, c["he2_t"]), g3_t.sum(0)
         gh2, gh2_t = gemmT(g3, M[2]), gemmT(g3_t, M[2])
         g2, g2_t = f32(P1, 2 * F), f32(P1, 2 * F)
@@ -215,6 +222,9 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
         g1, g1_t = f32(P1, F), f32(P1, F)
         call("hh_dsilu_dual", C.c_int64(P1 * F), gh1, gh1_t, c["pre1"], c["e1_t"], g1, g1_t)
         ent[f"l{l}.M0"], ent[f"l{l}.b0"] = tn_gemm(g1_t, phi) + tn_gemm(g1, phi_t), g1_t.sum(0)
+        # (g_e1 M1) . phi' = g_e1 . (phi' M1^T): the distance tangents of e1 instead of a K-wide adjoint of phi
+        de1, d2e1 = gemm(dphi, M[0]), gemm(d2phi, M[0])
+        call("hh_pair_rowdot", P1, F, g1, g1_t, de1, d2e1, d_t, 1, gphid, gphid_t)
         for k, (a_, b_) in enumerate(zip(tlin_grad(g_Pn_t, c["Xh"]), tlin_grad(g_Pn, c["Xh_t"]))):
             ent[f"l{l}.Va{k}"] = a_ + b_
         gXl, gXl_t = tlin(g_Pn, V[0:3], True), tlin(g_Pn_t, V[0:3], True)
@@ -244,6 +254,17 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     selfq, selfq_t, gZu_t, gZv_t = f32(N, F), f32(N, F), f32(N, F), f32(N, F)
     call("hh_embed_edge_dual", N, F, P, rowptr, col, epair, esign, z, Utab, Vtab, Q, Q_t, Cc, C_t, prhat, rhat_t, gA, gA_t, gq, gq_t,
          C.c_int64(dir_), selfq, selfq_t, gZu_t, gZv_t)
+    dQ, d2Q = gemm(dphi, Wdp), gemm(d2phi, Wdp)
+    for k in (0, 1):  # both directions of every pair (rows < P of each block)
+        call("hh_pair_rowdot", P, 3 * F, gq[k], gq_t[k], dQ, d2Q, d_t, 1, gphid, gphid_t)
+    ec, ec_t = torch.zeros(2, P1, 4), torch.zeros(2, P1, 4)
+    call("hh_edge_geom_dual", int(col.numel()), N, F, P, rowptr, col, epair, esign, z, Utab, Vtab, Q, Q_t, Cc, C_t, prhat, rhat_t, gA, gA_t,
+         ec, ec_t, C.c_int64(P1 * 4))
+    gdel, gdel_t = f32(max(P, 1), 3), f32(max(P, 1), 3)
+    call("hh_geom_dual", P, pd, prhat, d_t, rhat_t, dC, d2C, gC, gC_t, gphid, gphid_t, ec, ec_t, C.c_int64(P1 * 4), gdel, gdel_t)
+    g_pos, Hv = f32(N, 3), f32(N, 3)
+    call("hh_pair_to_atom", N, P, rowptr, epair, esign, gdel, g_pos)
+    call("hh_pair_to_atom", N, P, rowptr, epair, esign, gdel_t, Hv)
     dW = tn_gemm(gq_t[0, :P], phi[:P]) + tn_gemm(gq_t[1, :P], phi[:P]) + tn_gemm(gq[0, :P], phi_t[:P]) + tn_gemm(gq[1, :P], phi_t[:P])
     dW[:F] += selfq_t.sum(0)[:, None] * phi[P][None, :]
     db = gq_t[0, :P].sum(0) + gq_t[1, :P].sum(0)
@@ -283,4 +304,7 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     order += ["G_emb", "G_emb_t", "g_UX", "g_UX_t", "g_a2", "g_a2_t", "g_h1", "g_h1_t", "g_a1", "g_a1_t", "g_ln0", "g_ln0_t", "g_s0n", "g_s0n_t",
               "g_u0l", "g_u0l_t", "gA", "gA_t", "gq", "gq_t", "selfq", "selfq_t", "gZu_t", "gZv_t"]
     assert set(order) == set(bufs), set(order) ^ set(bufs)
-    return dict(ent=ent, s=s_val, bufs=bufs, order=order, P=P)
+    bufs.update(d2phi=d2phi, d2C=d2C, gC=gC, gC_t=gC_t, gphid=gphid, gphid_t=gphid_t, ec=ec, ec_t=ec_t, gdel=gdel[:P], gdel_t=gdel_t[:P])
+    order += ["d2phi", "d2C", "gC", "gC_t", "gphid", "gphid_t", "ec", "ec_t", "gdel", "gdel_t"]
+    assert set(order) == set(bufs)
+    return dict(ent=ent, s=s_val, bufs=bufs, order=order, P=P, Hv=Hv, F=-g_pos)

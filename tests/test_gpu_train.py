@@ -386,14 +386,16 @@ def test_parameter_update_stays_on_the_device(hip_lib, arch):
 
 
 def test_force_loss_position_gradient_is_announced_as_truncated(hip_lib):
-    """d loss / d pos THROUGH the forces is a second derivative in the positions, which this engine does not build; pos always
-    requires grad in derivative mode (the reference's side effect), so the backward cannot refuse - it warns once that pos.grad
-    holds the energy term's part only, and the parameter gradients are unaffected."""
+    """d loss / d pos THROUGH the forces is a second derivative in the positions.  The analytic pass (TensorNet + Scalar, the
+    default) builds it (tests/test_gpu_hvp.py); the difference-quotient force gradient (order 2 / 4, and every ET / TensorNet2
+    model) does not: pos always requires grad in derivative mode (the reference's side effect), so the backward cannot refuse - it
+    warns once that pos.grad holds the energy term's part only, and the parameter gradients are unaffected."""
     from torchmdnet_amd.models.model import create_model
 
     torch.manual_seed(2)
     model = create_model(dict(W.TINY_ARGS, derivative=True)).to("cuda")
     model.parameter_gradients = True
+    model.force_gradient_order = 2
     z, pos, batch = (t.cuda() for t in _ragged([12, 20], seed=4))
     y, F = model(z, pos, batch)
     with pytest.warns(UserWarning, match="second derivative in the positions"):

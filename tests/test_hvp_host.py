@@ -21,6 +21,9 @@ def _check(sd, hp, z, pos, batch, v, q=None, box=None, tol=2e-5):
                         box=None if box is None else box.double())
     out = HM.force_term_mirror(sd, hp, z, pos, batch, v, q=q, box=box)
     assert abs(out["s"].item() - ref["s"].item()) < tol * max(1.0, abs(ref["s"].item()))
+    # H v in the positions, and the forces out of the same geometry kernels (their value half)
+    assert (out["F"].double() - ref["F"]).abs().max().item() < tol * ref["F"].abs().max().item()
+    assert (out["Hv"].double() - ref["Hv"]).abs().max().item() < 5 * tol * ref["Hv"].abs().max().item()
     assert set(out["ent"]) == set(ref["ent"])
     for k, r in ref["ent"].items():
         o = out["ent"][k].double().reshape(r.shape)

@@ -41,7 +41,7 @@ void launch_group_bwd_dual(int N, int F, const float* g_Ch, const float* g_Ch_t,
                            hipStream_t s);
 void launch_pair_gw_dual(const Graph& g, int P, int F, const float* g_Mi, const float* g_Mi_t, const float* Pn, const float* Pn_t,
                          const float* self_gw, const float* self_gw_t, const float* e3, const float* e3_t, const float* C, const float* C_t,
-                         float* g_e3, float* g_e3_t, hipStream_t s);
+                         float* g_e3, float* g_e3_t, float* gcp, float* gcp_t, hipStream_t s);  // gcp: per-channel parts of g_C (or null)
 void launch_norm_bwd_dual(int N, int F, const float* X, const float* X_t, const float* G, const float* G_t, const float* gL,
                           const float* gL_t, float* Gn, float* Gn_t, hipStream_t s);
 void launch_gate_bwd_dual(int N, int F, const float* G, const float* G_t, const float* UX, const float* UX_t, const float* gates,
@@ -53,6 +53,19 @@ void launch_embed_edge_dual(const Graph& g, int N, int F, int P, const int64_t* 
                             const float* Q_t, const float* C, const float* C_t, const float* rhat_t, const float* gA, const float* gA_t,
                             float* gq, float* gq_t, int64_t dir_stride, float* selfq, float* selfq_t, float* gZu_t, float* gZv_t,
                             hipStream_t s);
+
+// ---- H v in the positions
+void launch_radial2(const Graph& g, int P, int K, const float* means, const float* betas, float lo, float up, float* d2phi, float* d2C,
+                    hipStream_t s);
+void launch_pair_rowdot(int rows, int W, const float* x, const float* x_t, const float* y, const float* y2, const float* d_t, bool accumulate,
+                        float* out, float* out_t, hipStream_t s);
+void launch_edge_geom_dual(const Graph& g, int E, int N, int F, int P, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                           const float* Q_t, const float* C, const float* C_t, const float* rhat_t, const float* gA, const float* gA_t,
+                           float* ec, float* ec_t, int64_t dir_stride, hipStream_t s);
+void launch_geom_dual(const Graph& g, int P, const float* d_t, const float* rhat_t, const float* dC, const float* d2C, const float* gC,
+                      const float* gC_t, const float* gphid, const float* gphid_t, const float* ec, const float* ec_t, int64_t dir_stride,
+                      float* gdel, float* gdel_t, hipStream_t s);
+void launch_pair_to_atom(const Graph& g, int N, int P, const float* gp, float* out, hipStream_t s);
 
 }  // namespace hvp
 }  // namespace tn

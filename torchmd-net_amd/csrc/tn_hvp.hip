@@ -115,9 +115,10 @@ __global__ __launch_bounds__(TB) void k_pair_gw_dual(Graph g, int P, int F, cons
                                const float* __restrict__ Pn, const float* __restrict__ Pn_t, const float* __restrict__ self_gw,
                                const float* __restrict__ self_gw_t, const float* __restrict__ e3, const float* __restrict__ e3_t,
                                const float* __restrict__ C, const float* __restrict__ C_t, float* __restrict__ g_e3,
-                               float* __restrict__ g_e3_t) {
+                               float* __restrict__ g_e3_t, float* __restrict__ gcp, float* __restrict__ gcp_t) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (int64_t)(P + 1) * F) pair_gw_dual(i, P, F, g.pair_i, g.pair_j, g_Mi, g_Mi_t, Pn, Pn_t, self_gw, self_gw_t, e3, e3_t, C, C_t, g_e3, g_e3_t);
+  if (i < (int64_t)(P + 1) * F)
+    pair_gw_dual(i, P, F, g.pair_i, g.pair_j, g_Mi, g_Mi_t, Pn, Pn_t, self_gw, self_gw_t, e3, e3_t, C, C_t, g_e3, g_e3_t, gcp, gcp_t);
 }
 __global__ __launch_bounds__(TB) void k_norm_bwd_dual(int N, int F, const float* __restrict__ X, const float* __restrict__ X_t, const float* __restrict__ G,
                                 const float* __restrict__ G_t, const float* __restrict__ gL, const float* __restrict__ gL_t,
@@ -147,6 +148,43 @@ __global__ __launch_bounds__(TB) void k_embed_edge_dual(Graph g, int N, int F, i
   NF_INDEX
   embed_edge_dual(n, f, F, P, g.rowptr, g.col, g.epair, g.esign, z, Utab, Vtab, Q, Q_t, C, C_t, g.prhat, rhat_t, gA, gA_t, gq, gq_t,
                   dir_stride, selfq, selfq_t, gZu_t, gZv_t);
+}
+__global__ __launch_bounds__(TB) void k_radial2(Graph g, int P, int K, const float* __restrict__ means, const float* __restrict__ betas,
+                                                float lo, float up, float* __restrict__ d2phi, float* __restrict__ d2C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)(P + 1) * K) radial2(i, P, K, g.pd, means, betas, lo, up, d2phi, d2C);
+}
+__global__ __launch_bounds__(TB) void k_pair_rowdot(int rows, int W, const float* __restrict__ x, const float* __restrict__ x_t,
+                                                    const float* __restrict__ y, const float* __restrict__ y2,
+                                                    const float* __restrict__ d_t, int accumulate, float* __restrict__ out,
+                                                    float* __restrict__ out_t) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < rows) pair_rowdot(p, W, x, x_t, y, y2, d_t, accumulate, out, out_t);
+}
+__global__ __launch_bounds__(TB) void k_edge_geom_dual(Graph g, int E, int N, int F, int P, const int64_t* __restrict__ z,
+                                                       const float* __restrict__ Utab, const float* __restrict__ Vtab,
+                                                       const float* __restrict__ Q, const float* __restrict__ Q_t,
+                                                       const float* __restrict__ C, const float* __restrict__ C_t,
+                                                       const float* __restrict__ rhat_t, const float* __restrict__ gA,
+                                                       const float* __restrict__ gA_t, float* __restrict__ ec, float* __restrict__ ec_t,
+                                                       int64_t dir_stride) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E)
+    edge_geom_dual(e, N, F, P, g.rowptr, g.col, g.epair, g.esign, z, Utab, Vtab, Q, Q_t, C, C_t, g.prhat, rhat_t, gA, gA_t, ec, ec_t,
+                   dir_stride);
+}
+__global__ __launch_bounds__(TB) void k_geom_dual(Graph g, int P, const float* __restrict__ d_t, const float* __restrict__ rhat_t,
+                                                  const float* __restrict__ dC, const float* __restrict__ d2C, const float* __restrict__ gC,
+                                                  const float* __restrict__ gC_t, const float* __restrict__ gphid,
+                                                  const float* __restrict__ gphid_t, const float* __restrict__ ec,
+                                                  const float* __restrict__ ec_t, int64_t dir_stride, float* __restrict__ gdel,
+                                                  float* __restrict__ gdel_t) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P) geom_dual(p, P, g.pd, g.prhat, d_t, rhat_t, dC, d2C, gC, gC_t, gphid, gphid_t, ec, ec_t, dir_stride, gdel, gdel_t);
+}
+__global__ __launch_bounds__(TB) void k_pair_to_atom(Graph g, int N, int P, const float* __restrict__ gp, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) pair_to_atom(i, P, g.rowptr, g.epair, g.esign, gp, out);
 }
 }  // namespace
 
@@ -217,8 +255,9 @@ void launch_group_bwd_dual(int N, int F, const float* g_Ch, const float* g_Ch_t,
 }
 void launch_pair_gw_dual(const Graph& g, int P, int F, const float* g_Mi, const float* g_Mi_t, const float* Pn, const float* Pn_t,
                          const float* self_gw, const float* self_gw_t, const float* e3, const float* e3_t, const float* C, const float* C_t,
-                         float* g_e3, float* g_e3_t, hipStream_t s) {
-  LAUNCH(k_pair_gw_dual, (int64_t)(P + 1) * F, g, P, F, g_Mi, g_Mi_t, Pn, Pn_t, self_gw, self_gw_t, e3, e3_t, C, C_t, g_e3, g_e3_t);
+                         float* g_e3, float* g_e3_t, float* gcp, float* gcp_t, hipStream_t s) {
+  LAUNCH(k_pair_gw_dual, (int64_t)(P + 1) * F, g, P, F, g_Mi, g_Mi_t, Pn, Pn_t, self_gw, self_gw_t, e3, e3_t, C, C_t, g_e3, g_e3_t, gcp,
+         gcp_t);
 }
 void launch_norm_bwd_dual(int N, int F, const float* X, const float* X_t, const float* G, const float* G_t, const float* gL,
                           const float* gL_t, float* Gn, float* Gn_t, hipStream_t s) {
@@ -239,6 +278,28 @@ void launch_embed_edge_dual(const Graph& g, int N, int F, int P, const int64_t* 
                             hipStream_t s) {
   LAUNCH(k_embed_edge_dual, (int64_t)N * F, g, N, F, P, z, Utab, Vtab, Q, Q_t, C, C_t, rhat_t, gA, gA_t, gq, gq_t, dir_stride, selfq,
          selfq_t, gZu_t, gZv_t);
+}
+
+void launch_radial2(const Graph& g, int P, int K, const float* means, const float* betas, float lo, float up, float* d2phi, float* d2C,
+                    hipStream_t s) {
+  LAUNCH(k_radial2, (int64_t)(P + 1) * K, g, P, K, means, betas, lo, up, d2phi, d2C);
+}
+void launch_pair_rowdot(int rows, int W, const float* x, const float* x_t, const float* y, const float* y2, const float* d_t, bool accumulate,
+                        float* out, float* out_t, hipStream_t s) {
+  LAUNCH(k_pair_rowdot, (int64_t)rows, rows, W, x, x_t, y, y2, d_t, accumulate ? 1 : 0, out, out_t);
+}
+void launch_edge_geom_dual(const Graph& g, int E, int N, int F, int P, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
+                           const float* Q_t, const float* C, const float* C_t, const float* rhat_t, const float* gA, const float* gA_t,
+                           float* ec, float* ec_t, int64_t dir_stride, hipStream_t s) {
+  LAUNCH(k_edge_geom_dual, (int64_t)E, g, E, N, F, P, z, Utab, Vtab, Q, Q_t, C, C_t, rhat_t, gA, gA_t, ec, ec_t, dir_stride);
+}
+void launch_geom_dual(const Graph& g, int P, const float* d_t, const float* rhat_t, const float* dC, const float* d2C, const float* gC,
+                      const float* gC_t, const float* gphid, const float* gphid_t, const float* ec, const float* ec_t, int64_t dir_stride,
+                      float* gdel, float* gdel_t, hipStream_t s) {
+  LAUNCH(k_geom_dual, (int64_t)P, g, P, d_t, rhat_t, dC, d2C, gC, gC_t, gphid, gphid_t, ec, ec_t, dir_stride, gdel, gdel_t);
+}
+void launch_pair_to_atom(const Graph& g, int N, int P, const float* gp, float* out, hipStream_t s) {
+  LAUNCH(k_pair_to_atom, (int64_t)N, g, N, P, gp, out);
 }
 
 }  // namespace hvp

@@ -39,6 +39,8 @@ struct HvpBuffers {
   float *self_gw, *self_gw_t, *g3, *g3_t, *gh2, *gh2_t, *g2, *g2_t, *gh1, *gh1_t, *g1, *g1_t;
   float *g_UX, *g_UX_t, *g_a2, *g_a2_t, *g_h1, *g_h1_t, *g_a1, *g_a1_t, *g_ln0, *g_ln0_t, *g_s0n, *g_s0n_t, *g_u0l, *g_u0l_t;
   float *gA, *gA_t, *gq, *gq_t, *selfq, *selfq_t, *gZu_t, *gZv_t, *onehot, *part;
+  // H v in the positions
+  float *d2phi, *d2C, *gC, *gC_t, *gphid, *gphid_t, *dQ, *d2Q, *de1, *d2e1, *gcp, *gcp_t, *ec, *ec_t, *gdel, *gdel_t, *gpos;
 };
 
 HvpBuffers carve_hvp(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t P, size_t* total) {
@@ -85,6 +87,9 @@ HvpBuffers carve_hvp(void* ws, const tmdnet_hparams& hp, int64_t N, int64_t P, s
   b.selfq = f(NF); b.selfq_t = f(NF); b.gZu_t = f(NF); b.gZv_t = f(NF); b.onehot = f(N * Z);
   const int64_t big = std::max<int64_t>({6 * F * F, 3 * F * K, Z * F, H * F, 3 * F * F});
   b.part = f((int64_t)train_part_floats((int)std::max<int64_t>(P1, 5 * N), big));
+  b.d2phi = f(P1 * K); b.d2C = f(P1); b.gC = f(P1); b.gC_t = f(P1); b.gphid = f(P1); b.gphid_t = f(P1); b.dQ = f(P1 * 3 * F); b.d2Q = f(P1 * 3 * F);
+  b.de1 = f(P1 * F); b.d2e1 = f(P1 * F); b.gcp = f(P1 * F); b.gcp_t = f(P1 * F); b.ec = f(2 * P1 * 4); b.ec_t = f(2 * P1 * 4);
+  b.gdel = f(P1 * 3); b.gdel_t = f(P1 * 3); b.gpos = f(N * 3);
   if (total) *total = c.off;
   return b;
 }
@@ -119,6 +124,8 @@ int tmdnet_hvp_debug_tensor(tmdnet_model* m, void* stream, const char* name, flo
   T_(g_a1, 2 * NF); T_(g_a1_t, 2 * NF); T_(g_ln0, NF); T_(g_ln0_t, NF); T_(g_s0n, NF); T_(g_s0n_t, NF); T_(g_u0l, N9); T_(g_u0l_t, N9);
   T_(gA, N * 10 * F); T_(gA_t, N * 10 * F); T_(gq, 2 * P1 * 3 * F); T_(gq_t, 2 * P1 * 3 * F); T_(selfq, NF); T_(selfq_t, NF);
   T_(gZu_t, NF); T_(gZv_t, NF);
+  T_(d2phi, P1 * K); T_(d2C, P1); T_(gC, P1); T_(gC_t, P1); T_(gphid, P1); T_(gphid_t, P1); T_(ec, 2 * P1 * 4); T_(ec_t, 2 * P1 * 4);
+  T_(gdel, (P1 - 1) * 3); T_(gdel_t, (P1 - 1) * 3);
 #undef T_
   for (int l = 0; l <= L; ++l) {
     t["X" + std::to_string(l)] = {b.X[l], N9};
@@ -153,7 +160,7 @@ int tmdnet_force_param_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t
 }
 
 int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
-                             int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q, const float* v, float* grads) {
+                             int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q, const float* v, float* grads, float* hv) {
   if (!m || !graph_ws || !ws || !v || !grads) return TMDNET_ERR_INVALID;
   if (!m->finalized) return fail(m, TMDNET_ERR_STATE, "parameters not finalised");
   if (m->et || m->tn2) return fail(m, TMDNET_ERR_INVALID, "the analytic second-order pass is built for TensorNet + Scalar");
@@ -222,6 +229,13 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
   // ================= geometry: radial functions per pair, tangent of the geometry along v
   launch_radial(g, P, RadialParams{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper}, b.phi, b.dphi, b.C, b.dC, s);
   hvp::launch_pair_tangent(g, P, K, v, b.dphi, b.dC, b.d_t, b.rhat_t, b.phi_t, b.C_t, s);
+  if (hv) {  // position gradient: second derivatives of the radial functions, per-pair accumulators of the distance gradient
+    hvp::launch_radial2(g, P, K, W.means, W.betas, hp.cutoff_lower, hp.cutoff_upper, b.d2phi, b.d2C, s);
+    launch_fill(b.gC, 0.f, P1, s);
+    launch_fill(b.gC_t, 0.f, P1, s);
+    launch_fill(b.gphid, 0.f, P1, s);
+    launch_fill(b.gphid_t, 0.f, P1, s);
+  }
 
   // ================= embedding, forward (reference tensornet.py:543-619)
   gemm(s, b.phi, K, W.Wdp, K, W.bdp, b.Q, 3 * F, P1, 3 * F, K);
@@ -311,7 +325,9 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
       launch_colsum(s, b.g_Mi_t + o, rc_[k], y.Pn + o, rc_[k], nullptr, nullptr, N * nc_[k], F, b.self_gw_t + (int64_t)k * F, false, b.part);
       launch_colsum(s, b.g_Mi + o, rc_[k], y.Pn_t + o, rc_[k], nullptr, nullptr, N * nc_[k], F, b.self_gw_t + (int64_t)k * F, true, b.part);
     }
-    hvp::launch_pair_gw_dual(g, P, F, b.g_Mi, b.g_Mi_t, y.Pn, y.Pn_t, b.self_gw, b.self_gw_t, y.pre3, y.e3_t, b.C, b.C_t, b.g3, b.g3_t, s);
+    hvp::launch_pair_gw_dual(g, P, F, b.g_Mi, b.g_Mi_t, y.Pn, y.Pn_t, b.self_gw, b.self_gw_t, y.pre3, y.e3_t, b.C, b.C_t, b.g3, b.g3_t,
+                             hv ? b.gcp : nullptr, hv ? b.gcp_t : nullptr, s);
+    if (hv) hvp::launch_pair_rowdot(P1, F, b.gcp, b.gcp_t, nullptr, nullptr, b.d_t, true, b.gC, b.gC_t, s);  // g_C[p] += sum g_w silu(e3)
     dense_grad(b.g3, b.g3_t, r3F, y.he2, y.he2_t, r2F, P1, 3 * F, 2 * F, t_ + "M2", t_ + "b2");
     gemm(s, b.g3, 3 * F, q_.M3T, 3 * F, nullptr, b.gh2, 2 * F, P1, 2 * F, 3 * F);
     gemm(s, b.g3_t, 3 * F, q_.M3T, 3 * F, nullptr, b.gh2_t, 2 * F, P1, 2 * F, 3 * F);
@@ -321,6 +337,11 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
     gemm(s, b.g2_t, 2 * F, q_.M2T, 2 * F, nullptr, b.gh1_t, F, P1, F, 2 * F);
     hvp::launch_dsilu_dual((int64_t)P1 * F, b.gh1, b.gh1_t, y.pre1, y.e1_t, b.g1, b.g1_t, s);
     dense_grad(b.g1, b.g1_t, rF, b.phi, b.phi_t, rK, P1, F, K, t_ + "M0", t_ + "b0");
+    if (hv) {  // (g_e1 M1) . phi' = g_e1 . (phi' M1^T): the distance tangents of e1 instead of a K-wide adjoint of phi
+      gemm(s, b.dphi, K, q_.M1, K, nullptr, b.de1, F, P1, F, K);
+      gemm(s, b.d2phi, K, q_.M1, K, nullptr, b.d2e1, F, P1, F, K);
+      hvp::launch_pair_rowdot(P1, F, b.g1, b.g1_t, b.de1, b.d2e1, b.d_t, true, b.gphid, b.gphid_t, s);
+    }
     tensor_linear_grad(b.g_Pn, b.g_Pn_t, y.Xh, y.Xh_t, t_ + "Va");
     tensor_linear(s, b.g_Pn, q_.VT, b.gXl, N, F);
     tensor_linear(s, b.g_Pn_t, q_.VT, b.gXl_t, N, F);
@@ -348,6 +369,19 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
   const int64_t dir = (int64_t)P1 * 3 * F;
   hvp::launch_embed_edge_dual(g, N, F, P, z, W.Utab, W.Vtab, b.Q, b.Q_t, b.C, b.C_t, b.rhat_t, b.gA, b.gA_t, b.gq, b.gq_t, dir, b.selfq,
                               b.selfq_t, b.gZu_t, b.gZv_t, s);
+  if (hv) {
+    gemm(s, b.dphi, K, W.Wdp, K, nullptr, b.dQ, 3 * F, P1, 3 * F, K);
+    gemm(s, b.d2phi, K, W.Wdp, K, nullptr, b.d2Q, 3 * F, P1, 3 * F, K);
+    hvp::launch_pair_rowdot(P, 3 * F, b.gq, b.gq_t, b.dQ, b.d2Q, b.d_t, true, b.gphid, b.gphid_t, s);  // both directions of every pair
+    hvp::launch_pair_rowdot(P, 3 * F, b.gq + dir, b.gq_t + dir, b.dQ, b.d2Q, b.d_t, true, b.gphid, b.gphid_t, s);
+    const int64_t edir = (int64_t)P1 * 4;
+    launch_fill(b.ec, 0.f, 2 * edir, s);
+    launch_fill(b.ec_t, 0.f, 2 * edir, s);
+    const int E = 2 * P + N;  // symmetric adjacency: both directions of every pair and one self edge per atom
+    hvp::launch_edge_geom_dual(g, E, N, F, P, z, W.Utab, W.Vtab, b.Q, b.Q_t, b.C, b.C_t, b.rhat_t, b.gA, b.gA_t, b.ec, b.ec_t, edir, s);
+    hvp::launch_geom_dual(g, P, b.d_t, b.rhat_t, b.dC, b.d2C, b.gC, b.gC_t, b.gphid, b.gphid_t, b.ec, b.ec_t, edir, b.gdel, b.gdel_t, s);
+    hvp::launch_pair_to_atom(g, N, P, b.gdel_t, hv, s);
+  }
   float* dWdp = at("Wdp");
   float* dbdp = at("bdp");
   launch_tn_gemm(s, b.gq_t, r3F, b.phi, rK, nullptr, nullptr, P, 3 * F, K, dWdp, false, b.part);

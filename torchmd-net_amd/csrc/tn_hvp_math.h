@@ -500,7 +500,7 @@ HVP_FN void group_bwd_dual(int n, int f, int F, const float* g_Ch, const float* 
 // through w = silu(e3) C to the adjoint of e3:  g_e3 = g_w C silu'(e3)                 (i over (P + 1) * F; rows of width 3F)
 HVP_FN void pair_gw_dual(int64_t idx, int P, int F, const int* pair_i, const int* pair_j, const float* g_Mi, const float* g_Mi_t,
                          const float* Pn, const float* Pn_t, const float* self_gw, const float* self_gw_t, const float* e3,
-                         const float* e3_t, const float* C, const float* C_t, float* g_e3, float* g_e3_t) {
+                         const float* e3_t, const float* C, const float* C_t, float* g_e3, float* g_e3_t, float* gcp, float* gcp_t) {
   const int p = (int)(idx / F), f = (int)(idx - (int64_t)p * F);
   float gw[3] = {0.f, 0.f, 0.f}, gwt[3] = {0.f, 0.f, 0.f};
   if (p < P) {
@@ -518,11 +518,18 @@ HVP_FN void pair_gw_dual(int64_t idx, int P, int F, const int* pair_i, const int
     }
   }
   const float c = C[p], ct = C_t[p];
+  float gc = 0.f, gct = 0.f;  // this channel's part of g_C[p] = sum g_w silu(e3) (position gradient only: gcp may be null)
   for (int k = 0; k < 3; ++k) {
     const int64_t o = (int64_t)p * 3 * F + k * F + f;
     const float d1 = silu1(e3[o]);
     g_e3[o] = gw[k] * c * d1;
     g_e3_t[o] = gwt[k] * c * d1 + gw[k] * ct * d1 + gw[k] * c * silu2(e3[o]) * e3_t[o];
+    gc += gw[k] * silu0(e3[o]);
+    gct += gwt[k] * silu0(e3[o]) + gw[k] * d1 * e3_t[o];
+  }
+  if (gcp) {
+    gcp[(int64_t)p * F + f] = gc;
+    gcp_t[(int64_t)p * F + f] = gct;
   }
 }
 // adjoint of X_hat = X / (s + 1) with the residual stream's G:  g_Xh = G + gL ;  G_new = g_Xh / (s + 1) + dquad(X) g_s
@@ -673,6 +680,152 @@ HVP_FN void embed_edge_dual(int i, int f, int F, int P, const int* rowptr, const
   selfq_t[(int64_t)i * F + f] = sqt;
   gZu_t[(int64_t)i * F + f] = zu;
   gZv_t[(int64_t)i * F + f] = zv;
+}
+
+// ------------------------------------------------------------------------------------------------ H v in the positions
+// second derivatives of the radial functions (ExpNormalSmearing models/utils.py:402-407, CosineCutoff :506-528), element (p, k)
+HVP_FN void cutoff_d2(float d, float lo, float up, float& c2) {
+  const float PI = 3.14159265358979323846f;
+  if (lo > 0.f) {
+    const float k = 2.0f * PI / (up - lo), arg = PI * (2.0f * (d - lo) / (up - lo) + 1.0f);
+    c2 = (d < up && d > lo) ? -0.5f * cosf(arg) * k * k : 0.f;
+  } else {
+    const float k = PI / up;
+    c2 = d < up ? -0.5f * cosf(d * k) * k * k : 0.f;
+  }
+}
+HVP_FN void radial2(int64_t idx, int P, int K, const float* pd, const float* means, const float* betas, float lo, float up, float* d2phi,
+                    float* d2C) {
+  const float PI = 3.14159265358979323846f;
+  const int p = (int)(idx / K), k = (int)(idx - (int64_t)p * K);
+  const float d = p < P ? pd[p] : 0.f;
+  const float kc = PI / up;
+  const bool in = d < up;
+  const float c0 = in ? 0.5f * (cosf(d * kc) + 1.0f) : 0.f, c1 = in ? -0.5f * sinf(d * kc) * kc : 0.f,
+              c2 = in ? -0.5f * cosf(d * kc) * kc * kc : 0.f;
+  const float alpha = 5.0f / (up - lo), u = expf(-alpha * (d - lo)), u1 = -alpha * u, u2 = alpha * alpha * u;
+  const float mu = means[k], beta = betas[k];
+  const float g = expf(-beta * (u - mu) * (u - mu));
+  const float h = -2.0f * beta * (u - mu) * u1, h1 = -2.0f * beta * (u1 * u1 + (u - mu) * u2);
+  const float g1 = g * h, g2 = g * (h * h + h1);
+  d2phi[idx] = c2 * g + 2.0f * c1 * g1 + c0 * g2;
+  if (k == 0) cutoff_d2(d, lo, up, d2C[p]);
+}
+// out[p] (+)= sum_j x[p, j] y[p, j] ;  out_t[p] (+)= sum_j ( x_t y + x y2 d_t[p] )      (y = null: 1 ; y2 = null: no second term)
+HVP_FN void pair_rowdot(int p, int W, const float* x, const float* x_t, const float* y, const float* y2, const float* d_t, int accumulate,
+                        float* out, float* out_t) {
+  const int64_t b = (int64_t)p * W;
+  float s = 0.f, st = 0.f;
+  for (int j = 0; j < W; ++j) {
+    const float yy = y ? y[b + j] : 1.0f;
+    s += x[b + j] * yy;
+    st += x_t[b + j] * yy;
+    if (y2) st += x[b + j] * y2[b + j] * d_t[p];
+  }
+  out[p] = (accumulate ? out[p] : 0.f) + s;
+  out_t[p] = (accumulate ? out_t[p] : 0.f) + st;
+}
+// directed edge e = (i <- j) of the embedding: its part of g_C[pair] and the gradient wrt its unit vector, summed over the channels
+//   ec[dir][p] = ( sum_{k,f} gW_k Zij Q_k ,  g_re[0..2] ) with  g_re = sum_f ( gv W_1 + dq(gT, r) W_2 ),  W_k = C Zij Q_k
+HVP_FN void edge_geom_dual(int e, int N, int F, int P, const int* rowptr, const int* col, const int* epair, const float* esign,
+                           const int64_t* z, const float* Utab, const float* Vtab, const float* Q, const float* Q_t, const float* C,
+                           const float* C_t, const float* prhat, const float* rhat_t, const float* gA, const float* gA_t, float* ec,
+                           float* ec_t, int64_t dir_stride) {
+  const float sg = esign[e];
+  const int p = epair[e];
+  if (sg == 0.f || p >= P) return;
+  int lo_ = 0, hi_ = N;  // row of the edge: the last i with rowptr[i] <= e
+  while (hi_ - lo_ > 1) {
+    const int mid = (lo_ + hi_) >> 1;
+    if (rowptr[mid] <= e) lo_ = mid;
+    else hi_ = mid;
+  }
+  const int i = lo_, j = col[e];
+  const int F3 = 3 * F, F10 = 10 * F;
+  float r[3], rt[3];
+  for (int a = 0; a < 3; ++a) {
+    r[a] = sg * prhat[p * 3 + a];
+    rt[a] = sg * rhat_t[p * 3 + a];
+  }
+  const float c = C[p], ct = C_t[p];
+  float gc = 0.f, gct = 0.f, gre[3] = {0.f, 0.f, 0.f}, gret[3] = {0.f, 0.f, 0.f};
+  for (int f = 0; f < F; ++f) {
+    const float zij = Utab[z[i] * F + f] + Vtab[z[j] * F + f];
+    float a[10], at[10], q[3], qt[3], w[3], wt[3];
+    for (int cc = 0; cc < 10; ++cc) {
+      a[cc] = gA[(int64_t)i * F10 + cc * F + f];
+      at[cc] = gA_t[(int64_t)i * F10 + cc * F + f];
+    }
+    for (int k = 0; k < 3; ++k) {
+      q[k] = Q[(int64_t)p * F3 + k * F + f];
+      qt[k] = Q_t[(int64_t)p * F3 + k * F + f];
+    }
+    edge_gw(a, at, r, rt, w, wt);
+    for (int k = 0; k < 3; ++k) {
+      gc += w[k] * zij * q[k];
+      gct += (wt[k] * q[k] + w[k] * qt[k]) * zij;
+    }
+    const float W1 = c * zij * q[1], W1t = ct * zij * q[1] + c * zij * qt[1], W2 = c * zij * q[2], W2t = ct * zij * q[2] + c * zij * qt[2];
+    const float* T = a + 4;
+    const float* Tt = at + 4;
+    const float dq[3] = {2.f * T[0] * r[0] + T[1] * r[1] + T[2] * r[2], T[1] * r[0] + 2.f * T[3] * r[1] + T[4] * r[2],
+                         T[2] * r[0] + T[4] * r[1] + 2.f * T[5] * r[2]};
+    const float dqt[3] = {2.f * Tt[0] * r[0] + Tt[1] * r[1] + Tt[2] * r[2] + 2.f * T[0] * rt[0] + T[1] * rt[1] + T[2] * rt[2],
+                          Tt[1] * r[0] + 2.f * Tt[3] * r[1] + Tt[4] * r[2] + T[1] * rt[0] + 2.f * T[3] * rt[1] + T[4] * rt[2],
+                          Tt[2] * r[0] + Tt[4] * r[1] + 2.f * Tt[5] * r[2] + T[2] * rt[0] + T[4] * rt[1] + 2.f * T[5] * rt[2]};
+    for (int x = 0; x < 3; ++x) {
+      gre[x] += a[1 + x] * W1 + dq[x] * W2;
+      gret[x] += at[1 + x] * W1 + a[1 + x] * W1t + dqt[x] * W2 + dq[x] * W2t;
+    }
+  }
+  const int64_t o = (sg > 0.f ? 0 : dir_stride) + (int64_t)p * 4;
+  ec[o] = gc;
+  ec_t[o] = gct;
+  for (int x = 0; x < 3; ++x) {
+    ec[o + 1 + x] = gre[x];
+    ec_t[o + 1 + x] = gret[x];
+  }
+}
+// pair p < P: distance gradient g_d, unit-vector gradient g_rh and their tangents -> g_delta (value: minus the force contribution of
+// the pair, for checking) and g_delta_t                                        (reference neighbor_utils.py:11-46, differentiated)
+HVP_FN void geom_dual(int p, int P, const float* pd, const float* prhat, const float* d_t, const float* rhat_t, const float* dC,
+                      const float* d2C, const float* gC, const float* gC_t, const float* gphid, const float* gphid_t, const float* ec,
+                      const float* ec_t, int64_t dir_stride, float* gdel, float* gdel_t) {
+  (void)P;
+  const float d = pd[p], dt = d_t[p], inv = 1.0f / d;
+  const float c_ = gC[p] + ec[(int64_t)p * 4] + ec[dir_stride + (int64_t)p * 4];
+  const float ct_ = gC_t[p] + ec_t[(int64_t)p * 4] + ec_t[dir_stride + (int64_t)p * 4];
+  const float gd = c_ * dC[p] + gphid[p];
+  const float gdt = ct_ * dC[p] + c_ * d2C[p] * dt + gphid_t[p];
+  float r[3], rt[3], h[3], ht[3];
+  float a_ = 0.f, at_ = 0.f;
+  for (int x = 0; x < 3; ++x) {
+    r[x] = prhat[p * 3 + x];
+    rt[x] = rhat_t[p * 3 + x];
+    h[x] = ec[(int64_t)p * 4 + 1 + x] - ec[dir_stride + (int64_t)p * 4 + 1 + x];  // sum over the two directions of sign * g_re
+    ht[x] = ec_t[(int64_t)p * 4 + 1 + x] - ec_t[dir_stride + (int64_t)p * 4 + 1 + x];
+  }
+  for (int x = 0; x < 3; ++x) {
+    a_ += h[x] * r[x];
+    at_ += ht[x] * r[x] + h[x] * rt[x];
+  }
+  for (int x = 0; x < 3; ++x) {
+    const float t1 = (h[x] - a_ * r[x]) * inv;
+    const float t1t = (ht[x] - at_ * r[x] - a_ * rt[x]) * inv - t1 * dt * inv;
+    gdel[p * 3 + x] = t1 + gd * r[x];
+    gdel_t[p * 3 + x] = t1t + gdt * r[x] + gd * rt[x];
+  }
+}
+// atom i: out[i] = sum over its edges of sign(e) g[pair(e)]   (+g at the pair's first atom, -g at its second, nothing for the self edge)
+HVP_FN void pair_to_atom(int i, int P, const int* rowptr, const int* epair, const float* esign, const float* g, float* out) {
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    const float sg = esign[e];
+    const int p = epair[e];
+    if (sg == 0.f || p >= P) continue;
+    for (int x = 0; x < 3; ++x) s[x] += sg * g[p * 3 + x];
+  }
+  for (int x = 0; x < 3; ++x) out[i * 3 + x] = s[x];
 }
 
 }  // namespace hvp

@@ -401,20 +401,28 @@ class _EnergyForceParamGrad(torch.autograd.Function):
         if g_energy is not None:
             g_pos = -g_energy.reshape(-1)[batch].unsqueeze(1) * forces  # first order in pos (as tmdnet::energy_forces' backward)
         if g_forces is not None and bool((g_forces != 0).any()):
-            if ctx.needs_input_grad[2] and not getattr(model, "_warned_pos_grad", False):
+            v = g_forces.detach().to(torch.float32)
+            order = int(getattr(model, "force_gradient_order", 0))
+            analytic = order == 0 and not (model._is_et() or model._is_tn2())
+            if not analytic and ctx.needs_input_grad[2] and not getattr(model, "_warned_pos_grad", False):
                 # pos always requires grad here (the reference's side effect, model.py:584-585), so this cannot tell a caller who
                 # wants d loss / d pos from one who does not: say it once instead of silently returning a truncated gradient
                 import warnings
 
                 warnings.warn("torchmdnet_amd: pos.grad of a loss that depends on the FORCES holds only the energy term's part "
-                              "(-g_E F): the second derivative in the positions is not built; the force output carries a graph "
-                              "to the parameters only", stacklevel=2)
+                              "(-g_E F): the difference-quotient force gradient (Equivariant Transformer, TensorNet2, "
+                              "force_gradient_order 2 / 4) carries a graph to the parameters only; the second derivative in the "
+                              "positions is built for TensorNet + Scalar (force_gradient_order = 0)", stacklevel=2)
                 model._warned_pos_grad = True
-            v = g_forces.detach().to(torch.float32)
-            order = int(getattr(model, "force_gradient_order", 0))
-            if order == 0 and not (model._is_et() or model._is_tn2()):
-                # analytic second-order pass (TensorNet + Scalar): d (g_F . F) / d theta = - d/d theta [ g_F . d sum_m E_m / d pos ]
-                add(model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v), -1.0)
+            if analytic:
+                # analytic second-order pass (TensorNet + Scalar): d (g_F . F) / d theta = - d/d theta [ g_F . d sum_m E_m / d pos ],
+                # and in the positions - H g_F (H = Hessian of the summed energy)
+                if ctx.needs_input_grad[2]:
+                    gth, hv = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, want_hv=True)
+                    g_pos = -hv if g_pos is None else g_pos - hv
+                else:
+                    gth = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v)
+                add(gth, -1.0)
             else:
                 order = order or 2  # no analytic pass for this architecture: the default difference quotient
                 scale = v.abs().max()
@@ -707,11 +715,12 @@ class TorchMD_Net(nn.Module):
         energy, token = self._train_forward(z, pos, batch, box, q, n_mol, keep=False)
         return energy, self._train_backward(token, grad_energy)
 
-    def force_term_parameter_gradients(self, z, pos, batch, box, q, n_mol, v):
+    def force_term_parameter_gradients(self, z, pos, batch, box, q, n_mol, v, want_hv=False):
         """d s / d theta of  s = v . d(sum_m E_m)/d pos = - v . F  for every weight of TensorNet + Scalar, analytically
         (tmdnet_force_param_grads: the tangent, along v, of the engine's forward + reverse program - what the reference gets from
         its second autograd pass, model.py:618-628 with create_graph=True).  -> {parameter: gradient}; d loss / d theta through
-        the forces is MINUS this with v = d loss / d F."""
+        the forces is MINUS this with v = d loss / d F.  want_hv: -> ({parameter: gradient}, H v [N, 3]) with H v = d s / d pos, the
+        Hessian of the summed energy applied to v (the position gradient of such a loss is - H v)."""
         if self._is_et() or self._is_tn2():
             raise NotImplementedError("the analytic second-order pass is built for TensorNet + Scalar")
         L = _C.lib()
@@ -749,8 +758,9 @@ class TorchMD_Net(nn.Module):
             gfl = C.c_int64(0)
             L.tmdnet_train_workspace_bytes(st.handle, n, n_mol, n_pairs, None, None, C.byref(gfl))
             flat = torch.empty(gfl.value, dtype=torch.float32, device=dev)
+            hv = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_hv else None
             rc = L.tmdnet_force_param_grads(st.handle, stream, _ptr(st.graph_ws), _ptr(st.hvp_ws), st.hvp_ws.numel(), n, n_mol, n_pairs,
-                                            _ptr(z), _ptr(batch), _ptr(q), _ptr(v32), _ptr(flat))
+                                            _ptr(z), _ptr(batch), _ptr(q), _ptr(v32), _ptr(flat), _ptr(hv))
             if rc != _C.OK:
                 raise RuntimeError(f"tmdnet_force_param_grads: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
             st.ws_epoch = getattr(st, "ws_epoch", 0) + 1  # the graph workspace was rebuilt: a kept forward half is stale
@@ -759,7 +769,8 @@ class TorchMD_Net(nn.Module):
                 off, numel = C.c_int64(0), C.c_int64(0)
                 name = L.tmdnet_param_grad_entry(st.handle, i, C.byref(off), C.byref(numel)).decode()
                 ent[name] = flat[off.value: off.value + numel.value]
-            return self._tensornet_grads(ent)
+            grads = self._tensornet_grads(ent)
+            return (grads, hv) if want_hv else grads
 
     def _train_forward(self, z, pos, batch, box, q, n_mol, keep=True):
         """Forward half of the parameter-gradient pass.  keep=True: the activations stay in the model's workspaces and the
