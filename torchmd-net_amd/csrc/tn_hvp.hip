@@ -7,6 +7,7 @@
 // be exact and simple - one launch per statement group of the specification - not tuned.
 #include "tn_hvp.h"
 
+#include "tn_common.h"
 #include "tn_hvp_math.h"
 
 namespace tn {
@@ -154,12 +155,30 @@ __global__ __launch_bounds__(TB) void k_radial2(Graph g, int P, int K, const flo
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (int64_t)(P + 1) * K) radial2(i, P, K, g.pd, means, betas, lo, up, d2phi, d2C);
 }
+// the two row kernels of the position gradient spread the channels of a row over a WAVE (coalesced rows, one wave_sum per result)
+// where the bodies of tn_hvp_math.h walk them in one thread - same summands, another (fixed) order
 __global__ __launch_bounds__(TB) void k_pair_rowdot(int rows, int W, const float* __restrict__ x, const float* __restrict__ x_t,
                                                     const float* __restrict__ y, const float* __restrict__ y2,
                                                     const float* __restrict__ d_t, int accumulate, float* __restrict__ out,
                                                     float* __restrict__ out_t) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < rows) pair_rowdot(p, W, x, x_t, y, y2, d_t, accumulate, out, out_t);
+  const int p = blockIdx.x * (TB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= rows) return;  // wave-uniform
+  const int64_t b = (int64_t)p * W;
+  float s0 = 0.f, st = 0.f, s2 = 0.f;
+  for (int j = lane; j < W; j += 64) {
+    const float yy = y ? y[b + j] : 1.0f;
+    s0 += x[b + j] * yy;
+    st += x_t[b + j] * yy;
+    if (y2) s2 += x[b + j] * y2[b + j];
+  }
+  s0 = wave_sum(s0);
+  st = wave_sum(st);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    if (y2) st += s2 * d_t[p];
+    out[p] = (accumulate ? out[p] : 0.f) + s0;
+    out_t[p] = (accumulate ? out_t[p] : 0.f) + st;
+  }
 }
 __global__ __launch_bounds__(TB) void k_edge_geom_dual(Graph g, int E, int N, int F, int P, const int64_t* __restrict__ z,
                                                        const float* __restrict__ Utab, const float* __restrict__ Vtab,
@@ -168,10 +187,30 @@ __global__ __launch_bounds__(TB) void k_edge_geom_dual(Graph g, int E, int N, in
                                                        const float* __restrict__ rhat_t, const float* __restrict__ gA,
                                                        const float* __restrict__ gA_t, float* __restrict__ ec, float* __restrict__ ec_t,
                                                        int64_t dir_stride) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < E)
-    edge_geom_dual(e, N, F, P, g.rowptr, g.col, g.epair, g.esign, z, Utab, Vtab, Q, Q_t, C, C_t, g.prhat, rhat_t, gA, gA_t, ec, ec_t,
-                   dir_stride);
+  const int e = blockIdx.x * (TB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= E) return;  // wave-uniform, as everything up to the channel loop
+  const float sg = g.esign[e];
+  const int p = g.epair[e];
+  if (sg == 0.f || p >= P) return;
+  const int i = edge_geom_row(e, N, g.rowptr), j = g.col[e];
+  float r[3], rt[3], acc[4] = {0.f, 0.f, 0.f, 0.f}, acc_t[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < 3; ++a) {
+    r[a] = sg * g.prhat[p * 3 + a];
+    rt[a] = sg * rhat_t[p * 3 + a];
+  }
+  const float c = C[p], ct = C_t[p];
+  for (int f = lane; f < F; f += 64) edge_geom_term(i, j, p, f, F, r, rt, c, ct, z, Utab, Vtab, Q, Q_t, gA, gA_t, acc, acc_t);
+  for (int x = 0; x < 4; ++x) {
+    acc[x] = wave_sum(acc[x]);
+    acc_t[x] = wave_sum(acc_t[x]);
+  }
+  if (lane == 0) {
+    const int64_t o = (sg > 0.f ? 0 : dir_stride) + (int64_t)p * 4;
+    for (int x = 0; x < 4; ++x) {
+      ec[o + x] = acc[x];
+      ec_t[o + x] = acc_t[x];
+    }
+  }
 }
 __global__ __launch_bounds__(TB) void k_geom_dual(Graph g, int P, const float* __restrict__ d_t, const float* __restrict__ rhat_t,
                                                   const float* __restrict__ dC, const float* __restrict__ d2C, const float* __restrict__ gC,
@@ -286,12 +325,12 @@ void launch_radial2(const Graph& g, int P, int K, const float* means, const floa
 }
 void launch_pair_rowdot(int rows, int W, const float* x, const float* x_t, const float* y, const float* y2, const float* d_t, bool accumulate,
                         float* out, float* out_t, hipStream_t s) {
-  LAUNCH(k_pair_rowdot, (int64_t)rows, rows, W, x, x_t, y, y2, d_t, accumulate ? 1 : 0, out, out_t);
+  LAUNCH(k_pair_rowdot, (int64_t)rows * 64, rows, W, x, x_t, y, y2, d_t, accumulate ? 1 : 0, out, out_t);  // a wave per row
 }
 void launch_edge_geom_dual(const Graph& g, int E, int N, int F, int P, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
                            const float* Q_t, const float* C, const float* C_t, const float* rhat_t, const float* gA, const float* gA_t,
                            float* ec, float* ec_t, int64_t dir_stride, hipStream_t s) {
-  LAUNCH(k_edge_geom_dual, (int64_t)E, g, E, N, F, P, z, Utab, Vtab, Q, Q_t, C, C_t, rhat_t, gA, gA_t, ec, ec_t, dir_stride);
+  LAUNCH(k_edge_geom_dual, (int64_t)E * 64, g, E, N, F, P, z, Utab, Vtab, Q, Q_t, C, C_t, rhat_t, gA, gA_t, ec, ec_t, dir_stride);  // a wave per edge
 }
 void launch_geom_dual(const Graph& g, int P, const float* d_t, const float* rhat_t, const float* dC, const float* d2C, const float* gC,
                       const float* gC_t, const float* gphid, const float* gphid_t, const float* ec, const float* ec_t, int64_t dir_stride,

@@ -727,6 +727,49 @@ HVP_FN void pair_rowdot(int p, int W, const float* x, const float* x_t, const fl
 }
 // directed edge e = (i <- j) of the embedding: its part of g_C[pair] and the gradient wrt its unit vector, summed over the channels
 //   ec[dir][p] = ( sum_{k,f} gW_k Zij Q_k ,  g_re[0..2] ) with  g_re = sum_f ( gv W_1 + dq(gT, r) W_2 ),  W_k = C Zij Q_k
+// edge_geom_term: channel f's summand into acc = (gc, gre[3]) and acc_t; edge_geom_row: the row atom of edge e (binary search in rowptr)
+HVP_FN int edge_geom_row(int e, int N, const int* rowptr) {
+  int lo_ = 0, hi_ = N;  // the last i with rowptr[i] <= e
+  while (hi_ - lo_ > 1) {
+    const int mid = (lo_ + hi_) >> 1;
+    if (rowptr[mid] <= e) lo_ = mid;
+    else hi_ = mid;
+  }
+  return lo_;
+}
+HVP_FN void edge_geom_term(int i, int j, int p, int f, int F, const float r[3], const float rt[3], float c, float ct, const int64_t* z,
+                           const float* Utab, const float* Vtab, const float* Q, const float* Q_t, const float* gA, const float* gA_t,
+                           float acc[4], float acc_t[4]) {
+  const int F3 = 3 * F, F10 = 10 * F;
+  const float zij = Utab[z[i] * F + f] + Vtab[z[j] * F + f];
+  float a[10], at[10], q[3], qt[3], w[3], wt[3];
+  for (int cc = 0; cc < 10; ++cc) {
+    a[cc] = gA[(int64_t)i * F10 + cc * F + f];
+    at[cc] = gA_t[(int64_t)i * F10 + cc * F + f];
+  }
+  for (int k = 0; k < 3; ++k) {
+    q[k] = Q[(int64_t)p * F3 + k * F + f];
+    qt[k] = Q_t[(int64_t)p * F3 + k * F + f];
+  }
+  edge_gw(a, at, r, rt, w, wt);
+  for (int k = 0; k < 3; ++k) {
+    acc[0] += w[k] * zij * q[k];
+    acc_t[0] += (wt[k] * q[k] + w[k] * qt[k]) * zij;
+  }
+  const float W1 = c * zij * q[1], W1t = ct * zij * q[1] + c * zij * qt[1], W2 = c * zij * q[2], W2t = ct * zij * q[2] + c * zij * qt[2];
+  const float* T = a + 4;
+  const float* Tt = at + 4;
+  const float dq[3] = {2.f * T[0] * r[0] + T[1] * r[1] + T[2] * r[2], T[1] * r[0] + 2.f * T[3] * r[1] + T[4] * r[2],
+                       T[2] * r[0] + T[4] * r[1] + 2.f * T[5] * r[2]};
+  const float dqt[3] = {2.f * Tt[0] * r[0] + Tt[1] * r[1] + Tt[2] * r[2] + 2.f * T[0] * rt[0] + T[1] * rt[1] + T[2] * rt[2],
+                        Tt[1] * r[0] + 2.f * Tt[3] * r[1] + Tt[4] * r[2] + T[1] * rt[0] + 2.f * T[3] * rt[1] + T[4] * rt[2],
+                        Tt[2] * r[0] + Tt[4] * r[1] + 2.f * Tt[5] * r[2] + T[2] * rt[0] + T[4] * rt[1] + 2.f * T[5] * rt[2]};
+  for (int x = 0; x < 3; ++x) {
+    acc[1 + x] += a[1 + x] * W1 + dq[x] * W2;
+    acc_t[1 + x] += at[1 + x] * W1 + a[1 + x] * W1t + dqt[x] * W2 + dq[x] * W2t;
+  }
+}
+// the whole edge by one thread (host check; the kernel spreads the channels over a wave and reduces)
 HVP_FN void edge_geom_dual(int e, int N, int F, int P, const int* rowptr, const int* col, const int* epair, const float* esign,
                            const int64_t* z, const float* Utab, const float* Vtab, const float* Q, const float* Q_t, const float* C,
                            const float* C_t, const float* prhat, const float* rhat_t, const float* gA, const float* gA_t, float* ec,
@@ -734,56 +777,17 @@ HVP_FN void edge_geom_dual(int e, int N, int F, int P, const int* rowptr, const 
   const float sg = esign[e];
   const int p = epair[e];
   if (sg == 0.f || p >= P) return;
-  int lo_ = 0, hi_ = N;  // row of the edge: the last i with rowptr[i] <= e
-  while (hi_ - lo_ > 1) {
-    const int mid = (lo_ + hi_) >> 1;
-    if (rowptr[mid] <= e) lo_ = mid;
-    else hi_ = mid;
-  }
-  const int i = lo_, j = col[e];
-  const int F3 = 3 * F, F10 = 10 * F;
-  float r[3], rt[3];
+  const int i = edge_geom_row(e, N, rowptr), j = col[e];
+  float r[3], rt[3], acc[4] = {0.f, 0.f, 0.f, 0.f}, acc_t[4] = {0.f, 0.f, 0.f, 0.f};
   for (int a = 0; a < 3; ++a) {
     r[a] = sg * prhat[p * 3 + a];
     rt[a] = sg * rhat_t[p * 3 + a];
   }
-  const float c = C[p], ct = C_t[p];
-  float gc = 0.f, gct = 0.f, gre[3] = {0.f, 0.f, 0.f}, gret[3] = {0.f, 0.f, 0.f};
-  for (int f = 0; f < F; ++f) {
-    const float zij = Utab[z[i] * F + f] + Vtab[z[j] * F + f];
-    float a[10], at[10], q[3], qt[3], w[3], wt[3];
-    for (int cc = 0; cc < 10; ++cc) {
-      a[cc] = gA[(int64_t)i * F10 + cc * F + f];
-      at[cc] = gA_t[(int64_t)i * F10 + cc * F + f];
-    }
-    for (int k = 0; k < 3; ++k) {
-      q[k] = Q[(int64_t)p * F3 + k * F + f];
-      qt[k] = Q_t[(int64_t)p * F3 + k * F + f];
-    }
-    edge_gw(a, at, r, rt, w, wt);
-    for (int k = 0; k < 3; ++k) {
-      gc += w[k] * zij * q[k];
-      gct += (wt[k] * q[k] + w[k] * qt[k]) * zij;
-    }
-    const float W1 = c * zij * q[1], W1t = ct * zij * q[1] + c * zij * qt[1], W2 = c * zij * q[2], W2t = ct * zij * q[2] + c * zij * qt[2];
-    const float* T = a + 4;
-    const float* Tt = at + 4;
-    const float dq[3] = {2.f * T[0] * r[0] + T[1] * r[1] + T[2] * r[2], T[1] * r[0] + 2.f * T[3] * r[1] + T[4] * r[2],
-                         T[2] * r[0] + T[4] * r[1] + 2.f * T[5] * r[2]};
-    const float dqt[3] = {2.f * Tt[0] * r[0] + Tt[1] * r[1] + Tt[2] * r[2] + 2.f * T[0] * rt[0] + T[1] * rt[1] + T[2] * rt[2],
-                          Tt[1] * r[0] + 2.f * Tt[3] * r[1] + Tt[4] * r[2] + T[1] * rt[0] + 2.f * T[3] * rt[1] + T[4] * rt[2],
-                          Tt[2] * r[0] + Tt[4] * r[1] + 2.f * Tt[5] * r[2] + T[2] * rt[0] + T[4] * rt[1] + 2.f * T[5] * rt[2]};
-    for (int x = 0; x < 3; ++x) {
-      gre[x] += a[1 + x] * W1 + dq[x] * W2;
-      gret[x] += at[1 + x] * W1 + a[1 + x] * W1t + dqt[x] * W2 + dq[x] * W2t;
-    }
-  }
+  for (int f = 0; f < F; ++f) edge_geom_term(i, j, p, f, F, r, rt, C[p], C_t[p], z, Utab, Vtab, Q, Q_t, gA, gA_t, acc, acc_t);
   const int64_t o = (sg > 0.f ? 0 : dir_stride) + (int64_t)p * 4;
-  ec[o] = gc;
-  ec_t[o] = gct;
-  for (int x = 0; x < 3; ++x) {
-    ec[o + 1 + x] = gre[x];
-    ec_t[o + 1 + x] = gret[x];
+  for (int x = 0; x < 4; ++x) {
+    ec[o + x] = acc[x];
+    ec_t[o + x] = acc_t[x];
   }
 }
 // pair p < P: distance gradient g_d, unit-vector gradient g_rh and their tangents -> g_delta (value: minus the force contribution of

@@ -133,8 +133,9 @@ static void reduce_slices(hipStream_t s, const float* part, int slices, int64_t 
 
 // 128 x 128 output tile per WAVE (sixteen 32 x 32 accumulators), every wave its own row range and its own partial output: per pair
 // of rows a wave loads 4 + 4 operand values for 16 matrix instructions, where the 64 x 64 kernel loads 2 + 2 for 4 - half the
-// operand traffic per flop, no LDS, no barrier.  For the pair-row products of the edge MLP (3F x 2F, 2F x F with F = 128).
-// Nout, Kin multiples of 128, plain row maps, no row scale.
+// operand traffic per flop, no LDS, no barrier.  For every product whose output is whole 128 x 128 tiles (F = 128: the edge MLP's
+// 3F x 2F and 2F x F, the per-atom MLPs, the F x F tensor linears by irreducible type).
+// Nout, Kin multiples of 128, no row scale.
 __global__ __launch_bounds__(256) void k_tn_gemm128(const float* __restrict__ A, RowMap ma, const float* __restrict__ B, RowMap mb,
                                                     const int* __restrict__ r_dev, int R, int Nout, int Kin,
                                                     int tiles_k, int rows_per_wave, float* __restrict__ part) {
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(256) void k_tn_gemm128(const float* __restrict__ A,
     for (int u = 0; u < 2; ++u) {
       const int rr = r + 2 * u + kk;
       const int rc = min(rr, r_hi - 1);
-      const float* pa = A + (int64_t)rc * ma.ld + n0 + cl;
-      const float* pb = B + (int64_t)rc * mb.ld + k0 + cl;
+      const float* pa = A + row_off(ma, rc) + n0 + cl;
+      const float* pb = B + row_off(mb, rc) + k0 + cl;
       const float sc = rr < r_hi ? 1.f : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -212,10 +213,10 @@ void launch_tn_gemm(hipStream_t s, const float* A, RowMap ma, const float* B, Ro
                     int Nout, int Kin, float* out, bool accumulate, float* part) {
   if (Nout <= 0 || Kin <= 0) return;
   const int64_t n = (int64_t)Nout * Kin;
-  if (Nout % 128 == 0 && Kin % 128 == 0 && n >= 2 * 128 * 128 && R >= 4096 && ma.reps == 1 && mb.reps == 1 && !rowscale) {
-    // one 128 x 128 tile per wave: about 1 500 waves when the partial-output budget allows it
+  if (Nout % 128 == 0 && Kin % 128 == 0 && R >= 4096 && !rowscale) {
+    // one 128 x 128 tile per wave: about 1 500 waves when the partial-output budget and the row count (>= 64 rows per wave) allow it
     const int tiles = (Nout / 128) * (Kin / 128);
-    int slices = std::max(1, std::min({max_partials(n) / 4, (1536 + 4 * tiles - 1) / (4 * tiles), R / 512}));
+    int slices = std::max(1, std::min({max_partials(n) / 4, (1536 + 4 * tiles - 1) / (4 * tiles), R / 256}));
     int rpw = (R + 4 * slices - 1) / (4 * slices);
     rpw = (rpw + 1) & ~1;  // pairs of rows
     hipLaunchKernelGGL(k_tn_gemm128, dim3(tiles, slices), dim3(256), 0, s, A, ma, B, mb, r_dev, R, Nout, Kin, Kin / 128, rpw, part);
@@ -223,10 +224,11 @@ void launch_tn_gemm(hipStream_t s, const float* A, RowMap ma, const float* B, Ro
     return;
   }
   const int tiles_n = (Nout + 63) / 64, tiles_k = (Kin + 63) / 64;
-  // row slices of >= 256 rows: as many as it takes to put about four blocks on every CU, within the partial-output budget (a 128 x 32
-  // output - two tiles - gets 512 slices, the 3F x 2F output of 24 tiles 42)
-  int slices = R > 0 ? std::max(1, std::min(max_partials(n), (R + 255) / 256)) : 1;
-  slices = std::max(1, std::min(slices, std::max(8, 1024 / (tiles_n * tiles_k))));
+  // row slices of >= 256 rows: as many as it takes to put about four blocks on every CU, at most 128 (512 for an output of one or
+  // two tiles: the 128 x 32 product of the first edge layer) and within the partial-output budget
+  const int tiles = tiles_n * tiles_k;
+  int slices = R > 0 ? std::max(1, std::min({max_partials(n), tiles <= 2 ? 512 : 128, (R + 255) / 256})) : 1;
+  slices = std::max(1, std::min(slices, std::max(8, 1024 / tiles)));
   int rps = R > 0 ? (R + slices - 1) / slices : 1;
   rps = (rps + 1) & ~1;  // pairs of rows
   hipLaunchKernelGGL(k_tn_gemm, dim3(tiles_n * tiles_k, slices), dim3(256), 0, s, A, ma, B, mb, rowscale, r_dev, R, Nout, Kin, tiles_k, rps,

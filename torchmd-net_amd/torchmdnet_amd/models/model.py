@@ -417,7 +417,7 @@ class _EnergyForceParamGrad(torch.autograd.Function):
             if analytic:
                 # analytic second-order pass (TensorNet + Scalar): d (g_F . F) / d theta = - d/d theta [ g_F . d sum_m E_m / d pos ],
                 # and in the positions - H g_F (H = Hessian of the summed energy)
-                if ctx.needs_input_grad[2]:
+                if ctx.needs_input_grad[2] and getattr(model, "force_position_gradient", True):
                     gth, hv = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, want_hv=True)
                     g_pos = -hv if g_pos is None else g_pos - hv
                 else:
@@ -477,6 +477,7 @@ class TorchMD_Net(nn.Module):
         # second-order pass along d loss / d F (force matching; TensorNet + Scalar - a central difference otherwise, order below).  The reference needs no switch (autograd records
         # everything); here the default call stays on the inference schedule (radial tables, no saved activations)
         self.parameter_gradients = False
+        self.force_position_gradient = True  # analytic pass: also - H g_F into pos.grad (False: the energy term's part only, a little faster)
         self.force_gradient_step = None  # Angstrom: largest atom displacement of the finite-difference direction (None: 0.005 / 0.02)
         self.force_gradient_order = 0    # 0: analytic second-order pass (TensorNet + Scalar) ; 2 / 4: central difference, two / four extra passes
         self.reset_parameters()
