@@ -287,3 +287,34 @@ def test_hand_second_order_pass_periodic(tiny, golden_dir):
     for k, r in ref.items():
         if r.abs().max() > 0:
             assert rel_err(mine[k].reshape(r.shape), r) < 1e-10, k
+
+
+@pytest.mark.parametrize("fixture", ["et_tiny_ref.pt", "et_tiny_vc_ref.pt"])
+def test_et_hand_second_order_pass_equals_autograd_of_autograd(golden_dir, fixture):
+    """oracle/et_second_order.py - the specification of an analytic force-matching pass for the Equivariant Transformer (not built in
+    the engine yet: DESIGN.md 9b) - against two nested autograd passes over oracle/et_torch.py in fp64: every parameter and H v
+    (both distance filters + neighbour embedding; vector cutoff + key filter only)."""
+    from oracle import et_second_order as E2
+
+    g = torch.load(os.path.join(golden_dir, fixture))
+    hp = ET.hparams_from_args(g["args"])
+    sd = {k: (t.double() if t.is_floating_point() else t) for k, t in g["state_dict"].items()}
+    z, pos, batch = g["z"], g["pos"].double(), g["batch"]
+    v = torch.randn(pos.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    keys = [k for k, t in sd.items() if t.is_floating_point() and t.dim() > 0 and "distance" not in k.split("neighbor_embedding.")[0]]
+    sdg = {k: (t.clone().requires_grad_(True) if k in keys else t) for k, t in sd.items()}
+    p = pos.clone().requires_grad_(True)
+    (gp,) = torch.autograd.grad(ET.energy(sdg, hp, z, p, batch).sum(), p, create_graph=True)
+    s = (gp * v).sum()
+    grads = torch.autograd.grad(s, [sdg[k] for k in keys] + [p], allow_unused=True)
+    out = E2.force_term(sd, hp, z, pos, batch, v)
+    assert abs(out["s"].item() - s.item()) < 1e-11 * max(1.0, abs(s.item()))
+    assert rel_err(out["F"], -gp.detach()) < 1e-11 and rel_err(out["Hv"], grads[-1]) < 1e-11
+    checked = 0
+    for k, r in zip(keys, grads[:-1]):
+        if r is None or r.abs().max() == 0:
+            assert k not in out["grads"] or out["grads"][k].abs().max() < 1e-12, k
+            continue
+        assert rel_err(out["grads"][k].reshape(r.shape), r) < 1e-10, k
+        checked += 1
+    assert checked >= 30
