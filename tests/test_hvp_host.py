@@ -46,3 +46,30 @@ def test_kernel_bodies_periodic_box(golden_dir):
     hp = T.hparams_from_args(tiny["args"])
     v = torch.randn(f["pos"].shape, generator=torch.Generator().manual_seed(5))
     _check(tiny["state_dict"], hp, f["z"], f["pos"], f["batch"], v, box=f["box"])
+
+
+@pytest.mark.parametrize("name,extra,sizes,charges", [
+    ("so3-ragged-single-atom", dict(equivariance_invariance_group="SO(3)"), [9, 14, 1], False),
+    ("one-layer-lower-cutoff", dict(num_layers=1, cutoff_lower=0.8, cutoff_upper=4.5), [13, 6], False),
+    ("odd-widths-three-layers", dict(embedding_dimension=24, num_rbf=10, max_z=100, num_layers=3), [12, 2, 7], True),
+])
+def test_kernel_bodies_on_the_gpu_test_configurations(name, extra, sizes, charges):
+    """the configurations of tests/test_gpu_hvp.py (scaled down), random-init models: ragged molecules incl. a single atom (a row
+    with its self edge only), SO(3), one layer with a lower cutoff, three layers with widths that are no power of two."""
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.TINY_ARGS, **extra)
+    torch.manual_seed(11)
+    model = create_model(dict(args))
+    zs, ps, bs = [], [], []
+    for m, n in enumerate(sizes):
+        zz, pp = W.synthetic_molecule(700 + m, n_atoms=n)
+        zs.append(torch.from_numpy(zz))
+        ps.append(torch.from_numpy(pp))
+        bs.append(torch.full((n,), m, dtype=torch.long))
+    z, pos, batch = torch.cat(zs), torch.cat(ps), torch.cat(bs)
+    q = torch.tensor([float(m % 3 - 1) for m in range(len(sizes))]) if charges else None
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(5))
+    sd = {k: t.detach() for k, t in model.state_dict().items()}
+    _check(sd, T.hparams_from_args(args), z, pos.float(), batch, v, q=q)
