@@ -307,8 +307,8 @@ int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, voi
  * (torchmdnet/models/model.py:618-628, create_graph = self.training) and the *_bwd_bwd kernels behind it
  * (torchmdnet/extensions/warp_ops/tensornet_mp.py:538-548 and siblings).  Analytic: the forward-mode tangent, along v, of the
  * forward + reverse program (no difference quotient); one self-contained pass that evaluates the radial functions directly and
- * keeps its own activations in `ws` (tmdnet_force_param_workspace_bytes: about 0.75 KB per atom-channel plus 0.2 KB per
- * pair-channel).  `grads` has the layout of tmdnet_energy_param_grads (tmdnet_param_grad_entry; d s / d bO2 = 0).  Needs a graph
+ * keeps its own activations in `ws` (tmdnet_force_param_workspace_bytes: about 2 KB per atom-channel plus 0.4 KB per
+ * pair-channel, 14 GiB for 256 molecules of 64 atoms at 128 channels - nothing is aliased).  `grads` has the layout of tmdnet_energy_param_grads (tmdnet_param_grad_entry; d s / d bO2 = 0).  Needs a graph
  * built with the exact pair count and without the cell list; `z` may be NULL when tmdnet_build_graph saw it; deterministic.
  * `hv` (device, [n_atoms, 3], or NULL): d s / d pos = H v, the Hessian of the summed energy applied to v - the position gradient
  * of a loss that depends on the forces is  - H (d loss / d F)  (the reference gets it from the same second autograd pass). */
