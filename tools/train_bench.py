@@ -1,6 +1,7 @@
 """Time of one training step through the parameter-gradient pass (developer tool): C2 model, S-mol64 molecules.
-energy-only: forward (inference schedule, direct radial functions) + tmdnet_energy_param_grads; force matching adds the central
-difference (two more passes at order 2)."""
+energy-only: forward (inference schedule, direct radial functions) + tmdnet_energy_param_grads; force matching adds the analytic
+second-order pass tmdnet_force_param_grads (model.force_gradient_order = 0, the default; 2 / 4: a central difference, two / four
+more first-order passes).  tools/train_step_time.py times the bench leg and the second-order pass alone."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "torchmd-net_amd"))
