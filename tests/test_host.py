@@ -399,3 +399,71 @@ def test_every_developer_switch_is_listed_for_the_gpu_switch_tests():
     missing = names - set(sw.SWITCHES) - sw.NOT_KERNEL_SWITCHES
     assert not missing, f"switches without a GPU test: {sorted(missing)}"
     assert set(sw.SWITCHES) <= names, f"stale entries: {sorted(set(sw.SWITCHES) - names)}"
+
+
+def test_force_matching_backward_combines_the_passes_with_the_right_signs(monkeypatch):
+    """Host logic of _EnergyForceParamGrad.backward with the engine calls replaced by stand-ins: loss = sum g_E . E + sum g_F . F
+    -> d/d theta = [energy pass seeded with g_E] - [second-order pass along g_F], d/d pos = - g_E[batch] F - H g_F (reference:
+    autograd through model.py:618-628 with create_graph=True); the difference-quotient orders call the first-order pass 2 / 4 more
+    times and announce the missing position term once; force_position_gradient = False skips H v and announces it too."""
+    import contextlib
+    import warnings
+
+    import torchmdnet_amd.models.model as M
+    from torchmdnet_amd import workloads as W
+
+    torch.manual_seed(0)
+    model = M.create_model(dict(W.TINY_ARGS, derivative=True))
+    params = [p for p in model.parameters() if p.requires_grad]
+    n, n_mol = 7, 2
+    z, batch = torch.ones(n, dtype=torch.long), torch.tensor([0, 0, 0, 1, 1, 1, 1])
+    E0, F0 = torch.tensor([1.5, -2.0]), torch.randn(n, 3)
+    hv0 = torch.randn(n, 3)
+    calls = dict(first=0, second=0, hv=0)
+
+    def energy_and_forces(*a, **k):
+        return E0.clone(), F0.clone()
+
+    def parameter_gradients_of(z_, pos_, batch_, box, q, n_mol_, ge):
+        calls["first"] += 1
+        return E0, {p: torch.full_like(p, float(ge.sum())) for p in params}
+
+    def force_term_parameter_gradients(z_, pos_, batch_, box, q, n_mol_, v, want_hv=False):
+        calls["second"] += 1
+        calls["hv"] += int(want_hv)
+        g = {p: torch.full_like(p, float(v.sum())) for p in params}
+        return (g, hv0.clone()) if want_hv else g
+
+    monkeypatch.setattr(M, "_direct_radial_functions", lambda m: contextlib.nullcontext())
+    for name, fn in (("energy_and_forces", energy_and_forces), ("parameter_gradients_of", parameter_gradients_of),
+                     ("force_term_parameter_gradients", force_term_parameter_gradients)):
+        monkeypatch.setattr(model, name, fn)
+    ge, R = torch.tensor([0.5, 2.0]), torch.randn(n, 3)
+
+    def run(order, pos_grad=True):
+        model.force_gradient_order, model.force_position_gradient, model._warned_pos_grad = order, pos_grad, False
+        for p in params:
+            p.grad = None
+        for k in calls:
+            calls[k] = 0
+        pos = torch.zeros(n, 3, requires_grad=True)
+        y, F = M._EnergyForceParamGrad.apply(model, z, pos, batch, None, None, n_mol, *params)
+        ((y * ge).sum() + (F * R).sum()).backward()
+        return pos.grad
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # the analytic pass with H v has nothing to announce
+        g_pos = run(0)
+    assert calls == dict(first=1, second=1, hv=1)
+    expect = float(ge.sum()) - float(R.sum())  # energy pass seeded with g_E, minus the second-order pass along v = g_F
+    assert all(torch.allclose(p.grad, torch.full_like(p, expect), rtol=1e-5, atol=1e-5) for p in params)
+    assert torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0 - hv0)
+    with pytest.warns(UserWarning, match="energy term's part"):
+        g_pos = run(0, pos_grad=False)
+    assert calls == dict(first=1, second=1, hv=0) and torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0)
+    for order, extra in ((2, 2), (4, 4)):
+        with pytest.warns(UserWarning, match="energy term's part"):
+            g_pos = run(order)
+        assert calls == dict(first=1 + extra, second=0, hv=0) and torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0)
+        # the stand-in's first-order gradient does not depend on pos: every difference quotient of it is zero
+        assert all(torch.allclose(p.grad, torch.full_like(p, float(ge.sum())), rtol=1e-5, atol=1e-5) for p in params)

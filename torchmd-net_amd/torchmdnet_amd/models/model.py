@@ -404,7 +404,8 @@ class _EnergyForceParamGrad(torch.autograd.Function):
             v = g_forces.detach().to(torch.float32)
             order = int(getattr(model, "force_gradient_order", 0))
             analytic = order == 0 and not (model._is_et() or model._is_tn2())
-            if not analytic and ctx.needs_input_grad[2] and not getattr(model, "_warned_pos_grad", False):
+            with_hv = analytic and ctx.needs_input_grad[2] and getattr(model, "force_position_gradient", True)
+            if not with_hv and ctx.needs_input_grad[2] and not getattr(model, "_warned_pos_grad", False):
                 # pos always requires grad here (the reference's side effect, model.py:584-585), so this cannot tell a caller who
                 # wants d loss / d pos from one who does not: say it once instead of silently returning a truncated gradient
                 import warnings
@@ -412,12 +413,13 @@ class _EnergyForceParamGrad(torch.autograd.Function):
                 warnings.warn("torchmdnet_amd: pos.grad of a loss that depends on the FORCES holds only the energy term's part "
                               "(-g_E F): the difference-quotient force gradient (Equivariant Transformer, TensorNet2, "
                               "force_gradient_order 2 / 4) carries a graph to the parameters only; the second derivative in the "
-                              "positions is built for TensorNet + Scalar (force_gradient_order = 0)", stacklevel=2)
+                              "positions is built for TensorNet + Scalar (force_gradient_order = 0, force_position_gradient = "
+                              "True)", stacklevel=2)
                 model._warned_pos_grad = True
             if analytic:
                 # analytic second-order pass (TensorNet + Scalar): d (g_F . F) / d theta = - d/d theta [ g_F . d sum_m E_m / d pos ],
                 # and in the positions - H g_F (H = Hessian of the summed energy)
-                if ctx.needs_input_grad[2] and getattr(model, "force_position_gradient", True):
+                if with_hv:
                     gth, hv = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, want_hv=True)
                     g_pos = -hv if g_pos is None else g_pos - hv
                 else:
