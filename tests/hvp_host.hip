@@ -3,6 +3,7 @@
 // the kernels of tn_hvp.hip run against oracle/tensornet_second_order.py on a machine without a GPU.  Nothing under
 // torchmd-net_amd/ links or loads this file.
 #include "../torchmd-net_amd/csrc/tn_hvp_math.h"
+#include "../torchmd-net_amd/csrc/tn_et_hvp_math.h"
 
 using namespace tn::hvp;
 
@@ -127,6 +128,107 @@ void hh_geom_dual(int P, const float* pd, const float* prhat, const float* d_t, 
 }
 void hh_pair_to_atom(int N, int P, const int* rowptr, const int* epair, const float* esign, const float* g, float* out) {
   for (int i = 0; i < N; ++i) pair_to_atom(i, P, rowptr, epair, esign, g, out);
+}
+
+// ---------------------------------------------------------------- Equivariant Transformer (tn_et_hvp_math.h)
+void he_rowscale_dual(int64_t rows, int W, const float* e, const float* e_t, const float* C, const float* C_t, float* o, float* o_t) {
+  for (int64_t i = 0; i < rows * W; ++i) rowscale_dual(i, W, e, e_t, C, C_t, o, o_t);
+}
+void he_nbr_embed_dual(int N, int F, int P, const int* rowptr, const int* col, const int* epair, const float* esign, const int64_t* z,
+                       const float* emb, const float* embN, const float* Wn, const float* Wn_t, float* xcat, float* xcat_t) {
+  for (int i = 0; i < N; ++i)
+    for (int f = 0; f < F; ++f) et_nbr_embed_dual(i, f, F, P, rowptr, col, epair, esign, z, emb, embN, Wn, Wn_t, xcat, xcat_t);
+}
+void he_embed_dual(int N, int F, const int64_t* z, const float* emb, float* x, float* x_t) {
+  for (int i = 0; i < N; ++i)
+    for (int f = 0; f < F; ++f) et_embed_dual(i, f, F, z, emb, x, x_t);
+}
+static EtAttn mk_attn(const float* qkv, const float* qkv_t, const float* vec, const float* vec_t, const float* dkv, const float* dkv_t,
+                      const float* C, const float* C_t, const float* prhat, const float* rhat_t, int F, int hd, int Wd, int ok, int ov, int vc,
+                      int P) {
+  return EtAttn{qkv, qkv_t, vec, vec_t, dkv, dkv_t, C, C_t, prhat, rhat_t, F, hd, Wd, ok, ov, vc, P};
+}
+void he_attn_fwd_dual(int N, int H, const float* qkv, const float* qkv_t, const float* vec, const float* vec_t, const float* dkv,
+                      const float* dkv_t, const float* C, const float* C_t, const float* prhat, const float* rhat_t, int F, int hd, int Wd, int ok,
+                      int ov, int vc, int P, const int* rowptr, const int* col, const int* epair, const float* esign, float* xagg,
+                      float* xagg_t, float* vagg, float* vagg_t) {
+  const EtAttn A_ = mk_attn(qkv, qkv_t, vec, vec_t, dkv, dkv_t, C, C_t, prhat, rhat_t, F, hd, Wd, ok, ov, vc, P);
+  for (int t = 0; t < N; ++t)
+    for (int h = 0; h < H; ++h) et_attn_fwd_dual(t, h, A_, rowptr, col, epair, esign, xagg, xagg_t, vagg, vagg_t);
+}
+void he_update_dual(int N, int F, const float* x, const float* x_t, const float* vec, const float* vec_t, const float* vp, const float* vp_t,
+                    const float* o, const float* o_t, const float* vagg, const float* vagg_t, float* xn, float* xn_t, float* vecn,
+                    float* vecn_t, float* vdot, float* vdot_t) {
+  for (int n = 0; n < N; ++n)
+    for (int f = 0; f < F; ++f) et_update_dual(n, f, F, x, x_t, vec, vec_t, vp, vp_t, o, o_t, vagg, vagg_t, xn, xn_t, vecn, vecn_t, vdot, vdot_t);
+}
+void he_cat_norm_dual(int N, int W, const float* x, const float* x_t, int Fx, const float* u, const float* u_t, int ldu, int Fn, int ldo,
+                      float* out, float* out_t) {
+  for (int n = 0; n < N; ++n)
+    for (int f = 0; f < W; ++f) et_cat_norm_dual(n, f, x, x_t, Fx, u, u_t, ldu, Fn, ldo, out, out_t);
+}
+void he_head_mid_dual(int N, int F2, const float* y, const float* y_t, const float* u2, const float* u2_t, int ldu, float* hcat2,
+                      float* hcat2_t, float* vq, float* vq_t) {
+  for (int n = 0; n < N; ++n)
+    for (int f = 0; f < F2; ++f) et_head_mid_dual(n, f, F2, y, y_t, u2, u2_t, ldu, hcat2, hcat2_t, vq, vq_t);
+}
+void he_norm_bwd_dual(int N, int W, const float* g_n, const float* g_n_t, int ldg, const float* u, const float* u_t, int ldu, float* g_u,
+                      float* g_u_t, int ldgu) {
+  for (int n = 0; n < N; ++n)
+    for (int f = 0; f < W; ++f) et_norm_bwd_dual(n, f, g_n, g_n_t, ldg, u, u_t, ldu, g_u, g_u_t, ldgu);
+}
+void he_head_mid_bwd_dual(int N, int F2, const float* y, const float* y_t, const float* u2, const float* u2_t, int ldu, const float* g_h2,
+                          const float* g_h2_t, const float* g_vq, const float* g_vq_t, float* g_y, float* g_y_t, float* g_u2, float* g_u2_t,
+                          int ldgu) {
+  for (int n = 0; n < N; ++n)
+    for (int f = 0; f < F2; ++f) et_head_mid_bwd_dual(n, f, F2, y, y_t, u2, u2_t, ldu, g_h2, g_h2_t, g_vq, g_vq_t, g_y, g_y_t, g_u2, g_u2_t, ldgu);
+}
+void he_update_bwd_dual(int N, int F, const float* g_x, const float* g_x_t, const float* g_vec, const float* g_vec_t, const float* vp,
+                        const float* vp_t, const float* o, const float* o_t, const float* vdot, const float* vdot_t, float* g_o, float* g_o_t,
+                        float* g_vp, float* g_vp_t) {
+  for (int n = 0; n < N; ++n)
+    for (int f = 0; f < F; ++f) et_update_bwd_dual(n, f, F, g_x, g_x_t, g_vec, g_vec_t, vp, vp_t, o, o_t, vdot, vdot_t, g_o, g_o_t, g_vp, g_vp_t);
+}
+void he_attn_bwd_dual(int N, int H, const float* qkv, const float* qkv_t, const float* vec, const float* vec_t, const float* dkv,
+                      const float* dkv_t, const float* C, const float* C_t, const float* prhat, const float* rhat_t, int F, int hd, int Wd, int ok,
+                      int ov, int vc, int P, const int* rowptr, const int* col, const int* epair, const float* esign, const float* g_xagg,
+                      const float* g_xagg_t, const float* g_vagg, const float* g_vagg_t, float* g_qkv, float* g_qkv_t, float* g_vec_in,
+                      float* g_vec_in_t, float* gq, float* gq_t, int64_t dir_stride, float* selfq, float* selfq_t, float* slots, float* slots_t,
+                      int64_t slot_dir_stride) {
+  const EtAttn A_ = mk_attn(qkv, qkv_t, vec, vec_t, dkv, dkv_t, C, C_t, prhat, rhat_t, F, hd, Wd, ok, ov, vc, P);
+  for (int t = 0; t < N; ++t)
+    for (int h = 0; h < H; ++h) {
+      et_attn_bwd_tgt_dual(t, h, H, A_, rowptr, col, epair, esign, g_xagg, g_xagg_t, g_vagg, g_vagg_t, g_qkv, g_qkv_t, gq, gq_t, dir_stride,
+                           selfq, selfq_t, slots, slots_t, slot_dir_stride);
+      et_attn_bwd_src_dual(t, h, A_, rowptr, col, epair, esign, g_xagg, g_xagg_t, g_vagg, g_vagg_t, g_qkv, g_qkv_t, g_vec_in, g_vec_in_t);
+    }
+}
+void he_filter_gpre_dual(int P, int Wd, const float* gq, const float* gq_t, int64_t dir_stride, const float* self_g, const float* self_g_t,
+                         const float* ekv, const float* ekv_t, float* g_e, float* g_e_t) {
+  for (int64_t i = 0; i < (int64_t)(P + 1) * Wd; ++i) et_filter_gpre_dual(i, P, Wd, gq, gq_t, dir_stride, self_g, self_g_t, ekv, ekv_t, g_e, g_e_t);
+}
+void he_nbr_bwd_dual(int N, int F, int P, const int* rowptr, const int* col, const int* epair, const float* esign, const int64_t* z,
+                     const float* embN, const float* Wn, const float* Wn_t, const float* g_xcat, const float* g_xcat_t, float* gq, float* gq_t,
+                     int64_t dir_stride, float* gZ_t) {
+  for (int i = 0; i < N; ++i)
+    for (int f = 0; f < F; ++f) et_nbr_bwd_dual(i, f, F, P, rowptr, col, epair, esign, z, embN, Wn, Wn_t, g_xcat, g_xcat_t, gq, gq_t, dir_stride, gZ_t);
+}
+void he_nbr_pair_dual(int P, int F, const float* gq, const float* gq_t, int64_t dir_stride, const float* C, const float* C_t, float* g_Wn,
+                      float* g_Wn_t, float* g_en, float* g_en_t) {
+  for (int64_t i = 0; i < (int64_t)P * F; ++i) et_nbr_pair_dual(i, F, gq, gq_t, dir_stride, C, C_t, g_Wn, g_Wn_t, g_en, g_en_t);
+}
+void he_pair_rowdot2(int rows, int W, const float* x, const float* x_t, const float* y, const float* y_t, int accumulate, float* out,
+                     float* out_t) {
+  for (int p = 0; p < rows; ++p) pair_rowdot2(p, W, x, x_t, y, y_t, accumulate, out, out_t);
+}
+void he_pair_slots_dual(int P, int H, int nsets, const float* slots, const float* slots_t, int64_t set_stride, int64_t slot_dir_stride,
+                        float* g_cut, float* g_cut_t, float* g_rh, float* g_rh_t) {
+  for (int p = 0; p < P; ++p) et_pair_slots_dual(p, H, nsets, slots, slots_t, set_stride, slot_dir_stride, g_cut, g_cut_t, g_rh, g_rh_t);
+}
+void he_geom_dual(int P, const float* pd, const float* prhat, const float* d_t, const float* rhat_t, const float* dC, const float* d2C,
+                  const float* g_cut, const float* g_cut_t, const float* g_dphi, const float* g_dphi_t, const float* g_rh, const float* g_rh_t,
+                  float* gdel, float* gdel_t) {
+  for (int p = 0; p < P; ++p) et_geom_dual(p, pd, prhat, d_t, rhat_t, dC, d2C, g_cut, g_cut_t, g_dphi, g_dphi_t, g_rh, g_rh_t, gdel, gdel_t);
 }
 
 }  // extern "C"

@@ -73,3 +73,31 @@ def test_kernel_bodies_on_the_gpu_test_configurations(name, extra, sizes, charge
     v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(5))
     sd = {k: t.detach() for k, t in model.state_dict().items()}
     _check(sd, T.hparams_from_args(args), z, pos.float(), batch, v, q=q)
+
+
+@pytest.mark.parametrize("fixture", ["et_tiny_ref.pt", "et_tiny_vc_ref.pt"])
+def test_et_kernel_bodies_in_packed_layout_match_specification(golden_dir, fixture):
+    """Equivariant Transformer: the bodies of csrc/tn_et_hvp_math.h in the engine's packed layouts and launch order
+    (tests/et_hvp_host_mirror.py) against oracle/et_second_order.py in fp64: every parameter (mapped back the way _et_grads does),
+    the forces out of the same geometry kernels, and H v."""
+    from oracle import et_second_order as E2
+    from oracle import et_torch as ET
+    from tests import et_hvp_host_mirror as EM
+
+    g = torch.load(os.path.join(golden_dir, fixture))
+    hp = ET.hparams_from_args(g["args"])
+    sd64 = {k: (t.double() if t.is_floating_point() else t) for k, t in g["state_dict"].items()}
+    z, pos, batch = g["z"], g["pos"], g["batch"]
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(3))
+    ref = E2.force_term(sd64, hp, z, pos.double(), batch, v.double())
+    out = EM.force_term_mirror(g["state_dict"], hp, z, pos, batch, v)
+    tol = 5e-5
+    assert abs(out["s"].item() - ref["s"].item()) < tol * max(1.0, abs(ref["s"].item()))
+    assert (out["F"].double() - ref["F"]).abs().max().item() < tol * ref["F"].abs().max().item()
+    assert (out["Hv"].double() - ref["Hv"]).abs().max().item() < tol * ref["Hv"].abs().max().item()
+    mine = EM.state_dict_grads(out["ent"], g["state_dict"], hp)
+    assert set(ref["grads"]) <= set(mine)
+    for k, r in ref["grads"].items():
+        o = mine[k].double().reshape(r.shape)
+        assert torch.isfinite(o).all(), k
+        assert (o - r).abs().max().item() < tol * max(r.abs().max().item(), 1e-6), k
