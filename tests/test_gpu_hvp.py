@@ -155,3 +155,43 @@ def test_force_matching_backward_takes_the_analytic_pass(hip_lib):
         json.dump({"worst": [worst, errs[worst]], "position_gradient": pos_err, "errors": errs}, fh, indent=1)
     assert errs[worst] < REL, (worst, errs[worst])
     assert pos_err < REL, pos_err
+
+
+@pytest.mark.parametrize("fixture", ["et_tiny_ref.pt", "et_tiny_vc_ref.pt"])
+def test_et_analytic_force_term_gradients_match_specification(hip_lib, golden_dir, fixture):
+    """Equivariant Transformer: tmdnet_force_param_grads (csrc/tn_et_hvp.hip + the schedule in tn_et_api.hip) against
+    oracle/et_second_order.py in fp64 (pinned to autograd-of-autograd): every parameter, and H v - both distance filters with the
+    neighbour embedding, and the vector cutoff with the key filter only."""
+    from oracle import et_second_order as E2
+    from oracle import et_torch as ET
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, fixture))
+    model = create_model(dict(g["args"]))
+    model.load_state_dict(g["state_dict"])
+    model = model.to("cuda")
+    z, pos, batch = g["z"], g["pos"], g["batch"]
+    n_mol = int(batch.max()) + 1
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(3))
+    grads, hv = model.force_term_parameter_gradients(z.cuda(), pos.cuda(), batch.cuda(), None, None, n_mol, v.cuda(), want_hv=True)
+    torch.cuda.synchronize()
+    hp = ET.hparams_from_args(g["args"])
+    sd64 = {k: (t.double() if t.is_floating_point() else t) for k, t in g["state_dict"].items()}
+    ref = E2.force_term(sd64, hp, z, pos.double(), batch, v.double())
+    by_name = {id(p): k for k, p in model.named_parameters()}
+    errs = {}
+    for p, gr in grads.items():
+        key = by_name[id(p)]
+        r = ref["grads"].get(key)
+        if r is None or r.abs().max() == 0:
+            assert gr.abs().max().item() < 1e-6, key
+            continue
+        errs[key] = (gr.cpu().double() - r.reshape(gr.shape)).abs().max().item() / r.abs().max().item()
+    hv_err = (hv.cpu().double() - ref["Hv"]).abs().max().item() / ref["Hv"].abs().max().item()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/hvp_{fixture[:-3]}.json", "w") as fh:
+        json.dump({"case": fixture, "hv_error": hv_err, "worst_param": max(errs.items(), key=lambda kv: kv[1]), "param_errors": errs}, fh, indent=1)
+    assert len(errs) >= 30
+    bad = {k: e for k, e in errs.items() if not e < REL}
+    assert not bad, bad
+    assert hv_err < REL, hv_err

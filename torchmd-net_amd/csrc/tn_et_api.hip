@@ -733,3 +733,282 @@ int et_debug_tensor(tmdnet_model* m, hipStream_t s, const char* name, float* out
   HIP_TRY(m, hipMemcpyAsync(out, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
   return TMDNET_OK;
 }
+
+// ------------------------------------------------------------------------------------ analytic second-order pass (force matching)
+// d/d theta and d/d pos of  s = v . d(sum_m E_m)/d pos  for the Equivariant Transformer: the forward-mode tangent, along v, of the
+// forward + reverse program above (reference: a second autograd pass, model.py:618-628 over torchmd_et.py:188-426).  One
+// self-contained pass in the packed layouts of this file; statement by statement oracle/et_second_order.py, launch by launch
+// tests/et_hvp_host_mirror.py (the same kernel bodies on the host).  Gradient buffer: et_train_layout.
+#include "tn_et_hvp_math.h"
+#include "tn_hvp.h"
+
+namespace {
+
+struct EtHvpLayer {
+  float *xt, *xt_t, *xh, *xh_t, *rstd, *rstd_t, *qkv, *qkv_t, *vp, *vp_t, *ekv, *ekv_t, *dkv, *dkv_t, *xagg, *xagg_t, *o, *o_t, *vdot, *vdot_t;
+};
+struct EtHvpBuffers {
+  float *phi, *dphi, *C, *dC, *d_t, *rhat_t, *phi_t, *C_t, *d2phi, *d2C, *g_dphi, *g_dphi_t;
+  float *en, *en_t, *WnC, *WnC_t, *xcat, *xcat_t;
+  std::vector<float*> x, x_t, vec, vec_t;  // L + 1
+  std::vector<EtHvpLayer> lay;
+  float *vagg, *vagg_t;
+  float *xf, *xfh, *rstdf, *xf_t, *xfh_t, *rstdf_t, *u12, *u12_t, *hcat, *hcat_t, *pre1, *pre1_t, *m1, *m1_t, *y, *y_t, *hcat2, *hcat2_t, *vq,
+      *vq_t, *w1, *w1_t, *pre2, *pre2_t, *g_pre2, *g_pre2_t, *headv;
+  // reverse
+  float *g_h2, *g_h2_t, *g_w1, *g_w1_t, *g_vq, *g_vq_t, *g_y, *g_y_t, *g_u12, *g_u12_t, *g_m1h, *g_m1h_t, *g_m1, *g_m1_t, *g_h1, *g_h1_t,
+      *g_vec, *g_vec_t, *g_xf, *g_xf_t, *g_x, *g_x_t;
+  float *g_o, *g_o_t, *g_vp, *g_vp_t, *g_xagg, *g_xagg_t, *g_vagg, *g_vagg_t, *g_qkv, *g_qkv_t, *g_vin, *g_vin_t, *gq, *gq_t, *selfq, *selfq_t,
+      *self_g, *self_g_t, *g_e, *g_e_t, *de, *d2e, *g_xt, *g_xt_t, *g_ln, *g_ln_t, *slots, *slots_t;
+  float *g_xcat, *g_xcat_t, *gZ_t, *g_Wn, *g_Wn_t, *g_en, *g_en_t, *g_cutn, *g_cutn_t, *g_cut, *g_cut_t, *g_rh, *g_rh_t, *gdel, *gdel_t, *onehot,
+      *part;
+};
+
+EtHvpBuffers et_carve_hvp(void* ws, const tmdnet_et_hparams& hp, int64_t N, int64_t P, size_t* total) {
+  const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, F2 = F / 2, U = F + F2, H = hp.num_heads, P1 = P + 1;
+  const int64_t Wd = std::max<int64_t>(wd_of(hp), 1), NF = N * F;
+  Carver c(ws);
+  EtHvpBuffers b;
+  auto f = [&](int64_t n) { return c.take<float>(n); };
+  b.phi = f(P1 * K); b.dphi = f(P1 * K); b.C = f(P1); b.dC = f(P1); b.d_t = f(P1); b.rhat_t = f(P1 * 3); b.phi_t = f(P1 * K); b.C_t = f(P1);
+  b.d2phi = f(P1 * K); b.d2C = f(P1); b.g_dphi = f(P1); b.g_dphi_t = f(P1);
+  b.en = f(P1 * F); b.en_t = f(P1 * F); b.WnC = f(P1 * F); b.WnC_t = f(P1 * F); b.xcat = f(2 * NF); b.xcat_t = f(2 * NF);
+  for (int l = 0; l <= L; ++l) {
+    b.x.push_back(f(NF)); b.x_t.push_back(f(NF)); b.vec.push_back(f(3 * NF)); b.vec_t.push_back(f(3 * NF));
+  }
+  for (int l = 0; l < L; ++l) {
+    EtHvpLayer y;
+    y.xt = f(NF); y.xt_t = f(NF); y.xh = f(NF); y.xh_t = f(NF); y.rstd = f(N); y.rstd_t = f(N); y.qkv = f(5 * NF); y.qkv_t = f(5 * NF);
+    y.vp = f(9 * NF); y.vp_t = f(9 * NF); y.ekv = f(P1 * Wd); y.ekv_t = f(P1 * Wd); y.dkv = f(P1 * Wd); y.dkv_t = f(P1 * Wd);
+    y.xagg = f(NF); y.xagg_t = f(NF); y.o = f(3 * NF); y.o_t = f(3 * NF); y.vdot = f(NF); y.vdot_t = f(NF);
+    b.lay.push_back(y);
+  }
+  b.vagg = f(3 * NF); b.vagg_t = f(3 * NF);
+  b.xf = f(NF); b.xfh = f(NF); b.rstdf = f(N); b.xf_t = f(NF); b.xfh_t = f(NF); b.rstdf_t = f(N); b.u12 = f(3 * N * U); b.u12_t = f(3 * N * U);
+  b.hcat = f(2 * NF); b.hcat_t = f(2 * NF); b.pre1 = f(NF); b.pre1_t = f(NF); b.m1 = f(NF); b.m1_t = f(NF); b.y = f(NF); b.y_t = f(NF);
+  b.hcat2 = f(NF); b.hcat2_t = f(NF); b.vq = f(3 * N * F2); b.vq_t = f(3 * N * F2); b.w1 = f(3 * N * F2); b.w1_t = f(3 * N * F2);
+  b.pre2 = f(N * F2); b.pre2_t = f(N * F2); b.g_pre2 = f(N * F2); b.g_pre2_t = f(N * F2); b.headv = f(N * F2);
+  b.g_h2 = f(NF); b.g_h2_t = f(NF); b.g_w1 = f(3 * N * F2); b.g_w1_t = f(3 * N * F2); b.g_vq = f(3 * N * F2); b.g_vq_t = f(3 * N * F2);
+  b.g_y = f(NF); b.g_y_t = f(NF); b.g_u12 = f(3 * N * U); b.g_u12_t = f(3 * N * U); b.g_m1h = f(NF); b.g_m1h_t = f(NF); b.g_m1 = f(NF);
+  b.g_m1_t = f(NF); b.g_h1 = f(2 * NF); b.g_h1_t = f(2 * NF); b.g_vec = f(3 * NF); b.g_vec_t = f(3 * NF); b.g_xf = f(NF); b.g_xf_t = f(NF);
+  b.g_x = f(NF); b.g_x_t = f(NF);
+  b.g_o = f(3 * NF); b.g_o_t = f(3 * NF); b.g_vp = f(9 * NF); b.g_vp_t = f(9 * NF); b.g_xagg = f(NF); b.g_xagg_t = f(NF); b.g_vagg = f(3 * NF);
+  b.g_vagg_t = f(3 * NF); b.g_qkv = f(5 * NF); b.g_qkv_t = f(5 * NF); b.g_vin = f(3 * NF); b.g_vin_t = f(3 * NF);
+  b.gq = f(2 * P1 * std::max<int64_t>(Wd, F)); b.gq_t = f(2 * P1 * std::max<int64_t>(Wd, F)); b.selfq = f(N * Wd); b.selfq_t = f(N * Wd);
+  b.self_g = f(Wd); b.self_g_t = f(Wd); b.g_e = f(P1 * Wd); b.g_e_t = f(P1 * Wd); b.de = f(P1 * std::max<int64_t>(Wd, F));
+  b.d2e = f(P1 * std::max<int64_t>(Wd, F)); b.g_xt = f(NF); b.g_xt_t = f(NF); b.g_ln = f(NF); b.g_ln_t = f(NF);
+  b.slots = f(L * 2 * P1 * H * 4); b.slots_t = f(L * 2 * P1 * H * 4);
+  b.g_xcat = f(2 * NF); b.g_xcat_t = f(2 * NF); b.gZ_t = f(NF); b.g_Wn = f(P1 * F); b.g_Wn_t = f(P1 * F); b.g_en = f(P1 * F); b.g_en_t = f(P1 * F);
+  b.g_cutn = f(P1); b.g_cutn_t = f(P1); b.g_cut = f(P1); b.g_cut_t = f(P1); b.g_rh = f(P1 * 3); b.g_rh_t = f(P1 * 3); b.gdel = f(P1 * 3);
+  b.gdel_t = f(P1 * 3); b.onehot = f(N * Z);
+  const int64_t big = std::max<int64_t>({5 * F * F, Wd * K, Z * F, 2 * F * F, U * F});
+  b.part = f((int64_t)train_part_floats((int)std::max<int64_t>(P1, 3 * N), big));
+  if (total) *total = c.off;
+  return b;
+}
+
+}  // namespace
+
+int et_force_param_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_pairs, size_t* bytes) {
+  et_carve_hvp(nullptr, m->et->hp, n_atoms, n_pairs, bytes);
+  return TMDNET_OK;
+}
+
+int et_force_param_grads(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
+                         int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* v, float* grads, float* hv) {
+  (void)n_mol;
+  (void)batch;
+  const tmdnet_et_hparams& hp = m->et->hp;
+  const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, F2 = F / 2, U = F + F2, H = hp.num_heads, hd = F / H;
+  const int Wd = wd_of(hp), N = (int)n_atoms, P = (int)n_pairs, P1 = P + 1;
+  const int ok = (hp.distance_influence & 1) ? 0 : -1, ov = (hp.distance_influence & 2) ? ((hp.distance_influence & 1) ? F : 0) : -1;
+  size_t need = 0;
+  EtHvpBuffers b = et_carve_hvp(ws, hp, n_atoms, n_pairs, &need);
+  if (need > ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "second-order workspace too small: need " + std::to_string(need));
+  const EtParams& W = m->et->P;
+  g_gemm_cat = CAT_GEMM_NODE;
+  g_mdev = nullptr;
+  g_madd = 0;
+  std::map<std::string, int64_t> off;
+  int64_t total = 0;
+  for (const auto& kv : et_train_layout(m)) {
+    off[kv.first] = total;
+    total += (kv.second + 63) & ~int64_t(63);
+  }
+  launch_fill(grads, 0.f, total, s);
+  auto at = [&](const std::string& k) { return grads + off.at(k); };
+  auto RP = [](int64_t ld) { return rows_plain(ld); };
+  // d W = g_y_t^T x + g_y^T x_t, d b = colsum(g_y_t) of a dense layer y = x W^T + b
+  auto dense = [&](const std::string& wkey, const std::string& bkey, const float* gy, const float* gy_t, int64_t ldg, const float* x,
+                   const float* x_t, int64_t ldx, int R, int Nout, int Kin) {
+    launch_tn_gemm(s, gy_t, RP(ldg), x, RP(ldx), nullptr, nullptr, R, Nout, Kin, at(wkey), false, b.part);
+    launch_tn_gemm(s, gy, RP(ldg), x_t, RP(ldx), nullptr, nullptr, R, Nout, Kin, at(wkey), true, b.part);
+    if (!bkey.empty()) launch_colsum(s, gy_t, RP(ldg), nullptr, RP(ldg), nullptr, nullptr, R, Nout, at(bkey), false, b.part);
+  };
+  auto ln_grad = [&](const std::string& wkey, const std::string& bkey, const float* gy, const float* gy_t, const float* xh, const float* xh_t) {
+    launch_colsum(s, gy_t, RP(F), xh, RP(F), nullptr, nullptr, N, F, at(wkey), false, b.part);
+    launch_colsum(s, gy, RP(F), xh_t, RP(F), nullptr, nullptr, N, F, at(wkey), true, b.part);
+    launch_colsum(s, gy_t, RP(F), nullptr, RP(F), nullptr, nullptr, N, F, at(bkey), false, b.part);
+  };
+
+  // ---- radial functions and the tangent of the geometry
+  launch_radial(g, P, RadialParams{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper}, b.phi, b.dphi, b.C, b.dC, s);
+  hvp::launch_pair_tangent(g, P, K, v, b.dphi, b.dC, b.d_t, b.rhat_t, b.phi_t, b.C_t, s);
+  hvp::launch_radial2(g, P, K, W.means, W.betas, hp.cutoff_lower, hp.cutoff_upper, b.d2phi, b.d2C, s);
+  launch_fill(b.g_dphi, 0.f, P1, s);
+  launch_fill(b.g_dphi_t, 0.f, P1, s);
+  launch_fill(b.g_cutn, 0.f, P1, s);
+  launch_fill(b.g_cutn_t, 0.f, P1, s);
+
+  // ---- embedding
+  if (hp.neighbor_embedding) {
+    gemm(s, b.phi, K, W.Wn, K, W.bn, b.en, F, P1, F, K);
+    gemm(s, b.phi_t, K, W.Wn, K, nullptr, b.en_t, F, P1, F, K);
+    hvp::launch_rowscale_dual(P1, F, b.en, b.en_t, b.C, b.C_t, b.WnC, b.WnC_t, s);
+    hvp::launch_et_nbr_embed_dual(g, N, F, P, z, W.emb, W.embN, b.WnC, b.WnC_t, b.xcat, b.xcat_t, s);
+    gemm(s, b.xcat, 2 * F, W.Wc, 2 * F, W.bc, b.x[0], F, N, F, 2 * F);
+    gemm(s, b.xcat_t, 2 * F, W.Wc, 2 * F, nullptr, b.x_t[0], F, N, F, 2 * F);
+  } else {
+    hvp::launch_et_embed_dual(N, F, z, W.emb, b.x[0], b.x_t[0], s);
+  }
+  launch_fill(b.vec[0], 0.f, (int64_t)N * 3 * F, s);
+  launch_fill(b.vec_t[0], 0.f, (int64_t)N * 3 * F, s);
+  std::vector<hvp::EtAttn> aa(L);
+  for (int l = 0; l < L; ++l) {
+    const EtLayerP& q = W.layer[l];
+    EtHvpLayer& y = b.lay[l];
+    hvp::launch_ln_dual(N, F, b.x[l], b.x_t[l], q.ln_w, q.ln_b, y.xt, y.xh, y.rstd, y.xt_t, y.xh_t, y.rstd_t, s);
+    gemm(s, y.xt, F, q.Wqkv, F, q.bqkv, y.qkv, 5 * F, N, 5 * F, F);
+    gemm(s, y.xt_t, F, q.Wqkv, F, nullptr, y.qkv_t, 5 * F, N, 5 * F, F);
+    gemm(s, b.vec[l], F, q.Wvp, F, nullptr, y.vp, 3 * F, 3 * N, 3 * F, F);
+    gemm(s, b.vec_t[l], F, q.Wvp, F, nullptr, y.vp_t, 3 * F, 3 * N, 3 * F, F);
+    if (Wd > 0) {
+      gemm(s, b.phi, K, q.Wdkv, K, q.bdkv, y.dkv, Wd, P1, Wd, K, GEMM_ACT_SILU, y.ekv, Wd);
+      gemm(s, b.phi_t, K, q.Wdkv, K, nullptr, y.ekv_t, Wd, P1, Wd, K);
+      hvp::launch_silu_tangent((int64_t)P1 * Wd, y.ekv, y.ekv_t, y.dkv_t, s);
+    }
+    aa[l] = hvp::EtAttn{y.qkv, y.qkv_t, b.vec[l], b.vec_t[l], y.dkv, y.dkv_t, b.C, b.C_t, g.prhat, b.rhat_t, F, hd, std::max(Wd, 1), ok, ov,
+                        hp.vector_cutoff ? 1 : 0, P};
+    hvp::launch_et_attn_fwd_dual(g, N, H, aa[l], y.xagg, y.xagg_t, b.vagg, b.vagg_t, s);
+    gemm(s, y.xagg, F, q.Wo, F, q.bo, y.o, 3 * F, N, 3 * F, F);
+    gemm(s, y.xagg_t, F, q.Wo, F, nullptr, y.o_t, 3 * F, N, 3 * F, F);
+    hvp::launch_et_update_dual(N, F, b.x[l], b.x_t[l], b.vec[l], b.vec_t[l], y.vp, y.vp_t, y.o, y.o_t, b.vagg, b.vagg_t, b.x[l + 1],
+                               b.x_t[l + 1], b.vec[l + 1], b.vec_t[l + 1], y.vdot, y.vdot_t, s);
+  }
+
+  // ---- out_norm and the EquivariantScalar head
+  hvp::launch_ln_dual(N, F, b.x[L], b.x_t[L], W.lno_w, W.lno_b, b.xf, b.xfh, b.rstdf, b.xf_t, b.xfh_t, b.rstdf_t, s);
+  gemm(s, b.vec[L], F, W.W1u, F, nullptr, b.u12, U, 3 * N, U, F);
+  gemm(s, b.vec_t[L], F, W.W1u, F, nullptr, b.u12_t, U, 3 * N, U, F);
+  hvp::launch_et_cat_norm_dual(N, F, b.xf, b.xf_t, F, b.u12, b.u12_t, U, F, 2 * F, b.hcat, b.hcat_t, s);
+  gemm(s, b.hcat, 2 * F, W.Wm1, 2 * F, W.bm1, b.m1, F, N, F, 2 * F, GEMM_ACT_SILU, b.pre1, F);
+  gemm(s, b.hcat_t, 2 * F, W.Wm1, 2 * F, nullptr, b.pre1_t, F, N, F, 2 * F);
+  hvp::launch_silu_tangent((int64_t)N * F, b.pre1, b.pre1_t, b.m1_t, s);
+  gemm(s, b.m1, F, W.Wm2, F, W.bm2, b.y, F, N, F, F);
+  gemm(s, b.m1_t, F, W.Wm2, F, nullptr, b.y_t, F, N, F, F);
+  hvp::launch_et_head_mid_dual(N, F2, b.y, b.y_t, b.u12 + F, b.u12_t + F, U, b.hcat2, b.hcat2_t, b.vq, b.vq_t, s);
+  gemm(s, b.vq, F2, W.W21, F2, nullptr, b.w1, F2, 3 * N, F2, F2);
+  gemm(s, b.vq_t, F2, W.W21, F2, nullptr, b.w1_t, F2, 3 * N, F2, F2);
+  hvp::launch_et_cat_norm_dual(N, F2, nullptr, nullptr, F2, b.w1, b.w1_t, F2, F2, F, b.hcat2, b.hcat2_t, s);
+  gemm(s, b.hcat2, F, W.Wn1, F, W.bn1, b.pre2, F2, N, F2, F);
+  gemm(s, b.hcat2_t, F, W.Wn1, F, nullptr, b.pre2_t, F2, N, F2, F);
+  hvp::launch_head_dual(N, F2, b.pre2, b.pre2_t, W.Wn2, W.std, b.g_pre2, b.g_pre2_t, b.headv, s);
+
+  // ---- reverse with tangents: head
+  launch_colsum(s, b.headv, RP(F2), nullptr, RP(F2), nullptr, nullptr, N, F2, at("Wn2"), false, b.part);  // d s / d bn2 = 0
+  dense("Wn1", "bn1", b.g_pre2, b.g_pre2_t, F2, b.hcat2, b.hcat2_t, F, N, F2, F);
+  gemm(s, b.g_pre2, F2, W.Wn1T, F2, nullptr, b.g_h2, F, N, F, F2);
+  gemm(s, b.g_pre2_t, F2, W.Wn1T, F2, nullptr, b.g_h2_t, F, N, F, F2);
+  hvp::launch_et_norm_bwd_dual(N, F2, b.g_h2 + F2, b.g_h2_t + F2, F, b.w1, b.w1_t, F2, b.g_w1, b.g_w1_t, F2, s);
+  dense("W21", "", b.g_w1, b.g_w1_t, F2, b.vq, b.vq_t, F2, 3 * N, F2, F2);
+  gemm(s, b.g_w1, F2, W.W21T, F2, nullptr, b.g_vq, F2, 3 * N, F2, F2);
+  gemm(s, b.g_w1_t, F2, W.W21T, F2, nullptr, b.g_vq_t, F2, 3 * N, F2, F2);
+  hvp::launch_et_head_mid_bwd_dual(N, F2, b.y, b.y_t, b.u12 + F, b.u12_t + F, U, b.g_h2, b.g_h2_t, b.g_vq, b.g_vq_t, b.g_y, b.g_y_t, b.g_u12 + F,
+                                   b.g_u12_t + F, U, s);
+  dense("Wm2", "bm2", b.g_y, b.g_y_t, F, b.m1, b.m1_t, F, N, F, F);
+  gemm(s, b.g_y, F, W.Wm2T, F, nullptr, b.g_m1h, F, N, F, F);
+  gemm(s, b.g_y_t, F, W.Wm2T, F, nullptr, b.g_m1h_t, F, N, F, F);
+  hvp::launch_dsilu_dual((int64_t)N * F, b.g_m1h, b.g_m1h_t, b.pre1, b.pre1_t, b.g_m1, b.g_m1_t, s);
+  dense("Wm1", "bm1", b.g_m1, b.g_m1_t, F, b.hcat, b.hcat_t, 2 * F, N, F, 2 * F);
+  gemm(s, b.g_m1, F, W.Wm1T, F, nullptr, b.g_h1, 2 * F, N, 2 * F, F);
+  gemm(s, b.g_m1_t, F, W.Wm1T, F, nullptr, b.g_h1_t, 2 * F, N, 2 * F, F);
+  hvp::launch_et_norm_bwd_dual(N, F, b.g_h1 + F, b.g_h1_t + F, 2 * F, b.u12, b.u12_t, U, b.g_u12, b.g_u12_t, U, s);
+  dense("W1u", "", b.g_u12, b.g_u12_t, U, b.vec[L], b.vec_t[L], F, 3 * N, U, F);
+  gemm(s, b.g_u12, U, W.W1uT, U, nullptr, b.g_vec, F, 3 * N, F, U);
+  gemm(s, b.g_u12_t, U, W.W1uT, U, nullptr, b.g_vec_t, F, 3 * N, F, U);
+  launch_et_copy2d(b.g_h1, 2 * F, b.g_xf, F, N, F, s);
+  launch_et_copy2d(b.g_h1_t, 2 * F, b.g_xf_t, F, N, F, s);
+  ln_grad("lno_w", "lno_b", b.g_xf, b.g_xf_t, b.xfh, b.xfh_t);
+  hvp::launch_lnbwd_dual(N, F, b.g_xf, b.g_xf_t, b.xfh, b.xfh_t, b.rstdf, b.rstdf_t, W.lno_w, b.g_x, b.g_x_t, s);
+
+  // ---- reverse with tangents: attention layers
+  const int64_t slot_dir = (int64_t)P1 * H * 4, Wdx = std::max(Wd, 1), qdir = (int64_t)P1 * Wdx;
+  for (int l = L - 1; l >= 0; --l) {
+    const EtLayerP& q = W.layer[l];
+    EtHvpLayer& y = b.lay[l];
+    const std::string t_ = "l" + std::to_string(l) + ".";
+    hvp::launch_et_update_bwd_dual(N, F, b.g_x, b.g_x_t, b.g_vec, b.g_vec_t, y.vp, y.vp_t, y.o, y.o_t, y.vdot, y.vdot_t, b.g_o, b.g_o_t, b.g_vp,
+                                   b.g_vp_t, s);
+    dense(t_ + "Wo", t_ + "bo", b.g_o, b.g_o_t, 3 * F, y.xagg, y.xagg_t, F, N, 3 * F, F);
+    dense(t_ + "Wvp", "", b.g_vp, b.g_vp_t, 3 * F, b.vec[l], b.vec_t[l], F, 3 * N, 3 * F, F);
+    gemm(s, b.g_o, 3 * F, q.WoT, 3 * F, nullptr, b.g_xagg, F, N, F, 3 * F);
+    gemm(s, b.g_o_t, 3 * F, q.WoT, 3 * F, nullptr, b.g_xagg_t, F, N, F, 3 * F);
+    // g_vagg = g_vec: snapshot, the sweeps read it while the source terms are added to g_vec
+    launch_et_copy2d(b.g_vec, 3 * F, b.g_vagg, 3 * F, N, 3 * F, s);
+    launch_et_copy2d(b.g_vec_t, 3 * F, b.g_vagg_t, 3 * F, N, 3 * F, s);
+    hvp::launch_et_attn_bwd_dual(g, N, H, aa[l], b.g_xagg, b.g_xagg_t, b.g_vagg, b.g_vagg_t, b.g_qkv, b.g_qkv_t, b.g_vin, b.g_vin_t, b.gq,
+                                 b.gq_t, qdir, b.selfq, b.selfq_t, b.slots + (int64_t)l * 2 * slot_dir, b.slots_t + (int64_t)l * 2 * slot_dir,
+                                 slot_dir, s);
+    if (Wd > 0) {  // filter rows: per pair (self pair: summed over the atoms) -> dk_proj / dv_proj, and the distance gradient through phi
+      launch_colsum(s, b.selfq, RP(Wd), nullptr, RP(Wd), nullptr, nullptr, N, Wd, b.self_g, false, b.part);
+      launch_colsum(s, b.selfq_t, RP(Wd), nullptr, RP(Wd), nullptr, nullptr, N, Wd, b.self_g_t, false, b.part);
+      hvp::launch_et_filter_gpre_dual(P, Wd, b.gq, b.gq_t, qdir, b.self_g, b.self_g_t, y.ekv, y.ekv_t, b.g_e, b.g_e_t, s);
+      dense(t_ + "Wdkv", t_ + "bdkv", b.g_e, b.g_e_t, Wd, b.phi, b.phi_t, K, P1, Wd, K);
+      gemm(s, b.dphi, K, q.Wdkv, K, nullptr, b.de, Wd, P1, Wd, K);
+      gemm(s, b.d2phi, K, q.Wdkv, K, nullptr, b.d2e, Wd, P1, Wd, K);
+      hvp::launch_pair_rowdot(P1, Wd, b.g_e, b.g_e_t, b.de, b.d2e, b.d_t, true, b.g_dphi, b.g_dphi_t, s);
+    }
+    dense(t_ + "Wqkv", t_ + "bqkv", b.g_qkv, b.g_qkv_t, 5 * F, y.xt, y.xt_t, F, N, 5 * F, F);
+    hvp::launch_add2((int64_t)N * 3 * F, b.g_vin, b.g_vec, s);
+    hvp::launch_add2((int64_t)N * 3 * F, b.g_vin_t, b.g_vec_t, s);
+    gemm(s, b.g_vp, 3 * F, q.WvpT, 3 * F, nullptr, b.g_vec, F, 3 * N, F, 3 * F, GEMM_ACCUM);
+    gemm(s, b.g_vp_t, 3 * F, q.WvpT, 3 * F, nullptr, b.g_vec_t, F, 3 * N, F, 3 * F, GEMM_ACCUM);
+    gemm(s, b.g_qkv, 5 * F, q.WqkvT, 5 * F, nullptr, b.g_xt, F, N, F, 5 * F);
+    gemm(s, b.g_qkv_t, 5 * F, q.WqkvT, 5 * F, nullptr, b.g_xt_t, F, N, F, 5 * F);
+    ln_grad(t_ + "ln_w", t_ + "ln_b", b.g_xt, b.g_xt_t, y.xh, y.xh_t);
+    hvp::launch_lnbwd_dual(N, F, b.g_xt, b.g_xt_t, y.xh, y.xh_t, y.rstd, y.rstd_t, q.ln_w, b.g_ln, b.g_ln_t, s);
+    hvp::launch_add2((int64_t)N * F, b.g_ln, b.g_x, s);
+    hvp::launch_add2((int64_t)N * F, b.g_ln_t, b.g_x_t, s);
+  }
+
+  // ---- embeddings
+  launch_onehot(z, N, Z, b.onehot, s);
+  if (hp.neighbor_embedding) {
+    dense("Wc", "bc", b.g_x, b.g_x_t, F, b.xcat, b.xcat_t, 2 * F, N, F, 2 * F);
+    gemm(s, b.g_x, F, W.WcT, F, nullptr, b.g_xcat, 2 * F, N, 2 * F, F);
+    gemm(s, b.g_x_t, F, W.WcT, F, nullptr, b.g_xcat_t, 2 * F, N, 2 * F, F);
+    launch_tn_gemm(s, b.onehot, RP(Z), b.g_xcat_t, RP(2 * F), nullptr, nullptr, N, Z, F, at("emb"), false, b.part);  // first half of g_xcat
+    const int64_t ndir = (int64_t)P1 * F;
+    hvp::launch_et_nbr_bwd_dual(g, N, F, P, z, W.embN, b.WnC, b.WnC_t, b.g_xcat, b.g_xcat_t, b.gq, b.gq_t, ndir, b.gZ_t, s);
+    launch_tn_gemm(s, b.onehot, RP(Z), b.gZ_t, RP(F), nullptr, nullptr, N, Z, F, at("embN"), false, b.part);
+    hvp::launch_et_nbr_pair_dual(P, F, b.gq, b.gq_t, ndir, b.C, b.C_t, b.g_Wn, b.g_Wn_t, b.g_en, b.g_en_t, s);
+    dense("Wn", "bn", b.g_en, b.g_en_t, F, b.phi, b.phi_t, K, P, F, K);
+    gemm(s, b.dphi, K, W.Wn, K, nullptr, b.de, F, P1, F, K);
+    gemm(s, b.d2phi, K, W.Wn, K, nullptr, b.d2e, F, P1, F, K);
+    hvp::launch_pair_rowdot(P, F, b.g_en, b.g_en_t, b.de, b.d2e, b.d_t, true, b.g_dphi, b.g_dphi_t, s);
+    hvp::launch_pair_rowdot2(P, F, b.g_Wn, b.g_Wn_t, b.en, b.en_t, true, b.g_cutn, b.g_cutn_t, s);
+  } else {
+    launch_tn_gemm(s, b.onehot, RP(Z), b.g_x_t, RP(F), nullptr, nullptr, N, Z, F, at("emb"), false, b.part);
+  }
+
+  // ---- geometry: H v
+  if (hv) {
+    hvp::launch_et_pair_slots_dual(P, H, L, b.slots, b.slots_t, 2 * slot_dir, slot_dir, b.g_cut, b.g_cut_t, b.g_rh, b.g_rh_t, s);
+    hvp::launch_add2(P, b.g_cutn, b.g_cut, s);
+    hvp::launch_add2(P, b.g_cutn_t, b.g_cut_t, s);
+    hvp::launch_et_geom_dual(g, P, b.d_t, b.rhat_t, b.dC, b.d2C, b.g_cut, b.g_cut_t, b.g_dphi, b.g_dphi_t, b.g_rh, b.g_rh_t, b.gdel, b.gdel_t, s);
+    hvp::launch_pair_to_atom(g, N, P, b.gdel_t, hv, s);
+  }
+  HIP_TRY(m, hipGetLastError());
+  return TMDNET_OK;
+}

@@ -67,5 +67,49 @@ void launch_geom_dual(const Graph& g, int P, const float* d_t, const float* rhat
                       float* gdel, float* gdel_t, hipStream_t s);
 void launch_pair_to_atom(const Graph& g, int N, int P, const float* gp, float* out, hipStream_t s);
 
+// ---- Equivariant Transformer (tn_et_hvp.hip; bodies and the EtAttn operand pack in tn_et_hvp_math.h)
+struct EtAttn;
+void launch_rowscale_dual(int64_t rows, int W, const float* e, const float* e_t, const float* C, const float* C_t, float* o, float* o_t,
+                          hipStream_t s);
+void launch_et_nbr_embed_dual(const Graph& g, int N, int F, int P, const int64_t* z, const float* emb, const float* embN, const float* Wn,
+                              const float* Wn_t, float* xcat, float* xcat_t, hipStream_t s);
+void launch_et_embed_dual(int N, int F, const int64_t* z, const float* emb, float* x, float* x_t, hipStream_t s);
+void launch_et_attn_fwd_dual(const Graph& g, int N, int H, const EtAttn& A_, float* xagg, float* xagg_t, float* vagg, float* vagg_t,
+                             hipStream_t s);
+void launch_et_update_dual(int N, int F, const float* x, const float* x_t, const float* vec, const float* vec_t, const float* vp,
+                           const float* vp_t, const float* o, const float* o_t, const float* vagg, const float* vagg_t, float* xn,
+                           float* xn_t, float* vecn, float* vecn_t, float* vdot, float* vdot_t, hipStream_t s);
+void launch_et_cat_norm_dual(int N, int W, const float* x, const float* x_t, int Fx, const float* u, const float* u_t, int ldu, int Fn,
+                             int ldo, float* out, float* out_t, hipStream_t s);
+void launch_et_head_mid_dual(int N, int F2, const float* y, const float* y_t, const float* u2, const float* u2_t, int ldu, float* hcat2,
+                             float* hcat2_t, float* vq, float* vq_t, hipStream_t s);
+void launch_et_norm_bwd_dual(int N, int W, const float* g_n, const float* g_n_t, int ldg, const float* u, const float* u_t, int ldu,
+                             float* g_u, float* g_u_t, int ldgu, hipStream_t s);
+void launch_et_head_mid_bwd_dual(int N, int F2, const float* y, const float* y_t, const float* u2, const float* u2_t, int ldu,
+                                 const float* g_h2, const float* g_h2_t, const float* g_vq, const float* g_vq_t, float* g_y, float* g_y_t,
+                                 float* g_u2, float* g_u2_t, int ldgu, hipStream_t s);
+void launch_et_update_bwd_dual(int N, int F, const float* g_x, const float* g_x_t, const float* g_vec, const float* g_vec_t, const float* vp,
+                               const float* vp_t, const float* o, const float* o_t, const float* vdot, const float* vdot_t, float* g_o,
+                               float* g_o_t, float* g_vp, float* g_vp_t, hipStream_t s);
+void launch_et_attn_bwd_dual(const Graph& g, int N, int H, const EtAttn& A_, const float* g_xagg, const float* g_xagg_t, const float* g_vagg,
+                             const float* g_vagg_t, float* g_qkv, float* g_qkv_t, float* g_vec_in, float* g_vec_in_t, float* gq, float* gq_t,
+                             int64_t dir_stride, float* selfq, float* selfq_t, float* slots, float* slots_t, int64_t slot_dir_stride,
+                             hipStream_t s);
+void launch_et_filter_gpre_dual(int P, int Wd, const float* gq, const float* gq_t, int64_t dir_stride, const float* self_g,
+                                const float* self_g_t, const float* ekv, const float* ekv_t, float* g_e, float* g_e_t, hipStream_t s);
+void launch_et_nbr_bwd_dual(const Graph& g, int N, int F, int P, const int64_t* z, const float* embN, const float* Wn, const float* Wn_t,
+                            const float* g_xcat, const float* g_xcat_t, float* gq, float* gq_t, int64_t dir_stride, float* gZ_t,
+                            hipStream_t s);
+void launch_et_nbr_pair_dual(int P, int F, const float* gq, const float* gq_t, int64_t dir_stride, const float* C, const float* C_t,
+                             float* g_Wn, float* g_Wn_t, float* g_en, float* g_en_t, hipStream_t s);
+void launch_pair_rowdot2(int rows, int W, const float* x, const float* x_t, const float* y, const float* y_t, bool accumulate, float* out,
+                         float* out_t, hipStream_t s);
+void launch_et_pair_slots_dual(int P, int H, int nsets, const float* slots, const float* slots_t, int64_t set_stride,
+                               int64_t slot_dir_stride, float* g_cut, float* g_cut_t, float* g_rh, float* g_rh_t, hipStream_t s);
+void launch_et_geom_dual(const Graph& g, int P, const float* d_t, const float* rhat_t, const float* dC, const float* d2C, const float* g_cut,
+                         const float* g_cut_t, const float* g_dphi, const float* g_dphi_t, const float* g_rh, const float* g_rh_t, float* gdel,
+                         float* gdel_t, hipStream_t s);
+void launch_add2(int64_t n, const float* a, float* o, hipStream_t s);  // o += a
+
 }  // namespace hvp
 }  // namespace tn

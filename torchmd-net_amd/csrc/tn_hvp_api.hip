@@ -154,7 +154,8 @@ int tmdnet_hvp_debug_tensor(tmdnet_model* m, void* stream, const char* name, flo
 int tmdnet_force_param_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, size_t* bytes) {
   (void)n_mol;
   if (!m || !bytes || n_atoms < 0 || n_pairs < 0) return TMDNET_ERR_INVALID;
-  if (m->et || m->tn2) return fail(m, TMDNET_ERR_INVALID, "the analytic second-order pass is built for TensorNet + Scalar");
+  if (m->et) return et_force_param_workspace_bytes(m, n_atoms, n_pairs, bytes);
+  if (m->tn2) return fail(m, TMDNET_ERR_INVALID, "the analytic second-order pass is built for TensorNet and the Equivariant Transformer");
   carve_hvp(nullptr, m->hp, n_atoms, n_pairs, bytes);
   return TMDNET_OK;
 }
@@ -163,12 +164,21 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
                              int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q, const float* v, float* grads, float* hv) {
   if (!m || !graph_ws || !ws || !v || !grads) return TMDNET_ERR_INVALID;
   if (!m->finalized) return fail(m, TMDNET_ERR_STATE, "parameters not finalised");
-  if (m->et || m->tn2) return fail(m, TMDNET_ERR_INVALID, "the analytic second-order pass is built for TensorNet + Scalar");
+  if (m->tn2) return fail(m, TMDNET_ERR_INVALID, "the analytic second-order pass is built for TensorNet and the Equivariant Transformer");
   if (n_pairs < 0) return fail(m, TMDNET_ERR_INVALID, "the second-order pass needs the exact pair count (dynamic shapes)");
   recall_graph(m, graph_ws);
   if (m->graph_is_cell) return fail(m, TMDNET_ERR_STATE, "second-order pass: build the graph without the cell list");
   if (m->atom_w) return fail(m, TMDNET_ERR_INVALID, "atom weights (tmdnet_set_atom_weights) are implemented for TensorNet inference only");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (m->et) {
+    if (q) return fail(m, TMDNET_ERR_INVALID, "the Equivariant Transformer takes no total charge (reference torchmd_et.py:188-196)");
+    Graph ge = carve_graph(graph_ws, n_atoms, n_mol, (int64_t)m->hp.max_num_neighbors * n_atoms, nullptr);
+    if (n_pairs > ge.pcap) return fail(m, TMDNET_ERR_INVALID, "n_pairs out of range");
+    if (m->graph_has_z) z = ge.z_c;
+    if (!z) return fail(m, TMDNET_ERR_INVALID, "z is required (here or in tmdnet_build_graph)");
+    CurScope cur_e(m);
+    return et_force_param_grads(m, s, ge, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, v, grads, hv);
+  }
   const tmdnet_hparams& hp = m->hp;
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden, o3 = hp.group_o3;
   const int N = (int)n_atoms, B = (int)n_mol, P = (int)n_pairs, P1 = P + 1;

@@ -403,7 +403,7 @@ class _EnergyForceParamGrad(torch.autograd.Function):
         if g_forces is not None and bool((g_forces != 0).any()):
             v = g_forces.detach().to(torch.float32)
             order = int(getattr(model, "force_gradient_order", 0))
-            analytic = order == 0 and not (model._is_et() or model._is_tn2())
+            analytic = order == 0 and not model._is_tn2()
             with_hv = analytic and ctx.needs_input_grad[2] and getattr(model, "force_position_gradient", True)
             if not with_hv and ctx.needs_input_grad[2] and not getattr(model, "_warned_pos_grad", False):
                 # pos always requires grad here (the reference's side effect, model.py:584-585), so this cannot tell a caller who
@@ -724,8 +724,10 @@ class TorchMD_Net(nn.Module):
         its second autograd pass, model.py:618-628 with create_graph=True).  -> {parameter: gradient}; d loss / d theta through
         the forces is MINUS this with v = d loss / d F.  want_hv: -> ({parameter: gradient}, H v [N, 3]) with H v = d s / d pos, the
         Hessian of the summed energy applied to v (the position gradient of such a loss is - H v)."""
-        if self._is_et() or self._is_tn2():
-            raise NotImplementedError("the analytic second-order pass is built for TensorNet + Scalar")
+        if self._is_tn2():
+            raise NotImplementedError("the analytic second-order pass is built for TensorNet + Scalar and the Equivariant Transformer")
+        if self._is_et():
+            q = None  # TorchMD_ET.forward ignores q
         L = _C.lib()
         dev = pos.device
         with torch.cuda.device(dev):
@@ -772,7 +774,7 @@ class TorchMD_Net(nn.Module):
                 off, numel = C.c_int64(0), C.c_int64(0)
                 name = L.tmdnet_param_grad_entry(st.handle, i, C.byref(off), C.byref(numel)).decode()
                 ent[name] = flat[off.value: off.value + numel.value]
-            grads = self._tensornet_grads(ent)
+            grads = self._et_grads(ent) if self._is_et() else self._tensornet_grads(ent)
             return (grads, hv) if want_hv else grads
 
     def _train_forward(self, z, pos, batch, box, q, n_mol, keep=True):
