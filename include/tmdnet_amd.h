@@ -301,7 +301,7 @@ int tmdnet_energy_param_grads(tmdnet_model* m, void* stream, void* graph_ws, voi
                               size_t train_bytes, int64_t n_atoms, int64_t n_mol, int64_t n_pairs, const int64_t* z,
                               const int64_t* batch, const float* q, const float* grad_energy, float* energy, float* grads);
 
-/* Second-order pass of force-matching training (TensorNet + Scalar): the gradient, with respect to every weight, of
+/* Second-order pass of force-matching training (TensorNet + Scalar, Equivariant Transformer): the gradient, with respect to every weight, of
  *     s(theta) = v . d(sum_m E_m)/d pos = - v . F          v [n_atoms, 3] = d loss / d F  (device, caller's atom order)
  * so that d loss / d theta through the forces is  - grads.  Replaces the reference's second autograd pass over its own graph
  * (torchmdnet/models/model.py:618-628, create_graph = self.training) and the *_bwd_bwd kernels behind it

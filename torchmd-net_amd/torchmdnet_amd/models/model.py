@@ -366,11 +366,11 @@ class _direct_radial_functions:
 
 class _EnergyForceParamGrad(torch.autograd.Function):
     """(E, F)(theta): d E / d theta exact (parameter-gradient pass); d (g_F . F) / d theta = - d/d theta of the directional
-    derivative s = v . d(sum_m E_m)/d pos along v = g_F.  TensorNet + Scalar (`model.force_gradient_order` = 0, the default):
+    derivative s = v . d(sum_m E_m)/d pos along v = g_F.  TensorNet + Scalar and the Equivariant Transformer (`model.force_gradient_order` = 0, the default):
     analytic - the engine's second-order pass tmdnet_force_param_grads, the forward-mode tangent along v of its forward + reverse
     program (csrc/tn_hvp_api.hip), which is what the reference's second autograd pass computes (create_graph=True,
     model.py:618-628 + the *_bwd_bwd kernels); measured 3e-6 of each tensor's largest entry against the oracle's double backward.
-    Equivariant Transformer / TensorNet2, or order 2 / 4 on request: a central difference of the exact parameter gradient at
+    TensorNet2, or order 2 / 4 on request: a central difference of the exact parameter gradient at
     pos +- h v / max|v| (two or four extra passes; `model.force_gradient_step` = h in Angstrom; 3e-4 / 1e-4 measured): a numerical
     stand-in with a stated accuracy (tests/test_gpu_train.py), not a parity path."""
 
@@ -411,10 +411,9 @@ class _EnergyForceParamGrad(torch.autograd.Function):
                 import warnings
 
                 warnings.warn("torchmdnet_amd: pos.grad of a loss that depends on the FORCES holds only the energy term's part "
-                              "(-g_E F): the difference-quotient force gradient (Equivariant Transformer, TensorNet2, "
-                              "force_gradient_order 2 / 4) carries a graph to the parameters only; the second derivative in the "
-                              "positions is built for TensorNet + Scalar (force_gradient_order = 0, force_position_gradient = "
-                              "True)", stacklevel=2)
+                              "(-g_E F): the difference-quotient force gradient (TensorNet2, force_gradient_order 2 / 4) carries a "
+                              "graph to the parameters only; the second derivative in the positions is built for TensorNet + "
+                              "Scalar and the Equivariant Transformer (force_gradient_order = 0, force_position_gradient = True)", stacklevel=2)
                 model._warned_pos_grad = True
             if analytic:
                 # analytic second-order pass (TensorNet + Scalar): d (g_F . F) / d theta = - d/d theta [ g_F . d sum_m E_m / d pos ],
@@ -481,7 +480,7 @@ class TorchMD_Net(nn.Module):
         self.parameter_gradients = False
         self.force_position_gradient = True  # analytic pass: also - H g_F into pos.grad (False: the energy term's part only, a little faster)
         self.force_gradient_step = None  # Angstrom: largest atom displacement of the finite-difference direction (None: 0.005 / 0.02)
-        self.force_gradient_order = 0    # 0: analytic second-order pass (TensorNet + Scalar) ; 2 / 4: central difference, two / four extra passes
+        self.force_gradient_order = 0    # 0: analytic second-order pass (TensorNet + Scalar, Equivariant Transformer) ; 2 / 4: central difference, two / four extra passes
         self.reset_parameters()
 
     def reset_parameters(self):
