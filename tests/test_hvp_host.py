@@ -101,3 +101,43 @@ def test_et_kernel_bodies_in_packed_layout_match_specification(golden_dir, fixtu
         o = mine[k].double().reshape(r.shape)
         assert torch.isfinite(o).all(), k
         assert (o - r).abs().max().item() < tol * max(r.abs().max().item(), 1e-6), k
+
+
+@pytest.mark.parametrize("name,extra,sizes", [
+    ("values-only-no-neighbour-embedding", dict(distance_influence="values", neighbor_embedding=False), [9, 14, 1]),
+    ("no-filters", dict(distance_influence="none"), [12, 5]),
+    ("keys-vector-cutoff-three-layers", dict(distance_influence="keys", vector_cutoff=True, num_layers=3), [7, 11, 2]),
+])
+def test_et_kernel_bodies_on_other_configurations(name, extra, sizes):
+    """branches the two fixtures do not reach: no neighbour embedding, value filter only, no distance filter at all, ragged molecules
+    incl. a single atom; random-init models, specification vs host run of the bodies in the packed layout."""
+    from oracle import et_second_order as E2
+    from oracle import et_torch as ET
+    from tests import et_hvp_host_mirror as EM
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.ET_TINY_ARGS, **extra)
+    torch.manual_seed(23)
+    model = create_model(dict(args))
+    zs, ps, bs = [], [], []
+    for m, n in enumerate(sizes):
+        zz, pp = W.synthetic_molecule(900 + m, n_atoms=n)
+        zs.append(torch.from_numpy(zz))
+        ps.append(torch.from_numpy(pp))
+        bs.append(torch.full((n,), m, dtype=torch.long))
+    z, pos, batch = torch.cat(zs), torch.cat(ps).float(), torch.cat(bs)
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(5))
+    sd = {k: t.detach() for k, t in model.state_dict().items()}
+    hp = ET.hparams_from_args(args)
+    sd64 = {k: (t.double() if t.is_floating_point() else t) for k, t in sd.items()}
+    ref = E2.force_term(sd64, hp, z, pos.double(), batch, v.double())
+    out = EM.force_term_mirror(sd, hp, z, pos, batch, v)
+    tol = 5e-4  # fp32 against fp64 on random-init models whose head activations reach 1e3 (measured 2e-4 there, 1e-5 elsewhere)
+    assert abs(out["s"].item() - ref["s"].item()) < tol * max(1.0, abs(ref["s"].item()))
+    assert (out["Hv"].double() - ref["Hv"]).abs().max().item() < tol * max(ref["Hv"].abs().max().item(), 1e-6)
+    mine = EM.state_dict_grads(out["ent"], sd, hp)
+    for k, r in ref["grads"].items():
+        o = mine[k].double().reshape(r.shape)
+        assert torch.isfinite(o).all(), k
+        assert (o - r).abs().max().item() < tol * max(r.abs().max().item(), 1e-6), k
