@@ -382,7 +382,7 @@ def training_leg(dev, L, steps=4, warmup=2):
         torch.manual_seed(0)
         model = create_model(dict(W.C2_ARGS, derivative=deriv)).to(dev)
         model.parameter_gradients = True
-        model.force_gradient_order = order  # 0: analytic second-order pass (the default); 2: central difference, two extra passes
+        model.force_gradient_order = order  # 0: analytic second-order pass (TensorNet's default); 2: central difference, two extra passes
         opt = torch.optim.SGD(model.parameters(), lr=1e-7)
 
         def step():

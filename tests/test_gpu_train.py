@@ -282,9 +282,9 @@ def test_force_matching_gradients_by_central_difference(hip_lib, order, bound):
 
 
 def test_et_training_through_autograd(hip_lib):
-    """Equivariant Transformer, derivative=True: energies and forces carry graphs to the weights (forces through the analytic
-    second-order pass since the end of round 4 - tests/test_gpu_hvp.py holds its 1e-4 bound; the looser bound here is the one of the
-    difference quotient it replaced); .grad against the oracle's fp64 double backward, and a few Adam steps lower the loss"""
+    """Equivariant Transformer, derivative=True: energies and forces carry graphs to the weights (forces through the difference
+    quotient, the default for this architecture; its analytic pass is tested in tests/test_gpu_hvp.py); .grad against the oracle's
+    fp64 double backward at the stated bound, and a few Adam steps lower the loss"""
     from oracle import et_torch as T
     from torchmdnet_amd.models.model import create_model
 

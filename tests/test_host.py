@@ -461,7 +461,7 @@ def test_force_matching_backward_combines_the_passes_with_the_right_signs(monkey
     with pytest.warns(UserWarning, match="energy term's part"):
         g_pos = run(0, pos_grad=False)
     assert calls == dict(first=1, second=1, hv=0) and torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0)
-    for order, extra in ((2, 2), (4, 4)):
+    for order, extra in ((2, 2), (4, 4)):  # (None on a TensorNet model means 0: covered by the first run's explicit 0)
         with pytest.warns(UserWarning, match="energy term's part"):
             g_pos = run(order)
         assert calls == dict(first=1 + extra, second=0, hv=0) and torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0)

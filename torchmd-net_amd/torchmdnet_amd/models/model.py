@@ -366,11 +366,12 @@ class _direct_radial_functions:
 
 class _EnergyForceParamGrad(torch.autograd.Function):
     """(E, F)(theta): d E / d theta exact (parameter-gradient pass); d (g_F . F) / d theta = - d/d theta of the directional
-    derivative s = v . d(sum_m E_m)/d pos along v = g_F.  TensorNet + Scalar and the Equivariant Transformer (`model.force_gradient_order` = 0, the default):
+    derivative s = v . d(sum_m E_m)/d pos along v = g_F.  TensorNet + Scalar (the default there) and the Equivariant Transformer
+    (`model.force_gradient_order = 0`):
     analytic - the engine's second-order pass tmdnet_force_param_grads, the forward-mode tangent along v of its forward + reverse
     program (csrc/tn_hvp_api.hip), which is what the reference's second autograd pass computes (create_graph=True,
     model.py:618-628 + the *_bwd_bwd kernels); measured 3e-6 of each tensor's largest entry against the oracle's double backward.
-    TensorNet2, or order 2 / 4 on request: a central difference of the exact parameter gradient at
+    TensorNet2, the Equivariant Transformer by default, or order 2 / 4 on request: a central difference of the exact parameter gradient at
     pos +- h v / max|v| (two or four extra passes; `model.force_gradient_step` = h in Angstrom; 3e-4 / 1e-4 measured): a numerical
     stand-in with a stated accuracy (tests/test_gpu_train.py), not a parity path."""
 
@@ -402,7 +403,10 @@ class _EnergyForceParamGrad(torch.autograd.Function):
             g_pos = -g_energy.reshape(-1)[batch].unsqueeze(1) * forces  # first order in pos (as tmdnet::energy_forces' backward)
         if g_forces is not None and bool((g_forces != 0).any()):
             v = g_forces.detach().to(torch.float32)
-            order = int(getattr(model, "force_gradient_order", 0))
+            order = getattr(model, "force_gradient_order", None)
+            if order is None:  # auto: the analytic pass where it has been timed (TensorNet), the order-2 difference quotient elsewhere
+                order = 2 if (model._is_et() or model._is_tn2()) else 0
+            order = int(order)
             analytic = order == 0 and not model._is_tn2()
             with_hv = analytic and ctx.needs_input_grad[2] and getattr(model, "force_position_gradient", True)
             if not with_hv and ctx.needs_input_grad[2] and not getattr(model, "_warned_pos_grad", False):
@@ -480,7 +484,9 @@ class TorchMD_Net(nn.Module):
         self.parameter_gradients = False
         self.force_position_gradient = True  # analytic pass: also - H g_F into pos.grad (False: the energy term's part only, a little faster)
         self.force_gradient_step = None  # Angstrom: largest atom displacement of the finite-difference direction (None: 0.005 / 0.02)
-        self.force_gradient_order = 0    # 0: analytic second-order pass (TensorNet + Scalar, Equivariant Transformer) ; 2 / 4: central difference, two / four extra passes
+        # None (auto): 0 for TensorNet + Scalar, 2 for the Equivariant Transformer (its analytic pass is exact but untuned and untimed at
+        # batch scale: ask for it with 0) and TensorNet2 ; 0: analytic second-order pass ; 2 / 4: central difference, two / four extra passes
+        self.force_gradient_order = None
         self.reset_parameters()
 
     def reset_parameters(self):
