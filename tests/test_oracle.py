@@ -318,3 +318,40 @@ def test_et_hand_second_order_pass_equals_autograd_of_autograd(golden_dir, fixtu
         assert rel_err(out["grads"][k].reshape(r.shape), r) < 1e-10, k
         checked += 1
     assert checked >= 30
+
+
+@pytest.mark.parametrize("fixture", ["tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_tn2_hand_second_order_pass_equals_autograd_of_autograd(golden_dir, fixture):
+    """oracle/tn2_second_order.py - a hand-derived E + F program of TensorNet2 + ScalarPlusWeightedCoulomb with its tangent (the
+    specification of an analytic force-matching pass; the engine keeps the difference quotient for this architecture) - against two
+    nested autograd passes over oracle/tn2_torch.py in fp64: energies, forces, every parameter, H v; all-to-all Coulomb with total
+    charges on ragged molecules, and the reaction-field branch in a periodic box."""
+    from oracle import tn2_second_order as N2
+    from oracle import tn2_torch as T2
+
+    g = torch.load(os.path.join(golden_dir, fixture))
+    hp = T2.hparams_from_args(g["args"])
+    sd = {k: (t.double() if t.is_floating_point() else t) for k, t in g["state_dict"].items()}
+    z, pos, batch = g["z"], g["pos"].double(), g["batch"]
+    q = g["q"].double() if g.get("q") is not None else None
+    box = g["box"].double() if g.get("box") is not None else None
+    v = torch.randn(pos.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    keys = [k for k, t in sd.items() if t.is_floating_point() and t.dim() > 0 and "distance" not in k and "qweights" not in k and "prior" not in k]
+    sdg = {k: (t.clone().requires_grad_(True) if k in keys else t) for k, t in sd.items()}
+    p = pos.clone().requires_grad_(True)
+    E = T2.energy(sdg, hp, z, p, batch, box=box, q=q)
+    (gp,) = torch.autograd.grad(E.sum(), p, create_graph=True)
+    s = (gp * v).sum()
+    grads = torch.autograd.grad(s, [sdg[k] for k in keys] + [p], allow_unused=True)
+    out = N2.force_term(sd, hp, z, pos, batch, v, box=box, q=q)
+    assert rel_err(out["E"], E.detach()) < 1e-12 and rel_err(out["F"], -gp.detach()) < 1e-11
+    assert abs(out["s"].item() - s.item()) < 1e-11 * max(1.0, abs(s.item())) and rel_err(out["Hv"], grads[-1]) < 1e-11
+    mine = N2.state_dict_grads(out, sd, hp)
+    checked = 0
+    for k, r in zip(keys, grads[:-1]):
+        if r is None or r.abs().max() == 0:
+            assert k not in mine or mine[k].abs().max() < 1e-12, k
+            continue
+        assert rel_err(mine[k].reshape(r.shape), r) < 1e-10, k
+        checked += 1
+    assert checked >= 60
