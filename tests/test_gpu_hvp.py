@@ -231,3 +231,39 @@ def test_engine_second_order_pass_equals_the_reference_double_backward(hip_lib, 
     bad = {k: e for k, e in errs.items() if not e < REL}
     assert not bad, bad
     assert hv_err < REL, hv_err
+
+
+def test_analytic_force_term_gradients_in_a_periodic_box(hip_lib, golden_dir):
+    """The second-order pass on a periodic system (triclinic box, minimum-image pairs from the brute-force graph): parameters and
+    H v against the specification in fp64 (pinned to autograd-of-autograd with the same box, tests/test_oracle.py)."""
+    from oracle import tensornet_second_order as S2
+    from oracle import tensornet_torch as T
+    from torchmdnet_amd.models.model import create_model
+
+    tiny = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    f = torch.load(os.path.join(golden_dir, "tiny_pbc_ref.pt"))
+    model = create_model(dict(f["args"]))
+    model.load_state_dict(tiny["state_dict"])
+    model = model.to("cuda")
+    z, pos, batch, box = f["z"], f["pos"], f["batch"], f["box"]
+    n_mol = int(batch.max()) + 1
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(7))
+    grads, hv = model.force_term_parameter_gradients(z.cuda(), pos.cuda(), batch.cuda(), box.cuda(), None, n_mol, v.cuda(), want_hv=True)
+    torch.cuda.synchronize()
+    sd64 = T.cast_state_dict(tiny["state_dict"], torch.float64)
+    hp = T.hparams_from_args(f["args"])
+    ref = S2.force_term(sd64, hp, z, pos.double(), batch, v.double(), box=box.double())
+    refg = S2.state_dict_grads(ref["ent"], sd64, hp)
+    by_name = {id(p): k for k, p in model.named_parameters()}
+    errs = {}
+    for p, g in grads.items():
+        r = refg[by_name[id(p)]].reshape(g.shape)
+        if r.abs().max() > 0:
+            errs[by_name[id(p)]] = (g.cpu().double() - r).abs().max().item() / r.abs().max().item()
+    hv_err = (hv.cpu().double() - ref["Hv"]).abs().max().item() / ref["Hv"].abs().max().item()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/hvp_periodic.json", "w") as fh:
+        json.dump({"hv_error": hv_err, "worst_param": max(errs.items(), key=lambda kv: kv[1]), "param_errors": errs}, fh, indent=1)
+    bad = {k: e for k, e in errs.items() if not e < REL}
+    assert len(errs) >= 30 and not bad, bad
+    assert hv_err < REL, hv_err
