@@ -141,3 +141,36 @@ def test_et_kernel_bodies_on_other_configurations(name, extra, sizes):
         o = mine[k].double().reshape(r.shape)
         assert torch.isfinite(o).all(), k
         assert (o - r).abs().max().item() < tol * max(r.abs().max().item(), 1e-6), k
+
+
+@pytest.mark.parametrize("fixture", ["tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_tn2_kernel_bodies_in_planned_schedule_match_specification(golden_dir, fixture):
+    """TensorNet2 + Coulomb head: the bodies of csrc/tn_tn2_hvp_math.h (+ TensorNet's) in the planned launch order
+    (tests/tn2_hvp_host_mirror.py) against oracle/tn2_second_order.py in fp64: every parameter, forces, H v; total charges with the
+    all-to-all Coulomb sum, and the reaction-field branch in a periodic box."""
+    from oracle import tn2_second_order as N2
+    from oracle import tn2_torch as T2
+    from tests import tn2_hvp_host_mirror as M2
+
+    g = torch.load(os.path.join(golden_dir, fixture))
+    hp = T2.hparams_from_args(g["args"])
+    sd64 = {k: (t.double() if t.is_floating_point() else t) for k, t in g["state_dict"].items()}
+    z, pos, batch = g["z"], g["pos"], g["batch"]
+    q = g["q"] if g.get("q") is not None else None
+    box = g["box"] if g.get("box") is not None else None
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(3))
+    ref = N2.force_term(sd64, hp, z, pos.double(), batch, v.double(), box=None if box is None else box.double(),
+                        q=None if q is None else q.double())
+    out = M2.force_term_mirror(g["state_dict"], hp, z, pos, batch, v, box=box, q=q)
+    tol = 5e-5
+    assert abs(out["s"].item() - ref["s"].item()) < tol * max(1.0, abs(ref["s"].item()))
+    assert (out["F"].double() - ref["F"]).abs().max().item() < tol * ref["F"].abs().max().item()
+    assert (out["Hv"].double() - ref["Hv"]).abs().max().item() < tol * ref["Hv"].abs().max().item()
+    refg = N2.state_dict_grads(ref, sd64, hp)
+    mine = N2.state_dict_grads(dict(ent={k: t.double() for k, t in out["ent"].items()}, extra={k: t.double() for k, t in out["extra"].items()}),
+                               sd64, hp)
+    assert set(refg) == set(mine)
+    for k, r in refg.items():
+        o = mine[k].reshape(r.shape)
+        assert torch.isfinite(o).all(), k
+        assert (o - r).abs().max().item() < tol * max(r.abs().max().item(), 1e-6), k
