@@ -258,9 +258,18 @@ void h2_cp_qeq_bwd_dual(int N, int B, int qd, const int* mstart, const int* mend
   for (int n = 0; n < N; ++n)
     for (int q = 0; q < qd; ++q) cp_qeq_bwd_dual(n, q, qd, batch, Qmol, out, out_t, sums, bs, g_ch, g_ch_t, ldg, off, g_out, g_out_t);
 }
-void h2_edge_in_dual(int E, int N, int K, int qd, const int* rowptr, const int* col, const int* epair, const float* phi, const float* phi_t,
-                     const float* ch, const float* ch_t, int ldc, int off, float* ein, float* ein_t) {
-  for (int64_t i = 0; i < (int64_t)E * (K + 2 * qd); ++i) tn2_edge_in_dual(i, N, K, qd, rowptr, col, epair, phi, phi_t, ch, ch_t, ldc, off, ein, ein_t);
+void h2_edge_pre1_dual(int E, int N, int F, const int* rowptr, const int* col, const int* epair, const float* Ap, const float* Ap_t,
+                       const float* Bt, const float* Bt_t, const float* Cs, const float* Cs_t, float* pre1, float* e1_t, float* he1,
+                       float* he1_t) {
+  for (int64_t i = 0; i < (int64_t)E * F; ++i) tn2_edge_pre1_dual(i, N, F, rowptr, col, epair, Ap, Ap_t, Bt, Bt_t, Cs, Cs_t, pre1, e1_t, he1, he1_t);
+}
+void h2_edge_reduce_dual(int N, int F, const int* rowptr, const int* col, const int* erev, const float* g1, const float* g1_t, float* gB,
+                         float* gB_t, float* gCs, float* gCs_t, float* gself, float* gself_t) {
+  for (int i = 0; i < N; ++i)
+    for (int f = 0; f < F; ++f) tn2_edge_reduce_dual(i, f, F, rowptr, col, erev, g1, g1_t, gB, gB_t, gCs, gCs_t, gself, gself_t);
+}
+void h2_pair_reduce_dual(int P, int F, const int* pair_edge, const int* erev, const float* g1, const float* g1_t, float* gAp, float* gAp_t) {
+  for (int64_t i = 0; i < (int64_t)P * F; ++i) tn2_pair_reduce_dual(i, F, pair_edge, erev, g1, g1_t, gAp, gAp_t);
 }
 void h2_w_dual(int E, int F3, const int* epair, const float* e3, const float* e3_t, const float* C, const float* C_t, float* w, float* w_t) {
   for (int64_t i = 0; i < (int64_t)E * F3; ++i) tn2_w_dual(i, F3, epair, e3, e3_t, C, C_t, w, w_t);
@@ -275,11 +284,6 @@ void h2_edge_gw_dual(int E, int N, int F, const int* rowptr, const int* col, con
                      float* g_e3_t, float* gcp, float* gcp_t) {
   for (int64_t i = 0; i < (int64_t)E * F; ++i)
     tn2_edge_gw_dual(i, N, F, rowptr, col, epair, g_Mi, g_Mi_t, Pn, Pn_t, e3, e3_t, C, C_t, g_e3, g_e3_t, gcp, gcp_t);
-}
-void h2_edge_reduce_dual(int N, int K, int qd, const int* rowptr, const int* erev, const float* g_in, const float* g_in_t, float* g_ch,
-                         float* g_ch_t, int ldg, int off) {
-  for (int i = 0; i < N; ++i)
-    for (int q = 0; q < qd; ++q) tn2_edge_reduce_dual(i, q, K, qd, rowptr, erev, g_in, g_in_t, g_ch, g_ch_t, ldg, off);
 }
 void h2_edge_rowdot(int E, int W, int ldx, const int* epair, const float* x, const float* x_t, const float* y, const float* y2,
                     const float* d_t, int accumulate, float* val, float* val_t) {

@@ -170,14 +170,13 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
         bM = [sd[Lp + f"linears_scalar.{k}.bias"] for k in range(3)]
         V = [sd[Lp + f"linears_tensor.{k}.weight"] for k in range(6)]
         c = dict(M=M, V=V)
-        Kin = K + 2 * qd
-        c["ein"], c["ein_t"] = f32(NE, Kin), f32(NE, Kin)
-        call("h2_edge_in_dual", NE, N, K, qd, rowptr, col, epair, phi, phi_t, charges, charges_t, QC, l * qd, c["ein"], c["ein_t"])
-        c["pre1"] = gemm(c["ein"], M[0], bM[0])
-        c["he1"] = Fn.silu(c["pre1"])
-        c["e1_t"] = gemm(c["ein_t"], M[0])
-        c["he1_t"] = f32(NE, F)
-        call("hh_silu_tangent", C.c_int64(NE * F), c["pre1"], c["e1_t"], c["he1_t"])
+        M1a, M1b, M1c = M[0][:, :K].contiguous(), M[0][:, K:K + qd].contiguous(), M[0][:, K + qd:].contiguous()  # the engine's three blocks
+        chl, chl_t = charges[:, l * qd:(l + 1) * qd].contiguous(), charges_t[:, l * qd:(l + 1) * qd].contiguous()
+        c.update(M1a=M1a, M1b=M1b, M1c=M1c, chl=chl, chl_t=chl_t)
+        Ap, Ap_t = gemm(phi, M1a, bM[0]), gemm(phi_t, M1a)          # [P + 1, F]
+        Bt, Bt_t, Cs, Cs_t = gemm(chl, M1b), gemm(chl_t, M1b), gemm(chl, M1c), gemm(chl_t, M1c)  # [N, F]
+        c["pre1"], c["e1_t"], c["he1"], c["he1_t"] = f32(NE, F), f32(NE, F), f32(NE, F), f32(NE, F)
+        call("h2_edge_pre1_dual", NE, N, F, rowptr, col, epair, Ap, Ap_t, Bt, Bt_t, Cs, Cs_t, c["pre1"], c["e1_t"], c["he1"], c["he1_t"])
         c["pre2"] = gemm(c["he1"], M[1], bM[1])
         c["he2"] = Fn.silu(c["pre2"])
         c["e2_t"] = gemm(c["he1_t"], M[1])
@@ -244,7 +243,7 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     G, G_t = f32(N, 9, F), f32(N, 9, F)
     call("hh_readout_bwd_dual", N, F, X[L], X_t[L], g_feat, g_feat_t, G, G_t)
     charge_head_bwd(L, G, G_t)
-    gCe, gCe_t, gphie, gphie_t = torch.zeros(NE), torch.zeros(NE), torch.zeros(NE), torch.zeros(NE)  # per directed edge, summed over the layers
+    gCe, gCe_t = torch.zeros(NE), torch.zeros(NE)  # adjoint of the cutoff factor per directed edge, summed over the layers
     for l in reversed(range(L)):
         c = lay[l]
         V, M = c["V"], c["M"]
@@ -271,10 +270,18 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
         gh1, gh1_t = gemmT(g2, M[1]), gemmT(g2_t, M[1])
         g1, g1_t = f32(NE, F), f32(NE, F)
         call("hh_dsilu_dual", C.c_int64(NE * F), gh1, gh1_t, c["pre1"], c["e1_t"], g1, g1_t)
-        ent[f"l{l}.M0"], ent[f"l{l}.b0"] = tn_gemm(g1_t, c["ein"]) + tn_gemm(g1, c["ein_t"]), g1_t.sum(0)
-        g_in, g_in_t = gemmT(g1, M[0]), gemmT(g1_t, M[0])  # [E, K + 2 q_dim]: adjoint of (phi | c_i | c_j)
-        call("h2_edge_rowdot", NE, K, K + 2 * qd, epair, g_in, g_in_t, dphi, d2phi, d_t, 1, gphie, gphie_t)  # sum_k g_phi phi' per edge
-        call("h2_edge_reduce_dual", N, K, qd, rowptr, erev, g_in, g_in_t, g_charges, g_charges_t, QC, l * qd)
+        gB, gB_t, gCs, gCs_t, gself, gself_t = f32(N, F), f32(N, F), f32(N, F), f32(N, F), f32(N, F), f32(N, F)
+        call("h2_edge_reduce_dual", N, F, rowptr, col, erev, g1, g1_t, gB, gB_t, gCs, gCs_t, gself, gself_t)
+        gAp, gAp_t = f32(P1, F), f32(P1, F)
+        call("h2_pair_reduce_dual", P, F, pair_edge, erev, g1, g1_t, gAp, gAp_t)
+        gAp[P], gAp_t[P] = gself.sum(0), gself_t.sum(0)  # the self pair's row: column sum over the atoms' self edges
+        ent[f"l{l}.M0"] = torch.cat([tn_gemm(gAp_t, phi) + tn_gemm(gAp, phi_t), tn_gemm(gB_t, c["chl"]) + tn_gemm(gB, c["chl_t"]),
+                                     tn_gemm(gCs_t, c["chl"]) + tn_gemm(gCs, c["chl_t"])], 1)  # [F, K + 2 q_dim] = (M0 | M0b | M0c)
+        ent[f"l{l}.b0"] = gAp_t.sum(0)
+        dAp, d2Ap = gemm(dphi, c["M1a"]), gemm(d2phi, c["M1a"])
+        call("hh_pair_rowdot", P, F, gAp, gAp_t, dAp, d2Ap, d_t, 1, gphid, gphid_t)  # (g_Ap M1a) . phi' = g_Ap . (phi' M1a^T)
+        g_charges[:, l * qd:(l + 1) * qd] += gemmT(gB, c["M1b"]) + gemmT(gCs, c["M1c"])
+        g_charges_t[:, l * qd:(l + 1) * qd] += gemmT(gB_t, c["M1b"]) + gemmT(gCs_t, c["M1c"])
         for k, (a_, b_) in enumerate(zip(tlin_grad(g_Pn_t, c["Xh"]), tlin_grad(g_Pn, c["Xh_t"]))):
             ent[f"l{l}.Va{k}"] = a_ + b_
         gXl, gXl_t = tlin(g_Pn, V[0:3], True), tlin(g_Pn_t, V[0:3], True)
@@ -311,9 +318,8 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     ec, ec_t = torch.zeros(2, P1, 4), torch.zeros(2, P1, 4)
     call("hh_edge_geom_dual", int(col.numel()), N, F, P, rowptr, col, epair, esign, z, Utab, Vtab, Q, Q_t, Cc, C_t, prhat, rhat_t, gA, gA_t,
          ec, ec_t, C.c_int64(P1 * 4))
-    # the layers' per-edge adjoints of C and of phi (both directions of a pair; self edges carry no geometry) -> per pair
+    # the layers' per-edge adjoint of C (both directions of a pair; self edges carry no geometry) -> per pair
     call("h2_pair_from_edges", P, pair_edge, erev, gCe, gCe_t, gC, gC_t)
-    call("h2_pair_from_edges", P, pair_edge, erev, gphie, gphie_t, gphid, gphid_t)
     gdel, gdel_t = f32(max(P, 1), 3), f32(max(P, 1), 3)
     call("hh_geom_dual", P, pd, prhat, d_t, rhat_t, dC, d2C, gC, gC_t, gphid, gphid_t, ec, ec_t, C.c_int64(P1 * 4), gdel, gdel_t)
     g_pos, Hv = f32(N, 3), f32(N, 3)

@@ -132,19 +132,52 @@ HVP_FN void cp_qeq_bwd_dual(int n, int q, int qd, const int64_t* batch, const fl
 }
 
 // ------------------------------------------------------------------------------------------------ edge MLP per directed edge
-// input row of edge e = (i <- j): ( phi[pair] | c_i | c_j )  [E][K + 2 qd]        (tensornet2.py:548-566); idx over E * (K + 2 qd)
-HVP_FN void tn2_edge_in_dual(int64_t idx, int N, int K, int qd, const int* rowptr, const int* col, const int* epair, const float* phi,
-                             const float* phi_t, const float* ch, const float* ch_t, int ldc, int off, float* ein, float* ein_t) {
-  const int W = K + 2 * qd;
-  const int e = (int)(idx / W), j = (int)(idx - (int64_t)e * W);
-  if (j < K) {
-    ein[idx] = phi[(int64_t)epair[e] * K + j];
-    ein_t[idx] = phi_t[(int64_t)epair[e] * K + j];
-  } else {
-    const int a = j < K + qd ? edge_geom_row(e, N, rowptr) : col[e], q = j < K + qd ? j - K : j - K - qd;
-    ein[idx] = ch[(int64_t)a * ldc + off + q];
-    ein_t[idx] = ch_t[(int64_t)a * ldc + off + q];
+// first edge-MLP layer per directed edge e = (i <- j), decomposed as the engine does (tn_tn2_api.hip): with the first weight matrix
+// split by columns M1 = [M1a | M1b | M1c] (tensornet2.py:548-566),  pre1[e] = Ap[pair] + Bt[i] + Cs[j],  Ap = phi M1a^T + b1 [P + 1][F],
+// Bt = c M1b^T, Cs = c M1c^T [N][F];  he1 = silu(pre1).                                                           (idx over E * F)
+HVP_FN void tn2_edge_pre1_dual(int64_t idx, int N, int F, const int* rowptr, const int* col, const int* epair, const float* Ap,
+                               const float* Ap_t, const float* Bt, const float* Bt_t, const float* Cs, const float* Cs_t, float* pre1,
+                               float* e1_t, float* he1, float* he1_t) {
+  const int e = (int)(idx / F), f = (int)(idx - (int64_t)e * F);
+  const int i = edge_geom_row(e, N, rowptr), j = col[e], p = epair[e];
+  const float a = Ap[(int64_t)p * F + f] + Bt[(int64_t)i * F + f] + Cs[(int64_t)j * F + f];
+  const float at = Ap_t[(int64_t)p * F + f] + Bt_t[(int64_t)i * F + f] + Cs_t[(int64_t)j * F + f];
+  pre1[idx] = a;
+  e1_t[idx] = at;
+  he1[idx] = silu0(a);
+  he1_t[idx] = silu1(a) * at;
+}
+// adjoint of that sum: gB[i] = sum_{e in row i} g1[e] (target block), gCs[i] = sum_{e in row i} g1[erev[e]] (the edges whose SOURCE is
+// i), gself[i] = g1[self edge of i] (its column sum is the self pair's row of gAp)                                   ((atom, channel))
+HVP_FN void tn2_edge_reduce_dual(int i, int f, int F, const int* rowptr, const int* col, const int* erev, const float* g1, const float* g1_t,
+                                 float* gB, float* gB_t, float* gCs, float* gCs_t, float* gself, float* gself_t) {
+  float b = 0.f, bt = 0.f, c = 0.f, ct = 0.f, sf = 0.f, sft = 0.f;
+  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    const int r = erev[e];
+    b += g1[(int64_t)e * F + f];
+    bt += g1_t[(int64_t)e * F + f];
+    c += g1[(int64_t)r * F + f];
+    ct += g1_t[(int64_t)r * F + f];
+    if (col[e] == i) {
+      sf = g1[(int64_t)e * F + f];
+      sft = g1_t[(int64_t)e * F + f];
+    }
   }
+  const int64_t o = (int64_t)i * F + f;
+  gB[o] = b;
+  gB_t[o] = bt;
+  gCs[o] = c;
+  gCs_t[o] = ct;
+  gself[o] = sf;
+  gself_t[o] = sft;
+}
+// gAp[p] = g1[e] + g1[erev[e]] for the lower edge e of pair p < P (row P = the self pair: filled from the column sum of gself)   (idx over P * F)
+HVP_FN void tn2_pair_reduce_dual(int64_t idx, int F, const int* pair_edge, const int* erev, const float* g1, const float* g1_t, float* gAp,
+                                 float* gAp_t) {
+  const int p = (int)(idx / F), f = (int)(idx - (int64_t)p * F);
+  const int e = pair_edge[p], r = erev[e];
+  gAp[idx] = g1[(int64_t)e * F + f] + g1[(int64_t)r * F + f];
+  gAp_t[idx] = g1_t[(int64_t)e * F + f] + g1_t[(int64_t)r * F + f];
 }
 // w = silu(e3) C(d) per directed edge row (width 3F)
 HVP_FN void tn2_w_dual(int64_t i, int F3, const int* epair, const float* e3, const float* e3_t, const float* C, const float* C_t, float* w,
@@ -199,19 +232,6 @@ HVP_FN void tn2_edge_gw_dual(int64_t idx, int N, int F, const int* rowptr, const
     gcp[idx] = gc;
     gcp_t[idx] = gct;
   }
-}
-// adjoint of the charges from the edge inputs g_in [E][K + 2 qd]: g_c[i] += sum_{e in row i} ( g_in[e, K + q] + g_in[erev[e], K + qd + q] )
-HVP_FN void tn2_edge_reduce_dual(int i, int q, int K, int qd, const int* rowptr, const int* erev, const float* g_in, const float* g_in_t,
-                                 float* g_ch, float* g_ch_t, int ldg, int off) {
-  const int W = K + 2 * qd;
-  float s = 0.f, st = 0.f;
-  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-    const int r = erev[e];
-    s += g_in[(int64_t)e * W + K + q] + g_in[(int64_t)r * W + K + qd + q];
-    st += g_in_t[(int64_t)e * W + K + q] + g_in_t[(int64_t)r * W + K + qd + q];
-  }
-  g_ch[(int64_t)i * ldg + off + q] += s;
-  g_ch_t[(int64_t)i * ldg + off + q] += st;
 }
 // per directed edge: val[e] (+)= sum_j x[e, j] y[pair(e), j] ; val_t[e] (+)= sum_j ( x_t y + x y2 d_t[pair] )       (rows of x have stride ldx)
 HVP_FN void edge_rowdot(int e, int W, int ldx, const int* epair, const float* x, const float* x_t, const float* y, const float* y2,
