@@ -293,10 +293,11 @@ void h2_pair_from_edges(int P, const int* pair_edge, const int* erev, const floa
   for (int p = 0; p < P; ++p) pair_from_edges(p, pair_edge, erev, val, val_t, out, out_t);
 }
 void h2_coulomb_atom_dual(int N, int QC, const int* mstart, const int* mend, const int64_t* batch, const float* pos, const float* v,
-                          const float* box, const float* ch, const float* ch_t, const float* wq, float wsum, float cut, float eps, float scale,
-                          float* e_atom, float* e_atom_t, float* g_q, float* g_q_t, float* g_pos, float* hv) {
+                          const float* box, int box_per_mol, const float* ch, const float* ch_t, const float* wq, float wsum, float cut, float eps,
+                          float scale, float* e_atom, float* e_atom_t, float* g_q, float* g_q_t, float* g_pos, float* hv) {
   for (int i = 0; i < N; ++i)
-    coulomb_atom_dual(i, QC, mstart, mend, batch, pos, v, box, ch, ch_t, wq, wsum, cut, eps, scale, e_atom, e_atom_t, g_q, g_q_t, g_pos, hv);
+    coulomb_atom_dual(i, QC, mstart, mend, batch, pos, v, box, box_per_mol, ch, ch_t, wq, wsum, cut, eps, scale, e_atom, e_atom_t, g_q, g_q_t,
+                      g_pos, hv);
 }
 
 }  // extern "C"

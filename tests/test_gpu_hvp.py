@@ -195,3 +195,74 @@ def test_et_analytic_force_term_gradients_match_specification(hip_lib, golden_di
     bad = {k: e for k, e in errs.items() if not e < REL}
     assert not bad, bad
     assert hv_err < REL, hv_err
+
+
+@pytest.mark.parametrize("fixture", ["tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_tn2_analytic_force_term_gradients_match_specification(hip_lib, golden_dir, fixture):
+    """TensorNet2 + ScalarPlusWeightedCoulomb: tmdnet_force_param_grads (csrc/tn_tn2_hvp.hip + the T2 statements of the schedule in
+    tn_hvp_api.hip) against oracle/tn2_second_order.py in fp64 (pinned to autograd-of-autograd): every parameter - the charge heads
+    and the three blocks of the first edge layer included - and H v with the Coulomb term's own pair geometry; total charges with the
+    all-to-all sum, and the reaction-field branch in a periodic box.  The intermediates are walked against the host run of the same
+    bodies (tests/tn2_hvp_host_mirror.py): per-edge tensors ("l*.pre1" ... "g1") assume the same CSR edge order on both sides - if
+    every per-edge tensor differs and no per-atom one does, look there first."""
+    from oracle import tn2_second_order as N2
+    from oracle import tn2_torch as T2
+    from tests import tn2_hvp_host_mirror as M2
+    from torchmdnet_amd import _C
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, fixture))
+    model = create_model(dict(g["args"]))
+    model.load_state_dict(g["state_dict"])
+    model = model.to("cuda")
+    z, pos, batch = g["z"], g["pos"], g["batch"]
+    q = g["q"] if g.get("q") is not None else None
+    box = g["box"] if g.get("box") is not None else None
+    n_mol = int(batch.max()) + 1
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(3))
+    grads, hv = model.force_term_parameter_gradients(z.cuda(), pos.cuda(), batch.cuda(), None if box is None else box.cuda(),
+                                                     None if q is None else q.cuda(), n_mol, v.cuda(), want_hv=True)
+    torch.cuda.synchronize()
+    hp = T2.hparams_from_args(g["args"])
+    mir = M2.force_term_mirror(g["state_dict"], hp, z, pos, batch, v, box=box, q=q)
+    L, st = _C.lib(), model._engine
+    rows = []
+    for name in mir["order"]:
+        ref = mir["bufs"][name]
+        n = L.tmdnet_hvp_debug_tensor(st.handle, None, name.encode(), None, 0)
+        if n != ref.numel():
+            rows.append((name, f"size {n} != {ref.numel()}"))
+            continue
+        out = torch.empty(ref.numel(), dtype=torch.float32, device="cuda")
+        assert L.tmdnet_hvp_debug_tensor(st.handle, None, name.encode(), C.c_void_p(out.data_ptr()), out.numel()) == 0
+        torch.cuda.synchronize()
+        o, r = out.cpu(), ref.reshape(-1)
+        if name in ("gAp", "gAp_t", "gdel", "gdel_t") and r.numel() != o.numel():
+            continue
+        err = (o - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        rows.append((name, err if torch.isfinite(o).all() else float("inf")))
+    first_bad = next(((n, e) for n, e in rows if not (isinstance(e, float) and e < 1e-3)), None)
+    sd64 = {k: (t.double() if t.is_floating_point() else t) for k, t in g["state_dict"].items()}
+    ref = N2.force_term(sd64, hp, z, pos.double(), batch, v.double(), box=None if box is None else box.double(),
+                        q=None if q is None else q.double())
+    refg = N2.state_dict_grads(ref, sd64, hp)
+    by_name = {id(p): k for k, p in model.named_parameters()}
+    errs = {}
+    for p, gr in grads.items():
+        key = by_name[id(p)]
+        r = refg.get(key)
+        if r is None or r.abs().max() == 0:
+            assert gr.abs().max().item() < 1e-6, key
+            continue
+        errs[key] = (gr.cpu().double() - r.reshape(gr.shape)).abs().max().item() / r.abs().max().item()
+    hv_err = (hv.cpu().double() - ref["Hv"]).abs().max().item() / ref["Hv"].abs().max().item()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/hvp_{fixture[:-3]}.json", "w") as fh:
+        json.dump({"case": fixture, "hv_error": hv_err, "worst_param": max(errs.items(), key=lambda kv: kv[1]), "param_errors": errs,
+                   "first_bad_buffer": first_bad, "buffers": rows}, fh, indent=1)
+    assert first_bad is None, first_bad
+    missing = {k for k, t in refg.items() if t.abs().max() > 0} - set(errs)
+    assert not missing, missing
+    bad = {k: e for k, e in errs.items() if not e < REL}
+    assert not bad, bad
+    assert hv_err < REL, hv_err

@@ -223,7 +223,7 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     pos32 = pos.float().contiguous()
     boxf = None if box is None else box.float().contiguous()
     e_c, e_c_t, g_q, g_q_t, gpos_c, hv_c = f32(N), f32(N), f32(N, QC), f32(N, QC), f32(N, 3), f32(N, 3)
-    call("h2_coulomb_atom_dual", N, QC, mstart, mend, batch, pos32, v, boxf, charges, charges_t, qw, float(qw.sum()),
+    call("h2_coulomb_atom_dual", N, QC, mstart, mend, batch, pos32, v, boxf, 0, charges, charges_t, qw, float(qw.sum()),
          float(cut) if cut is not None else -1.0, float(hp.get("coulomb_epsilon_solvent", 78.3)), float(COULOMB_FACTOR), e_c, e_c_t, g_q, g_q_t,
          gpos_c, hv_c)
     s_val = (headv * O2).sum() + std * e_c_t.sum()
@@ -334,4 +334,40 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     nz = sd[T + "emb.weight"].shape[0]
     onehot = Fn.one_hot(z, nz).float()
     ent["Utab"], ent["Vtab"] = tn_gemm(onehot, gZu_t), tn_gemm(onehot, gZv_t)
-    return dict(ent=ent, extra=ext, s=s_val, Hv=Hv, F=-g_pos)
+    # the engine's intermediates by the names tmdnet_hvp_debug_tensor knows, in schedule order (tests/test_gpu_hvp.py walks them; the
+    # scratch of the reverse sweep holds its last layer, l = 0, and the adjoint of the charges its final sum)
+    bufs, order = {}, []
+
+    def put(name, t):
+        bufs[name] = t
+        order.append(name)
+
+    for nm, t in (("phi", phi), ("phi_t", phi_t), ("C_t", C_t), ("d2phi", d2phi), ("Q", Q), ("u0", u0), ("u0_t", u0_t), ("X0", X[0]), ("X_t0", X_t[0])):
+        put(nm, t)
+
+    def put_head(k):
+        S = cps[k]
+        c_ = f"cp{k}."
+        for nm, t in (("ln", S["hs"][0]), ("ln_t", S["hs_t"][0]), ("xh", S["xh"]), ("rstd_t", S["rstd_t"]), ("a1", S["pres"][0]),
+                      ("a1_t", S["pres_t"][0]), ("h1", S["hs"][1]), ("h1_t", S["hs_t"][1]), ("a2", S["pres"][1]), ("a2_t", S["pres_t"][1]),
+                      ("h2", S["hs"][2]), ("h2_t", S["hs_t"][2]), ("out", S["out"]), ("out_t", S["out_t"])):
+            put(c_ + nm, t)
+
+    put_head(0)
+    for l, c in enumerate(lay):
+        for nm in ("pre1", "e1_t", "he1", "he1_t", "pre2", "e2_t", "he2_t", "pre3", "e3_t", "w", "w_t", "Xh", "Xh_t", "Pn", "Pn_t", "Mi", "Mi_t", "Ch",
+                   "Ch_t", "D", "D_t"):
+            put(f"l{l}.{nm}", c[nm])
+        put(f"X{l + 1}", X[l + 1])
+        put(f"X_t{l + 1}", X_t[l + 1])
+        put_head(l + 1)
+    for nm, t in (("charges", charges), ("charges_t", charges_t), ("feat", feat), ("lnr_t", lnr_t), ("al", al), ("x_t", x_t), ("ao_t", ao_t),
+                  ("headv", headv), ("e_c", e_c), ("e_c_t", e_c_t), ("g_q", g_q), ("g_q_t", g_q_t), ("gpos_c", gpos_c), ("hv_c", hv_c),
+                  ("g_feat", g_feat), ("g_feat_t", g_feat_t), ("g_Mi", g_Mi), ("g_Mi_t", g_Mi_t), ("g_Pn", g_Pn), ("g_Pn_t", g_Pn_t), ("g3", g3),
+                  ("g3_t", g3_t), ("g2", g2), ("g2_t", g2_t), ("g1", g1), ("g1_t", g1_t), ("gB", gB), ("gB_t", gB_t), ("gCs", gCs), ("gCs_t", gCs_t),
+                  ("gself", gself), ("gself_t", gself_t), ("gAp", gAp), ("gAp_t", gAp_t), ("g_charges", g_charges), ("g_charges_t", g_charges_t),
+                  ("gCe", gCe), ("gCe_t", gCe_t), ("G_emb", G), ("G_emb_t", G_t), ("g_UX", g_UX), ("g_UX_t", g_UX_t), ("g_a2_t", g_a2_t),
+                  ("g_a1_t", g_a1_t), ("g_s0n_t", g_s0n_t), ("gA", gA), ("gA_t", gA_t), ("gC", gC), ("gC_t", gC_t), ("gphid", gphid),
+                  ("gphid_t", gphid_t), ("gdel", gdel), ("gdel_t", gdel_t)):
+        put(nm, t)
+    return dict(ent=ent, extra=ext, s=s_val, Hv=Hv, F=-g_pos, bufs=bufs, order=order, P=P)

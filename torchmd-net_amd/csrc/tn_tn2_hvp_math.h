@@ -268,9 +268,10 @@ HVP_FN void exp_cutoff_d2(float d, float rc, float& f, float& f1, float& f2) {
 // charges g_q[i] = sum_j 2 h wq c_j (seed 1 on every atom's energy: a pair counts for both of its atoms) and the position gradient
 // g_pos[i] = sum_j 2 S h' r_ij, all with tangents.  scale = COULOMB_FACTOR.
 HVP_FN void coulomb_atom_dual(int i, int QC, const int* mstart, const int* mend, const int64_t* batch, const float* pos, const float* v,
-                              const float* box, const float* ch, const float* ch_t, const float* wq, float wsum, float cut, float eps,
+                              const float* box_all, int box_per_mol, const float* ch, const float* ch_t, const float* wq, float wsum, float cut, float eps,
                               float scale, float* e_atom, float* e_atom_t, float* g_q, float* g_q_t, float* g_pos, float* hv) {
   const int m = (int)batch[i];
+  const float* box = box_all ? box_all + (box_per_mol ? (int64_t)m * 9 : 0) : nullptr;
   float ea = 0.f, eat = 0.f, gp[3] = {0.f, 0.f, 0.f}, gpt[3] = {0.f, 0.f, 0.f};
   for (int q = 0; q < QC; ++q) g_q[(int64_t)i * QC + q] = g_q_t[(int64_t)i * QC + q] = 0.f;
   const float k_rf = cut > 0.f ? (1.0f / (cut * cut * cut)) * (eps - 1.0f) / (2.0f * eps + 1.0f) : 0.f;
@@ -330,6 +331,14 @@ HVP_FN void coulomb_atom_dual(int i, int QC, const int* mstart, const int* mend,
     hv[i * 3 + x] = gpt[x];
   }
 }
+
+// dst[n, off + q] += src[n, q]     (a [N][qd] block into a column block of a [N][ld] buffer)      ; y += a x
+HVP_FN void add_cols(int64_t idx, int qd, const float* src, float* dst, int ld, int off) {
+  const int64_t n = idx / qd, q = idx - n * qd;
+  dst[n * ld + off + q] += src[idx];
+}
+HVP_FN void axpy1(int64_t i, float a, const float* x, float* y) { y[i] += a * x[i]; }
+HVP_FN void scale1(int64_t i, float a, const float* x, float* y) { y[i] = a * x[i]; }
 
 }  // namespace hvp
 }  // namespace tn

@@ -405,9 +405,9 @@ class _EnergyForceParamGrad(torch.autograd.Function):
             v = g_forces.detach().to(torch.float32)
             order = getattr(model, "force_gradient_order", None)
             if order is None:  # auto: the analytic pass where it has been timed (TensorNet), the order-2 difference quotient elsewhere
-                order = 2 if (model._is_et() or model._is_tn2()) else 0
+                order = 2 if (model._is_et() or model._is_tn2()) else 0  # TensorNet2's analytic pass: host-validated, ask for it with 0
             order = int(order)
-            analytic = order == 0 and not model._is_tn2()
+            analytic = order == 0
             with_hv = analytic and ctx.needs_input_grad[2] and getattr(model, "force_position_gradient", True)
             if not with_hv and ctx.needs_input_grad[2] and not getattr(model, "_warned_pos_grad", False):
                 # pos always requires grad here (the reference's side effect, model.py:584-585), so this cannot tell a caller who
@@ -729,8 +729,6 @@ class TorchMD_Net(nn.Module):
         its second autograd pass, model.py:618-628 with create_graph=True).  -> {parameter: gradient}; d loss / d theta through
         the forces is MINUS this with v = d loss / d F.  want_hv: -> ({parameter: gradient}, H v [N, 3]) with H v = d s / d pos, the
         Hessian of the summed energy applied to v (the position gradient of such a loss is - H v)."""
-        if self._is_tn2():
-            raise NotImplementedError("the analytic second-order pass is built for TensorNet + Scalar and the Equivariant Transformer")
         if self._is_et():
             q = None  # TorchMD_ET.forward ignores q
         L = _C.lib()
@@ -779,7 +777,7 @@ class TorchMD_Net(nn.Module):
                 off, numel = C.c_int64(0), C.c_int64(0)
                 name = L.tmdnet_param_grad_entry(st.handle, i, C.byref(off), C.byref(numel)).decode()
                 ent[name] = flat[off.value: off.value + numel.value]
-            grads = self._et_grads(ent) if self._is_et() else self._tensornet_grads(ent)
+            grads = self._et_grads(ent) if self._is_et() else (self._tn2_grads(ent) if self._is_tn2() else self._tensornet_grads(ent))
             return (grads, hv) if want_hv else grads
 
     def _train_forward(self, z, pos, batch, box, q, n_mol, keep=True):
