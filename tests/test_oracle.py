@@ -355,3 +355,44 @@ def test_tn2_hand_second_order_pass_equals_autograd_of_autograd(golden_dir, fixt
         assert rel_err(mine[k].reshape(r.shape), r) < 1e-10, k
         checked += 1
     assert checked >= 60
+
+
+@pytest.mark.parametrize("fixture", ["tiny_ref.pt", "et_tiny_ref.pt", "et_tiny_vc_ref.pt", "tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_second_order_specifications_equal_the_reference_double_backward(golden_dir, fixture):
+    """The three specifications of the analytic force-matching pass against the UNMODIFIED reference's own second autograd pass
+    (model.py:618-628 in training mode, fp64; tests/golden/second_order_ref.pt from oracle/make_golden_second_order.py): s = - v . F,
+    H v = d s / d pos and d s / d theta for every parameter the reference gave a gradient."""
+    ref = torch.load(os.path.join(golden_dir, "second_order_ref.pt"))[fixture]
+    g = torch.load(os.path.join(golden_dir, fixture))
+    sd = {k: (t.double() if t.is_floating_point() else t) for k, t in g["state_dict"].items()}
+    z, pos, batch, v = g["z"], g["pos"].double(), g["batch"], ref["v"]
+    q = g["q"].double() if g.get("q") is not None else None
+    box = g["box"].double() if g.get("box") is not None else None
+    if fixture.startswith("et_"):
+        from oracle import et_second_order as E2
+
+        out = E2.force_term(sd, ET.hparams_from_args(g["args"]), z, pos, batch, v)
+        mine = out["grads"]
+    elif fixture.startswith("tn2_"):
+        from oracle import tn2_second_order as N2
+        from oracle import tn2_torch as T2
+
+        hp = T2.hparams_from_args(g["args"])
+        out = N2.force_term(sd, hp, z, pos, batch, v, box=box, q=q)
+        mine = N2.state_dict_grads(out, sd, hp)
+    else:
+        hp = T.hparams_from_args(g["args"])
+        out = S2.force_term(sd, hp, z, pos, batch, v, q=q)
+        mine = S2.state_dict_grads(out["ent"], sd, hp)
+    assert rel_err(out["F"], ref["F"]) < 1e-10
+    assert abs(out["s"].item() - ref["s"].item()) < 1e-10 * max(1.0, abs(ref["s"].item()))
+    assert rel_err(out["Hv"], ref["Hv"]) < 1e-10
+    checked = 0
+    for k, r in ref["grads"].items():
+        if r.abs().max() == 0:
+            assert k not in mine or mine[k].abs().max() < 1e-12, k
+            continue
+        assert k in mine, k
+        assert rel_err(mine[k].reshape(r.shape), r) < 1e-9, k
+        checked += 1
+    assert checked >= 30
