@@ -268,7 +268,7 @@ def test_tn2_analytic_force_term_gradients_match_specification(hip_lib, golden_d
     assert hv_err < REL, hv_err
 
 
-@pytest.mark.parametrize("fixture", ["tiny_ref.pt", "et_tiny_ref.pt", "et_tiny_vc_ref.pt"])
+@pytest.mark.parametrize("fixture", ["tiny_ref.pt", "et_tiny_ref.pt", "et_tiny_vc_ref.pt", "tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
 def test_engine_second_order_pass_equals_the_reference_double_backward(hip_lib, golden_dir, fixture):
     """The engine's analytic pass directly against what the UNMODIFIED reference's second autograd pass gave for the same weights,
     inputs and direction v (tests/golden/second_order_ref.pt, fp64, made by oracle/make_golden_second_order.py): H v and every
@@ -283,8 +283,9 @@ def test_engine_second_order_pass_equals_the_reference_double_backward(hip_lib, 
     z, pos, batch = g["z"], g["pos"], g["batch"]
     q = g["q"] if g.get("q") is not None else None
     n_mol = int(batch.max()) + 1
-    grads, hv = model.force_term_parameter_gradients(z.cuda(), pos.cuda(), batch.cuda(), None, None if q is None else q.cuda(), n_mol,
-                                                     ref["v"].float().cuda(), want_hv=True)
+    box = g["box"] if g.get("box") is not None else None
+    grads, hv = model.force_term_parameter_gradients(z.cuda(), pos.cuda(), batch.cuda(), None if box is None else box.cuda(),
+                                                     None if q is None else q.cuda(), n_mol, ref["v"].float().cuda(), want_hv=True)
     torch.cuda.synchronize()
     by_name = {id(p): k for k, p in model.named_parameters()}
     mine = {by_name[id(p)]: t.cpu().double() for p, t in grads.items()}
