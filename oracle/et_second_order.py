@@ -84,7 +84,7 @@ def dir_dual(u, u_t, n, n_t):
     return dirn, torch.where(ok, (u_t - dirn * n_t[:, None, :]) / ns, torch.zeros_like(u))
 
 
-def force_term(sd, hp, z, pos, batch, v, box=None):
+def force_term(sd, hp, z, pos, batch, v, box=None, ge=None):
     """-> dict(E, F, s, grads={state-dict key: d s / d parameter}, Hv)."""
     R = "representation_model."
     F, H, L = hp["hidden_channels"], hp["num_heads"], hp["num_layers"]
@@ -236,6 +236,9 @@ def force_term(sd, hp, z, pos, batch, v, box=None):
     # ================= reverse with tangents: head
     g_y2, g_y2_t = torch.zeros_like(y2), torch.zeros_like(y2)
     g_y2[:, 0] = std
+    if ge is not None:  # one-pass training: gradient of S = s - sum_m ge_m E_m (oracle/tensornet_second_order.py force_term)
+        g_y2_t[:, 0] = -std * ge.to(dt).reshape(-1)[batch]
+        s_val = s_val - (ge.to(dt).reshape(-1) * Emol.reshape(-1)).sum()
     lin_grad(O1 + "update_net.layers.2", g_y2, g_y2_t, h2, h2_t)
     g_h2, g_h2_t = g_y2 @ W(O1 + "update_net.layers.2"), g_y2_t @ W(O1 + "update_net.layers.2")
     g_pre2, g_pre2_t = g_h2 * d1(pre2), g_h2_t * d1(pre2) + g_h2 * d2(pre2) * pre2_t

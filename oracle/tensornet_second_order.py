@@ -110,8 +110,11 @@ def r6_dual(re, re_t):
     return torch.stack([2 * x * a, a * y + x * b, a * z + x * c, 2 * y * b, b * z + y * c, 2 * z * c], 1)
 
 
-def force_term(sd, hp, z, pos, batch, v, box=None, q=None):
-    """returns dict(E, F, s, ent={engine entry name: d s / d entry}, Hv=d s / d pos, inter={name: tensor})."""
+def force_term(sd, hp, z, pos, batch, v, box=None, q=None, ge=None):
+    """returns dict(E, F, s, ent={engine entry name: d s / d entry}, Hv=d s / d pos, inter={name: tensor}).
+    ge [n_mol] (one-pass training): everything is the gradient of  S = s - sum_m ge_m E_m  instead - the tangent of the adjoint
+    h = g_t - (adjoint of sum_m ge_m E_m) obeys the recursion of g_t, so only its seed at the head changes: with v = d loss / d F and
+    ge = d loss / d E the whole parameter gradient of loss(E, F) is  - ent  and the position gradient  - Hv."""
     R = "representation_model."
     Fh, L, K = hp["hidden_channels"], hp["num_layers"], hp["num_rbf"]
     lo, up = float(hp["cutoff_lower"]), float(hp["cutoff_upper"])
@@ -249,6 +252,12 @@ def force_term(sd, hp, z, pos, batch, v, box=None, q=None):
     g_ao, g_ao_t = (std * O2).expand(n, -1) * silu_d1(ao), (std * O2).expand(n, -1) * silu_d2(ao) * ao_t
     ent["O2"] = std * (silu_d1(ao) * ao_t).sum(0, keepdim=True)
     ent["bO2"] = torch.zeros(1, dtype=dt)
+    if ge is not None:  # seed - ge[molecule] of the tangent adjoint at every atom's energy
+        wa = ge.to(dt).reshape(-1)[batch][:, None]
+        g_ao_t = g_ao_t - wa * g_ao
+        ent["O2"] = ent["O2"] - std * (wa * Fn.silu(ao)).sum(0, keepdim=True)
+        ent["bO2"] = ent["bO2"] - std * wa.sum()
+        s_val = s_val - (ge.to(dt).reshape(-1) * E.reshape(-1)).sum()
     ent["O1"], ent["bO1"] = g_ao_t.t() @ x + g_ao.t() @ x_t, g_ao_t.sum(0)
     g_x, g_x_t = g_ao @ O1, g_ao_t @ O1
     g_al, g_al_t = g_x * silu_d1(al), g_x_t * silu_d1(al) + g_x * silu_d2(al) * al_t

@@ -176,7 +176,7 @@ def coulomb_dual(hp, ch, ch_t, pos, batch, v, qw, box=None):
     return dict(e_atom=e_atom, e_atom_t=e_atom_t, g_ch=g_ch, g_ch_t=g_ch_t, g_pos=g_pos, Hv=Hv)
 
 
-def force_term(sd, hp, z, pos, batch, v, box=None, q=None):
+def force_term(sd, hp, z, pos, batch, v, box=None, q=None, ge=None):
     """returns dict(E, F, s, ent={TensorNet-style entry name: d s / d entry}, extra={state-dict key: gradient of the charge heads},
     Hv=d s / d pos, inter={name: tensor})."""
     R = "representation_model."
@@ -326,6 +326,15 @@ def force_term(sd, hp, z, pos, batch, v, box=None, q=None):
     g_ao, g_ao_t = (std * O2).expand(n, -1) * silu_d1(ao), (std * O2).expand(n, -1) * silu_d2(ao) * ao_t
     ent["O2"] = std * (silu_d1(ao) * ao_t).sum(0, keepdim=True)
     ent["bO2"] = torch.zeros(1, dtype=dt)
+    cou_g_ch_t, cou_Hv = cou["g_ch_t"], cou["Hv"]
+    if ge is not None:  # one-pass training: gradient of S = s - sum_m ge_m E_m (oracle/tensornet_second_order.py force_term); the
+        # Coulomb pairs lie inside a molecule, so its adjoints take the factor of their atom's molecule
+        wa = ge.to(dt).reshape(-1)[batch][:, None]
+        g_ao_t = g_ao_t - wa * g_ao
+        ent["O2"] = ent["O2"] - std * (wa * Fn.silu(ao)).sum(0, keepdim=True)
+        ent["bO2"] = ent["bO2"] - std * wa.sum()
+        cou_g_ch_t, cou_Hv = cou["g_ch_t"] - wa * cou["g_ch"], cou["Hv"] - wa * cou["g_pos"]
+        s_val = s_val - (ge.to(dt).reshape(-1) * E.reshape(-1)).sum()
     ent["O1"], ent["bO1"] = g_ao_t.t() @ x + g_ao.t() @ x_t, g_ao_t.sum(0)
     g_x, g_x_t = g_ao @ O1, g_ao_t @ O1
     g_al, g_al_t = g_x * silu_d1(al), g_x_t * silu_d1(al) + g_x * silu_d2(al) * al_t
@@ -338,7 +347,7 @@ def force_term(sd, hp, z, pos, batch, v, box=None, q=None):
     inter.update(g_ao_t=g_ao_t, g_al_t=g_al_t, g_feat_t=g_feat_t, G_top_t=G_t)
     # adjoints of the charge channels: from the Coulomb term (all sets at once) and, below, from the edge MLP of the layer they feed
     g_chs = [std * cou["g_ch"][:, k * qd:(k + 1) * qd].clone() for k in range(L + 1)]
-    g_chs_t = [std * cou["g_ch_t"][:, k * qd:(k + 1) * qd].clone() for k in range(L + 1)]
+    g_chs_t = [std * cou_g_ch_t[:, k * qd:(k + 1) * qd].clone() for k in range(L + 1)]
     # charge head on the final X: adjoint into the residual stream
     gx, gx_t = charge_predict_bwd_dual(sd, R + (f"charge_predicts.{L - 1}." if L > 0 else "charge_predict_0."), cps[L], g_chs[L], g_chs_t[L],
                                        batch, nmol, qd, G_)
@@ -486,7 +495,7 @@ def force_term(sd, hp, z, pos, batch, v, box=None, q=None):
     g_delta = term1 + g_d[:, None] * rhat
     g_delta_t = term1_t + g_d_t[:, None] * rhat + g_d[:, None] * rhat_t
     g_pos = torch.zeros(n, 3, dtype=dt).index_add(0, pi, g_delta).index_add(0, pj, -g_delta) + std * cou["g_pos"]
-    Hv = torch.zeros(n, 3, dtype=dt).index_add(0, pi, g_delta_t).index_add(0, pj, -g_delta_t) + std * cou["Hv"]
+    Hv = torch.zeros(n, 3, dtype=dt).index_add(0, pi, g_delta_t).index_add(0, pj, -g_delta_t) + std * cou_Hv
     inter.update(g_d_t=g_d_t, g_rh_t=g_rh_t)
     return dict(E=E, F=-g_pos, s=s_val, ent=ent, extra=G_, Hv=Hv, inter=inter)
 

@@ -396,3 +396,77 @@ def test_second_order_specifications_equal_the_reference_double_backward(golden_
         assert rel_err(mine[k].reshape(r.shape), r) < 1e-9, k
         checked += 1
     assert checked >= 30
+
+
+def test_hand_second_order_pass_with_energy_seed(tiny):
+    """One-pass training: with ge = d loss / d E the specification returns the gradient of  S = v . d(sum E)/d pos - sum_m ge_m E_m
+    (parameters and positions) - against autograd of that scalar in fp64."""
+    sd64 = T.cast_state_dict(tiny["state_dict"], torch.float64)
+    hp = T.hparams_from_args(tiny["args"])
+    z, pos, batch, q = tiny["z"], tiny["pos"].double(), tiny["batch"], tiny["q"].double()
+    nmol = int(batch.max()) + 1
+    v = torch.randn(pos.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    ge = torch.randn(nmol, dtype=torch.float64, generator=torch.Generator().manual_seed(4))
+    keys = [k for k, t in sd64.items() if t.dtype == pos.dtype and t.dim() > 0 and "distance" not in k and "prior" not in k]
+    sdg = {k: (t.clone().requires_grad_(True) if k in keys else t) for k, t in sd64.items()}
+    p = pos.clone().requires_grad_(True)
+    E = T.energy(sdg, hp, z, p, batch, q=q)
+    (gp,) = torch.autograd.grad(E.sum(), p, create_graph=True)
+    S = (gp * v).sum() - (ge * E.view(-1)).sum()
+    grads = torch.autograd.grad(S, [sdg[k] for k in keys] + [p], allow_unused=True)
+    out = S2.force_term(sd64, hp, z, pos, batch, v, q=q, ge=ge)
+    assert abs(out["s"].item() - S.item()) < 1e-12 * max(1.0, abs(S.item()))
+    assert rel_err(out["Hv"], grads[-1]) < 1e-11
+    mine = S2.state_dict_grads(out["ent"], sd64, hp)
+    for k, r in zip(keys, grads[:-1]):
+        if r is not None and r.abs().max() > 0:
+            assert rel_err(mine[k].reshape(r.shape), r) < 1e-10, k
+
+
+@pytest.mark.parametrize("fixture", ["et_tiny_ref.pt", "tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_et_tn2_second_order_pass_with_energy_seed(golden_dir, fixture):
+    """One-pass training for the Equivariant Transformer and TensorNet2 (Coulomb head included): gradient of
+    S = v . d(sum E)/d pos - sum_m ge_m E_m  in the parameters and the positions against autograd of that scalar in fp64."""
+    g = torch.load(os.path.join(golden_dir, fixture))
+    sd = {k: (t.double() if t.is_floating_point() else t) for k, t in g["state_dict"].items()}
+    z, pos, batch = g["z"], g["pos"].double(), g["batch"]
+    q = g["q"].double() if g.get("q") is not None else None
+    box = g["box"].double() if g.get("box") is not None else None
+    nmol = int(batch.max()) + 1
+    v = torch.randn(pos.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    ge = torch.randn(nmol, dtype=torch.float64, generator=torch.Generator().manual_seed(4))
+    et = fixture.startswith("et_")
+    if et:
+        from oracle import et_second_order as E2
+
+        hp = ET.hparams_from_args(g["args"])
+        keys = [k for k, t in sd.items() if t.is_floating_point() and t.dim() > 0 and "distance" not in k.split("neighbor_embedding.")[0]]
+        energy = lambda sdg, p: ET.energy(sdg, hp, z, p, batch)
+    else:
+        from oracle import tn2_second_order as N2
+        from oracle import tn2_torch as T2
+
+        hp = T2.hparams_from_args(g["args"])
+        keys = [k for k, t in sd.items() if t.is_floating_point() and t.dim() > 0 and "distance" not in k and "qweights" not in k and "prior" not in k]
+        energy = lambda sdg, p: T2.energy(sdg, hp, z, p, batch, box=box, q=q)
+    sdg = {k: (t.clone().requires_grad_(True) if k in keys else t) for k, t in sd.items()}
+    p = pos.clone().requires_grad_(True)
+    E = energy(sdg, p)
+    (gp,) = torch.autograd.grad(E.sum(), p, create_graph=True)
+    S = (gp * v).sum() - (ge * E.view(-1)).sum()
+    grads = torch.autograd.grad(S, [sdg[k] for k in keys] + [p], allow_unused=True)
+    if et:
+        out = E2.force_term(sd, hp, z, pos, batch, v, ge=ge)
+        mine = out["grads"]
+    else:
+        out = N2.force_term(sd, hp, z, pos, batch, v, box=box, q=q, ge=ge)
+        mine = N2.state_dict_grads(out, sd, hp)
+    assert abs(out["s"].item() - S.item()) < 1e-11 * max(1.0, abs(S.item()))
+    assert rel_err(out["Hv"], grads[-1]) < 1e-11
+    checked = 0
+    for k, r in zip(keys, grads[:-1]):
+        if r is None or r.abs().max() == 0:
+            continue
+        assert rel_err(mine[k].reshape(r.shape), r) < 1e-10, k
+        checked += 1
+    assert checked >= 30
