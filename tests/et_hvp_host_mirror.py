@@ -19,7 +19,7 @@ def thirds(w, F, hd):
     return w[src].contiguous(), src
 
 
-def force_term_mirror(sd, hp, z, pos, batch, v, box=None):
+def force_term_mirror(sd, hp, z, pos, batch, v, box=None, ge=None):
     R = "representation_model."
     sd = {k: (t.float() if t.is_floating_point() else t) for k, t in sd.items()}
     F, H, L, K = hp["hidden_channels"], hp["num_heads"], hp["num_layers"], hp["num_rbf"]
@@ -144,11 +144,15 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None):
     call("he_cat_norm_dual", N, F2, None, None, F2, w1, w1_t, F2, F2, F, hcat2, hcat2_t)
     pre2, pre2_t = gemm(hcat2, Wn1, bn1), gemm(hcat2_t, Wn1)
     g_pre2, g_pre2_t, headv = f32(N, F2), f32(N, F2), f32(N, F2)
-    call("hh_head_dual", C.c_int64(N * F2), F2, pre2, pre2_t, Wn2, std, g_pre2, g_pre2_t, headv)
+    b64 = batch.to(torch.int64).contiguous()
+    ge32 = None if ge is None else ge.float().contiguous()  # one-pass training: energy seed (tn_hvp_math.h head_dual)
+    call("hh_head_dual", C.c_int64(N * F2), F2, pre2, pre2_t, Wn2, std, ge32, b64, g_pre2, g_pre2_t, headv)
     s_val = (headv * Wn2).sum()
 
     # ---- reverse with tangents: head
     ent["Wn2"], ent["bn2"] = headv.sum(0), torch.zeros(1)
+    if ge is not None:
+        call("hh_head_bias_seed", N, std, ge32, b64, ent["bn2"])
     dense("Wn1", "bn1", g_pre2, g_pre2_t, hcat2, hcat2_t)
     g_h2, g_h2_t = gemmT(g_pre2, Wn1), gemmT(g_pre2_t, Wn1)  # (g_xs | g_n2)
     g_w1, g_w1_t = f32(N, 3, F2), f32(N, 3, F2)
@@ -282,5 +286,6 @@ def state_dict_grads(ent, sd, hp):
                 O0 + "update_net.layers.0.bias": ent["bm1"], O0 + "update_net.layers.2.weight": ent["Wm2"],
                 O0 + "update_net.layers.2.bias": ent["bm2"], O1 + "vec1_proj.weight": ent["W21"], O1 + "update_net.layers.0.weight": ent["Wn1"],
                 O1 + "update_net.layers.0.bias": ent["bn1"], O1 + "update_net.layers.2.weight": w2,
-                O1 + "update_net.layers.2.bias": torch.zeros_like(sd[O1 + "update_net.layers.2.bias"], dtype=torch.float32)})
+                O1 + "update_net.layers.2.bias": torch.cat([ent["bn2"].reshape(1),
+                                                             torch.zeros(sd[O1 + "update_net.layers.2.bias"].numel() - 1)])})
     return out

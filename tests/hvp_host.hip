@@ -60,9 +60,23 @@ void hh_feat_dual(int N, int F, const float* X, const float* X_t, float* feat, f
   for (int n = 0; n < N; ++n)
     for (int f = 0; f < F; ++f) feat_dual(n, f, F, X, X_t, feat, feat_t);
 }
-void hh_head_dual(int64_t n, int H, const float* ao, const float* ao_t, const float* O2, float std_, float* g_ao, float* g_ao_t,
-                  float* headv) {
-  for (int64_t i = 0; i < n; ++i) head_dual(i, H, ao, ao_t, O2, std_, g_ao, g_ao_t, headv);
+void hh_head_dual(int64_t n, int H, const float* ao, const float* ao_t, const float* O2, float std_, const float* ge, const int64_t* batch,
+                  float* g_ao, float* g_ao_t, float* headv) {
+  for (int64_t i = 0; i < n; ++i) head_dual(i, H, ao, ao_t, O2, std_, ge, batch, g_ao, g_ao_t, headv);
+}
+void hh_head_bias_seed(int N, float std_, const float* ge, const int64_t* batch, float* out) {  // k_head_bias_seed's order of summation
+  float part[256];
+  for (int t = 0; t < 256; ++t) {
+    float a = 0.f;
+    for (int n = t; n < N; n += 256) a += head_bias_seed_term(n, ge, batch);
+    part[t] = a;
+  }
+  float tot = 0.f;
+  for (int k = 0; k < 256; ++k) tot += part[k];
+  out[0] = -std_ * tot;
+}
+void hh_row_seed(int N, int W, const float* ge, const int64_t* batch, const float* x, float* x_t) {
+  for (int64_t i = 0; i < (int64_t)N * W; ++i) row_seed(i, W, ge, batch, x, x_t);
 }
 void hh_readout_bwd_dual(int N, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G, float* G_t) {
   for (int n = 0; n < N; ++n)

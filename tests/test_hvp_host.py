@@ -174,3 +174,61 @@ def test_tn2_kernel_bodies_in_planned_schedule_match_specification(golden_dir, f
         o = mine[k].reshape(r.shape)
         assert torch.isfinite(o).all(), k
         assert (o - r).abs().max().item() < tol * max(r.abs().max().item(), 1e-6), k
+
+
+@pytest.mark.parametrize("fixture", ["tiny_ref.pt", "et_tiny_ref.pt", "et_tiny_vc_ref.pt", "tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_kernel_bodies_with_energy_seed_match_specification(golden_dir, fixture):
+    """One-pass training: the bodies with the energy seed ge (head_dual's extra term, the head's last bias, the Coulomb head's
+    adjoints) in the engine's schedule, against the specifications' gradient of  S = s - sum_m ge_m E_m  in fp64: every parameter
+    and the position gradient."""
+    g = torch.load(os.path.join(golden_dir, fixture))
+    sd = g["state_dict"]
+    sd64 = {k: (t.double() if t.is_floating_point() else t) for k, t in sd.items()}
+    z, pos, batch = g["z"], g["pos"], g["batch"]
+    q = g["q"] if g.get("q") is not None else None
+    box = g["box"] if g.get("box") is not None else None
+    nmol = int(batch.max()) + 1
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(3))
+    ge = torch.randn(nmol, generator=torch.Generator().manual_seed(4))
+    d = lambda t: None if t is None else t.double()
+    if fixture.startswith("et_"):
+        from oracle import et_second_order as E2
+        from oracle import et_torch as ET
+        from tests import et_hvp_host_mirror as EM
+
+        hp = ET.hparams_from_args(g["args"])
+        ref = E2.force_term(sd64, hp, z, pos.double(), batch, v.double(), ge=ge.double())
+        out = EM.force_term_mirror(sd, hp, z, pos, batch, v, ge=ge)
+        refg, mine = ref["grads"], EM.state_dict_grads(out["ent"], sd, hp)
+    elif fixture.startswith("tn2_"):
+        from oracle import tn2_second_order as N2
+        from oracle import tn2_torch as T2
+        from tests import tn2_hvp_host_mirror as M2
+
+        hp = T2.hparams_from_args(g["args"])
+        ref = N2.force_term(sd64, hp, z, pos.double(), batch, v.double(), box=d(box), q=d(q), ge=ge.double())
+        out = M2.force_term_mirror(sd, hp, z, pos, batch, v, box=box, q=q, ge=ge)
+        refg = N2.state_dict_grads(ref, sd64, hp)
+        mine = N2.state_dict_grads(dict(ent={k: t.double() for k, t in out["ent"].items()}, extra={k: t.double() for k, t in out["extra"].items()}),
+                                   sd64, hp)
+    else:
+        from oracle import tensornet_second_order as S2
+        from oracle import tensornet_torch as T
+        from tests import hvp_host_mirror as HM
+
+        hp = T.hparams_from_args(g["args"])
+        ref = S2.force_term(sd64, hp, z, pos.double(), batch, v.double(), q=d(q), ge=ge.double())
+        out = HM.force_term_mirror(sd, hp, z, pos, batch, v, q=q, ge=ge)
+        refg = S2.state_dict_grads(ref["ent"], sd64, hp)
+        mine = S2.state_dict_grads({k: t.double() for k, t in out["ent"].items()}, sd64, hp)
+    tol = 5e-5
+    assert (out["Hv"].double() - ref["Hv"]).abs().max().item() < tol * ref["Hv"].abs().max().item()
+    checked = 0
+    for k, r in refg.items():
+        if r.abs().max() == 0:
+            continue
+        o = mine[k].double().reshape(r.shape)
+        assert torch.isfinite(o).all(), k
+        assert (o - r).abs().max().item() < tol * r.abs().max().item(), (k, (o - r).abs().max().item(), r.abs().max().item())
+        checked += 1
+    assert checked >= 30

@@ -13,7 +13,7 @@ from oracle import tensornet_second_order as S2
 from tests.hvp_host_mirror import call, f32
 
 
-def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
+def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None, ge=None):
     """-> TensorNet-style entries + the charge heads' gradients by state-dict key, in fp32, by the planned engine schedule."""
     R = "representation_model."
     T = R + "tensor_embedding."
@@ -216,7 +216,8 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     call("hh_silu_tangent", C.c_int64(N * F), al, al_t, x_t)
     ao, ao_t = gemm(x, O1, bO1), gemm(x_t, O1)
     g_ao, g_ao_t, headv = f32(N, H), f32(N, H), f32(N, H)
-    call("hh_head_dual", C.c_int64(N * H), H, ao, ao_t, O2, std, g_ao, g_ao_t, headv)
+    ge32 = None if ge is None else ge.float().contiguous()  # one-pass training: energy seed (tn_hvp_math.h head_dual)
+    call("hh_head_dual", C.c_int64(N * H), H, ao, ao_t, O2, std, ge32, batch, g_ao, g_ao_t, headv)
     qw = sd["output_model.qweights"].float().contiguous()
     cut = hp.get("coulomb_cutoff")
     from oracle.tn2_torch import COULOMB_FACTOR
@@ -227,10 +228,15 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
          float(cut) if cut is not None else -1.0, float(hp.get("coulomb_epsilon_solvent", 78.3)), float(COULOMB_FACTOR), e_c, e_c_t, g_q, g_q_t,
          gpos_c, hv_c)
     s_val = (headv * O2).sum() + std * e_c_t.sum()
+    if ge is not None:  # the Coulomb pairs lie inside a molecule: its adjoints take their atom's factor
+        call("hh_row_seed", N, QC, ge32, batch, g_q, g_q_t)
+        call("hh_row_seed", N, 3, ge32, batch, gpos_c, hv_c)
     g_charges, g_charges_t = (std * g_q).contiguous(), (std * g_q_t).contiguous()  # adjoints of all charge sets; the edge MLPs add theirs
 
     # ---- reverse pass with tangents
     ent["O2"], ent["bO2"] = headv.sum(0, keepdim=True), torch.zeros(1)
+    if ge is not None:
+        call("hh_head_bias_seed", N, std, ge32, batch, ent["bO2"])
     ent["O1"], ent["bO1"] = tn_gemm(g_ao_t, x) + tn_gemm(g_ao, x_t), g_ao_t.sum(0)
     g_x, g_x_t = gemmT(g_ao, O1), gemmT(g_ao_t, O1)
     g_al, g_al_t = f32(N, F), f32(N, F)

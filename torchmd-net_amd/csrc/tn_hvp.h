@@ -30,7 +30,12 @@ void launch_group_dual(int N, int F, const float* Pn, const float* Pn_t, const f
 void launch_update_dual(int N, int F, const float* Xh, const float* Xh_t, const float* D, const float* D_t, const float* kap, float* Xn,
                         float* Xn_t, hipStream_t s);
 void launch_feat_dual(int N, int F, const float* X, const float* X_t, float* feat, float* feat_t, hipStream_t s);
-void launch_head_dual(int N, int H, const float* ao, const float* ao_t, const float* O2, float std_, float* g_ao, float* g_ao_t,
+// ge != null: the energy seed of one-pass training (tn_hvp_math.h head_dual); launch_head_bias_seed: out[0] = - std sum_n ge[molecule(n)];
+// launch_row_seed: x_t[n, :] -= ge[molecule(n)] x[n, :]
+void launch_head_bias_seed(int N, float std_, const float* ge, const int64_t* batch, float* out, hipStream_t s);
+void launch_row_seed(int N, int W, const float* ge, const int64_t* batch, const float* x, float* x_t, hipStream_t s);
+void launch_head_dual(int N, int H, const float* ao, const float* ao_t, const float* O2, float std_, const float* ge, const int64_t* batch,
+                      float* g_ao, float* g_ao_t,
                       float* headv, hipStream_t s);
 void launch_readout_bwd_dual(int N, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G,
                              float* G_t, hipStream_t s);

@@ -89,9 +89,29 @@ __global__ __launch_bounds__(TB) void k_feat_dual(int N, int F, const float* __r
   feat_dual(n, f, F, X, X_t, feat, feat_t);
 }
 __global__ __launch_bounds__(TB) void k_head_dual(int64_t total, int H, const float* __restrict__ ao, const float* __restrict__ ao_t, const float* __restrict__ O2,
-                            float std_, float* __restrict__ g_ao, float* __restrict__ g_ao_t, float* __restrict__ headv) {
+                            float std_, const float* __restrict__ ge, const int64_t* __restrict__ batch, float* __restrict__ g_ao,
+                            float* __restrict__ g_ao_t, float* __restrict__ headv) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) head_dual(i, H, ao, ao_t, O2, std_, g_ao, g_ao_t, headv);
+  if (i < total) head_dual(i, H, ao, ao_t, O2, std_, ge, batch, g_ao, g_ao_t, headv);
+}
+// out[0] = - std sum_n ge[molecule(n)]: ONE block, each thread a strided partial sum, the 256 partials added in order by thread 0
+__global__ __launch_bounds__(TB) void k_head_bias_seed(int N, float std_, const float* __restrict__ ge, const int64_t* __restrict__ batch,
+                                                       float* __restrict__ out) {
+  __shared__ float part[TB];
+  float a = 0.f;
+  for (int n = threadIdx.x; n < N; n += TB) a += head_bias_seed_term(n, ge, batch);
+  part[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < TB; ++k) t += part[k];
+    out[0] = -std_ * t;
+  }
+}
+__global__ __launch_bounds__(TB) void k_row_seed(int64_t total, int W, const float* __restrict__ ge, const int64_t* __restrict__ batch,
+                                                 const float* __restrict__ x, float* __restrict__ x_t) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) row_seed(i, W, ge, batch, x, x_t);
 }
 __global__ __launch_bounds__(TB) void k_readout_bwd_dual(int N, int F, const float* __restrict__ X, const float* __restrict__ X_t,
                                    const float* __restrict__ g_feat, const float* __restrict__ g_feat_t, float* __restrict__ G,
@@ -275,9 +295,15 @@ void launch_update_dual(int N, int F, const float* Xh, const float* Xh_t, const 
 void launch_feat_dual(int N, int F, const float* X, const float* X_t, float* feat, float* feat_t, hipStream_t s) {
   LAUNCH(k_feat_dual, (int64_t)N * F, N, F, X, X_t, feat, feat_t);
 }
-void launch_head_dual(int N, int H, const float* ao, const float* ao_t, const float* O2, float std_, float* g_ao, float* g_ao_t,
-                      float* headv, hipStream_t s) {
-  LAUNCH(k_head_dual, (int64_t)N * H, (int64_t)N * H, H, ao, ao_t, O2, std_, g_ao, g_ao_t, headv);
+void launch_head_dual(int N, int H, const float* ao, const float* ao_t, const float* O2, float std_, const float* ge, const int64_t* batch,
+                      float* g_ao, float* g_ao_t, float* headv, hipStream_t s) {
+  LAUNCH(k_head_dual, (int64_t)N * H, (int64_t)N * H, H, ao, ao_t, O2, std_, ge, batch, g_ao, g_ao_t, headv);
+}
+void launch_head_bias_seed(int N, float std_, const float* ge, const int64_t* batch, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_head_bias_seed, dim3(1), dim3(TB), 0, s, N, std_, ge, batch, out);
+}
+void launch_row_seed(int N, int W, const float* ge, const int64_t* batch, const float* x, float* x_t, hipStream_t s) {
+  LAUNCH(k_row_seed, (int64_t)N * W, (int64_t)N * W, W, ge, batch, x, x_t);
 }
 void launch_readout_bwd_dual(int N, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G,
                              float* G_t, hipStream_t s) {

@@ -402,12 +402,21 @@ HVP_FN void feat_dual(int n, int f, int F, const float* X, const float* X_t, flo
 
 // ------------------------------------------------------------------------------------------------ head, reverse pass
 // seed: g_ao = std O2 silu'(ao); headv = std silu'(ao) ao_t is the summand of d s / d O2   (i over N * H)
-HVP_FN void head_dual(int64_t i, int H, const float* ao, const float* ao_t, const float* O2, float std_, float* g_ao, float* g_ao_t,
-                      float* headv) {
+// ge != null (one-pass training): everything downstream is the gradient of  S = s - sum_m ge_m E_m  - the tangent adjoint minus the
+// adjoint of sum_m ge_m E_m obeys the tangent adjoint's recursion, so only its seed changes: - ge[molecule] at every atom's energy
+HVP_FN void head_dual(int64_t i, int H, const float* ao, const float* ao_t, const float* O2, float std_, const float* ge,
+                      const int64_t* batch, float* g_ao, float* g_ao_t, float* headv) {
   const float o2 = std_ * O2[i % H], d1 = silu1(ao[i]);
+  const float w = ge ? ge[batch ? batch[i / H] : 0] : 0.f;
   g_ao[i] = o2 * d1;
-  g_ao_t[i] = o2 * silu2(ao[i]) * ao_t[i];
-  headv[i] = std_ * d1 * ao_t[i];
+  g_ao_t[i] = o2 * silu2(ao[i]) * ao_t[i] - w * o2 * d1;
+  headv[i] = std_ * d1 * ao_t[i] - w * std_ * silu0(ao[i]);
+}
+// d S / d (the head's last bias) = - std sum_n ge[molecule(n)]   (one logical thread; the kernel sums in blocks of 256)
+HVP_FN float head_bias_seed_term(int n, const float* ge, const int64_t* batch) { return ge[batch ? batch[n] : 0]; }
+// per atom row (width W): x_t -= ge[molecule] x  - the Coulomb head's adjoints under the energy seed (its pairs lie inside a molecule)
+HVP_FN void row_seed(int64_t i, int W, const float* ge, const int64_t* batch, const float* x, float* x_t) {
+  x_t[i] -= ge[batch ? batch[i / W] : 0] * x[i];
 }
 // G = dquad(X) g_feat[type]
 HVP_FN void readout_bwd_dual(int n, int f, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G,
