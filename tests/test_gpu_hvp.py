@@ -109,8 +109,11 @@ def test_analytic_force_term_gradients_match_specification(hip_lib, name, extra,
     assert not bad, bad
 
 
-def test_force_matching_backward_takes_the_analytic_pass(hip_lib):
-    """derivative=True + parameter_gradients=True with force_gradient_order = 0: loss(E, F).backward() fills the weights' .grad
+@pytest.mark.parametrize("one_pass", [True, False])
+def test_force_matching_backward_takes_the_analytic_pass(hip_lib, one_pass):
+    """one_pass = True (the default): ONE second-order pass seeded with d loss / d E (tmdnet_loss_param_grads) delivers the energy
+    term's gradient as well; False: first-order pass + second-order pass.  Same bound for both.
+    derivative=True + parameter_gradients=True with force_gradient_order = 0: loss(E, F).backward() fills the weights' .grad
     with the energy term's exact gradient plus the analytic force term, and pos.grad with - g_E F - H g_F, against the double
     backward of the oracle in fp64 at the first-order pass's bound (the difference-quotient orders stay at 1e-3 / 2e-3 and
     leave the position term out, test_gpu_train.py)."""
@@ -131,6 +134,7 @@ def test_force_matching_backward_takes_the_analytic_pass(hip_lib):
     model = create_model(dict(args)).to("cuda")
     model.parameter_gradients = True
     model.force_gradient_order = 0
+    model.one_pass_training = one_pass
     z, pos, batch = _ragged([22, 35, 9], seed=1300)
     R = torch.randn(pos.shape, generator=torch.Generator().manual_seed(3))
     ge = torch.tensor([0.7, -1.1, 0.4])
@@ -151,7 +155,7 @@ def test_force_matching_backward_takes_the_analytic_pass(hip_lib):
             errs[k] = (p.grad.cpu().double() - ref[k]).abs().max().item() / ref[k].abs().max().item()
     worst = max(errs, key=errs.get)
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/force_gradient_analytic.json", "w") as fh:
+    with open(f"gpurun_out/force_gradient_analytic_{'one' if one_pass else 'two'}_pass.json", "w") as fh:
         json.dump({"worst": [worst, errs[worst]], "position_gradient": pos_err, "errors": errs}, fh, indent=1)
     assert errs[worst] < REL, (worst, errs[worst])
     assert pos_err < REL, pos_err
@@ -298,6 +302,66 @@ def test_engine_second_order_pass_equals_the_reference_double_backward(hip_lib, 
     hv_err = (hv.cpu().double() - ref["Hv"]).abs().max().item() / ref["Hv"].abs().max().item()
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/hvp_vs_reference_{fixture[:-3]}.json", "w") as fh:
+        json.dump({"case": fixture, "hv_error": hv_err, "worst_param": max(errs.items(), key=lambda kv: kv[1]), "param_errors": errs}, fh, indent=1)
+    assert len(errs) >= 30
+    bad = {k: e for k, e in errs.items() if not e < REL}
+    assert not bad, bad
+    assert hv_err < REL, hv_err
+
+
+@pytest.mark.parametrize("fixture", ["tiny_ref.pt", "et_tiny_ref.pt", "et_tiny_vc_ref.pt", "tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_seeded_second_order_pass_matches_specification(hip_lib, golden_dir, fixture):
+    """tmdnet_loss_param_grads: with ge = d loss / d E the pass returns the gradient of  S = v . d(sum E)/d pos - sum_m ge_m E_m  in
+    every parameter and in the positions (one-pass training), against the specifications in fp64 (pinned to autograd of that scalar,
+    tests/test_oracle.py)."""
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, fixture))
+    model = create_model(dict(g["args"]))
+    model.load_state_dict(g["state_dict"])
+    model = model.to("cuda")
+    sd64 = {k: (t.double() if t.is_floating_point() else t) for k, t in g["state_dict"].items()}
+    z, pos, batch = g["z"], g["pos"], g["batch"]
+    q = g["q"] if g.get("q") is not None else None
+    box = g["box"] if g.get("box") is not None else None
+    n_mol = int(batch.max()) + 1
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(3))
+    ge = torch.randn(n_mol, generator=torch.Generator().manual_seed(4))
+    d = lambda t: None if t is None else t.double()
+    c = lambda t: None if t is None else t.cuda()
+    grads, hv = model.force_term_parameter_gradients(z.cuda(), pos.cuda(), batch.cuda(), c(box), c(q), n_mol, v.cuda(), want_hv=True, ge=ge.cuda())
+    torch.cuda.synchronize()
+    if fixture.startswith("et_"):
+        from oracle import et_second_order as E2
+        from oracle import et_torch as ET
+
+        ref = E2.force_term(sd64, ET.hparams_from_args(g["args"]), z, pos.double(), batch, v.double(), ge=ge.double())
+        refg = ref["grads"]
+    elif fixture.startswith("tn2_"):
+        from oracle import tn2_second_order as N2
+        from oracle import tn2_torch as T2
+
+        hp = T2.hparams_from_args(g["args"])
+        ref = N2.force_term(sd64, hp, z, pos.double(), batch, v.double(), box=d(box), q=d(q), ge=ge.double())
+        refg = N2.state_dict_grads(ref, sd64, hp)
+    else:
+        from oracle import tensornet_second_order as S2
+        from oracle import tensornet_torch as T
+
+        hp = T.hparams_from_args(g["args"])
+        ref = S2.force_term(sd64, hp, z, pos.double(), batch, v.double(), q=d(q), ge=ge.double())
+        refg = S2.state_dict_grads(ref["ent"], sd64, hp)
+    by_name = {id(p): k for k, p in model.named_parameters()}
+    mine = {by_name[id(p)]: t.cpu().double() for p, t in grads.items()}
+    errs = {}
+    for k, r in refg.items():
+        if r.abs().max() == 0:
+            continue
+        assert k in mine, k
+        errs[k] = (mine[k].reshape(r.shape) - r).abs().max().item() / r.abs().max().item()
+    hv_err = (hv.cpu().double() - ref["Hv"]).abs().max().item() / ref["Hv"].abs().max().item()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/hvp_seeded_{fixture[:-3]}.json", "w") as fh:
         json.dump({"case": fixture, "hv_error": hv_err, "worst_param": max(errs.items(), key=lambda kv: kv[1]), "param_errors": errs}, fh, indent=1)
     assert len(errs) >= 30
     bad = {k: e for k, e in errs.items() if not e < REL}

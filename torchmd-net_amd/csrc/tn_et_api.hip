@@ -815,9 +815,8 @@ int et_force_param_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64
 }
 
 int et_force_param_grads(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
-                         int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* v, float* grads, float* hv) {
+                         int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* v, const float* ge, float* grads, float* hv) {
   (void)n_mol;
-  (void)batch;
   const tmdnet_et_hparams& hp = m->et->hp;
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, F2 = F / 2, U = F + F2, H = hp.num_heads, hd = F / H;
   const int Wd = wd_of(hp), N = (int)n_atoms, P = (int)n_pairs, P1 = P + 1;
@@ -912,10 +911,11 @@ int et_force_param_grads(tmdnet_model* m, hipStream_t s, const Graph& g, void* w
   hvp::launch_et_cat_norm_dual(N, F2, nullptr, nullptr, F2, b.w1, b.w1_t, F2, F2, F, b.hcat2, b.hcat2_t, s);
   gemm(s, b.hcat2, F, W.Wn1, F, W.bn1, b.pre2, F2, N, F2, F);
   gemm(s, b.hcat2_t, F, W.Wn1, F, nullptr, b.pre2_t, F2, N, F2, F);
-  hvp::launch_head_dual(N, F2, b.pre2, b.pre2_t, W.Wn2, W.std, b.g_pre2, b.g_pre2_t, b.headv, s);
+  hvp::launch_head_dual(N, F2, b.pre2, b.pre2_t, W.Wn2, W.std, ge, batch, b.g_pre2, b.g_pre2_t, b.headv, s);
 
   // ---- reverse with tangents: head
   launch_colsum(s, b.headv, RP(F2), nullptr, RP(F2), nullptr, nullptr, N, F2, at("Wn2"), false, b.part);  // d s / d bn2 = 0
+  if (ge) hvp::launch_head_bias_seed(N, W.std, ge, batch, at("bn2"), s);  // energy seed: d S / d bn2 = - std sum_n ge[molecule(n)]
   dense("Wn1", "bn1", b.g_pre2, b.g_pre2_t, F2, b.hcat2, b.hcat2_t, F, N, F2, F);
   gemm(s, b.g_pre2, F2, W.Wn1T, F2, nullptr, b.g_h2, F, N, F, F2);
   gemm(s, b.g_pre2_t, F2, W.Wn1T, F2, nullptr, b.g_h2_t, F, N, F, F2);

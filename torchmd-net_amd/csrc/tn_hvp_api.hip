@@ -230,7 +230,17 @@ int tmdnet_force_param_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t
 
 int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
                              int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q, const float* v, float* grads, float* hv) {
+  return tmdnet_loss_param_grads(m, stream, graph_ws, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, q, v, nullptr, grads, hv);
+}
+
+// ge == null: gradient of s = v . d(sum E)/d pos.  ge [n_mol] = d loss / d E: gradient of S = s - sum_m ge_m E_m, i.e. minus the whole
+// gradient of loss(E, F) in ONE pass: the tangent adjoint minus the adjoint of sum_m ge_m E_m obeys the tangent adjoint's recursion,
+// so only its seed at the head changes (head_dual; the head's last bias; the Coulomb head's adjoints for TensorNet2).
+int tmdnet_loss_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
+                            int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q, const float* v, const float* ge,
+                            float* grads, float* hv) {
   if (!m || !graph_ws || !ws || !v || !grads) return TMDNET_ERR_INVALID;
+  if (ge && n_mol > 1 && !batch) return fail(m, TMDNET_ERR_INVALID, "an energy seed for several molecules needs batch");
   if (!m->finalized) return fail(m, TMDNET_ERR_STATE, "parameters not finalised");
   if (n_pairs < 0) return fail(m, TMDNET_ERR_INVALID, "the second-order pass needs the exact pair count (dynamic shapes)");
   recall_graph(m, graph_ws);
@@ -239,12 +249,12 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (m->et) {
     if (q) return fail(m, TMDNET_ERR_INVALID, "the Equivariant Transformer takes no total charge (reference torchmd_et.py:188-196)");
-    Graph ge = carve_graph(graph_ws, n_atoms, n_mol, (int64_t)m->hp.max_num_neighbors * n_atoms, nullptr);
-    if (n_pairs > ge.pcap) return fail(m, TMDNET_ERR_INVALID, "n_pairs out of range");
-    if (m->graph_has_z) z = ge.z_c;
+    Graph ge_ = carve_graph(graph_ws, n_atoms, n_mol, (int64_t)m->hp.max_num_neighbors * n_atoms, nullptr);
+    if (n_pairs > ge_.pcap) return fail(m, TMDNET_ERR_INVALID, "n_pairs out of range");
+    if (m->graph_has_z) z = ge_.z_c;
     if (!z) return fail(m, TMDNET_ERR_INVALID, "z is required (here or in tmdnet_build_graph)");
     CurScope cur_e(m);
-    return et_force_param_grads(m, s, ge, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, v, grads, hv);
+    return et_force_param_grads(m, s, ge_, ws, ws_bytes, n_atoms, n_mol, n_pairs, z, batch, v, ge, grads, hv);
   }
   const tmdnet_hparams& hp = m->hp;
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, H = hp.head_hidden, o3 = hp.group_o3;
@@ -430,10 +440,11 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
   hvp::launch_silu_tangent((int64_t)N * F, b.al, b.al_t, b.x_t, s);
   gemm(s, b.x, F, W.O1, F, W.bO1, b.ao, H, N, H, F);
   gemm(s, b.x_t, F, W.O1, F, nullptr, b.ao_t, H, N, H, F);
-  hvp::launch_head_dual(N, H, b.ao, b.ao_t, W.O2, W.std, b.g_ao, b.g_ao_t, b.headv, s);
+  hvp::launch_head_dual(N, H, b.ao, b.ao_t, W.O2, W.std, ge, batch, b.g_ao, b.g_ao_t, b.headv, s);
 
   // ================= reverse sweep with tangents: head and readout
   launch_colsum(s, b.headv, rH, nullptr, rH, nullptr, nullptr, N, H, at("O2"), false, b.part);  // d s / d bO2 = 0 (filled above)
+  if (ge) hvp::launch_head_bias_seed(N, W.std, ge, batch, at("bO2"), s);                         // d S / d bO2 = - std sum_n ge[molecule(n)]
   dense_grad(b.g_ao, b.g_ao_t, rH, b.x, b.x_t, rF, N, H, F, "O1", "bO1");
   gemm(s, b.g_ao, H, W.O1T, H, nullptr, b.g_x, F, N, F, H);
   gemm(s, b.g_ao_t, H, W.O1T, H, nullptr, b.g_x_t, F, N, F, H);
@@ -448,6 +459,10 @@ int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void
     hvp::launch_coulomb_atom_dual(g, N, QC, batch, m->g_pos, v, m->g_box_mode ? m->g_box : nullptr, m->g_box_mode == 2 ? 1 : 0, t2.charges, t2.charges_t, T2->qweights,
                                   t2.wsum, T2->hp.coulomb_cutoff, T2->hp.coulomb_epsilon_solvent, 0.5f * 27.211386024367243f * 0.5291772105638411f,
                                   t2.e_c, t2.e_c_t, t2.g_q, t2.g_q_t, t2.gpos_c, t2.hv_c, s);
+    if (ge) {  // the Coulomb pairs lie inside a molecule: its adjoints take their atom's factor
+      hvp::launch_row_seed(N, QC, ge, batch, t2.g_q, t2.g_q_t, s);
+      hvp::launch_row_seed(N, 3, ge, batch, t2.gpos_c, t2.hv_c, s);
+    }
     hvp::launch_scale1((int64_t)N * QC, W.std, t2.g_q, t2.g_charges, s);
     hvp::launch_scale1((int64_t)N * QC, W.std, t2.g_q_t, t2.g_charges_t, s);
     charge_head_bwd(L, b.X[L], b.X_t[L], b.G, b.G_t);
