@@ -21,7 +21,8 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(ROOT, "oracle", "_build", "libhvp_host.so")
-        src = [os.path.join(ROOT, "tests", "hvp_host.hip"), os.path.join(ROOT, "torchmd-net_amd", "csrc", "tn_hvp_math.h")]
+        src = [os.path.join(ROOT, "tests", "hvp_host.hip")] + [os.path.join(ROOT, "torchmd-net_amd", "csrc", h) for h in
+                                                               ("tn_hvp_math.h", "tn_et_hvp_math.h", "tn_tn2_hvp_math.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
             os.makedirs(os.path.dirname(so), exist_ok=True)
             subprocess.check_call(["hipcc", "-x", "hip", "--cuda-host-only", "-O1", "-fPIC", "-shared", src[0], "-o", so])

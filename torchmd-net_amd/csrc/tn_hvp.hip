@@ -16,6 +16,9 @@ namespace hvp {
 namespace {
 constexpr int TB = 256;
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); }
+struct RedWave {  // the row's lanes = one wave (all 64 active: the row index is wave-uniform)
+  __device__ float operator()(float v) const { return wave_sum(v); }
+};
 #define NF_INDEX                                                           \
   const int64_t idx_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     \
   if (idx_ >= (int64_t)N * F) return;                                      \
@@ -38,14 +41,14 @@ __global__ __launch_bounds__(TB) void k_embed_scatter_dual(Graph g, int N, int F
 __global__ __launch_bounds__(TB) void k_ln_dual(int R, int W, const float* __restrict__ x, const float* __restrict__ x_t, const float* __restrict__ w,
                           const float* __restrict__ b, float* __restrict__ y, float* __restrict__ xh, float* __restrict__ rstd,
                           float* __restrict__ y_t, float* __restrict__ xh_t, float* __restrict__ rstd_t) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < R) ln_dual(r, W, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
+  const int r = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);  // a wave per row
+  if (r < R) ln_dual_lanes(r, W, (int)(threadIdx.x & 63), 64, RedWave{}, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
 }
 __global__ __launch_bounds__(TB) void k_lnbwd_dual(int R, int W, const float* __restrict__ g, const float* __restrict__ g_t, const float* __restrict__ xh,
                              const float* __restrict__ xh_t, const float* __restrict__ rstd, const float* __restrict__ rstd_t,
                              const float* __restrict__ w, float* __restrict__ o, float* __restrict__ o_t) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < R) lnbwd_dual(r, W, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
+  const int r = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);  // a wave per row
+  if (r < R) lnbwd_dual_lanes(r, W, (int)(threadIdx.x & 63), 64, RedWave{}, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
 }
 __global__ __launch_bounds__(TB) void k_silu_tangent(int64_t n, const float* __restrict__ a, const float* __restrict__ a_t, float* __restrict__ h_t) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,11 +266,11 @@ void launch_embed_scatter_dual(const Graph& g, int N, int F, int P, const int64_
 }
 void launch_ln_dual(int R, int W, const float* x, const float* x_t, const float* w, const float* b, float* y, float* xh, float* rstd,
                     float* y_t, float* xh_t, float* rstd_t, hipStream_t s) {
-  LAUNCH(k_ln_dual, (int64_t)R, R, W, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
+  LAUNCH(k_ln_dual, (int64_t)R * 64, R, W, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
 }
 void launch_lnbwd_dual(int R, int W, const float* g, const float* g_t, const float* xh, const float* xh_t, const float* rstd,
                        const float* rstd_t, const float* w, float* o, float* o_t, hipStream_t s) {
-  LAUNCH(k_lnbwd_dual, (int64_t)R, R, W, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
+  LAUNCH(k_lnbwd_dual, (int64_t)R * 64, R, W, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
 }
 void launch_silu_tangent(int64_t n, const float* a, const float* a_t, float* h_t, hipStream_t s) { LAUNCH(k_silu_tangent, n, n, a, a_t, h_t); }
 void launch_dsilu_dual(int64_t n, const float* g, const float* g_t, const float* a, const float* a_t, float* o, float* o_t, hipStream_t s) {
