@@ -232,3 +232,59 @@ def test_kernel_bodies_with_energy_seed_match_specification(golden_dir, fixture)
         assert (o - r).abs().max().item() < tol * r.abs().max().item(), (k, (o - r).abs().max().item(), r.abs().max().item())
         checked += 1
     assert checked >= 30
+@pytest.mark.parametrize("fixture", ["tiny_ref.pt", "et_tiny_ref.pt", "et_tiny_vc_ref.pt", "tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_entry_to_parameter_mapping_against_the_reference_double_backward(golden_dir, fixture):
+    """The product's mapping of engine gradient entries to parameters (models/model.py _tensornet_grads / _et_grads) fed with the
+    host run of the kernel bodies (same entry names as the engine's layout), against the UNMODIFIED reference's own second autograd
+    pass (tests/golden/second_order_ref.pt): every parameter the reference has a non-zero gradient for must come out, at fp32
+    accuracy - what tests/test_gpu_hvp.py::test_engine_second_order_pass_equals_the_reference_double_backward checks with the
+    engine's numbers on the GPU."""
+    from torchmdnet_amd.models.model import create_model
+
+    ref = torch.load(os.path.join(golden_dir, "second_order_ref.pt"))[fixture]
+    g = torch.load(os.path.join(golden_dir, fixture))
+    model = create_model(dict(g["args"]))
+    model.load_state_dict(g["state_dict"])
+    z, pos, batch, v = g["z"], g["pos"], g["batch"], ref["v"].float()
+    if fixture.startswith("et_"):
+        from oracle import et_torch as ET
+        from tests import et_hvp_host_mirror as EM
+
+        out = EM.force_term_mirror(g["state_dict"], ET.hparams_from_args(g["args"]), z, pos, batch, v)
+        grads = model._et_grads({k: t.reshape(-1) for k, t in out["ent"].items()})
+    elif fixture.startswith("tn2_"):
+        from oracle import tn2_torch as T2
+        from tests import tn2_hvp_host_mirror as M2
+
+        out = M2.force_term_mirror(g["state_dict"], T2.hparams_from_args(g["args"]), z, pos, batch, v, box=g.get("box"), q=g.get("q"))
+        ent = {k: t.reshape(-1) for k, t in out["ent"].items()}
+        R_ = "representation_model."
+        F_, K_, qd_ = g["args"]["embedding_dimension"], g["args"]["num_rbf"], g["args"]["q_dim"]
+        for l in range(g["args"]["num_layers"]):  # the engine's layout: the first edge layer as its three column blocks
+            m0 = out["ent"][f"l{l}.M0"].reshape(F_, K_ + 2 * qd_)
+            ent[f"l{l}.M0"], ent[f"l{l}.M0b"], ent[f"l{l}.M0c"] = (m0[:, :K_].reshape(-1), m0[:, K_:K_ + qd_].reshape(-1),
+                                                                   m0[:, K_ + qd_:].reshape(-1))
+        heads = [R_ + "charge_predict_0."] + [R_ + f"charge_predicts.{l}." for l in range(g["args"]["num_layers"])]
+        for h, pre in enumerate(heads):  # the charge heads' entries by the engine's names
+            for key, sk in (("ln_w", "q_norm.weight"), ("ln_b", "q_norm.bias"), ("W1", "q_mlp.layers.0.weight"), ("b1", "q_mlp.layers.0.bias"),
+                            ("W2", "q_mlp.layers.2.weight"), ("b2", "q_mlp.layers.2.bias"), ("W3", "q_mlp.layers.4.weight"),
+                            ("b3", "q_mlp.layers.4.bias")):
+                ent[f"cp{h}.{key}"] = out["extra"][pre + sk].reshape(-1)
+        grads = model._tn2_grads(ent)
+    else:
+        from oracle import tensornet_torch as T
+        from tests import hvp_host_mirror as HM
+
+        out = HM.force_term_mirror(g["state_dict"], T.hparams_from_args(g["args"]), z, pos, batch, v, q=g["q"])
+        grads = model._tensornet_grads({k: t.reshape(-1) for k, t in out["ent"].items()})
+    by_name = {id(p): k for k, p in model.named_parameters()}
+    mine = {by_name[id(p)]: t.double() for p, t in grads.items()}
+    tol, checked = 5e-5, 0
+    for k, r in ref["grads"].items():
+        if r.abs().max() == 0:
+            continue
+        assert k in mine, k
+        assert (mine[k].reshape(r.shape) - r).abs().max().item() < tol * r.abs().max().item(), k
+        checked += 1
+    assert checked >= 30
+    assert (out["Hv"].double() - ref["Hv"]).abs().max().item() < tol * ref["Hv"].abs().max().item()
