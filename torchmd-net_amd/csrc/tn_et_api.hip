@@ -817,6 +817,7 @@ int et_force_param_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64
 int et_force_param_grads(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
                          int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* v, const float* ge, float* grads, float* hv) {
   (void)n_mol;
+  if (m->et->hp.hidden_channels > 512) return fail(m, TMDNET_ERR_INVALID, "second-order pass: hidden_channels <= 512 (a block per atom, a thread per channel)");
   const tmdnet_et_hparams& hp = m->et->hp;
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, F2 = F / 2, U = F + F2, H = hp.num_heads, hd = F / H;
   const int Wd = wd_of(hp), N = (int)n_atoms, P = (int)n_pairs, P1 = P + 1;
