@@ -244,7 +244,31 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, ge=None):
     g_pos, Hv = f32(N, 3), f32(N, 3)
     call("hh_pair_to_atom", N, P, rowptr, epair, esign, gdel, g_pos)
     call("hh_pair_to_atom", N, P, rowptr, epair, esign, gdel_t, Hv)
-    return dict(ent=ent, s=s_val, Hv=Hv, F=-g_pos)
+    # the engine's intermediates by the names tmdnet_hvp_debug_tensor knows (csrc/tn_et_api.hip et_hvp_debug_tensor), in schedule order;
+    # the reverse sweep's scratch holds its last layer (l = 0)
+    bufs, order = {}, []
+
+    def put(name, t):
+        bufs[name] = t
+        order.append(name)
+
+    for l in range(L + 1):
+        put(f"x{l}", X[l]); put(f"x_t{l}", X_t[l]); put(f"vec{l}", V[l]); put(f"vec_t{l}", V_t[l])
+        if l < L:
+            c = lay[l]
+            put(f"l{l}.qkv", c["attn"][0]); put(f"l{l}.qkv_t", c["attn"][1])
+            if c["Wd"] > 0:
+                put(f"l{l}.dkv", c["attn"][4]); put(f"l{l}.dkv_t", c["attn"][5])
+            put(f"l{l}.xagg", c["xagg"]); put(f"l{l}.xagg_t", c["xagg_t"]); put(f"l{l}.o_t", c["o_t"]); put(f"l{l}.vdot_t", c["vdot_t"])
+    for nm, t in (("pre2", pre2), ("pre2_t", pre2_t), ("g_pre2_t", g_pre2_t), ("headv", headv), ("g_qkv", g_qkv), ("g_qkv_t", g_qkv_t),
+                  ("g_vin", g_vin), ("g_vin_t", g_vin_t), ("gq", gq), ("gq_t", gq_t), ("selfq", selfq), ("selfq_t", selfq_t), ("slots", slots),
+                  ("slots_t", slots_t), ("g_x", g_x), ("g_x_t", g_x_t), ("g_cut", g_cut), ("g_cut_t", g_cut_t), ("g_rh", g_rh), ("g_rh_t", g_rh_t),
+                  ("gdel", gdel), ("gdel_t", gdel_t)):
+        put(nm, t)
+    # rows the kernels never write (nor read): the self pair's row of every per-pair block
+    never = {"gq": (2, P1), "gq_t": (2, P1), "slots": (2 * L, P1), "slots_t": (2 * L, P1), "g_cut": (1, P1), "g_cut_t": (1, P1), "g_rh": (1, P1),
+             "g_rh_t": (1, P1)}
+    return dict(ent=ent, s=s_val, Hv=Hv, F=-g_pos, bufs=bufs, order=order, never=never, P=P)
 
 
 def state_dict_grads(ent, sd, hp):

@@ -192,9 +192,38 @@ def test_et_analytic_force_term_gradients_match_specification(hip_lib, golden_di
             continue
         errs[key] = (gr.cpu().double() - r.reshape(gr.shape)).abs().max().item() / r.abs().max().item()
     hv_err = (hv.cpu().double() - ref["Hv"]).abs().max().item() / ref["Hv"].abs().max().item()
+    # the engine's intermediates against the host run of the same bodies, in schedule order (et_hvp_debug_tensor)
+    from tests import et_hvp_host_mirror as EM
+    from torchmdnet_amd import _C
+
+    mir = EM.force_term_mirror(g["state_dict"], hp, z, pos, batch, v)
+    L_, st = _C.lib(), model._engine
+    rows = []
+    for name in mir["order"]:
+        r_ = mir["bufs"][name]
+        n = L_.tmdnet_hvp_debug_tensor(st.handle, None, name.encode(), None, 0)
+        if name in ("gdel", "gdel_t") and n != r_.numel():
+            continue
+        if n != r_.numel():
+            rows.append((name, f"size {n} != {r_.numel()}"))
+            continue
+        out = torch.empty(r_.numel(), dtype=torch.float32, device="cuda")
+        assert L_.tmdnet_hvp_debug_tensor(st.handle, None, name.encode(), C.c_void_p(out.data_ptr()), out.numel()) == 0
+        torch.cuda.synchronize()
+        o, r = out.cpu(), r_.reshape(-1).clone()
+        if name in mir["never"]:  # the self pair's row of every per-pair block is never written (nor read)
+            nb, P1_ = mir["never"][name]
+            keep = torch.ones(nb, P1_, r.numel() // (nb * P1_), dtype=torch.bool)
+            keep[:, P1_ - 1] = False
+            o, r = o[keep.reshape(-1)], r[keep.reshape(-1)]
+        err = (o - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        rows.append((name, err if torch.isfinite(o).all() else float("inf")))
+    first_bad = next(((n, e) for n, e in rows if not (isinstance(e, float) and e < 1e-3)), None)
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/hvp_{fixture[:-3]}.json", "w") as fh:
-        json.dump({"case": fixture, "hv_error": hv_err, "worst_param": max(errs.items(), key=lambda kv: kv[1]), "param_errors": errs}, fh, indent=1)
+        json.dump({"case": fixture, "hv_error": hv_err, "worst_param": max(errs.items(), key=lambda kv: kv[1]), "param_errors": errs,
+                   "first_bad_buffer": first_bad, "buffers": rows}, fh, indent=1)
+    assert first_bad is None, first_bad
     assert len(errs) >= 30
     bad = {k: e for k, e in errs.items() if not e < REL}
     assert not bad, bad

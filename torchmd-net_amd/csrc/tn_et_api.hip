@@ -764,6 +764,11 @@ struct EtHvpBuffers {
       *part;
 };
 
+// last call's buffers (developer / test hook tmdnet_hvp_debug_tensor)
+thread_local EtHvpBuffers g_et_last;
+thread_local int64_t g_et_lastN = -1, g_et_lastP = 0;
+thread_local const tmdnet_model* g_et_last_model = nullptr;
+
 EtHvpBuffers et_carve_hvp(void* ws, const tmdnet_et_hparams& hp, int64_t N, int64_t P, size_t* total) {
   const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, F2 = F / 2, U = F + F2, H = hp.num_heads, P1 = P + 1;
   const int64_t Wd = std::max<int64_t>(wd_of(hp), 1), NF = N * F;
@@ -1011,5 +1016,53 @@ int et_force_param_grads(tmdnet_model* m, hipStream_t s, const Graph& g, void* w
     hvp::launch_pair_to_atom(g, N, P, b.gdel_t, hv, s);
   }
   HIP_TRY(m, hipGetLastError());
+  g_et_last = b;
+  g_et_lastN = N;
+  g_et_lastP = P;
+  g_et_last_model = m;
+  return TMDNET_OK;
+}
+
+// intermediates of the last et_force_param_grads call by name (tests/test_gpu_hvp.py walks them against tests/et_hvp_host_mirror.py):
+// "x{l}" "x_t{l}" "vec{l}" "vec_t{l}" (l = 0 .. L), "l{l}.qkv" ".qkv_t" ".dkv" ".dkv_t" ".xagg" ".xagg_t" ".o_t" ".vdot_t", the head's
+// "pre2" "pre2_t" "g_pre2_t" "headv", the reverse sweep's scratch as its LAST layer (l = 0) left it: "g_qkv" "g_qkv_t" "g_vin" "g_vin_t"
+// "gq" "gq_t" "selfq" "selfq_t", and "slots" "slots_t" [L][2][P + 1][H][4], "g_x" "g_x_t" (at the embedding), "g_cut" "g_rh" "gdel" (+ "_t")
+int et_hvp_debug_tensor(tmdnet_model* m, hipStream_t s, const char* name, float* out, int64_t numel) {
+  if (g_et_last_model != m || g_et_lastN < 0) return fail(m, TMDNET_ERR_STATE, "no second-order pass has run on this handle (this thread)");
+  const tmdnet_et_hparams& hp = m->et->hp;
+  const int64_t F = hp.hidden_channels, L = hp.num_layers, H = hp.num_heads, N = g_et_lastN, P = g_et_lastP, P1 = P + 1, NF = N * F, F2 = F / 2;
+  const int64_t Wd = std::max<int64_t>(wd_of(hp), 1);
+  const EtHvpBuffers& b = g_et_last;
+  std::map<std::string, std::pair<const float*, int64_t>> t;
+  for (int l = 0; l <= L; ++l) {
+    const std::string k = std::to_string(l);
+    t["x" + k] = {b.x[l], NF};
+    t["x_t" + k] = {b.x_t[l], NF};
+    t["vec" + k] = {b.vec[l], 3 * NF};
+    t["vec_t" + k] = {b.vec_t[l], 3 * NF};
+  }
+  for (int l = 0; l < L; ++l) {
+    const EtHvpLayer& y = b.lay[l];
+    const std::string q = "l" + std::to_string(l) + ".";
+    t[q + "qkv"] = {y.qkv, 5 * NF};
+    t[q + "qkv_t"] = {y.qkv_t, 5 * NF};
+    t[q + "dkv"] = {y.dkv, P1 * Wd};
+    t[q + "dkv_t"] = {y.dkv_t, P1 * Wd};
+    t[q + "xagg"] = {y.xagg, NF};
+    t[q + "xagg_t"] = {y.xagg_t, NF};
+    t[q + "o_t"] = {y.o_t, 3 * NF};
+    t[q + "vdot_t"] = {y.vdot_t, NF};
+  }
+#define T_(field, n) t[#field] = {b.field, (n)}
+  T_(pre2, N * F2); T_(pre2_t, N * F2); T_(g_pre2_t, N * F2); T_(headv, N * F2); T_(g_qkv, 5 * NF); T_(g_qkv_t, 5 * NF); T_(g_vin, 3 * NF);
+  T_(g_vin_t, 3 * NF); T_(gq, 2 * P1 * Wd); T_(gq_t, 2 * P1 * Wd); T_(selfq, N * Wd); T_(selfq_t, N * Wd); T_(slots, L * 2 * P1 * H * 4);
+  T_(slots_t, L * 2 * P1 * H * 4); T_(g_x, NF); T_(g_x_t, NF); T_(g_cut, P1); T_(g_cut_t, P1); T_(g_rh, P1 * 3); T_(g_rh_t, P1 * 3);
+  T_(gdel, P * 3); T_(gdel_t, P * 3);
+#undef T_
+  auto it = t.find(name);
+  if (it == t.end()) return fail(m, TMDNET_ERR_INVALID, std::string("unknown second-order tensor: ") + name);
+  if (!out) return (int)it->second.second;
+  if (numel != it->second.second) return fail(m, TMDNET_ERR_INVALID, "second-order tensor: size mismatch");
+  HIP_TRY(m, hipMemcpyAsync(out, it->second.first, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s));
   return TMDNET_OK;
 }

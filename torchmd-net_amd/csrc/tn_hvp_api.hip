@@ -141,6 +141,7 @@ thread_local const tmdnet_model* g_last_model = nullptr;
 
 int tmdnet_hvp_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* out, int64_t numel) {
   if (!m || !name) return TMDNET_ERR_INVALID;
+  if (m->et) return et_hvp_debug_tensor(m, reinterpret_cast<hipStream_t>(stream), name, out, numel);
   if (g_last_model != m || g_lastN < 0) return fail(m, TMDNET_ERR_STATE, "no second-order pass has run on this handle (this thread)");
   const tmdnet_hparams& hp = m->hp;
   const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, H = hp.head_hidden, N = g_lastN, P1 = g_lastP + 1;
