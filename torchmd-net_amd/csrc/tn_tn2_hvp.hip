@@ -3,6 +3,7 @@
 // run on the host in tests/tn2_hvp_host_mirror.py.  Training path, exact and simple, not tuned.
 #include "tn_hvp.h"
 
+#include "tn_common.h"
 #include "tn_tn2_hvp_math.h"
 
 namespace tn {
@@ -103,8 +104,25 @@ __global__ __launch_bounds__(TB) void k_tn2_pair_reduce_dual(int64_t total, int 
 __global__ __launch_bounds__(TB) void k_edge_rowdot(Graph g, int E, int W, int ldx, const float* __restrict__ x, const float* __restrict__ x_t,
                                                     const float* __restrict__ y, const float* __restrict__ y2, const float* __restrict__ d_t,
                                                     int accumulate, float* __restrict__ val, float* __restrict__ val_t) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < E) edge_rowdot(e, W, ldx, g.epair, x, x_t, y, y2, d_t, accumulate, val, val_t);
+  // a wave per directed edge (edge_rowdot's sums, lanes strided over the row, as k_pair_rowdot in tn_hvp.hip)
+  const int e = blockIdx.x * (TB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= E) return;  // wave-uniform
+  const int p = g.epair[e];
+  float s0 = 0.f, st = 0.f, s2 = 0.f;
+  for (int j = lane; j < W; j += 64) {
+    const float yy = y ? y[(int64_t)p * W + j] : 1.0f;
+    s0 += x[(int64_t)e * ldx + j] * yy;
+    st += x_t[(int64_t)e * ldx + j] * yy;
+    if (y2) s2 += x[(int64_t)e * ldx + j] * y2[(int64_t)p * W + j];
+  }
+  s0 = wave_sum(s0);
+  st = wave_sum(st);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    if (y2) st += s2 * d_t[p];
+    val[e] = (accumulate ? val[e] : 0.f) + s0;
+    val_t[e] = (accumulate ? val_t[e] : 0.f) + st;
+  }
 }
 __global__ __launch_bounds__(TB) void k_pair_from_edges(int P, const int* __restrict__ pair_edge, const int* __restrict__ erev,
                                                         const float* __restrict__ val, const float* __restrict__ val_t, float* __restrict__ out,
@@ -194,7 +212,7 @@ void launch_tn2_edge_reduce_dual(const Graph& g, int N, int P, int F, const int*
 }
 void launch_edge_rowdot(const Graph& g, int E, int W, int ldx, const float* x, const float* x_t, const float* y, const float* y2,
                         const float* d_t, bool accumulate, float* val, float* val_t, hipStream_t s) {
-  LAUNCH(k_edge_rowdot, (int64_t)E, g, E, W, ldx, x, x_t, y, y2, d_t, accumulate ? 1 : 0, val, val_t);
+  LAUNCH(k_edge_rowdot, (int64_t)E * 64, g, E, W, ldx, x, x_t, y, y2, d_t, accumulate ? 1 : 0, val, val_t);  // a wave per edge
 }
 void launch_pair_from_edges(int P, const int* pair_edge, const int* erev, const float* val, const float* val_t, float* out, float* out_t,
                             hipStream_t s) {
