@@ -288,3 +288,55 @@ def test_entry_to_parameter_mapping_against_the_reference_double_backward(golden
         checked += 1
     assert checked >= 30
     assert (out["Hv"].double() - ref["Hv"]).abs().max().item() < tol * ref["Hv"].abs().max().item()
+
+
+@pytest.mark.parametrize("name,extra,sizes,charges", [
+    ("so3-one-layer-no-total-charge", dict(equivariance_invariance_group="SO(3)", num_layers=1, q_weights=[1.0, 0.5]), [9, 14], False),
+    ("three-layers-small-q", dict(num_layers=3, q_dim=4, q_weights=[1.0, 0.5, 2.0, 1.5]), [7, 12, 1, 5], True),
+    ("reaction-field-no-box", dict(coulomb_cutoff=4.0), [11, 8], True),
+])
+def test_tn2_kernel_bodies_on_other_configurations(name, extra, sizes, charges):
+    """TensorNet2 branches the two fixtures do not reach: SO(3), one and three layers (q_weights per charge set), no total charge,
+    a single-atom molecule, the reaction-field Coulomb term without a box; random-init models, specification vs host run of the bodies."""
+    from oracle import tn2_second_order as N2
+    from oracle import tn2_torch as T2
+    from tests import tn2_hvp_host_mirror as M2
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.TINY_ARGS, model="tensornet2", output_model="ScalarPlusWeightedCoulomb", q_dim=8, q_weights=[1.0, 0.5, 2.0], derivative=True)
+    args.update(extra)
+    torch.manual_seed(29)
+    model = create_model(dict(args))
+    with torch.no_grad():  # default init leaves the charge channels tiny: give every block weight
+        for k, p in model.named_parameters():
+            if "charge_predict" in k and p.dim() > 1:
+                p.mul_(3.0)
+    zs, ps, bs = [], [], []
+    for m, n in enumerate(sizes):
+        zz, pp = W.synthetic_molecule(1700 + m, n_atoms=n)
+        zs.append(torch.from_numpy(zz))
+        ps.append(torch.from_numpy(pp))
+        bs.append(torch.full((n,), m, dtype=torch.long))
+    z, pos, batch = torch.cat(zs), torch.cat(ps).float(), torch.cat(bs)
+    q = torch.tensor([float(m % 3 - 1) for m in range(len(sizes))]) if charges else None
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(5))
+    ge = torch.randn(len(sizes), generator=torch.Generator().manual_seed(6))
+    sd = {k: t.detach() for k, t in model.state_dict().items()}
+    hp = T2.hparams_from_args(args)
+    sd64 = {k: (t.double() if t.is_floating_point() else t) for k, t in sd.items()}
+    for seed in (None, ge):
+        ref = N2.force_term(sd64, hp, z, pos.double(), batch, v.double(), q=None if q is None else q.double(),
+                            ge=None if seed is None else seed.double())
+        out = M2.force_term_mirror(sd, hp, z, pos, batch, v, q=q, ge=seed)
+        tol = 2e-4
+        assert (out["Hv"].double() - ref["Hv"]).abs().max().item() < tol * ref["Hv"].abs().max().item()
+        refg = N2.state_dict_grads(ref, sd64, hp)
+        mine = N2.state_dict_grads(dict(ent={k: t.double() for k, t in out["ent"].items()}, extra={k: t.double() for k, t in out["extra"].items()}),
+                                   sd64, hp)
+        for k, r in refg.items():
+            if r.abs().max() == 0:
+                continue
+            o = mine[k].reshape(r.shape)
+            assert torch.isfinite(o).all(), k
+            assert (o - r).abs().max().item() < tol * r.abs().max().item(), (name, k, (o - r).abs().max().item(), r.abs().max().item())
