@@ -396,3 +396,48 @@ def test_seeded_second_order_pass_matches_specification(hip_lib, golden_dir, fix
     bad = {k: e for k, e in errs.items() if not e < REL}
     assert not bad, bad
     assert hv_err < REL, hv_err
+
+
+@pytest.mark.parametrize("name,extra,sizes,charges", [
+    ("so3-one-layer-no-total-charge", dict(equivariance_invariance_group="SO(3)", num_layers=1, q_weights=[1.0, 0.5]), [9, 14], False),
+    ("three-layers-small-q", dict(num_layers=3, q_dim=4, q_weights=[1.0, 0.5, 2.0, 1.5]), [7, 12, 1, 5], True),
+    ("reaction-field-no-box", dict(coulomb_cutoff=4.0), [11, 8], True),
+])
+def test_tn2_analytic_pass_on_other_configurations(hip_lib, name, extra, sizes, charges):
+    """TensorNet2 branches the two fixtures do not reach (SO(3), one / three layers, no total charge, a single-atom molecule, the
+    reaction-field term without a box), random-init, with the energy seed: engine vs specification, parameters and position gradient."""
+    from oracle import tn2_second_order as N2
+    from oracle import tn2_torch as T2
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.TINY_ARGS, model="tensornet2", output_model="ScalarPlusWeightedCoulomb", q_dim=8, q_weights=[1.0, 0.5, 2.0], derivative=True)
+    args.update(extra)
+    torch.manual_seed(29)
+    model = create_model(dict(args))
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "charge_predict" in k and p.dim() > 1:
+                p.mul_(3.0)
+    model = model.to("cuda")
+    z, pos, batch = _ragged(sizes, seed=1700)
+    B = len(sizes)
+    q = torch.tensor([float(m % 3 - 1) for m in range(B)]) if charges else None
+    v = torch.randn(pos.shape, generator=torch.Generator().manual_seed(5))
+    ge = torch.randn(B, generator=torch.Generator().manual_seed(6))
+    grads, hv = model.force_term_parameter_gradients(z.cuda(), pos.cuda(), batch.cuda(), None, None if q is None else q.cuda(), B, v.cuda(),
+                                                     want_hv=True, ge=ge.cuda())
+    torch.cuda.synchronize()
+    sd64 = {k: (t.detach().cpu().double() if t.is_floating_point() else t.detach().cpu()) for k, t in model.state_dict().items()}
+    hp = T2.hparams_from_args(args)
+    ref = N2.force_term(sd64, hp, z, pos.double(), batch, v.double(), q=None if q is None else q.double(), ge=ge.double())
+    refg = N2.state_dict_grads(ref, sd64, hp)
+    by_name = {id(p): k for k, p in model.named_parameters()}
+    mine = {by_name[id(p)]: t.cpu().double() for p, t in grads.items()}
+    errs = {k: (mine[k].reshape(r.shape) - r).abs().max().item() / r.abs().max().item() for k, r in refg.items() if r.abs().max() > 0}
+    hv_err = (hv.cpu().double() - ref["Hv"]).abs().max().item() / ref["Hv"].abs().max().item()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/hvp_tn2_{name}.json", "w") as fh:
+        json.dump({"case": name, "hv_error": hv_err, "worst_param": max(errs.items(), key=lambda kv: kv[1]), "param_errors": errs}, fh, indent=1)
+    bad = {k: e for k, e in errs.items() if not e < 5 * REL}  # random-init heads: fp32 conditioning (host run of the bodies: 2e-4 bound)
+    assert not bad, bad
+    assert hv_err < 5 * REL, hv_err
