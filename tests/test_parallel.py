@@ -197,3 +197,64 @@ def test_spatial_evaluator_argument_checks_and_single_rank():
         d = torch.remainder(pos_l[n_own:, 0] - pos[gidx[n_own:], 0] + 10.0, 20.0) - 10.0
         assert float(d.abs().max()) < 1e-4
     assert bool((owned == 1).all())
+
+
+def _ddp_worker(rank, world, port, tmpdir):
+    """Data-parallel training: the model's parameter gradients come out of a custom autograd function (one engine pass per
+    backward); wrapped in DistributedDataParallel they must be averaged over the ranks like any other gradient.  The engine calls are
+    replaced by stand-ins whose gradients depend on the rank (no GPU here): what is tested is that the graph the forward builds -
+    parameters as inputs of _EnergyForceParamGrad - is one DDP's hooks see."""
+    import contextlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "torchmd-net_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torchmdnet_amd.models.model as M
+    from torchmdnet_amd import workloads as W
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)  # different initial weights per rank: DDP broadcasts rank 0's
+    model = M.create_model(dict(W.TINY_ARGS, derivative=True))
+    model.parameter_gradients = True
+    model.force_gradient_order = 0
+    n, n_mol = 7, 2
+    z, batch = torch.ones(n, dtype=torch.long), torch.tensor([0, 0, 0, 1, 1, 1, 1])
+    E0, F0 = torch.tensor([1.5, -2.0]), torch.arange(n * 3, dtype=torch.float32).reshape(n, 3) / 10
+    params = [p for p in model.parameters() if p.requires_grad]
+    w = float(rank + 1)
+    M._require_cuda = lambda *a, **k: None
+    M._direct_radial_functions = lambda m: contextlib.nullcontext()
+    model.energy_and_forces = lambda *a, **k: (E0.clone(), F0.clone())
+    model.parameter_gradients_of = lambda z_, p_, b_, box, q, nm, ge: (E0, {p: torch.full_like(p, w * float(ge.sum())) for p in params})
+
+    def second(z_, p_, b_, box, q, nm, v, want_hv=False, ge=None):
+        g = {p: torch.full_like(p, w * float(v.sum())) for p in params}
+        return (g, torch.zeros(n, 3)) if want_hv else g
+
+    model.force_term_parameter_gradients = second
+    ddp = torch.nn.parallel.DistributedDataParallel(model)
+    first = params[0].detach().clone()
+    gathered = [torch.zeros_like(first) for _ in range(world)]
+    dist.all_gather(gathered, first)
+    same_start = all(torch.equal(gathered[0], t) for t in gathered)  # rank 0's weights everywhere
+    ge, R = torch.tensor([0.5, 2.0]), torch.ones(n, 3)
+    pos = torch.zeros(n, 3)
+    y, F = ddp(z, pos, batch)
+    ((y.view(-1) * ge).sum() + (F * R).sum()).backward()
+    # per rank: w * (sum ge - sum R); DDP averages over the ranks
+    expect = sum((r + 1.0) for r in range(world)) / world * (float(ge.sum()) - float(R.sum()))
+    ok = same_start and all(p.grad is not None and torch.allclose(p.grad, torch.full_like(p, expect), rtol=1e-5, atol=1e-5) for p in params)
+    with open(os.path.join(tmpdir, f"ddp{rank}"), "w") as fh:
+        fh.write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_force_matching_gradients_average_under_ddp_gloo_world2(tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"ddp{r}").read() == "1"
