@@ -4,7 +4,9 @@ create_graph=True, so a loss on them back-propagates through the first derivativ
 
 For every fixture below the reference model is rebuilt in fp64 from the fixture's weights, put in training mode, evaluated on the
 fixture's inputs, and  s = v . d(sum_m E_m)/d pos = - sum_i v_i . F_i  is back-propagated (v seeded).  Stored per fixture:
-v, s, H v = d s / d pos and d s / d theta for every parameter (by state-dict key), in fp64.
+v, s, H v = d s / d pos and d s / d theta for every parameter (by state-dict key), in fp64; and, for a loss of energies and forces
+loss = sum_m ge_m E_m + sum_i v_i . F_i (ge seeded), its gradient in every parameter and in the positions from one backward of the
+reference (what one-pass training must reproduce: minus the gradient of S = s - sum_m ge_m E_m).
 
 tests/test_oracle.py pins the three specifications oracle/{tensornet,et,tn2}_second_order.py to these numbers (the -m gpu tests
 compare the engine with the specifications).
@@ -46,7 +48,16 @@ def second_order(mm, g):
     s = -(v * f).sum()
     s.backward()
     grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
-    return dict(v=v, s=s.detach(), Hv=pos.grad.detach().clone(), E=y.detach(), F=f.detach(), grads=grads)
+    out = dict(v=v, s=s.detach(), Hv=pos.grad.detach().clone(), E=y.detach(), F=f.detach(), grads=grads)
+    # a loss of energies AND forces, loss = sum_m ge_m E_m + sum_i v_i . F_i: its whole gradient from ONE backward of the reference
+    model.zero_grad()
+    pos2 = g["pos"].double().clone().requires_grad_(True)
+    y2, f2 = model(g["z"], pos2, g["batch"], box=None if box is None else box.double(), q=None if q is None else q.double())
+    ge = torch.randn(y2.shape[0], generator=torch.Generator().manual_seed(V_SEED + 1), dtype=torch.float64)
+    ((ge * y2.view(-1)).sum() + (v * f2).sum()).backward()
+    out.update(ge=ge, loss_grads={k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None},
+               loss_pos_grad=pos2.grad.detach().clone())
+    return out
 
 
 def main():

@@ -470,3 +470,41 @@ def test_et_tn2_second_order_pass_with_energy_seed(golden_dir, fixture):
         assert rel_err(mine[k].reshape(r.shape), r) < 1e-10, k
         checked += 1
     assert checked >= 30
+
+
+@pytest.mark.parametrize("fixture", ["tiny_ref.pt", "et_tiny_ref.pt", "et_tiny_vc_ref.pt", "tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_seeded_specifications_equal_the_reference_backward_of_an_energy_and_force_loss(golden_dir, fixture):
+    """loss = sum_m ge_m E_m + sum_i v_i . F_i back-propagated ONCE through the unmodified reference (training mode, fp64;
+    tests/golden/second_order_ref.pt) against the seeded specifications: d loss / d theta = - d S / d theta and d loss / d pos =
+    - d S / d pos with S = v . d(sum E)/d pos - sum_m ge_m E_m  - the identity one-pass training rests on (tmdnet_loss_param_grads)."""
+    ref = torch.load(os.path.join(golden_dir, "second_order_ref.pt"))[fixture]
+    g = torch.load(os.path.join(golden_dir, fixture))
+    sd = {k: (t.double() if t.is_floating_point() else t) for k, t in g["state_dict"].items()}
+    z, pos, batch, v, ge = g["z"], g["pos"].double(), g["batch"], ref["v"], ref["ge"]
+    q = g["q"].double() if g.get("q") is not None else None
+    box = g["box"].double() if g.get("box") is not None else None
+    if fixture.startswith("et_"):
+        from oracle import et_second_order as E2
+
+        out = E2.force_term(sd, ET.hparams_from_args(g["args"]), z, pos, batch, v, ge=ge)
+        mine = out["grads"]
+    elif fixture.startswith("tn2_"):
+        from oracle import tn2_second_order as N2
+        from oracle import tn2_torch as T2
+
+        hp = T2.hparams_from_args(g["args"])
+        out = N2.force_term(sd, hp, z, pos, batch, v, box=box, q=q, ge=ge)
+        mine = N2.state_dict_grads(out, sd, hp)
+    else:
+        hp = T.hparams_from_args(g["args"])
+        out = S2.force_term(sd, hp, z, pos, batch, v, q=q, ge=ge)
+        mine = S2.state_dict_grads(out["ent"], sd, hp)
+    assert rel_err(-out["Hv"], ref["loss_pos_grad"]) < 1e-10
+    checked = 0
+    for k, r in ref["loss_grads"].items():
+        if r.abs().max() == 0:
+            continue
+        assert k in mine, k
+        assert rel_err(-mine[k].reshape(r.shape), r) < 1e-9, k
+        checked += 1
+    assert checked >= 30
