@@ -510,3 +510,36 @@ def test_et_analytic_pass_on_other_configurations(hip_lib, name, extra, sizes):
     bad = {k: e for k, e in errs.items() if not e < 1e-3}  # random-init heads reach 1e3: fp32 conditioning (host run of the bodies: 2e-4 there)
     assert len(errs) >= 20 and not bad, bad
     assert hv_err < 1e-3, hv_err
+
+
+@pytest.mark.parametrize("fixture", ["tiny_ref.pt", "et_tiny_ref.pt", "et_tiny_vc_ref.pt", "tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_one_pass_gradient_equals_the_reference_backward_of_an_energy_and_force_loss(hip_lib, golden_dir, fixture):
+    """tmdnet_loss_param_grads directly against ONE backward of the unmodified reference for loss = sum_m ge_m E_m + sum_i v_i . F_i
+    (tests/golden/second_order_ref.pt): d loss / d theta = - grads, d loss / d pos = - hv."""
+    from torchmdnet_amd.models.model import create_model
+
+    ref = torch.load(os.path.join(golden_dir, "second_order_ref.pt"))[fixture]
+    g = torch.load(os.path.join(golden_dir, fixture))
+    model = create_model(dict(g["args"]))
+    model.load_state_dict(g["state_dict"])
+    model = model.to("cuda")
+    z, pos, batch = g["z"], g["pos"], g["batch"]
+    q = g["q"] if g.get("q") is not None else None
+    box = g["box"] if g.get("box") is not None else None
+    c = lambda t: None if t is None else t.cuda()
+    n_mol = int(batch.max()) + 1
+    grads, hv = model.force_term_parameter_gradients(z.cuda(), pos.cuda(), batch.cuda(), c(box), c(q), n_mol, ref["v"].float().cuda(), want_hv=True,
+                                                     ge=ref["ge"].float().cuda())
+    torch.cuda.synchronize()
+    by_name = {id(p): k for k, p in model.named_parameters()}
+    mine = {by_name[id(p)]: -t.cpu().double() for p, t in grads.items()}
+    errs = {k: (mine[k].reshape(r.shape) - r).abs().max().item() / r.abs().max().item() for k, r in ref["loss_grads"].items()
+            if r.abs().max() > 0}
+    pos_err = (-hv.cpu().double() - ref["loss_pos_grad"]).abs().max().item() / ref["loss_pos_grad"].abs().max().item()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/one_pass_vs_reference_{fixture[:-3]}.json", "w") as fh:
+        json.dump({"case": fixture, "position_gradient": pos_err, "worst_param": max(errs.items(), key=lambda kv: kv[1]), "param_errors": errs}, fh,
+                  indent=1)
+    bad = {k: e for k, e in errs.items() if not e < REL}
+    assert len(errs) >= 30 and not bad, bad
+    assert pos_err < REL, pos_err
