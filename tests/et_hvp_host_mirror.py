@@ -261,10 +261,13 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, ge=None):
                 put(f"l{l}.dkv", c["attn"][4]); put(f"l{l}.dkv_t", c["attn"][5])
             put(f"l{l}.xagg", c["xagg"]); put(f"l{l}.xagg_t", c["xagg_t"]); put(f"l{l}.o_t", c["o_t"]); put(f"l{l}.vdot_t", c["vdot_t"])
     for nm, t in (("pre2", pre2), ("pre2_t", pre2_t), ("g_pre2_t", g_pre2_t), ("headv", headv), ("g_qkv", g_qkv), ("g_qkv_t", g_qkv_t),
-                  ("g_vin", g_vin), ("g_vin_t", g_vin_t), ("gq", gq), ("gq_t", gq_t), ("selfq", selfq), ("selfq_t", selfq_t), ("slots", slots),
+                  ("g_vin", g_vin), ("g_vin_t", g_vin_t), ("selfq", selfq), ("selfq_t", selfq_t), ("slots", slots),
                   ("slots_t", slots_t), ("g_x", g_x), ("g_x_t", g_x_t), ("g_cut", g_cut), ("g_cut_t", g_cut_t), ("g_rh", g_rh), ("g_rh_t", g_rh_t),
                   ("gdel", gdel), ("gdel_t", gdel_t)):
         put(nm, t)
+    if not ne:  # with the neighbour embedding the engine reuses the filter-adjoint rows for that embedding's per-pair adjoints afterwards
+        put("gq", gq)
+        put("gq_t", gq_t)
     # rows the kernels never write (nor read): the self pair's row of every per-pair block
     never = {"gq": (2, P1), "gq_t": (2, P1), "slots": (2 * L, P1), "slots_t": (2 * L, P1), "g_cut": (1, P1), "g_cut_t": (1, P1), "g_rh": (1, P1),
              "g_rh_t": (1, P1)}
