@@ -13,14 +13,15 @@ from oracle import tensornet_torch as T
 pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
 
 
-def _check(sd, hp, z, pos, batch, v, q=None, box=None, tol=2e-5):
+def _check(sd, hp, z, pos, batch, v, q=None, box=None, tol=2e-5, ge=None):
     from tests import hvp_host_mirror as HM
 
     sd64 = T.cast_state_dict(sd, torch.float64)
     ref = S2.force_term(sd64, hp, z, pos.double(), batch, v.double(), q=None if q is None else q.double(),
-                        box=None if box is None else box.double())
-    out = HM.force_term_mirror(sd, hp, z, pos, batch, v, q=q, box=box)
-    assert abs(out["s"].item() - ref["s"].item()) < tol * max(1.0, abs(ref["s"].item()))
+                        box=None if box is None else box.double(), ge=None if ge is None else ge.double())
+    out = HM.force_term_mirror(sd, hp, z, pos, batch, v, q=q, box=box, ge=ge)
+    if ge is None:  # (seeded: the mirror's s is the head's part only)
+        assert abs(out["s"].item() - ref["s"].item()) < tol * max(1.0, abs(ref["s"].item()))
     # H v in the positions, and the forces out of the same geometry kernels (their value half)
     assert (out["F"].double() - ref["F"]).abs().max().item() < tol * ref["F"].abs().max().item()
     assert (out["Hv"].double() - ref["Hv"]).abs().max().item() < 5 * tol * ref["Hv"].abs().max().item()
@@ -38,6 +39,9 @@ def test_kernel_bodies_in_engine_schedule_match_specification(golden_dir, extra,
     hp = dict(T.hparams_from_args(tiny["args"]), **extra)
     v = torch.randn(tiny["pos"].shape, generator=torch.Generator().manual_seed(3))
     _check(tiny["state_dict"], hp, tiny["z"], tiny["pos"], tiny["batch"], v, q=tiny["q"] if use_q else None)
+    # the same with the energy seed of one-pass training
+    ge = torch.randn(int(tiny["batch"].max()) + 1, generator=torch.Generator().manual_seed(8))
+    _check(tiny["state_dict"], hp, tiny["z"], tiny["pos"], tiny["batch"], v, q=tiny["q"] if use_q else None, ge=ge)
 
 
 def test_kernel_bodies_periodic_box(golden_dir):
@@ -46,6 +50,7 @@ def test_kernel_bodies_periodic_box(golden_dir):
     hp = T.hparams_from_args(tiny["args"])
     v = torch.randn(f["pos"].shape, generator=torch.Generator().manual_seed(5))
     _check(tiny["state_dict"], hp, f["z"], f["pos"], f["batch"], v, box=f["box"])
+    _check(tiny["state_dict"], hp, f["z"], f["pos"], f["batch"], v, box=f["box"], ge=torch.tensor([0.8]))
 
 
 @pytest.mark.parametrize("name,extra,sizes,charges", [
