@@ -377,12 +377,14 @@ def training_leg(dev, L, steps=4, warmup=2):
     out = {"workload": "C2 model, S-mol64 256 x 64 atoms, one optimizer step (SGD) per step, random-init (seed 0)"}
     z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS)
     z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
-    for key, deriv, order in (("ms_per_step_energy_only", False, 0), ("ms_per_step_energy_and_forces", True, 0),
-                              ("ms_per_step_energy_and_forces_difference_quotient", True, 2)):
+    for key, deriv, order, one_pass in (("ms_per_step_energy_only", False, 0, True), ("ms_per_step_energy_and_forces", True, 0, True),
+                                        ("ms_per_step_energy_and_forces_two_passes", True, 0, False),
+                                        ("ms_per_step_energy_and_forces_difference_quotient", True, 2, False)):
         torch.manual_seed(0)
         model = create_model(dict(W.C2_ARGS, derivative=deriv)).to(dev)
         model.parameter_gradients = True
         model.force_gradient_order = order  # 0: analytic second-order pass (TensorNet's default); 2: central difference, two extra passes
+        model.one_pass_training = one_pass  # True: the seeded second-order pass delivers the energy term's gradient too (tmdnet_loss_param_grads)
         opt = torch.optim.SGD(model.parameters(), lr=1e-7)
 
         def step():

@@ -99,7 +99,7 @@ const char* tmdnet_version(void);
 /* ABI revision of this header: bumped whenever an exported signature or struct layout changes (3: `z` in
  * tmdnet_build_graph[_static], `strategy` in tmdnet_neighbor_pairs).  A binding compares its compile-time
  * TMDNET_ABI_VERSION with the loaded library's tmdnet_abi_version() before its first call. */
-#define TMDNET_ABI_VERSION 6
+#define TMDNET_ABI_VERSION 7
 int tmdnet_abi_version(void);
 
 /* Parameters are addressed by the reference's state-dict keys without the "model." prefix
@@ -316,6 +316,16 @@ int tmdnet_force_param_workspace_bytes(tmdnet_model* m, int64_t n_atoms, int64_t
 int tmdnet_force_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms,
                              int64_t n_mol, int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q, const float* v,
                              float* grads, float* hv);
+/* The whole gradient of a loss(E, F) in ONE pass: tmdnet_force_param_grads with an energy seed.  ge [n_mol] = d loss / d E (device;
+ * NULL = tmdnet_force_param_grads): grads = d S / d theta and hv = d S / d pos of
+ *     S = v . d(sum_m E_m)/d pos - sum_m ge_m E_m ,
+ * so d loss / d theta = - grads and d loss / d pos = - hv, without the separate tmdnet_energy_param_grads pass (the reference gets
+ * both terms from one backward over its autograd graph, torchmdnet/models/model.py:618-628).  How: the tangent adjoint minus the
+ * adjoint of sum_m ge_m E_m obeys the tangent adjoint's own recursion, so only its seed at the head differs.  Terms outside the
+ * engine's parameter set (an Atomref prior's table: index_add of ge[molecule] over z) stay with the caller. */
+int tmdnet_loss_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
+                            int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* q, const float* v, const float* ge,
+                            float* grads, float* hv);
 /* Developer / test hook: copies one intermediate of the LAST tmdnet_force_param_grads call on this handle (same thread, workspace
  * untouched since) into `out` (device); names are the buffer names of csrc/tn_hvp_api.hip ("u0_t", "l0.Mi_t", "g_Pn", ...).
  * out == NULL: returns the element count instead of a status. */

@@ -19,7 +19,7 @@ def thirds(w, F, hd):
     return w[src].contiguous(), src
 
 
-def force_term_mirror(sd, hp, z, pos, batch, v, box=None):
+def force_term_mirror(sd, hp, z, pos, batch, v, box=None, ge=None):
     R = "representation_model."
     sd = {k: (t.float() if t.is_floating_point() else t) for k, t in sd.items()}
     F, H, L, K = hp["hidden_channels"], hp["num_heads"], hp["num_layers"], hp["num_rbf"]
@@ -144,11 +144,15 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None):
     call("he_cat_norm_dual", N, F2, None, None, F2, w1, w1_t, F2, F2, F, hcat2, hcat2_t)
     pre2, pre2_t = gemm(hcat2, Wn1, bn1), gemm(hcat2_t, Wn1)
     g_pre2, g_pre2_t, headv = f32(N, F2), f32(N, F2), f32(N, F2)
-    call("hh_head_dual", C.c_int64(N * F2), F2, pre2, pre2_t, Wn2, std, g_pre2, g_pre2_t, headv)
+    b64 = batch.to(torch.int64).contiguous()
+    ge32 = None if ge is None else ge.float().contiguous()  # one-pass training: energy seed (tn_hvp_math.h head_dual)
+    call("hh_head_dual", C.c_int64(N * F2), F2, pre2, pre2_t, Wn2, std, ge32, b64, g_pre2, g_pre2_t, headv)
     s_val = (headv * Wn2).sum()
 
     # ---- reverse with tangents: head
     ent["Wn2"], ent["bn2"] = headv.sum(0), torch.zeros(1)
+    if ge is not None:
+        call("hh_head_bias_seed", N, std, ge32, b64, ent["bn2"])
     dense("Wn1", "bn1", g_pre2, g_pre2_t, hcat2, hcat2_t)
     g_h2, g_h2_t = gemmT(g_pre2, Wn1), gemmT(g_pre2_t, Wn1)  # (g_xs | g_n2)
     g_w1, g_w1_t = f32(N, 3, F2), f32(N, 3, F2)
@@ -240,7 +244,34 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None):
     g_pos, Hv = f32(N, 3), f32(N, 3)
     call("hh_pair_to_atom", N, P, rowptr, epair, esign, gdel, g_pos)
     call("hh_pair_to_atom", N, P, rowptr, epair, esign, gdel_t, Hv)
-    return dict(ent=ent, s=s_val, Hv=Hv, F=-g_pos)
+    # the engine's intermediates by the names tmdnet_hvp_debug_tensor knows (csrc/tn_et_api.hip et_hvp_debug_tensor), in schedule order;
+    # the reverse sweep's scratch holds its last layer (l = 0)
+    bufs, order = {}, []
+
+    def put(name, t):
+        bufs[name] = t
+        order.append(name)
+
+    for l in range(L + 1):
+        put(f"x{l}", X[l]); put(f"x_t{l}", X_t[l]); put(f"vec{l}", V[l]); put(f"vec_t{l}", V_t[l])
+        if l < L:
+            c = lay[l]
+            put(f"l{l}.qkv", c["attn"][0]); put(f"l{l}.qkv_t", c["attn"][1])
+            if c["Wd"] > 0:
+                put(f"l{l}.dkv", c["attn"][4]); put(f"l{l}.dkv_t", c["attn"][5])
+            put(f"l{l}.xagg", c["xagg"]); put(f"l{l}.xagg_t", c["xagg_t"]); put(f"l{l}.o_t", c["o_t"]); put(f"l{l}.vdot_t", c["vdot_t"])
+    for nm, t in (("pre2", pre2), ("pre2_t", pre2_t), ("g_pre2_t", g_pre2_t), ("headv", headv), ("g_qkv", g_qkv), ("g_qkv_t", g_qkv_t),
+                  ("g_vin", g_vin), ("g_vin_t", g_vin_t), ("selfq", selfq), ("selfq_t", selfq_t), ("slots", slots),
+                  ("slots_t", slots_t), ("g_x", g_x), ("g_x_t", g_x_t), ("g_cut", g_cut), ("g_cut_t", g_cut_t), ("g_rh", g_rh), ("g_rh_t", g_rh_t),
+                  ("gdel", gdel), ("gdel_t", gdel_t)):
+        put(nm, t)
+    if not ne:  # with the neighbour embedding the engine reuses the filter-adjoint rows for that embedding's per-pair adjoints afterwards
+        put("gq", gq)
+        put("gq_t", gq_t)
+    # rows the kernels never write (nor read): the self pair's row of every per-pair block
+    never = {"gq": (2, P1), "gq_t": (2, P1), "slots": (2 * L, P1), "slots_t": (2 * L, P1), "g_cut": (1, P1), "g_cut_t": (1, P1), "g_rh": (1, P1),
+             "g_rh_t": (1, P1)}
+    return dict(ent=ent, s=s_val, Hv=Hv, F=-g_pos, bufs=bufs, order=order, never=never, P=P)
 
 
 def state_dict_grads(ent, sd, hp):
@@ -282,5 +313,6 @@ def state_dict_grads(ent, sd, hp):
                 O0 + "update_net.layers.0.bias": ent["bm1"], O0 + "update_net.layers.2.weight": ent["Wm2"],
                 O0 + "update_net.layers.2.bias": ent["bm2"], O1 + "vec1_proj.weight": ent["W21"], O1 + "update_net.layers.0.weight": ent["Wn1"],
                 O1 + "update_net.layers.0.bias": ent["bn1"], O1 + "update_net.layers.2.weight": w2,
-                O1 + "update_net.layers.2.bias": torch.zeros_like(sd[O1 + "update_net.layers.2.bias"], dtype=torch.float32)})
+                O1 + "update_net.layers.2.bias": torch.cat([ent["bn2"].reshape(1),
+                                                             torch.zeros(sd[O1 + "update_net.layers.2.bias"].numel() - 1)])})
     return out

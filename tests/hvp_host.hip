@@ -4,6 +4,7 @@
 // torchmd-net_amd/ links or loads this file.
 #include "../torchmd-net_amd/csrc/tn_hvp_math.h"
 #include "../torchmd-net_amd/csrc/tn_et_hvp_math.h"
+#include "../torchmd-net_amd/csrc/tn_tn2_hvp_math.h"
 
 using namespace tn::hvp;
 
@@ -59,9 +60,23 @@ void hh_feat_dual(int N, int F, const float* X, const float* X_t, float* feat, f
   for (int n = 0; n < N; ++n)
     for (int f = 0; f < F; ++f) feat_dual(n, f, F, X, X_t, feat, feat_t);
 }
-void hh_head_dual(int64_t n, int H, const float* ao, const float* ao_t, const float* O2, float std_, float* g_ao, float* g_ao_t,
-                  float* headv) {
-  for (int64_t i = 0; i < n; ++i) head_dual(i, H, ao, ao_t, O2, std_, g_ao, g_ao_t, headv);
+void hh_head_dual(int64_t n, int H, const float* ao, const float* ao_t, const float* O2, float std_, const float* ge, const int64_t* batch,
+                  float* g_ao, float* g_ao_t, float* headv) {
+  for (int64_t i = 0; i < n; ++i) head_dual(i, H, ao, ao_t, O2, std_, ge, batch, g_ao, g_ao_t, headv);
+}
+void hh_head_bias_seed(int N, float std_, const float* ge, const int64_t* batch, float* out) {  // k_head_bias_seed's order of summation
+  float part[256];
+  for (int t = 0; t < 256; ++t) {
+    float a = 0.f;
+    for (int n = t; n < N; n += 256) a += head_bias_seed_term(n, ge, batch);
+    part[t] = a;
+  }
+  float tot = 0.f;
+  for (int k = 0; k < 256; ++k) tot += part[k];
+  out[0] = -std_ * tot;
+}
+void hh_row_seed(int N, int W, const float* ge, const int64_t* batch, const float* x, float* x_t) {
+  for (int64_t i = 0; i < (int64_t)N * W; ++i) row_seed(i, W, ge, batch, x, x_t);
 }
 void hh_readout_bwd_dual(int N, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G, float* G_t) {
   for (int n = 0; n < N; ++n)
@@ -229,6 +244,74 @@ void he_geom_dual(int P, const float* pd, const float* prhat, const float* d_t, 
                   const float* g_cut, const float* g_cut_t, const float* g_dphi, const float* g_dphi_t, const float* g_rh, const float* g_rh_t,
                   float* gdel, float* gdel_t) {
   for (int p = 0; p < P; ++p) et_geom_dual(p, pd, prhat, d_t, rhat_t, dC, d2C, g_cut, g_cut_t, g_dphi, g_dphi_t, g_rh, g_rh_t, gdel, gdel_t);
+}
+
+// ---------------------------------------------------------------- TensorNet2 (tn_tn2_hvp_math.h)
+void h2_cp_feat_dual(int N, int F, const float* X, const float* X_t, float* feat, float* feat_t) {
+  for (int n = 0; n < N; ++n)
+    for (int f = 0; f < F; ++f) cp_feat_dual(n, f, F, X, X_t, feat, feat_t);
+}
+void h2_cp_feat_bwd_dual(int N, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G, float* G_t) {
+  for (int n = 0; n < N; ++n)
+    for (int f = 0; f < F; ++f) cp_feat_bwd_dual(n, f, F, X, X_t, g_feat, g_feat_t, G, G_t);
+}
+void h2_cp_mol_sums(int B, int qd, const int* mstart, const int* mend, const float* out, const float* out_t, float* sums) {
+  for (int m = 0; m < B; ++m)
+    for (int q = 0; q < qd; ++q) cp_mol_sums(m, q, qd, mstart, mend, out, out_t, sums);
+}
+void h2_cp_qeq_dual(int N, int qd, const int64_t* batch, const float* Qmol, const float* out, const float* out_t, const float* sums, float* ch,
+                    float* ch_t, int ldc, int off) {
+  for (int n = 0; n < N; ++n)
+    for (int q = 0; q < qd; ++q) cp_qeq_dual(n, q, qd, batch, Qmol, out, out_t, sums, ch, ch_t, ldc, off);
+}
+void h2_cp_qeq_bwd_dual(int N, int B, int qd, const int* mstart, const int* mend, const int64_t* batch, const float* Qmol, const float* out,
+                        const float* out_t, const float* sums, const float* g_ch, const float* g_ch_t, int ldg, int off, float* bs,
+                        float* g_out, float* g_out_t) {
+  for (int m = 0; m < B; ++m)
+    for (int q = 0; q < qd; ++q) cp_mol_sums_bwd(m, q, qd, mstart, mend, batch, Qmol, out, out_t, sums, g_ch, g_ch_t, ldg, off, bs);
+  for (int n = 0; n < N; ++n)
+    for (int q = 0; q < qd; ++q) cp_qeq_bwd_dual(n, q, qd, batch, Qmol, out, out_t, sums, bs, g_ch, g_ch_t, ldg, off, g_out, g_out_t);
+}
+void h2_edge_pre1_dual(int E, int N, int F, const int* rowptr, const int* col, const int* epair, const float* Ap, const float* Ap_t,
+                       const float* Bt, const float* Bt_t, const float* Cs, const float* Cs_t, float* pre1, float* e1_t, float* he1,
+                       float* he1_t) {
+  for (int64_t i = 0; i < (int64_t)E * F; ++i) tn2_edge_pre1_dual(i, N, F, rowptr, col, epair, Ap, Ap_t, Bt, Bt_t, Cs, Cs_t, pre1, e1_t, he1, he1_t);
+}
+void h2_edge_reduce_dual(int N, int F, const int* rowptr, const int* col, const int* erev, const float* g1, const float* g1_t, float* gB,
+                         float* gB_t, float* gCs, float* gCs_t, float* gself, float* gself_t) {
+  for (int i = 0; i < N; ++i)
+    for (int f = 0; f < F; ++f) tn2_edge_reduce_dual(i, f, F, rowptr, col, erev, g1, g1_t, gB, gB_t, gCs, gCs_t, gself, gself_t);
+}
+void h2_pair_reduce_dual(int P, int F, const int* pair_edge, const int* erev, const float* g1, const float* g1_t, float* gAp, float* gAp_t) {
+  for (int64_t i = 0; i < (int64_t)P * F; ++i) tn2_pair_reduce_dual(i, F, pair_edge, erev, g1, g1_t, gAp, gAp_t);
+}
+void h2_w_dual(int E, int F3, const int* epair, const float* e3, const float* e3_t, const float* C, const float* C_t, float* w, float* w_t) {
+  for (int64_t i = 0; i < (int64_t)E * F3; ++i) tn2_w_dual(i, F3, epair, e3, e3_t, C, C_t, w, w_t);
+}
+void h2_edge_sweep2(int N, int F, const int* rowptr, const int* col, const int* emap, const float* wA, const float* srcA, const float* wB,
+                    const float* srcB, const float* init, float* out) {
+  for (int n = 0; n < N; ++n)
+    for (int f = 0; f < F; ++f) edge_sweep2(n, f, F, rowptr, col, emap, wA, srcA, wB, srcB, init, out);
+}
+void h2_edge_gw_dual(int E, int N, int F, const int* rowptr, const int* col, const int* epair, const float* g_Mi, const float* g_Mi_t,
+                     const float* Pn, const float* Pn_t, const float* e3, const float* e3_t, const float* C, const float* C_t, float* g_e3,
+                     float* g_e3_t, float* gcp, float* gcp_t) {
+  for (int64_t i = 0; i < (int64_t)E * F; ++i)
+    tn2_edge_gw_dual(i, N, F, rowptr, col, epair, g_Mi, g_Mi_t, Pn, Pn_t, e3, e3_t, C, C_t, g_e3, g_e3_t, gcp, gcp_t);
+}
+void h2_edge_rowdot(int E, int W, int ldx, const int* epair, const float* x, const float* x_t, const float* y, const float* y2,
+                    const float* d_t, int accumulate, float* val, float* val_t) {
+  for (int e = 0; e < E; ++e) edge_rowdot(e, W, ldx, epair, x, x_t, y, y2, d_t, accumulate, val, val_t);
+}
+void h2_pair_from_edges(int P, const int* pair_edge, const int* erev, const float* val, const float* val_t, float* out, float* out_t) {
+  for (int p = 0; p < P; ++p) pair_from_edges(p, pair_edge, erev, val, val_t, out, out_t);
+}
+void h2_coulomb_atom_dual(int N, int QC, const int* mstart, const int* mend, const int64_t* batch, const float* pos, const float* v,
+                          const float* box, int box_per_mol, const float* ch, const float* ch_t, const float* wq, float wsum, float cut, float eps,
+                          float scale, float* e_atom, float* e_atom_t, float* g_q, float* g_q_t, float* g_pos, float* hv) {
+  for (int i = 0; i < N; ++i)
+    coulomb_atom_dual(i, QC, mstart, mend, batch, pos, v, box, box_per_mol, ch, ch_t, wq, wsum, cut, eps, scale, e_atom, e_atom_t, g_q, g_q_t,
+                      g_pos, hv);
 }
 
 }  // extern "C"

@@ -21,7 +21,8 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(ROOT, "oracle", "_build", "libhvp_host.so")
-        src = [os.path.join(ROOT, "tests", "hvp_host.hip"), os.path.join(ROOT, "torchmd-net_amd", "csrc", "tn_hvp_math.h")]
+        src = [os.path.join(ROOT, "tests", "hvp_host.hip")] + [os.path.join(ROOT, "torchmd-net_amd", "csrc", h) for h in
+                                                               ("tn_hvp_math.h", "tn_et_hvp_math.h", "tn_tn2_hvp_math.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
             os.makedirs(os.path.dirname(so), exist_ok=True)
             subprocess.check_call(["hipcc", "-x", "hip", "--cuda-host-only", "-O1", "-fPIC", "-shared", src[0], "-o", so])
@@ -50,7 +51,7 @@ def f32(*shape):
     return torch.full(shape, float("nan"), dtype=torch.float32)  # NaN-filled: an element a kernel forgets to write shows up
 
 
-def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
+def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None, ge=None):
     """-> {engine entry name: d s / d entry} in fp32, by the engine's schedule."""
     R = "representation_model."
     T = R + "tensor_embedding."
@@ -177,11 +178,15 @@ def force_term_mirror(sd, hp, z, pos, batch, v, box=None, q=None):
     call("hh_silu_tangent", C.c_int64(N * F), al, al_t, x_t)
     ao, ao_t = gemm(x, O1, bO1), gemm(x_t, O1)
     g_ao, g_ao_t, headv = f32(N, H), f32(N, H), f32(N, H)
-    call("hh_head_dual", C.c_int64(N * H), H, ao, ao_t, O2, std, g_ao, g_ao_t, headv)
+    b64 = batch.to(torch.int64).contiguous()
+    ge32 = None if ge is None else ge.float().contiguous()  # one-pass training: energy seed (tn_hvp_math.h head_dual)
+    call("hh_head_dual", C.c_int64(N * H), H, ao, ao_t, O2, std, ge32, b64, g_ao, g_ao_t, headv)
     s_val = (headv * O2).sum()
 
     # ---- reverse pass with tangents
     ent["O2"], ent["bO2"] = headv.sum(0, keepdim=True), torch.zeros(1)
+    if ge is not None:
+        call("hh_head_bias_seed", N, std, ge32, b64, ent["bO2"])
     ent["O1"], ent["bO1"] = tn_gemm(g_ao_t, x) + tn_gemm(g_ao, x_t), g_ao_t.sum(0)
     g_x, g_x_t = gemmT(g_ao, O1), gemmT(g_ao_t, O1)
     g_al, g_al_t = f32(N, F), f32(N, F)

@@ -428,11 +428,14 @@ def test_force_matching_backward_combines_the_passes_with_the_right_signs(monkey
         calls["first"] += 1
         return E0, {p: torch.full_like(p, float(ge.sum())) for p in params}
 
-    def force_term_parameter_gradients(z_, pos_, batch_, box, q, n_mol_, v, want_hv=False):
+    def force_term_parameter_gradients(z_, pos_, batch_, box, q, n_mol_, v, want_hv=False, ge=None):
+        # with an energy seed: the gradients of S = s - sum ge E (parameters: minus the energy pass' stand-in; positions: + ge F)
         calls["second"] += 1
         calls["hv"] += int(want_hv)
-        g = {p: torch.full_like(p, float(v.sum())) for p in params}
-        return (g, hv0.clone()) if want_hv else g
+        calls["seeded"] = calls.get("seeded", 0) + int(ge is not None)
+        g = {p: torch.full_like(p, float(v.sum()) - (0.0 if ge is None else float(ge.sum()))) for p in params}
+        hv = hv0.clone() if ge is None else hv0 + ge[batch_].unsqueeze(1) * F0
+        return (g, hv) if want_hv else g
 
     monkeypatch.setattr(M, "_direct_radial_functions", lambda m: contextlib.nullcontext())
     for name, fn in (("energy_and_forces", energy_and_forces), ("parameter_gradients_of", parameter_gradients_of),
@@ -440,8 +443,9 @@ def test_force_matching_backward_combines_the_passes_with_the_right_signs(monkey
         monkeypatch.setattr(model, name, fn)
     ge, R = torch.tensor([0.5, 2.0]), torch.randn(n, 3)
 
-    def run(order, pos_grad=True):
+    def run(order, pos_grad=True, one_pass=False):
         model.force_gradient_order, model.force_position_gradient, model._warned_pos_grad = order, pos_grad, False
+        model.one_pass_training = one_pass
         for p in params:
             p.grad = None
         for k in calls:
@@ -454,13 +458,25 @@ def test_force_matching_backward_combines_the_passes_with_the_right_signs(monkey
     with warnings.catch_warnings():
         warnings.simplefilter("error")  # the analytic pass with H v has nothing to announce
         g_pos = run(0)
-    assert calls == dict(first=1, second=1, hv=1)
+    assert calls == dict(first=1, second=1, hv=1, seeded=0)
     expect = float(ge.sum()) - float(R.sum())  # energy pass seeded with g_E, minus the second-order pass along v = g_F
     assert all(torch.allclose(p.grad, torch.full_like(p, expect), rtol=1e-5, atol=1e-5) for p in params)
     assert torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0 - hv0)
     with pytest.warns(UserWarning, match="energy term's part"):
         g_pos = run(0, pos_grad=False)
-    assert calls == dict(first=1, second=1, hv=0) and torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0)
+    assert calls == dict(first=1, second=1, hv=0, seeded=0) and torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0)
+    # one pass (the default): no first-order pass at all, the seeded second-order pass delivers both terms, same numbers
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        g_pos = run(0, one_pass=True)
+    assert calls == dict(first=0, second=1, hv=1, seeded=1)
+    assert all(torch.allclose(p.grad, torch.full_like(p, expect), rtol=1e-5, atol=1e-5) for p in params)
+    assert torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0 - hv0)
+    with pytest.warns(UserWarning, match="energy term's part"):
+        g_pos = run(0, pos_grad=False, one_pass=True)
+    assert calls == dict(first=0, second=1, hv=0, seeded=1) and torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0)
+    assert all(torch.allclose(p.grad, torch.full_like(p, expect), rtol=1e-5, atol=1e-5) for p in params)
+    calls.pop("seeded")
     for order, extra in ((2, 2), (4, 4)):  # (None on a TensorNet model means 0: covered by the first run's explicit 0)
         with pytest.warns(UserWarning, match="energy term's part"):
             g_pos = run(order)

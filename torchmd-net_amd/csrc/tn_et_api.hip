@@ -764,6 +764,11 @@ struct EtHvpBuffers {
       *part;
 };
 
+// last call's buffers (developer / test hook tmdnet_hvp_debug_tensor)
+thread_local EtHvpBuffers g_et_last;
+thread_local int64_t g_et_lastN = -1, g_et_lastP = 0;
+thread_local const tmdnet_model* g_et_last_model = nullptr;
+
 EtHvpBuffers et_carve_hvp(void* ws, const tmdnet_et_hparams& hp, int64_t N, int64_t P, size_t* total) {
   const int64_t F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, F2 = F / 2, U = F + F2, H = hp.num_heads, P1 = P + 1;
   const int64_t Wd = std::max<int64_t>(wd_of(hp), 1), NF = N * F;
@@ -815,9 +820,9 @@ int et_force_param_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64
 }
 
 int et_force_param_grads(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
-                         int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* v, float* grads, float* hv) {
+                         int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* v, const float* ge, float* grads, float* hv) {
   (void)n_mol;
-  (void)batch;
+  if (m->et->hp.hidden_channels > 512) return fail(m, TMDNET_ERR_INVALID, "second-order pass: hidden_channels <= 512 (a block per atom, a thread per channel)");
   const tmdnet_et_hparams& hp = m->et->hp;
   const int F = hp.hidden_channels, K = hp.num_rbf, L = hp.num_layers, Z = hp.max_z, F2 = F / 2, U = F + F2, H = hp.num_heads, hd = F / H;
   const int Wd = wd_of(hp), N = (int)n_atoms, P = (int)n_pairs, P1 = P + 1;
@@ -912,10 +917,11 @@ int et_force_param_grads(tmdnet_model* m, hipStream_t s, const Graph& g, void* w
   hvp::launch_et_cat_norm_dual(N, F2, nullptr, nullptr, F2, b.w1, b.w1_t, F2, F2, F, b.hcat2, b.hcat2_t, s);
   gemm(s, b.hcat2, F, W.Wn1, F, W.bn1, b.pre2, F2, N, F2, F);
   gemm(s, b.hcat2_t, F, W.Wn1, F, nullptr, b.pre2_t, F2, N, F2, F);
-  hvp::launch_head_dual(N, F2, b.pre2, b.pre2_t, W.Wn2, W.std, b.g_pre2, b.g_pre2_t, b.headv, s);
+  hvp::launch_head_dual(N, F2, b.pre2, b.pre2_t, W.Wn2, W.std, ge, batch, b.g_pre2, b.g_pre2_t, b.headv, s);
 
   // ---- reverse with tangents: head
   launch_colsum(s, b.headv, RP(F2), nullptr, RP(F2), nullptr, nullptr, N, F2, at("Wn2"), false, b.part);  // d s / d bn2 = 0
+  if (ge) hvp::launch_head_bias_seed(N, W.std, ge, batch, at("bn2"), s);  // energy seed: d S / d bn2 = - std sum_n ge[molecule(n)]
   dense("Wn1", "bn1", b.g_pre2, b.g_pre2_t, F2, b.hcat2, b.hcat2_t, F, N, F2, F);
   gemm(s, b.g_pre2, F2, W.Wn1T, F2, nullptr, b.g_h2, F, N, F, F2);
   gemm(s, b.g_pre2_t, F2, W.Wn1T, F2, nullptr, b.g_h2_t, F, N, F, F2);
@@ -1010,5 +1016,53 @@ int et_force_param_grads(tmdnet_model* m, hipStream_t s, const Graph& g, void* w
     hvp::launch_pair_to_atom(g, N, P, b.gdel_t, hv, s);
   }
   HIP_TRY(m, hipGetLastError());
+  g_et_last = b;
+  g_et_lastN = N;
+  g_et_lastP = P;
+  g_et_last_model = m;
+  return TMDNET_OK;
+}
+
+// intermediates of the last et_force_param_grads call by name (tests/test_gpu_hvp.py walks them against tests/et_hvp_host_mirror.py):
+// "x{l}" "x_t{l}" "vec{l}" "vec_t{l}" (l = 0 .. L), "l{l}.qkv" ".qkv_t" ".dkv" ".dkv_t" ".xagg" ".xagg_t" ".o_t" ".vdot_t", the head's
+// "pre2" "pre2_t" "g_pre2_t" "headv", the reverse sweep's scratch as its LAST layer (l = 0) left it: "g_qkv" "g_qkv_t" "g_vin" "g_vin_t"
+// "gq" "gq_t" "selfq" "selfq_t", and "slots" "slots_t" [L][2][P + 1][H][4], "g_x" "g_x_t" (at the embedding), "g_cut" "g_rh" "gdel" (+ "_t")
+int et_hvp_debug_tensor(tmdnet_model* m, hipStream_t s, const char* name, float* out, int64_t numel) {
+  if (g_et_last_model != m || g_et_lastN < 0) return fail(m, TMDNET_ERR_STATE, "no second-order pass has run on this handle (this thread)");
+  const tmdnet_et_hparams& hp = m->et->hp;
+  const int64_t F = hp.hidden_channels, L = hp.num_layers, H = hp.num_heads, N = g_et_lastN, P = g_et_lastP, P1 = P + 1, NF = N * F, F2 = F / 2;
+  const int64_t Wd = std::max<int64_t>(wd_of(hp), 1);
+  const EtHvpBuffers& b = g_et_last;
+  std::map<std::string, std::pair<const float*, int64_t>> t;
+  for (int l = 0; l <= L; ++l) {
+    const std::string k = std::to_string(l);
+    t["x" + k] = {b.x[l], NF};
+    t["x_t" + k] = {b.x_t[l], NF};
+    t["vec" + k] = {b.vec[l], 3 * NF};
+    t["vec_t" + k] = {b.vec_t[l], 3 * NF};
+  }
+  for (int l = 0; l < L; ++l) {
+    const EtHvpLayer& y = b.lay[l];
+    const std::string q = "l" + std::to_string(l) + ".";
+    t[q + "qkv"] = {y.qkv, 5 * NF};
+    t[q + "qkv_t"] = {y.qkv_t, 5 * NF};
+    t[q + "dkv"] = {y.dkv, P1 * Wd};
+    t[q + "dkv_t"] = {y.dkv_t, P1 * Wd};
+    t[q + "xagg"] = {y.xagg, NF};
+    t[q + "xagg_t"] = {y.xagg_t, NF};
+    t[q + "o_t"] = {y.o_t, 3 * NF};
+    t[q + "vdot_t"] = {y.vdot_t, NF};
+  }
+#define T_(field, n) t[#field] = {b.field, (n)}
+  T_(pre2, N * F2); T_(pre2_t, N * F2); T_(g_pre2_t, N * F2); T_(headv, N * F2); T_(g_qkv, 5 * NF); T_(g_qkv_t, 5 * NF); T_(g_vin, 3 * NF);
+  T_(g_vin_t, 3 * NF); T_(gq, 2 * P1 * Wd); T_(gq_t, 2 * P1 * Wd); T_(selfq, N * Wd); T_(selfq_t, N * Wd); T_(slots, L * 2 * P1 * H * 4);
+  T_(slots_t, L * 2 * P1 * H * 4); T_(g_x, NF); T_(g_x_t, NF); T_(g_cut, P1); T_(g_cut_t, P1); T_(g_rh, P1 * 3); T_(g_rh_t, P1 * 3);
+  T_(gdel, P * 3); T_(gdel_t, P * 3);
+#undef T_
+  auto it = t.find(name);
+  if (it == t.end()) return fail(m, TMDNET_ERR_INVALID, std::string("unknown second-order tensor: ") + name);
+  if (!out) return (int)it->second.second;
+  if (numel != it->second.second) return fail(m, TMDNET_ERR_INVALID, "second-order tensor: size mismatch");
+  HIP_TRY(m, hipMemcpyAsync(out, it->second.first, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s));
   return TMDNET_OK;
 }

@@ -1,9 +1,12 @@
 // Kernels of the analytic second-order pass of the Equivariant Transformer (gfx950): index arithmetic around the bodies of
 // tn_et_hvp_math.h (one logical thread = one (atom, channel), (atom, head), pair-row element or pair), as tn_hvp.hip is around
 // tn_hvp_math.h.  Specification oracle/et_second_order.py; the same bodies run on the host in tests/et_hvp_host_mirror.py.
-// Training path, written to be exact and simple, not tuned: the attention sweeps give a thread a whole (atom, head).
+// Training path, written to be exact and simple.  The attention sweeps: a block per atom, a thread per channel, the head sums by DPP /
+// shuffle over the head's hd lanes (the bodies' lane-group form with nc = 1; the host harness runs the same statements with a whole
+// head per thread): coalesced rows, accumulators in registers, every output written once.
 #include "tn_hvp.h"
 
+#include "tn_common.h"
 #include "tn_et_hvp_math.h"
 
 namespace tn {
@@ -12,6 +15,16 @@ namespace hvp {
 namespace {
 constexpr int TB = 256;
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); }
+struct EtRedHead {  // sum over the hd = 2^k <= 64 lanes of one head (all of them active together: a block = one atom, F % hd == 0)
+  int hd;
+  __device__ float operator()(float v) const {
+    v = row_sum(v, hd < 16 ? hd : 16);
+    if (hd >= 32) v += __shfl_xor(v, 16, 64);
+    if (hd >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+  }
+};
+inline int et_block(int F) { return ((F + 63) / 64) * 64; }
 #define IDX2(ROWS, W)                                                   \
   const int64_t idx_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  \
   if (idx_ >= (int64_t)(ROWS) * (W)) return;                            \
@@ -35,10 +48,12 @@ __global__ __launch_bounds__(TB) void k_et_embed_dual(int N, int F, const int64_
   IDX2(N, F)
   et_embed_dual(n, f, F, z, emb, x, x_t);
 }
-__global__ __launch_bounds__(TB) void k_et_attn_fwd_dual(Graph g, int N, int H, EtAttn A_, float* __restrict__ xagg,
+__global__ __launch_bounds__(512) void k_et_attn_fwd_dual(Graph g, int N, int H, EtAttn A_, float* __restrict__ xagg,
                                                          float* __restrict__ xagg_t, float* __restrict__ vagg, float* __restrict__ vagg_t) {
-  IDX2(N, H)
-  et_attn_fwd_dual(n, f, A_, g.rowptr, g.col, g.epair, g.esign, xagg, xagg_t, vagg, vagg_t);
+  (void)H;
+  const int t = blockIdx.x, c = threadIdx.x;  // a block per target atom, a thread per channel
+  if (t >= N || c >= A_.F) return;
+  et_attn_fwd_dual_g<1>(t, c, 1, EtRedHead{A_.hd}, A_, g.rowptr, g.col, g.epair, g.esign, xagg, xagg_t, vagg, vagg_t);
 }
 __global__ __launch_bounds__(TB) void k_et_update_dual(int N, int F, const float* __restrict__ x, const float* __restrict__ x_t,
                                                        const float* __restrict__ vec, const float* __restrict__ vec_t,
@@ -88,23 +103,27 @@ __global__ __launch_bounds__(TB) void k_et_update_bwd_dual(int N, int F, const f
   IDX2(N, F)
   et_update_bwd_dual(n, f, F, g_x, g_x_t, g_vec, g_vec_t, vp, vp_t, o, o_t, vdot, vdot_t, g_o, g_o_t, g_vp, g_vp_t);
 }
-__global__ __launch_bounds__(TB) void k_et_attn_bwd_tgt_dual(Graph g, int N, int H, EtAttn A_, const float* __restrict__ g_xagg,
+__global__ __launch_bounds__(512) void k_et_attn_bwd_tgt_dual(Graph g, int N, int H, EtAttn A_, const float* __restrict__ g_xagg,
                                                              const float* __restrict__ g_xagg_t, const float* __restrict__ g_vagg,
                                                              const float* __restrict__ g_vagg_t, float* __restrict__ g_qkv,
                                                              float* __restrict__ g_qkv_t, float* __restrict__ gq, float* __restrict__ gq_t,
                                                              int64_t dir_stride, float* __restrict__ selfq, float* __restrict__ selfq_t,
                                                              float* __restrict__ slots, float* __restrict__ slots_t, int64_t slot_dir_stride) {
-  IDX2(N, H)
-  et_attn_bwd_tgt_dual(n, f, H, A_, g.rowptr, g.col, g.epair, g.esign, g_xagg, g_xagg_t, g_vagg, g_vagg_t, g_qkv, g_qkv_t, gq, gq_t,
-                       dir_stride, selfq, selfq_t, slots, slots_t, slot_dir_stride);
+  const int t = blockIdx.x, c = threadIdx.x;
+  if (t >= N || c >= A_.F) return;
+  et_attn_bwd_tgt_dual_g<1>(t, c / A_.hd, c, 1, (c % A_.hd) == 0, EtRedHead{A_.hd}, H, A_, g.rowptr, g.col, g.epair, g.esign, g_xagg, g_xagg_t,
+                            g_vagg, g_vagg_t, g_qkv, g_qkv_t, gq, gq_t, dir_stride, selfq, selfq_t, slots, slots_t, slot_dir_stride);
 }
-__global__ __launch_bounds__(TB) void k_et_attn_bwd_src_dual(Graph g, int N, int H, EtAttn A_, const float* __restrict__ g_xagg,
+__global__ __launch_bounds__(512) void k_et_attn_bwd_src_dual(Graph g, int N, int H, EtAttn A_, const float* __restrict__ g_xagg,
                                                              const float* __restrict__ g_xagg_t, const float* __restrict__ g_vagg,
                                                              const float* __restrict__ g_vagg_t, float* __restrict__ g_qkv,
                                                              float* __restrict__ g_qkv_t, float* __restrict__ g_vec_in,
                                                              float* __restrict__ g_vec_in_t) {
-  IDX2(N, H)
-  et_attn_bwd_src_dual(n, f, A_, g.rowptr, g.col, g.epair, g.esign, g_xagg, g_xagg_t, g_vagg, g_vagg_t, g_qkv, g_qkv_t, g_vec_in, g_vec_in_t);
+  (void)H;
+  const int s_ = blockIdx.x, c = threadIdx.x;
+  if (s_ >= N || c >= A_.F) return;
+  et_attn_bwd_src_dual_g<1>(s_, c, 1, EtRedHead{A_.hd}, A_, g.rowptr, g.col, g.epair, g.esign, g_xagg, g_xagg_t, g_vagg, g_vagg_t, g_qkv, g_qkv_t,
+                            g_vec_in, g_vec_in_t);
 }
 __global__ __launch_bounds__(TB) void k_et_filter_gpre_dual(int64_t total, int P, int Wd, const float* __restrict__ gq,
                                                             const float* __restrict__ gq_t, int64_t dir_stride,
@@ -175,7 +194,7 @@ void launch_et_embed_dual(int N, int F, const int64_t* z, const float* emb, floa
 }
 void launch_et_attn_fwd_dual(const Graph& g, int N, int H, const EtAttn& A_, float* xagg, float* xagg_t, float* vagg, float* vagg_t,
                              hipStream_t s) {
-  LAUNCH(k_et_attn_fwd_dual, (int64_t)N * H, g, N, H, A_, xagg, xagg_t, vagg, vagg_t);
+  if (N > 0) hipLaunchKernelGGL(k_et_attn_fwd_dual, dim3(N), dim3(et_block(A_.F)), 0, s, g, N, H, A_, xagg, xagg_t, vagg, vagg_t);
 }
 void launch_et_update_dual(int N, int F, const float* x, const float* x_t, const float* vec, const float* vec_t, const float* vp,
                            const float* vp_t, const float* o, const float* o_t, const float* vagg, const float* vagg_t, float* xn,
@@ -208,9 +227,11 @@ void launch_et_attn_bwd_dual(const Graph& g, int N, int H, const EtAttn& A_, con
                              const float* g_vagg_t, float* g_qkv, float* g_qkv_t, float* g_vec_in, float* g_vec_in_t, float* gq, float* gq_t,
                              int64_t dir_stride, float* selfq, float* selfq_t, float* slots, float* slots_t, int64_t slot_dir_stride,
                              hipStream_t s) {
-  LAUNCH(k_et_attn_bwd_tgt_dual, (int64_t)N * H, g, N, H, A_, g_xagg, g_xagg_t, g_vagg, g_vagg_t, g_qkv, g_qkv_t, gq, gq_t, dir_stride, selfq,
-         selfq_t, slots, slots_t, slot_dir_stride);
-  LAUNCH(k_et_attn_bwd_src_dual, (int64_t)N * H, g, N, H, A_, g_xagg, g_xagg_t, g_vagg, g_vagg_t, g_qkv, g_qkv_t, g_vec_in, g_vec_in_t);
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_et_attn_bwd_tgt_dual, dim3(N), dim3(et_block(A_.F)), 0, s, g, N, H, A_, g_xagg, g_xagg_t, g_vagg, g_vagg_t, g_qkv,
+                     g_qkv_t, gq, gq_t, dir_stride, selfq, selfq_t, slots, slots_t, slot_dir_stride);
+  hipLaunchKernelGGL(k_et_attn_bwd_src_dual, dim3(N), dim3(et_block(A_.F)), 0, s, g, N, H, A_, g_xagg, g_xagg_t, g_vagg, g_vagg_t, g_qkv,
+                     g_qkv_t, g_vec_in, g_vec_in_t);
 }
 void launch_et_filter_gpre_dual(int P, int Wd, const float* gq, const float* gq_t, int64_t dir_stride, const float* self_g,
                                 const float* self_g_t, const float* ekv, const float* ekv_t, float* g_e, float* g_e_t, hipStream_t s) {

@@ -52,18 +52,23 @@ struct EtAttn {  // operands of the attention sweeps of one layer (all with thei
   const float *qkv, *qkv_t, *vec, *vec_t, *dkv, *dkv_t, *C, *C_t, *prhat, *rhat_t;
   int F, hd, Wd, ok, ov, vc, P;  // vc: the cutoff scales the values (vector_cutoff) instead of the attention weights
 };
-// attention weight of edge (t <- s) for head h and its tangent: a = sum_{c in h} q_t k_s dk, A = silu(a) ca
-HVP_FN void et_edge_weight(const EtAttn& A_, int t, int s, int p, int h, float& a, float& a_t) {
+// The attention sweeps in LANE-GROUP form: a logical thread holds `nc` channels c0 .. c0 + nc - 1 of ONE head and red(v) is the sum of
+// v over the head's channels.  Kernels: nc = 1 (the lane's own channel), red = sum over the head's hd lanes (a block = an atom, so
+// the edge loop is uniform); host harness: nc = hd (the whole head in one thread), red = identity.  Same statements in both; NC is
+// the capacity of the per-channel arrays.  Accumulators live in registers and every output is written once.
+constexpr int ET_MAXHD = 64;
+struct EtRedOne {
+  HVP_FN float operator()(float v) const { return v; }
+};
+// channel c's term of the attention logit of edge (t <- s) and of its tangent: a = sum_{c in h} q_t k_s dk
+HVP_FN void et_edge_weight_c(const EtAttn& A_, int t, int s, int p, int c, float& a, float& a_t) {
   const int F = A_.F, F5 = 5 * A_.F;
-  a = a_t = 0.f;
-  for (int c = h * A_.hd; c < (h + 1) * A_.hd; ++c) {
-    const float q = A_.qkv[(int64_t)t * F5 + c], qt = A_.qkv_t[(int64_t)t * F5 + c];
-    const float k = A_.qkv[(int64_t)s * F5 + F + c], kt = A_.qkv_t[(int64_t)s * F5 + F + c];
-    const float dk = A_.ok >= 0 ? A_.dkv[(int64_t)p * A_.Wd + A_.ok + c] : 1.0f;
-    const float dkt = A_.ok >= 0 ? A_.dkv_t[(int64_t)p * A_.Wd + A_.ok + c] : 0.0f;
-    a += q * k * dk;
-    a_t += qt * k * dk + q * kt * dk + q * k * dkt;
-  }
+  const float q = A_.qkv[(int64_t)t * F5 + c], qt = A_.qkv_t[(int64_t)t * F5 + c];
+  const float k = A_.qkv[(int64_t)s * F5 + F + c], kt = A_.qkv_t[(int64_t)s * F5 + F + c];
+  const float dk = A_.ok >= 0 ? A_.dkv[(int64_t)p * A_.Wd + A_.ok + c] : 1.0f;
+  const float dkt = A_.ok >= 0 ? A_.dkv_t[(int64_t)p * A_.Wd + A_.ok + c] : 0.0f;
+  a += q * k * dk;
+  a_t += qt * k * dk + q * kt * dk + q * k * dkt;
 }
 // value filters of channel c (three thirds) and the scaled values s_j = v_j[s] cv f_j
 HVP_FN void et_edge_values(const EtAttn& A_, int s, int p, int c, float cv, float cvt, float sv[3], float svt[3], float v3[3], float v3t[3],
@@ -90,32 +95,50 @@ HVP_FN void et_edge_geometry(const EtAttn& A_, int p, float sg, float r[3], floa
   ca = A_.vc ? 1.0f : c;
   cat = A_.vc ? 0.0f : ct;
 }
-// (target atom t, head h): xagg[t, c] = sum_e s_x A ;  vagg[t, :, c] = sum_e vec[s] s_1 + s_2 r        (torchmd_et.py:368-426)
-HVP_FN void et_attn_fwd_dual(int t, int h, const EtAttn& A_, const int* rowptr, const int* col, const int* epair, const float* esign,
-                             float* xagg, float* xagg_t, float* vagg, float* vagg_t) {
-  const int F = A_.F, hd = A_.hd;
-  for (int c = h * hd; c < (h + 1) * hd; ++c) {
-    xagg[(int64_t)t * F + c] = xagg_t[(int64_t)t * F + c] = 0.f;
-    for (int x = 0; x < 3; ++x) vagg[((int64_t)t * 3 + x) * F + c] = vagg_t[((int64_t)t * 3 + x) * F + c] = 0.f;
+// target atom t, the channels c0 .. of one head: xagg[t, c] = sum_e s_x A ;  vagg[t, :, c] = sum_e vec[s] s_1 + s_2 r   (torchmd_et.py:368-426)
+template <int NC, class Red>
+HVP_FN void et_attn_fwd_dual_g(int t, int c0, int nc, Red red, const EtAttn& A_, const int* rowptr, const int* col, const int* epair,
+                               const float* esign, float* xagg, float* xagg_t, float* vagg, float* vagg_t) {
+  const int F = A_.F;
+  float xa[NC], xat[NC], va[NC][3], vat[NC][3];
+  for (int i = 0; i < nc; ++i) {
+    xa[i] = xat[i] = 0.f;
+    for (int x = 0; x < 3; ++x) va[i][x] = vat[i][x] = 0.f;
   }
   for (int e = rowptr[t]; e < rowptr[t + 1]; ++e) {
     const int s = col[e], p = epair[e];
-    float r[3], rt[3], cv, cvt, ca, cat, a, a_t;
+    float r[3], rt[3], cv, cvt, ca, cat, a = 0.f, a_t = 0.f;
     et_edge_geometry(A_, p, esign[e], r, rt, cv, cvt, ca, cat);
-    et_edge_weight(A_, t, s, p, h, a, a_t);
+    for (int i = 0; i < nc; ++i) et_edge_weight_c(A_, t, s, p, c0 + i, a, a_t);
+    a = red(a);
+    a_t = red(a_t);
     const float Aw = silu0(a) * ca, Awt = silu1(a) * a_t * ca + silu0(a) * cat;
-    for (int c = h * hd; c < (h + 1) * hd; ++c) {
+    for (int i = 0; i < nc; ++i) {
+      const int c = c0 + i;
       float sv[3], svt[3], v3[3], v3t[3], f3[3], f3t[3];
       et_edge_values(A_, s, p, c, cv, cvt, sv, svt, v3, v3t, f3, f3t);
-      xagg[(int64_t)t * F + c] += sv[0] * Aw;
-      xagg_t[(int64_t)t * F + c] += svt[0] * Aw + sv[0] * Awt;
+      xa[i] += sv[0] * Aw;
+      xat[i] += svt[0] * Aw + sv[0] * Awt;
       for (int x = 0; x < 3; ++x) {
         const float ve = A_.vec[((int64_t)s * 3 + x) * F + c], vet = A_.vec_t[((int64_t)s * 3 + x) * F + c];
-        vagg[((int64_t)t * 3 + x) * F + c] += ve * sv[1] + sv[2] * r[x];
-        vagg_t[((int64_t)t * 3 + x) * F + c] += vet * sv[1] + ve * svt[1] + svt[2] * r[x] + sv[2] * rt[x];
+        va[i][x] += ve * sv[1] + sv[2] * r[x];
+        vat[i][x] += vet * sv[1] + ve * svt[1] + svt[2] * r[x] + sv[2] * rt[x];
       }
     }
   }
+  for (int i = 0; i < nc; ++i) {
+    const int c = c0 + i;
+    xagg[(int64_t)t * F + c] = xa[i];
+    xagg_t[(int64_t)t * F + c] = xat[i];
+    for (int x = 0; x < 3; ++x) {
+      vagg[((int64_t)t * 3 + x) * F + c] = va[i][x];
+      vagg_t[((int64_t)t * 3 + x) * F + c] = vat[i][x];
+    }
+  }
+}
+HVP_FN void et_attn_fwd_dual(int t, int h, const EtAttn& A_, const int* rowptr, const int* col, const int* epair, const float* esign,
+                             float* xagg, float* xagg_t, float* vagg, float* vagg_t) {  // one thread = a whole head (host harness)
+  et_attn_fwd_dual_g<ET_MAXHD>(t, h * A_.hd, A_.hd, EtRedOne{}, A_, rowptr, col, epair, esign, xagg, xagg_t, vagg, vagg_t);
 }
 // x_new = x + vdot o2 + o3, vec_new = vec + vec3 o1 + vagg, vdot = sum_a vec1 vec2                      (torchmd_et.py:345-366)
 HVP_FN void et_update_dual(int n, int f, int F, const float* x, const float* x_t, const float* vec, const float* vec_t, const float* vp,
@@ -247,28 +270,40 @@ HVP_FN void et_update_bwd_dual(int n, int f, int F, const float* g_x, const floa
 }
 
 // the adjoint quantities of one edge (t <- s) and head h that both reverse sweeps need: everything up to g_a (per head) and the
-// per-channel adjoints of the scaled values g_s[j]
+// head quantities of one edge in the reverse sweeps
 struct EtEdgeAdj {
   float a, a_t, Aw, Awt, g_a, g_a_t, g_ca, g_ca_t;  // g_ca: this head's part of the adjoint of the attention-side cutoff factor
 };
-HVP_FN void et_edge_adjoint_head(const EtAttn& A_, int t, int s, int p, int h, float cv, float cvt, float ca, float cat, const float* g_xagg,
-                                 const float* g_xagg_t, EtEdgeAdj& E_) {
-  const int F = A_.F;
-  et_edge_weight(A_, t, s, p, h, E_.a, E_.a_t);
-  const float a = E_.a, at = E_.a_t;
+// from the head sums a = sum_c q k dk and g_A = sum_c g_xagg[t, c] s_x (and their tangents)
+HVP_FN void et_edge_adjoint_of(float a, float at, float gA, float gAt, float ca, float cat, EtEdgeAdj& E_) {
+  E_.a = a;
+  E_.a_t = at;
   E_.Aw = silu0(a) * ca;
   E_.Awt = silu1(a) * at * ca + silu0(a) * cat;
-  float gA = 0.f, gAt = 0.f;  // g_A = sum_{c in h} g_xagg[t, c] s_x
-  for (int c = h * A_.hd; c < (h + 1) * A_.hd; ++c) {
-    float sv[3], svt[3], v3[3], v3t[3], f3[3], f3t[3];
-    et_edge_values(A_, s, p, c, cv, cvt, sv, svt, v3, v3t, f3, f3t);
-    gA += g_xagg[(int64_t)t * F + c] * sv[0];
-    gAt += g_xagg_t[(int64_t)t * F + c] * sv[0] + g_xagg[(int64_t)t * F + c] * svt[0];
-  }
   E_.g_a = gA * silu1(a) * ca;
   E_.g_a_t = gAt * silu1(a) * ca + gA * silu2(a) * at * ca + gA * silu1(a) * cat;
   E_.g_ca = gA * silu0(a);
   E_.g_ca_t = gAt * silu0(a) + gA * silu1(a) * at;
+}
+// the head sums of edge (t <- s) over this thread's channels (values kept per channel for the statements that follow), then reduced
+template <int NC, class Red>
+HVP_FN void et_edge_head(const EtAttn& A_, int t, int s, int p, int c0, int nc, Red red, float cv, float cvt, float ca, float cat,
+                         const float* g_xagg, const float* g_xagg_t, float sv[][3], float svt[][3], float v3[][3], float v3t[][3],
+                         float f3[][3], float f3t[][3], EtEdgeAdj& E_) {
+  const int F = A_.F;
+  float a = 0.f, at = 0.f, gA = 0.f, gAt = 0.f;
+  for (int i = 0; i < nc; ++i) {
+    const int c = c0 + i;
+    et_edge_weight_c(A_, t, s, p, c, a, at);
+    et_edge_values(A_, s, p, c, cv, cvt, sv[i], svt[i], v3[i], v3t[i], f3[i], f3t[i]);
+    gA += g_xagg[(int64_t)t * F + c] * sv[i][0];
+    gAt += g_xagg_t[(int64_t)t * F + c] * sv[i][0] + g_xagg[(int64_t)t * F + c] * svt[i][0];
+  }
+  a = red(a);
+  at = red(at);
+  gA = red(gA);
+  gAt = red(gAt);
+  et_edge_adjoint_of(a, at, gA, gAt, ca, cat, E_);
 }
 // per-channel adjoints of the scaled values of edge (t <- s): g_s = ( g_xagg[t] A , sum_x g_vagg[t, x] vec[s, x] , sum_x g_vagg[t, x] r_x )
 HVP_FN void et_edge_gs(const EtAttn& A_, int t, int s, int c, const float r[3], const float rt[3], float Aw, float Awt, const float* g_xagg,
@@ -287,56 +322,71 @@ HVP_FN void et_edge_gs(const EtAttn& A_, int t, int s, int c, const float r[3], 
     gst[2] += gvt * r[x] + gv * rt[x];
   }
 }
-// TARGET role, (atom t, head h): g_q[t, c] over the row's edges; per directed edge the filter adjoints g_dk, g_dv (gq[dir][pair][Wd],
-// self edge: selfq[t][Wd]) and this head's parts of the cutoff / unit-vector adjoints: slots[dir][pair][h][5] = (g_cutoff, g_r[3], 0)
+// TARGET role, atom t, channels c0 .. of head h: g_q[t, c] over the row's edges; per directed edge the filter adjoints g_dk, g_dv
+// (gq[dir][pair][Wd], self edge: selfq[t][Wd]) and this head's parts of the cutoff / unit-vector adjoints:
+// slots[dir][pair][h][4] = (g_cutoff, g_r[3]), written by the head's `leader` thread
 //   g_cutoff = g_cv (vector_cutoff: the channels' sum g_s v f) or g_ca;  g_r = sum_c g_vagg[t, :, c] s_2
-HVP_FN void et_attn_bwd_tgt_dual(int t, int h, int H, const EtAttn& A_, const int* rowptr, const int* col, const int* epair, const float* esign,
-                                 const float* g_xagg, const float* g_xagg_t, const float* g_vagg, const float* g_vagg_t, float* g_qkv,
-                                 float* g_qkv_t, float* gq, float* gq_t, int64_t dir_stride, float* selfq, float* selfq_t, float* slots,
-                                 float* slots_t, int64_t slot_dir_stride) {
-  const int F = A_.F, hd = A_.hd, F5 = 5 * A_.F, Wd = A_.Wd;
-  for (int c = h * hd; c < (h + 1) * hd; ++c) g_qkv[(int64_t)t * F5 + c] = g_qkv_t[(int64_t)t * F5 + c] = 0.f;
+template <int NC, class Red>
+HVP_FN void et_attn_bwd_tgt_dual_g(int t, int h, int c0, int nc, bool leader, Red red, int H, const EtAttn& A_, const int* rowptr,
+                                   const int* col, const int* epair, const float* esign, const float* g_xagg, const float* g_xagg_t,
+                                   const float* g_vagg, const float* g_vagg_t, float* g_qkv, float* g_qkv_t, float* gq, float* gq_t,
+                                   int64_t dir_stride, float* selfq, float* selfq_t, float* slots, float* slots_t,
+                                   int64_t slot_dir_stride) {
+  const int F = A_.F, F5 = 5 * A_.F, Wd = A_.Wd;
+  float gqa[NC], gqat[NC];
+  for (int i = 0; i < nc; ++i) gqa[i] = gqat[i] = 0.f;
   for (int e = rowptr[t]; e < rowptr[t + 1]; ++e) {
     const int s = col[e], p = epair[e];
     const float sg = esign[e];
     const bool self = sg == 0.f || p >= A_.P;
     float r[3], rt[3], cv, cvt, ca, cat;
     et_edge_geometry(A_, p, sg, r, rt, cv, cvt, ca, cat);
+    float sv[NC][3], svt[NC][3], v3[NC][3], v3t[NC][3], f3[NC][3], f3t[NC][3];
     EtEdgeAdj E_;
-    et_edge_adjoint_head(A_, t, s, p, h, cv, cvt, ca, cat, g_xagg, g_xagg_t, E_);
+    et_edge_head<NC>(A_, t, s, p, c0, nc, red, cv, cvt, ca, cat, g_xagg, g_xagg_t, sv, svt, v3, v3t, f3, f3t, E_);
     float* fo = self ? selfq + (int64_t)t * Wd : gq + (sg > 0.f ? 0 : dir_stride) + (int64_t)p * Wd;
     float* fot = self ? selfq_t + (int64_t)t * Wd : gq_t + (sg > 0.f ? 0 : dir_stride) + (int64_t)p * Wd;
-    float gcut = A_.vc ? 0.f : E_.g_ca, gcutt = A_.vc ? 0.f : E_.g_ca_t, gr[3] = {0.f, 0.f, 0.f}, grt[3] = {0.f, 0.f, 0.f};
-    for (int c = h * hd; c < (h + 1) * hd; ++c) {
+    float gcut = 0.f, gcutt = 0.f, gr[3] = {0.f, 0.f, 0.f}, grt[3] = {0.f, 0.f, 0.f};  // this thread's channels' part
+    for (int i = 0; i < nc; ++i) {
+      const int c = c0 + i;
       const float q = A_.qkv[(int64_t)t * F5 + c], qt = A_.qkv_t[(int64_t)t * F5 + c];
       const float k = A_.qkv[(int64_t)s * F5 + F + c], kt = A_.qkv_t[(int64_t)s * F5 + F + c];
       const float dk = A_.ok >= 0 ? A_.dkv[(int64_t)p * Wd + A_.ok + c] : 1.0f, dkt = A_.ok >= 0 ? A_.dkv_t[(int64_t)p * Wd + A_.ok + c] : 0.0f;
-      g_qkv[(int64_t)t * F5 + c] += E_.g_a * k * dk;
-      g_qkv_t[(int64_t)t * F5 + c] += E_.g_a_t * k * dk + E_.g_a * kt * dk + E_.g_a * k * dkt;
+      gqa[i] += E_.g_a * k * dk;
+      gqat[i] += E_.g_a_t * k * dk + E_.g_a * kt * dk + E_.g_a * k * dkt;
       if (A_.ok >= 0) {
         fo[A_.ok + c] = E_.g_a * q * k;
         fot[A_.ok + c] = E_.g_a_t * q * k + E_.g_a * qt * k + E_.g_a * q * kt;
       }
-      float sv[3], svt[3], v3[3], v3t[3], f3[3], f3t[3], gs[3], gst[3];
-      et_edge_values(A_, s, p, c, cv, cvt, sv, svt, v3, v3t, f3, f3t);
+      float gs[3], gst[3];
       et_edge_gs(A_, t, s, c, r, rt, E_.Aw, E_.Awt, g_xagg, g_xagg_t, g_vagg, g_vagg_t, gs, gst);
       for (int j = 0; j < 3; ++j) {
         if (A_.ov >= 0) {
-          fo[A_.ov + j * F + c] = gs[j] * v3[j] * cv;
-          fot[A_.ov + j * F + c] = gst[j] * v3[j] * cv + gs[j] * v3t[j] * cv + gs[j] * v3[j] * cvt;
+          fo[A_.ov + j * F + c] = gs[j] * v3[i][j] * cv;
+          fot[A_.ov + j * F + c] = gst[j] * v3[i][j] * cv + gs[j] * v3t[i][j] * cv + gs[j] * v3[i][j] * cvt;
         }
         if (A_.vc) {
-          gcut += gs[j] * v3[j] * f3[j];
-          gcutt += gst[j] * v3[j] * f3[j] + gs[j] * v3t[j] * f3[j] + gs[j] * v3[j] * f3t[j];
+          gcut += gs[j] * v3[i][j] * f3[i][j];
+          gcutt += gst[j] * v3[i][j] * f3[i][j] + gs[j] * v3t[i][j] * f3[i][j] + gs[j] * v3[i][j] * f3t[i][j];
         }
       }
       for (int x = 0; x < 3; ++x) {
         const float gv = g_vagg[((int64_t)t * 3 + x) * F + c], gvt = g_vagg_t[((int64_t)t * 3 + x) * F + c];
-        gr[x] += gv * sv[2];
-        grt[x] += gvt * sv[2] + gv * svt[2];
+        gr[x] += gv * sv[i][2];
+        grt[x] += gvt * sv[i][2] + gv * svt[i][2];
       }
     }
-    if (!self) {
+    gcut = red(gcut);
+    gcutt = red(gcutt);
+    for (int x = 0; x < 3; ++x) {
+      gr[x] = red(gr[x]);
+      grt[x] = red(grt[x]);
+    }
+    if (!A_.vc) {
+      gcut = E_.g_ca;
+      gcutt = E_.g_ca_t;
+    }
+    if (!self && leader) {
       const int64_t o = (sg > 0.f ? 0 : slot_dir_stride) + ((int64_t)p * H + h) * 4;
       slots[o] = gcut;
       slots_t[o] = gcutt;
@@ -346,43 +396,76 @@ HVP_FN void et_attn_bwd_tgt_dual(int t, int h, int H, const EtAttn& A_, const in
       }
     }
   }
+  for (int i = 0; i < nc; ++i) {
+    g_qkv[(int64_t)t * F5 + c0 + i] = gqa[i];
+    g_qkv_t[(int64_t)t * F5 + c0 + i] = gqat[i];
+  }
 }
-// SOURCE role, (atom s, head h): over the edges (t <- s) of the row (the graph is symmetric: row s lists the targets t):
-//   g_k[s, c] += g_a q_t dk ;  g_v_j[s, c] += g_s_j cv f_j ;  g_vec[s, :, c] += g_vagg[t, :, c] s_1
-HVP_FN void et_attn_bwd_src_dual(int s, int h, const EtAttn& A_, const int* rowptr, const int* col, const int* epair, const float* esign,
+HVP_FN void et_attn_bwd_tgt_dual(int t, int h, int H, const EtAttn& A_, const int* rowptr, const int* col, const int* epair, const float* esign,
                                  const float* g_xagg, const float* g_xagg_t, const float* g_vagg, const float* g_vagg_t, float* g_qkv,
-                                 float* g_qkv_t, float* g_vec_in, float* g_vec_in_t) {
-  const int F = A_.F, hd = A_.hd, F5 = 5 * A_.F;
-  for (int c = h * hd; c < (h + 1) * hd; ++c) {
-    for (int j = 1; j < 5; ++j) g_qkv[(int64_t)s * F5 + j * F + c] = g_qkv_t[(int64_t)s * F5 + j * F + c] = 0.f;
-    for (int x = 0; x < 3; ++x) g_vec_in[((int64_t)s * 3 + x) * F + c] = g_vec_in_t[((int64_t)s * 3 + x) * F + c] = 0.f;
+                                 float* g_qkv_t, float* gq, float* gq_t, int64_t dir_stride, float* selfq, float* selfq_t, float* slots,
+                                 float* slots_t, int64_t slot_dir_stride) {  // one thread = a whole head (host harness)
+  et_attn_bwd_tgt_dual_g<ET_MAXHD>(t, h, h * A_.hd, A_.hd, true, EtRedOne{}, H, A_, rowptr, col, epair, esign, g_xagg, g_xagg_t, g_vagg,
+                                   g_vagg_t, g_qkv, g_qkv_t, gq, gq_t, dir_stride, selfq, selfq_t, slots, slots_t, slot_dir_stride);
+}
+// SOURCE role, atom s, channels c0 .. of one head: over the edges (t <- s) of the row (the graph is symmetric: row s lists the targets t):
+//   g_k[s, c] += g_a q_t dk ;  g_v_j[s, c] += g_s_j cv f_j ;  g_vec[s, :, c] += g_vagg[t, :, c] s_1
+template <int NC, class Red>
+HVP_FN void et_attn_bwd_src_dual_g(int s, int c0, int nc, Red red, const EtAttn& A_, const int* rowptr, const int* col, const int* epair,
+                                   const float* esign, const float* g_xagg, const float* g_xagg_t, const float* g_vagg,
+                                   const float* g_vagg_t, float* g_qkv, float* g_qkv_t, float* g_vec_in, float* g_vec_in_t) {
+  const int F = A_.F, F5 = 5 * A_.F;
+  float gk[NC], gkt[NC], gv3[NC][3], gv3t[NC][3], gve[NC][3], gvet[NC][3];
+  for (int i = 0; i < nc; ++i) {
+    gk[i] = gkt[i] = 0.f;
+    for (int x = 0; x < 3; ++x) gv3[i][x] = gv3t[i][x] = gve[i][x] = gvet[i][x] = 0.f;
   }
   for (int e = rowptr[s]; e < rowptr[s + 1]; ++e) {
     const int t = col[e], p = epair[e];
     // the edge (t <- s) seen from row s: its sign is the one of row t's entry, i.e. minus this row's
     float r[3], rt[3], cv, cvt, ca, cat;
     et_edge_geometry(A_, p, -esign[e], r, rt, cv, cvt, ca, cat);
+    float sv[NC][3], svt[NC][3], v3[NC][3], v3t[NC][3], f3[NC][3], f3t[NC][3];
     EtEdgeAdj E_;
-    et_edge_adjoint_head(A_, t, s, p, h, cv, cvt, ca, cat, g_xagg, g_xagg_t, E_);
-    for (int c = h * hd; c < (h + 1) * hd; ++c) {
+    et_edge_head<NC>(A_, t, s, p, c0, nc, red, cv, cvt, ca, cat, g_xagg, g_xagg_t, sv, svt, v3, v3t, f3, f3t, E_);
+    for (int i = 0; i < nc; ++i) {
+      const int c = c0 + i;
       const float q = A_.qkv[(int64_t)t * F5 + c], qt = A_.qkv_t[(int64_t)t * F5 + c];
       const float dk = A_.ok >= 0 ? A_.dkv[(int64_t)p * A_.Wd + A_.ok + c] : 1.0f, dkt = A_.ok >= 0 ? A_.dkv_t[(int64_t)p * A_.Wd + A_.ok + c] : 0.0f;
-      g_qkv[(int64_t)s * F5 + F + c] += E_.g_a * q * dk;
-      g_qkv_t[(int64_t)s * F5 + F + c] += E_.g_a_t * q * dk + E_.g_a * qt * dk + E_.g_a * q * dkt;
-      float sv[3], svt[3], v3[3], v3t[3], f3[3], f3t[3], gs[3], gst[3];
-      et_edge_values(A_, s, p, c, cv, cvt, sv, svt, v3, v3t, f3, f3t);
+      gk[i] += E_.g_a * q * dk;
+      gkt[i] += E_.g_a_t * q * dk + E_.g_a * qt * dk + E_.g_a * q * dkt;
+      float gs[3], gst[3];
       et_edge_gs(A_, t, s, c, r, rt, E_.Aw, E_.Awt, g_xagg, g_xagg_t, g_vagg, g_vagg_t, gs, gst);
       for (int j = 0; j < 3; ++j) {
-        g_qkv[(int64_t)s * F5 + (2 + j) * F + c] += gs[j] * cv * f3[j];
-        g_qkv_t[(int64_t)s * F5 + (2 + j) * F + c] += gst[j] * cv * f3[j] + gs[j] * cvt * f3[j] + gs[j] * cv * f3t[j];
+        gv3[i][j] += gs[j] * cv * f3[i][j];
+        gv3t[i][j] += gst[j] * cv * f3[i][j] + gs[j] * cvt * f3[i][j] + gs[j] * cv * f3t[i][j];
       }
       for (int x = 0; x < 3; ++x) {
         const float gv = g_vagg[((int64_t)t * 3 + x) * F + c], gvt = g_vagg_t[((int64_t)t * 3 + x) * F + c];
-        g_vec_in[((int64_t)s * 3 + x) * F + c] += gv * sv[1];
-        g_vec_in_t[((int64_t)s * 3 + x) * F + c] += gvt * sv[1] + gv * svt[1];
+        gve[i][x] += gv * sv[i][1];
+        gvet[i][x] += gvt * sv[i][1] + gv * svt[i][1];
       }
     }
   }
+  for (int i = 0; i < nc; ++i) {
+    const int c = c0 + i;
+    g_qkv[(int64_t)s * F5 + F + c] = gk[i];
+    g_qkv_t[(int64_t)s * F5 + F + c] = gkt[i];
+    for (int j = 0; j < 3; ++j) {
+      g_qkv[(int64_t)s * F5 + (2 + j) * F + c] = gv3[i][j];
+      g_qkv_t[(int64_t)s * F5 + (2 + j) * F + c] = gv3t[i][j];
+    }
+    for (int x = 0; x < 3; ++x) {
+      g_vec_in[((int64_t)s * 3 + x) * F + c] = gve[i][x];
+      g_vec_in_t[((int64_t)s * 3 + x) * F + c] = gvet[i][x];
+    }
+  }
+}
+HVP_FN void et_attn_bwd_src_dual(int s, int h, const EtAttn& A_, const int* rowptr, const int* col, const int* epair, const float* esign,
+                                 const float* g_xagg, const float* g_xagg_t, const float* g_vagg, const float* g_vagg_t, float* g_qkv,
+                                 float* g_qkv_t, float* g_vec_in, float* g_vec_in_t) {  // one thread = a whole head (host harness)
+  et_attn_bwd_src_dual_g<ET_MAXHD>(s, h * A_.hd, A_.hd, EtRedOne{}, A_, rowptr, col, epair, esign, g_xagg, g_xagg_t, g_vagg, g_vagg_t, g_qkv,
+                                   g_qkv_t, g_vec_in, g_vec_in_t);
 }
 // filter rows: adjoint of dkv per PAIR = the two directions' rows (self pair: the column sums over the atoms' self edges), through
 // dkv = silu(ekv):  g_e = g_dkv silu'(ekv)                                                      (idx over (P + 1) * Wd)

@@ -30,7 +30,12 @@ void launch_group_dual(int N, int F, const float* Pn, const float* Pn_t, const f
 void launch_update_dual(int N, int F, const float* Xh, const float* Xh_t, const float* D, const float* D_t, const float* kap, float* Xn,
                         float* Xn_t, hipStream_t s);
 void launch_feat_dual(int N, int F, const float* X, const float* X_t, float* feat, float* feat_t, hipStream_t s);
-void launch_head_dual(int N, int H, const float* ao, const float* ao_t, const float* O2, float std_, float* g_ao, float* g_ao_t,
+// ge != null: the energy seed of one-pass training (tn_hvp_math.h head_dual); launch_head_bias_seed: out[0] = - std sum_n ge[molecule(n)];
+// launch_row_seed: x_t[n, :] -= ge[molecule(n)] x[n, :]
+void launch_head_bias_seed(int N, float std_, const float* ge, const int64_t* batch, float* out, hipStream_t s);
+void launch_row_seed(int N, int W, const float* ge, const int64_t* batch, const float* x, float* x_t, hipStream_t s);
+void launch_head_dual(int N, int H, const float* ao, const float* ao_t, const float* O2, float std_, const float* ge, const int64_t* batch,
+                      float* g_ao, float* g_ao_t,
                       float* headv, hipStream_t s);
 void launch_readout_bwd_dual(int N, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G,
                              float* G_t, hipStream_t s);
@@ -110,6 +115,38 @@ void launch_et_geom_dual(const Graph& g, int P, const float* d_t, const float* r
                          const float* g_cut_t, const float* g_dphi, const float* g_dphi_t, const float* g_rh, const float* g_rh_t, float* gdel,
                          float* gdel_t, hipStream_t s);
 void launch_add2(int64_t n, const float* a, float* o, hipStream_t s);  // o += a
+
+// ---- TensorNet2 + Coulomb head (tn_tn2_hvp.hip; bodies in tn_tn2_hvp_math.h)
+void launch_cp_feat_dual(int N, int F, const float* X, const float* X_t, float* feat, float* feat_t, hipStream_t s);
+void launch_cp_feat_bwd_dual(int N, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G, float* G_t,
+                             hipStream_t s);
+void launch_cp_qeq_dual(const Graph& g, int N, int B, int qd, const int64_t* batch, const float* Qmol, const float* out, const float* out_t,
+                        float* sums, float* ch, float* ch_t, int ldc, int off, hipStream_t s);
+void launch_cp_qeq_bwd_dual(const Graph& g, int N, int B, int qd, const int64_t* batch, const float* Qmol, const float* out,
+                            const float* out_t, const float* sums, const float* g_ch, const float* g_ch_t, int ldg, int off, float* bs,
+                            float* g_out, float* g_out_t, hipStream_t s);
+void launch_tn2_edge_pre1_dual(const Graph& g, int E, int N, int F, const float* Ap, const float* Ap_t, const float* Bt, const float* Bt_t,
+                               const float* Cs, const float* Cs_t, float* pre1, float* e1_t, float* he1, float* he1_t, hipStream_t s);
+void launch_tn2_w_dual(const Graph& g, int E, int F3, const float* e3, const float* e3_t, const float* C, const float* C_t, float* w,
+                       float* w_t, hipStream_t s);
+void launch_edge_sweep2(const Graph& g, int N, int F, const int* emap, const float* wA, const float* srcA, const float* wB, const float* srcB,
+                        const float* init, float* out, hipStream_t s);
+void launch_tn2_edge_gw_dual(const Graph& g, int E, int N, int F, const float* g_Mi, const float* g_Mi_t, const float* Pn, const float* Pn_t,
+                             const float* e3, const float* e3_t, const float* C, const float* C_t, float* g_e3, float* g_e3_t, float* gcp,
+                             float* gcp_t, hipStream_t s);
+void launch_tn2_edge_reduce_dual(const Graph& g, int N, int P, int F, const int* erev, const int* pair_edge, const float* g1,
+                                 const float* g1_t, float* gB, float* gB_t, float* gCs, float* gCs_t, float* gself, float* gself_t,
+                                 float* gAp, float* gAp_t, hipStream_t s);
+void launch_edge_rowdot(const Graph& g, int E, int W, int ldx, const float* x, const float* x_t, const float* y, const float* y2,
+                        const float* d_t, bool accumulate, float* val, float* val_t, hipStream_t s);
+void launch_pair_from_edges(int P, const int* pair_edge, const int* erev, const float* val, const float* val_t, float* out, float* out_t,
+                            hipStream_t s);
+void launch_coulomb_atom_dual(const Graph& g, int N, int QC, const int64_t* batch, const float* pos, const float* v, const float* box,
+                              int box_per_mol, const float* ch, const float* ch_t, const float* wq, float* wsum_scratch, float cut, float eps,
+                              float scale, float* e_atom, float* e_atom_t, float* g_q, float* g_q_t, float* g_pos, float* hv, hipStream_t s);
+void launch_add_cols(int N, int qd, const float* src, float* dst, int ld, int off, hipStream_t s);
+void launch_axpy1(int64_t n, float a, const float* x, float* y, hipStream_t s);   // y += a x
+void launch_scale1(int64_t n, float a, const float* x, float* y, hipStream_t s);  // y = a x
 
 }  // namespace hvp
 }  // namespace tn

@@ -16,6 +16,9 @@ namespace hvp {
 namespace {
 constexpr int TB = 256;
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); }
+struct RedWave {  // the row's lanes = one wave (all 64 active: the row index is wave-uniform)
+  __device__ float operator()(float v) const { return wave_sum(v); }
+};
 #define NF_INDEX                                                           \
   const int64_t idx_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     \
   if (idx_ >= (int64_t)N * F) return;                                      \
@@ -38,14 +41,14 @@ __global__ __launch_bounds__(TB) void k_embed_scatter_dual(Graph g, int N, int F
 __global__ __launch_bounds__(TB) void k_ln_dual(int R, int W, const float* __restrict__ x, const float* __restrict__ x_t, const float* __restrict__ w,
                           const float* __restrict__ b, float* __restrict__ y, float* __restrict__ xh, float* __restrict__ rstd,
                           float* __restrict__ y_t, float* __restrict__ xh_t, float* __restrict__ rstd_t) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < R) ln_dual(r, W, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
+  const int r = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);  // a wave per row
+  if (r < R) ln_dual_lanes(r, W, (int)(threadIdx.x & 63), 64, RedWave{}, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
 }
 __global__ __launch_bounds__(TB) void k_lnbwd_dual(int R, int W, const float* __restrict__ g, const float* __restrict__ g_t, const float* __restrict__ xh,
                              const float* __restrict__ xh_t, const float* __restrict__ rstd, const float* __restrict__ rstd_t,
                              const float* __restrict__ w, float* __restrict__ o, float* __restrict__ o_t) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < R) lnbwd_dual(r, W, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
+  const int r = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);  // a wave per row
+  if (r < R) lnbwd_dual_lanes(r, W, (int)(threadIdx.x & 63), 64, RedWave{}, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
 }
 __global__ __launch_bounds__(TB) void k_silu_tangent(int64_t n, const float* __restrict__ a, const float* __restrict__ a_t, float* __restrict__ h_t) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,9 +92,29 @@ __global__ __launch_bounds__(TB) void k_feat_dual(int N, int F, const float* __r
   feat_dual(n, f, F, X, X_t, feat, feat_t);
 }
 __global__ __launch_bounds__(TB) void k_head_dual(int64_t total, int H, const float* __restrict__ ao, const float* __restrict__ ao_t, const float* __restrict__ O2,
-                            float std_, float* __restrict__ g_ao, float* __restrict__ g_ao_t, float* __restrict__ headv) {
+                            float std_, const float* __restrict__ ge, const int64_t* __restrict__ batch, float* __restrict__ g_ao,
+                            float* __restrict__ g_ao_t, float* __restrict__ headv) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) head_dual(i, H, ao, ao_t, O2, std_, g_ao, g_ao_t, headv);
+  if (i < total) head_dual(i, H, ao, ao_t, O2, std_, ge, batch, g_ao, g_ao_t, headv);
+}
+// out[0] = - std sum_n ge[molecule(n)]: ONE block, each thread a strided partial sum, the 256 partials added in order by thread 0
+__global__ __launch_bounds__(TB) void k_head_bias_seed(int N, float std_, const float* __restrict__ ge, const int64_t* __restrict__ batch,
+                                                       float* __restrict__ out) {
+  __shared__ float part[TB];
+  float a = 0.f;
+  for (int n = threadIdx.x; n < N; n += TB) a += head_bias_seed_term(n, ge, batch);
+  part[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < TB; ++k) t += part[k];
+    out[0] = -std_ * t;
+  }
+}
+__global__ __launch_bounds__(TB) void k_row_seed(int64_t total, int W, const float* __restrict__ ge, const int64_t* __restrict__ batch,
+                                                 const float* __restrict__ x, float* __restrict__ x_t) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) row_seed(i, W, ge, batch, x, x_t);
 }
 __global__ __launch_bounds__(TB) void k_readout_bwd_dual(int N, int F, const float* __restrict__ X, const float* __restrict__ X_t,
                                    const float* __restrict__ g_feat, const float* __restrict__ g_feat_t, float* __restrict__ G,
@@ -243,11 +266,11 @@ void launch_embed_scatter_dual(const Graph& g, int N, int F, int P, const int64_
 }
 void launch_ln_dual(int R, int W, const float* x, const float* x_t, const float* w, const float* b, float* y, float* xh, float* rstd,
                     float* y_t, float* xh_t, float* rstd_t, hipStream_t s) {
-  LAUNCH(k_ln_dual, (int64_t)R, R, W, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
+  LAUNCH(k_ln_dual, (int64_t)R * 64, R, W, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
 }
 void launch_lnbwd_dual(int R, int W, const float* g, const float* g_t, const float* xh, const float* xh_t, const float* rstd,
                        const float* rstd_t, const float* w, float* o, float* o_t, hipStream_t s) {
-  LAUNCH(k_lnbwd_dual, (int64_t)R, R, W, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
+  LAUNCH(k_lnbwd_dual, (int64_t)R * 64, R, W, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
 }
 void launch_silu_tangent(int64_t n, const float* a, const float* a_t, float* h_t, hipStream_t s) { LAUNCH(k_silu_tangent, n, n, a, a_t, h_t); }
 void launch_dsilu_dual(int64_t n, const float* g, const float* g_t, const float* a, const float* a_t, float* o, float* o_t, hipStream_t s) {
@@ -275,9 +298,15 @@ void launch_update_dual(int N, int F, const float* Xh, const float* Xh_t, const 
 void launch_feat_dual(int N, int F, const float* X, const float* X_t, float* feat, float* feat_t, hipStream_t s) {
   LAUNCH(k_feat_dual, (int64_t)N * F, N, F, X, X_t, feat, feat_t);
 }
-void launch_head_dual(int N, int H, const float* ao, const float* ao_t, const float* O2, float std_, float* g_ao, float* g_ao_t,
-                      float* headv, hipStream_t s) {
-  LAUNCH(k_head_dual, (int64_t)N * H, (int64_t)N * H, H, ao, ao_t, O2, std_, g_ao, g_ao_t, headv);
+void launch_head_dual(int N, int H, const float* ao, const float* ao_t, const float* O2, float std_, const float* ge, const int64_t* batch,
+                      float* g_ao, float* g_ao_t, float* headv, hipStream_t s) {
+  LAUNCH(k_head_dual, (int64_t)N * H, (int64_t)N * H, H, ao, ao_t, O2, std_, ge, batch, g_ao, g_ao_t, headv);
+}
+void launch_head_bias_seed(int N, float std_, const float* ge, const int64_t* batch, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_head_bias_seed, dim3(1), dim3(TB), 0, s, N, std_, ge, batch, out);
+}
+void launch_row_seed(int N, int W, const float* ge, const int64_t* batch, const float* x, float* x_t, hipStream_t s) {
+  LAUNCH(k_row_seed, (int64_t)N * W, (int64_t)N * W, W, ge, batch, x, x_t);
 }
 void launch_readout_bwd_dual(int N, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G,
                              float* G_t, hipStream_t s) {

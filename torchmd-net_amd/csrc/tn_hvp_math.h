@@ -234,25 +234,33 @@ HVP_FN void embed_scatter_dual(int i, int f, int F, int P, const int* rowptr, co
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm (one row of width W)
-HVP_FN void ln_dual(int row, int W, const float* x, const float* x_t, const float* w, const float* b, float* y, float* xh, float* rstd,
-                    float* y_t, float* xh_t, float* rstd_t) {
+// `nl` lanes share a row (lane = 0 .. nl - 1, columns strided by nl); red(v) = the sum of v over the row's lanes.  The kernels give
+// a row to a WAVE (nl = 64, red = wave_sum), the host harness to one thread (nl = 1, red = identity): the same statements run in both.
+struct RedOne {
+  HVP_FN float operator()(float v) const { return v; }
+};
+template <class Red>
+HVP_FN void ln_dual_lanes(int row, int W, int lane, int nl, Red red, const float* x, const float* x_t, const float* w, const float* b,
+                          float* y, float* xh, float* rstd, float* y_t, float* xh_t, float* rstd_t) {
   const float* xr = x + (int64_t)row * W;
   const float* xtr = x_t + (int64_t)row * W;
   float mu = 0.f, mt = 0.f;
-  for (int k = 0; k < W; ++k) {
+  for (int k = lane; k < W; k += nl) {
     mu += xr[k];
     mt += xtr[k];
   }
-  mu /= W;
-  mt /= W;
-  float var = 0.f;
-  for (int k = 0; k < W; ++k) var += (xr[k] - mu) * (xr[k] - mu);
-  var /= W;
+  mu = red(mu) / W;
+  mt = red(mt) / W;
+  float var = 0.f, m = 0.f;  // m: mean(xh * x_t)
+  for (int k = lane; k < W; k += nl) {
+    const float dx = xr[k] - mu;
+    var += dx * dx;
+    m += dx * xtr[k];
+  }
+  var = red(var) / W;
   const float rs = 1.0f / sqrtf(var + 1e-5f);
-  float m = 0.f;  // mean(xh * x_t)
-  for (int k = 0; k < W; ++k) m += (xr[k] - mu) * rs * xtr[k];
-  m /= W;
-  for (int k = 0; k < W; ++k) {
+  m = red(m) * rs / W;
+  for (int k = lane; k < W; k += nl) {
     const float h = (xr[k] - mu) * rs, ht = rs * (xtr[k] - mt - h * m);
     const int64_t o = (int64_t)row * W + k;
     xh[o] = h;
@@ -260,32 +268,43 @@ HVP_FN void ln_dual(int row, int W, const float* x, const float* x_t, const floa
     y[o] = h * w[k] + b[k];
     y_t[o] = ht * w[k];
   }
-  rstd[row] = rs;
-  rstd_t[row] = -rs * rs * m;
+  if (lane == 0) {
+    rstd[row] = rs;
+    rstd_t[row] = -rs * rs * m;
+  }
+}
+HVP_FN void ln_dual(int row, int W, const float* x, const float* x_t, const float* w, const float* b, float* y, float* xh, float* rstd,
+                    float* y_t, float* xh_t, float* rstd_t) {
+  ln_dual_lanes(row, W, 0, 1, RedOne{}, x, x_t, w, b, y, xh, rstd, y_t, xh_t, rstd_t);
 }
 // adjoint of the normalisation (g = gradient wrt y) and its tangent
-HVP_FN void lnbwd_dual(int row, int W, const float* g, const float* g_t, const float* xh, const float* xh_t, const float* rstd,
-                       const float* rstd_t, const float* w, float* o, float* o_t) {
+template <class Red>
+HVP_FN void lnbwd_dual_lanes(int row, int W, int lane, int nl, Red red, const float* g, const float* g_t, const float* xh, const float* xh_t,
+                             const float* rstd, const float* rstd_t, const float* w, float* o, float* o_t) {
   const int64_t b = (int64_t)row * W;
   float c1 = 0.f, c2 = 0.f, c1t = 0.f, c2t = 0.f;
-  for (int k = 0; k < W; ++k) {
+  for (int k = lane; k < W; k += nl) {
     const float gw = g[b + k] * w[k], gwt = g_t[b + k] * w[k];
     c1 += gw;
     c2 += gw * xh[b + k];
     c1t += gwt;
     c2t += gwt * xh[b + k] + gw * xh_t[b + k];
   }
-  c1 /= W;
-  c2 /= W;
-  c1t /= W;
-  c2t /= W;
+  c1 = red(c1) / W;
+  c2 = red(c2) / W;
+  c1t = red(c1t) / W;
+  c2t = red(c2t) / W;
   const float rs = rstd[row], rst = rstd_t[row];
-  for (int k = 0; k < W; ++k) {
+  for (int k = lane; k < W; k += nl) {
     const float gw = g[b + k] * w[k], gwt = g_t[b + k] * w[k];
     const float core = gw - c1 - xh[b + k] * c2;
     o[b + k] = core * rs;
     o_t[b + k] = (gwt - c1t - xh_t[b + k] * c2 - xh[b + k] * c2t) * rs + core * rst;
   }
+}
+HVP_FN void lnbwd_dual(int row, int W, const float* g, const float* g_t, const float* xh, const float* xh_t, const float* rstd,
+                       const float* rstd_t, const float* w, float* o, float* o_t) {
+  lnbwd_dual_lanes(row, W, 0, 1, RedOne{}, g, g_t, xh, xh_t, rstd, rstd_t, w, o, o_t);
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise
@@ -402,12 +421,21 @@ HVP_FN void feat_dual(int n, int f, int F, const float* X, const float* X_t, flo
 
 // ------------------------------------------------------------------------------------------------ head, reverse pass
 // seed: g_ao = std O2 silu'(ao); headv = std silu'(ao) ao_t is the summand of d s / d O2   (i over N * H)
-HVP_FN void head_dual(int64_t i, int H, const float* ao, const float* ao_t, const float* O2, float std_, float* g_ao, float* g_ao_t,
-                      float* headv) {
+// ge != null (one-pass training): everything downstream is the gradient of  S = s - sum_m ge_m E_m  - the tangent adjoint minus the
+// adjoint of sum_m ge_m E_m obeys the tangent adjoint's recursion, so only its seed changes: - ge[molecule] at every atom's energy
+HVP_FN void head_dual(int64_t i, int H, const float* ao, const float* ao_t, const float* O2, float std_, const float* ge,
+                      const int64_t* batch, float* g_ao, float* g_ao_t, float* headv) {
   const float o2 = std_ * O2[i % H], d1 = silu1(ao[i]);
+  const float w = ge ? ge[batch ? batch[i / H] : 0] : 0.f;
   g_ao[i] = o2 * d1;
-  g_ao_t[i] = o2 * silu2(ao[i]) * ao_t[i];
-  headv[i] = std_ * d1 * ao_t[i];
+  g_ao_t[i] = o2 * silu2(ao[i]) * ao_t[i] - w * o2 * d1;
+  headv[i] = std_ * d1 * ao_t[i] - w * std_ * silu0(ao[i]);
+}
+// d S / d (the head's last bias) = - std sum_n ge[molecule(n)]   (one logical thread; the kernel sums in blocks of 256)
+HVP_FN float head_bias_seed_term(int n, const float* ge, const int64_t* batch) { return ge[batch ? batch[n] : 0]; }
+// per atom row (width W): x_t -= ge[molecule] x  - the Coulomb head's adjoints under the energy seed (its pairs lie inside a molecule)
+HVP_FN void row_seed(int64_t i, int W, const float* ge, const int64_t* batch, const float* x, float* x_t) {
+  x_t[i] -= ge[batch ? batch[i / W] : 0] * x[i];
 }
 // G = dquad(X) g_feat[type]
 HVP_FN void readout_bwd_dual(int n, int f, int F, const float* X, const float* X_t, const float* g_feat, const float* g_feat_t, float* G,

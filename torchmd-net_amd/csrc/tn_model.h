@@ -322,5 +322,6 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
 int et_debug_tensor(tmdnet_model* m, hipStream_t s, const char* name, float* out, int64_t numel);
 // analytic second-order pass of force matching (the Equivariant Transformer's half of tmdnet_force_param_grads)
 int et_force_param_workspace_bytes(const tmdnet_model* m, int64_t n_atoms, int64_t n_pairs, size_t* bytes);
+int et_hvp_debug_tensor(tmdnet_model* m, hipStream_t s, const char* name, float* out, int64_t numel);
 int et_force_param_grads(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol,
-                         int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* v, float* grads, float* hv);
+                         int64_t n_pairs, const int64_t* z, const int64_t* batch, const float* v, const float* ge, float* grads, float* hv);

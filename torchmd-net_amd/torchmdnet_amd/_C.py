@@ -103,6 +103,7 @@ def lib():
     L.tmdnet_energy_param_grads.argtypes = [vp, vp, vp, vp, sz, vp, sz, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.tmdnet_force_param_workspace_bytes.argtypes = [vp, i64, i64, i64, C.POINTER(sz)]
     L.tmdnet_force_param_grads.argtypes = [vp, vp, vp, vp, sz, i64, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.tmdnet_loss_param_grads.argtypes = [vp, vp, vp, vp, sz, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.tmdnet_hvp_debug_tensor.argtypes = [vp, vp, C.c_char_p, vp, i64]
     abi = int(re.search(r"#define\s+TMDNET_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read()).group(1))
     if L.tmdnet_abi_version() != abi:

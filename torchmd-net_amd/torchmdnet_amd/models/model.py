@@ -396,18 +396,22 @@ class _EnergyForceParamGrad(torch.autograd.Function):
             for p, g in grads.items():
                 total[p] = g * w if p not in total else total[p] + g * w
 
-        if g_energy is not None and bool((g_energy != 0).any()):
+        has_e = g_energy is not None and bool((g_energy != 0).any())
+        has_f = g_forces is not None and bool((g_forces != 0).any())
+        order = getattr(model, "force_gradient_order", None)
+        if order is None:  # auto: the analytic pass where it has been timed (TensorNet), the order-2 difference quotient elsewhere
+            order = 2 if (model._is_et() or model._is_tn2()) else 0  # TensorNet2's analytic pass: host-validated, ask for it with 0
+        order = int(order)
+        analytic = order == 0
+        # one pass for both terms: the analytic second-order pass with the energy seed ge = d loss / d E (tmdnet_loss_param_grads)
+        one_pass = has_e and has_f and analytic and getattr(model, "one_pass_training", True)
+        if has_e and not one_pass:
             add(model.parameter_gradients_of(z, pos, batch, box, q, n_mol, g_energy)[1], 1.0)
         g_pos = None
-        if g_energy is not None:
+        if g_energy is not None and not (one_pass and ctx.needs_input_grad[2] and getattr(model, "force_position_gradient", True)):
             g_pos = -g_energy.reshape(-1)[batch].unsqueeze(1) * forces  # first order in pos (as tmdnet::energy_forces' backward)
-        if g_forces is not None and bool((g_forces != 0).any()):
+        if has_f:
             v = g_forces.detach().to(torch.float32)
-            order = getattr(model, "force_gradient_order", None)
-            if order is None:  # auto: the analytic pass where it has been timed (TensorNet), the order-2 difference quotient elsewhere
-                order = 2 if (model._is_et() or model._is_tn2()) else 0
-            order = int(order)
-            analytic = order == 0 and not model._is_tn2()
             with_hv = analytic and ctx.needs_input_grad[2] and getattr(model, "force_position_gradient", True)
             if not with_hv and ctx.needs_input_grad[2] and not getattr(model, "_warned_pos_grad", False):
                 # pos always requires grad here (the reference's side effect, model.py:584-585), so this cannot tell a caller who
@@ -422,11 +426,12 @@ class _EnergyForceParamGrad(torch.autograd.Function):
             if analytic:
                 # analytic second-order pass (TensorNet + Scalar): d (g_F . F) / d theta = - d/d theta [ g_F . d sum_m E_m / d pos ],
                 # and in the positions - H g_F (H = Hessian of the summed energy)
+                seed = g_energy.detach().reshape(-1) if one_pass else None  # then gth / hv are the gradients of s - sum_m ge_m E_m
                 if with_hv:
-                    gth, hv = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, want_hv=True)
+                    gth, hv = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, want_hv=True, ge=seed)
                     g_pos = -hv if g_pos is None else g_pos - hv
                 else:
-                    gth = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v)
+                    gth = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, ge=seed)
                 add(gth, -1.0)
             else:
                 order = order or 2  # no analytic pass for this architecture: the default difference quotient
@@ -487,6 +492,9 @@ class TorchMD_Net(nn.Module):
         # None (auto): 0 for TensorNet + Scalar, 2 for the Equivariant Transformer (its analytic pass is exact but untuned and untimed at
         # batch scale: ask for it with 0) and TensorNet2 ; 0: analytic second-order pass ; 2 / 4: central difference, two / four extra passes
         self.force_gradient_order = None
+        # loss(E, F).backward() with the analytic pass: True = ONE seeded second-order pass delivers the energy term's gradient too
+        # (tmdnet_loss_param_grads); False = the first-order pass for the energy term plus the second-order pass for the forces
+        self.one_pass_training = True
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -723,14 +731,15 @@ class TorchMD_Net(nn.Module):
         energy, token = self._train_forward(z, pos, batch, box, q, n_mol, keep=False)
         return energy, self._train_backward(token, grad_energy)
 
-    def force_term_parameter_gradients(self, z, pos, batch, box, q, n_mol, v, want_hv=False):
+    def force_term_parameter_gradients(self, z, pos, batch, box, q, n_mol, v, want_hv=False, ge=None):
         """d s / d theta of  s = v . d(sum_m E_m)/d pos = - v . F  for every weight of TensorNet + Scalar, analytically
         (tmdnet_force_param_grads: the tangent, along v, of the engine's forward + reverse program - what the reference gets from
         its second autograd pass, model.py:618-628 with create_graph=True).  -> {parameter: gradient}; d loss / d theta through
         the forces is MINUS this with v = d loss / d F.  want_hv: -> ({parameter: gradient}, H v [N, 3]) with H v = d s / d pos, the
-        Hessian of the summed energy applied to v (the position gradient of such a loss is - H v)."""
-        if self._is_tn2():
-            raise NotImplementedError("the analytic second-order pass is built for TensorNet + Scalar and the Equivariant Transformer")
+        Hessian of the summed energy applied to v (the position gradient of such a loss is - H v).
+        ge [n_mol] = d loss / d E (one-pass training, tmdnet_loss_param_grads): the gradients of  S = s - sum_m ge_m E_m  instead, so
+        that the whole gradient of loss(E, F) is minus the result (parameters) and minus H v' (positions); an Atomref prior's table,
+        which the engine does not hold, is added here."""
         if self._is_et():
             q = None  # TorchMD_ET.forward ignores q
         L = _C.lib()
@@ -769,17 +778,24 @@ class TorchMD_Net(nn.Module):
             L.tmdnet_train_workspace_bytes(st.handle, n, n_mol, n_pairs, None, None, C.byref(gfl))
             flat = torch.empty(gfl.value, dtype=torch.float32, device=dev)
             hv = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_hv else None
-            rc = L.tmdnet_force_param_grads(st.handle, stream, _ptr(st.graph_ws), _ptr(st.hvp_ws), st.hvp_ws.numel(), n, n_mol, n_pairs,
-                                            _ptr(z), _ptr(batch), _ptr(q), _ptr(v32), _ptr(flat), _ptr(hv))
+            ge32 = None if ge is None else ge.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+            assert ge32 is None or ge32.numel() == n_mol
+            rc = L.tmdnet_loss_param_grads(st.handle, stream, _ptr(st.graph_ws), _ptr(st.hvp_ws), st.hvp_ws.numel(), n, n_mol, n_pairs,
+                                           _ptr(z), _ptr(batch), _ptr(q), _ptr(v32), _ptr(ge32), _ptr(flat), _ptr(hv))
             if rc != _C.OK:
-                raise RuntimeError(f"tmdnet_force_param_grads: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
+                raise RuntimeError(f"tmdnet_loss_param_grads: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
             st.ws_epoch = getattr(st, "ws_epoch", 0) + 1  # the graph workspace was rebuilt: a kept forward half is stale
             ent = {}
             for i in range(L.tmdnet_param_grad_count(st.handle)):
                 off, numel = C.c_int64(0), C.c_int64(0)
                 name = L.tmdnet_param_grad_entry(st.handle, i, C.byref(off), C.byref(numel)).decode()
                 ent[name] = flat[off.value: off.value + numel.value]
-            grads = self._et_grads(ent) if self._is_et() else self._tensornet_grads(ent)
+            grads = self._et_grads(ent) if self._is_et() else (self._tn2_grads(ent) if self._is_tn2() else self._tensornet_grads(ent))
+            if ge32 is not None and self.prior_model is not None:  # d S / d atomref[z] = - sum of ge[molecule] over the atoms of species z
+                for pr in self.prior_model:
+                    if pr.enable:
+                        w = pr.atomref.weight
+                        grads[w] = -torch.zeros(w.shape[0], dtype=torch.float32, device=dev).index_add_(0, z, ge32[batch]).view_as(w)
             return (grads, hv) if want_hv else grads
 
     def _train_forward(self, z, pos, batch, box, q, n_mol, keep=True):
