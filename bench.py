@@ -367,29 +367,29 @@ def tn2_leg(dev, L, steps=8, warmup=3):
 
 
 def training_leg(dev, L, steps=4, warmup=2):
-    """Training steps of the C2 model on the bench batch through the parameter-gradient pass: energy-only
-    (forward + tmdnet_energy_param_grads + SGD step with its parameter re-upload) and energy + forces (plus the analytic
-    second-order pass tmdnet_force_param_grads behind the force gradient; the round-3 difference quotient timed beside it).  Not the headline metric: a measured number for SURVEY 8(f)4."""
+    """Training steps on the bench batch, one SGD step per step, for the three architectures: energy-only (forward +
+    tmdnet_energy_param_grads + device-side parameter update) and energy + forces in the DEFAULT mode - the analytic second-order
+    pass seeded with d loss / d E (tmdnet_loss_param_grads: one pass delivers the whole gradient of loss(E, F)); for TensorNet the
+    two-pass form and the order-2 difference quotient (a test cross-check) are timed beside it.  Not the headline metric: a
+    measured number for SURVEY 8(f)4."""
     import torch
     from torchmdnet_amd import workloads as W
     from torchmdnet_amd.models.model import create_model
 
-    out = {"workload": "C2 model, S-mol64 256 x 64 atoms, one optimizer step (SGD) per step, random-init (seed 0)"}
     z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS)
     z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
-    for key, deriv, order, one_pass in (("ms_per_step_energy_only", False, 0, True), ("ms_per_step_energy_and_forces", True, 0, True),
-                                        ("ms_per_step_energy_and_forces_two_passes", True, 0, False),
-                                        ("ms_per_step_energy_and_forces_difference_quotient", True, 2, False)):
+
+    def time_step(args, deriv, order, one_pass, q=None):
         torch.manual_seed(0)
-        model = create_model(dict(W.C2_ARGS, derivative=deriv)).to(dev)
+        model = create_model(dict(args, derivative=deriv)).to(dev)
         model.parameter_gradients = True
-        model.force_gradient_order = order  # 0: analytic second-order pass (TensorNet's default); 2: central difference, two extra passes
-        model.one_pass_training = one_pass  # True: the seeded second-order pass delivers the energy term's gradient too (tmdnet_loss_param_grads)
+        model.force_gradient_order = order  # None: the default (analytic second-order pass); 2: central difference, two extra passes
+        model.one_pass_training = one_pass  # True (default): the seeded second-order pass delivers the energy term's gradient too
         opt = torch.optim.SGD(model.parameters(), lr=1e-7)
 
         def step():
             opt.zero_grad()
-            y, f = model(z, pos, batch)
+            y, f = model(z, pos, batch, q=q)
             loss = (y ** 2).mean() + ((f ** 2).mean() if deriv else 0.0)
             loss.backward()
             opt.step()
@@ -403,7 +403,26 @@ def training_leg(dev, L, steps=4, warmup=2):
             loss = step()
         torch.cuda.synchronize(dev)
         assert torch.isfinite(loss)
-        out[key] = (time.perf_counter() - t0) / steps * 1e3
+        dt = (time.perf_counter() - t0) / steps * 1e3
+        del model, opt
+        torch.cuda.empty_cache()
+        return dt
+
+    out = {"workload": "C2 model, S-mol64 256 x 64 atoms, one optimizer step (SGD) per step, random-init (seed 0)",
+           "force_gradient": "analytic second-order pass, one seeded pass for loss(E, F) (the default for every architecture)"}
+    out["ms_per_step_energy_only"] = time_step(W.C2_ARGS, False, None, True)
+    out["ms_per_step_energy_and_forces"] = time_step(W.C2_ARGS, True, None, True)
+    out["energy_and_forces_over_energy_only"] = out["ms_per_step_energy_and_forces"] / out["ms_per_step_energy_only"]
+    out["ms_per_step_energy_and_forces_two_passes"] = time_step(W.C2_ARGS, True, None, False)
+    out["ms_per_step_energy_and_forces_difference_quotient"] = time_step(W.C2_ARGS, True, 2, False)
+    tn2 = dict(W.C2_ARGS, model="tensornet2", output_model="ScalarPlusWeightedCoulomb", q_dim=16, q_weights=[1.0, 1.0, 1.0])
+    for name, args, q in (("equivariant_transformer", W.C4_ARGS, None), ("tensornet2", tn2, torch.zeros(N_MOL, device=dev))):
+        try:
+            r = {"ms_per_step_energy_only": time_step(args, False, None, True, q), "ms_per_step_energy_and_forces": time_step(args, True, None, True, q)}
+            r["energy_and_forces_over_energy_only"] = r["ms_per_step_energy_and_forces"] / r["ms_per_step_energy_only"]
+        except Exception as exc:  # noqa: BLE001
+            r = {"error": repr(exc)}
+        out[name] = r
     return out
 
 

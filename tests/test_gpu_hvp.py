@@ -543,3 +543,39 @@ def test_one_pass_gradient_equals_the_reference_backward_of_an_energy_and_force_
     bad = {k: e for k, e in errs.items() if not e < REL}
     assert len(errs) >= 30 and not bad, bad
     assert pos_err < REL, pos_err
+
+
+@pytest.mark.parametrize("fixture", ["tiny_ref.pt", "et_tiny_ref.pt", "et_tiny_vc_ref.pt", "tn2_tiny_ref.pt", "tn2_tiny_rf_ref.pt"])
+def test_default_training_backward_equals_the_reference_backward(hip_lib, golden_dir, fixture):
+    """The path a training script takes with NO switch touched except `parameter_gradients` (reference: model.py:618-628 with
+    create_graph=self.training, module.py:200-290): `loss(E, F).backward()` through autograd.  force_gradient_order = None must
+    mean the analytic pass for TensorNet, the Equivariant Transformer AND TensorNet2, in one seeded pass: .grad of every parameter
+    and pos.grad against ONE backward of the unmodified reference (tests/golden/second_order_ref.pt) at 1e-4, and no
+    truncated-position-gradient warning."""
+    import warnings
+    from torchmdnet_amd.models.model import create_model
+
+    ref = torch.load(os.path.join(golden_dir, "second_order_ref.pt"))[fixture]
+    g = torch.load(os.path.join(golden_dir, fixture))
+    model = create_model(dict(g["args"], derivative=True))
+    model.load_state_dict(g["state_dict"])
+    model = model.to("cuda")
+    model.parameter_gradients = True
+    assert model.force_gradient_order is None and model.one_pass_training
+    c = lambda t: None if t is None else t.cuda()
+    pos = g["pos"].cuda().requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        E, F = model(g["z"].cuda(), pos, g["batch"].cuda(), box=c(g.get("box")), q=c(g.get("q")))
+        loss = (E.view(-1) * ref["ge"].float().cuda()).sum() + (F * ref["v"].float().cuda()).sum()
+        loss.backward()
+    errs = {}
+    for k, p in model.named_parameters():
+        r = ref["loss_grads"].get(k)
+        if r is not None and r.abs().max() > 0:
+            assert p.grad is not None, k
+            errs[k] = (p.grad.cpu().double().reshape(r.shape) - r).abs().max().item() / r.abs().max().item()
+    pos_err = (pos.grad.cpu().double() - ref["loss_pos_grad"]).abs().max().item() / ref["loss_pos_grad"].abs().max().item()
+    bad = {k: e for k, e in errs.items() if not e < REL}
+    assert len(errs) >= 30 and not bad, bad
+    assert pos_err < REL, pos_err

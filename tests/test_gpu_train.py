@@ -282,9 +282,8 @@ def test_force_matching_gradients_by_central_difference(hip_lib, order, bound):
 
 
 def test_et_training_through_autograd(hip_lib):
-    """Equivariant Transformer, derivative=True: energies and forces carry graphs to the weights (forces through the difference
-    quotient, the default for this architecture; its analytic pass is tested in tests/test_gpu_hvp.py); .grad against the oracle's
-    fp64 double backward at the stated bound, and a few Adam steps lower the loss"""
+    """Equivariant Transformer, derivative=True: energies and forces carry graphs to the weights (the analytic one-pass default);
+    .grad against the oracle's fp64 double backward at 1e-4, and a few Adam steps lower the loss"""
     from oracle import et_torch as T
     from torchmdnet_amd.models.model import create_model
 
@@ -308,7 +307,7 @@ def test_et_training_through_autograd(hip_lib):
         if r is not None and r.abs().max() > 0:
             assert prm.grad is not None, k
             worst = max(worst, (prm.grad.cpu().double() - r).abs().max().item() / r.abs().max().item())
-    assert worst < 2e-3, worst
+    assert worst < 1e-4, worst
     opt = torch.optim.Adam(model.parameters(), lr=2e-3)
     tgt_e, tgt_f = torch.tensor([[0.2], [-0.1], [0.3]]).cuda(), torch.zeros_like(pos).cuda()
     losses = []
@@ -386,10 +385,41 @@ def test_parameter_update_stays_on_the_device(hip_lib, arch):
     assert model._engine.device_updates == n and not torch.equal(E2, E)
 
 
+def test_trained_model_evaluates_like_a_fresh_one_at_batch_scale_and_on_a_side_stream(hip_lib):
+    """(1) the device-side update was queued on the caller's (non-blocking) stream while the radial tables were
+    rebuilt with NULL-stream kernels - nothing ordered the rebuild after the gather; (2) the radial-basis embedding's images stayed
+    off after the first device-side update, so a trained model took another schedule than a freshly loaded one.  Now: an update on a
+    SIDE stream followed by a batch-scale evaluation (radial tables + radial-basis embedding: >= 1024 atoms, F = 128, K = 32) on
+    that stream is bit-identical to a fresh handle with the same weights, and the embedding is on again."""
+    from torchmdnet_amd.models.model import create_model
+
+    torch.manual_seed(4)
+    model = create_model(dict(W.C2_ARGS)).to("cuda")
+    z, pos, batch = (t.cuda() for t in W.synthetic_batch(n_mol=24, n_atoms=64))
+    model(z, pos, batch)  # full upload; tables + images built
+    assert model.engine_info("embed_rb") == 1.0
+    side = torch.cuda.Stream()
+    g = torch.Generator(device="cuda").manual_seed(6)
+    for _ in range(2):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.02 * torch.randn(p.shape, device="cuda", generator=g) * p.abs().mean())
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            E, F = model(z, pos, batch)
+        torch.cuda.current_stream().wait_stream(side)
+    assert model._engine.device_updates == 2
+    assert model.engine_info("embed_rb") == 1.0
+    fresh = create_model(dict(W.C2_ARGS)).to("cuda")
+    fresh.load_state_dict(model.state_dict())
+    Er, Fr = fresh(z, pos, batch)
+    torch.cuda.synchronize()
+    assert torch.equal(E, Er) and torch.equal(F, Fr)
+
+
 def test_force_loss_position_gradient_is_announced_as_truncated(hip_lib):
-    """d loss / d pos THROUGH the forces is a second derivative in the positions.  The analytic pass (TensorNet + Scalar, the
-    default) builds it (tests/test_gpu_hvp.py); the difference-quotient force gradient (order 2 / 4, and every ET / TensorNet2
-    model) does not: pos always requires grad in derivative mode (the reference's side effect), so the backward cannot refuse - it
+    """d loss / d pos THROUGH the forces is a second derivative in the positions.  The analytic pass (the default for every
+    architecture) builds it (tests/test_gpu_hvp.py); the difference-quotient cross-check (order 2 / 4 on request) does not: pos always requires grad in derivative mode (the reference's side effect), so the backward cannot refuse - it
     warns once that pos.grad holds the energy term's part only, and the parameter gradients are unaffected."""
     from torchmdnet_amd.models.model import create_model
 

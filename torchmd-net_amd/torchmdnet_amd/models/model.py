@@ -366,14 +366,15 @@ class _direct_radial_functions:
 
 class _EnergyForceParamGrad(torch.autograd.Function):
     """(E, F)(theta): d E / d theta exact (parameter-gradient pass); d (g_F . F) / d theta = - d/d theta of the directional
-    derivative s = v . d(sum_m E_m)/d pos along v = g_F.  TensorNet + Scalar (the default there) and the Equivariant Transformer
-    (`model.force_gradient_order = 0`):
-    analytic - the engine's second-order pass tmdnet_force_param_grads, the forward-mode tangent along v of its forward + reverse
-    program (csrc/tn_hvp_api.hip), which is what the reference's second autograd pass computes (create_graph=True,
-    model.py:618-628 + the *_bwd_bwd kernels); measured 3e-6 of each tensor's largest entry against the oracle's double backward.
-    TensorNet2, the Equivariant Transformer by default, or order 2 / 4 on request: a central difference of the exact parameter gradient at
-    pos +- h v / max|v| (two or four extra passes; `model.force_gradient_step` = h in Angstrom; 3e-4 / 1e-4 measured): a numerical
-    stand-in with a stated accuracy (tests/test_gpu_train.py), not a parity path."""
+    derivative s = v . d(sum_m E_m)/d pos along v = g_F.  Every architecture (TensorNet + Scalar, the Equivariant Transformer,
+    TensorNet2 + its Coulomb head) takes the ANALYTIC pass: the engine's second-order pass tmdnet_force_param_grads /
+    tmdnet_loss_param_grads, the forward-mode tangent along v of its forward + reverse program (csrc/tn_hvp_api.hip), which is what
+    the reference's second autograd pass computes (create_graph=True, model.py:618-628 + the *_bwd_bwd kernels); compared directly
+    with the unmodified reference's double backward at 1e-4 on five fixtures (tests/test_gpu_hvp.py; measured 3e-6 .. 5e-6).
+    A loss of energies AND forces is ONE seeded pass (`one_pass_training`); `H v` lands in pos.grad.
+    `model.force_gradient_order = 2 / 4` keeps a central difference of the exact parameter gradient at pos +- h v / max|v|
+    (`model.force_gradient_step` = h in Angstrom; 3e-4 / 1e-4 measured) as a cross-check for tests - slower than the analytic pass on
+    all three architectures (profiles/r05_second_order_time.json) and not a parity path."""
 
     @staticmethod
     def forward(ctx, model, z, pos, batch, box, q, n_mol, *params):
@@ -399,9 +400,7 @@ class _EnergyForceParamGrad(torch.autograd.Function):
         has_e = g_energy is not None and bool((g_energy != 0).any())
         has_f = g_forces is not None and bool((g_forces != 0).any())
         order = getattr(model, "force_gradient_order", None)
-        if order is None:  # auto: the analytic pass where it has been timed (TensorNet), the order-2 difference quotient elsewhere
-            order = 2 if (model._is_et() or model._is_tn2()) else 0  # TensorNet2's analytic pass: host-validated, ask for it with 0
-        order = int(order)
+        order = int(order or 0)  # None / 0: the analytic pass (every architecture); 2 / 4: the difference-quotient cross-check
         analytic = order == 0
         # one pass for both terms: the analytic second-order pass with the energy seed ge = d loss / d E (tmdnet_loss_param_grads)
         one_pass = has_e and has_f and analytic and getattr(model, "one_pass_training", True)
@@ -412,19 +411,21 @@ class _EnergyForceParamGrad(torch.autograd.Function):
             g_pos = -g_energy.reshape(-1)[batch].unsqueeze(1) * forces  # first order in pos (as tmdnet::energy_forces' backward)
         if has_f:
             v = g_forces.detach().to(torch.float32)
-            with_hv = analytic and ctx.needs_input_grad[2] and getattr(model, "force_position_gradient", True)
-            if not with_hv and ctx.needs_input_grad[2] and not getattr(model, "_warned_pos_grad", False):
+            want_hv = ctx.needs_input_grad[2] and getattr(model, "force_position_gradient", True)
+            with_hv = analytic and want_hv
+            if want_hv and not analytic and not getattr(model, "_warned_pos_grad", False):
                 # pos always requires grad here (the reference's side effect, model.py:584-585), so this cannot tell a caller who
-                # wants d loss / d pos from one who does not: say it once instead of silently returning a truncated gradient
+                # wants d loss / d pos from one who does not: say it once instead of silently returning a truncated gradient.
+                # (force_position_gradient = False is the caller's own choice: no warning then.)
                 import warnings
 
                 warnings.warn("torchmdnet_amd: pos.grad of a loss that depends on the FORCES holds only the energy term's part "
-                              "(-g_E F): the difference-quotient force gradient (TensorNet2, force_gradient_order 2 / 4) carries a "
-                              "graph to the parameters only; the second derivative in the positions is built for TensorNet + "
-                              "Scalar and the Equivariant Transformer (force_gradient_order = 0, force_position_gradient = True)", stacklevel=2)
+                              "(-g_E F): the difference-quotient force gradient (force_gradient_order 2 / 4) carries a graph to "
+                              "the parameters only; the second derivative in the positions comes with the analytic pass "
+                              "(force_gradient_order = None / 0, the default)", stacklevel=2)
                 model._warned_pos_grad = True
             if analytic:
-                # analytic second-order pass (TensorNet + Scalar): d (g_F . F) / d theta = - d/d theta [ g_F . d sum_m E_m / d pos ],
+                # analytic second-order pass: d (g_F . F) / d theta = - d/d theta [ g_F . d sum_m E_m / d pos ],
                 # and in the positions - H g_F (H = Hessian of the summed energy)
                 seed = g_energy.detach().reshape(-1) if one_pass else None  # then gth / hv are the gradients of s - sum_m ge_m E_m
                 if with_hv:
@@ -434,7 +435,6 @@ class _EnergyForceParamGrad(torch.autograd.Function):
                     gth = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, ge=seed)
                 add(gth, -1.0)
             else:
-                order = order or 2  # no analytic pass for this architecture: the default difference quotient
                 scale = v.abs().max()
                 vh = v / scale
                 h = getattr(model, "force_gradient_step", None)
@@ -482,15 +482,14 @@ class TorchMD_Net(nn.Module):
         self.pair_storage = "fp32"  # "bf16": Equivariant Transformer pair rows in reduced-precision storage (create_model)
         self.static_check = True  # static_shapes mode: poll the overflow flag after every non-captured call
         self.cell_list_min_atoms = 1024  # single periodic systems at least this large use the O(N) cell list
-        # True: the outputs carry an autograd graph to the PARAMETERS (TensorNet + Scalar): loss(y, F).backward() fills .grad of
-        # every weight - d y / d theta exactly from the engine's parameter-gradient pass, d F / d theta from its analytic
-        # second-order pass along d loss / d F (force matching; TensorNet + Scalar - a central difference otherwise, order below).  The reference needs no switch (autograd records
+        # True: the outputs carry an autograd graph to the PARAMETERS: loss(y, F).backward() fills .grad of every weight - d y / d theta
+        # exactly from the engine's parameter-gradient pass, d F / d theta from its analytic second-order pass along d loss / d F
+        # (force matching; one seeded pass for a loss of both).  The reference needs no switch (autograd records
         # everything); here the default call stays on the inference schedule (radial tables, no saved activations)
         self.parameter_gradients = False
         self.force_position_gradient = True  # analytic pass: also - H g_F into pos.grad (False: the energy term's part only, a little faster)
         self.force_gradient_step = None  # Angstrom: largest atom displacement of the finite-difference direction (None: 0.005 / 0.02)
-        # None (auto): 0 for TensorNet + Scalar, 2 for the Equivariant Transformer (its analytic pass is exact but untuned and untimed at
-        # batch scale: ask for it with 0) and TensorNet2 ; 0: analytic second-order pass ; 2 / 4: central difference, two / four extra passes
+        # None / 0: analytic second-order pass (all three architectures) ; 2 / 4: central difference, two / four extra passes (tests)
         self.force_gradient_order = None
         # loss(E, F).backward() with the analytic pass: True = ONE seeded second-order pass delivers the energy term's gradient too
         # (tmdnet_loss_param_grads); False = the first-order pass for the energy term plus the second-order pass for the forces
@@ -621,6 +620,12 @@ class TorchMD_Net(nn.Module):
         fp = self._fingerprint()
         if st.handle is not None and st.fingerprint == fp:
             return st
+        dev = next(self.parameters()).device
+        if dev.type == "cuda" and torch.cuda.current_device() != dev.index:
+            # allocations and the device-side update must land on the MODEL's GPU, not on whatever device is current (a model on a
+            # non-current GPU of a single multi-GPU process)
+            with torch.cuda.device(dev):
+                return self._sync_engine()
         L = _C.lib()
         hp = self._et_hparams() if self._is_et() else (self._tn2_hparams() if self._is_tn2() else self._hparams())
         hp_key = (type(hp).__name__, bytes(hp))
@@ -1052,7 +1057,11 @@ class TorchMD_Net(nn.Module):
                 if atom_weights.numel() != n:
                     raise ValueError(f"atom_weights must have one entry per atom ({n}), got {atom_weights.numel()}")
             L.tmdnet_set_atom_weights(st.handle, _ptr(atom_weights))
-            st.atom_weights = atom_weights  # a captured graph replays the call: the vector has to outlive it
+            st.atom_weights = atom_weights
+            if atom_weights is not None and torch.cuda.is_current_stream_capturing():
+                # a captured graph replays the call with this pointer: the vector has to outlive every replay, and a later call
+                # (which overwrites st.atom_weights) must not free it
+                st.captured_atom_weights = getattr(st, "captured_atom_weights", []) + [atom_weights]
             rc = L.tmdnet_energy_forces(st.handle, stream, _ptr(st.graph_ws), _ptr(st.fwd_ws), st.fwd_ws.numel(), n, n_mol,
                                         n_pairs, _ptr(z), _ptr(batch), _ptr(q), int(want_forces), _ptr(energy), _ptr(forces))
             if atom_weights is not None:
