@@ -576,3 +576,55 @@ def test_four_atoms_per_block_phase_kernels_vs_oracle(hip_lib, F, L, group):
     Eb, Fb = model(zb.cuda(), pb.cuda(), bb.cuda(), box=box.cuda())
     Ebr, Fbr = T.energy_and_forces(sd, hp, zb, pb, bb, box=box)
     assert rel_err(Eb.cpu(), Ebr) < REL and rel_err(Fb.cpu(), Fbr) < REL
+
+
+def test_host_tensors_are_staged_through_the_gpu_engine(hip_lib, golden_dir):
+    """The reference's tests build `create_model(args)` and their inputs on the HOST (tests/test_model.py:19-47).  The drop-in
+    forward stages host tensors to the GPU engine and back (TorchMD_Net._forward_host_tensors - no CPU arithmetic): same numbers as
+    the device-resident call, host-resident outputs, and `energy.sum().backward()` fills the HOST pos.grad with -F."""
+    from torchmdnet_amd.models.model import create_model
+
+    g = torch.load(os.path.join(golden_dir, "tiny_ref.pt"))
+    host = create_model(dict(g["args"], derivative=True))
+    host.load_state_dict(g["state_dict"])  # parameters stay on the host
+    dev = _model_from_sd(dict(g["args"], derivative=True), g["state_dict"])
+    z, pos, batch = g["z"], g["pos"].clone(), g["batch"]
+    E, F = host(z, pos, batch)
+    assert E.device.type == "cpu" and F.device.type == "cpu" and pos.requires_grad
+    Ed, Fd = dev(z.cuda(), pos.detach().cuda(), batch.cuda())
+    assert torch.equal(E, Ed.cpu()) and torch.equal(F, Fd.cpu())
+    assert rel_err(E.view(-1), g["E_q0"].view(-1)) < REL and rel_err(F, g["F_q0"]) < REL
+    host2 = create_model(dict(g["args"], derivative=False))
+    host2.load_state_dict(g["state_dict"])
+    p = g["pos"].clone().requires_grad_(True)
+    y, _ = host2(z, p, batch)
+    y.sum().backward()
+    assert p.grad.device.type == "cpu" and rel_err(-p.grad, g["F_q0"]) < REL
+
+
+def test_neighbor_list_is_capturable(hip_lib):
+    """reference tests/test_neighbors.py:452-588: OptimizedDistance (resize_to_fit=False) warmed up on a side stream, captured with
+    torch.cuda.graph (forward and backward) and replayed: no host read-back while the stream is capturing."""
+    from torchmdnet_amd.models.utils import OptimizedDistance
+
+    torch.manual_seed(0)
+    pos = (torch.rand(150, 3, device="cuda") * 4).requires_grad_(True)
+    batch = torch.arange(3, device="cuda").repeat_interleave(50)
+    nl = OptimizedDistance(cutoff_upper=1.5, max_num_pairs=4096, return_vecs=True, resize_to_fit=False)
+    ref = nl(pos, batch)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            ei, d, v = nl(pos, batch)
+            d.sum().backward()
+            pos.grad.zero_()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ei, d, v = nl(pos, batch)
+            d.sum().backward()
+        ei.fill_(0)
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ei, ref[0]) and torch.equal(d.detach(), ref[1].detach())

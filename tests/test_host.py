@@ -462,7 +462,8 @@ def test_force_matching_backward_combines_the_passes_with_the_right_signs(monkey
     expect = float(ge.sum()) - float(R.sum())  # energy pass seeded with g_E, minus the second-order pass along v = g_F
     assert all(torch.allclose(p.grad, torch.full_like(p, expect), rtol=1e-5, atol=1e-5) for p in params)
     assert torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0 - hv0)
-    with pytest.warns(UserWarning, match="energy term's part"):
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # force_position_gradient = False is the caller's own choice: silent
         g_pos = run(0, pos_grad=False)
     assert calls == dict(first=1, second=1, hv=0, seeded=0) and torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0)
     # one pass (the default): no first-order pass at all, the seeded second-order pass delivers both terms, same numbers
@@ -472,12 +473,13 @@ def test_force_matching_backward_combines_the_passes_with_the_right_signs(monkey
     assert calls == dict(first=0, second=1, hv=1, seeded=1)
     assert all(torch.allclose(p.grad, torch.full_like(p, expect), rtol=1e-5, atol=1e-5) for p in params)
     assert torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0 - hv0)
-    with pytest.warns(UserWarning, match="energy term's part"):
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
         g_pos = run(0, pos_grad=False, one_pass=True)
     assert calls == dict(first=0, second=1, hv=0, seeded=1) and torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0)
     assert all(torch.allclose(p.grad, torch.full_like(p, expect), rtol=1e-5, atol=1e-5) for p in params)
     calls.pop("seeded")
-    for order, extra in ((2, 2), (4, 4)):  # (None on a TensorNet model means 0: covered by the first run's explicit 0)
+    for order, extra in ((2, 2), (4, 4)):  # (None means 0 for every architecture: covered by the first run's explicit 0)
         with pytest.warns(UserWarning, match="energy term's part"):
             g_pos = run(order)
         assert calls == dict(first=1 + extra, second=0, hv=0) and torch.allclose(g_pos, -ge[batch].unsqueeze(1) * F0)

@@ -327,7 +327,7 @@ class _EnergyParamGrad(torch.autograd.Function):
         out = []
         for p in ctx.params:
             g = grads.get(p)
-            out.append(None if g is None or not p.requires_grad else g.to(p.dtype).reshape(p.shape))
+            out.append(None if g is None or not p.requires_grad else g.to(device=p.device, dtype=p.dtype).reshape(p.shape))
         return (None,) * 7 + tuple(out)
 
 
@@ -451,7 +451,7 @@ class _EnergyForceParamGrad(torch.autograd.Function):
         out = []
         for p in ctx.params:
             g = total.get(p)
-            out.append(None if g is None or not p.requires_grad else g.to(p.dtype).reshape(p.shape))
+            out.append(None if g is None or not p.requires_grad else g.to(device=p.device, dtype=p.dtype).reshape(p.shape))
         return (None, None, g_pos, None, None, None, None) + tuple(out)
 
 
@@ -996,7 +996,8 @@ class TorchMD_Net(nn.Module):
         _require_cuda(pos, "TorchMD_Net.forward")
         L = _C.lib()
         dev = pos.device
-        if next(self.parameters()).device != dev:
+        pdev = next(self.parameters()).device
+        if pdev != dev and pdev.type != "cpu":  # host-resident parameters are uploaded to the engine from the host (full upload)
             raise RuntimeError("model and inputs are on different devices")
         self._check_input(z, "z", dev, (torch.long,))
         self._check_input(batch, "batch", dev, (torch.long, torch.int32))
@@ -1179,6 +1180,20 @@ class TorchMD_Net(nn.Module):
             raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
         return out
 
+    def _forward_host_tensors(self, z, pos, batch, box, q, num_systems):
+        """HOST tensors (the reference's default: `create_model(args)` and `torch.randn(...)` live on the CPU, tests/test_model.py):
+        the inputs are staged to the current AMD GPU, the HIP engine computes there, and the outputs come back as host tensors on
+        `pos.device` - the boundary "hands over host buffers" (DESIGN: PCIe-inclusive).  This is NOT a CPU path: without a GPU the
+        call fails exactly as before.  The moves are autograd-visible (`Tensor.to`), so `energy.backward()` and `pos.grad` work on
+        the caller's host tensors; a module whose parameters live on the host is uploaded to the engine from there."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        pdev = next(self.parameters()).device
+        if pdev.type == "cuda":
+            dev = pdev
+        mv = lambda t: None if t is None else t.to(dev)
+        y, f = self.forward(z.to(dev), pos.to(dev), mv(batch), mv(box), mv(q), None, None, num_systems)
+        return y.to(pos.device), f.to(pos.device)
+
     # ---------------------------------------------------------------- reference-compatible forward
     def forward(self, z: Tensor, pos: Tensor, batch: Optional[Tensor] = None, box: Optional[Tensor] = None,
                 q: Optional[Tensor] = None, s: Optional[Tensor] = None, extra_args: Optional[Dict[str, Tensor]] = None,
@@ -1189,6 +1204,8 @@ class TorchMD_Net(nn.Module):
             raise NotImplementedError("torchmdnet_amd computes in fp32; cast positions to float32")
         if self.derivative:
             pos.requires_grad_(True)  # reference side effect (model.py:584-585)
+        if pos.device.type == "cpu" and torch.cuda.is_available():  # without a GPU: _require_cuda below raises, as ever
+            return self._forward_host_tensors(z, pos, batch, box, q, num_systems)
         if num_systems is not None:
             n_mol = int(num_systems)
         else:
@@ -1203,6 +1220,8 @@ class TorchMD_Net(nn.Module):
         rm = self.representation_model
         if box is None and rm.distance.use_periodic:
             box = rm.distance.box
+        if box is not None and box.device != pos.device:
+            box = box.to(pos.device)  # a host-resident module evaluated through _forward_host_tensors
         want_forces = bool(self.derivative or (pos.requires_grad and torch.is_grad_enabled()))
         _require_cuda(pos, "TorchMD_Net.forward")
         if self.parameter_gradients and torch.is_grad_enabled():

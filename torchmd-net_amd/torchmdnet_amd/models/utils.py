@@ -127,6 +127,13 @@ class OptimizedDistance(nn.Module):
 
     def forward(self, pos: Tensor, batch: Optional[Tensor] = None, box: Optional[Tensor] = None
                 ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+        if pos.device.type == "cpu" and torch.cuda.is_available():
+            # host tensors (the reference's tests build them on the CPU by default): staged to the current AMD GPU, the pair list is
+            # built by the HIP kernels there and comes back as host tensors; the moves are autograd-visible.  Not a CPU path:
+            # without a GPU the call fails below.
+            dev = torch.device("cuda", torch.cuda.current_device())
+            out = self.forward(pos.to(dev), None if batch is None else batch.to(dev), None if box is None else box.to(dev))
+            return tuple(None if t is None else t.to(pos.device) for t in out)
         _require_cuda(pos, "OptimizedDistance")
         if pos.dtype != torch.float32:
             raise RuntimeError("torchmdnet_amd neighbour kernels are fp32 (BASELINE north_star); got " + str(pos.dtype))
@@ -139,7 +146,14 @@ class OptimizedDistance(nn.Module):
         if batch is None:
             batch = torch.zeros(n, dtype=torch.long, device=pos.device)
         batch = batch.to(torch.long).contiguous()
-        n_mol = int(batch.max().item()) + 1 if n > 0 else 0
+        # the molecule count is a host read-back; while the stream is being captured into a HIP graph (reference
+        # tests/test_neighbors.py:452-588) the value of the warm-up calls is reused, as OutputModel.reduce does for dim_size
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self._n_mol = int(batch.max().item()) + 1 if n > 0 else 0
+        elif getattr(self, "_n_mol", None) is None:
+            raise RuntimeError("Warming up is needed before capturing OptimizedDistance into a CUDA graph")
+        n_mol = self._n_mol
         # registered torch op (torchmdnet_amd/ops.py: fake impl + autograd = the reference's neighbor_grad_positions as a HIP
         # kernel), same outputs as torch.ops.torchmdnet.warp_neighbor_{brute,cell}_fwd (warp_ops/neighbors.py:34-148)
         from torchmdnet_amd import ops  # noqa: F401  (registers torch.ops.tmdnet.*)
@@ -147,7 +161,7 @@ class OptimizedDistance(nn.Module):
         neighbors, deltas, dist, num_pairs = torch.ops.tmdnet.neighbor_pairs(
             pos, batch, box if use_periodic else None, float(self.cutoff_lower), float(self.cutoff_upper), int(max_pairs),
             bool(self.loop), bool(self.include_transpose), 1 if self.strategy == "cell" else 0, n_mol)
-        if not torch.compiler.is_compiling() and int(num_pairs.item()) > max_pairs:
+        if not torch.compiler.is_compiling() and not capturing and int(num_pairs.item()) > max_pairs:
             # reference: torch._assert_async -> RuntimeError (models/utils.py:297-300)
             raise RuntimeError("Found num_pairs > max_num_pairs, please increase max_num_pairs")
         edge_index, edge_vec, edge_weight = neighbors, deltas, dist
