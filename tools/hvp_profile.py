@@ -12,6 +12,7 @@ model = create_model(dict(W.C2_ARGS, derivative=True)).to(dev)
 z, pos, batch = W.synthetic_batch(n_mol=256, n_atoms=64)
 z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
 v = torch.randn_like(pos)
-for _ in range(int(os.environ.get("REPS", "4"))):
-    model.force_term_parameter_gradients(z, pos, batch, None, None, 256, v)
+ge = torch.randn(256, device=dev)
+for _ in range(int(os.environ.get("REPS", "4"))):  # the seeded pass of one-pass training (with H v), as a training step runs it
+    model.force_term_parameter_gradients(z, pos, batch, None, None, 256, v, want_hv=True, ge=ge)
 torch.cuda.synchronize()

@@ -118,16 +118,19 @@ def classify(nodeid, outcome, longrepr):
     return "fail", msg or (text.strip().splitlines()[-1][:300] if text.strip() else "")
 
 
-@pytest.hookimpl(hookwrapper=True)
-def pytest_runtest_makereport(item, call):
-    out = yield
-    rep = out.get_result()
-    if rep.when == "call" or (rep.when == "setup" and rep.outcome != "passed"):
-        cls, why = classify(item.nodeid, rep.outcome, str(rep.longrepr) if rep.longrepr else "")
-        RESULTS[item.nodeid] = {"outcome": rep.outcome, "class": cls, "why": why}
+def pytest_runtest_logreport(report):
+    # (runs in the controller for every worker's reports under pytest-xdist, including "worker crashed" ones)
+    if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
+        text = getattr(report, "longreprtext", "") or (str(report.longrepr) if report.longrepr else "")
+        cls, why = classify(report.nodeid, report.outcome, text)
+        if "crashed" in text and "worker" in text:
+            cls, why = "fail", "the test process died (hard crash inside torch / the runtime): " + text.strip().splitlines()[0][:160]
+        RESULTS[report.nodeid] = {"outcome": report.outcome, "class": cls, "why": why}
 
 
 def pytest_sessionfinish(session, exitstatus):
+    if hasattr(session.config, "workerinput"):
+        return  # a pytest-xdist worker: the controller writes the report
     path = os.environ.get("REF_TEST_REPORT", os.path.join(REPO, "gpurun_out", "reference_tests.json"))
     os.makedirs(os.path.dirname(path), exist_ok=True)
     summary = {}

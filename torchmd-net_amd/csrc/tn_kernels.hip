@@ -949,6 +949,84 @@ void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, con
                      PairRowTable{});
 }
 
+// Value + tangent of a neighbour sum in ONE sweep (second-order pass, tn_hvp_api.hip):
+//     out[i] += sum_e w[p(e)] src[col(e)] ;  out_t[i] += sum_e w[p(e)] src_t[col(e)]  (+)  sum_e w_t[p(e)] src[col(e)]
+// Three plain sweeps read w twice and w_t once (and the adjacency three times); here every pair row is read once per row atom.
+// The three sums are accumulated separately in list order and added in the order the three launches did: bit-identical to them.
+__global__ void k_message_dual(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ w_t,
+                               const float* __restrict__ src, const float* __restrict__ src_t, float* __restrict__ out,
+                               float* __restrict__ out_t) {
+  const int i = xcd_chunk(blockIdx.x, gridDim.x);
+  if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
+  const int F3 = 3 * F, F9 = 9 * F;
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float a[9], b1[9], b2[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) a[c] = b1[c] = b2[c] = 0.f;
+    struct In {
+      float w[3], wt[3], s[9], st[9];
+    };
+    auto load = [&](int e, In& o) {
+      const int j = g.col[e], p = g.epair[e];
+      const float* wp = w + (int64_t)p * F3 + f;
+      const float* wq = w_t + (int64_t)p * F3 + f;
+      const float* sp = src + (int64_t)j * F9 + f;
+      const float* sq = src_t + (int64_t)j * F9 + f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        o.w[k] = wp[k * F];
+        o.wt[k] = wq[k * F];
+      }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        o.s[c] = sp[c * F];
+        o.st[c] = sq[c * F];
+      }
+    };
+    auto add = [&](const In& o) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const int k = type_of(c);
+        a[c] = __fmaf_rn(o.w[k], o.s[c], a[c]);
+        b1[c] = __fmaf_rn(o.w[k], o.st[c], b1[c]);
+        b2[c] = __fmaf_rn(o.wt[k], o.s[c], b2[c]);
+      }
+    };
+    int e = e0;
+    for (; e + 2 <= e1; e += 2) {  // two edges' rows requested together (48 loads in flight), accumulated in list order
+      In x0, x1;
+      load(e, x0);
+      load(e + 1, x1);
+      add(x0);
+      add(x1);
+    }
+    if (e < e1) {
+      In x0;
+      load(e, x0);
+      add(x0);
+    }
+    float* o = out + (int64_t)i * F9 + f;
+    float* ot = out_t + (int64_t)i * F9 + f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      o[c * F] += a[c];
+      ot[c * F] = (ot[c * F] + b1[c]) + b2[c];
+    }
+  }
+}
+void launch_message_dual(const Graph& g, int N, int F, const float* w, const float* w_t, const float* src, const float* src_t,
+                         float* out, float* out_t, hipStream_t s) {
+  if (N <= 0) return;
+  if (split_rows_ok(N, F)) {  // small systems: the split-row sweeps (the chip is mostly idle there: three launches are fine)
+    launch_message_adjoint(g, N, F, w, src, out, s);
+    launch_message_adjoint(g, N, F, w, src_t, out_t, s);
+    launch_message_adjoint(g, N, F, w_t, src, out_t, s);
+    return;
+  }
+  hipLaunchKernelGGL(k_message_dual, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, w_t, src, src_t, out, out_t);
+}
+
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
   if (N <= 0) return;
   if (split_rows_ok(N, F)) {

@@ -124,8 +124,40 @@ __global__ __launch_bounds__(256) void k_reduce_slices_wide(const float* __restr
     out[i] = t;
   }
 }
+// many outputs (a 3F x 2F weight: 98 304) x ~100 slices: one thread per output is 1.5 waves per SIMD walking its slices one
+// dependent-latency load at a time (73 us, 0.7 TB/s): four threads (one per wave of the block) share an output - consecutive
+// lanes = consecutive outputs, so every load instruction is a full line - eight slices requested per trip, fixed order inside
+// the thread and across the four
+__global__ __launch_bounds__(256) void k_reduce_slices4(const float* __restrict__ part, int slices, int64_t n, int accumulate,
+                                                        float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  float s = 0.f;
+  if (i < n) {
+    int k = grp;
+    for (; k + 28 < slices; k += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(k + 4 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < slices; k += 4) s += part[(int64_t)k * n + i];
+  }
+  red[grp][e] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    float t = accumulate ? out[i] : 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) t += red[l][e];
+    out[i] = t;
+  }
+}
 static void reduce_slices(hipStream_t s, const float* part, int slices, int64_t n, bool accumulate, float* out) {
-  if (slices >= 32 && n <= 16384)
+  if (slices >= 16 && n > 16384)
+    hipLaunchKernelGGL(k_reduce_slices4, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, slices, n, accumulate ? 1 : 0, out);
+  else if (slices >= 32 && n <= 16384)
     hipLaunchKernelGGL(k_reduce_slices_wide, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, part, slices, n, accumulate ? 1 : 0, out);
   else
     hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, slices, n, accumulate ? 1 : 0, out);

@@ -1028,9 +1028,9 @@ class TorchMD_Net(nn.Module):
             L.tmdnet_set_cell_grid(st.handle, *((-1, -1, -1) if auto else (0, 0, 0)))
             nbytes = C.c_size_t(0)
             L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
-            st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
             counts = (C.c_int64 * 8)()
             static = bool(getattr(self.representation_model, "static_shapes", False))
+            st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
             if static:
                 # static shapes (reference tensornet.py:277-290): no read-back, no synchronisation -> the whole call
                 # can be captured in a HIP graph; launch grids / workspaces are sized by max_num_neighbors * N

@@ -138,9 +138,12 @@ class OptimizedDistance(nn.Module):
         if pos.dtype != torch.float32:
             raise RuntimeError("torchmdnet_amd neighbour kernels are fp32 (BASELINE north_star); got " + str(pos.dtype))
         use_periodic = self.use_periodic or box is not None
-        if box is None:
-            box = self.box
-        box = box.to(device=pos.device, dtype=pos.dtype).contiguous()
+        if use_periodic:
+            if box is None:
+                box = self.box
+            box = box.to(device=pos.device, dtype=pos.dtype).contiguous()  # (no copy when the module lives on pos.device)
+        else:
+            box = None  # the zero buffer is never read: no host-to-device copy of it (not permitted while a stream is capturing)
         n = pos.shape[0]
         max_pairs = self.max_num_pairs if self.max_num_pairs >= 0 else -self.max_num_pairs * n
         if batch is None:
