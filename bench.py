@@ -226,6 +226,32 @@ def traffic_source(pmc, kernel_name):
             "kernel_name": kernel_name, "measured_in_this_run": False}
 
 
+def request_ceiling(kernel_prefix, avg_launch_us):
+    """Second ceiling of a gather sweep: its L2 REQUEST rate against the rate the vector memory path sustains for
+    random 128-byte pieces (tools/microbench/gather_bw.hip: 6.8 TB/s = 53.1 G requests/s over 256 CUs).  Requests per launch are
+    TCC_REQ_sum of the committed counter table (profiles/pmc_issue.json, tools/pmc_issue.py: own rocprofv3 --pmc passes), the
+    launch time is this run's.  A sweep at ~0.9 of this ceiling with ~0.4 of the HBM one is bound by the number of requests it
+    makes, not by the bytes they carry."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json")))
+    except Exception:
+        return None
+    hits = [(k, v) for k, v in tab.get("kernels", {}).items() if k.startswith(kernel_prefix) and v.get("TCC_REQ_sum")]
+    if not hits:
+        return None
+    name, k = max(hits, key=lambda kv: kv[1]["TCC_REQ_sum"])
+    peak = 6.8e12 / 128 / 1e9
+    ach = k["TCC_REQ_sum"] / (avg_launch_us * 1e-6) / 1e9
+    out = {"bound": "l2_requests", "achieved": ach, "peak": peak, "unit": "G requests/s", "frac": ach / peak,
+           "requests_per_launch": k["TCC_REQ_sum"], "read_requests_per_launch": k.get("TCP_TCC_READ_REQ_sum"),
+           "peak_note": "random 128-byte pieces, 4 requests in flight per wave at 2 waves per SIMD: 6.8 TB/s (tools/microbench/gather_bw.hip)",
+           "source": {"file": "profiles/pmc_issue.json", "kernel_name": name, "git_commit": tab.get("git_commit"), "measured_in_this_run": False}}
+    for key in ("frac_wait_any", "frac_wait_inst_any", "frac_active_inst_any", "lds_bank_conflict_frac", "l2_hit_rate"):
+        if key in k:
+            out[key] = k[key]
+    return out
+
+
 def load_pmc():
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
@@ -379,10 +405,11 @@ def training_leg(dev, L, steps=4, warmup=2):
     z, pos, batch = W.synthetic_batch(n_mol=N_MOL, n_atoms=N_ATOMS)
     z, pos, batch = z.to(dev), pos.to(dev), batch.to(dev)
 
-    def time_step(args, deriv, order, one_pass, q=None):
+    def time_step(args, deriv, order, one_pass, q=None, pos_grad=True):
         torch.manual_seed(0)
         model = create_model(dict(args, derivative=deriv)).to(dev)
         model.parameter_gradients = True
+        model.force_position_gradient = pos_grad
         model.force_gradient_order = order  # None: the default (analytic second-order pass); 2: central difference, two extra passes
         model.one_pass_training = one_pass  # True (default): the seeded second-order pass delivers the energy term's gradient too
         opt = torch.optim.SGD(model.parameters(), lr=1e-7)
@@ -413,6 +440,9 @@ def training_leg(dev, L, steps=4, warmup=2):
     out["ms_per_step_energy_only"] = time_step(W.C2_ARGS, False, None, True)
     out["ms_per_step_energy_and_forces"] = time_step(W.C2_ARGS, True, None, True)
     out["energy_and_forces_over_energy_only"] = out["ms_per_step_energy_and_forces"] / out["ms_per_step_energy_only"]
+    # the default also delivers d loss / d pos = -H v (pos requires grad in derivative mode, the reference's side effect, so its
+    # autograd computes it too); a training loop that never reads pos.grad switches it off with force_position_gradient = False
+    out["ms_per_step_energy_and_forces_no_position_gradient"] = time_step(W.C2_ARGS, True, None, True, pos_grad=False)
     out["ms_per_step_energy_and_forces_two_passes"] = time_step(W.C2_ARGS, True, None, False)
     out["ms_per_step_energy_and_forces_difference_quotient"] = time_step(W.C2_ARGS, True, 2, False)
     tn2 = dict(W.C2_ARGS, model="tensornet2", output_model="ScalarPlusWeightedCoulomb", q_dim=16, q_weights=[1.0, 1.0, 1.0])
@@ -687,6 +717,10 @@ def main():
                          cls_rec["launches"] // max(rsteps, 1), "share_of_step": cls_rec["ms"] / rsteps / (el / a.steps * 1e3),
                          "traffic": cavg.get("traffic"), "traffic_ratio": cavg.get("traffic_ratio")}
         gemm_rec = rgroups.get(("gemm_node", gemm_label))
+        if dom_cls == "message":
+            rq = request_ceiling("k_message_adjoint_rows8" if "adjoint" in dom_label else "k_message_rows8", roof["avg_launch_us"])
+            if rq:
+                roof["request_ceiling"] = rq
         out = {
             "metric": "molecules/sec (64-atom molecules) TensorNet E+F",
             "value": mols_per_step * a.steps / el,
