@@ -235,6 +235,93 @@ __global__ __launch_bounds__(TB) void k_edge_geom_dual(Graph g, int E, int N, in
     }
   }
 }
+// the same per (edge, channel) arithmetic with a WAVE PER ROW ATOM: the atom's gA / gA_t (20 values per channel) stay in registers while
+// the wave walks the row's edges - the wave-per-edge kernel above re-read them for every edge (13 KB per edge instead of 3: 0.94 ms
+// at the bench batch).  The next edge's records and rows are requested before the current edge is reduced.  F <= 64 NCH.
+template <int NCH>
+__global__ __launch_bounds__(TB) void k_edge_geom_rows(Graph g, int N, int F, int P, const int64_t* __restrict__ z,
+                                                       const float* __restrict__ Utab, const float* __restrict__ Vtab,
+                                                       const float* __restrict__ Q, const float* __restrict__ Q_t,
+                                                       const float* __restrict__ C, const float* __restrict__ C_t,
+                                                       const float* __restrict__ rhat_t, const float* __restrict__ gA,
+                                                       const float* __restrict__ gA_t, float* __restrict__ ec, float* __restrict__ ec_t,
+                                                       int64_t dir_stride) {
+  const int i = blockIdx.x * (TB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= N) return;  // wave-uniform
+  const int F3 = 3 * F, F10 = 10 * F;
+  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  float a[NCH][10], at[NCH][10], ui[NCH];
+  const int64_t zi = z[i];
+#pragma unroll
+  for (int u = 0; u < NCH; ++u) {
+    const int f = min(lane + 64 * u, F - 1);  // lanes past F: a valid channel, masked below
+    ui[u] = Utab[zi * F + f];
+#pragma unroll
+    for (int cc = 0; cc < 10; ++cc) {
+      a[u][cc] = gA[(int64_t)i * F10 + cc * F + f];
+      at[u][cc] = gA_t[(int64_t)i * F10 + cc * F + f];
+    }
+  }
+  struct Rec {
+    float sg, c, ct, r[3], rt[3], q[NCH][3], qt[NCH][3], vj[NCH];
+    int p;
+  };
+  auto load = [&](int e, Rec& o) {
+    e = min(e, e1 - 1);
+    o.sg = g.esign[e];
+    o.p = g.epair[e];
+    const int pc = min(o.p, P);  // (row P exists: the self pair's)
+    const int64_t zj = z[g.col[e]];
+    o.c = C[pc];
+    o.ct = C_t[pc];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+      o.r[x] = g.prhat[pc * 3 + x];
+      o.rt[x] = rhat_t[pc * 3 + x];
+    }
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int f = min(lane + 64 * u, F - 1);
+      o.vj[u] = Vtab[zj * F + f];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        o.q[u][k] = Q[(int64_t)pc * F3 + k * F + f];
+        o.qt[u][k] = Q_t[(int64_t)pc * F3 + k * F + f];
+      }
+    }
+  };
+  if (e0 >= e1) return;
+  Rec cur, nxt;
+  load(e0, cur);
+  for (int e = e0; e < e1; ++e) {
+    load(e + 1, nxt);
+    if (cur.sg != 0.f && cur.p < P) {  // wave-uniform
+      float r[3], rt[3], acc[4] = {0.f, 0.f, 0.f, 0.f}, acc_t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        r[x] = cur.sg * cur.r[x];
+        rt[x] = cur.sg * cur.rt[x];
+      }
+#pragma unroll
+      for (int u = 0; u < NCH; ++u)
+        if (lane + 64 * u < F) edge_geom_core(a[u], at[u], ui[u] + cur.vj[u], cur.q[u], cur.qt[u], r, rt, cur.c, cur.ct, acc, acc_t);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        acc[x] = wave_sum(acc[x]);
+        acc_t[x] = wave_sum(acc_t[x]);
+      }
+      if (lane == 0) {
+        const int64_t o = (cur.sg > 0.f ? 0 : dir_stride) + (int64_t)cur.p * 4;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          ec[o + x] = acc[x];
+          ec_t[o + x] = acc_t[x];
+        }
+      }
+    }
+    cur = nxt;
+  }
+}
 __global__ __launch_bounds__(TB) void k_geom_dual(Graph g, int P, const float* __restrict__ d_t, const float* __restrict__ rhat_t,
                                                   const float* __restrict__ dC, const float* __restrict__ d2C, const float* __restrict__ gC,
                                                   const float* __restrict__ gC_t, const float* __restrict__ gphid,
@@ -359,7 +446,9 @@ void launch_pair_rowdot(int rows, int W, const float* x, const float* x_t, const
 void launch_edge_geom_dual(const Graph& g, int E, int N, int F, int P, const int64_t* z, const float* Utab, const float* Vtab, const float* Q,
                            const float* Q_t, const float* C, const float* C_t, const float* rhat_t, const float* gA, const float* gA_t,
                            float* ec, float* ec_t, int64_t dir_stride, hipStream_t s) {
-  LAUNCH(k_edge_geom_dual, (int64_t)E * 64, g, E, N, F, P, z, Utab, Vtab, Q, Q_t, C, C_t, rhat_t, gA, gA_t, ec, ec_t, dir_stride);  // a wave per edge
+  if (F <= 64) LAUNCH((k_edge_geom_rows<1>), (int64_t)N * 64, g, N, F, P, z, Utab, Vtab, Q, Q_t, C, C_t, rhat_t, gA, gA_t, ec, ec_t, dir_stride);  // a wave per row atom
+  else if (F <= 128) LAUNCH((k_edge_geom_rows<2>), (int64_t)N * 64, g, N, F, P, z, Utab, Vtab, Q, Q_t, C, C_t, rhat_t, gA, gA_t, ec, ec_t, dir_stride);
+  else LAUNCH(k_edge_geom_dual, (int64_t)E * 64, g, E, N, F, P, z, Utab, Vtab, Q, Q_t, C, C_t, rhat_t, gA, gA_t, ec, ec_t, dir_stride);  // a wave per edge
 }
 void launch_geom_dual(const Graph& g, int P, const float* d_t, const float* rhat_t, const float* dC, const float* d2C, const float* gC,
                       const float* gC_t, const float* gphid, const float* gphid_t, const float* ec, const float* ec_t, int64_t dir_stride,

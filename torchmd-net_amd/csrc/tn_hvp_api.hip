@@ -420,9 +420,7 @@ int tmdnet_loss_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void*
       hvp::launch_edge_sweep2(g, N, F, nullptr, y.w, y.Pn, nullptr, nullptr, nullptr, y.Mi, s);
       hvp::launch_edge_sweep2(g, N, F, nullptr, y.w, y.Pn_t, y.w_t, y.Pn, nullptr, y.Mi_t, s);
     } else {
-      launch_fill(y.Mi, 0.f, N9, s);
-      launch_fill(y.Mi_t, 0.f, N9, s);
-      launch_message_dual(g, N, F, y.w, y.w_t, y.Pn, y.Pn_t, y.Mi, y.Mi_t, s);  // one sweep: every pair row read once per row atom
+      launch_message_dual(g, N, F, y.w, y.w_t, y.Pn, y.Pn_t, y.Mi, y.Mi_t, false, s);  // one sweep: every pair row read once per row atom
     }
     hvp::launch_group_dual(N, F, y.Pn, y.Pn_t, y.Mi, y.Mi_t, kap, o3, y.Ch, y.Ch_t, s);
     tensor_linear(s, y.Ch, q_.V + 3, y.D, N, F);
@@ -489,7 +487,7 @@ int tmdnet_loss_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void*
       if (hv) hvp::launch_edge_rowdot(g, E, F, F, b.gcp, b.gcp_t, nullptr, nullptr, b.d_t, true, t2.gCe, t2.gCe_t, s);
     } else {
     hvp::launch_group_bwd_dual(N, F, b.g_Ch, b.g_Ch_t, y.Pn, y.Pn_t, y.Mi, y.Mi_t, kap, o3, b.g_Mi, b.g_Mi_t, b.g_Pn, b.g_Pn_t, s);
-    launch_message_dual(g, N, F, y.w, y.w_t, b.g_Mi, b.g_Mi_t, b.g_Pn, b.g_Pn_t, s);
+    launch_message_dual(g, N, F, y.w, y.w_t, b.g_Mi, b.g_Mi_t, b.g_Pn, b.g_Pn_t, true, s);
     // edge MLP: g_w per pair (self pair: summed over the atoms, per irreducible type), back through silu(.) C, M3, M2, M1
     for (int k = 0; k < 3; ++k) {
       const int64_t o = (int64_t)c0_[k] * F;

@@ -765,20 +765,11 @@ HVP_FN int edge_geom_row(int e, int N, const int* rowptr) {
   }
   return lo_;
 }
-HVP_FN void edge_geom_term(int i, int j, int p, int f, int F, const float r[3], const float rt[3], float c, float ct, const int64_t* z,
-                           const float* Utab, const float* Vtab, const float* Q, const float* Q_t, const float* gA, const float* gA_t,
-                           float acc[4], float acc_t[4]) {
-  const int F3 = 3 * F, F10 = 10 * F;
-  const float zij = Utab[z[i] * F + f] + Vtab[z[j] * F + f];
-  float a[10], at[10], q[3], qt[3], w[3], wt[3];
-  for (int cc = 0; cc < 10; ++cc) {
-    a[cc] = gA[(int64_t)i * F10 + cc * F + f];
-    at[cc] = gA_t[(int64_t)i * F10 + cc * F + f];
-  }
-  for (int k = 0; k < 3; ++k) {
-    q[k] = Q[(int64_t)p * F3 + k * F + f];
-    qt[k] = Q_t[(int64_t)p * F3 + k * F + f];
-  }
+// the arithmetic of one (edge, channel) on values already at hand: a / at = gA / gA_t of the row atom (10 components), zij = U[z_i] + V[z_j],
+// q / qt = the pair's distance projections and their tangents
+HVP_FN void edge_geom_core(const float a[10], const float at[10], float zij, const float q[3], const float qt[3], const float r[3],
+                           const float rt[3], float c, float ct, float acc[4], float acc_t[4]) {
+  float w[3], wt[3];
   edge_gw(a, at, r, rt, w, wt);
   for (int k = 0; k < 3; ++k) {
     acc[0] += w[k] * zij * q[k];
@@ -796,6 +787,22 @@ HVP_FN void edge_geom_term(int i, int j, int p, int f, int F, const float r[3], 
     acc[1 + x] += a[1 + x] * W1 + dq[x] * W2;
     acc_t[1 + x] += at[1 + x] * W1 + a[1 + x] * W1t + dqt[x] * W2 + dq[x] * W2t;
   }
+}
+HVP_FN void edge_geom_term(int i, int j, int p, int f, int F, const float r[3], const float rt[3], float c, float ct, const int64_t* z,
+                           const float* Utab, const float* Vtab, const float* Q, const float* Q_t, const float* gA, const float* gA_t,
+                           float acc[4], float acc_t[4]) {
+  const int F3 = 3 * F, F10 = 10 * F;
+  const float zij = Utab[z[i] * F + f] + Vtab[z[j] * F + f];
+  float a[10], at[10], q[3], qt[3];
+  for (int cc = 0; cc < 10; ++cc) {
+    a[cc] = gA[(int64_t)i * F10 + cc * F + f];
+    at[cc] = gA_t[(int64_t)i * F10 + cc * F + f];
+  }
+  for (int k = 0; k < 3; ++k) {
+    q[k] = Q[(int64_t)p * F3 + k * F + f];
+    qt[k] = Q_t[(int64_t)p * F3 + k * F + f];
+  }
+  edge_geom_core(a, at, zij, q, qt, r, rt, c, ct, acc, acc_t);
 }
 // the whole edge by one thread (host check; the kernel spreads the channels over a wave and reduces)
 HVP_FN void edge_geom_dual(int e, int N, int F, int P, const int* rowptr, const int* col, const int* epair, const float* esign,

@@ -84,7 +84,7 @@ void launch_norm_x(const float* X, float* Xh, int N, int F, hipStream_t s);
 // mode 0: forward message + O(3)/SO(3) product + normalisation -> Mi, Ch ; mode 1: dst[i] += sum_e w * src[j] (adjoint)
 struct PairRowTable;  // tn_interp.h: a layer's radial table for sweeps that evaluate the per-pair rows themselves
 void launch_message_dual(const Graph& g, int N, int F, const float* w, const float* w_t, const float* src, const float* src_t,
-                         float* out, float* out_t, hipStream_t s);  // value + tangent sweep (second-order pass)
+                         float* out, float* out_t, bool accumulate, hipStream_t s);  // value + tangent sweep (second-order pass)
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
                     float* Mi, float* Ch, hipStream_t s, const PairRowTable* rt = nullptr);
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);

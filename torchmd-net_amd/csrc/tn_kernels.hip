@@ -953,6 +953,7 @@ void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, con
 //     out[i] += sum_e w[p(e)] src[col(e)] ;  out_t[i] += sum_e w[p(e)] src_t[col(e)]  (+)  sum_e w_t[p(e)] src[col(e)]
 // Three plain sweeps read w twice and w_t once (and the adjacency three times); here every pair row is read once per row atom.
 // The three sums are accumulated separately in list order and added in the order the three launches did: bit-identical to them.
+template <bool ACC>  // ACC: out += ... (the reverse site adds to what the group-product adjoint wrote); else out = ... (no zero fill, no read)
 __global__ void k_message_dual(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ w_t,
                                const float* __restrict__ src, const float* __restrict__ src_t, float* __restrict__ out,
                                float* __restrict__ out_t) {
@@ -1010,21 +1011,31 @@ __global__ void k_message_dual(Graph g, int N, int F, const float* __restrict__ 
     float* ot = out_t + (int64_t)i * F9 + f;
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      o[c * F] += a[c];
-      ot[c * F] = (ot[c * F] + b1[c]) + b2[c];
+      if (ACC) {
+        o[c * F] += a[c];
+        ot[c * F] = (ot[c * F] + b1[c]) + b2[c];
+      } else {  // (= 0 + a, (0 + b1) + b2: what the three launches over a zero-filled buffer gave)
+        o[c * F] = a[c];
+        ot[c * F] = b1[c] + b2[c];
+      }
     }
   }
 }
 void launch_message_dual(const Graph& g, int N, int F, const float* w, const float* w_t, const float* src, const float* src_t,
-                         float* out, float* out_t, hipStream_t s) {
+                         float* out, float* out_t, bool accumulate, hipStream_t s) {
   if (N <= 0) return;
   if (split_rows_ok(N, F)) {  // small systems: the split-row sweeps (the chip is mostly idle there: three launches are fine)
+    if (!accumulate) {
+      launch_fill(out, 0.f, (int64_t)N * 9 * F, s);
+      launch_fill(out_t, 0.f, (int64_t)N * 9 * F, s);
+    }
     launch_message_adjoint(g, N, F, w, src, out, s);
     launch_message_adjoint(g, N, F, w, src_t, out_t, s);
     launch_message_adjoint(g, N, F, w_t, src, out_t, s);
     return;
   }
-  hipLaunchKernelGGL(k_message_dual, dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, w_t, src, src_t, out, out_t);
+  if (accumulate) hipLaunchKernelGGL((k_message_dual<true>), dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, w_t, src, src_t, out, out_t);
+  else hipLaunchKernelGGL((k_message_dual<false>), dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, w_t, src, src_t, out, out_t);
 }
 
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s) {
