@@ -428,13 +428,13 @@ def test_force_matching_backward_combines_the_passes_with_the_right_signs(monkey
         calls["first"] += 1
         return E0, {p: torch.full_like(p, float(ge.sum())) for p in params}
 
-    def force_term_parameter_gradients(z_, pos_, batch_, box, q, n_mol_, v, want_hv=False, ge=None):
+    def force_term_parameter_gradients(z_, pos_, batch_, box, q, n_mol_, v, want_hv=False, ge=None, scale=1.0):
         # with an energy seed: the gradients of S = s - sum ge E (parameters: minus the energy pass' stand-in; positions: + ge F)
         calls["second"] += 1
         calls["hv"] += int(want_hv)
         calls["seeded"] = calls.get("seeded", 0) + int(ge is not None)
-        g = {p: torch.full_like(p, float(v.sum()) - (0.0 if ge is None else float(ge.sum()))) for p in params}
-        hv = hv0.clone() if ge is None else hv0 + ge[batch_].unsqueeze(1) * F0
+        g = {p: scale * torch.full_like(p, float(v.sum()) - (0.0 if ge is None else float(ge.sum()))) for p in params}
+        hv = scale * (hv0.clone() if ge is None else hv0 + ge[batch_].unsqueeze(1) * F0)  # (the engine scales its flat output once)
         return (g, hv) if want_hv else g
 
     monkeypatch.setattr(M, "_direct_radial_functions", lambda m: contextlib.nullcontext())

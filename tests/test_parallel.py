@@ -230,9 +230,9 @@ def _ddp_worker(rank, world, port, tmpdir):
     model.energy_and_forces = lambda *a, **k: (E0.clone(), F0.clone())
     model.parameter_gradients_of = lambda z_, p_, b_, box, q, nm, ge: (E0, {p: torch.full_like(p, w * float(ge.sum())) for p in params})
 
-    def second(z_, p_, b_, box, q, nm, v, want_hv=False, ge=None):
+    def second(z_, p_, b_, box, q, nm, v, want_hv=False, ge=None, scale=1.0):
         # seeded (one-pass training): the gradient of s - sum ge E, i.e. the force term minus the energy pass' stand-in
-        g = {p: torch.full_like(p, w * (float(v.sum()) - (0.0 if ge is None else float(ge.sum())))) for p in params}
+        g = {p: torch.full_like(p, scale * w * (float(v.sum()) - (0.0 if ge is None else float(ge.sum())))) for p in params}
         return (g, torch.zeros(n, 3)) if want_hv else g
 
     model.force_term_parameter_gradients = second

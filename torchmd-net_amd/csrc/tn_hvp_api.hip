@@ -293,16 +293,15 @@ int tmdnet_loss_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void*
   // dW = g_y_t^T x + g_y^T x_t  and  db = colsum(g_y_t)  of a dense layer y = x W^T + b
   auto dense_grad = [&](const float* gy, const float* gy_t, RowMap mg, const float* x, const float* x_t, RowMap mx, int R, int Nout, int Kin,
                         const std::string& wkey, const std::string& bkey) {
-    launch_tn_gemm(s, gy_t, mg, x, mx, nullptr, nullptr, R, Nout, Kin, at(wkey), false, b.part);
-    launch_tn_gemm(s, gy, mg, x_t, mx, nullptr, nullptr, R, Nout, Kin, at(wkey), true, b.part);
+    launch_tn_gemm_pair(s, gy_t, x, gy, x_t, mg, mx, nullptr, R, Nout, Kin, at(wkey), false, b.part);
     if (!bkey.empty()) launch_colsum(s, gy_t, mg, nullptr, mg, nullptr, nullptr, R, Nout, at(bkey), false, b.part);
   };
   // the three weight sets of a 9-component tensor linear out_c = in_c W_type(c)^T
   auto tensor_linear_grad = [&](const float* gO, const float* gO_t, const float* In, const float* In_t, const std::string& key) {
     for (int t = 0; t < 3; ++t) {
       const int64_t o = (int64_t)c0_[t] * F;
-      launch_tn_gemm(s, gO_t + o, rc_[t], In + o, rc_[t], nullptr, nullptr, N * nc_[t], F, F, at(key + std::to_string(t)), false, b.part);
-      launch_tn_gemm(s, gO + o, rc_[t], In_t + o, rc_[t], nullptr, nullptr, N * nc_[t], F, F, at(key + std::to_string(t)), true, b.part);
+      launch_tn_gemm_pair(s, gO_t + o, In + o, gO + o, In_t + o, rc_[t], rc_[t], nullptr, N * nc_[t], F, F, at(key + std::to_string(t)), false,
+                          b.part);
     }
   };
   // scale-vector gradients of a LayerNorm: d w = colsum(g_t xh + g xh_t), d b = colsum(g_t)

@@ -19,6 +19,8 @@ inline RowMap rows_comp(int F, int ncomp) { return RowMap{(int64_t)9 * F, ncomp,
 
 size_t train_part_floats(int R, int64_t out_elems);  // scratch of one launch_tn_gemm / launch_colsum
 // out[n][k] (+)= sum_r A[r][n] * rowscale[r] * B[r][k]     (r_dev: optional device-side row count, min'ed with R)
+void launch_tn_gemm_pair(hipStream_t s, const float* A1, const float* B1, const float* A2, const float* B2, RowMap ma, RowMap mb,
+                         const int* r_dev, int R, int Nout, int Kin, float* out, bool accumulate, float* part);  // out (+)= A1^T B1 + A2^T B2
 void launch_tn_gemm(hipStream_t s, const float* A, RowMap ma, const float* B, RowMap mb, const float* rowscale, const int* r_dev, int R,
                     int Nout, int Kin, float* out, bool accumulate, float* part);
 // out[c] (+)= sum_r A[r][c] * (B ? B[r][c] : 1) * rowscale[r]

@@ -168,12 +168,20 @@ static void reduce_slices(hipStream_t s, const float* part, int slices, int64_t 
 // operand traffic per flop, no LDS, no barrier.  For every product whose output is whole 128 x 128 tiles (F = 128: the edge MLP's
 // 3F x 2F and 2F x F, the per-atom MLPs, the F x F tensor linears by irreducible type).
 // Nout, Kin multiples of 128, no row scale.
+// A2 / B2 (optional): a second product with the same row maps and shapes whose partial outputs follow the first one's - the two
+// terms g_y_t^T x + g_y^T x_t of a dual weight gradient are then ONE launch and ONE slice reduction (blockIdx.y >= seg_slices).
 __global__ __launch_bounds__(256) void k_tn_gemm128(const float* __restrict__ A, RowMap ma, const float* __restrict__ B, RowMap mb,
+                                                    const float* __restrict__ A2, const float* __restrict__ B2, int seg_slices,
                                                     const int* __restrict__ r_dev, int R, int Nout, int Kin,
                                                     int tiles_k, int rows_per_wave, float* __restrict__ part) {
   if (r_dev) R = min(R, *r_dev);
   const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = blockIdx.y * 4 + wave;
+  const bool second = (int)blockIdx.y >= seg_slices;  // block-uniform
+  if (second) {
+    A = A2;
+    B = B2;
+  }
+  const int sub = ((int)blockIdx.y - (second ? seg_slices : 0)) * 4 + wave;
   const int tn_ = tile / tiles_k, tk = tile - tn_ * tiles_k;
   const int n0 = tn_ * 128, k0 = tk * 128;
   const int kk = lane >> 5, cl = lane & 31;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(256) void k_tn_gemm128(const float* __restrict__ A,
         b[u][i] = bn[u][i];
       }
   }
-  float* o = part + (int64_t)sub * Nout * Kin;
+  float* o = part + (int64_t)((int)blockIdx.y * 4 + wave) * Nout * Kin;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -251,7 +259,8 @@ void launch_tn_gemm(hipStream_t s, const float* A, RowMap ma, const float* B, Ro
     int slices = std::max(1, std::min({max_partials(n) / 4, (1536 + 4 * tiles - 1) / (4 * tiles), R / 256}));
     int rpw = (R + 4 * slices - 1) / (4 * slices);
     rpw = (rpw + 1) & ~1;  // pairs of rows
-    hipLaunchKernelGGL(k_tn_gemm128, dim3(tiles, slices), dim3(256), 0, s, A, ma, B, mb, r_dev, R, Nout, Kin, Kin / 128, rpw, part);
+    hipLaunchKernelGGL(k_tn_gemm128, dim3(tiles, slices), dim3(256), 0, s, A, ma, B, mb, nullptr, nullptr, slices, r_dev, R, Nout, Kin,
+                       Kin / 128, rpw, part);
     reduce_slices(s, part, 4 * slices, n, accumulate, out);
     return;
   }
@@ -266,6 +275,26 @@ void launch_tn_gemm(hipStream_t s, const float* A, RowMap ma, const float* B, Ro
   hipLaunchKernelGGL(k_tn_gemm, dim3(tiles_n * tiles_k, slices), dim3(256), 0, s, A, ma, B, mb, rowscale, r_dev, R, Nout, Kin, tiles_k, rps,
                      part);
   reduce_slices(s, part, slices, n, accumulate, out);
+}
+
+// out (+)= A1^T B1 + A2^T B2 (same row maps, shapes and row count): one launch and one slice reduction where the 128 x 128 kernel
+// applies, two plain products otherwise
+void launch_tn_gemm_pair(hipStream_t s, const float* A1, const float* B1, const float* A2, const float* B2, RowMap ma, RowMap mb,
+                         const int* r_dev, int R, int Nout, int Kin, float* out, bool accumulate, float* part) {
+  if (Nout <= 0 || Kin <= 0) return;
+  const int64_t n = (int64_t)Nout * Kin;
+  if (Nout % 128 == 0 && Kin % 128 == 0 && R >= 4096 && max_partials(n) >= 8) {
+    const int tiles = (Nout / 128) * (Kin / 128);
+    int slices = std::max(1, std::min({max_partials(n) / 8, (1536 + 4 * tiles - 1) / (4 * tiles), R / 256}));
+    int rpw = (R + 4 * slices - 1) / (4 * slices);
+    rpw = (rpw + 1) & ~1;
+    hipLaunchKernelGGL(k_tn_gemm128, dim3(tiles, 2 * slices), dim3(256), 0, s, A1, ma, B1, mb, A2, B2, slices, r_dev, R, Nout, Kin, Kin / 128,
+                       rpw, part);
+    reduce_slices(s, part, 8 * slices, n, accumulate, out);
+    return;
+  }
+  launch_tn_gemm(s, A1, ma, B1, mb, nullptr, r_dev, R, Nout, Kin, out, accumulate, part);
+  launch_tn_gemm(s, A2, ma, B2, mb, nullptr, r_dev, R, Nout, Kin, out, true, part);
 }
 
 // part[slice][c] = sum_{r in slice} A[r][c] * (B ? B[r][c] : 1) * (rs ? rs[r] : 1)

@@ -380,6 +380,7 @@ class _EnergyForceParamGrad(torch.autograd.Function):
     def forward(ctx, model, z, pos, batch, box, q, n_mol, *params):
         with _direct_radial_functions(model):
             energy, forces = model.energy_and_forces(z, pos, batch, box, q, n_mol, want_forces=True)
+        ctx.set_materialize_grads(False)  # an output the loss does not use arrives as None in backward: no `.any()` read-back needed
         ctx.model, ctx.n_mol, ctx.params = model, n_mol, params
         ctx.save_for_backward(z, pos, batch, forces, *(t for t in (box, q) if t is not None))
         ctx.has = (box is not None, q is not None)
@@ -395,10 +396,12 @@ class _EnergyForceParamGrad(torch.autograd.Function):
 
         def add(grads, w):
             for p, g in grads.items():
-                total[p] = g * w if p not in total else total[p] + g * w
+                gw = g if w == 1.0 else g * w
+                total[p] = gw if p not in total else total[p] + gw
 
-        has_e = g_energy is not None and bool((g_energy != 0).any())
-        has_f = g_forces is not None and bool((g_forces != 0).any())
+        if g_energy is None and g_forces is None:
+            return (None,) * (7 + len(ctx.params))
+        has_e, has_f = g_energy is not None, g_forces is not None  # (an all-zero gradient just costs its pass: no host read-back here)
         order = getattr(model, "force_gradient_order", None)
         order = int(order or 0)  # None / 0: the analytic pass (every architecture); 2 / 4: the difference-quotient cross-check
         analytic = order == 0
@@ -428,12 +431,14 @@ class _EnergyForceParamGrad(torch.autograd.Function):
                 # analytic second-order pass: d (g_F . F) / d theta = - d/d theta [ g_F . d sum_m E_m / d pos ],
                 # and in the positions - H g_F (H = Hessian of the summed energy)
                 seed = g_energy.detach().reshape(-1) if one_pass else None  # then gth / hv are the gradients of s - sum_m ge_m E_m
+                # scale = -1: d loss / d theta through the forces is MINUS the pass' result - applied once to its flat output
+                # instead of one multiply per parameter
                 if with_hv:
-                    gth, hv = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, want_hv=True, ge=seed)
-                    g_pos = -hv if g_pos is None else g_pos - hv
+                    gth, hv = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, want_hv=True, ge=seed, scale=-1.0)
+                    g_pos = hv if g_pos is None else g_pos + hv
                 else:
-                    gth = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, ge=seed)
-                add(gth, -1.0)
+                    gth = model.force_term_parameter_gradients(z, pos.detach(), batch, box, q, n_mol, v, ge=seed, scale=-1.0)
+                add(gth, 1.0)
             else:
                 scale = v.abs().max()
                 vh = v / scale
@@ -736,7 +741,7 @@ class TorchMD_Net(nn.Module):
         energy, token = self._train_forward(z, pos, batch, box, q, n_mol, keep=False)
         return energy, self._train_backward(token, grad_energy)
 
-    def force_term_parameter_gradients(self, z, pos, batch, box, q, n_mol, v, want_hv=False, ge=None):
+    def force_term_parameter_gradients(self, z, pos, batch, box, q, n_mol, v, want_hv=False, ge=None, scale=1.0):
         """d s / d theta of  s = v . d(sum_m E_m)/d pos = - v . F  for every weight of TensorNet + Scalar, analytically
         (tmdnet_force_param_grads: the tangent, along v, of the engine's forward + reverse program - what the reference gets from
         its second autograd pass, model.py:618-628 with create_graph=True).  -> {parameter: gradient}; d loss / d theta through
@@ -790,6 +795,10 @@ class TorchMD_Net(nn.Module):
             if rc != _C.OK:
                 raise RuntimeError(f"tmdnet_loss_param_grads: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
             st.ws_epoch = getattr(st, "ws_epoch", 0) + 1  # the graph workspace was rebuilt: a kept forward half is stale
+            if scale != 1.0:  # every map below is linear in the flat buffer
+                flat.mul_(scale)
+                if hv is not None:
+                    hv.mul_(scale)
             ent = {}
             for i in range(L.tmdnet_param_grad_count(st.handle)):
                 off, numel = C.c_int64(0), C.c_int64(0)
@@ -800,7 +809,7 @@ class TorchMD_Net(nn.Module):
                 for pr in self.prior_model:
                     if pr.enable:
                         w = pr.atomref.weight
-                        grads[w] = -torch.zeros(w.shape[0], dtype=torch.float32, device=dev).index_add_(0, z, ge32[batch]).view_as(w)
+                        grads[w] = (-scale) * torch.zeros(w.shape[0], dtype=torch.float32, device=dev).index_add_(0, z, ge32[batch]).view_as(w)
             return (grads, hv) if want_hv else grads
 
     def _train_forward(self, z, pos, batch, box, q, n_mol, keep=True):
