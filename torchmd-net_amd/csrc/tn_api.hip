@@ -549,33 +549,6 @@ int ensure_radial_tables(tmdnet_model* m, hipStream_t s) {
   return TMDNET_OK;
 }
 
-// The radial-basis embedding's weight images are made on the host (embed_rb_images).  After a device-side parameter update they
-// are stale: the first batch-scale graph build outside a training step fetches Wdp / bdp (3F x K + 3F floats) back, rebuilds
-// and re-uploads them, so a trained model evaluates exactly like a freshly loaded one.
-static int refresh_rb_images(tmdnet_model* m, hipStream_t s) {
-  if (!m->rb_stale) return TMDNET_OK;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return TMDNET_OK;  // stays off in this capture
-  const int F = m->hp.hidden_channels, K = m->hp.num_rbf;
-  if (!m->rb_img || !embed_rb_shape_ok(F, K)) {
-    m->rb_stale = false;
-    return TMDNET_OK;
-  }
-  HIP_TRY(m, hipDeviceSynchronize());
-  std::vector<float> Wdp((size_t)3 * F * K), bdp((size_t)3 * F);
-  HIP_TRY(m, hipMemcpy(Wdp.data(), m->P.Wdp, Wdp.size() * sizeof(float), hipMemcpyDeviceToHost));
-  HIP_TRY(m, hipMemcpy(bdp.data(), m->P.bdp, bdp.size() * sizeof(float), hipMemcpyDeviceToHost));
-  const size_t nf = embed_rb_image_elems(F, K, false), nr = embed_rb_image_elems(F, K, true);
-  if (m->rb_cap < nf + nr) return fail(m, TMDNET_ERR_STATE, "radial-basis image buffer too small");
-  std::vector<uint16_t> img(nf + nr);
-  embed_rb_images(Wdp.data(), bdp.data(), F, K, img.data(), img.data() + nf);
-  HIP_TRY(m, hipMemcpy(m->rb_img, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-  m->rb_fwd = m->rb_img;
-  m->rb_rev = m->rb_img + nf;
-  m->rb_stale = false;
-  return TMDNET_OK;
-}
-
 extern "C" {
 
 const char* tmdnet_version(void) { return "tmdnet_amd 0.3 (gfx950)"; }
@@ -1003,23 +976,21 @@ int tmdnet_finalize_params(tmdnet_model* m) {
       t2.qweights = D("qweights");
     }
   }
-  {  // embedding in the radial basis: MFMA fragment images of the distance projections (tn_embed_rb.hip)
+  {  // embedding in the radial basis: MFMA fragment images of the distance projections (tn_embed_rb.hip), made by a kernel from the
+     // uploaded Wdp / bdp - the same kernel tmdnet_update_params_device runs after its gather
     m->rb_fwd = m->rb_rev = nullptr;
-    m->rb_stale = false;
     const char* env = getenv("TMDNET_EMBED_RB");  // developer switch: 0 keeps the per-pair tables for the embedding
     if (!(env && atoi(env) == 0) && embed_rb_shape_ok(F, K)) {
       const size_t nf = embed_rb_image_elems(F, K, false), nr = embed_rb_image_elems(F, K, true);
-      std::vector<uint16_t> img(nf + nr);
-      embed_rb_images(pk.buf.data() + off.at("Wdp"), pk.buf.data() + off.at("bdp"), F, K, img.data(), img.data() + nf);
-      if (m->rb_img && m->rb_cap < img.size()) {
+      if (m->rb_img && m->rb_cap < nf + nr) {
         HIP_TRY(m, hipFree(m->rb_img));
         m->rb_img = nullptr;
       }
       if (!m->rb_img) {
-        HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->rb_img), img.size() * sizeof(uint16_t)));
-        m->rb_cap = img.size();
+        HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->rb_img), (nf + nr) * sizeof(uint16_t)));
+        m->rb_cap = nf + nr;
       }
-      HIP_TRY(m, hipMemcpy(m->rb_img, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      launch_embed_rb_images(m->dev + off.at("Wdp"), m->dev + off.at("bdp"), F, K, m->rb_img, m->rb_img + nf, nullptr);
       m->rb_fwd = m->rb_img;
       m->rb_rev = m->rb_img + nf;
     }
@@ -1109,10 +1080,8 @@ int tmdnet_update_params_device(tmdnet_model* m, void* stream, int32_t count, co
   launch_ztables(m->P.emb, m->P.emb2_waT, m->P.emb2_wbT, m->P.emb2_b, m->hp.max_z, F, const_cast<float*>(m->P.Utab),
                  const_cast<float*>(m->P.Vtab), s);
   m->tabs_pending = true;           // radial tables: rebuilt by the first call that uses them
-  if (m->rb_fwd || m->rb_stale) {  // the radial-basis embedding's images are made on the host: off until the next batch-scale
-    m->rb_fwd = m->rb_rev = nullptr;  // graph build outside a training step rebuilds them (refresh_rb_images)
-    m->rb_stale = true;
-  }
+  if (m->rb_fwd)  // the radial-basis embedding's weight images follow the gather on the same stream
+    launch_embed_rb_images(m->P.Wdp, m->P.bdp, F, m->hp.num_rbf, m->rb_img, m->rb_img + embed_rb_image_elems(F, m->hp.num_rbf, false), s);
   HIP_TRY(m, hipGetLastError());
   return TMDNET_OK;
 }
@@ -1187,8 +1156,6 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   Graph g = carve_graph(graph_ws, n_atoms, n_mol, ecap, &need);
   if (need > graph_ws_bytes) return fail(m, TMDNET_ERR_WORKSPACE, "graph workspace too small");
   if (box_mode != 0 && !box) return fail(m, TMDNET_ERR_INVALID, "box_mode != 0 needs a box");
-  if (m->rb_stale && !m->train && z && n_atoms >= m->rb_min_atoms)
-    if (const int rc_rb = refresh_rb_images(m, s)) return rc_rb;
   const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
   set_cell(g, m, cell, n_mol);
   m->graph_is_cell = cell;

@@ -419,63 +419,62 @@ __global__ __launch_bounds__(256) void k_embed_gm(int N, const int64_t* __restri
   }
 }
 
-// ------------------------------------------------------------------------------------------------ host side
-// fragment images of the distance-projection weights Wdp [3F][K], bdp [3F] (built once per parameter upload)
+// ------------------------------------------------------------------------------------------------ weight images
+// fragment images of the distance-projection weights Wdp [3F][K], bdp [3F], rebuilt by a kernel with every parameter upload AND
+// every device-side update (one definition: a trained handle and a freshly loaded one hold the same bits)
 //   forward  B[c][ct][s][plane][lane][8]: value(n = 32 ct + (l & 31), k = 16 s + 8 (l >> 5) + j) = Wdp[(c F + n) K + k];
 //            last k-step (s = K / 16): k-half 0, j = 0 -> bdp[c F + n], zeros elsewhere
 //   reverse  B2[c][ct][s][plane][lane][8]: value(n = 32 ct + (l & 31) (an index k' of the radial basis), f = 16 s + 8 (l >> 5) + j)
 //            = Wdp[(c F + f) K + n]
-static inline uint16_t rb_bf16(float x) {
-  uint32_t u;
-  memcpy(&u, &x, 4);
+__device__ __forceinline__ uint16_t rb_bf16(float x) {  // round to nearest even; infinities / NaNs truncated
+  uint32_t u = __float_as_uint(x);
   if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-static inline float rb_f32(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float x;
-  memcpy(&x, &u, 4);
-  return x;
+__device__ __forceinline__ float rb_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+size_t embed_rb_image_elems(int F, int K, bool reverse) {
+  return reverse ? (size_t)3 * (K / 32) * (F / 16) * 1536 : (size_t)3 * (F / 32) * (K / 16 + 1) * 1536;
 }
-static inline void rb_put(uint16_t* blk, int lane, int j, float x) {  // blk: [3 planes][64 lanes][8]
+// one thread per (block of 1536, lane, j): the exact 3-way split of one weight into the three planes
+__global__ void k_embed_rb_images(const float* __restrict__ Wdp, const float* __restrict__ bdp, int F, int K, uint16_t* __restrict__ fwd,
+                                  uint16_t* __restrict__ rev) {
+  const int CT = F / 32, NKS = K / 16, KS = K / 32, FS = F / 16;
+  const int nf = 3 * CT * (NKS + 1) * 512, nr = 3 * KS * FS * 512;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nf + nr) return;
+  float x = 0.f;
+  uint16_t* blk;
+  int l, j;
+  if (idx < nf) {
+    const int b = idx >> 9, e = idx & 511;
+    l = e >> 3;
+    j = e & 7;
+    const int s = b % (NKS + 1), ct = (b / (NKS + 1)) % CT, c = b / ((NKS + 1) * CT);
+    const int n = 32 * ct + (l & 31), k = 16 * s + 8 * (l >> 5) + j;
+    if (s < NKS) x = Wdp[((size_t)c * F + n) * K + k];
+    else if ((l >> 5) == 0 && j == 0) x = bdp[c * F + n];
+    blk = fwd + (size_t)b * 1536;
+  } else {
+    const int r = idx - nf, b = r >> 9, e = r & 511;
+    l = e >> 3;
+    j = e & 7;
+    const int s = b % FS, ct = (b / FS) % KS, c = b / (FS * KS);
+    const int n = 32 * ct + (l & 31), f = 16 * s + 8 * (l >> 5) + j;
+    x = Wdp[((size_t)c * F + f) * K + n];
+    blk = rev + (size_t)b * 1536;
+  }
   const uint16_t h = rb_bf16(x);
   const float r1 = x - rb_f32(h);
   const uint16_t m = rb_bf16(r1);
   const float r2 = r1 - rb_f32(m);
-  const uint16_t l = rb_bf16(r2);
-  blk[(0 * 64 + lane) * 8 + j] = h;
-  blk[(1 * 64 + lane) * 8 + j] = m;
-  blk[(2 * 64 + lane) * 8 + j] = l;
+  blk[(0 * 64 + l) * 8 + j] = h;
+  blk[(1 * 64 + l) * 8 + j] = m;
+  blk[(2 * 64 + l) * 8 + j] = rb_bf16(r2);
 }
-size_t embed_rb_image_elems(int F, int K, bool reverse) {
-  return reverse ? (size_t)3 * (K / 32) * (F / 16) * 1536 : (size_t)3 * (F / 32) * (K / 16 + 1) * 1536;
-}
-void embed_rb_images(const float* Wdp, const float* bdp, int F, int K, uint16_t* fwd, uint16_t* rev) {
-  const int CT = F / 32, NKS = K / 16, KS = K / 32, FS = F / 16;
-  for (int c = 0; c < 3; ++c) {
-    for (int ct = 0; ct < CT; ++ct)
-      for (int s = 0; s <= NKS; ++s) {
-        uint16_t* blk = fwd + ((size_t)(c * CT + ct) * (NKS + 1) + s) * 1536;
-        for (int l = 0; l < 64; ++l)
-          for (int j = 0; j < 8; ++j) {
-            const int n = 32 * ct + (l & 31), k = 16 * s + 8 * (l >> 5) + j;
-            float x = 0.f;
-            if (s < NKS) x = Wdp[((size_t)c * F + n) * K + k];
-            else if ((l >> 5) == 0 && j == 0) x = bdp[c * F + n];
-            rb_put(blk, l, j, x);
-          }
-      }
-    for (int ct = 0; ct < KS; ++ct)
-      for (int s = 0; s < FS; ++s) {
-        uint16_t* blk = rev + ((size_t)(c * KS + ct) * FS + s) * 1536;
-        for (int l = 0; l < 64; ++l)
-          for (int j = 0; j < 8; ++j) {
-            const int n = 32 * ct + (l & 31), f = 16 * s + 8 * (l >> 5) + j;
-            rb_put(blk, l, j, Wdp[((size_t)c * F + f) * K + n]);
-          }
-      }
-  }
+void launch_embed_rb_images(const float* Wdp_dev, const float* bdp_dev, int F, int K, uint16_t* fwd_dev, uint16_t* rev_dev, hipStream_t s) {
+  const int total = 3 * (F / 32) * (K / 16 + 1) * 512 + 3 * (K / 32) * (F / 16) * 512;
+  hipLaunchKernelGGL(k_embed_rb_images, dim3((total + 255) / 256), dim3(256), 0, s, Wdp_dev, bdp_dev, F, K, fwd_dev, rev_dev);
 }
 
 bool embed_rb_shape_ok(int F, int K) { return (F == 64 || F == 128) && (K == 32 || K == 64); }

@@ -186,7 +186,7 @@ int embed_rb_ntp(int nt);  // species count rounded up to 4 / 8; 0: more than 8 
 int64_t embed_rb_moment_elems(int64_t N, int ntp, int K);
 int64_t embed_rb_gmoment_elems(int64_t N, int ntp, int K);
 size_t embed_rb_image_elems(int F, int K, bool reverse);
-void embed_rb_images(const float* Wdp_host, const float* bdp_host, int F, int K, uint16_t* fwd, uint16_t* rev);
+void launch_embed_rb_images(const float* Wdp_dev, const float* bdp_dev, int F, int K, uint16_t* fwd_dev, uint16_t* rev_dev, hipStream_t s);
 void launch_pair_scalars(const Graph& g, int Pcap, float lo, float up, float* ps, hipStream_t s);  // [P + 1][8]: C, C', C0, C0', u
 void launch_embed_moments(const Graph& g, int N, RadialParams rp, int ntp, const float* ps, float* m, hipStream_t s);
 void launch_embed_combine(const Graph& g, int N, int F, int K, int ntp, const int64_t* z, const float* Utab, const float* Vtab,

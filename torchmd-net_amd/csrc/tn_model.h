@@ -205,7 +205,6 @@ struct tmdnet_model {
   int64_t rb_min_atoms = 1024;
   int pair_bf16 = 0;          // option "pair_rows_bf16" (Equivariant Transformer): per-pair filter rows stored as bf16
   bool tabs_pending = false;  // parameters changed since the radial tables were built: rebuilt by the next call that uses them
-  bool rb_stale = false;      // device-side update since rb_img was made: rebuilt by the next batch-scale graph build (refresh_rb_images)
   int64_t tab_min_pairs = 1;  // developer / test switch (option "edge_table_min_pairs"): fewer pairs take the value + tangent GEMMs
   bool finalized = false;
   std::string err;

@@ -332,12 +332,12 @@ class _EnergyParamGrad(torch.autograd.Function):
 
 
 class _direct_radial_functions:
-    """Scope in which the engine evaluates the radial functions directly (no radial tables, no radial-basis embedding): the
-    inference-schedule calls INSIDE a training step - the weights change every step, re-tabulating would cost ~100 ms each.
-    The previous values are restored on exit, so later validation / MD calls on the same module keep the benchmarked schedule
-    (round 3 set the options once and for all)."""
+    """Scope in which the engine evaluates the radial functions directly (no radial tables): the inference-schedule calls INSIDE a
+    training step - the weights change every step, re-tabulating would cost ~16 ms each.  The embedding in the radial basis stays on
+    (its weight images are rebuilt on the device with every parameter update).  The previous values are restored on exit, so later
+    validation / MD calls on the same module keep the benchmarked schedule."""
 
-    NAMES = ("edge_table_min_pairs", "embed_rb_min_atoms")
+    NAMES = ("edge_table_min_pairs",)
 
     def __init__(self, model):
         self.model = model
@@ -774,8 +774,7 @@ class TorchMD_Net(nn.Module):
             L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
             st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
             counts = (C.c_int64 * 8)()
-            rc = L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32), _ptr(batch),
-                                      _ptr(z), _ptr(box), box_mode, counts)
+            rc = self._build_graph_for_a_training_pass(st, stream, n, n_mol, p32, batch, z, box, box_mode, counts)
             self._raise_bad_indices(counts, L.tmdnet_last_error(st.handle).decode())
             if rc != _C.OK:
                 raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
@@ -812,6 +811,21 @@ class TorchMD_Net(nn.Module):
                         grads[w] = (-scale) * torch.zeros(w.shape[0], dtype=torch.float32, device=dev).index_add_(0, z, ge32[batch]).view_as(w)
             return (grads, hv) if want_hv else grads
 
+    def _build_graph_for_a_training_pass(self, st, stream, n, n_mol, p32, batch, z, box, box_mode, counts):
+        """tmdnet_build_graph for the parameter-gradient passes.  They evaluate the radial functions directly, so their graph needs
+        neither the species map of the radial-basis embedding nor its weight images - which a device-side parameter update leaves
+        stale, and whose rebuild (device synchronisation + a host round trip, `refresh_rb_images`) would otherwise be paid by every
+        training step: the embedding's atom threshold is out of reach for the duration of this one call."""
+        L = _C.lib()
+        v = C.c_double()
+        L.tmdnet_get_info(st.handle, b"embed_rb_min_atoms", C.byref(v))
+        L.tmdnet_set_option(st.handle, b"embed_rb_min_atoms", 1e15)
+        try:
+            return L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32), _ptr(batch),
+                                        _ptr(z), _ptr(box), box_mode, counts)
+        finally:
+            L.tmdnet_set_option(st.handle, b"embed_rb_min_atoms", v.value)
+
     def _train_forward(self, z, pos, batch, box, q, n_mol, keep=True):
         """Forward half of the parameter-gradient pass.  keep=True: the activations stay in the model's workspaces and the
         returned token lets `_train_backward` run the reverse half on them - unless another engine call used the workspaces
@@ -840,8 +854,7 @@ class TorchMD_Net(nn.Module):
             L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
             st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
             counts = (C.c_int64 * 8)()
-            rc = L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32), _ptr(batch),
-                                      _ptr(z), _ptr(box), box_mode, counts)
+            rc = self._build_graph_for_a_training_pass(st, stream, n, n_mol, p32, batch, z, box, box_mode, counts)
             self._raise_bad_indices(counts, L.tmdnet_last_error(st.handle).decode())
             if rc != _C.OK:
                 raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
