@@ -846,8 +846,7 @@ int et_force_param_grads(tmdnet_model* m, hipStream_t s, const Graph& g, void* w
   // d W = g_y_t^T x + g_y^T x_t, d b = colsum(g_y_t) of a dense layer y = x W^T + b
   auto dense = [&](const std::string& wkey, const std::string& bkey, const float* gy, const float* gy_t, int64_t ldg, const float* x,
                    const float* x_t, int64_t ldx, int R, int Nout, int Kin) {
-    launch_tn_gemm(s, gy_t, RP(ldg), x, RP(ldx), nullptr, nullptr, R, Nout, Kin, at(wkey), false, b.part);
-    launch_tn_gemm(s, gy, RP(ldg), x_t, RP(ldx), nullptr, nullptr, R, Nout, Kin, at(wkey), true, b.part);
+    launch_tn_gemm_pair(s, gy_t, x, gy, x_t, RP(ldg), RP(ldx), nullptr, R, Nout, Kin, at(wkey), false, b.part);  // one launch, one reduction
     if (!bkey.empty()) launch_colsum(s, gy_t, RP(ldg), nullptr, RP(ldg), nullptr, nullptr, R, Nout, at(bkey), false, b.part);
   };
   auto ln_grad = [&](const std::string& wkey, const std::string& bkey, const float* gy, const float* gy_t, const float* xh, const float* xh_t) {

@@ -583,10 +583,8 @@ int tmdnet_loss_param_grads(tmdnet_model* m, void* stream, void* graph_ws, void*
   }
   float* dWdp = at("Wdp");
   float* dbdp = at("bdp");
-  launch_tn_gemm(s, b.gq_t, r3F, b.phi, rK, nullptr, nullptr, P, 3 * F, K, dWdp, false, b.part);
-  launch_tn_gemm(s, b.gq_t + dir, r3F, b.phi, rK, nullptr, nullptr, P, 3 * F, K, dWdp, true, b.part);
-  launch_tn_gemm(s, b.gq, r3F, b.phi_t, rK, nullptr, nullptr, P, 3 * F, K, dWdp, true, b.part);
-  launch_tn_gemm(s, b.gq + dir, r3F, b.phi_t, rK, nullptr, nullptr, P, 3 * F, K, dWdp, true, b.part);
+  launch_tn_gemm_pair(s, b.gq_t, b.phi, b.gq, b.phi_t, r3F, rK, nullptr, P, 3 * F, K, dWdp, false, b.part);              // direction i <- j
+  launch_tn_gemm_pair(s, b.gq_t + dir, b.phi, b.gq + dir, b.phi_t, r3F, rK, nullptr, P, 3 * F, K, dWdp, true, b.part);   // direction j <- i
   launch_tn_gemm(s, b.selfq_t, rF, b.phi + (int64_t)P * K, rows_plain(0), nullptr, nullptr, N, F, K, dWdp, true, b.part);  // self pair: phi_t = 0
   launch_colsum(s, b.gq_t, r3F, nullptr, r3F, nullptr, nullptr, P, 3 * F, dbdp, false, b.part);
   launch_colsum(s, b.gq_t + dir, r3F, nullptr, r3F, nullptr, nullptr, P, 3 * F, dbdp, true, b.part);

@@ -28,12 +28,19 @@ __device__ __forceinline__ int64_t row_off(const RowMap& m, int r) {
 }
 
 // out_part[slice][n][k] = sum_{r in slice} A[r][n] * rs[r] * B[r][k]     (64 x 64 tile per block, four waves share the slice)
+// A2 / B2 (optional, same row maps): a second product whose slices follow the first one's (blockIdx.y >= seg_slices) - see k_tn_gemm128
 __global__ __launch_bounds__(256) void k_tn_gemm(const float* __restrict__ A, RowMap ma, const float* __restrict__ B, RowMap mb,
+                                                 const float* __restrict__ A2, const float* __restrict__ B2, int seg_slices,
                                                  const float* __restrict__ rs, const int* __restrict__ r_dev, int R, int Nout, int Kin,
                                                  int tiles_k, int rows_per_slice, float* __restrict__ part) {
   __shared__ float red[3][64 * 64];
   if (r_dev) R = min(R, *r_dev);
-  const int tile = blockIdx.x, slice = blockIdx.y;
+  const bool second = (int)blockIdx.y >= seg_slices;  // block-uniform
+  if (second) {
+    A = A2;
+    B = B2;
+  }
+  const int tile = blockIdx.x, slice = (int)blockIdx.y - (second ? seg_slices : 0);
   const int tn_ = tile / tiles_k, tk = tile - tn_ * tiles_k;
   const int n0 = tn_ * 64, k0 = tk * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256) void k_tn_gemm(const float* __restrict__ A, Ro
   }
   __syncthreads();
   if (wave > 0) return;
-  float* o = part + (int64_t)slice * Nout * Kin;
+  float* o = part + (int64_t)blockIdx.y * Nout * Kin;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -272,8 +279,8 @@ void launch_tn_gemm(hipStream_t s, const float* A, RowMap ma, const float* B, Ro
   slices = std::max(1, std::min(slices, std::max(8, 1024 / tiles)));
   int rps = R > 0 ? (R + slices - 1) / slices : 1;
   rps = (rps + 1) & ~1;  // pairs of rows
-  hipLaunchKernelGGL(k_tn_gemm, dim3(tiles_n * tiles_k, slices), dim3(256), 0, s, A, ma, B, mb, rowscale, r_dev, R, Nout, Kin, tiles_k, rps,
-                     part);
+  hipLaunchKernelGGL(k_tn_gemm, dim3(tiles_n * tiles_k, slices), dim3(256), 0, s, A, ma, B, mb, nullptr, nullptr, slices, rowscale, r_dev, R,
+                     Nout, Kin, tiles_k, rps, part);
   reduce_slices(s, part, slices, n, accumulate, out);
 }
 
@@ -293,8 +300,15 @@ void launch_tn_gemm_pair(hipStream_t s, const float* A1, const float* B1, const 
     reduce_slices(s, part, 8 * slices, n, accumulate, out);
     return;
   }
-  launch_tn_gemm(s, A1, ma, B1, mb, nullptr, r_dev, R, Nout, Kin, out, accumulate, part);
-  launch_tn_gemm(s, A2, ma, B2, mb, nullptr, r_dev, R, Nout, Kin, out, true, part);
+  // the 64 x 64 kernel (narrow outputs: F x K, 3F x K): half the slices per product, both products in one launch
+  const int tiles_n = (Nout + 63) / 64, tiles_k = (Kin + 63) / 64, tiles = tiles_n * tiles_k;
+  int slices = R > 0 ? std::max(1, std::min({max_partials(n) / 2, tiles <= 2 ? 256 : 64, (R + 255) / 256})) : 1;
+  slices = std::max(1, std::min(slices, std::max(4, 512 / tiles)));
+  int rps = R > 0 ? (R + slices - 1) / slices : 1;
+  rps = (rps + 1) & ~1;
+  hipLaunchKernelGGL(k_tn_gemm, dim3(tiles, 2 * slices), dim3(256), 0, s, A1, ma, B1, mb, A2, B2, slices, nullptr, r_dev, R, Nout, Kin, tiles_k,
+                     rps, part);
+  reduce_slices(s, part, 2 * slices, n, accumulate, out);
 }
 
 // part[slice][c] = sum_{r in slice} A[r][c] * (B ? B[r][c] : 1) * (rs ? rs[r] : 1)
