@@ -99,7 +99,7 @@ const char* tmdnet_version(void);
 /* ABI revision of this header: bumped whenever an exported signature or struct layout changes (3: `z` in
  * tmdnet_build_graph[_static], `strategy` in tmdnet_neighbor_pairs).  A binding compares its compile-time
  * TMDNET_ABI_VERSION with the loaded library's tmdnet_abi_version() before its first call. */
-#define TMDNET_ABI_VERSION 7
+#define TMDNET_ABI_VERSION 8
 int tmdnet_abi_version(void);
 
 /* Parameters are addressed by the reference's state-dict keys without the "model." prefix
@@ -183,6 +183,23 @@ int tmdnet_set_cell_grid(tmdnet_model* m, int32_t ncx, int32_t ncy, int32_t ncz)
  * multi-GPU story stops at data parallelism over molecules.  TensorNet only (ET / TensorNet2 and the
  * parameter-gradient pass refuse a handle with weights set). */
 int tmdnet_set_atom_weights(tmdnet_model* m, const float* weights_dev);
+
+/* Per-layer halo exchange (ABI 8) for a domain decomposition whose halo is ONE cutoff deep (parallel.HaloExchangeEvaluator; the
+ * reference has no counterpart).  A rank's local system is its owned atoms (weight 1) plus the ghost
+ * copies within one cutoff of its domain (weight 0).  Every per-atom kernel of the step is local to a row, and a neighbour sweep
+ * only gathers rows of neighbours, so the result on the owned atoms is exact as long as the ghost rows of the tensor each sweep
+ * gathers hold their owners' values.  With a callback set, tmdnet_energy_forces (TensorNet inference, exact pair count) calls
+ *     fn(user, stage, rows, n_rows, row_floats, perm, stream)
+ * on the host, between enqueueing the kernel that writes `rows` ([n_rows][row_floats] floats on the device, n_rows = n_atoms) and
+ * the sweep that gathers it: stage l = P_l of layer l (forward, row_floats = 9 F), 100 + l = the adjoint of layer l's message
+ * (reverse, 9 F), 200 = the adjoint of the embedding sum (reverse, 10 F); 2 L + 1 calls per step.  The callback overwrites the
+ * ghost rows with their owners' rows, ordered on `stream`.  Row r of `rows` belongs to the caller's atom perm[r] (perm == NULL:
+ * to atom r; a device vector, valid during the call).  A non-zero return aborts the step with TMDNET_ERR_STATE.  The forces come
+ * back for every local atom; those of the owned atoms are complete (no reduction over ranks), those of the ghosts are not.
+ * fn == NULL switches the exchange off.  Not capturable: the callback runs at enqueue time. */
+typedef int (*tmdnet_halo_exchange_fn)(void* user, int32_t stage, float* rows, int64_t n_rows, int64_t row_floats,
+                                       const int32_t* perm, void* stream);
+int tmdnet_set_halo_exchange(tmdnet_model* m, tmdnet_halo_exchange_fn fn, void* user);
 int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t graph_ws_bytes, int64_t n_atoms, int64_t n_mol,
                        const float* pos, const int64_t* batch, const int64_t* z, const float* box, int32_t box_mode,
                        int64_t counts_host[8]);

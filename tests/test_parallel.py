@@ -259,3 +259,165 @@ def test_force_matching_gradients_average_under_ddp_gloo_world2(tmp_path):
     mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert open(tmp_path / f"ddp{r}").read() == "1"
+
+
+# ---------------------------------------------------------------------------------- per-layer halo exchange (host logic)
+def _toy_pairs(pos, box, rc):
+    """All directed pairs (i, j, d, unit vector from j to i) of a small orthorhombic periodic system, minimum image."""
+    L = torch.diagonal(box)
+    d = pos[:, None, :] - pos[None, :, :]
+    d = d - torch.round(d / L) * L
+    r = d.norm(dim=-1)
+    i, j = torch.nonzero((r < rc) & (r > 0), as_tuple=True)
+    return i, j, r[i, j], d[i, j] / r[i, j][:, None]
+
+
+def _toy_step(z, pos, box, w, rc, exchange=None):
+    """A two-sweep model with the structure of a TensorNet step, forward and hand-written reverse: an embedding sum over geometry and
+    species, a per-atom function, a message sum over the neighbours' rows; the reverse gathers the neighbours' adjoints.  The three
+    places where a sweep reads a neighbour's row are the three stages of the exchange (tmdnet_set_halo_exchange)."""
+    C = 4
+    s = torch.cos(z[:, None].double() * torch.arange(1, C + 1).double())          # species rows [n, C]
+    i, j, r, u = _toy_pairs(pos.double(), box.double(), rc)
+    phi_f = lambda t: torch.cos(t * 0.7) * (rc - t) ** 2
+    dphi_f = lambda t: -0.7 * torch.sin(t * 0.7) * (rc - t) ** 2 - 2 * torch.cos(t * 0.7) * (rc - t)
+    psi_f = lambda t: (rc - t) ** 3
+    dpsi_f = lambda t: -3 * (rc - t) ** 2
+    n = z.shape[0]
+    a = torch.zeros(n, C, dtype=torch.float64).index_add_(0, i, phi_f(r)[:, None] * s[j])
+    p = torch.tanh(a)
+    if exchange is not None:
+        exchange(0, p, None)
+    m = torch.zeros(n, C, dtype=torch.float64).index_add_(0, i, psi_f(r)[:, None] * p[j])
+    e = (m * p).sum(1) + (a * a).sum(1)
+    E = (w.double() * e).sum()
+    # reverse
+    ge = w.double()[:, None]
+    gm = ge * p
+    if exchange is not None:
+        exchange(100, gm, None)
+    gp = ge * m + torch.zeros(n, C, dtype=torch.float64).index_add_(0, i, psi_f(r)[:, None] * gm[j])
+    ga = gp * (1 - p * p) + 2 * a * ge
+    if exchange is not None:
+        exchange(200, ga, None)
+    # d E / d d_ij of the directed pair (i <- j), both directions of the undirected pair appear in the list
+    gd = dpsi_f(r) * (gm[i] * p[j]).sum(1) + dphi_f(r) * (ga[i] * s[j]).sum(1)
+    # row i moves along u, row j against it; summing a pair's two directed entries on atom i gives its complete force
+    F = torch.zeros(n, 3, dtype=torch.float64).index_add_(0, i, -gd[:, None] * u).index_add_(0, j, gd[:, None] * u)
+    return E.reshape(1).float(), F.float()
+
+
+def _toy_whole(z, pos, box, rc):
+    return _toy_step(z, pos, box, torch.ones(z.shape[0]), rc)
+
+
+def test_toy_step_reverse_is_the_gradient():
+    z, pos, box = _periodic_system(40, [9.0, 5.5, 6.0], seed=4)
+    pos = pos.double().requires_grad_(True)
+    L = torch.diagonal(box).double()
+    d = pos[:, None, :] - pos[None, :, :]
+    d = d - torch.round(d.detach() / L) * L
+    r = (d * d).sum(-1).add(torch.eye(40, dtype=torch.float64)).sqrt()
+    mask = ((r < 2.5) & ~torch.eye(40, dtype=torch.bool)).double()
+    s = torch.cos(z[:, None].double() * torch.arange(1, 5).double())
+    a = ((torch.cos(r * 0.7) * (2.5 - r) ** 2 * mask)[:, :, None] * s[None, :, :]).sum(1)
+    p = torch.tanh(a)
+    m = (((2.5 - r) ** 3 * mask)[:, :, None] * p[None, :, :]).sum(1)
+    E = ((m * p).sum(1) + (a * a).sum(1)).sum()
+    (g,) = torch.autograd.grad(E, pos)
+    E2, F2 = _toy_whole(z, pos.detach().float(), box, 2.5)
+    assert abs(float(E.detach()) - float(E2)) < 1e-5 * abs(float(E.detach()))
+    assert (F2.double() + g).abs().max().item() < 1e-5 * g.abs().max().item()
+
+
+class _Mailbox:
+    def __init__(self, world):
+        import threading
+        self.barrier, self.slots = threading.Barrier(world), {}
+
+    def transport(self, rank, world, send, recv_counts):
+        for p in range(world):
+            self.slots[(rank, p)] = send[p].clone()
+        self.barrier.wait()
+        got = [self.slots[(p, rank)] for p in range(world)]
+        self.barrier.wait()
+        return got
+
+
+def test_halo_exchange_plan_and_protocol_ranks_as_threads():
+    """parallel.HaloExchangeEvaluator on the toy step: 2, 3 and 4 slabs with a halo of ONE cutoff, ghost rows refreshed at the three
+    stages; every rank's owned forces are complete (no reduction over the ranks) and the energies add up.  Without the exchange
+    the same decomposition is wrong, so the comparison would notice a hook that does nothing."""
+    import threading
+    from torchmdnet_amd.parallel import HaloExchangeEvaluator
+
+    rc = 2.5
+    z, pos, box = _periodic_system(90, [21.0, 6.0, 5.5], seed=11)
+    Ew, Fw = _toy_whole(z, pos, box, rc)
+    for world in (2, 3, 4):
+        mb = _Mailbox(world)
+        evs = [HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex: _toy_step(zl, pl, bl, wl, rc, ex), rc, transport=mb.transport)
+               for _ in range(world)]
+        plans = [evs[0].plan(pos, box, r, world) for r in range(world)]
+        for r in range(world):  # what r sends to p is what p expects from r, atom by atom; every ghost has exactly one source
+            for p in range(world):
+                assert torch.equal(plans[r].gidx[plans[r].send[p]], plans[p].gidx[plans[p].recv[r]])
+            assert sum(int(t.numel()) for t in plans[r].recv) == plans[r].n_ghost and int(plans[r].recv[r].numel()) == 0
+        assert sum(pl.n_own for pl in plans) == 90
+        out, err = [None] * world, []
+
+        def run(r):
+            try:
+                out[r] = evs[r].step(z, pos, box, r, world)
+            except BaseException as e:  # noqa: BLE001
+                err.append(e)
+                mb.barrier.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not err, err
+        E, F = torch.zeros(1), torch.zeros(90, 3)
+        for plan, e, f_l in out:
+            E = E + e
+            F[plan.gidx[:plan.n_own]] = f_l[:plan.n_own]
+        assert abs(float(E) - float(Ew)) < 1e-5 * abs(float(Ew)), world
+        assert (F - Fw).abs().max().item() < 1e-5 * Fw.abs().max().item(), world
+        assert all(ev.rows_moved == 3 * 4 * pl.n_ghost for ev, pl in zip(evs, plans))
+    ev = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex: _toy_step(zl, pl, bl, wl, rc, None), rc)
+    plan, _, f_l = ev.step(z, pos, box, 0, 2)
+    assert (f_l[:plan.n_own] - Fw[plan.gidx[:plan.n_own]]).abs().max().item() > 1e-2 * Fw.abs().max().item()
+    with pytest.raises(ValueError, match="own ghost"):
+        HaloExchangeEvaluator(None, 12.0).plan(pos, box, 0, 2)  # cutoff 12 A > 21 A - one slab
+
+
+def _halo_worker(rank, world, port, tmpdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "torchmd-net_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from torchmdnet_amd.parallel import HaloExchangeEvaluator
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rc = 2.5
+    z, pos, box = _periodic_system(90, [21.0, 6.0, 5.5], seed=11)
+    ev = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex: _toy_step(zl, pl, bl, wl, rc, ex), rc)
+    E, F = ev.evaluate(z, pos, box)  # all-to-all per exchange, then the [3 N + 1] all-reduce
+    Ew, Fw = _toy_whole(z, pos, box, rc)
+    ok = abs(float(E) - float(Ew)) < 1e-5 * abs(float(Ew)) and (F - Fw).abs().max().item() < 1e-5 * Fw.abs().max().item()
+    ok = ok and ev.rows_moved > 0
+    with open(os.path.join(tmpdir, f"hx{rank}"), "w") as fh:
+        fh.write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_gloo_world2(tmp_path):
+    """The default transport: one all_to_all_single per exchange between two processes (gloo here, RCCL on GPUs)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_halo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"hx{r}").read() == "1"

@@ -1273,6 +1273,13 @@ int tmdnet_set_atom_weights(tmdnet_model* m, const float* weights_dev) {
   return TMDNET_OK;
 }
 
+int tmdnet_set_halo_exchange(tmdnet_model* m, tmdnet_halo_exchange_fn fn, void* user) {
+  if (!m) return TMDNET_ERR_INVALID;
+  m->halo_fn = fn;
+  m->halo_user = fn ? user : nullptr;
+  return TMDNET_OK;
+}
+
 int tmdnet_graph_cell_grid(tmdnet_model* m, void* stream, void* graph_ws, int64_t n_atoms, int64_t n_mol, int64_t grid_host[4]) {
   if (!m || !graph_ws || !grid_host) return TMDNET_ERR_INVALID;
   recall_graph(m, graph_ws);
@@ -1327,6 +1334,9 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   if (m->graph_is_cell && m->graph_cell_multi) batch = g.bat_c;  // several molecules renumbered in cell order: their internal batch
   if (m->atom_w && (m->et || m->tn2 || m->train))
     return fail(m, TMDNET_ERR_INVALID, "atom weights (tmdnet_set_atom_weights) are implemented for TensorNet inference only");
+  if (m->halo_fn && (m->et || m->tn2 || m->train || n_pairs < 0))
+    return fail(m, TMDNET_ERR_INVALID, "the halo exchange (tmdnet_set_halo_exchange) is implemented for TensorNet inference with the "
+                                       "exact pair count (tmdnet_build_graph, not the static mode)");
   if (m->et) {
     if (q) return fail(m, TMDNET_ERR_INVALID, "the Equivariant Transformer takes no total charge (reference torchmd_et.py:188-196)");
     CurScope cur_(m);
@@ -1409,7 +1419,14 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     rts[l] = PairRowTable{m->tabs.tab[1 + l], g.pd, g.counts, hp.cutoff_lower, h_, 1.0f / h_, m->tabs.T};
   }
   const bool use_mid = !small_fused_ok(N, F, H, L);  // 513 .. 1 024 atoms: four atoms per block (tn_mid.hip)
-  const bool fused_small = !tc && !ntp && !recompute && (small_fused_ok(N, F, H, L) || mid_fused_ok(N, F, H, L)) &&
+  // ghost rows refreshed between the kernels of a step (tmdnet_set_halo_exchange): 0 = ok
+  auto HALO = [&](int stage, float* rows, int row_floats) -> int {
+    if (!m->halo_fn) return 0;
+    return m->halo_fn(m->halo_user, stage, rows, (int64_t)N, (int64_t)row_floats, perm, (void*)s);
+  };
+#define HALO_TRY(stage, rows, row_floats) \
+  do { if (HALO(stage, rows, row_floats)) return fail(m, TMDNET_ERR_STATE, "halo exchange callback failed at stage " + std::to_string(stage)); } while (0)
+  const bool fused_small = !tc && !ntp && !recompute && !m->halo_fn && (small_fused_ok(N, F, H, L) || mid_fused_ok(N, F, H, L)) &&
                            (!want_forces || (message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD")));
   if (run_fwd) {
     if (use_tab) {
@@ -1544,6 +1561,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         Tl9Args ta{};
         ta.A = b.X[l]; ta.C = b.Pn[l]; ta.N = N; ta.F = F;
         tlin9(s, TL9_PRO_NORM, TL9_EPI_PLAIN, q_.V, ta, 2.0, "norm");
+        HALO_TRY(l, b.Pn[l], 9 * F);
         KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s, recompute ? &rts[l] : nullptr));
         // dX = linear(C_hat), then X_new = X_hat + dX + kappa dX.dX (and the readout invariants after the last layer) in the epilogue
         Tl9Args tb{};
@@ -1554,6 +1572,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       }
       if (l == 0) KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], Xh_l, N, F, s));
       tensor_linear(s, Xh_l, q_.V, b.Pn[l], N, F);
+      HALO_TRY(l, b.Pn[l], 9 * F);
       KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s, recompute ? &rts[l] : nullptr));
       tensor_linear(s, Ch_l, q_.V + 3, b.D[l], N, F);
       // update fused with the next consumer of the new X: the next layer's normalisation, or the readout invariants
@@ -1660,6 +1679,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       tensor_linear(s, b.gD, q_.VT + 3, b.gCh, N, F);
       KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch_k, o3, N, F, b.gMi, b.gPn, s));
       }
+      HALO_TRY(100 + l, b.gMi, 9 * F);
       if (tc) {
         // edge MLP of this layer: g_w per pair (self pair: summed over the atoms), then back through silu(.) C, M3, M2, M1
         const std::string t_ = "l" + std::to_string(l) + ".";
@@ -1722,6 +1742,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);
       KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 11 * Fd * 4, launch_embed_bwd_atom(b.g_u0l, b.u0, b.g_s0n, N, F, b.gA, s));
     }
+    HALO_TRY(200, b.gA, 10 * F);
     if (tc) {
       // embedding: tensor linears, gate MLP, init_norm, then the edge weights W_k = C (U[z_i] + V[z_j]) (Wdp phi + bdp)_k
       tensor_linear_grad(b.gUX, b.u0, "Ue");

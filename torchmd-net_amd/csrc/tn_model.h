@@ -154,6 +154,9 @@ struct TrainCtx {
 struct tmdnet_model {
   bool recompute_rows = false;  // option "recompute_pair_rows": the sweeps interpolate the per-pair rows themselves (no w / dw workspace)
   const float* atom_w = nullptr;  // per-atom weights of the energy sum (tmdnet_set_atom_weights), caller's atom order
+  // per-layer halo exchange (tmdnet_set_halo_exchange): called between the per-atom kernels and the neighbour sweeps of a step
+  int (*halo_fn)(void*, int32_t, float*, int64_t, int64_t, const int32_t*, void*) = nullptr;
+  void* halo_user = nullptr;
   tmdnet_hparams hp;
   TrainCtx* train = nullptr;  // non-null while tmdnet_energy_param_grads drives tmdnet_energy_forces
   std::vector<std::pair<std::string, int64_t>> train_entries;  // gradient buffer layout (name, numel), built on first use

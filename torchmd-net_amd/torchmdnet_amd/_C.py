@@ -77,6 +77,7 @@ def lib():
     L.tmdnet_build_graph.argtypes = [vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, i32, C.POINTER(i64)]
     L.tmdnet_set_cell_grid.argtypes = [vp, i32, i32, i32]
     L.tmdnet_set_atom_weights.argtypes = [vp, vp]
+    L.tmdnet_set_halo_exchange.argtypes = [vp, HALO_EXCHANGE_FN, vp]
     L.tmdnet_build_graph_static.argtypes = [vp, vp, vp, sz, i64, i64, vp, vp, vp, vp, i32]
     L.tmdnet_graph_counts.argtypes = [vp, vp, vp, i64, i64, C.POINTER(i64)]
     L.tmdnet_graph_cell_grid.argtypes = [vp, vp, vp, i64, i64, C.POINTER(i64)]
@@ -114,6 +115,10 @@ def lib():
             fn.restype = C.c_int
     _lib = L
     return L
+
+
+# tmdnet_halo_exchange_fn (include/tmdnet_amd.h): (user, stage, rows, n_rows, row_floats, perm, stream) -> 0 on success
+HALO_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p)
 
 
 def declared_symbols():

@@ -1011,10 +1011,14 @@ class TorchMD_Net(nn.Module):
         if t.dtype not in dtypes:
             raise TypeError(f"torchmdnet_amd: `{name}` must have dtype {' or '.join(str(d) for d in dtypes)}, got {t.dtype}")
 
-    def energy_and_forces(self, z, pos, batch, box, q, n_mol, want_forces=True, atom_weights=None) -> Tuple[Tensor, Optional[Tensor]]:
+    def energy_and_forces(self, z, pos, batch, box, q, n_mol, want_forces=True, atom_weights=None,
+                          halo_exchange=None) -> Tuple[Tensor, Optional[Tensor]]:
         """Raw engine call: returns (E [n_mol], F [N,3] or None), both fp32 on ``pos.device``.  ``atom_weights`` ([N] fp32, this
         framework's extension for domain decomposition, parallel.SpatialEvaluator): E_mol = sum_i w_i e_i + mean and F = -dE/dpos
-        of that sum (TensorNet only)."""
+        of that sum (TensorNet only).  ``halo_exchange(stage, rows, inv)`` (parallel.HaloExchangeEvaluator, TensorNet only) is
+        called 2 L + 1 times inside the step (``tmdnet_set_halo_exchange``, include/tmdnet_amd.h): it overwrites the ghost rows of
+        ``rows`` [N, row_floats] (a view of the engine's workspace) with their owners' values on the current stream; the row of
+        the caller's atom i is ``rows[i]`` when ``inv`` is None and ``rows[inv[i]]`` otherwise (cell order)."""
         _require_cuda(pos, "TorchMD_Net.forward")
         L = _C.lib()
         dev = pos.device
@@ -1085,10 +1089,38 @@ class TorchMD_Net(nn.Module):
                 # a captured graph replays the call with this pointer: the vector has to outlive every replay, and a later call
                 # (which overwrites st.atom_weights) must not free it
                 st.captured_atom_weights = getattr(st, "captured_atom_weights", []) + [atom_weights]
-            rc = L.tmdnet_energy_forces(st.handle, stream, _ptr(st.graph_ws), _ptr(st.fwd_ws), st.fwd_ws.numel(), n, n_mol,
-                                        n_pairs, _ptr(z), _ptr(batch), _ptr(q), int(want_forces), _ptr(energy), _ptr(forces))
+            halo_state = {}
+            if halo_exchange is not None:
+                ws_t, g_t = st.fwd_ws, st.graph_ws
+
+                def _halo(_user, stage, rows_ptr, n_rows, row_floats, perm_ptr, _stream):
+                    try:  # an exception must not unwind through the C frames: kept, re-raised after the call
+                        o = int(rows_ptr) - ws_t.data_ptr()
+                        rows = ws_t[o:o + 4 * n_rows * row_floats].view(torch.float32).view(n_rows, row_floats)
+                        if perm_ptr and "inv" not in halo_state:
+                            po = int(perm_ptr) - g_t.data_ptr()
+                            perm = g_t[po:po + 4 * n_rows].view(torch.int32).long()
+                            inv = torch.empty_like(perm)
+                            inv[perm] = torch.arange(n_rows, device=perm.device)
+                            halo_state["inv"] = inv
+                        halo_exchange(int(stage), rows, halo_state.get("inv"))
+                        return 0
+                    except BaseException as e:  # noqa: BLE001
+                        halo_state["error"] = e
+                        return 1
+
+                halo_state["cb"] = _C.HALO_EXCHANGE_FN(_halo)
+                L.tmdnet_set_halo_exchange(st.handle, halo_state["cb"], None)
+            try:
+                rc = L.tmdnet_energy_forces(st.handle, stream, _ptr(st.graph_ws), _ptr(st.fwd_ws), st.fwd_ws.numel(), n, n_mol,
+                                            n_pairs, _ptr(z), _ptr(batch), _ptr(q), int(want_forces), _ptr(energy), _ptr(forces))
+            finally:
+                if halo_exchange is not None:
+                    L.tmdnet_set_halo_exchange(st.handle, _C.HALO_EXCHANGE_FN(), None)
             if atom_weights is not None:
                 L.tmdnet_set_atom_weights(st.handle, None)
+            if "error" in halo_state:
+                raise halo_state["error"]
             if rc != _C.OK:
                 raise RuntimeError(f"tmdnet_energy_forces: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
             if static and self.static_check and not torch.cuda.is_current_stream_capturing():

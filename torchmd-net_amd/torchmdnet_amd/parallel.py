@@ -257,3 +257,137 @@ class SpatialEvaluator:
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
             forces, e = buf[:-1].reshape(-1, 3), buf[-1:]
         return e + self.energy_offset, forces
+
+
+class HaloPlan:
+    """What one rank needs for a step of ``HaloExchangeEvaluator``: its local system and, per peer, the local rows it sends
+    (owned atoms that are ghosts over there) and the local rows it receives into (its ghosts owned over there), both in the order
+    of the receiver's ghost list."""
+
+    def __init__(self, gidx, pos_l, box_l, n_own, send, recv):
+        self.gidx, self.pos_l, self.box_l, self.n_own, self.send, self.recv = gidx, pos_l, box_l, n_own, send, recv
+
+    @property
+    def n_ghost(self) -> int:
+        return int(self.gidx.numel()) - self.n_own
+
+
+def distributed_transport(group: Optional[dist.ProcessGroup] = None):
+    """Rows between the ranks by ONE all-to-all per exchange (RCCL over xGMI; under gloo - the tests, two processes on one GPU -
+    the device rows are staged through the host)."""
+
+    def transport(rank: int, world: int, send, recv_counts):
+        width = send[0].shape[1]
+        out = torch.cat(send) if world > 1 else send[0]
+        host = out.is_cuda and dist.get_backend(group) == "gloo"
+        src = out.cpu() if host else out.contiguous()
+        dst = torch.empty((sum(recv_counts), width), dtype=src.dtype, device=src.device)
+        dist.all_to_all_single(dst, src, list(recv_counts), [int(t.shape[0]) for t in send], group=group)
+        if host:
+            dst = dst.to(out.device)
+        return list(torch.split(dst, list(recv_counts)))
+
+    return transport
+
+
+class HaloExchangeEvaluator:
+    """ONE large periodic system over the ranks with a halo of ONE cutoff and an exchange of ghost rows inside the step (the step
+    after ``SpatialEvaluator``'s deep halo; the reference has no counterpart).
+
+    A TensorNet step is per-atom kernels (local to a row) cut by neighbour sweeps that gather the rows of an atom's neighbours
+    (reference tensornet.py:757-806: the message sum of every layer; tensornet.py:543-619: the embedding sum, which gathers
+    geometry and species only).  A rank holds its slab's atoms (weight 1 in the energy sum) and the periodic images within one
+    cutoff of the slab as ghosts (weight 0): every neighbour of an owned atom is local.  What the ghosts lack is their own
+    neighbourhood, so their rows are wrong wherever a sweep has been - and are replaced, before each sweep that gathers them, by
+    the rows their owners computed: P_l before the message sum of layer l, the adjoint of that sum's output on the way back,
+    and the adjoint of the embedding sum before the pair gradients of the embedding; 2 L + 1 exchanges of [n_ghost, 9 F or 10 F]
+    floats (``tmdnet_set_halo_exchange``, include/tmdnet_amd.h).  The forces of the owned atoms come out complete - an owned
+    atom's pairs are all local and both halves of a pair's distance gradient are computed from exchanged rows - so, unlike the
+    deep halo, nothing is reduced over the ranks: every rank returns the forces of its own atoms and the energy is one scalar
+    all-reduce.  ``evaluate`` still all-reduces a [3 N + 1] vector so that every rank ends with the whole answer, like
+    ``SpatialEvaluator.evaluate``; an MD driver that keeps the atoms distributed uses ``step`` and skips it.
+
+    ``compute(z_l, pos_l, box_l, w_l, exchange) -> (E [1], F_l [n_l, 3])`` is injected (the engine:
+    ``model.energy_and_forces(..., atom_weights=w_l, halo_exchange=exchange)``); ``transport(rank, world, send, recv_counts)``
+    moves the rows (``distributed_transport``; the tests also run the ranks as threads of one process with a mailbox)."""
+
+    def __init__(self, compute: Callable, cutoff_upper: float, group: Optional[dist.ProcessGroup] = None,
+                 axis: Optional[int] = None, energy_offset: float = 0.0, transport: Optional[Callable] = None):
+        self.compute, self.group = compute, group
+        self.energy_offset = float(energy_offset)
+        self._slabs = SpatialEvaluator(None, cutoff_upper, 0, group, axis)  # halo = one cutoff
+        self.transport = transport if transport is not None else distributed_transport(group)
+        self.rows_moved = 0  # floats received by this rank in the last step (for the probes)
+
+    def plan(self, pos: torch.Tensor, box: torch.Tensor, rank: int, world: int) -> HaloPlan:
+        """Computed by every rank from the replicated positions: no negotiation.  The ghost list of rank r is what
+        ``SpatialEvaluator.local_system`` returns for a halo of one cutoff; its owner-side mirror is the same list seen from the
+        owner."""
+        sl = self._slabs
+        if world == 1:
+            gidx, pos_l, box_l, n_own = sl.local_system(pos, box, 0, 1)
+            return HaloPlan(gidx, pos_l, box_l, n_own, [gidx[:0]], [gidx[:0]])
+        lengths = torch.diagonal(box)
+        a = int(torch.argmax(lengths)) if sl.axis is None else int(sl.axis)
+        La = float(lengths[a])
+        if sl.halo > La - La / world:
+            raise ValueError(f"cutoff {sl.halo:g} exceeds the box length {La:g} minus one slab: an atom would be its own ghost")
+        x = torch.remainder(pos[:, a], La)
+        slab = torch.clamp(torch.floor(x / (La / world)).long(), max=world - 1)
+        local = [sl.local_system(pos, box, r, world) for r in range(world)]
+        gidx, pos_l, box_l, n_own = local[rank]
+        # row of every owned atom in its owner's local system
+        row_at_owner = torch.empty(pos.shape[0], dtype=torch.long, device=pos.device)
+        for r in range(world):
+            row_at_owner[local[r][0][:local[r][3]]] = torch.arange(local[r][3], device=pos.device)
+        ghosts = gidx[n_own:]
+        recv = [n_own + torch.nonzero(slab[ghosts] == p).flatten() for p in range(world)]
+        send = []
+        for p in range(world):
+            theirs = local[p][0][local[p][3]:]  # rank p's ghost list, in its order
+            send.append(row_at_owner[theirs[slab[theirs] == rank]])
+        return HaloPlan(gidx, pos_l, box_l, n_own, send, recv)
+
+    def exchange_fn(self, plan: HaloPlan, rank: int, world: int) -> Callable:
+        send_all = torch.cat(plan.send)
+        recv_all = torch.cat(plan.recv)
+        send_counts = [int(t.numel()) for t in plan.send]
+        recv_counts = [int(t.numel()) for t in plan.recv]
+        self.rows_moved = 0
+
+        def exchange(stage: int, rows: torch.Tensor, inv: Optional[torch.Tensor]):
+            if recv_all.numel() == 0 and send_all.numel() == 0:
+                return
+            src = send_all if inv is None else inv[send_all]
+            dst = recv_all if inv is None else inv[recv_all]
+            got = self.transport(rank, world, list(torch.split(rows[src], send_counts)), recv_counts)
+            rows[dst] = torch.cat(got)
+            self.rows_moved += int(dst.numel()) * int(rows.shape[1])
+
+        return exchange
+
+    def step(self, z, pos, box, rank: int, world: int):
+        """-> (plan, E_r - offset [1], forces of the local atoms [n_l, 3]; rows [:plan.n_own] are complete)."""
+        plan = self.plan(pos, box, rank, world)
+        w_l = torch.zeros(plan.gidx.numel(), dtype=torch.float32, device=pos.device)
+        w_l[:plan.n_own] = 1.0
+        e, f_l = self.compute(z[plan.gidx], plan.pos_l, plan.box_l, w_l, self.exchange_fn(plan, rank, world) if world > 1 else None)
+        return plan, e.reshape(1).to(torch.float32) - self.energy_offset, f_l.to(torch.float32)
+
+    def evaluate(self, z, pos, box) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Every rank calls with the full (replicated) system; returns (E [1], F [N, 3]) of the whole system on every rank."""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        plan, e, f_l = self.step(z, pos, box, rank, world)
+        forces = torch.zeros((pos.shape[0], 3), dtype=torch.float32, device=pos.device)
+        forces[plan.gidx[:plan.n_own]] = f_l[:plan.n_own]
+        if world > 1:
+            buf = torch.cat([forces.reshape(-1), e])
+            if buf.is_cuda and dist.get_backend(self.group) == "gloo":
+                host = buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                buf = host.to(buf.device)
+            else:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            forces, e = buf[:-1].reshape(-1, 3), buf[-1:]
+        return e + self.energy_offset, forces
