@@ -1,6 +1,9 @@
 """Developer probe (through gpurun): one periodic water box decomposed into R slabs (parallel.SpatialEvaluator), every slab's local
 system timed on ONE GPU -> the per-rank step time a node of R GPUs would see (max over slabs) against the whole system on one GPU.
-The collective (one all-reduce of 3N + 1 floats) is not in these numbers."""
+The collective (one all-reduce of 3N + 1 floats) is not in these numbers.  Beside the deep halo, the per-layer halo exchange
+(parallel.HaloExchangeEvaluator): the same slabs with ONE cutoff of ghosts, the 2 L + 1 exchanges served by a loop-back transport that
+hands every rank rows of its own of the right count - the gathers and scatters of the exchange are timed, the links are not
+(`halo_bytes_per_step` is what a rank receives over xGMI per step)."""
 import json, os, sys, time
 
 R = os.environ.get("GRAFT_REPO_ROOT", ".")
@@ -8,7 +11,7 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "torchmd-net_amd"))
 import torch
 from torchmdnet_amd import workloads as W
 from torchmdnet_amd.models.model import create_model
-from torchmdnet_amd.parallel import SpatialEvaluator
+from torchmdnet_amd.parallel import HaloExchangeEvaluator, SpatialEvaluator
 
 
 def timed(fn, reps=10):
@@ -43,6 +46,23 @@ def main():
                 per.append((int(gidx.numel()), timed(lambda: model.energy_and_forces(zl, pos_l, bl, box_l, None, 1, True, atom_weights=w))))
             rec["ranks"][world] = {"local_atoms_max": max(p[0] for p in per), "step_ms_max": max(p[1] for p in per),
                                    "speedup_vs_one_gpu": whole / max(p[1] for p in per)}
+            # per-layer halo exchange: one cutoff of ghosts, loop-back rows
+            def loopback(rank, world_, send, recv_counts):
+                rows = torch.cat(send)
+                return [rows[torch.arange(c, device=rows.device) % max(int(rows.shape[0]), 1)] for c in recv_counts]
+
+            hx = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex: model.energy_and_forces(zl, pl, torch.zeros_like(zl), bl, None, 1, True,
+                                                                                          atom_weights=wl, halo_exchange=ex),
+                                       args["cutoff_upper"], transport=loopback)
+            per = []
+            for r in range(world):
+                plan = hx.plan(pos, box, r, world)
+                t = timed(lambda: hx.step(z, pos, box, r, world))
+                t_plan = timed(lambda: hx.plan(pos, box, r, world), reps=3)
+                per.append((int(plan.gidx.numel()), t - t_plan, plan.n_ghost, hx.rows_moved * 4))
+            rec["ranks"][world].update({"exchange_local_atoms_max": max(p[0] for p in per), "exchange_step_ms_max": max(p[1] for p in per),
+                                        "exchange_ghosts_max": max(p[2] for p in per), "halo_bytes_per_step": max(p[3] for p in per),
+                                        "exchange_speedup_vs_one_gpu": whole / max(p[1] for p in per)})
         out[f"water_{n_side}"] = rec
         print(json.dumps({f"water_{n_side}": rec}))
     os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)

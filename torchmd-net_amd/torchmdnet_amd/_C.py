@@ -126,7 +126,7 @@ def declared_symbols():
     with open(HEADER_PATH) as fh:
         txt = fh.read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(tmdnet_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(tmdnet_[a-z0-9_]+)\s*\(", txt)))
 
 
 def check_symbols():
