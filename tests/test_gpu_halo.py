@@ -29,8 +29,9 @@ class Mailbox:
 def _evaluator(model, args, transport=None, group=None):
     from torchmdnet_amd.parallel import HaloExchangeEvaluator
 
-    def compute(zl, pl, boxl, wl, exchange):
-        return model.energy_and_forces(zl, pl, torch.zeros_like(zl), boxl, None, 1, True, atom_weights=wl, halo_exchange=exchange)
+    def compute(zl, pl, boxl, wl, exchange, grid):
+        return model.energy_and_forces(zl, pl, torch.zeros_like(zl), boxl, None, 1, True, atom_weights=wl, halo_exchange=exchange,
+                                       cell_grid=grid)
 
     return HaloExchangeEvaluator(compute, args["cutoff_upper"], group=group, energy_offset=float(model.mean), transport=transport)
 
@@ -64,7 +65,8 @@ def _threaded(args, seed, z, pos, box, world):
     for plan, e, f_l in out:
         E = E + e
         F[plan.gidx[:plan.n_own]] = f_l[:plan.n_own]
-    return E + evs[0].energy_offset, F, [int(o[0].gidx.numel()) for o in out], [ev.rows_moved for ev in evs]
+    active = [(int(m.engine_info("halo_active_rows")), o[0].n_own) for m, o in zip(models, out)]
+    return E + evs[0].energy_offset, F, [int(o[0].gidx.numel()) for o in out], [ev.rows_moved for ev in evs], active
 
 
 def test_halo_exchange_small_system_vs_whole_and_deep_halo(hip_lib):
@@ -81,7 +83,7 @@ def test_halo_exchange_small_system_vs_whole_and_deep_halo(hip_lib):
     Ew, Fw = whole.energy_and_forces(z, pos, torch.zeros_like(z), box, None, 1, True)
     deep = SpatialEvaluator(None, args["cutoff_upper"], args["num_layers"])
     for world in (2, 3):
-        E, F, n_local, moved = _threaded(args, 2, z, pos, box, world)
+        E, F, n_local, moved, _ = _threaded(args, 2, z, pos, box, world)
         n_deep = [int(deep.local_system(pos, box, r, world)[0].numel()) for r in range(world)]
         assert max(n_local) < min(n_deep), (n_local, n_deep)  # the point of the exchange: fewer redundant atoms per rank
         assert min(moved) > 0
@@ -90,24 +92,27 @@ def test_halo_exchange_small_system_vs_whole_and_deep_halo(hip_lib):
 
 
 def test_halo_exchange_c2_water_box_cell_order(hip_lib):
-    """C2 model (cutoff 5 A, two layers) on a 5184-atom water box in 2 slabs: ~3600 local atoms each (deep halo: ~6800), renumbered
-    in cell order inside the engine - the callback's `perm` maps the rows; fused tensor linears and radial tables as in the bench."""
+    """C2 model (cutoff 5 A, two layers) on a 10 125-atom water box in 2 slabs: ~7 800 local atoms each (deep halo: ~11 600),
+    renumbered in cell order inside the engine - the callback's `perm` maps the rows; fused tensor linears and radial tables as in
+    the bench.  The slabs are aligned with the cell grid, so the per-atom kernels run on the owned rows only."""
     from torchmdnet_amd import workloads as W
     from torchmdnet_amd.models.model import create_model
 
     args = dict(W.C2_ARGS)
-    z, pos, box = (t.cuda() for t in W.water_box(n_side=12))
+    z, pos, box = (t.cuda() for t in W.water_box(n_side=15))
     torch.manual_seed(0)
     whole = create_model(dict(args)).cuda()
     Ew, Fw = whole.energy_and_forces(z, pos, torch.zeros_like(z), box, None, 1, True)
-    E, F, n_local, moved = _threaded(args, 0, z, pos, box, 2)
-    assert 1024 < max(n_local) < 4500, n_local
+    E, F, n_local, moved, active = _threaded(args, 0, z, pos, box, 2)
+    assert 1024 < max(n_local) < 9000, n_local
+    # the slabs are aligned with the cell grid: the owned atoms are one range of the cell order and the per-atom kernels ran on it only
+    assert all(rows == n_own for rows, n_own in active), active
     assert abs(float(E) - float(Ew)) < 1e-5 * max(1.0, abs(float(Ew)))
     assert (F - Fw).abs().max().item() < 1e-5 * max(1.0, Fw.abs().max().item())
     # without the exchange the same local systems give wrong forces on the atoms near the cut: the test would notice a no-op hook
     from torchmdnet_amd.parallel import HaloExchangeEvaluator
-    ev = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex: whole.energy_and_forces(zl, pl, torch.zeros_like(zl), bl, None, 1, True,
-                                                                                  atom_weights=wl), args["cutoff_upper"])
+    ev = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex, grid: whole.energy_and_forces(zl, pl, torch.zeros_like(zl), bl, None, 1, True,
+                                                                                        atom_weights=wl), args["cutoff_upper"])
     plan, _, f_l = ev.step(z, pos, box, 0, 2)
     assert (f_l[:plan.n_own] - Fw[plan.gidx[:plan.n_own]]).abs().max().item() > 1e-3 * Fw.abs().max().item()
 

@@ -352,43 +352,44 @@ def test_halo_exchange_plan_and_protocol_ranks_as_threads():
     from torchmdnet_amd.parallel import HaloExchangeEvaluator
 
     rc = 2.5
-    z, pos, box = _periodic_system(90, [21.0, 6.0, 5.5], seed=11)
-    Ew, Fw = _toy_whole(z, pos, box, rc)
-    for world in (2, 3, 4):
-        mb = _Mailbox(world)
-        evs = [HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex: _toy_step(zl, pl, bl, wl, rc, ex), rc, transport=mb.transport)
-               for _ in range(world)]
-        plans = [evs[0].plan(pos, box, r, world) for r in range(world)]
-        for r in range(world):  # what r sends to p is what p expects from r, atom by atom; every ghost has exactly one source
-            for p in range(world):
-                assert torch.equal(plans[r].gidx[plans[r].send[p]], plans[p].gidx[plans[p].recv[r]])
-            assert sum(int(t.numel()) for t in plans[r].recv) == plans[r].n_ghost and int(plans[r].recv[r].numel()) == 0
-        assert sum(pl.n_own for pl in plans) == 90
-        out, err = [None] * world, []
+    for lengths, worlds in (([21.0, 6.0, 5.5], (2, 3, 4)), ([6.0, 5.5, 21.0], (3,))):  # slab axis z: the local axes are permuted
+      z, pos, box = _periodic_system(90, lengths, seed=11)
+      Ew, Fw = _toy_whole(z, pos, box, rc)
+      for world in worlds:
+          mb = _Mailbox(world)
+          evs = [HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex, grid: _toy_step(zl, pl, bl, wl, rc, ex), rc, transport=mb.transport)
+                 for _ in range(world)]
+          plans = [evs[0].plan(pos, box, r, world) for r in range(world)]
+          for r in range(world):  # what r sends to p is what p expects from r, atom by atom; every ghost has exactly one source
+              for p in range(world):
+                  assert torch.equal(plans[r].gidx[plans[r].send[p]], plans[p].gidx[plans[p].recv[r]])
+              assert sum(int(t.numel()) for t in plans[r].recv) == plans[r].n_ghost and int(plans[r].recv[r].numel()) == 0
+          assert sum(pl.n_own for pl in plans) == 90
+          out, err = [None] * world, []
 
-        def run(r):
-            try:
-                out[r] = evs[r].step(z, pos, box, r, world)
-            except BaseException as e:  # noqa: BLE001
-                err.append(e)
-                mb.barrier.abort()
+          def run(r):
+              try:
+                  out[r] = evs[r].step(z, pos, box, r, world)
+              except BaseException as e:  # noqa: BLE001
+                  err.append(e)
+                  mb.barrier.abort()
 
-        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        assert not err, err
-        E, F = torch.zeros(1), torch.zeros(90, 3)
-        for plan, e, f_l in out:
-            E = E + e
-            F[plan.gidx[:plan.n_own]] = f_l[:plan.n_own]
-        assert abs(float(E) - float(Ew)) < 1e-5 * abs(float(Ew)), world
-        assert (F - Fw).abs().max().item() < 1e-5 * Fw.abs().max().item(), world
-        assert all(ev.rows_moved == 3 * 4 * pl.n_ghost for ev, pl in zip(evs, plans))
-    ev = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex: _toy_step(zl, pl, bl, wl, rc, None), rc)
+          th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+          [t.start() for t in th]
+          [t.join() for t in th]
+          assert not err, err
+          E, F = torch.zeros(1), torch.zeros(90, 3)
+          for plan, e, f_l in out:
+              E = E + e
+              F[plan.gidx[:plan.n_own]] = f_l[:plan.n_own]
+          assert abs(float(E) - float(Ew)) < 1e-5 * abs(float(Ew)), world
+          assert (F - Fw).abs().max().item() < 1e-5 * Fw.abs().max().item(), world
+          assert all(ev.rows_moved == 3 * 4 * pl.n_ghost for ev, pl in zip(evs, plans))
+    ev = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex, grid: _toy_step(zl, pl, bl, wl, rc, None), rc)
     plan, _, f_l = ev.step(z, pos, box, 0, 2)
     assert (f_l[:plan.n_own] - Fw[plan.gidx[:plan.n_own]]).abs().max().item() > 1e-2 * Fw.abs().max().item()
     with pytest.raises(ValueError, match="own ghost"):
-        HaloExchangeEvaluator(None, 12.0).plan(pos, box, 0, 2)  # cutoff 12 A > 21 A - one slab
+        HaloExchangeEvaluator(None, 11.0).plan(pos, box, 0, 2)  # a halo of 11 A on either side of a 10.5 A slab in 21 A
 
 
 def _halo_worker(rank, world, port, tmpdir):
@@ -404,7 +405,7 @@ def _halo_worker(rank, world, port, tmpdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rc = 2.5
     z, pos, box = _periodic_system(90, [21.0, 6.0, 5.5], seed=11)
-    ev = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex: _toy_step(zl, pl, bl, wl, rc, ex), rc)
+    ev = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex, grid: _toy_step(zl, pl, bl, wl, rc, ex), rc)
     E, F = ev.evaluate(z, pos, box)  # all-to-all per exchange, then the [3 N + 1] all-reduce
     Ew, Fw = _toy_whole(z, pos, box, rc)
     ok = abs(float(E) - float(Ew)) < 1e-5 * abs(float(Ew)) and (F - Fw).abs().max().item() < 1e-5 * Fw.abs().max().item()

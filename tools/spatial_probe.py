@@ -51,18 +51,21 @@ def main():
                 rows = torch.cat(send)
                 return [rows[torch.arange(c, device=rows.device) % max(int(rows.shape[0]), 1)] for c in recv_counts]
 
-            hx = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex: model.energy_and_forces(zl, pl, torch.zeros_like(zl), bl, None, 1, True,
-                                                                                          atom_weights=wl, halo_exchange=ex),
+            hx = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex, grid: model.energy_and_forces(zl, pl, torch.zeros_like(zl), bl, None, 1,
+                                                                                                True, atom_weights=wl, halo_exchange=ex,
+                                                                                                cell_grid=grid),
                                        args["cutoff_upper"], transport=loopback)
             per = []
             for r in range(world):
                 plan = hx.plan(pos, box, r, world)
                 t = timed(lambda: hx.step(z, pos, box, r, world))
                 t_plan = timed(lambda: hx.plan(pos, box, r, world), reps=3)
-                per.append((int(plan.gidx.numel()), t - t_plan, plan.n_ghost, hx.rows_moved * 4))
+                per.append((int(plan.gidx.numel()), t - t_plan, plan.n_ghost, hx.rows_moved * 4, int(model.engine_info("halo_active_rows")),
+                            plan.n_own))
             rec["ranks"][world].update({"exchange_local_atoms_max": max(p[0] for p in per), "exchange_step_ms_max": max(p[1] for p in per),
                                         "exchange_ghosts_max": max(p[2] for p in per), "halo_bytes_per_step": max(p[3] for p in per),
-                                        "exchange_speedup_vs_one_gpu": whole / max(p[1] for p in per)})
+                                        "exchange_speedup_vs_one_gpu": whole / max(p[1] for p in per),
+                                        "per_atom_kernels_on_owned_rows_only": [p[4] == p[5] for p in per]})
         out[f"water_{n_side}"] = rec
         print(json.dumps({f"water_{n_side}": rec}))
     os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)

@@ -633,6 +633,7 @@ int tmdnet_destroy(tmdnet_model* m) {
   if (m->upd_ofs) (void)hipFree(m->upd_ofs);
   if (m->upd_ptrs) (void)hipFree(m->upd_ptrs);
   if (m->rb_img) (void)hipFree(m->rb_img);
+  if (m->halo_rng) (void)hipFree(m->halo_rng);
   delete m;
   return TMDNET_OK;
 }
@@ -1124,6 +1125,8 @@ int tmdnet_get_info(const tmdnet_model* m, const char* name, double* value) {
   else if (n == "recompute_pair_rows") *value = m->recompute_rows ? 1.0 : 0.0;
   else if (n == "embed_rb") *value = m->rb_fwd ? 1.0 : 0.0;
   else if (n == "species_last_build") *value = (double)m->last_nt;
+  else if (n == "halo_active_first") *value = (double)m->halo_active[0];  // rows the per-atom kernels of the last step ran on
+  else if (n == "halo_active_rows") *value = (double)m->halo_active[1];
   else return TMDNET_ERR_INVALID;
   return TMDNET_OK;
 }
@@ -1426,6 +1429,31 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   };
 #define HALO_TRY(stage, rows, row_floats) \
   do { if (HALO(stage, rows, row_floats)) return fail(m, TMDNET_ERR_STATE, "halo exchange callback failed at stage " + std::to_string(stage)); } while (0)
+  // Halo exchange with the owned atoms CONTIGUOUS in the engine's order (parallel.HaloExchangeEvaluator aligns its slabs with the
+  // cell grid, whose major axis is x): the per-atom kernels run on the owned rows [a0, a0 + Na) only.  Nothing of a ghost is read
+  // but its rows of the tensors a sweep gathers, and those come from the exchange; the sweeps, the pair kernels and the embedding's
+  // neighbour sums keep all rows (a ghost's half of a pair's distance gradient is computed at the ghost's row).
+  int a0 = 0, Na = N;
+  if (m->halo_fn && m->atom_w && m->graph_is_cell && want_forces && !tc && (int64_t)N > 256 * (int64_t)B) {
+    if (!m->halo_rng) HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->halo_rng), 4 * sizeof(int)));
+    int h[4] = {0, 0, 0, 0};
+    launch_owned_range(m->atom_w, perm, N, m->halo_rng, s);
+    HIP_TRY(m, hipMemcpyAsync(h, m->halo_rng, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(m, hipStreamSynchronize(s));
+    const bool images = tlin9_images(W.Ue) && tlin9_images(W.UeT) && L > 0 && tlin9_images(W.layer[0].V) && tlin9_images(W.layer[0].VT);
+    if (h[2] > 0 && h[2] < N && h[1] - h[0] + 1 == h[2] && images && tlin9_ok(h[2], F, true)) {  // only the fused tensor linears take a row range
+      a0 = h[0];
+      Na = h[2];
+    }
+  }
+  const bool rng = Na != N;  // then the fused tensor linears are the only schedule (checked above), whatever their last round of tiles
+  const bool t9 = !tc && tlin9_ok(Na, F, rng) && tlin9_images(W.Ue) && tlin9_images(W.UeT) && (L == 0 || tlin9_images(W.layer[0].V));
+  const bool t9r = !tc && L > 0 && tlin9_ok(Na, F, rng) && tlin9_images(W.UeT) && tlin9_images(W.layer[0].VT);
+  m->halo_active[0] = a0;
+  m->halo_active[1] = Na;
+  const int64_t o1_ = a0, oF = (int64_t)a0 * F, o2F = 2 * oF, o3F = 3 * oF, o9F = 9 * oF, oH = (int64_t)a0 * H;
+  const float* const q_a = q ? q + o1_ : nullptr;                    // per-atom charge factor (kappa) of the active rows
+  const int64_t* const batch_a = batch_k ? batch_k + o1_ : nullptr;  // their molecule index
   const bool fused_small = !tc && !ntp && !recompute && !m->halo_fn && (small_fused_ok(N, F, H, L) || mid_fused_ok(N, F, H, L)) &&
                            (!want_forces || (message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD")));
   if (run_fwd) {
@@ -1535,16 +1563,16 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       KR(CAT_SCATTER, Pd * 12 * Fd + E_ * 12 + Nd * 10 * Fd * 4,
          launch_embed_scatter(g, N, F, z, W.Utab, W.Vtab, b.Q, b.C, b.u0, b.s0n, s));
     }
-    KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.s0n, W.ln0_w, W.ln0_b, N, F, b.ln0, b.xh0, b.rstd0, s));
+    KR(CAT_ELEMENTWISE, Nd * Fd * 12,
+       launch_layernorm_fwd(b.s0n + oF, W.ln0_w, W.ln0_b, Na, F, b.ln0 + oF, b.xh0 + oF, b.rstd0 + o1_, s));
     NODE();
-    gemm(s, b.ln0, F, W.L1, F, W.bL1, b.h1, 2 * F, N, 2 * F, F, GEMM_ACT_SILU, b.a1, 2 * F);
-    gemm(s, b.h1, 2 * F, W.L2, 2 * F, W.bL2, b.gates, 3 * F, N, 3 * F, 2 * F, GEMM_ACT_SILU, b.a2, 3 * F);
+    gemm(s, b.ln0 + oF, F, W.L1, F, W.bL1, b.h1 + o2F, 2 * F, Na, 2 * F, F, GEMM_ACT_SILU, b.a1 + o2F, 2 * F);
+    gemm(s, b.h1 + o2F, 2 * F, W.L2, 2 * F, W.bL2, b.gates + o3F, 3 * F, Na, 3 * F, 2 * F, GEMM_ACT_SILU, b.a2 + o3F, 3 * F);
     // fused 9-component tensor linears (tn_tlin9.hip) at batch scale; the parameter-gradient pass keeps the unfused schedule,
     // whose intermediates (X_hat, C_hat, g_D, g_C_hat per layer) are operands of its weight-gradient products
-    const bool t9 = !tc && tlin9_ok(N, F) && tlin9_images(W.Ue) && tlin9_images(W.UeT) && (L == 0 || tlin9_images(W.layer[0].V));
     if (t9) {
       Tl9Args ta{};
-      ta.A = b.u0; ta.C = b.X[0]; ta.o1 = b.UX; ta.e3 = b.gates; ta.N = N; ta.F = F;
+      ta.A = b.u0 + o9F; ta.C = b.X[0] + o9F; ta.o1 = b.UX + o9F; ta.e3 = b.gates + o3F; ta.N = Na; ta.F = F;
       tlin9(s, TL9_PRO_PLAIN, TL9_EPI_MULGATE, W.Ue, ta, 3.0 + 1.0 / 3.0, "gate");
     } else
       tensor_linear(s, b.u0, W.Ue, b.X[0], N, F, GEMM_MUL_AUX, b.UX, b.gates);
@@ -1559,14 +1587,16 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       if (t9) {
         // X / (||X||^2 + 1) while the rows are staged; X_hat is never stored (the update recomputes it from X)
         Tl9Args ta{};
-        ta.A = b.X[l]; ta.C = b.Pn[l]; ta.N = N; ta.F = F;
+        ta.A = b.X[l] + o9F; ta.C = b.Pn[l] + o9F; ta.N = Na; ta.F = F;
         tlin9(s, TL9_PRO_NORM, TL9_EPI_PLAIN, q_.V, ta, 2.0, "norm");
         HALO_TRY(l, b.Pn[l], 9 * F);
-        KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s, recompute ? &rts[l] : nullptr));
+        KR(CAT_MESSAGE, wB + idxB + 3 * nodeB,
+           launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s, recompute ? &rts[l] : nullptr, a0, rng ? Na : -1));
         // dX = linear(C_hat), then X_new = X_hat + dX + kappa dX.dX (and the readout invariants after the last layer) in the epilogue
         Tl9Args tb{};
-        tb.A = Ch_l; tb.C = b.D[l]; tb.e0 = b.X[l]; tb.o1 = b.X[l + 1]; tb.o2 = b.feat; tb.want_feat = l + 1 == L; tb.kap = q;
-        tb.N = N; tb.F = F;
+        tb.A = Ch_l + o9F; tb.C = b.D[l] + o9F; tb.e0 = b.X[l] + o9F; tb.o1 = b.X[l + 1] + o9F; tb.o2 = b.feat + o3F;
+        tb.want_feat = l + 1 == L; tb.kap = q_a;
+        tb.N = Na; tb.F = F;
         tlin9(s, TL9_PRO_PLAIN, TL9_EPI_UPDATE, q_.V + 3, tb, 4.0 + (l + 1 == L ? 1.0 / 3.0 : 0.0), "update");
         continue;
       }
@@ -1580,17 +1610,20 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
                                                          l + 1 < L ? Xh_n : b.feat, s));
     }
     // ---- readout + head + per-molecule sum
-    if (L == 0) KR(CAT_ELEMENTWISE, nodeB + Nd * 3 * Fd * 4, launch_readout_feat(b.X[L], N, F, b.feat, s));
-    KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_fwd(b.feat, W.lnr_w, W.lnr_b, N, 3 * F, b.lnr, b.xhr, b.rstdr, s));
+    if (L == 0) KR(CAT_ELEMENTWISE, nodeB + Nd * 3 * Fd * 4, launch_readout_feat(b.X[L] + o9F, Na, F, b.feat + o3F, s));
+    KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12,
+       launch_layernorm_fwd(b.feat + o3F, W.lnr_w, W.lnr_b, Na, 3 * F, b.lnr + o3F, b.xhr + o3F, b.rstdr + o1_, s));
     NODE();
-    gemm(s, b.lnr, 3 * F, W.Lin, 3 * F, W.bLin, b.x, F, N, F, 3 * F, GEMM_ACT_SILU, b.al, F);
-    gemm(s, b.x, F, W.O1, F, W.bO1, b.ao, H, N, H, F);
+    gemm(s, b.lnr + o3F, 3 * F, W.Lin, 3 * F, W.bLin, b.x + oF, F, Na, F, 3 * F, GEMM_ACT_SILU, b.al + oF, F);
+    gemm(s, b.x + oF, F, W.O1, F, W.bO1, b.ao + oH, H, Na, H, F);
     if ((int64_t)N <= 256 * (int64_t)B) {  // small molecules: head + per-molecule sum in one launch (a block walks its molecule)
       KR(CAT_ELEMENTWISE, Nd * H * 4, launch_head_mol_sum(g, b.ao, W.O2, W.bO2, N, B, H, W.std, W.atomref, z, batch, W.mean, energy, s,
                                                           want_forces ? b.g_ao : nullptr, m->atom_w, perm));
     } else {
+      if (Na != N) launch_fill(b.ea, 0.f, N, s);  // the ghosts' rows of the per-atom energies: not computed, not counted
       KR(CAT_ELEMENTWISE, Nd * H * 4,
-         launch_head_energy(b.ao, W.O2, W.bO2, N, H, W.std, W.atomref, z, b.ea, s, want_forces ? b.g_ao : nullptr, m->atom_w, perm));
+         launch_head_energy(b.ao + oH, W.O2, W.bO2, Na, H, W.std, W.atomref, z + o1_, b.ea + o1_, s, want_forces ? b.g_ao + oH : nullptr,
+                            perm ? m->atom_w : (m->atom_w ? m->atom_w + o1_ : nullptr), perm ? perm + o1_ : nullptr));
       KR(CAT_ELEMENTWISE, Nd * 4, launch_mol_sum(g, b.ea, batch, N, B, W.mean, energy, s));
     }
     }  // !fused_small
@@ -1642,8 +1675,8 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       launch_tn_gemm(s, b.g_ao, rH, b.x, rF, nullptr, nullptr, N, H, F, tc->at("O1"), false, tc->part);
       launch_colsum(s, b.g_ao, rH, nullptr, rH, nullptr, nullptr, N, H, tc->at("bO1"), false, tc->part);
     }
-    gemm(s, b.g_ao, H, W.O1T, H, nullptr, b.g_al, F, N, F, H, GEMM_MUL_DSILU_AUX, nullptr, 0, b.al, F);
-    gemm(s, b.g_al, F, W.LinT, F, nullptr, b.g_ln, 3 * F, N, 3 * F, F);
+    gemm(s, b.g_ao + oH, H, W.O1T, H, nullptr, b.g_al + oF, F, Na, F, H, GEMM_MUL_DSILU_AUX, nullptr, 0, b.al + oF, F);
+    gemm(s, b.g_al + oF, F, W.LinT, F, nullptr, b.g_ln + o3F, 3 * F, Na, 3 * F, F);
     if (tc) {
       launch_tn_gemm(s, b.g_al, rF, b.lnr, r3F, nullptr, nullptr, N, F, 3 * F, tc->at("Lin"), false, tc->part);
       launch_colsum(s, b.g_al, rF, nullptr, rF, nullptr, nullptr, N, F, tc->at("bLin"), false, tc->part);
@@ -1651,15 +1684,16 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       launch_colsum(s, b.g_ln, r3F, nullptr, r3F, nullptr, nullptr, N, 3 * F, tc->at("lnr_b"), false, tc->part);
     }
     if (F % 64 == 0) {
-      KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 8, launch_lnbwd_readout_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, F, b.X[L], b.G, s));
+      KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 8,
+         launch_lnbwd_readout_bwd(b.g_ln + o3F, b.xhr + o3F, b.rstdr + o1_, W.lnr_w, Na, F, b.X[L] + o9F, b.G + o9F, s));
     } else {
-      KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12, launch_layernorm_bwd(b.g_ln, b.xhr, b.rstdr, W.lnr_w, N, 3 * F, b.g_feat, s));
-      KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 4, launch_readout_bwd(b.X[L], b.g_feat, N, F, b.G, s));
+      KR(CAT_ELEMENTWISE, Nd * 3 * Fd * 12,
+         launch_layernorm_bwd(b.g_ln + o3F, b.xhr + o3F, b.rstdr + o1_, W.lnr_w, Na, 3 * F, b.g_feat + o3F, s));
+      KR(CAT_ELEMENTWISE, 2 * nodeB + Nd * 3 * Fd * 4, launch_readout_bwd(b.X[L] + o9F, b.g_feat + o3F, Na, F, b.G + o9F, s));
     }
     // zero-fills are kernels, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to
     // re-execute on replay (ROCm 7.2), which silently accumulated gC / g_phi across MD steps
     const bool merged_gd = message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD") && !tc;
-    const bool t9r = !tc && L > 0 && tlin9_ok(N, F) && tlin9_images(W.UeT) && tlin9_images(W.layer[0].VT);
     const int gd_nw = message_adjoint_gd_waves(g, N, F, recompute);
     const int64_t gd_stride = 2 * (int64_t)P1;
     if (!merged_gd) launch_fill(b.gd, 0.f, P1, s);  // the per-layer pair kernels accumulate into it
@@ -1669,9 +1703,10 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         // update adjoint while G is staged (g_D never reaches memory), transposed linear; the adjoint of the group product stays a
         // kernel of its own: in the epilogue its 3x3 temporaries spilled and the fused launch lost to the pair (180 vs 77 + 62 us)
         Tl9Args ta{};
-        ta.A = b.G; ta.A2 = b.D[l]; ta.kap = q; ta.N = N; ta.F = F; ta.C = b.gCh;
+        ta.A = b.G + o9F; ta.A2 = b.D[l] + o9F; ta.kap = q_a; ta.N = Na; ta.F = F; ta.C = b.gCh + o9F;
         tlin9(s, TL9_PRO_UPDBWD, TL9_EPI_PLAIN, q_.VT + 3, ta, 3.0, "updbwd");
-        KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh, b.Pn[l], b.Mi[l], q, batch_k, o3, N, F, b.gMi, b.gPn, s));
+        KR(CAT_ELEMENTWISE, 5 * nodeB, launch_message_bwd_node(b.gCh + o9F, b.Pn[l] + o9F, b.Mi[l] + o9F, q_a, batch_a, o3, Na, F,
+                                                               b.gMi + o9F, b.gPn + o9F, s));
       } else {
       // gD of the layers below the top one comes out of the previous iteration's fused normalisation adjoint
       if (l == L - 1) KR(CAT_ELEMENTWISE, 3 * nodeB, launch_update_bwd(b.G, b.D[l], q, batch_k, N, F, b.gD, s));
@@ -1702,7 +1737,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       if (merged_gd) {
         KR(CAT_MESSAGE, 2 * wB + idxB + 4 * nodeB + 8 * (Pd + 1) * gd_nw,  // w, dw, gMi, Pn, gPn (read + write), g_d slots
            launch_message_adjoint_gd(g, N, F, b.w[l], b.dw[l], b.gMi, b.Pn[l], b.gPn, b.gd_slots + (int64_t)l * gd_nw * gd_stride,
-                                     gd_stride, s, recompute ? &rts[l] : nullptr));
+                                     gd_stride, s, recompute ? &rts[l] : nullptr, a0, rng ? a0 + Na : -1));
       } else {
         KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
         if (!tc) KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));
@@ -1711,12 +1746,12 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         // transposed linear + normalisation adjoint (incoming: the residual stream's G) in the epilogue; layer 0 goes on through
         // the embedding's gate adjoint there
         Tl9Args ta{};
-        ta.A = b.gPn; ta.e0 = b.X[l]; ta.e1 = b.G; ta.N = N; ta.F = F;
+        ta.A = b.gPn + o9F; ta.e0 = b.X[l] + o9F; ta.e1 = b.G + o9F; ta.N = Na; ta.F = F;
         if (l > 0) {
-          ta.C = b.G;
+          ta.C = b.G + o9F;
           tlin9(s, TL9_PRO_PLAIN, TL9_EPI_NORMBWD, q_.VT, ta, 4.0, "normbwd");
         } else {
-          ta.C = b.gUX; ta.o1 = b.g_a2; ta.e2 = b.UX; ta.e3 = b.gates; ta.e4 = b.a2;
+          ta.C = b.gUX + o9F; ta.o1 = b.g_a2 + o3F; ta.e2 = b.UX + o9F; ta.e3 = b.gates + o3F; ta.e4 = b.a2 + o3F;
           tlin9(s, TL9_PRO_PLAIN, TL9_EPI_NORMBWD_GATE, q_.VT, ta, 5.0 + 1.0, "normbwd+gate");
         }
         continue;
@@ -1729,14 +1764,16 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         KR(CAT_ELEMENTWISE, 5 * nodeB + Nd * 3 * Fd * 12,
            launch_norm_bwd_gate_bwd(b.X[0], b.gXl, N, F, b.G, b.UX, b.gates, b.a2, b.gUX, b.g_a2, s));
     }
-    if (L == 0) KR(CAT_ELEMENTWISE, 3 * nodeB + Nd * 3 * Fd * 12, launch_embed_gate_bwd(b.G, b.UX, b.gates, b.a2, N, F, b.gUX, b.g_a2, s));
+    if (L == 0)
+      KR(CAT_ELEMENTWISE, 3 * nodeB + Nd * 3 * Fd * 12,
+         launch_embed_gate_bwd(b.G + o9F, b.UX + o9F, b.gates + o3F, b.a2 + o3F, Na, F, b.gUX + o9F, b.g_a2 + o3F, s));
     NODE();
-    gemm(s, b.g_a2, 3 * F, W.L2T, 3 * F, nullptr, b.g_a1, 2 * F, N, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.a1, 2 * F);
-    gemm(s, b.g_a1, 2 * F, W.L1T, 2 * F, nullptr, b.g_ln0, F, N, F, 2 * F);
-    KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_bwd(b.g_ln0, b.xh0, b.rstd0, W.ln0_w, N, F, b.g_s0n, s));
-    if (!tc && tlin9_ok(N, F) && tlin9_images(W.UeT)) {
+    gemm(s, b.g_a2 + o3F, 3 * F, W.L2T, 3 * F, nullptr, b.g_a1 + o2F, 2 * F, Na, 2 * F, 3 * F, GEMM_MUL_DSILU_AUX, nullptr, 0, b.a1 + o2F, 2 * F);
+    gemm(s, b.g_a1 + o2F, 2 * F, W.L1T, 2 * F, nullptr, b.g_ln0 + oF, F, Na, F, 2 * F);
+    KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_bwd(b.g_ln0 + oF, b.xh0 + oF, b.rstd0 + o1_, W.ln0_w, Na, F, b.g_s0n + oF, s));
+    if (!tc && tlin9_ok(Na, F, rng) && tlin9_images(W.UeT)) {
       Tl9Args ta{};
-      ta.A = b.gUX; ta.e0 = b.u0; ta.e1 = b.g_s0n; ta.o1 = b.gA; ta.N = N; ta.F = F;
+      ta.A = b.gUX + o9F; ta.e0 = b.u0 + o9F; ta.e1 = b.g_s0n + oF; ta.o1 = b.gA + 10 * oF; ta.N = Na; ta.F = F;
       tlin9(s, TL9_PRO_PLAIN, TL9_EPI_EMBBWD, W.UeT, ta, 2.0 + 11.0 / 9.0, "embbwd");
     } else {
       tensor_linear(s, b.gUX, W.UeT, b.g_u0l, N, F);

@@ -86,7 +86,7 @@ struct PairRowTable;  // tn_interp.h: a layer's radial table for sweeps that eva
 void launch_message_dual(const Graph& g, int N, int F, const float* w, const float* w_t, const float* src, const float* src_t,
                          float* out, float* out_t, bool accumulate, hipStream_t s);  // value + tangent sweep (second-order pass)
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
-                    float* Mi, float* Ch, hipStream_t s, const PairRowTable* rt = nullptr);
+                    float* Mi, float* Ch, hipStream_t s, const PairRowTable* rt = nullptr, int row0 = 0, int nrows = -1);  // nrows >= 0: rows [row0, row0 + nrows) only
 void launch_message_adjoint(const Graph& g, int N, int F, const float* w, const float* gMi, float* gPn, hipStream_t s);
 // adjoint sweep + the layer's per-pair distance gradient in one pass (replaces launch_message_adjoint + launch_pair_gd when
 // message_adjoint_gd_ok): partial sums go to slots[wave][2 * pair + direction], summed by launch_geom_gd
@@ -96,7 +96,8 @@ bool message_adjoint_pair_ok(const Graph& g, int N, int F);  // tn_message_pair.
 void launch_message_adjoint_pair(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                  float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
-                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt = nullptr);
+                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt = nullptr, int own0 = 0,
+                               int own1 = -1);  // own1 >= 0: rows outside [own0, own1) are ghosts (their pairs with owned atoms only, no gPn)
 // next = 0: plain; 1: nxt = X_hat of the new X (next layer's k_norm_x); 2: nxt = readout invariants of the new X
 void launch_layer_update(const float* Xh, const float* D, const float* q, const int64_t* batch, int N, int F, float* Xn, int next,
                          float* nxt, hipStream_t s);
@@ -127,6 +128,9 @@ void launch_head_mol_sum(const Graph& g, const float* ao, const float* O2, const
                          float* g_ao = nullptr, const float* atom_w = nullptr, const int* perm = nullptr);
 void launch_embed_gate_bwd(const float* G, const float* UX, const float* gates, const float* a2, int N, int F, float* gUX, float* g_a2,
                            hipStream_t s);
+// out[0..2] = first row, last row, number of rows n with aw[perm ? perm[n] : n] != 0 (halo exchange: are the owned atoms one
+// contiguous range of the engine's order?)
+void launch_owned_range(const float* aw, const int* perm, int N, int* out, hipStream_t s);
 void launch_embed_bwd_atom(const float* g_u0_lin, const float* u0, const float* g_s0n, int N, int F, float* gA, hipStream_t s);
 void launch_force_gather(const Graph& g, int N, const float* g_delta, const int* perm, float* forces, hipStream_t s);
 void launch_fill(float* p, float v, int64_t n, hipStream_t s);

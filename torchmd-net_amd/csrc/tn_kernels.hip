@@ -680,8 +680,8 @@ __device__ __forceinline__ void csr_gather(const Graph& g, int i, int F, int f, 
 template <bool RC>
 __global__ void k_message(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ Pn,
                           const float* __restrict__ q, const int64_t* __restrict__ batch, int o3, float* __restrict__ Mi,
-                          float* __restrict__ Ch, PairRowTable rt) {
-  const int i = xcd_chunk(blockIdx.x, gridDim.x);
+                          float* __restrict__ Ch, PairRowTable rt, int row0) {
+  const int i = row0 + xcd_chunk(blockIdx.x, gridDim.x);  // row0 > 0: the owned rows of a halo exchange (gridDim.x of them)
   if (g.counts[2]) return;  // pair overflow: the adjacency was not filled (the host reports the error)
   const float kap = kappa_of(q, batch, i);
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
@@ -813,10 +813,19 @@ __global__ __launch_bounds__(1024) void k_message_split(Graph g, int N, int F, c
 static bool split_rows_ok(int N, int F) { return N <= kSplitRows && F <= 128 && F % 64 == 0; }
 
 void launch_message(const Graph& g, int N, int F, const float* w, const float* src, const float* q, const int64_t* batch, int o3,
-                    float* Mi, float* Ch, hipStream_t s, const PairRowTable* rt) {
+                    float* Mi, float* Ch, hipStream_t s, const PairRowTable* rt, int row0, int nrows) {
   if (N <= 0) return;
+  if (nrows < 0) {
+    row0 = 0;
+    nrows = N;
+  }
   if (rt) {  // rows evaluated from the table inside the sweep
-    hipLaunchKernelGGL((k_message<true>), dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, *rt);
+    hipLaunchKernelGGL((k_message<true>), dim3(nrows), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, *rt, row0);
+    return;
+  }
+  if (nrows != N && !split_rows_ok(N, F) && !(g.small_mols && message_pair_ok(N, F))) {  // a row range: the row kernel (one large
+                                                                                            // system; the other kernels take all rows)
+    hipLaunchKernelGGL((k_message<false>), dim3(nrows), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, PairRowTable{}, row0);
     return;
   }
   if (split_rows_ok(N, F)) {
@@ -827,7 +836,7 @@ void launch_message(const Graph& g, int N, int F, const float* w, const float* s
   // order has windows of hundreds of rows: there the row kernel with four edges in flight is faster (10 k-atom box:
   // 0.36 -> 0.26 ms per sweep)
   if (g.small_mols && message_pair_ok(N, F)) return launch_message_pair(g, N, F, w, src, q, batch, o3, Mi, Ch, s);
-  hipLaunchKernelGGL((k_message<false>), dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, PairRowTable{});
+  hipLaunchKernelGGL((k_message<false>), dim3(N), dim3(fthreads(F)), 0, s, g, N, F, w, src, q, batch, o3, Mi, Ch, PairRowTable{}, 0);
 }
 
 // adjoint of the message sum: the graph and the edge weights are symmetric, so the transpose sweep is the
@@ -852,11 +861,29 @@ __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict
 template <bool RC>
 __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ dw,
                                      const float* __restrict__ gMi, const float* __restrict__ Pn, float* __restrict__ gPn,
-                                     float* __restrict__ slots, int64_t slot_stride, PairRowTable rt) {
+                                     float* __restrict__ slots, int64_t slot_stride, PairRowTable rt, int own0, int own1) {
   const int i = xcd_chunk(blockIdx.x, gridDim.x);
   if (g.counts[2]) return;
   const int f = threadIdx.x, lane = f & 63, wave = f >> 6;  // blockDim.x == F (multiple of 64)
-  const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
+  // halo exchange, owned rows [own0, own1): a ghost's row is here for its half of the distance gradient of the pairs it has
+  // with owned atoms only - the columns of a row ascend (tn_cell.hip), so those edges are one sub-range of the row; its gPn
+  // is not wanted
+  const bool ghost = i < own0 || i >= own1;
+  if (ghost) {
+    int lo = e0, hi = e1;
+    while (lo < hi) {  // first edge with col >= own0
+      const int mid = (lo + hi) >> 1;
+      if (g.col[mid] < own0) lo = mid + 1; else hi = mid;
+    }
+    e0 = lo;
+    hi = e1;
+    while (lo < hi) {  // first edge with col >= own1
+      const int mid = (lo + hi) >> 1;
+      if (g.col[mid] < own1) lo = mid + 1; else hi = mid;
+    }
+    e1 = lo;
+  }
   const int F3 = 3 * F, F9 = 9 * F;
   float y[9], acc[9];
   load9(Pn + (int64_t)i * F9 + f, F, y);
@@ -922,6 +949,7 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
     h = wave_sum(h);
     if (lane == 0 && si >= 0) slots[(int64_t)wave * slot_stride + si] = h;
   }
+  if (ghost) return;
   float* o = gPn + (int64_t)i * F9 + f;
 #pragma unroll
   for (int c = 0; c < 9; ++c) o[c * F] += acc[c];
@@ -932,10 +960,20 @@ int message_adjoint_gd_waves(const Graph& g, int N, int F, bool rows_from_table)
   return (!rows_from_table && !split_rows_ok(N, F) && message_adjoint_pair_ok(g, N, F)) ? F / 32 : F / 64;
 }
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
-                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt) {
+                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt, int own0, int own1) {
   if (N <= 0) return;
+  if (own1 < 0) {
+    own0 = 0;
+    own1 = N;
+  }
   if (rt) {
-    hipLaunchKernelGGL((k_message_adjoint_gd<true>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, *rt);
+    hipLaunchKernelGGL((k_message_adjoint_gd<true>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, *rt, own0, own1);
+    return;
+  }
+  if ((own0 != 0 || own1 != N) && !split_rows_ok(N, F) && !message_adjoint_pair_ok(g, N, F)) {  // an owned range: the row kernel
+                                                                                                   // (the others treat every row alike)
+    hipLaunchKernelGGL((k_message_adjoint_gd<false>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride,
+                       PairRowTable{}, own0, own1);
     return;
   }
   if (split_rows_ok(N, F)) {
@@ -946,7 +984,7 @@ void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, con
   // batches of small molecules: the tile kernel (tn_message_pair.hip: gMi window and adjacency slice in LDS, balanced rows)
   if (message_adjoint_pair_ok(g, N, F)) return launch_message_adjoint_pair(g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, s);
   hipLaunchKernelGGL((k_message_adjoint_gd<false>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride,
-                     PairRowTable{});
+                     PairRowTable{}, 0, N);
 }
 
 // Value + tangent of a neighbour sum in ONE sweep (second-order pass, tn_hvp_api.hip):
@@ -1550,6 +1588,45 @@ __global__ void k_fill(float* p, float v, int64_t n) {
 void launch_fill(float* p, float v, int64_t n, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, s, p, v, n);
+}
+
+// ---- halo exchange: range of the owned rows (one block; a few tens of thousands of atoms)
+__global__ __launch_bounds__(1024) void k_owned_range(const float* __restrict__ aw, const int* __restrict__ perm, int N,
+                                                      int* __restrict__ out) {
+  __shared__ int red[3][16];
+  int lo = 0x7fffffff, hi = -1, cnt = 0;
+  for (int n = threadIdx.x; n < N; n += 1024)
+    if (aw[perm ? perm[n] : n] != 0.f) {
+      lo = min(lo, n);
+      hi = max(hi, n);
+      ++cnt;
+    }
+  for (int off = 32; off >= 1; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off, 64));
+    hi = max(hi, __shfl_xor(hi, off, 64));
+    cnt += __shfl_xor(cnt, off, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = lo;
+    red[1][wave] = hi;
+    red[2][wave] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) {
+      lo = min(lo, red[0][w]);
+      hi = max(hi, red[1][w]);
+      cnt += red[2][w];
+    }
+    out[0] = lo;
+    out[1] = hi;
+    out[2] = cnt;
+    out[3] = 0;
+  }
+}
+void launch_owned_range(const float* aw, const int* perm, int N, int* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_owned_range, dim3(1), dim3(1024), 0, s, aw, perm, N, out);
 }
 
 }  // namespace tn

@@ -157,6 +157,8 @@ struct tmdnet_model {
   // per-layer halo exchange (tmdnet_set_halo_exchange): called between the per-atom kernels and the neighbour sweeps of a step
   int (*halo_fn)(void*, int32_t, float*, int64_t, int64_t, const int32_t*, void*) = nullptr;
   void* halo_user = nullptr;
+  int* halo_rng = nullptr;          // device scratch: first / last / count of the owned rows in the engine's order
+  int halo_active[2] = {0, 0};      // [first row, rows] the per-atom kernels of the last step ran on ("halo_active_rows")
   tmdnet_hparams hp;
   TrainCtx* train = nullptr;  // non-null while tmdnet_energy_param_grads drives tmdnet_energy_forces
   std::vector<std::pair<std::string, int64_t>> train_entries;  // gradient buffer layout (name, numel), built on first use

@@ -37,7 +37,7 @@ struct Tl9Args {
   int N, F, o3, want_feat;
 };
 
-bool tlin9_ok(int N, int F);
+bool tlin9_ok(int N, int F, bool any_rounds = false);  // any_rounds: accept a mostly empty last round of tiles (see the definition)
 size_t split_weight_fm_elems(int64_t n, int64_t k);  // uint16 elements of one image
 void launch_split_weight_fm(const float* W_dev, int64_t n, int64_t k, uint16_t* out_dev, hipStream_t s);
 int launch_tlin9(const Tl9Args& a, int pro, int epi, hipStream_t s);

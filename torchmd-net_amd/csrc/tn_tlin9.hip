@@ -500,13 +500,14 @@ static int t9_num_cu() {
   return n_cu;
 }
 
-bool tlin9_ok(int N, int F) {
+bool tlin9_ok(int N, int F, bool any_rounds) {
   static const bool off = getenv("TMDNET_NO_TLIN9") != nullptr || getenv("TMDNET_NO_SPLIT_BF16") != nullptr;  // developer switches
   if (off || F < T9_NT || F % T9_NT) return false;  // (F % 128 == 0: the double-chunk count per tile is even)
   // batch scale only: below ~128 tiles the launch does not fill the chip and the split-K kernels of the small-system path win
   // (measured with the threshold at 1: 64 atoms 0.233 -> 0.391 ms per replayed step, 2048 atoms 0.65 -> 0.74, 4096 atoms equal)
   const int64_t tiles = (int64_t)((N + T9_RA - 1) / T9_RA) * (F / T9_NT);
   if (tiles < 128) return false;
+  if (any_rounds) return true;  // the caller has no other schedule for these rows (the owned range of a halo exchange)
   // one persistent block per CU: the launch takes ceil(tiles / CUs) tile times, so a mostly empty last round is paid in full
   // (10 125 atoms = 317 tiles on 256 CUs: two rounds for 1.24 rounds of work, the water box stepped 3.02 -> 3.16 ms)
   const int64_t n_cu = t9_num_cu(), rounds = (tiles + n_cu - 1) / n_cu;

@@ -1012,13 +1012,14 @@ class TorchMD_Net(nn.Module):
             raise TypeError(f"torchmdnet_amd: `{name}` must have dtype {' or '.join(str(d) for d in dtypes)}, got {t.dtype}")
 
     def energy_and_forces(self, z, pos, batch, box, q, n_mol, want_forces=True, atom_weights=None,
-                          halo_exchange=None) -> Tuple[Tensor, Optional[Tensor]]:
+                          halo_exchange=None, cell_grid=None) -> Tuple[Tensor, Optional[Tensor]]:
         """Raw engine call: returns (E [n_mol], F [N,3] or None), both fp32 on ``pos.device``.  ``atom_weights`` ([N] fp32, this
         framework's extension for domain decomposition, parallel.SpatialEvaluator): E_mol = sum_i w_i e_i + mean and F = -dE/dpos
         of that sum (TensorNet only).  ``halo_exchange(stage, rows, inv)`` (parallel.HaloExchangeEvaluator, TensorNet only) is
         called 2 L + 1 times inside the step (``tmdnet_set_halo_exchange``, include/tmdnet_amd.h): it overwrites the ghost rows of
         ``rows`` [N, row_floats] (a view of the engine's workspace) with their owners' values on the current stream; the row of
-        the caller's atom i is ``rows[i]`` when ``inv`` is None and ``rows[inv[i]]`` otherwise (cell order)."""
+        the caller's atom i is ``rows[i]`` when ``inv`` is None and ``rows[inv[i]]`` otherwise (cell order).  ``cell_grid``
+        (n_x, n_y, n_z) fixes the neighbour search's grid (``tmdnet_set_cell_grid``; default: from the box on the device)."""
         _require_cuda(pos, "TorchMD_Net.forward")
         L = _C.lib()
         dev = pos.device
@@ -1051,7 +1052,10 @@ class TorchMD_Net(nn.Module):
             # reference's cell strategy, models/utils.py:206-212) -, brute force inside each molecule otherwise
             # ... or several LARGE molecules that share the box / the bounding box (interleaved in cell order inside the engine)
             auto = box_mode != 2 and n_mol >= 1 and n >= self.cell_list_min_atoms * n_mol
-            L.tmdnet_set_cell_grid(st.handle, *((-1, -1, -1) if auto else (0, 0, 0)))
+            grid = (-1, -1, -1) if auto else (0, 0, 0)
+            if cell_grid is not None and auto:
+                grid = tuple(int(v) for v in cell_grid)
+            L.tmdnet_set_cell_grid(st.handle, *grid)
             nbytes = C.c_size_t(0)
             L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
             counts = (C.c_int64 * 8)()

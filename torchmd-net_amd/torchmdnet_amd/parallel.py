@@ -262,10 +262,12 @@ class SpatialEvaluator:
 class HaloPlan:
     """What one rank needs for a step of ``HaloExchangeEvaluator``: its local system and, per peer, the local rows it sends
     (owned atoms that are ghosts over there) and the local rows it receives into (its ghosts owned over there), both in the order
-    of the receiver's ghost list."""
+    of the receiver's ghost list.  ``order``: the axes of the local system (slab axis first); ``cell_grid``: the grid of the
+    engine's neighbour search that puts the owned atoms into one contiguous range of its cell order, or None."""
 
-    def __init__(self, gidx, pos_l, box_l, n_own, send, recv):
+    def __init__(self, gidx, pos_l, box_l, n_own, send, recv, order=(0, 1, 2), cell_grid=None):
         self.gidx, self.pos_l, self.box_l, self.n_own, self.send, self.recv = gidx, pos_l, box_l, n_own, send, recv
+        self.order, self.cell_grid = tuple(order), cell_grid
 
     @property
     def n_ghost(self) -> int:
@@ -307,33 +309,49 @@ class HaloExchangeEvaluator:
     all-reduce.  ``evaluate`` still all-reduces a [3 N + 1] vector so that every rank ends with the whole answer, like
     ``SpatialEvaluator.evaluate``; an MD driver that keeps the atoms distributed uses ``step`` and skips it.
 
-    ``compute(z_l, pos_l, box_l, w_l, exchange) -> (E [1], F_l [n_l, 3])`` is injected (the engine:
-    ``model.energy_and_forces(..., atom_weights=w_l, halo_exchange=exchange)``); ``transport(rank, world, send, recv_counts)``
+    ``compute(z_l, pos_l, box_l, w_l, exchange, cell_grid) -> (E [1], F_l [n_l, 3])`` is injected (the engine:
+    ``model.energy_and_forces(..., atom_weights=w_l, halo_exchange=exchange, cell_grid=cell_grid)``); ``transport(rank, world, send, recv_counts)``
     moves the rows (``distributed_transport``; the tests also run the ranks as threads of one process with a mailbox)."""
 
     def __init__(self, compute: Callable, cutoff_upper: float, group: Optional[dist.ProcessGroup] = None,
                  axis: Optional[int] = None, energy_offset: float = 0.0, transport: Optional[Callable] = None):
         self.compute, self.group = compute, group
         self.energy_offset = float(energy_offset)
-        self._slabs = SpatialEvaluator(None, cutoff_upper, 0, group, axis)  # halo = one cutoff
+        self.cutoff = float(cutoff_upper)
+        self._slabs = SpatialEvaluator(None, cutoff_upper, 0, group, axis)
         self.transport = transport if transport is not None else distributed_transport(group)
         self.rows_moved = 0  # floats received by this rank in the last step (for the probes)
 
     def plan(self, pos: torch.Tensor, box: torch.Tensor, rank: int, world: int) -> HaloPlan:
         """Computed by every rank from the replicated positions: no negotiation.  The ghost list of rank r is what
-        ``SpatialEvaluator.local_system`` returns for a halo of one cutoff; its owner-side mirror is the same list seen from the
-        owner."""
+        ``SpatialEvaluator.local_system`` returns for a halo of one cell; its owner-side mirror is the same list seen from the
+        owner.
+
+        The slabs are aligned with the engine's cell grid: a slab of width w holds n_w = floor(w / cutoff) cells of width
+        c = w / n_w >= cutoff along the slab axis, the halo is ONE such cell on either side, and the local system's axes are
+        permuted so that the slab axis comes first - the major key of the engine's cell order.  Coordinates stay absolute (so
+        the distances round as in the whole system), the local box is n_x cells long with at least a cutoff of empty cells between
+        the upper halo and the periodic image of the lower one.  In cell order the local atoms are then [lower ghosts][owned]
+        [upper ghosts]: the engine finds the owned atoms in one contiguous range and runs its per-atom kernels on that range only
+        (tmdnet_get_info "halo_active_rows"); any other arrangement is still exact, with the ghosts' rows computed in vain."""
         sl = self._slabs
+        rc = self.cutoff
         if world == 1:
             gidx, pos_l, box_l, n_own = sl.local_system(pos, box, 0, 1)
             return HaloPlan(gidx, pos_l, box_l, n_own, [gidx[:0]], [gidx[:0]])
+        if box.dim() != 2 or bool((box - torch.diag(torch.diagonal(box))).abs().max() > 0):
+            raise ValueError("HaloExchangeEvaluator: one orthorhombic box [3, 3] (diagonal) for the whole system")
         lengths = torch.diagonal(box)
         a = int(torch.argmax(lengths)) if sl.axis is None else int(sl.axis)
         La = float(lengths[a])
-        if sl.halo > La - La / world:
-            raise ValueError(f"cutoff {sl.halo:g} exceeds the box length {La:g} minus one slab: an atom would be its own ghost")
+        w = La / world
+        n_w = int(w // rc)
+        cw = w / n_w if n_w >= 1 else rc           # cell width along the slab axis; slabs thinner than a cutoff: no alignment
+        sl = SpatialEvaluator(None, cw, 0, self.group, a)  # halo = one cell >= one cutoff
+        if sl.halo > La - w:
+            raise ValueError(f"halo {sl.halo:g} exceeds the box length {La:g} minus one slab: an atom would be its own ghost")
         x = torch.remainder(pos[:, a], La)
-        slab = torch.clamp(torch.floor(x / (La / world)).long(), max=world - 1)
+        slab = torch.clamp(torch.floor(x / w).long(), max=world - 1)
         local = [sl.local_system(pos, box, r, world) for r in range(world)]
         gidx, pos_l, box_l, n_own = local[rank]
         # row of every owned atom in its owner's local system
@@ -346,7 +364,22 @@ class HaloExchangeEvaluator:
         for p in range(world):
             theirs = local[p][0][local[p][3]:]  # rank p's ghost list, in its order
             send.append(row_at_owner[theirs[slab[theirs] == rank]])
-        return HaloPlan(gidx, pos_l, box_l, n_own, send, recv)
+        order = [a] + [k for k in range(3) if k != a]
+        grid = None
+        if n_w >= 1:
+            # occupied cells along the slab axis, absolute index: rank n_w - 1 (lower halo) .. rank n_w + n_w (upper halo); the lower
+            # halo of rank 0 sits at negative coordinates and wraps to the last cell of the local box
+            n_vac = 1 if cw >= 1.05 * rc else 2
+            k1 = rank * n_w + n_w
+            ncx = k1 + 1 + n_vac + (1 if rank == 0 else 0)
+            ncy, ncz = (max(1, int(float(lengths[k]) // rc)) for k in order[1:])
+            if ncx * ncy * ncz <= 4 * int(gidx.numel()):
+                grid = (ncx, ncy, ncz)
+                box_l = box_l.clone()
+                box_l[a, a] = ncx * cw
+        pos_l = pos_l[:, order].contiguous()
+        box_l = torch.diag(torch.diagonal(box_l)[order]).contiguous()
+        return HaloPlan(gidx, pos_l, box_l, n_own, send, recv, order, grid)
 
     def exchange_fn(self, plan: HaloPlan, rank: int, world: int) -> Callable:
         send_all = torch.cat(plan.send)
@@ -371,8 +404,10 @@ class HaloExchangeEvaluator:
         plan = self.plan(pos, box, rank, world)
         w_l = torch.zeros(plan.gidx.numel(), dtype=torch.float32, device=pos.device)
         w_l[:plan.n_own] = 1.0
-        e, f_l = self.compute(z[plan.gidx], plan.pos_l, plan.box_l, w_l, self.exchange_fn(plan, rank, world) if world > 1 else None)
-        return plan, e.reshape(1).to(torch.float32) - self.energy_offset, f_l.to(torch.float32)
+        e, f_l = self.compute(z[plan.gidx], plan.pos_l, plan.box_l, w_l, self.exchange_fn(plan, rank, world) if world > 1 else None,
+                              plan.cell_grid)
+        back = [plan.order.index(k) for k in range(3)]  # the local system's axes back to the caller's
+        return plan, e.reshape(1).to(torch.float32) - self.energy_offset, f_l.to(torch.float32)[:, back]
 
     def evaluate(self, z, pos, box) -> Tuple[torch.Tensor, torch.Tensor]:
         """Every rank calls with the full (replicated) system; returns (E [1], F [N, 3]) of the whole system on every rank."""
