@@ -1161,6 +1161,8 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   if (box_mode != 0 && !box) return fail(m, TMDNET_ERR_INVALID, "box_mode != 0 needs a box");
   const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
   set_cell(g, m, cell, n_mol);
+  // halo exchange set before the graph is built (tmdnet_set_halo_exchange + tmdnet_set_atom_weights): ghost-ghost pairs are left out
+  if (cell && m->halo_fn && m->atom_w && !m->et && !m->tn2) g.ghost_w = m->atom_w;
   m->graph_is_cell = cell;
   m->graph_cell_multi = cell && n_mol > 1;
   m->graph_has_z = z != nullptr;

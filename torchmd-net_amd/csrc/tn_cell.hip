@@ -183,6 +183,10 @@ __global__ __launch_bounds__(256) void k_nbr_cell(Graph g, int N, float lo2, flo
   const int ncx = g.cgrid[0], ncy = g.cgrid[1], ncz = g.cgrid[2];
   const int ci = g.cell_key_sorted[i];
   const int bi = bat ? bat[i] : 0;
+  // halo exchange: nothing of a ghost's own neighbourhood is used (its rows come from its owner), so a ghost keeps its pairs with
+  // owned atoms only
+  const float* __restrict__ gw = g.ghost_w;
+  const bool ghost_i = gw && gw[g.perm[i]] == 0.f;
   const int cz = ci % ncz, cy = (ci / ncz) % ncy, cx = ci / (ncz * ncy);
   // lanes 0..26 -> neighbour cell id (periodic wrap); others -> +inf; 32-lane bitonic sort ascending
   int nid = 0x7fffffff;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void k_nbr_cell(Graph g, int N, float lo2, flo
         if (j == i) {
           hit = loop != 0;
           self = true;
-        } else if (!bat || bat[j] == bi) {
+        } else if ((!bat || bat[j] == bi) && !(ghost_i && gw[g.perm[j]] == 0.f)) {
           d2 = (j < i) ? cell_d2(pos, i, j, box, dx, dy, dz) : cell_d2(pos, j, i, box, dx, dy, dz);
           hit = d2 < up2 && d2 >= lo2;
         }

@@ -42,6 +42,7 @@ struct Graph {  // device pointers into the graph workspace
   size_t sort_tmp_bytes;
   int ncx, ncy, ncz;     // explicit grid (tmdnet_set_cell_grid); 0 = from the box
   int use_cell;          // 0: brute force, 1: cell list / one molecule, 2: cell list / several molecules
+  const float* ghost_w;  // halo exchange (cell list): the caller's atom weights; pairs of two weight-0 atoms (ghosts) are left out
   int max_z;
   int small_mols;        // host hint: on average <= 96 atoms per molecule, i.e. the column window of a 64-row tile fits LDS
 };

@@ -1056,33 +1056,8 @@ class TorchMD_Net(nn.Module):
             if cell_grid is not None and auto:
                 grid = tuple(int(v) for v in cell_grid)
             L.tmdnet_set_cell_grid(st.handle, *grid)
-            nbytes = C.c_size_t(0)
-            L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
-            counts = (C.c_int64 * 8)()
-            static = bool(getattr(self.representation_model, "static_shapes", False))
-            st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
-            if static:
-                # static shapes (reference tensornet.py:277-290): no read-back, no synchronisation -> the whole call
-                # can be captured in a HIP graph; launch grids / workspaces are sized by max_num_neighbors * N
-                rc = L.tmdnet_build_graph_static(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32),
-                                                 _ptr(batch), _ptr(z), _ptr(box), box_mode)
-                n_pairs, n_edges = -1, -1
-            else:
-                rc = L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32),
-                                          _ptr(batch), _ptr(z), _ptr(box), box_mode, counts)
-                n_pairs, n_edges = int(counts[0]), int(counts[1])
-                st.counts = (n_pairs, n_edges, int(counts[3]))
-                self._raise_bad_indices(counts, L.tmdnet_last_error(st.handle).decode())
-            if rc == _C.ERR_OVERFLOW:
-                # same exception type and message as the reference (models/utils.py:297-300)
-                raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
-            if rc != _C.OK:
-                raise RuntimeError(f"tmdnet_build_graph: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
-            L.tmdnet_forward_workspace_bytes(st.handle, n, n_mol, n_pairs, n_edges, int(want_forces), C.byref(nbytes))
-            st.fwd_ws = self._grow(st.fwd_ws, nbytes.value, dev)
-            energy = torch.empty(n_mol, dtype=torch.float32, device=dev)
-            forces = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_forces else None
-            st.ws_epoch = getattr(st, "ws_epoch", 0) + 1  # the workspaces of a pending parameter-gradient pass are gone
+            # the atom weights and the exchange are set BEFORE the graph is built: with both, the cell list leaves out the pairs of two
+            # ghosts (tmdnet_build_graph)
             if atom_weights is not None:
                 atom_weights = atom_weights.detach().to(device=dev, dtype=torch.float32).contiguous()
                 if atom_weights.numel() != n:
@@ -1095,10 +1070,10 @@ class TorchMD_Net(nn.Module):
                 st.captured_atom_weights = getattr(st, "captured_atom_weights", []) + [atom_weights]
             halo_state = {}
             if halo_exchange is not None:
-                ws_t, g_t = st.fwd_ws, st.graph_ws
 
                 def _halo(_user, stage, rows_ptr, n_rows, row_floats, perm_ptr, _stream):
                     try:  # an exception must not unwind through the C frames: kept, re-raised after the call
+                        ws_t, g_t = st.fwd_ws, st.graph_ws  # grown after the graph is built
                         o = int(rows_ptr) - ws_t.data_ptr()
                         rows = ws_t[o:o + 4 * n_rows * row_floats].view(torch.float32).view(n_rows, row_floats)
                         if perm_ptr and "inv" not in halo_state:
@@ -1116,13 +1091,40 @@ class TorchMD_Net(nn.Module):
                 halo_state["cb"] = _C.HALO_EXCHANGE_FN(_halo)
                 L.tmdnet_set_halo_exchange(st.handle, halo_state["cb"], None)
             try:
+                nbytes = C.c_size_t(0)
+                L.tmdnet_graph_workspace_bytes(st.handle, n, n_mol, C.byref(nbytes))
+                counts = (C.c_int64 * 8)()
+                static = bool(getattr(self.representation_model, "static_shapes", False))
+                st.graph_ws = self._grow(st.graph_ws, nbytes.value, dev)
+                if static:
+                    # static shapes (reference tensornet.py:277-290): no read-back, no synchronisation -> the whole call
+                    # can be captured in a HIP graph; launch grids / workspaces are sized by max_num_neighbors * N
+                    rc = L.tmdnet_build_graph_static(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32),
+                                                     _ptr(batch), _ptr(z), _ptr(box), box_mode)
+                    n_pairs, n_edges = -1, -1
+                else:
+                    rc = L.tmdnet_build_graph(st.handle, stream, _ptr(st.graph_ws), st.graph_ws.numel(), n, n_mol, _ptr(p32),
+                                              _ptr(batch), _ptr(z), _ptr(box), box_mode, counts)
+                    n_pairs, n_edges = int(counts[0]), int(counts[1])
+                    st.counts = (n_pairs, n_edges, int(counts[3]))
+                    self._raise_bad_indices(counts, L.tmdnet_last_error(st.handle).decode())
+                if rc == _C.ERR_OVERFLOW:
+                    # same exception type and message as the reference (models/utils.py:297-300)
+                    raise RuntimeError(L.tmdnet_last_error(st.handle).decode())
+                if rc != _C.OK:
+                    raise RuntimeError(f"tmdnet_build_graph: {L.tmdnet_last_error(st.handle).decode()} (code {rc})")
+                L.tmdnet_forward_workspace_bytes(st.handle, n, n_mol, n_pairs, n_edges, int(want_forces), C.byref(nbytes))
+                st.fwd_ws = self._grow(st.fwd_ws, nbytes.value, dev)
+                energy = torch.empty(n_mol, dtype=torch.float32, device=dev)
+                forces = torch.empty((n, 3), dtype=torch.float32, device=dev) if want_forces else None
+                st.ws_epoch = getattr(st, "ws_epoch", 0) + 1  # the workspaces of a pending parameter-gradient pass are gone
                 rc = L.tmdnet_energy_forces(st.handle, stream, _ptr(st.graph_ws), _ptr(st.fwd_ws), st.fwd_ws.numel(), n, n_mol,
                                             n_pairs, _ptr(z), _ptr(batch), _ptr(q), int(want_forces), _ptr(energy), _ptr(forces))
-            finally:
+            finally:  # also when the graph phase raised: the handle must not keep a callback or weights that are about to be freed
                 if halo_exchange is not None:
                     L.tmdnet_set_halo_exchange(st.handle, _C.HALO_EXCHANGE_FN(), None)
-            if atom_weights is not None:
-                L.tmdnet_set_atom_weights(st.handle, None)
+                if atom_weights is not None:
+                    L.tmdnet_set_atom_weights(st.handle, None)
             if "error" in halo_state:
                 raise halo_state["error"]
             if rc != _C.OK:
