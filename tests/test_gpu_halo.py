@@ -136,7 +136,7 @@ def test_halo_exchange_is_refused_where_it_is_not_implemented(hip_lib):
     assert torch.isfinite(F1).all()
 
 
-def _two_rank_worker(rank, world, port, tmpdir):
+def _two_rank_worker(rank, world, port, tmpdir, n_side):
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -153,7 +153,7 @@ def _two_rank_worker(rank, world, port, tmpdir):
     args = dict(W.C2_ARGS)
     torch.manual_seed(0)
     model = create_model(dict(args)).cuda()
-    z, pos, box = (t.cuda() for t in W.water_box(n_side=15))
+    z, pos, box = (t.cuda() for t in W.water_box(n_side=n_side))
     ev = _evaluator(model, args)
     E, F = ev.evaluate(z, pos, box)
     torch.save({"E": E.cpu(), "F": F.cpu(), "n_local": int(ev.plan(pos, box, rank, world).gidx.numel()), "moved": ev.rows_moved},
@@ -161,22 +161,28 @@ def _two_rank_worker(rank, world, port, tmpdir):
     dist.destroy_process_group()
 
 
-def test_two_processes_exchanging_halos_equal_one(hip_lib, tmp_path):
+@pytest.mark.parametrize("n_side", [15, 32])
+def test_two_processes_exchanging_halos_equal_one(hip_lib, tmp_path, n_side):
     """The protocol end to end: two processes on one GPU, ONE all-to-all per exchange over gloo (rows staged through the host; RCCL
-    refuses two ranks on one device), 10 125-atom periodic water box, C2 model: 5 exchanges of ~2 000 ghost rows per rank."""
+    refuses two ranks on one device), periodic water boxes of 10 125 and 98 304 atoms, C2 model: 5 exchanges of ~2 500 / ~12 000
+    ghost rows per rank.  Energy to 1e-6; forces to 3e-6 of the largest component (measured 1.1e-6 on the 98 304-atom box, which
+    is what renumbering the atoms of the WHOLE system changes, tools/halo_accuracy_probe.py: the local systems keep the true box
+    and the atoms' own coordinates, so only the order of the neighbour sums differs)."""
     import socket
     import torch.multiprocessing as mp
     from torchmdnet_amd import workloads as W
     from torchmdnet_amd.models.model import create_model
 
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), n_side), nprocs=2, join=True)
     torch.manual_seed(0)
     model = create_model(dict(W.C2_ARGS)).cuda()
-    z, pos, box = (t.cuda() for t in W.water_box(n_side=15))
+    z, pos, box = (t.cuda() for t in W.water_box(n_side=n_side))
     Ew, Fw = model.energy_and_forces(z, pos, torch.zeros_like(z), box, None, 1, True)
     outs = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
     assert torch.equal(outs[0]["E"], outs[1]["E"]) and torch.equal(outs[0]["F"], outs[1]["F"])
     assert max(o["n_local"] for o in outs) < 0.8 * z.shape[0] and min(o["moved"] for o in outs) > 0
-    assert abs(float(outs[0]["E"]) - float(Ew)) < 1e-6 * max(1.0, abs(float(Ew)))
-    assert (outs[0]["F"] - Fw.cpu()).abs().max().item() < 1e-5 * max(1.0, Fw.abs().max().item())
+    err_e = abs(float(outs[0]["E"]) - float(Ew)) / max(1.0, abs(float(Ew)))
+    err_f = (outs[0]["F"] - Fw.cpu()).abs().max().item() / max(1.0, Fw.abs().max().item())
+    print(f"halo exchange, 2 processes, {z.shape[0]} atoms: energy {err_e:.2e}, forces {err_f:.2e} (relative)")
+    assert err_e < 1e-6 and err_f < 3e-6

@@ -318,67 +318,66 @@ class HaloExchangeEvaluator:
         self.compute, self.group = compute, group
         self.energy_offset = float(energy_offset)
         self.cutoff = float(cutoff_upper)
-        self._slabs = SpatialEvaluator(None, cutoff_upper, 0, group, axis)
+        self.axis = axis
         self.transport = transport if transport is not None else distributed_transport(group)
         self.rows_moved = 0  # floats received by this rank in the last step (for the probes)
 
     def plan(self, pos: torch.Tensor, box: torch.Tensor, rank: int, world: int) -> HaloPlan:
-        """Computed by every rank from the replicated positions: no negotiation.  The ghost list of rank r is what
-        ``SpatialEvaluator.local_system`` returns for a halo of one cell; its owner-side mirror is the same list seen from the
-        owner.
+        """Computed by every rank from the replicated positions: no negotiation, O(N) work.
+
+        The local system keeps the TRUE box and the atoms' own coordinates: the ghosts are the atoms (not images) within one halo
+        width of the slab along the periodic slab axis, each once, and the engine's minimum-image arithmetic is the whole system's -
+        no shifted copies whose coordinates would round differently (a shift by a 99 A box length moves fp32 coordinates by up to
+        4e-6 A, 1e-5 of the forces next to the cut).  Pairs of two ghosts may appear or not (the engine leaves them out): nothing
+        of a ghost's own neighbourhood is used.
 
         The slabs are aligned with the engine's cell grid: a slab of width w holds n_w = floor(w / cutoff) cells of width
         c = w / n_w >= cutoff along the slab axis, the halo is ONE such cell on either side, and the local system's axes are
-        permuted so that the slab axis comes first - the major key of the engine's cell order.  Coordinates stay absolute (so
-        the distances round as in the whole system), the local box is n_x cells long with at least a cutoff of empty cells between
-        the upper halo and the periodic image of the lower one.  In cell order the local atoms are then [lower ghosts][owned]
-        [upper ghosts]: the engine finds the owned atoms in one contiguous range and runs its per-atom kernels on that range only
+        permuted so that the slab axis comes first - the major key of the engine's cell order.  In cell order the owned atoms are
+        then one contiguous range, and the engine runs its per-atom kernels and forward sweeps on that range only
         (tmdnet_get_info "halo_active_rows"); any other arrangement is still exact, with the ghosts' rows computed in vain."""
-        sl = self._slabs
         rc = self.cutoff
+        n = pos.shape[0]
         if world == 1:
-            gidx, pos_l, box_l, n_own = sl.local_system(pos, box, 0, 1)
-            return HaloPlan(gidx, pos_l, box_l, n_own, [gidx[:0]], [gidx[:0]])
+            return HaloPlan(torch.arange(n, device=pos.device), pos, box, n, [pos.new_zeros(0, dtype=torch.long)],
+                            [pos.new_zeros(0, dtype=torch.long)])
         if box.dim() != 2 or bool((box - torch.diag(torch.diagonal(box))).abs().max() > 0):
             raise ValueError("HaloExchangeEvaluator: one orthorhombic box [3, 3] (diagonal) for the whole system")
         lengths = torch.diagonal(box)
-        a = int(torch.argmax(lengths)) if sl.axis is None else int(sl.axis)
+        a = int(torch.argmax(lengths)) if self.axis is None else int(self.axis)
         La = float(lengths[a])
         w = La / world
         n_w = int(w // rc)
-        cw = w / n_w if n_w >= 1 else rc           # cell width along the slab axis; slabs thinner than a cutoff: no alignment
-        sl = SpatialEvaluator(None, cw, 0, self.group, a)  # halo = one cell >= one cutoff
-        if sl.halo > La - w:
-            raise ValueError(f"halo {sl.halo:g} exceeds the box length {La:g} minus one slab: an atom would be its own ghost")
+        h = w / n_w if n_w >= 1 else rc            # halo = one cell >= one cutoff; slabs thinner than a cutoff: no alignment
+        if 2 * h > La - w:
+            raise ValueError(f"two halos of {h:g} do not fit beside a slab of {w:g} in the box length {La:g}: an atom would be its "
+                             "own ghost, or a ghost on both sides")
         x = torch.remainder(pos[:, a], La)
-        slab = torch.clamp(torch.floor(x / w).long(), max=world - 1)
-        local = [sl.local_system(pos, box, r, world) for r in range(world)]
-        gidx, pos_l, box_l, n_own = local[rank]
-        # row of every owned atom in its owner's local system
-        row_at_owner = torch.empty(pos.shape[0], dtype=torch.long, device=pos.device)
-        for r in range(world):
-            row_at_owner[local[r][0][:local[r][3]]] = torch.arange(local[r][3], device=pos.device)
-        ghosts = gidx[n_own:]
+        slab = torch.clamp(torch.floor(x / w).long(), max=world - 1)  # x == La rounds into the last slab
+
+        def halo_of(p: int, xs: torch.Tensor, slabs: torch.Tensor):
+            """Atoms (of `xs`) within h below the lower face or above the upper face of slab p, not in it."""
+            dlo = torch.remainder(p * w - xs, La)            # distance below the slab's lower face (periodic)
+            dhi = torch.remainder(xs - (p * w + w), La)      # distance above its upper face
+            return (slabs != p) & (((dlo > 0) & (dlo <= h)) | (dhi < h))
+
+        own = torch.nonzero(slab == rank).flatten()
+        ghosts = torch.nonzero(halo_of(rank, x, slab)).flatten()  # ascending atom index, every atom once
+        gidx = torch.cat([own, ghosts])
+        n_own = int(own.numel())
         recv = [n_own + torch.nonzero(slab[ghosts] == p).flatten() for p in range(world)]
-        send = []
-        for p in range(world):
-            theirs = local[p][0][local[p][3]:]  # rank p's ghost list, in its order
-            send.append(row_at_owner[theirs[slab[theirs] == rank]])
+        # what the others hold of mine, in THEIR ghost order (ascending atom index = ascending row of mine)
+        x_own, s_own = x[own], slab[own]
+        rows = torch.arange(n_own, device=pos.device)
+        send = [rows[:0] if p == rank else rows[halo_of(p, x_own, s_own)] for p in range(world)]
         order = [a] + [k for k in range(3) if k != a]
         grid = None
         if n_w >= 1:
-            # occupied cells along the slab axis, absolute index: rank n_w - 1 (lower halo) .. rank n_w + n_w (upper halo); the lower
-            # halo of rank 0 sits at negative coordinates and wraps to the last cell of the local box
-            n_vac = 1 if cw >= 1.05 * rc else 2
-            k1 = rank * n_w + n_w
-            ncx = k1 + 1 + n_vac + (1 if rank == 0 else 0)
-            ncy, ncz = (max(1, int(float(lengths[k]) // rc)) for k in order[1:])
-            if ncx * ncy * ncz <= 4 * int(gidx.numel()):
-                grid = (ncx, ncy, ncz)
-                box_l = box_l.clone()
-                box_l[a, a] = ncx * cw
-        pos_l = pos_l[:, order].contiguous()
-        box_l = torch.diag(torch.diagonal(box_l)[order]).contiguous()
+            cells = (n_w * world,) + tuple(max(1, int(float(lengths[k]) // rc)) for k in order[1:])
+            if cells[0] * cells[1] * cells[2] <= 4 * int(gidx.numel()):
+                grid = cells
+        pos_l = pos[gidx][:, order].contiguous()
+        box_l = torch.diag(lengths[order]).to(box.dtype).contiguous()
         return HaloPlan(gidx, pos_l, box_l, n_own, send, recv, order, grid)
 
     def exchange_fn(self, plan: HaloPlan, rank: int, world: int) -> Callable:
