@@ -196,7 +196,11 @@ int tmdnet_set_atom_weights(tmdnet_model* m, const float* weights_dev);
  * ghost rows with their owners' rows, ordered on `stream`.  Row r of `rows` belongs to the caller's atom perm[r] (perm == NULL:
  * to atom r; a device vector, valid during the call).  A non-zero return aborts the step with TMDNET_ERR_STATE.  The forces come
  * back for every local atom; those of the owned atoms are complete (no reduction over ranks), those of the ghosts are not.
- * fn == NULL switches the exchange off.  Not capturable: the callback runs at enqueue time. */
+ * fn == NULL switches the exchange off.  Not capturable: the callback runs at enqueue time.
+ * Set together with the atom weights BEFORE tmdnet_build_graph, the cell list leaves out pairs of two weight-0 atoms (nothing of a
+ * ghost's own neighbourhood is used).  If the weight-1 atoms are one contiguous range of the engine's cell order (cells are numbered
+ * x-major; a slab along x whose faces are cell faces of tmdnet_set_cell_grid's grid is such a range), the per-atom kernels and the
+ * forward sweeps run on that range only: tmdnet_get_info "halo_active_first" / "halo_active_rows" report it. */
 typedef int (*tmdnet_halo_exchange_fn)(void* user, int32_t stage, float* rows, int64_t n_rows, int64_t row_floats,
                                        const int32_t* perm, void* stream);
 int tmdnet_set_halo_exchange(tmdnet_model* m, tmdnet_halo_exchange_fn fn, void* user);

@@ -204,7 +204,7 @@ void tensor_linear(hipStream_t s, const float* A, const float* const W3[3], floa
 // per-workspace record of the last graph build (tn_model.h GraphRecord)
 void remember_graph(tmdnet_model* m, const void* graph_ws) {
   if (m->graph_rec.size() >= 64 && !m->graph_rec.count(graph_ws)) m->graph_rec.clear();  // workspaces regrown many times: old addresses are dead
-  m->graph_rec[graph_ws] = tmdnet_model::GraphRecord{m->graph_is_cell, m->graph_cell_multi, m->graph_has_z, m->last_nt, m->lastE};
+  m->graph_rec[graph_ws] = tmdnet_model::GraphRecord{m->graph_is_cell, m->graph_cell_multi, m->graph_has_z, m->last_nt, m->lastE, m->graph_no_ghost_pairs};
 }
 void recall_graph(tmdnet_model* m, const void* graph_ws) {
   auto it = m->graph_rec.find(graph_ws);
@@ -214,6 +214,7 @@ void recall_graph(tmdnet_model* m, const void* graph_ws) {
   m->graph_has_z = it->second.has_z;
   m->last_nt = it->second.nt;
   m->lastE = it->second.lastE;
+  m->graph_no_ghost_pairs = it->second.no_ghost_pairs;
 }
 
 // fused form (tn_tlin9.hip): the weights' fragment-major images must exist (F % 32 == 0); `tensors` = [N, 9, F] tensors the
@@ -1163,6 +1164,7 @@ int tmdnet_build_graph(tmdnet_model* m, void* stream, void* graph_ws, size_t gra
   set_cell(g, m, cell, n_mol);
   // halo exchange set before the graph is built (tmdnet_set_halo_exchange + tmdnet_set_atom_weights): ghost-ghost pairs are left out
   if (cell && m->halo_fn && m->atom_w && !m->et && !m->tn2) g.ghost_w = m->atom_w;
+  m->graph_no_ghost_pairs = g.ghost_w != nullptr;
   m->graph_is_cell = cell;
   m->graph_cell_multi = cell && n_mol > 1;
   m->graph_has_z = z != nullptr;
@@ -1224,6 +1226,7 @@ int tmdnet_build_graph_static(tmdnet_model* m, void* stream, void* graph_ws, siz
   if (box_mode != 0 && !box) return fail(m, TMDNET_ERR_INVALID, "box_mode != 0 needs a box");
   const bool cell = cell_applicable(m, n_atoms, n_mol, box_mode);
   set_cell(g, m, cell, n_mol);
+  m->graph_no_ghost_pairs = false;
   m->graph_is_cell = cell;
   m->graph_cell_multi = cell && n_mol > 1;
   m->graph_has_z = z != nullptr;
@@ -1739,7 +1742,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       if (merged_gd) {
         KR(CAT_MESSAGE, 2 * wB + idxB + 4 * nodeB + 8 * (Pd + 1) * gd_nw,  // w, dw, gMi, Pn, gPn (read + write), g_d slots
            launch_message_adjoint_gd(g, N, F, b.w[l], b.dw[l], b.gMi, b.Pn[l], b.gPn, b.gd_slots + (int64_t)l * gd_nw * gd_stride,
-                                     gd_stride, s, recompute ? &rts[l] : nullptr, a0, rng ? a0 + Na : -1));
+                                     gd_stride, s, recompute ? &rts[l] : nullptr, a0, rng ? a0 + Na : -1, !m->graph_no_ghost_pairs));
       } else {
         KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message_adjoint(g, N, F, b.w[l], b.gMi, b.gPn, s));
         if (!tc) KR(CAT_PAIR, Pd * (12 * Fd + 12) + 2 * nodeB, launch_pair_gd(g, P, F, b.gMi, b.Pn[l], b.dw[l], b.gd, s));

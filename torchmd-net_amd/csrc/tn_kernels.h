@@ -98,7 +98,8 @@ void launch_message_adjoint_pair(const Graph& g, int N, int F, const float* w, c
                                  float* gPn, float* slots, int64_t slot_stride, hipStream_t s);
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt = nullptr, int own0 = 0,
-                               int own1 = -1);  // own1 >= 0: rows outside [own0, own1) are ghosts (their pairs with owned atoms only, no gPn)
+                               int own1 = -1, bool narrow = true);  // own1 >= 0: rows outside [own0, own1) are ghosts (no gPn; narrow: their pairs
+                                                                    // with owned atoms are searched for in the row - the graph holds ghost-ghost pairs)
 // next = 0: plain; 1: nxt = X_hat of the new X (next layer's k_norm_x); 2: nxt = readout invariants of the new X
 void launch_layer_update(const float* Xh, const float* D, const float* q, const int64_t* batch, int N, int F, float* Xn, int next,
                          float* nxt, hipStream_t s);

@@ -861,7 +861,7 @@ __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict
 template <bool RC>
 __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ dw,
                                      const float* __restrict__ gMi, const float* __restrict__ Pn, float* __restrict__ gPn,
-                                     float* __restrict__ slots, int64_t slot_stride, PairRowTable rt, int own0, int own1) {
+                                     float* __restrict__ slots, int64_t slot_stride, PairRowTable rt, int own0, int own1, int narrow) {
   const int i = xcd_chunk(blockIdx.x, gridDim.x);
   if (g.counts[2]) return;
   const int f = threadIdx.x, lane = f & 63, wave = f >> 6;  // blockDim.x == F (multiple of 64)
@@ -870,7 +870,7 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
   // with owned atoms only - the columns of a row ascend (tn_cell.hip), so those edges are one sub-range of the row; its gPn
   // is not wanted
   const bool ghost = i < own0 || i >= own1;
-  if (ghost) {
+  if (ghost && narrow) {  // (not needed when the graph was built without the pairs of two ghosts)
     int lo = e0, hi = e1;
     while (lo < hi) {  // first edge with col >= own0
       const int mid = (lo + hi) >> 1;
@@ -960,20 +960,20 @@ int message_adjoint_gd_waves(const Graph& g, int N, int F, bool rows_from_table)
   return (!rows_from_table && !split_rows_ok(N, F) && message_adjoint_pair_ok(g, N, F)) ? F / 32 : F / 64;
 }
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
-                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt, int own0, int own1) {
+                               float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt, int own0, int own1, bool narrow) {
   if (N <= 0) return;
   if (own1 < 0) {
     own0 = 0;
     own1 = N;
   }
   if (rt) {
-    hipLaunchKernelGGL((k_message_adjoint_gd<true>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, *rt, own0, own1);
+    hipLaunchKernelGGL((k_message_adjoint_gd<true>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, *rt, own0, own1, narrow ? 1 : 0);
     return;
   }
   if ((own0 != 0 || own1 != N) && !split_rows_ok(N, F) && !message_adjoint_pair_ok(g, N, F)) {  // an owned range: the row kernel
                                                                                                    // (the others treat every row alike)
     hipLaunchKernelGGL((k_message_adjoint_gd<false>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride,
-                       PairRowTable{}, own0, own1);
+                       PairRowTable{}, own0, own1, narrow ? 1 : 0);
     return;
   }
   if (split_rows_ok(N, F)) {
@@ -984,7 +984,7 @@ void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, con
   // batches of small molecules: the tile kernel (tn_message_pair.hip: gMi window and adjacency slice in LDS, balanced rows)
   if (message_adjoint_pair_ok(g, N, F)) return launch_message_adjoint_pair(g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride, s);
   hipLaunchKernelGGL((k_message_adjoint_gd<false>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride,
-                     PairRowTable{}, 0, N);
+                     PairRowTable{}, 0, N, 0);
 }
 
 // Value + tangent of a neighbour sum in ONE sweep (second-order pass, tn_hvp_api.hip):

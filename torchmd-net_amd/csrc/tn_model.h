@@ -158,6 +158,7 @@ struct tmdnet_model {
   int (*halo_fn)(void*, int32_t, float*, int64_t, int64_t, const int32_t*, void*) = nullptr;
   void* halo_user = nullptr;
   int* halo_rng = nullptr;          // device scratch: first / last / count of the owned rows in the engine's order
+  bool graph_no_ghost_pairs = false;  // the last graph was built with the exchange set: no pairs of two ghosts in it
   int halo_active[2] = {0, 0};      // [first row, rows] the per-atom kernels of the last step ran on ("halo_active_rows")
   tmdnet_hparams hp;
   TrainCtx* train = nullptr;  // non-null while tmdnet_energy_param_grads drives tmdnet_energy_forces
@@ -182,7 +183,7 @@ struct tmdnet_model {
   bool graph_has_z = false;   // last build validated z into Graph::z_c (internal order)
   // what each graph workspace was last built as (host side, keyed by its address): a call that takes a workspace restores the four
   // fields above / last_nt from its record, so builds on several workspaces may be interleaved with their evaluations
-  struct GraphRecord { bool is_cell, cell_multi, has_z; int nt; int64_t lastE; };
+  struct GraphRecord { bool is_cell, cell_multi, has_z; int nt; int64_t lastE; bool no_ghost_pairs; };
   std::unordered_map<const void*, GraphRecord> graph_rec;
   std::vector<ParamSpec> specs;
   std::map<std::string, std::vector<float>> host;
