@@ -16,14 +16,14 @@ class Mailbox:
     def __init__(self, world):
         self.barrier, self.slots = threading.Barrier(world), {}
 
-    def transport(self, rank, world, send, recv_counts):
-        for p in range(world):
-            self.slots[(rank, p)] = send[p]
+    def transport(self, rank, world, send, send_counts, recv_counts):
+        for p, rows in enumerate(torch.split(send, send_counts)):
+            self.slots[(rank, p)] = rows
         self.barrier.wait()
         got = [self.slots[(p, rank)] for p in range(world)]
         assert [int(t.shape[0]) for t in got] == list(recv_counts)
         self.barrier.wait()
-        return got
+        return torch.cat(got)
 
 
 def _evaluator(model, args, transport=None, group=None):

@@ -335,11 +335,11 @@ class _Mailbox:
         import threading
         self.barrier, self.slots = threading.Barrier(world), {}
 
-    def transport(self, rank, world, send, recv_counts):
-        for p in range(world):
-            self.slots[(rank, p)] = send[p].clone()
+    def transport(self, rank, world, send, send_counts, recv_counts):
+        for p, rows in enumerate(torch.split(send, send_counts)):
+            self.slots[(rank, p)] = rows.clone()
         self.barrier.wait()
-        got = [self.slots[(p, rank)] for p in range(world)]
+        got = torch.cat([self.slots[(p, rank)] for p in range(world)])
         self.barrier.wait()
         return got
 

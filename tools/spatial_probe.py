@@ -47,9 +47,9 @@ def main():
             rec["ranks"][world] = {"local_atoms_max": max(p[0] for p in per), "step_ms_max": max(p[1] for p in per),
                                    "speedup_vs_one_gpu": whole / max(p[1] for p in per)}
             # per-layer halo exchange: one cutoff of ghosts, loop-back rows
-            def loopback(rank, world_, send, recv_counts):
-                rows = torch.cat(send)
-                return [rows[torch.arange(c, device=rows.device) % max(int(rows.shape[0]), 1)] for c in recv_counts]
+            def loopback(rank, world_, send, send_counts, recv_counts):  # as many rows back as a peer would send
+                n = sum(recv_counts)
+                return send[:n] if n <= send.shape[0] else send[torch.arange(n, device=send.device) % max(int(send.shape[0]), 1)]
 
             hx = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex, grid: model.energy_and_forces(zl, pl, torch.zeros_like(zl), bl, None, 1,
                                                                                                 True, atom_weights=wl, halo_exchange=ex,

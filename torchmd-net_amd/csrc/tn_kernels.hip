@@ -858,18 +858,22 @@ __global__ void k_message_adjoint(Graph g, int N, int F, const float* __restrict
 // and g_d[p] = h(i <- j) + h(j <- i) (tn_pairgrad.hip); gMi[j] is loaded for the adjoint anyway and Pn[i] is the row's own,
 // so the separate per-pair kernel (a 4-row gather per pair) disappears.  The per-edge channel sum of a wave goes to its
 // own slot (wave, pair, direction): one writer per slot, summed in fixed order by k_geom_gd -> deterministic.
-template <bool RC>
+// TWO (halo exchange, the graph holds no pairs of two ghosts): the grid covers the owned rows [own0, own1) only, and an owned row
+// also writes the GHOST's half of every pair it has with a ghost j, h(j <- i) = sum dw[p] * gMi[i] * Pn[j] - the pair's rows are in
+// registers anyway; it costs the gather of Pn[j] and saves the ghost's whole row (its own gather of gMi[i], a second read of the
+// pair's rows, a block per ghost).
+template <bool RC, bool TWO = false>
 __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restrict__ w, const float* __restrict__ dw,
                                      const float* __restrict__ gMi, const float* __restrict__ Pn, float* __restrict__ gPn,
                                      float* __restrict__ slots, int64_t slot_stride, PairRowTable rt, int own0, int own1, int narrow) {
-  const int i = xcd_chunk(blockIdx.x, gridDim.x);
+  const int i = (TWO ? own0 : 0) + xcd_chunk(blockIdx.x, gridDim.x);
   if (g.counts[2]) return;
   const int f = threadIdx.x, lane = f & 63, wave = f >> 6;  // blockDim.x == F (multiple of 64)
   int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   // halo exchange, owned rows [own0, own1): a ghost's row is here for its half of the distance gradient of the pairs it has
   // with owned atoms only - the columns of a row ascend (tn_cell.hip), so those edges are one sub-range of the row; its gPn
   // is not wanted
-  const bool ghost = i < own0 || i >= own1;
+  const bool ghost = !TWO && (i < own0 || i >= own1);
   if (ghost && narrow) {  // (not needed when the graph was built without the pairs of two ghosts)
     int lo = e0, hi = e1;
     while (lo < hi) {  // first edge with col >= own0
@@ -887,6 +891,8 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
   const int F3 = 3 * F, F9 = 9 * F;
   float y[9], acc[9];
   load9(Pn + (int64_t)i * F9 + f, F, y);
+  float gi[TWO ? 9 : 1];
+  if (TWO) load9(gMi + (int64_t)i * F9 + f, F, gi);
 #pragma unroll
   for (int c = 0; c < 9; ++c) acc[c] = 0.f;
   // the per-edge channel sums h are reduced FOUR edges at a time (wave_sum4: seven exchanges for four wave sums instead
@@ -926,6 +932,14 @@ __global__ void k_message_adjoint_gd(Graph g, int N, int F, const float* __restr
     const float tS = __fmaf_rn(s9[8], y[8], __fmaf_rn(s9[7], y[7], __fmaf_rn(s9[6], y[6], __fmaf_rn(s9[5], y[5], __fmul_rn(s9[4], y[4])))));
     h = __fmaf_rn(d2, tS, __fmaf_rn(d1, tA, __fmul_rn(d0, __fmul_rn(s9[0], y[0]))));
     slot_idx = sg != 0.f ? 2 * p + (sg > 0.f ? 0 : 1) : -1;  // self edge: no slot
+    if (TWO && (j < own0 || j >= own1)) {  // uniform over the block: the ghost's half of this pair
+      float pj[9];
+      load9(Pn + (int64_t)j * F9 + f, F, pj);
+      const float uA = __fmaf_rn(gi[3], pj[3], __fmaf_rn(gi[2], pj[2], __fmul_rn(gi[1], pj[1])));
+      const float uS = __fmaf_rn(gi[8], pj[8], __fmaf_rn(gi[7], pj[7], __fmaf_rn(gi[6], pj[6], __fmaf_rn(gi[5], pj[5], __fmul_rn(gi[4], pj[4])))));
+      const float h2 = wave_sum(__fmaf_rn(d2, uS, __fmaf_rn(d1, uA, __fmul_rn(d0, __fmul_rn(gi[0], pj[0])))));
+      if (lane == 0) slots[(int64_t)wave * slot_stride + 2 * p + (sg > 0.f ? 1 : 0)] = h2;
+    }
   };
   int e = e0;
   for (; e + 4 <= e1; e += 4) {
@@ -961,6 +975,7 @@ int message_adjoint_gd_waves(const Graph& g, int N, int F, bool rows_from_table)
 }
 void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, const float* dw, const float* gMi, const float* Pn,
                                float* gPn, float* slots, int64_t slot_stride, hipStream_t s, const PairRowTable* rt, int own0, int own1, bool narrow) {
+  const bool two = !narrow && own1 >= 0 && (own0 != 0 || own1 != N);  // no ghost-ghost pairs in the graph: the owned rows serve both halves
   if (N <= 0) return;
   if (own1 < 0) {
     own0 = 0;
@@ -972,8 +987,12 @@ void launch_message_adjoint_gd(const Graph& g, int N, int F, const float* w, con
   }
   if ((own0 != 0 || own1 != N) && !split_rows_ok(N, F) && !message_adjoint_pair_ok(g, N, F)) {  // an owned range: the row kernel
                                                                                                    // (the others treat every row alike)
-    hipLaunchKernelGGL((k_message_adjoint_gd<false>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride,
-                       PairRowTable{}, own0, own1, narrow ? 1 : 0);
+    if (two)
+      hipLaunchKernelGGL((k_message_adjoint_gd<false, true>), dim3(own1 - own0), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots,
+                         slot_stride, PairRowTable{}, own0, own1, 0);
+    else
+      hipLaunchKernelGGL((k_message_adjoint_gd<false>), dim3(N), dim3(F), 0, s, g, N, F, w, dw, gMi, Pn, gPn, slots, slot_stride,
+                         PairRowTable{}, own0, own1, narrow ? 1 : 0);
     return;
   }
   if (split_rows_ok(N, F)) {

@@ -276,18 +276,15 @@ class HaloPlan:
 
 def distributed_transport(group: Optional[dist.ProcessGroup] = None):
     """Rows between the ranks by ONE all-to-all per exchange (RCCL over xGMI; under gloo - the tests, two processes on one GPU -
-    the device rows are staged through the host)."""
+    the device rows are staged through the host).  ``transport(rank, world, send, send_counts, recv_counts) -> recv``: ``send``
+    [sum(send_counts), width] holds the rows for peer 0, then peer 1, ...; ``recv`` [sum(recv_counts), width] likewise."""
 
-    def transport(rank: int, world: int, send, recv_counts):
-        width = send[0].shape[1]
-        out = torch.cat(send) if world > 1 else send[0]
-        host = out.is_cuda and dist.get_backend(group) == "gloo"
-        src = out.cpu() if host else out.contiguous()
-        dst = torch.empty((sum(recv_counts), width), dtype=src.dtype, device=src.device)
-        dist.all_to_all_single(dst, src, list(recv_counts), [int(t.shape[0]) for t in send], group=group)
-        if host:
-            dst = dst.to(out.device)
-        return list(torch.split(dst, list(recv_counts)))
+    def transport(rank: int, world: int, send: torch.Tensor, send_counts, recv_counts):
+        host = send.is_cuda and dist.get_backend(group) == "gloo"
+        src = send.cpu() if host else send.contiguous()
+        dst = torch.empty((sum(recv_counts), send.shape[1]), dtype=src.dtype, device=src.device)
+        dist.all_to_all_single(dst, src, list(recv_counts), list(send_counts), group=group)
+        return dst.to(send.device) if host else dst
 
     return transport
 
@@ -310,7 +307,7 @@ class HaloExchangeEvaluator:
     ``SpatialEvaluator.evaluate``; an MD driver that keeps the atoms distributed uses ``step`` and skips it.
 
     ``compute(z_l, pos_l, box_l, w_l, exchange, cell_grid) -> (E [1], F_l [n_l, 3])`` is injected (the engine:
-    ``model.energy_and_forces(..., atom_weights=w_l, halo_exchange=exchange, cell_grid=cell_grid)``); ``transport(rank, world, send, recv_counts)``
+    ``model.energy_and_forces(..., atom_weights=w_l, halo_exchange=exchange, cell_grid=cell_grid)``); ``transport(rank, world, send, send_counts, recv_counts)``
     moves the rows (``distributed_transport``; the tests also run the ranks as threads of one process with a mailbox)."""
 
     def __init__(self, compute: Callable, cutoff_upper: float, group: Optional[dist.ProcessGroup] = None,
@@ -392,8 +389,7 @@ class HaloExchangeEvaluator:
                 return
             src = send_all if inv is None else inv[send_all]
             dst = recv_all if inv is None else inv[recv_all]
-            got = self.transport(rank, world, list(torch.split(rows[src], send_counts)), recv_counts)
-            rows[dst] = torch.cat(got)
+            rows[dst] = self.transport(rank, world, rows[src], send_counts, recv_counts)
             self.rows_moved += int(dst.numel()) * int(rows.shape[1])
 
         return exchange
