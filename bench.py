@@ -21,7 +21,8 @@ region, with the class average beside it; `roofline_scatter` = the CSR message s
 `cpu_baseline` = the oracle (a restatement of the reference's PyTorch CPU path) timed on this host; `et_c4` and
 `water10k` = BASELINE configs[3] / configs[4] with their own dominant-kernel rooflines; `tensornet2` = the AceFF-2.0
 architecture at the same batch; `md_single_system` = ns/day of
-a HIP-graph-replayed 64-atom system.
+a HIP-graph-replayed 64-atom system; `one_system_8_slabs` = one rank's step of a 98 304-atom periodic box cut into 8 slabs
+(per-layer halo exchange beside the deep halo, one rank at a time on this GPU).
 """
 import argparse
 import ctypes as C
@@ -363,6 +364,64 @@ def water10k_leg(dev, L, steps=8, warmup=3, dt_fs=1.0):
             "ms_per_step": dt * 1e3, "ns_per_day": 86400.0 / dt * dt_fs * 1e-6, "dt_fs": dt_fs,
             "roofline": with_aux_traffic(roofline_of(rec, cls, label), [AUX_KERNEL_PREFIX.get(label.split("(")[0].split(" ")[0], "k_message_adjoint_gd")]),
             "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
+
+
+def one_system_leg(dev, L, steps=5, warmup=2, n_side=32, world=8):
+    """SURVEY 8(e), one periodic system over ranks (no counterpart in the reference): per-rank step of a 98 304-atom water box cut
+    into 8 slabs, measured on THIS GPU one rank at a time - the deep halo (parallel.SpatialEvaluator, no exchange inside the step)
+    and the per-layer halo exchange (parallel.HaloExchangeEvaluator over tmdnet_set_halo_exchange) with a loop-back transport:
+    the gathers and scatters of the 2 L + 1 exchanges are in the time, the links and the plan (index arithmetic on the replicated
+    positions) are not.  `ms_per_step` is the slowest of the sampled ranks (first, middle, last)."""
+    import torch
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+    from torchmdnet_amd.parallel import HaloExchangeEvaluator, SpatialEvaluator
+
+    torch.manual_seed(0)
+    args = dict(W.C2_ARGS)
+    model = create_model(dict(args)).to(dev)
+    z, pos, box = (t.to(dev) for t in W.water_box(n_side=n_side))
+    batch = torch.zeros_like(z)
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    whole = timed(lambda: model.energy_and_forces(z, pos, batch, box, None, 1, True))
+
+    def loopback(rank, world_, send, send_counts, recv_counts):  # as many rows back as the peers would send
+        n = sum(recv_counts)
+        return send[:n] if n <= send.shape[0] else send[torch.arange(n, device=send.device) % max(int(send.shape[0]), 1)]
+
+    hx = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex, grid: model.energy_and_forces(zl, pl, torch.zeros_like(zl), bl, None, 1, True,
+                                                                                        atom_weights=wl, halo_exchange=ex, cell_grid=grid),
+                               args["cutoff_upper"], transport=loopback)
+    deep = SpatialEvaluator(None, args["cutoff_upper"], args["num_layers"])
+    ranks = sorted({0, world // 2, world - 1})
+    ex_ms, deep_ms, local, owned, active, moved = [], [], [], [], [], []
+    for r in ranks:
+        plan = hx.plan(pos, box, r, world)
+        t_plan = timed(lambda: hx.plan(pos, box, r, world))
+        ex_ms.append(timed(lambda: hx.step(z, pos, box, r, world)) - t_plan)
+        local.append(int(plan.gidx.numel())); owned.append(plan.n_own); moved.append(hx.rows_moved * 4)
+        active.append(int(model.engine_info("halo_active_rows")))
+        gidx, pos_l, box_l, n_own = deep.local_system(pos, box, r, world)
+        zl, bl = z[gidx].contiguous(), torch.zeros_like(gidx)
+        w = torch.zeros(gidx.numel(), device=dev); w[:n_own] = 1
+        deep_ms.append(timed(lambda: model.energy_and_forces(zl, pos_l, bl, box_l, None, 1, True, atom_weights=w)))
+    return {"workload": f"{int(z.shape[0])}-atom periodic water box (TensorNet C2 hyper-parameters, random-init) cut into {world} slabs; one "
+                        f"rank at a time on one GPU, ranks {ranks} sampled; loop-back transport (links and plan not timed)",
+            "atoms": int(z.shape[0]), "ranks": world, "whole_system_one_gpu_ms": whole,
+            "ms_per_step": max(ex_ms), "speedup_vs_one_gpu": whole / max(ex_ms),
+            "local_atoms": max(local), "owned_atoms": max(owned), "rows_of_the_per_atom_kernels": max(active),
+            "received_bytes_per_rank_and_step": max(moved), "plan_ms": t_plan,
+            "deep_halo_ms_per_step": max(deep_ms), "deep_halo_speedup_vs_one_gpu": whole / max(deep_ms)}
 
 
 AUX_KERNEL_PREFIX = {"launch_message_adjoint_gd": "k_message_adjoint_gd", "launch_message": "k_message<", "gemm": "k_gemm_sb1",
@@ -779,7 +838,8 @@ def main():
                 out["md_single_system"] = {"error": repr(exc)}
         if world == 1 and not a.no_aux:
             for key, leg in (("et_c4", et_c4_leg), ("et_c4_bf16", lambda d, l: et_c4_leg(d, l, pair_storage="bf16")),
-                             ("water10k", water10k_leg), ("tensornet2", tn2_leg), ("training_c2", training_leg)):
+                             ("water10k", water10k_leg), ("tensornet2", tn2_leg), ("training_c2", training_leg),
+                             ("one_system_8_slabs", one_system_leg)):
                 try:
                     out[key] = leg(dev, L)
                 except Exception as exc:  # noqa: BLE001

@@ -1285,6 +1285,7 @@ int tmdnet_set_halo_exchange(tmdnet_model* m, tmdnet_halo_exchange_fn fn, void* 
   if (!m) return TMDNET_ERR_INVALID;
   m->halo_fn = fn;
   m->halo_user = fn ? user : nullptr;
+  if (fn && !m->halo_rng) HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->halo_rng), 4 * sizeof(int)));  // not inside the step
   return TMDNET_OK;
 }
 
@@ -1439,8 +1440,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   // but its rows of the tensors a sweep gathers, and those come from the exchange; the sweeps, the pair kernels and the embedding's
   // neighbour sums keep all rows (a ghost's half of a pair's distance gradient is computed at the ghost's row).
   int a0 = 0, Na = N;
-  if (m->halo_fn && m->atom_w && m->graph_is_cell && want_forces && !tc && (int64_t)N > 256 * (int64_t)B) {
-    if (!m->halo_rng) HIP_TRY(m, hipMalloc(reinterpret_cast<void**>(&m->halo_rng), 4 * sizeof(int)));
+  if (m->halo_fn && m->halo_rng && m->atom_w && m->graph_is_cell && want_forces && !tc && (int64_t)N > 256 * (int64_t)B) {
     int h[4] = {0, 0, 0, 0};
     launch_owned_range(m->atom_w, perm, N, m->halo_rng, s);
     HIP_TRY(m, hipMemcpyAsync(h, m->halo_rng, sizeof(h), hipMemcpyDeviceToHost, s));
