@@ -290,13 +290,13 @@ def distributed_transport(group: Optional[dist.ProcessGroup] = None):
 
 
 class HaloExchangeEvaluator:
-    """ONE large periodic system over the ranks with a halo of ONE cutoff and an exchange of ghost rows inside the step (the step
-    after ``SpatialEvaluator``'s deep halo; the reference has no counterpart).
+    """ONE large periodic system over the ranks with a halo of ONE cell (>= one cutoff) and an exchange of ghost rows inside the step
+    (the step after ``SpatialEvaluator``'s deep halo; the reference has no counterpart).
 
     A TensorNet step is per-atom kernels (local to a row) cut by neighbour sweeps that gather the rows of an atom's neighbours
     (reference tensornet.py:757-806: the message sum of every layer; tensornet.py:543-619: the embedding sum, which gathers
-    geometry and species only).  A rank holds its slab's atoms (weight 1 in the energy sum) and the periodic images within one
-    cutoff of the slab as ghosts (weight 0): every neighbour of an owned atom is local.  What the ghosts lack is their own
+    geometry and species only).  A rank holds its slab's atoms (weight 1 in the energy sum) and the atoms within one cell of the
+    slab as ghosts (weight 0), in the true periodic box: every neighbour of an owned atom is local.  What the ghosts lack is their own
     neighbourhood, so their rows are wrong wherever a sweep has been - and are replaced, before each sweep that gathers them, by
     the rows their owners computed: P_l before the message sum of layer l, the adjoint of that sum's output on the way back,
     and the adjoint of the embedding sum before the pair gradients of the embedding; 2 L + 1 exchanges of [n_ghost, 9 F or 10 F]
@@ -307,8 +307,8 @@ class HaloExchangeEvaluator:
     ``SpatialEvaluator.evaluate``; an MD driver that keeps the atoms distributed uses ``step`` and skips it.
 
     ``compute(z_l, pos_l, box_l, w_l, exchange, cell_grid) -> (E [1], F_l [n_l, 3])`` is injected (the engine:
-    ``model.energy_and_forces(..., atom_weights=w_l, halo_exchange=exchange, cell_grid=cell_grid)``); ``transport(rank, world, send, send_counts, recv_counts)``
-    moves the rows (``distributed_transport``; the tests also run the ranks as threads of one process with a mailbox)."""
+    ``model.energy_and_forces(..., atom_weights=w_l, halo_exchange=exchange, cell_grid=cell_grid)``);
+    ``transport(rank, world, send, send_counts, recv_counts) -> recv`` moves the rows (``distributed_transport``; the tests also run the ranks as threads of one process with a mailbox)."""
 
     def __init__(self, compute: Callable, cutoff_upper: float, group: Optional[dist.ProcessGroup] = None,
                  axis: Optional[int] = None, energy_offset: float = 0.0, transport: Optional[Callable] = None):
