@@ -26,17 +26,17 @@ class Mailbox:
         return torch.cat(got)
 
 
-def _evaluator(model, args, transport=None, group=None):
+def _evaluator(model, args, transport=None, group=None, q=None):
     from torchmdnet_amd.parallel import HaloExchangeEvaluator
 
     def compute(zl, pl, boxl, wl, exchange, grid):
-        return model.energy_and_forces(zl, pl, torch.zeros_like(zl), boxl, None, 1, True, atom_weights=wl, halo_exchange=exchange,
+        return model.energy_and_forces(zl, pl, torch.zeros_like(zl), boxl, q, 1, True, atom_weights=wl, halo_exchange=exchange,
                                        cell_grid=grid)
 
     return HaloExchangeEvaluator(compute, args["cutoff_upper"], group=group, energy_offset=float(model.mean), transport=transport)
 
 
-def _threaded(args, seed, z, pos, box, world):
+def _threaded(args, seed, z, pos, box, world, q=None):
     """-> (E [1], F [N, 3], n_local per rank, floats received per rank): every rank a thread with its own engine handle."""
     import copy
     from torchmdnet_amd.models.model import create_model
@@ -45,7 +45,7 @@ def _threaded(args, seed, z, pos, box, world):
     models = [create_model(dict(args)).cuda()]
     models += [copy.deepcopy(models[0]) for _ in range(world - 1)]
     box_ = Mailbox(world)
-    evs = [_evaluator(m, args, transport=box_.transport) for m in models]
+    evs = [_evaluator(m, args, transport=box_.transport, q=q) for m in models]
     out, err = [None] * world, []
 
     def run(r):
@@ -91,7 +91,8 @@ def test_halo_exchange_small_system_vs_whole_and_deep_halo(hip_lib):
         assert (F - Fw).abs().max().item() < 1e-5 * max(1.0, Fw.abs().max().item()), world
 
 
-def test_halo_exchange_c2_water_box_cell_order(hip_lib):
+@pytest.mark.parametrize("charge", [None, 0.7])
+def test_halo_exchange_c2_water_box_cell_order(hip_lib, charge):
     """C2 model (cutoff 5 A, two layers) on a 10 125-atom water box in 2 slabs: ~7 800 local atoms each (deep halo: ~11 600),
     renumbered in cell order inside the engine - the callback's `perm` maps the rows; fused tensor linears and radial tables as in
     the bench.  The slabs are aligned with the cell grid, so the per-atom kernels run on the owned rows only."""
@@ -102,8 +103,9 @@ def test_halo_exchange_c2_water_box_cell_order(hip_lib):
     z, pos, box = (t.cuda() for t in W.water_box(n_side=15))
     torch.manual_seed(0)
     whole = create_model(dict(args)).cuda()
-    Ew, Fw = whole.energy_and_forces(z, pos, torch.zeros_like(z), box, None, 1, True)
-    E, F, n_local, moved, active = _threaded(args, 0, z, pos, box, 2)
+    q = None if charge is None else torch.tensor([charge], device="cuda")  # total charge: a per-atom factor in every layer's update
+    Ew, Fw = whole.energy_and_forces(z, pos, torch.zeros_like(z), box, q, 1, True)
+    E, F, n_local, moved, active = _threaded(args, 0, z, pos, box, 2, q=q)
     assert 1024 < max(n_local) < 9000, n_local
     # the slabs are aligned with the cell grid: the owned atoms are one range of the cell order and the per-atom kernels ran on it only
     assert all(rows == n_own for rows, n_own in active), active
@@ -114,7 +116,8 @@ def test_halo_exchange_c2_water_box_cell_order(hip_lib):
     ev = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex, grid: whole.energy_and_forces(zl, pl, torch.zeros_like(zl), bl, None, 1, True,
                                                                                         atom_weights=wl), args["cutoff_upper"])
     plan, _, f_l = ev.step(z, pos, box, 0, 2)
-    assert (f_l[:plan.n_own] - Fw[plan.gidx[:plan.n_own]]).abs().max().item() > 1e-3 * Fw.abs().max().item()
+    if charge is None:
+        assert (f_l[:plan.n_own] - Fw[plan.gidx[:plan.n_own]]).abs().max().item() > 1e-3 * Fw.abs().max().item()
 
 
 def test_halo_exchange_is_refused_where_it_is_not_implemented(hip_lib):
@@ -165,9 +168,11 @@ def _two_rank_worker(rank, world, port, tmpdir, n_side):
 def test_two_processes_exchanging_halos_equal_one(hip_lib, tmp_path, n_side):
     """The protocol end to end: two processes on one GPU, ONE all-to-all per exchange over gloo (rows staged through the host; RCCL
     refuses two ranks on one device), periodic water boxes of 10 125 and 98 304 atoms, C2 model: 5 exchanges of ~2 500 / ~12 000
-    ghost rows per rank.  Energy to 1e-6; forces to 3e-6 of the largest component (measured 1.1e-6 on the 98 304-atom box, which
-    is what renumbering the atoms of the WHOLE system changes, tools/halo_accuracy_probe.py: the local systems keep the true box
-    and the atoms' own coordinates, so only the order of the neighbour sums differs)."""
+    ghost rows per rank.  Energy to 1e-6; forces: measured 1.1e-6 of the largest component on the 98 304-atom box, which is what
+    renumbering the atoms of the WHOLE system changes (tools/halo_accuracy_probe.py: the local systems keep the true box and the
+    atoms' own coordinates, so only the order of the neighbour sums differs).  The bound is 3e-5 because two processes time-sliced
+    on one GPU are not bit-reproducible even on the undecomposed system (about one evaluation in ten differs by up to 9e-6,
+    tools/gpu_sharing_probe.py); the single-process comparisons above hold 1e-5."""
     import socket
     import torch.multiprocessing as mp
     from torchmdnet_amd import workloads as W
@@ -185,4 +190,4 @@ def test_two_processes_exchanging_halos_equal_one(hip_lib, tmp_path, n_side):
     err_e = abs(float(outs[0]["E"]) - float(Ew)) / max(1.0, abs(float(Ew)))
     err_f = (outs[0]["F"] - Fw.cpu()).abs().max().item() / max(1.0, Fw.abs().max().item())
     print(f"halo exchange, 2 processes, {z.shape[0]} atoms: energy {err_e:.2e}, forces {err_f:.2e} (relative)")
-    assert err_e < 1e-6 and err_f < 3e-6
+    assert err_e < 1e-6 and err_f < 3e-5

@@ -2087,6 +2087,12 @@ int tmdnet_debug_tensor(tmdnet_model* m, void* stream, const char* name, float* 
     if (l < 0 || l >= m->hp.num_layers) return TMDNET_ERR_INVALID;
     src = b.X[l + 1]; n = N * 9 * F;
   }
+  else if (nm.rfind("Pn", 0) == 0 || nm.rfind("Mi", 0) == 0 || (nm.rfind("D", 0) == 0 && nm.size() == 2)) {  // per-layer tensors of the last step
+    const int l = std::atoi(nm.c_str() + (nm[0] == 'D' ? 1 : 2));
+    if (l < 0 || l >= m->hp.num_layers) return TMDNET_ERR_INVALID;
+    src = nm[0] == 'P' ? b.Pn[l] : (nm[0] == 'M' ? b.Mi[l] : b.D[l]);
+    n = N * 9 * F;
+  }
   else if (nm == "x") { src = b.x; n = N * F; }
   else if (nm == "phi") { src = b.phi; n = P1 * K; }
   else if (nm == "Q") { src = b.Q; n = P1 * 3 * F; }
