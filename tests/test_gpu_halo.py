@@ -26,17 +26,17 @@ class Mailbox:
         return torch.cat(got)
 
 
-def _evaluator(model, args, transport=None, group=None, q=None):
+def _evaluator(model, args, transport=None, group=None, q=None, aligned=True):
     from torchmdnet_amd.parallel import HaloExchangeEvaluator
 
     def compute(zl, pl, boxl, wl, exchange, grid):
         return model.energy_and_forces(zl, pl, torch.zeros_like(zl), boxl, q, 1, True, atom_weights=wl, halo_exchange=exchange,
-                                       cell_grid=grid)
+                                       cell_grid=grid if aligned else None)
 
     return HaloExchangeEvaluator(compute, args["cutoff_upper"], group=group, energy_offset=float(model.mean), transport=transport)
 
 
-def _threaded(args, seed, z, pos, box, world, q=None):
+def _threaded(args, seed, z, pos, box, world, q=None, aligned=True):
     """-> (E [1], F [N, 3], n_local per rank, floats received per rank): every rank a thread with its own engine handle."""
     import copy
     from torchmdnet_amd.models.model import create_model
@@ -45,7 +45,7 @@ def _threaded(args, seed, z, pos, box, world, q=None):
     models = [create_model(dict(args)).cuda()]
     models += [copy.deepcopy(models[0]) for _ in range(world - 1)]
     box_ = Mailbox(world)
-    evs = [_evaluator(m, args, transport=box_.transport, q=q) for m in models]
+    evs = [_evaluator(m, args, transport=box_.transport, q=q, aligned=aligned) for m in models]
     out, err = [None] * world, []
 
     def run(r):
@@ -118,6 +118,23 @@ def test_halo_exchange_c2_water_box_cell_order(hip_lib, charge):
     plan, _, f_l = ev.step(z, pos, box, 0, 2)
     if charge is None:
         assert (f_l[:plan.n_own] - Fw[plan.gidx[:plan.n_own]]).abs().max().item() > 1e-3 * Fw.abs().max().item()
+
+
+def test_halo_exchange_without_the_aligned_grid_is_exact_too(hip_lib):
+    """The engine's own cell grid (floor(L / cutoff) cells per axis) does not have the slabs' faces as cell faces: the owned atoms are
+    not one range of the cell order, every kernel takes every local row (the graph still has no ghost-ghost pairs), same result."""
+    from torchmdnet_amd import workloads as W
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.C2_ARGS)
+    z, pos, box = (t.cuda() for t in W.water_box(n_side=15))
+    torch.manual_seed(0)
+    whole = create_model(dict(args)).cuda()
+    Ew, Fw = whole.energy_and_forces(z, pos, torch.zeros_like(z), box, None, 1, True)
+    E, F, n_local, moved, active = _threaded(args, 0, z, pos, box, 2, aligned=False)
+    assert all(rows == n for (rows, _), n in zip(active, n_local)), (active, n_local)  # no owned range: all local rows
+    assert abs(float(E) - float(Ew)) < 1e-5 * max(1.0, abs(float(Ew)))
+    assert (F - Fw).abs().max().item() < 1e-5 * max(1.0, Fw.abs().max().item())
 
 
 def test_halo_exchange_is_refused_where_it_is_not_implemented(hip_lib):

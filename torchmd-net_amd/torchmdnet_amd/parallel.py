@@ -362,11 +362,15 @@ class HaloExchangeEvaluator:
         ghosts = torch.nonzero(halo_of(rank, x, slab)).flatten()  # ascending atom index, every atom once
         gidx = torch.cat([own, ghosts])
         n_own = int(own.numel())
-        recv = [n_own + torch.nonzero(slab[ghosts] == p).flatten() for p in range(world)]
+        # a halo no wider than a slab reaches the two adjacent slabs only
+        peers = {(rank - 1) % world, (rank + 1) % world} - {rank} if h <= w else set(range(world)) - {rank}
+        none = own[:0]
+        g_slab = slab[ghosts]
+        recv = [n_own + torch.nonzero(g_slab == p).flatten() if p in peers else none for p in range(world)]
         # what the others hold of mine, in THEIR ghost order (ascending atom index = ascending row of mine)
         x_own, s_own = x[own], slab[own]
         rows = torch.arange(n_own, device=pos.device)
-        send = [rows[:0] if p == rank else rows[halo_of(p, x_own, s_own)] for p in range(world)]
+        send = [rows[halo_of(p, x_own, s_own)] if p in peers else none for p in range(world)]
         order = [a] + [k for k in range(3) if k != a]
         grid = None
         if n_w >= 1:
