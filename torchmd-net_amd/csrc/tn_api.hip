@@ -1826,6 +1826,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   m->has_last = true;
   return TMDNET_OK;
 }
+#undef HALO_TRY
 
 
 // ------------------------------------------------------------------------------------ parameter gradients (TensorNet + Scalar)
