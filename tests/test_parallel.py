@@ -388,6 +388,10 @@ def test_halo_exchange_plan_and_protocol_ranks_as_threads():
     ev = HaloExchangeEvaluator(lambda zl, pl, bl, wl, ex, grid: _toy_step(zl, pl, bl, wl, rc, None), rc)
     plan, _, f_l = ev.step(z, pos, box, 0, 2)
     assert (f_l[:plan.n_own] - Fw[plan.gidx[:plan.n_own]]).abs().max().item() > 1e-2 * Fw.abs().max().item()
+    squeezed = pos.clone()
+    squeezed[:, 2] = squeezed[:, 2] * 0.3  # all atoms in the lowest third of the slab axis: the upper slabs are vacuum
+    with pytest.raises(ValueError, match="without atoms"):
+        HaloExchangeEvaluator(None, rc).plan(squeezed, box, 0, 3)
     with pytest.raises(ValueError, match="own ghost"):
         HaloExchangeEvaluator(None, 11.0).plan(pos, box, 0, 2)  # a halo of 11 A on either side of a 10.5 A slab in 21 A
 

@@ -351,6 +351,9 @@ class HaloExchangeEvaluator:
                              "own ghost, or a ghost on both sides")
         x = torch.remainder(pos[:, a], La)
         slab = torch.clamp(torch.floor(x / w).long(), max=world - 1)  # x == La rounds into the last slab
+        if int(torch.bincount(slab, minlength=world).min()) == 0:
+            # every rank sees it (replicated positions) and raises: a rank without a step would leave its peers waiting in the exchanges
+            raise ValueError("HaloExchangeEvaluator: a slab without atoms (vacuum along the slab axis); choose another axis or fewer ranks")
 
         def halo_of(p: int, xs: torch.Tensor, slabs: torch.Tensor):
             """Atoms (of `xs`) within h below the lower face or above the upper face of slab p, not in it."""
