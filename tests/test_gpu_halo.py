@@ -174,7 +174,8 @@ def _two_rank_worker(rank, world, port, tmpdir, n_side):
     torch.manual_seed(0)
     model = create_model(dict(args)).cuda()
     z, pos, box = (t.cuda() for t in W.water_box(n_side=n_side))
-    ev = _evaluator(model, args)
+    from torchmdnet_amd.parallel import HaloExchangeEvaluator
+    ev = HaloExchangeEvaluator.for_model(model)  # cutoff, energy offset and the engine call from the model; transport: torch.distributed
     E, F = ev.evaluate(z, pos, box)
     torch.save({"E": E.cpu(), "F": F.cpu(), "n_local": int(ev.plan(pos, box, rank, world).gidx.numel()), "moved": ev.rows_moved},
                os.path.join(tmpdir, f"rank{rank}.pt"))

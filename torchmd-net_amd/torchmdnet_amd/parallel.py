@@ -319,6 +319,18 @@ class HaloExchangeEvaluator:
         self.transport = transport if transport is not None else distributed_transport(group)
         self.rows_moved = 0  # floats received by this rank in the last step (for the probes)
 
+    @classmethod
+    def for_model(cls, model, group: Optional[dist.ProcessGroup] = None, axis: Optional[int] = None, transport: Optional[Callable] = None,
+                  q: Optional[torch.Tensor] = None):
+        """The evaluator of a ``torchmdnet_amd`` TensorNet model on its GPU: cutoff and energy offset from the model, the engine call
+        (``energy_and_forces`` with the atom weights, the exchange and the aligned cell grid) as ``compute``."""
+
+        def compute(z_l, pos_l, box_l, w_l, exchange, cell_grid):
+            return model.energy_and_forces(z_l, pos_l, torch.zeros_like(z_l), box_l, q, 1, True, atom_weights=w_l, halo_exchange=exchange,
+                                           cell_grid=cell_grid)
+
+        return cls(compute, float(model.representation_model.cutoff_upper), group, axis, float(model.mean), transport)
+
     def plan(self, pos: torch.Tensor, box: torch.Tensor, rank: int, world: int) -> HaloPlan:
         """Computed by every rank from the replicated positions: no negotiation, O(N) work.
 
