@@ -186,18 +186,19 @@ def pmc_kernel_bytes(pmc, cls, label):
     return None, None
 
 
-def load_pmc_aux():
-    """PMC summary of the auxiliary legs (tools/profile_round.sh: the same two passes over `bench.py --aux-only`)."""
+def load_pmc_aux(name="pmc_traffic_aux.json"):
+    """PMC summary of the auxiliary legs (tools/profile_round.sh: the same two passes over `bench.py --aux-only`; the halo-exchange
+    leg: over tools/halo_profile.py -> pmc_traffic_halo.json)."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_aux.json")))
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return {}
 
 
-def aux_traffic(prefixes):
+def aux_traffic(prefixes, name="pmc_traffic_aux.json"):
     """(bytes per launch, kernel name, summary) of the first kernel of the aux summary whose name starts with one of `prefixes`
     (the heaviest one when several template instances match), or None."""
-    pmc = load_pmc_aux()
+    pmc = load_pmc_aux(name)
     per = pmc.get("_per_kernel_total", {})
     for pre in prefixes:
         pre, suf = pre if isinstance(pre, tuple) else (pre, "")  # (prefix, suffix): e.g. the storage mode is the LAST template argument
@@ -208,13 +209,13 @@ def aux_traffic(prefixes):
     return None
 
 
-def with_aux_traffic(roof, prefixes):
-    hit = aux_traffic(prefixes)
+def with_aux_traffic(roof, prefixes, name="pmc_traffic_aux.json"):
+    hit = aux_traffic(prefixes, name)
     if hit:
         roof["traffic"] = hit[0]
         roof["traffic_ratio"] = hit[0] / max(roof.get("algorithmic_bytes_per_launch", 0.0), 1.0)
         src = traffic_source(hit[2], hit[1])
-        src["file"] = "profiles/pmc_traffic_aux.json"
+        src["file"] = "profiles/" + name
         roof["traffic_source"] = src
     return roof
 
@@ -415,7 +416,16 @@ def one_system_leg(dev, L, steps=5, warmup=2, n_side=32, world=8):
         zl, bl = z[gidx].contiguous(), torch.zeros_like(gidx)
         w = torch.zeros(gidx.numel(), device=dev); w[:n_own] = 1
         deep_ms.append(timed(lambda: model.energy_and_forces(zl, pos_l, bl, box_l, None, 1, True, atom_weights=w)))
-    return {"workload": f"{int(z.shape[0])}-atom periodic water box (TensorNet C2 hyper-parameters, random-init) cut into {world} slabs; one "
+    # roofline of the step's dominant kernel (the reverse sweep on the owned rows), middle rank: HIP events of the library's profiler
+    r = ranks[len(ranks) // 2]
+    profile_begin(model, L)
+    hx.step(z, pos, box, r, world)
+    classes, groups = profile_records(model, L, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    (cls, label), rec = dominant(groups)
+    roof = with_aux_traffic(roofline_of(rec, cls, label, note_kernel="k_message_adjoint_gd<false, true> (owned rows, both halves of owned-ghost pairs)"),
+                            ["k_message_adjoint_gd<false, true>", "k_message_adjoint_gd"], "pmc_traffic_halo.json")
+    return {"roofline": roof, "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]},
+            "workload": f"{int(z.shape[0])}-atom periodic water box (TensorNet C2 hyper-parameters, random-init) cut into {world} slabs; one "
                         f"rank at a time on one GPU, ranks {ranks} sampled; loop-back transport (links and plan not timed)",
             "atoms": int(z.shape[0]), "ranks": world, "whole_system_one_gpu_ms": whole,
             "ms_per_step": max(ex_ms), "speedup_vs_one_gpu": whole / max(ex_ms),

@@ -18,6 +18,12 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p
 python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_rd_aux $R/gpurun_out/pmc_wr_aux $R/gpurun_out/pmc_traffic_aux.json "python bench.py --aux-only --steps 1 --warmup 1"
 find $R/gpurun_out/pmc_rd_aux $R/gpurun_out/pmc_wr_aux -name '*.csv' -size +4M -delete
 find $R/gpurun_out/prof_aux -name '*kernel_trace.csv' -size +8M -delete
+# one rank's step of the halo exchange (98k-atom box, 8 slabs: bench.py leg one_system_8_slabs): kernel stats + the two PMC passes
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_halo -- python $R/tools/halo_profile.py > $R/gpurun_out/prof_halo.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_rd_halo -- python $R/tools/halo_profile.py > $R/gpurun_out/pmc_rd_halo.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_wr_halo -- python $R/tools/halo_profile.py > $R/gpurun_out/pmc_wr_halo.log 2>&1
+python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_rd_halo $R/gpurun_out/pmc_wr_halo $R/gpurun_out/pmc_traffic_halo.json "python tools/halo_profile.py"
+find $R/gpurun_out/pmc_rd_halo $R/gpurun_out/pmc_wr_halo -name '*.csv' -size +4M -delete
 # issue-side counters of the dominant kernels (the request ceiling bench.py prints next to the HBM one): six --pmc passes
 python $R/tools/pmc_issue.py $R/gpurun_out/pmc_issue.json > $R/gpurun_out/pmc_issue.log 2>&1
 # keep only the summaries (counter CSVs of every dispatch are large)

@@ -1595,7 +1595,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         ta.A = b.X[l] + o9F; ta.C = b.Pn[l] + o9F; ta.N = Na; ta.F = F;
         tlin9(s, TL9_PRO_NORM, TL9_EPI_PLAIN, q_.V, ta, 2.0, "norm");
         HALO_TRY(l, b.Pn[l], 9 * F);
-        KR(CAT_MESSAGE, wB + idxB + 3 * nodeB,
+        KR(CAT_MESSAGE, wB + idxB + nodeB * (1.0 + 2.0 * Na / Nd),  // P of every local atom is gathered; Mi, C_hat of the swept rows are written
            launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s, recompute ? &rts[l] : nullptr, a0, rng ? Na : -1));
         // dX = linear(C_hat), then X_new = X_hat + dX + kappa dX.dX (and the readout invariants after the last layer) in the epilogue
         Tl9Args tb{};
@@ -1740,7 +1740,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         NODE();
       }
       if (merged_gd) {
-        KR(CAT_MESSAGE, 2 * wB + idxB + 4 * nodeB + 8 * (Pd + 1) * gd_nw,  // w, dw, gMi, Pn, gPn (read + write), g_d slots
+        KR(CAT_MESSAGE, 2 * wB + idxB + nodeB * (2.0 + 2.0 * Na / Nd) + 8 * (Pd + 1) * gd_nw,  // w, dw, gMi, Pn, gPn (read + write: swept rows), g_d slots
            launch_message_adjoint_gd(g, N, F, b.w[l], b.dw[l], b.gMi, b.Pn[l], b.gPn, b.gd_slots + (int64_t)l * gd_nw * gd_stride,
                                      gd_stride, s, recompute ? &rts[l] : nullptr, a0, rng ? a0 + Na : -1, !m->graph_no_ghost_pairs));
       } else {
