@@ -36,6 +36,6 @@ case "$1" in
   stage) stage ;;
   run) run ;;
   gpurun) stage; trap 'rm -rf "$ROOT/.ref_stage"' EXIT   # the staged copies of reference files leave the tree again
-          /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/run_reference_tests.sh run' ;;
+          /usr/local/graft/bin/gpurun --timeout ${REF_GPURUN_TIMEOUT:-1800} -- 'bash tools/run_reference_tests.sh run' ;;
   *) echo "usage: $0 stage | run | gpurun"; exit 2 ;;
 esac
