@@ -371,8 +371,9 @@ def one_system_leg(dev, L, steps=5, warmup=2, n_side=32, world=8):
     """SURVEY 8(e), one periodic system over ranks (no counterpart in the reference): per-rank step of a 98 304-atom water box cut
     into 8 slabs, measured on THIS GPU one rank at a time - the deep halo (parallel.SpatialEvaluator, no exchange inside the step)
     and the per-layer halo exchange (parallel.HaloExchangeEvaluator over tmdnet_set_halo_exchange) with a loop-back transport:
-    the gathers and scatters of the 2 L + 1 exchanges are in the time, the links and the plan (index arithmetic on the replicated
-    positions) are not.  `ms_per_step` is the slowest of the sampled ranks (first, middle, last)."""
+    `ms_per_step` = engine step with the gathers and scatters of the 2 L + 1 exchanges + the plan (index arithmetic on the replicated
+    positions) + a device-to-device copy of the received rows (a lower bound of the transport), slowest of the sampled ranks (first,
+    middle, last); `ms_per_step_with_link_estimate` prices the rows over two xGMI links instead.  Every speed-up here is a PROJECTION."""
     import torch
     from torchmdnet_amd import workloads as W
     from torchmdnet_amd.models.model import create_model
@@ -405,13 +406,20 @@ def one_system_leg(dev, L, steps=5, warmup=2, n_side=32, world=8):
                                args["cutoff_upper"], transport=loopback)
     deep = SpatialEvaluator(None, args["cutoff_upper"], args["num_layers"])
     ranks = sorted({0, world // 2, world - 1})
-    ex_ms, deep_ms, local, owned, active, moved = [], [], [], [], [], []
+    ex_ms, plan_ms, copy_ms, deep_ms, local, owned, active, moved = [], [], [], [], [], [], [], []
     for r in ranks:
         plan = hx.plan(pos, box, r, world)
         t_plan = timed(lambda: hx.plan(pos, box, r, world))
+        plan_ms.append(t_plan)
         ex_ms.append(timed(lambda: hx.step(z, pos, box, r, world)) - t_plan)
         local.append(int(plan.gidx.numel())); owned.append(plan.n_own); moved.append(hx.rows_moved * 4)
         active.append(int(model.engine_info("halo_active_rows")))
+        # transport term, a LOWER bound measured on this GPU: the rows this rank receives in a step copied device to device once
+        # (what a peer-to-peer xGMI write would at least cost at HBM speed; the links themselves are ~7x slower, see `links_ms_estimate`)
+        rows = torch.empty(max(hx.rows_moved, 1), dtype=torch.float32, device=dev)
+        dst = torch.empty_like(rows)
+        copy_ms.append(timed(lambda: dst.copy_(rows)))
+        del rows, dst
         gidx, pos_l, box_l, n_own = deep.local_system(pos, box, r, world)
         zl, bl = z[gidx].contiguous(), torch.zeros_like(gidx)
         w = torch.zeros(gidx.numel(), device=dev); w[:n_own] = 1
@@ -424,14 +432,24 @@ def one_system_leg(dev, L, steps=5, warmup=2, n_side=32, world=8):
     (cls, label), rec = dominant(groups)
     roof = with_aux_traffic(roofline_of(rec, cls, label, note_kernel="k_message_adjoint_gd<false, true> (owned rows, both halves of owned-ghost pairs)"),
                             ["k_message_adjoint_gd<false, true>", "k_message_adjoint_gd"], "pmc_traffic_halo.json")
+    worst = max(range(len(ranks)), key=lambda k: ex_ms[k] + plan_ms[k] + copy_ms[k])
+    engine, total = ex_ms[worst], ex_ms[worst] + plan_ms[worst] + copy_ms[worst]
+    # two xGMI neighbours per slab, ~153 GB/s per link and direction (MI355X_MICROARCH.md): what the links would add if nothing hid them
+    links_ms = max(moved) / 2 / 153e9 * 1e3
     return {"roofline": roof, "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]},
             "workload": f"{int(z.shape[0])}-atom periodic water box (TensorNet C2 hyper-parameters, random-init) cut into {world} slabs; one "
-                        f"rank at a time on one GPU, ranks {ranks} sampled; loop-back transport (links and plan not timed)",
+                        f"rank at a time on ONE GPU, ranks {ranks} sampled; loop-back transport: a PROJECTION of the multi-GPU step, not a "
+                        "measured one (RCCL transport never run on hardware)",
             "atoms": int(z.shape[0]), "ranks": world, "whole_system_one_gpu_ms": whole,
-            "ms_per_step": max(ex_ms), "speedup_vs_one_gpu": whole / max(ex_ms),
+            "ms_per_step": total, "engine_and_row_moves_ms": engine, "plan_ms": plan_ms[worst],
+            "transport_lower_bound_ms": copy_ms[worst], "links_ms_estimate": links_ms,
+            "ms_per_step_with_link_estimate": engine + plan_ms[worst] + links_ms,
+            "projected_speedup_vs_one_gpu": whole / total,
+            "projected_speedup_vs_one_gpu_with_link_estimate": whole / (engine + plan_ms[worst] + links_ms),
+            "projected_speedup_without_plan_and_links": whole / engine,
             "local_atoms": max(local), "owned_atoms": max(owned), "rows_of_the_per_atom_kernels": max(active),
-            "received_bytes_per_rank_and_step": max(moved), "plan_ms": t_plan,
-            "deep_halo_ms_per_step": max(deep_ms), "deep_halo_speedup_vs_one_gpu": whole / max(deep_ms)}
+            "received_bytes_per_rank_and_step": max(moved),
+            "deep_halo_ms_per_step": max(deep_ms), "deep_halo_projected_speedup_vs_one_gpu": whole / max(deep_ms)}
 
 
 AUX_KERNEL_PREFIX = {"launch_message_adjoint_gd": "k_message_adjoint_gd", "launch_message": "k_message<", "gemm": "k_gemm_sb1",
@@ -579,6 +597,46 @@ def cpu_baseline(args_dict, state_dict, budget_s=25.0):
             "sample": f"{done} of the {N_MOL} S-mol64 molecules in chunks of {chunk}, oracle/tensornet_torch.py (reference "
                       f"PyTorch CPU algorithm, autograd forces), 2 warm-ups + best of 5 per chunk, {time.perf_counter() - t_start:.1f} s; "
                       "the unmodified reference on the build container: BASELINE.md section 4"}
+
+
+def gpu_eager_baseline(args_dict, state_dict, dev, chunk=32, reps=3):
+    """SURVEY 8(d)'s same-node GPU comparator: the reference ALGORITHM as plain PyTorch-ROCm eager on this MI355X
+    (oracle/tensornet_torch.py = reference tensornet.py:54-81 with OPT=False, autograd forces, dense O(n^2) neighbour search per
+    molecule), on the same S-mol64 batch, in chunks of `chunk` molecules (the [E, 3, 3, F] temporaries of all 256 at once are a few
+    GB: chunked so that the comparator, not the allocator, is timed).  Outside the timed region of the headline; a reported
+    baseline like `cpu_baseline`, never the thing measured or shipped."""
+    import torch
+    from oracle import tensornet_torch as T
+    from torchmdnet_amd import workloads as W
+
+    hp = T.hparams_from_args(args_dict)
+    sd = {k: v.detach().to(dev) for k, v in state_dict.items()}
+    batches = []
+    for first in range(0, N_MOL, chunk):
+        z, pos, batch = W.synthetic_batch(n_mol=min(chunk, N_MOL - first), n_atoms=N_ATOMS, first_seed=first)
+        batches.append((z.to(dev), pos.to(dev), batch.to(dev)))
+
+    def sweep():
+        out = []
+        for z, pos, batch in batches:
+            out.append(T.energy_and_forces(sd, hp, z, pos, batch))
+        return out
+
+    sweep()  # warm-up (allocator, kernel selection)
+    torch.cuda.synchronize(dev)
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = sweep()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        best = el if best is None or el < best else best
+    assert all(torch.isfinite(e).all() and torch.isfinite(f).all() for e, f in res)
+    return {"value": N_MOL / best, "unit": "molecules/s", "ms_per_batch": best * 1e3, "kind": "port",
+            "what": "oracle/tensornet_torch.py (the reference's pure-PyTorch algorithm, reference tensornet.py:54-81 OPT=False branch, "
+                    "autograd forces) as PyTorch-ROCm eager on this GPU",
+            "sample": f"all {N_MOL} S-mol64 molecules in chunks of {chunk}, 1 warm-up + best of {reps} sweeps",
+            "torch": torch.__version__, "hip": getattr(torch.version, "hip", None), "device": torch.cuda.get_device_name(dev)}
 
 
 # ----------------------------------------------------------------------------------------------- launch
@@ -859,6 +917,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args_dict, model.state_dict())
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(exc)}
+            try:
+                out["gpu_eager_baseline"] = gpu_eager_baseline(args_dict, model.state_dict(), dev)
+                out["gpu_eager_baseline"]["hip_engine_over_eager"] = out["value"] / out["gpu_eager_baseline"]["value"]
+            except Exception as exc:  # noqa: BLE001
+                out["gpu_eager_baseline"] = {"error": repr(exc)}
+            torch.cuda.empty_cache()
         if a.breakdown:
             os.makedirs(os.path.dirname(os.path.abspath(a.breakdown)), exist_ok=True)
             with open(a.breakdown, "w") as fh:

@@ -128,6 +128,8 @@ _installed = False
 def install():
     """Install the shims and put /root/reference on sys.path.  Idempotent."""
     global _installed
+    if "purge_foreign_torchmdnet" in globals():
+        purge_foreign_torchmdnet()
     if _installed:
         return
     if not reference_available():
@@ -158,7 +160,30 @@ def install():
     _installed = True
 
 
+def _is_reference_module(mod) -> bool:
+    f = getattr(mod, "__file__", None) or ""
+    return os.path.abspath(f).startswith(os.path.abspath(REFERENCE_ROOT) + os.sep)
+
+
+def purge_foreign_torchmdnet():
+    """Drop every ``torchmdnet*`` entry of sys.modules that is not the reference's own file (e.g. the aliases that
+    ``torchmdnet_amd.install_as_torchmdnet()`` registers) and forget the installed state, so that the next install() binds
+    the real reference again.  Returns the number of entries removed."""
+    global _installed
+    top = sys.modules.get("torchmdnet")
+    mm = sys.modules.get("torchmdnet.models.model")
+    clean = (top is None or _is_reference_module(top)) and (mm is None or _is_reference_module(mm))
+    if clean:
+        return 0
+    names = [k for k in sys.modules if k == "torchmdnet" or k.startswith("torchmdnet.")]
+    for k in names:
+        del sys.modules[k]
+    _installed = False
+    return len(names)
+
+
 def reference_model_module():
+    purge_foreign_torchmdnet()
     install()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -182,6 +182,7 @@ def test_install_as_torchmdnet_alias():
     import torchmdnet_amd
 
     saved = {k: v for k, v in sys.modules.items() if k == "torchmdnet" or k.startswith("torchmdnet.")}
+    saved_installed = R._installed
     try:
         for k in saved:
             del sys.modules[k]
@@ -222,6 +223,8 @@ def test_install_as_torchmdnet_alias():
         for k in [k for k in sys.modules if k == "torchmdnet" or k.startswith("torchmdnet.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+        R._installed = saved_installed and "torchmdnet.extensions.ops" in saved
+        assert R.purge_foreign_torchmdnet() == 0, "the torchmdnet alias leaked out of this test"
 
 
 def test_load_model_equivariant_transformer_checkpoint(tmp_path):

@@ -396,6 +396,75 @@ def test_halo_exchange_plan_and_protocol_ranks_as_threads():
         HaloExchangeEvaluator(None, 11.0).plan(pos, box, 0, 2)  # a halo of 11 A on either side of a 10.5 A slab in 21 A
 
 
+def test_halo_plan_atoms_on_and_beside_slab_faces():
+    """ownership and ghost membership come from one integer per atom, so an atom on a slab face, a few ulp
+    beside it, or an ulp below 0 (where the wrap rounds to the box length) is local to every rank that owns one of its
+    neighbours.  Box lengths and worlds include the advisor's failing cases (x = 31.049997 in 62.1 with 6 slabs, 82.75 in 99.3)."""
+    import numpy as np
+    from torchmdnet_amd.parallel import HaloExchangeEvaluator
+
+    rc = 5.0
+    for La, world in ((62.1, 6), (99.3, 6), (40.0, 4), (31.0, 2), (30.0, 6), (61.7, 3)):
+        lengths = torch.tensor([La, 11.0, 12.0])
+        box = torch.diag(lengths)
+        g = torch.Generator().manual_seed(int(La * 10) + world)
+        pos = torch.rand(600, 3, generator=g) * lengths
+        w = La / world
+        xs = [31.049997, 82.75, -1e-7, -1e-9, 0.0, La, float(np.nextafter(np.float32(La), np.float32(0)))]
+        for p in range(world + 1):
+            f32 = np.float32(p * w)
+            xs += [float(f32)]
+            up, dn = f32, f32
+            for _ in range(3):
+                up, dn = np.nextafter(up, np.float32(1e9)), np.nextafter(dn, np.float32(-1e9))
+                xs += [float(up), float(dn)]
+            n_w = int(w // rc)
+            if n_w >= 1:  # the far side of the halo cell too
+                xs += [float(np.float32(p * w + w / n_w)), float(np.float32(p * w - w / n_w))]
+        face = torch.rand(len(xs), 3, generator=g) * lengths
+        face[:, 0] = torch.tensor(xs, dtype=torch.float32)
+        pos = torch.cat([pos, face])
+        n = pos.shape[0]
+        ev = HaloExchangeEvaluator(None, rc)
+        plans = [ev.plan(pos, box, r, world) for r in range(world)]
+        owned = torch.cat([pl.gidx[:pl.n_own] for pl in plans])
+        assert sorted(owned.tolist()) == list(range(n))  # every atom owned exactly once
+        d = pos[:, None, :] - pos[None, :, :]
+        d = d - lengths * torch.round(d / lengths)
+        within = d.norm(dim=-1) < rc
+        for r, pl in enumerate(plans):
+            local = torch.zeros(n, dtype=torch.bool)
+            local[pl.gidx] = True
+            assert pl.gidx.unique().numel() == pl.gidx.numel()
+            need = within[pl.gidx[:pl.n_own]].any(dim=0)
+            missing = torch.nonzero(need & ~local).flatten()
+            assert missing.numel() == 0, (La, world, r, pos[missing, 0].tolist())
+            for p in range(world):
+                assert torch.equal(pl.gidx[pl.send[p]], plans[p].gidx[plans[p].recv[r]])
+            assert sum(int(t.numel()) for t in pl.recv) == pl.n_ghost
+
+
+def test_halo_exchange_enters_a_collective_transport_with_zero_rows():
+    """a rank without ghost traffic still enters a collective transport (its peers are in the all-to-all)."""
+    from torchmdnet_amd.parallel import HaloExchangeEvaluator, HaloPlan
+
+    calls = []
+
+    def transport(rank, world, send, send_counts, recv_counts):
+        calls.append((tuple(send.shape), tuple(send_counts), tuple(recv_counts)))
+        return send.new_zeros((0, send.shape[1]))
+
+    none = torch.zeros(0, dtype=torch.long)
+    plan = HaloPlan(torch.arange(4), torch.zeros(4, 3), torch.eye(3), 4, [none, none], [none, none])
+    rows = torch.ones(4, 6)
+    ev = HaloExchangeEvaluator(None, 1.0, transport=transport)
+    ev.exchange_fn(plan, 0, 2)(0, rows, None)
+    assert calls == []  # a point-to-point transport: nothing to do
+    transport.collective = True
+    ev.exchange_fn(plan, 0, 2)(0, rows, None)
+    assert calls == [((0, 6), (0, 0), (0, 0))] and bool((rows == 1).all())
+
+
 def _halo_worker(rank, world, port, tmpdir):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -814,7 +814,7 @@ class TorchMD_Net(nn.Module):
     def _build_graph_for_a_training_pass(self, st, stream, n, n_mol, p32, batch, z, box, box_mode, counts):
         """tmdnet_build_graph for the parameter-gradient passes.  They evaluate the radial functions directly, so their graph needs
         neither the species map of the radial-basis embedding nor its weight images - which a device-side parameter update leaves
-        stale, and whose rebuild (device synchronisation + a host round trip, `refresh_rb_images`) would otherwise be paid by every
+        stale, and whose rebuild (`k_embed_rb_images` on the update's stream, tn_embed_rb.hip) would otherwise be paid by every
         training step: the embedding's atom threshold is out of reach for the duration of this one call."""
         L = _C.lib()
         v = C.c_double()
@@ -1067,7 +1067,9 @@ class TorchMD_Net(nn.Module):
             if atom_weights is not None and torch.cuda.is_current_stream_capturing():
                 # a captured graph replays the call with this pointer: the vector has to outlive every replay, and a later call
                 # (which overwrites st.atom_weights) must not free it
-                st.captured_atom_weights = getattr(st, "captured_atom_weights", []) + [atom_weights]
+                # (bounded: a re-capture with the same storage adds nothing, and only the most recent 8 captures are kept alive)
+                kept = [w for w in getattr(st, "captured_atom_weights", []) if w.data_ptr() != atom_weights.data_ptr()]
+                st.captured_atom_weights = (kept + [atom_weights])[-8:]
             halo_state = {}
             if halo_exchange is not None:
 

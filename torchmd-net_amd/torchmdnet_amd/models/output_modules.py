@@ -6,7 +6,8 @@ from torch import nn
 from torchmdnet_amd.models.utils import MLP
 
 # the reference's own list (output_modules.py:19), which its tests parametrise over: of these only "Scalar" is in SURVEY section 8's
-# scope - the two property heads raise NotImplementedError in create_model.  What the engine evaluates: __engine_heads__
+# scope - the two property heads are defined below as classes that raise NotImplementedError on construction, so that
+# `from ...output_modules import *` works and create_model refuses them by name.  What the engine evaluates: __engine_heads__
 __all__ = ["Scalar", "DipoleMoment", "ElectronicSpatialExtent"]
 __engine_heads__ = ["Scalar", "EquivariantScalar", "ScalarPlusWeightedCoulomb"]
 
@@ -124,3 +125,19 @@ class ScalarPlusWeightedCoulomb(OutputModel):
 
     def reset_parameters(self):
         self.output_network.reset_parameters()
+
+
+class _OutOfScopeHead(OutputModel):
+    """Property heads of the reference (output_modules.py:166-341) outside SURVEY section 8's energy + force path."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError(f"output_model={type(self).__name__} is outside the HIP energy+force path (Scalar, EquivariantScalar, "
+                                  "ScalarPlusWeightedCoulomb)")
+
+
+class DipoleMoment(_OutOfScopeHead):
+    pass
+
+
+class ElectronicSpatialExtent(_OutOfScopeHead):
+    pass

@@ -286,6 +286,7 @@ def distributed_transport(group: Optional[dist.ProcessGroup] = None):
         dist.all_to_all_single(dst, src, list(recv_counts), list(send_counts), group=group)
         return dst.to(send.device) if host else dst
 
+    transport.collective = True
     return transport
 
 
@@ -361,31 +362,49 @@ class HaloExchangeEvaluator:
         if 2 * h > La - w:
             raise ValueError(f"two halos of {h:g} do not fit beside a slab of {w:g} in the box length {La:g}: an atom would be its "
                              "own ghost, or a ghost on both sides")
+        # Ownership and halo membership come from ONE integer per atom - its cell along the slab axis - so that an atom on (or an
+        # ulp beside) a slab face is never owned by one slab and missed as a ghost by its neighbour; the distance tests below are
+        # closed, signed (an atom binned across a face by rounding has a slightly negative distance) and tolerant, and only ADD ghosts.
         x = torch.remainder(pos[:, a], La)
-        slab = torch.clamp(torch.floor(x / w).long(), max=world - 1)  # x == La rounds into the last slab
+        x = torch.where(x >= La, torch.zeros_like(x), x)  # remainder of a tiny negative coordinate rounds to La: the same point as 0
+        if n_w >= 1:
+            n_cell = n_w * world
+            cell = torch.clamp(torch.floor(x * (n_cell / La)).long(), 0, n_cell - 1)
+            slab = torch.div(cell, n_w, rounding_mode="floor")
+        else:
+            n_cell, cell = 0, None
+            slab = torch.clamp(torch.floor(x / w).long(), 0, world - 1)
         if int(torch.bincount(slab, minlength=world).min()) == 0:
             # every rank sees it (replicated positions) and raises: a rank without a step would leave its peers waiting in the exchanges
             raise ValueError("HaloExchangeEvaluator: a slab without atoms (vacuum along the slab axis); choose another axis or fewer ranks")
+        tol = 1e-5 * h + 4e-7 * La
 
-        def halo_of(p: int, xs: torch.Tensor, slabs: torch.Tensor):
-            """Atoms (of `xs`) within h below the lower face or above the upper face of slab p, not in it."""
-            dlo = torch.remainder(p * w - xs, La)            # distance below the slab's lower face (periodic)
-            dhi = torch.remainder(xs - (p * w + w), La)      # distance above its upper face
-            return (slabs != p) & (((dlo > 0) & (dlo <= h)) | (dhi < h))
+        def halo_of(p: int, xs: torch.Tensor, slabs: torch.Tensor, cells: Optional[torch.Tensor]):
+            """Atoms (of `xs`) of another slab within h of a face of slab p: in the cell layer beside the face, or by distance."""
+            dlo = p * w - xs                                 # signed distance below the slab's lower face, wrapped to [-La/2, La/2]
+            dlo = dlo - La * torch.round(dlo / La)
+            dhi = xs - (p * w + w)                           # signed distance above its upper face
+            dhi = dhi - La * torch.round(dhi / La)
+            near = ((dlo >= -tol) & (dlo <= h + tol)) | ((dhi >= -tol) & (dhi <= h + tol))
+            if cells is not None:
+                near = near | (cells == (p * n_w - 1) % n_cell) | (cells == ((p + 1) * n_w) % n_cell)
+            return (slabs != p) & near
 
         own = torch.nonzero(slab == rank).flatten()
-        ghosts = torch.nonzero(halo_of(rank, x, slab)).flatten()  # ascending atom index, every atom once
+        ghosts = torch.nonzero(halo_of(rank, x, slab, cell)).flatten()  # ascending atom index, every atom once
         gidx = torch.cat([own, ghosts])
         n_own = int(own.numel())
-        # a halo no wider than a slab reaches the two adjacent slabs only
-        peers = {(rank - 1) % world, (rank + 1) % world} - {rank} if h <= w else set(range(world)) - {rank}
+        # a halo no wider than a slab reaches the two adjacent slabs - and, through the closed tests, an atom exactly on the far face of
+        # one: every other slab is asked (world masks over the owned atoms; empty lists for all but two or three of them)
+        peers = set(range(world)) - {rank}
         none = own[:0]
         g_slab = slab[ghosts]
         recv = [n_own + torch.nonzero(g_slab == p).flatten() if p in peers else none for p in range(world)]
         # what the others hold of mine, in THEIR ghost order (ascending atom index = ascending row of mine)
         x_own, s_own = x[own], slab[own]
+        c_own = cell[own] if cell is not None else None
         rows = torch.arange(n_own, device=pos.device)
-        send = [rows[halo_of(p, x_own, s_own)] if p in peers else none for p in range(world)]
+        send = [rows[halo_of(p, x_own, s_own, c_own)] if p in peers else none for p in range(world)]
         order = [a] + [k for k in range(3) if k != a]
         grid = None
         if n_w >= 1:
@@ -404,8 +423,8 @@ class HaloExchangeEvaluator:
         self.rows_moved = 0
 
         def exchange(stage: int, rows: torch.Tensor, inv: Optional[torch.Tensor]):
-            if recv_all.numel() == 0 and send_all.numel() == 0:
-                return
+            if recv_all.numel() == 0 and send_all.numel() == 0 and not getattr(self.transport, "collective", False):
+                return  # a collective transport is entered by every rank every time (zero rows here): the peers would hang otherwise
             src = send_all if inv is None else inv[send_all]
             dst = recv_all if inv is None else inv[recv_all]
             rows[dst] = self.transport(rank, world, rows[src], send_counts, recv_counts)
