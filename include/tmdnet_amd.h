@@ -99,7 +99,7 @@ const char* tmdnet_version(void);
 /* ABI revision of this header: bumped whenever an exported signature or struct layout changes (3: `z` in
  * tmdnet_build_graph[_static], `strategy` in tmdnet_neighbor_pairs).  A binding compares its compile-time
  * TMDNET_ABI_VERSION with the loaded library's tmdnet_abi_version() before its first call. */
-#define TMDNET_ABI_VERSION 8
+#define TMDNET_ABI_VERSION 9
 int tmdnet_abi_version(void);
 
 /* Parameters are addressed by the reference's state-dict keys without the "model." prefix
@@ -264,6 +264,19 @@ int tmdnet_neighbor_pairs(void* stream, void* ws, size_t ws_bytes, int64_t n_ato
 int tmdnet_neighbor_grad(void* stream, const int64_t* neighbors, const float* deltas, const float* distances,
                          const float* grad_deltas, const float* grad_distances, int64_t num_entries, int64_t n_atoms,
                          float* grad_positions);
+
+/* The same operator for DOUBLE positions (ABI 9).  The reference's neighbour kernels are generic over the position dtype
+ * (torchmdnet/extensions/warp_kernels/neighbors_brute.py:27-175 and neighbors_cell.py:17-153 are instantiated for float32 and
+ * float64; torchmdnet/extensions/warp_ops/neighbors.py:34-148 dispatches on positions.dtype; tests/test_neighbors.py:83,157,281
+ * run both).  Outputs, padding, overflow reporting and the order (lower pairs by (i, j), their transposes, self loops) as above;
+ * every strategy takes the brute-force search (same pair set); `ws` as for tmdnet_neighbor_pairs.  The model path stays fp32. */
+int tmdnet_neighbor_pairs_f64(void* stream, void* ws, size_t ws_bytes, int64_t n_atoms, int64_t n_mol, const double* pos,
+                              const int64_t* batch, const double* box, int32_t box_mode, double cutoff_lower, double cutoff_upper,
+                              int64_t max_num_pairs, int32_t loop, int32_t include_transpose, int64_t* neighbors, double* deltas,
+                              double* distances, int32_t* num_pairs);
+int tmdnet_neighbor_grad_f64(void* stream, const int64_t* neighbors, const double* deltas, const double* distances,
+                             const double* grad_deltas, const double* grad_distances, int64_t num_entries, int64_t n_atoms,
+                             double* grad_positions);
 
 /* ---- per-kernel-class timing (HIP events recorded on the launch stream around every launch of the
  * selected classes; bit c of category_mask selects class c).  tmdnet_profile_end synchronises the

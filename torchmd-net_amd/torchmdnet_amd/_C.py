@@ -86,6 +86,9 @@ def lib():
     L.tmdnet_neighbor_workspace_bytes.argtypes = [i64, i64, i64, C.POINTER(sz)]
     L.tmdnet_neighbor_pairs.argtypes = [vp, vp, sz, i64, i64, vp, vp, vp, i32, f32, f32, i64, i32, i32, i32, vp, vp, vp, vp]
     L.tmdnet_neighbor_grad.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, vp]
+    f64 = C.c_double
+    L.tmdnet_neighbor_pairs_f64.argtypes = [vp, vp, sz, i64, i64, vp, vp, vp, i32, f64, f64, i64, i32, i32, vp, vp, vp, vp]
+    L.tmdnet_neighbor_grad_f64.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, vp]
     L.tmdnet_profile_begin.argtypes = [vp, C.c_uint32]
     L.tmdnet_profile_end.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     L.tmdnet_profile_end_records.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double),

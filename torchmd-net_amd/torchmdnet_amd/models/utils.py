@@ -135,8 +135,9 @@ class OptimizedDistance(nn.Module):
             out = self.forward(pos.to(dev), None if batch is None else batch.to(dev), None if box is None else box.to(dev))
             return tuple(None if t is None else t.to(pos.device) for t in out)
         _require_cuda(pos, "OptimizedDistance")
-        if pos.dtype != torch.float32:
-            raise RuntimeError("torchmdnet_amd neighbour kernels are fp32 (BASELINE north_star); got " + str(pos.dtype))
+        if pos.dtype not in (torch.float32, torch.float64):
+            raise RuntimeError("torchmdnet_amd neighbour kernels are fp32 and fp64 (the reference's Warp kernels are instantiated for "
+                               "these two, neighbors_brute.py:27); got " + str(pos.dtype))
         use_periodic = self.use_periodic or box is not None
         if use_periodic:
             if box is None:

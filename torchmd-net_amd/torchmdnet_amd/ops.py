@@ -10,7 +10,9 @@ evaluation is ONE library call - so two ops are registered:
       autograd: d(sum_m g_m E_m)/d pos_i = -g_{batch_i} F_i  (molecules are independent); no second derivatives
   tmdnet::neighbor_pairs(pos, batch, box?, cutoff_lower, cutoff_upper, max_num_pairs, loop, include_transpose, strategy)
       -> (neighbors [2,M] int64, deltas [M,3], distances [M], num_pairs [1] int32)      (reference op: same outputs)
+      float32 or float64 positions, like the reference's (tmdnet_neighbor_pairs / tmdnet_neighbor_pairs_f64)
       autograd: neighbor_grad_positions of the reference (extensions/neighbor_utils.py:11-46) as a HIP kernel
+      (tmdnet::neighbor_grad), itself differentiable (second derivatives: gradgradcheck of the reference's tests)
 
 ``engine`` is an integer key into a registry of TorchMD_Net modules (custom-op arguments must be tensors or scalars; the
 parameters live in the library handle the module owns).  Both ops are device_types="cuda": there is no CPU kernel.
@@ -103,15 +105,21 @@ def neighbor_pairs(pos: Tensor, batch: Tensor, box: Optional[Tensor], cutoff_low
             ws = torch.empty(int(nbytes.value * 1.1) + 256, dtype=torch.uint8, device=dev)
             _ws_cache[key] = ws
         neighbors = torch.empty((2, max_num_pairs), dtype=torch.long, device=dev)
-        deltas = torch.empty((max_num_pairs, 3), dtype=torch.float32, device=dev)
-        dist = torch.empty((max_num_pairs,), dtype=torch.float32, device=dev)
+        f64 = pos.dtype == torch.float64  # the reference's operator is generic over the position dtype (warp_ops/neighbors.py:34-148)
+        deltas = torch.empty((max_num_pairs, 3), dtype=pos.dtype, device=dev)
+        dist = torch.empty((max_num_pairs,), dtype=pos.dtype, device=dev)
         num_pairs = torch.zeros(1, dtype=torch.int32, device=dev)
         p = pos.detach().contiguous()
         b = batch.contiguous()
-        bx = None if box is None else box.detach().to(torch.float32).contiguous()
-        rc = L.tmdnet_neighbor_pairs(_stream_ptr(dev), _ptr(ws), ws.numel(), n, n_mol, _ptr(p), _ptr(b), _ptr(bx), box_mode,
-                                     float(cutoff_lower), float(cutoff_upper), max_num_pairs, int(loop), int(include_transpose),
-                                     int(strategy), _ptr(neighbors), _ptr(deltas), _ptr(dist), _ptr(num_pairs))
+        bx = None if box is None else box.detach().to(pos.dtype).contiguous()
+        if f64:
+            rc = L.tmdnet_neighbor_pairs_f64(_stream_ptr(dev), _ptr(ws), ws.numel(), n, n_mol, _ptr(p), _ptr(b), _ptr(bx), box_mode,
+                                             float(cutoff_lower), float(cutoff_upper), max_num_pairs, int(loop), int(include_transpose),
+                                             _ptr(neighbors), _ptr(deltas), _ptr(dist), _ptr(num_pairs))
+        else:
+            rc = L.tmdnet_neighbor_pairs(_stream_ptr(dev), _ptr(ws), ws.numel(), n, n_mol, _ptr(p), _ptr(b), _ptr(bx), box_mode,
+                                         float(cutoff_lower), float(cutoff_upper), max_num_pairs, int(loop), int(include_transpose),
+                                         int(strategy), _ptr(neighbors), _ptr(deltas), _ptr(dist), _ptr(num_pairs))
     if rc != _C.OK:
         raise RuntimeError(f"tmdnet_neighbor_pairs failed with code {rc}")
     return neighbors, deltas, dist, num_pairs
@@ -119,8 +127,8 @@ def neighbor_pairs(pos: Tensor, batch: Tensor, box: Optional[Tensor], cutoff_low
 
 @neighbor_pairs.register_fake
 def _(pos, batch, box, cutoff_lower, cutoff_upper, max_num_pairs, loop, include_transpose, strategy, n_mol):
-    return (pos.new_empty((2, max_num_pairs), dtype=torch.long), pos.new_empty((max_num_pairs, 3), dtype=torch.float32),
-            pos.new_empty((max_num_pairs,), dtype=torch.float32), pos.new_empty((1,), dtype=torch.int32))
+    return (pos.new_empty((2, max_num_pairs), dtype=torch.long), pos.new_empty((max_num_pairs, 3)),
+            pos.new_empty((max_num_pairs,)), pos.new_empty((1,), dtype=torch.int32))
 
 
 @torch.library.custom_op("tmdnet::neighbor_grad", mutates_args=(), device_types="cuda")
@@ -128,12 +136,14 @@ def neighbor_grad(neighbors: Tensor, deltas: Tensor, distances: Tensor, grad_del
                   n_atoms: int) -> Tensor:
     L = _C.lib()
     dev = deltas.device
-    out = torch.empty((n_atoms, 3), dtype=torch.float32, device=dev)
-    gd = None if grad_deltas is None else grad_deltas.to(torch.float32).contiguous()
-    gw = None if grad_distances is None else grad_distances.to(torch.float32).contiguous()
+    dt = deltas.dtype
+    out = torch.empty((n_atoms, 3), dtype=dt, device=dev)
+    gd = None if grad_deltas is None else grad_deltas.to(dt).contiguous()
+    gw = None if grad_distances is None else grad_distances.to(dt).contiguous()
+    fn = L.tmdnet_neighbor_grad_f64 if dt == torch.float64 else L.tmdnet_neighbor_grad
     with torch.cuda.device(dev):
-        rc = L.tmdnet_neighbor_grad(_stream_ptr(dev), _ptr(neighbors.contiguous()), _ptr(deltas.contiguous()), _ptr(distances.contiguous()),
-                                    _ptr(gd), _ptr(gw), distances.shape[0], n_atoms, _ptr(out))
+        rc = fn(_stream_ptr(dev), _ptr(neighbors.contiguous()), _ptr(deltas.contiguous()), _ptr(distances.contiguous()),
+                _ptr(gd), _ptr(gw), distances.shape[0], n_atoms, _ptr(out))
     if rc != _C.OK:
         raise RuntimeError(f"tmdnet_neighbor_grad failed with code {rc}")
     return out
@@ -142,6 +152,39 @@ def neighbor_grad(neighbors: Tensor, deltas: Tensor, distances: Tensor, grad_del
 @neighbor_grad.register_fake
 def _(neighbors, deltas, distances, grad_deltas, grad_distances, n_atoms):
     return deltas.new_empty((n_atoms, 3))
+
+
+# Second derivatives through the neighbour operator (reference tests/test_neighbors.py:272-315 runs gradgradcheck; the reference
+# gets them for free because its backward, extensions/neighbor_utils.py:11-46, is written in differentiable torch ops).
+# neighbor_grad is  out[i_p] += G_p, out[j_p] -= G_p  with  G_p = g_delta_p + delta_p g_dist_p / d_p  (padded and d = 0 entries
+# contribute nothing).  With H the gradient arriving at `out` and h_p = H[i_p] - H[j_p]:
+#     d/d g_delta_p = h_p ;  d/d g_dist_p = h_p . delta_p / d_p ;  d/d delta_p = h_p g_dist_p / d_p ;  d/d d_p = -(h_p . delta_p) g_dist_p / d_p^2
+# Elementwise expressions on gathered rows, written in torch so that they are differentiable again; off every hot path.
+def _ng_setup(ctx, inputs, output):
+    neighbors, deltas, distances, grad_deltas, grad_distances, n_atoms = inputs
+    ctx.have = (grad_deltas is not None, grad_distances is not None)
+    ctx.save_for_backward(neighbors, deltas, distances, grad_distances)
+
+
+def _ng_backward(ctx, H):
+    neighbors, deltas, distances, grad_distances = ctx.saved_tensors
+    have_gd, have_gw = ctx.have
+    valid = (neighbors[0] >= 0) & (neighbors[1] >= 0) & (distances != 0)
+    i = neighbors[0].clamp(min=0)
+    j = neighbors[1].clamp(min=0)
+    h = (H[i] - H[j]) * valid.unsqueeze(-1).to(H.dtype)
+    safe_d = torch.where(valid, distances, torch.ones_like(distances))
+    g_gdel = h if have_gd else None
+    g_gdist = g_del = g_d = None
+    if have_gw:
+        hd = (h * deltas).sum(-1)
+        g_gdist = hd / safe_d
+        g_del = h * (grad_distances / safe_d).unsqueeze(-1)
+        g_d = -hd * grad_distances / (safe_d * safe_d)
+    return None, g_del, g_d, g_gdel, g_gdist, None
+
+
+neighbor_grad.register_autograd(_ng_backward, setup_context=_ng_setup)
 
 
 def _np_setup(ctx, inputs, output):
