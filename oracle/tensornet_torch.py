@@ -142,10 +142,10 @@ def tensor_embedding(sd: Dict[str, Tensor], hp: dict, z: Tensor, edge_index: Ten
         dim=1,
     )  # [E,3,F]  :558-567
     # tensornet_embedding_message_passing, :405-445
-    I0 = torch.zeros(n, F, dtype=pos_dtype).index_add(0, ei, W[:, 0])
-    v0 = torch.zeros(n, 3, F, dtype=pos_dtype).index_add(0, ei, W[:, 1, None, :] * rhat[:, :, None])
+    I0 = torch.zeros(n, F, dtype=pos_dtype, device=W.device).index_add(0, ei, W[:, 0])
+    v0 = torch.zeros(n, 3, F, dtype=pos_dtype, device=W.device).index_add(0, ei, W[:, 1, None, :] * rhat[:, :, None])
     outer = rhat[:, :, None] * rhat[:, None, :]
-    T0 = torch.zeros(n, 3, 3, F, dtype=pos_dtype).index_add(0, ei, W[:, 2, None, None, :] * outer[..., None])
+    T0 = torch.zeros(n, 3, 3, F, dtype=pos_dtype, device=W.device).index_add(0, ei, W[:, 2, None, None, :] * outer[..., None])
     A0 = skew(v0)
     S0 = 0.5 * (T0 + T0.transpose(1, 2)) - T0.diagonal(dim1=1, dim2=2).mean(-1)[:, None, None, :] * _eye(T0)  # :133-141
     X = I0[:, None, None, :] * _eye(T0) + A0 + S0
@@ -246,8 +246,8 @@ def energy(sd, hp, z, pos, batch, box=None, q=None, num_systems=None, atomref=No
     if atom_weights is not None:
         e = e * atom_weights.to(e.dtype).reshape(-1, 1)
     nmol = int(batch.max()) + 1 if num_systems is None else num_systems
-    y = torch.zeros(nmol, 1, dtype=e.dtype).index_add(0, batch, e)  # output_modules.py:43-73
-    return y + sd.get("mean", torch.zeros((), dtype=e.dtype))  # model.py:606-607
+    y = torch.zeros(nmol, 1, dtype=e.dtype, device=e.device).index_add(0, batch, e)  # output_modules.py:43-73
+    return y + sd.get("mean", torch.zeros((), dtype=e.dtype, device=e.device))  # model.py:606-607
 
 
 def energy_and_forces(sd, hp, z, pos, batch, box=None, q=None, num_systems=None, atomref=None, atom_weights=None):
