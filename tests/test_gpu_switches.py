@@ -66,7 +66,7 @@ SWITCHES = {"TMDNET_NO_MSG_ROWS8": "1", "TMDNET_NO_SPLIT_BF16": "1", "TMDNET_NO_
             "TMDNET_ET_GENERIC_SWEEPS": "1", "TMDNET_SIDE_STREAM": "1", "TMDNET_EI_RUN": "3", "TMDNET_EDGE_DIRECT_MAX": "0",
             "TMDNET_SPLIT_ROWS": "0", "TMDNET_GEMM_BPC": "2", "TMDNET_EDGE_TABLE_MIN_PAIRS": "100000000", "TMDNET_NO_TLIN9": "1",
             "TMDNET_MSG_NOBALANCE": "1", "TMDNET_SMALL_FUSED_MAX": "0", "TMDNET_MID_FUSED_MAX": "0",
-            "TMDNET_NO_ADJ_ROWS8": "1", "TMDNET_NO_TABLE_SIDE_STREAM": "1"}
+            "TMDNET_NO_ADJ_ROWS8": "1"}
 NOT_KERNEL_SWITCHES = {"TMDNET_DEBUG", "TMDNET_REFERENCE_ROOT"}  # error-message verbosity; location of the reference for CPU tests
 COMBOS.update({k.lower(): {k: v} for k, v in SWITCHES.items()})
 
@@ -77,42 +77,3 @@ def test_developer_switch_combination(hip_lib, name):
     out = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "SWITCHES_OK" in out.stdout, (name, out.stdout[-500:], out.stderr[-1500:])
 
-
-def test_table_side_stream_is_bit_identical_to_the_single_stream_schedule(hip_lib):
-    """Round 6: the per-pair rows from the radial tables are written on a second stream beside the node kernels (TensorNet: one
-    fork / join per step; Equivariant Transformer: one join per layer).  Same kernels and arithmetic: energies and forces must be
-    bit-identical to the single-stream schedule (switch read when the handle is created), at sizes where the side stream is
-    taken (>= 16 384 pairs), and repeatable."""
-    import torch
-    from torchmdnet_amd import workloads as W
-    from torchmdnet_amd.models.model import create_model
-
-    def make(args, off):
-        if off:
-            os.environ["TMDNET_NO_TABLE_SIDE_STREAM"] = "1"
-        else:
-            os.environ.pop("TMDNET_NO_TABLE_SIDE_STREAM", None)
-        try:
-            torch.manual_seed(0)
-            return create_model(dict(args)).to("cuda")
-        finally:
-            os.environ.pop("TMDNET_NO_TABLE_SIDE_STREAM", None)
-
-    z, pos, batch = (t.cuda() for t in W.synthetic_batch(n_mol=48))
-    zw, pw, bw = (t.cuda() for t in W.water_box(n_side=11))
-    cases = [(W.C2_ARGS, (z, pos, batch, None, None, 48), {}), (W.C4_ARGS, (z, pos, batch, None, None, 48), {}),
-             (W.C4_ARGS, (z, pos, batch, None, None, 48), {"pair_storage": "bf16"}),
-             (dict(W.C2_ARGS, max_num_neighbors=96), (zw, pw, torch.zeros_like(zw), bw, None, 1), {})]
-    for args, inp, attrs in cases:
-        on, off = make(args, False), make(args, True)
-        off.load_state_dict(on.state_dict())
-        for m in (on, off):
-            for k, v in attrs.items():
-                setattr(m, k, v)
-        e1, f1 = on.energy_and_forces(*inp)
-        e0, f0 = off.energy_and_forces(*inp)
-        assert int(on._engine.counts[0]) + 1 >= 16384, "the case is too small to take the side stream"
-        assert torch.isfinite(f1).all() and torch.equal(e1, e0) and torch.equal(f1, f0), (args.get("model"), attrs)
-        for _ in range(3):
-            e2, f2 = on.energy_and_forces(*inp)
-            assert torch.equal(e2, e1) and torch.equal(f2, f1)

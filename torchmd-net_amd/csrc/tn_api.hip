@@ -555,21 +555,6 @@ extern "C" {
 const char* tmdnet_version(void) { return "tmdnet_amd 0.3 (gfx950)"; }
 int tmdnet_abi_version(void) { return TMDNET_ABI_VERSION; }
 
-// second stream + fork / join events (tn_model.h): created with the handle (a stream costs nothing until something is enqueued)
-static void create_side_stream(tmdnet_model* m, int num_layers) {
-  m->side_mlp = getenv("TMDNET_SIDE_STREAM") != nullptr;  // opt-in (profiles/r01_notes.md): +2 % batch throughput, but the GEMMs then share the chip
-  m->side_tab = getenv("TMDNET_NO_TABLE_SIDE_STREAM") == nullptr;
-  if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) m->side = nullptr;
-  if (!m->side) {
-    (void)hipGetLastError();
-    return;
-  }
-  (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&m->ev_tab, hipEventDisableTiming);
-  m->ev_join.resize(num_layers > 0 ? num_layers : 1);
-  for (auto& e : m->ev_join) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-}
-
 int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out) {
   if (!hp || !out) return TMDNET_ERR_INVALID;
   if (hp->hidden_channels <= 0 || hp->num_layers < 0 || hp->num_rbf <= 0 || hp->max_z <= 0 || hp->head_hidden <= 0 ||
@@ -579,7 +564,14 @@ int tmdnet_create(const tmdnet_hparams* hp, tmdnet_model** out) {
   m->hp = *hp;
   if (const char* e = getenv("TMDNET_EDGE_TABLE_MIN_PAIRS")) m->tab_min_pairs = atoll(e);  // developer switch (default: tn_model.h)
   build_specs(m);
-  create_side_stream(m, hp->num_layers);
+  if (getenv("TMDNET_SIDE_STREAM")) {  // opt-in (profiles/r01_notes.md): +2 % batch throughput, but the GEMMs then share the chip
+    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) m->side = nullptr;
+    if (m->side) {
+      (void)hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
+      m->ev_join.resize(hp->num_layers);
+      for (auto& e : m->ev_join) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    }
+  }
   *out = m;
   return TMDNET_OK;
 }
@@ -621,7 +613,6 @@ int tmdnet_create_et(const tmdnet_et_hparams* hp, tmdnet_model** out) {
     delete m;
     return rc;
   }
-  create_side_stream(m, hp->num_layers);
   *out = m;
   return TMDNET_OK;
 }
@@ -632,7 +623,6 @@ int tmdnet_destroy(tmdnet_model* m) {
   if (m->side) {
     (void)hipStreamSynchronize(m->side);
     (void)hipEventDestroy(m->ev_fork);
-    if (m->ev_tab) (void)hipEventDestroy(m->ev_tab);
     for (auto& e : m->ev_join) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(m->side);
   }
@@ -1471,14 +1461,6 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
   const int64_t* const batch_a = batch_k ? batch_k + o1_ : nullptr;  // their molecule index
   const bool fused_small = !tc && !ntp && !recompute && !m->halo_fn && (small_fused_ok(N, F, H, L) || mid_fused_ok(N, F, H, L)) &&
                            (!want_forces || (message_adjoint_gd_ok(N, F) && !getenv("TMDNET_SEPARATE_PAIR_GD")));
-  bool tab_side = false;  // the per-pair rows of this step are being written on the side stream: TAB_JOIN before their first reader
-#define TAB_JOIN()                                                  \
-  do {                                                              \
-    if (tab_side) {                                                 \
-      HIP_TRY(m, hipStreamWaitEvent(s, m->ev_tab, 0));              \
-      tab_side = false;                                             \
-    }                                                               \
-  } while (0)
   if (run_fwd) {
     if (use_tab) {
       // radial tables (tn_edge_table.hip): sort the pairs by distance, one streaming Hermite-interpolation kernel for all
@@ -1498,24 +1480,11 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         douts[nt_++] = want_forces ? b.dw[l] : nullptr;
       }
       const double rowB = 12.0 * Fd;
-      // With the embedding in the radial basis nothing reads these rows (or C, dC) before layer 0's sweep: they are written on the
-      // side stream beside the embedding and the first node kernels (tn_model.h), joined at `TAB_JOIN` below.
-      tab_side = nt_ > 0 && m->side && m->side_tab && ntp && L > 0 && !fused_small && !m->halo_fn && (int64_t)P1 >= 16384;
-      if (tab_side) {
-        HIP_TRY(m, hipEventRecord(m->ev_fork, s));
-        HIP_TRY(m, hipStreamWaitEvent(m->side, m->ev_fork, 0));
-      }
-      if (nt_ > 0) {
-        hipStream_t const s_main = s;
-        {
-          hipStream_t const s = tab_side ? m->side : s_main;  // (the KR macro records its events on `s`)
-          KR(CAT_EDGE_TABLE, (Pd + 1) * (rowB * nt_ * (want_forces ? 2 : 1) + 24) + (double)(m->tabs.T + 2) * 2 * rowB * nt_,
-             (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
-              launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, nt_, tabs, outs, douts, b.skeys_s, b.svals_s, s, b.C,
-                                 b.dC)));
-        }
-      }
-      if (tab_side) HIP_TRY(m, hipEventRecord(m->ev_tab, m->side));
+      if (nt_ > 0)
+        KR(CAT_EDGE_TABLE, (Pd + 1) * (rowB * nt_ * (want_forces ? 2 : 1) + 24) + (double)(m->tabs.T + 2) * 2 * rowB * nt_,
+           (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
+            launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, 3 * F, nt_, tabs, outs, douts, b.skeys_s, b.svals_s, s, b.C,
+                               b.dC)));
     } else {
       // ---- radial functions per pair
       RadialParams rp{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper};
@@ -1523,7 +1492,7 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       // ---- edge MLPs of all layers: functions of the pair geometry only -> side stream (tn_model.h)
       // only at batch scale: for a small system the cross-queue joins cost more than the overlap gives (graph replay of a
       // 64-atom molecule 0.36 -> 0.40 ms, profiles/r01_notes.md)
-      es = (m->side && m->side_mlp && L > 0 && P >= 16384 && !tc) ? m->side : s;
+      es = (m->side && L > 0 && P >= 16384 && !tc) ? m->side : s;
       if (es != s) {
         HIP_TRY(m, hipEventRecord(m->ev_fork, s));
         HIP_TRY(m, hipStreamWaitEvent(es, m->ev_fork, 0));
@@ -1626,7 +1595,6 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
         ta.A = b.X[l] + o9F; ta.C = b.Pn[l] + o9F; ta.N = Na; ta.F = F;
         tlin9(s, TL9_PRO_NORM, TL9_EPI_PLAIN, q_.V, ta, 2.0, "norm");
         HALO_TRY(l, b.Pn[l], 9 * F);
-        TAB_JOIN();
         KR(CAT_MESSAGE, wB + idxB + nodeB * (1.0 + 2.0 * Na / Nd),  // P of every local atom is gathered; Mi, C_hat of the swept rows are written
            launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s, recompute ? &rts[l] : nullptr, a0, rng ? Na : -1));
         // dX = linear(C_hat), then X_new = X_hat + dX + kappa dX.dX (and the readout invariants after the last layer) in the epilogue
@@ -1640,7 +1608,6 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
       if (l == 0) KR(CAT_ELEMENTWISE, 2 * nodeB, launch_norm_x(b.X[l], Xh_l, N, F, s));
       tensor_linear(s, Xh_l, q_.V, b.Pn[l], N, F);
       HALO_TRY(l, b.Pn[l], 9 * F);
-      TAB_JOIN();
       KR(CAT_MESSAGE, wB + idxB + 3 * nodeB, launch_message(g, N, F, b.w[l], b.Pn[l], q, batch_k, o3, b.Mi[l], Ch_l, s, recompute ? &rts[l] : nullptr));
       tensor_linear(s, Ch_l, q_.V + 3, b.D[l], N, F);
       // update fused with the next consumer of the new X: the next layer's normalisation, or the readout invariants
@@ -1666,7 +1633,6 @@ int tmdnet_energy_forces(tmdnet_model* m, void* stream, void* graph_ws, void* ws
     }
     }  // !fused_small
   }
-  TAB_JOIN();  // (no layer swept: nothing may be left running on the side stream when this call returns)
 
   if (want_forces && run_bwd && fused_small) {
     const int gd_nw = message_adjoint_gd_waves(g, N, F, recompute);

@@ -501,13 +501,6 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
   // written by the table interpolation as bf16 and widened to fp32 when the sweeps load them; every product and sum stays fp32.
   // Only with the tables (the value + tangent GEMMs write fp32 rows): otherwise the call silently keeps fp32 storage.
   const int pbf = (m->pair_bf16 && use_tab) ? 1 : 0;
-  bool tab_side = false;  // the layers' filter rows are written on the side stream; layers [0, tab_joined) have been joined
-  int tab_joined = 0;
-#define ET_TAB_JOIN(upto)                                                        \
-  do {                                                                           \
-    if (tab_side)                                                                \
-      for (; tab_joined < (upto); ++tab_joined) HIP_TRY(m, hipStreamWaitEvent(s, m->ev_join[tab_joined], 0)); \
-  } while (0)
   const double pB = pbf ? 2.0 : 4.0;  // bytes per stored pair-row element
   if (use_tab) {
     // all per-pair filters from the radial tables: one bucket sort of the pairs, one interpolation launch per row length
@@ -519,21 +512,11 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
       douts.push_back(want_forces ? b.tkv[l] : nullptr);
     }
     const double nt = (double)m->tabs.T + 2;
-    // Round 6: the filter rows of layer l are first read by layer l's attention sweep, and writing them is pure output streaming
-    // (10 GB on ET-SPICE 256 x 64: 2.1 ms of an 11 ms step) while the sweeps are bound by instruction issue.  At batch scale the
-    // bucket sort (which also writes C, dC) and the neighbour embedding's rows stay on the caller's stream; the layers' rows are
-    // written on the side stream (tn_model.h), one launch and one join event per layer, beside the projections and sweeps of the
-    // layers before.  Same kernels, same arithmetic: k_edge_interp<1> per layer instead of <4> + <1>.
-    tab_side = n_dkv > 0 && m->side && m->side_tab && !m->halo_fn && (int64_t)P1 >= 16384 && (int)m->ev_join.size() >= n_dkv;
-    if (!tab_side) {
-      KR(CAT_EDGE_TABLE, (Pd + 1) * (pB * Wd * n_dkv * (want_forces ? 2 : 1) + 24) + nt * 12.0 * Wd * n_dkv,
-         (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
-          n_dkv ? launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, Wd, n_dkv, tabs.data(), outs.data(), douts.data(),
-                                     b.skeys_s, b.svals_s, s, b.C, b.dC, pbf)
-                : (void)0));
-    } else {
-      KR(CAT_EDGE_TABLE, (Pd + 1) * 24, launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s));
-    }
+    KR(CAT_EDGE_TABLE, (Pd + 1) * (pB * Wd * n_dkv * (want_forces ? 2 : 1) + 24) + nt * 12.0 * Wd * n_dkv,
+       (launch_pair_buckets(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, b.C, b.dC, b.shist, b.skeys_s, b.svals_s, s),
+        n_dkv ? launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, Wd, n_dkv, tabs.data(), outs.data(), douts.data(),
+                                   b.skeys_s, b.svals_s, s, b.C, b.dC, pbf)
+              : (void)0));
     if (hp.neighbor_embedding) {
       const float* t1[1] = {m->tabs.tab[n_dkv]};
       float* o1[1] = {b.Wn};
@@ -541,20 +524,6 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
       KR(CAT_EDGE_TABLE, (Pd + 1) * 4.0 * Fd * (want_forces ? 2 : 1) + nt * 12.0 * Fd,
          launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, F, 1, t1, o1, d1, b.skeys_s, b.svals_s, s,
                             n_dkv ? nullptr : b.C, n_dkv ? nullptr : b.dC));
-    }
-    if (tab_side) {
-      HIP_TRY(m, hipEventRecord(m->ev_fork, s));
-      HIP_TRY(m, hipStreamWaitEvent(m->side, m->ev_fork, 0));
-      hipStream_t const s_main = s;
-      for (int l = 0; l < n_dkv; ++l) {
-        hipStream_t const s = m->side;  // (the KR macro records its events on `s`)
-        (void)s_main;
-        KR(CAT_EDGE_TABLE, (Pd + 1) * pB * Wd * (want_forces ? 2 : 1) + nt * 12.0 * Wd,
-           launch_edge_interp(g, P, hp.cutoff_lower, hp.cutoff_upper, m->tabs.T, Wd, 1, &tabs[l], &outs[l], &douts[l], b.skeys_s, b.svals_s, s,
-                              nullptr, nullptr, pbf));
-        HIP_TRY(m, hipEventRecord(m->ev_join[l], s));
-      }
-      tab_joined = 0;
     }
   } else {
     KR(CAT_ELEMENTWISE, Pd * K * 8, launch_radial(g, P, RadialParams{W.means, W.betas, K, hp.cutoff_lower, hp.cutoff_upper}, b.phi, b.dphi, b.C, b.dC, s));
@@ -591,14 +560,12 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     // algorithmic bytes (every distinct tensor once): dkv [P+1, Wd], qkv [N,5F], vec [N,3F] in; xagg [N,F],
     // vagg [N,3F] out; edge indices
     float* const xagg_l = tc ? tc->Ch[l] : b.xagg;  // kept per layer when parameter gradients are wanted
-    ET_TAB_JOIN(l + 1);
     KR(CAT_MESSAGE, (Pd + 1) * Wd * pB + Nd * Fd * 4 * 12 + Ed * 12, launch_et_attn_fwd(g, N, a, xagg_l, b.vagg, s));
     NODE();
     gemm(s, xagg_l, F, q.Wo, F, q.bo, b.o[l], 3 * F, N, 3 * F, F);
     KR(CAT_ELEMENTWISE, Nd * Fd * 4 * 20,
        launch_et_update(b.x[l], b.vec[l], b.vp[l], b.o[l], b.vagg, N, F, b.x[l + 1], b.vec[l + 1], b.vdot[l], s));
   }
-  ET_TAB_JOIN(n_dkv);  // (every layer joined: nothing may be left running on the side stream when this call returns)
   NODE();
   KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_layernorm_fwd(b.x[L], W.lno_w, W.lno_b, N, F, b.xf, b.xfh, b.rstdf, s));
   const int U = F + F2;  // u12 row width: vec1_proj | vec2_proj of head block 0

@@ -169,13 +169,6 @@ struct tmdnet_model {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr;
   std::vector<hipEvent_t> ev_join;
-  // Round 6: the stream always exists.  The per-pair rows from the radial tables (bucket sort + k_edge_interp: pure output streaming,
-  // 0.28 ms at C2, 2.1 ms on ET-SPICE) depend on the pair geometry only and their first reader is layer 0's neighbour sweep, so they
-  // run on `side` beside the embedding / node kernels (issue-bound, HBM stores idle): fork after the graph, join (`ev_tab`, ET: one
-  // `ev_join[l]` per layer) before the first sweep that reads them.  `side_mlp`: TMDNET_SIDE_STREAM=1, the same for the edge MLPs
-  // of the no-table path (opt-in as before); `side_tab`: off with TMDNET_NO_TABLE_SIDE_STREAM=1 (A/B switch).
-  hipEvent_t ev_tab = nullptr;
-  bool side_mlp = false, side_tab = true;
   EtModel* et = nullptr;  // non-null: Equivariant Transformer handle (hp then only carries what the graph phase reads)
   Tn2Model* tn2 = nullptr;  // non-null: TensorNet2 handle (hp carries the shared TensorNet hyper-parameters)
   // geometry of the last graph build (caller-owned device pointers; the TensorNet2 Coulomb head needs positions again)
