@@ -19,7 +19,13 @@ WISH = [
     ["TCC_EA0_RDREQ_LEVEL_sum", "TCC_EA0_RDREQ_LEVEL_avr", "TCC_BUSY_sum", "TCC_CYCLE_sum"],
     ["FETCH_SIZE"],
     ["TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TA_TA_BUSY_sum"],
+    ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_VALU"],
+    ["SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INST_CYCLES_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS"],
+    ["TA_BUSY_avr", "TA_BUSY_max", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TA_TCP_STATE_READ_sum"],
+    ["GRBM_GUI_ACTIVE", "GRBM_COUNT"],
 ]
+if os.environ.get("PASSES"):  # e.g. PASSES=0,4,6,7,8 : a subset of the passes above
+    WISH = [WISH[int(i)] for i in os.environ["PASSES"].split(",")]
 KRE = re.compile(os.environ.get("KREGEX", r"k_message_adjoint_gd|k_message<|k_edge_interp|k_tlin9|k_gemm_sb1"))
 env = dict(os.environ, TMPDIR="/tmp")
 try:

@@ -18,6 +18,10 @@ struct EtAttnArgs {   // per-layer operands of the attention sweeps
   int vector_cutoff;
   int64_t slot_stride;  // reverse target sweep: distance between the per-wave slot arrays of gd2 / gr2 (= 2 (P + 1))
   int pair_bf16;        // 1: dkv / tkv rows are stored as bf16 (option "pair_rows_bf16"): the sweeps read half the bytes
+  // device flag written by launch_et_tile_open: 0 = every row's neighbours lie inside its tile of 64 rows (the tile sweeps of
+  // tn_et_g16.hip run and the row sweeps return at once), else the other way round; null: row sweeps only
+  const int* tile_open;
+  const float* erec;  // [E][8] per-edge records of the tile sweeps (launch_et_tile_prep)
 };
 
 // element `idx` of a per-pair row array kept in fp32 or, in the reduced-precision storage mode, bf16.  Branch-free on purpose:
@@ -51,6 +55,13 @@ void launch_et_train_gpre(const Graph& g, int P, int Wd, const float* slots, int
                           float* g_pre, hipStream_t s);
 void launch_et_train_nbr(const Graph& g, int N, int F, const int64_t* z, const float* embN, const float* Wn, const float* g_xcat,
                          float* slots, int64_t dir_stride, float* gEN, hipStream_t s);
+// third generation of the two attention sweeps (tn_et_g16.hip); et_g16_ok: the layout and the 32-bit offsets apply (P1 = pair rows)
+bool et_g16_ok(int N, int64_t P1, const EtAttnArgs& a);
+// once per step before the first sweep: the closed-tiles flag and the per-edge records (ecap = rows of erec)
+void launch_et_tile_prep(const Graph& g, int N, const float* C, const float* dC, int64_t ecap, int* flag, float* erec, hipStream_t s);
+void launch_et_attn_fwd_g16(const Graph& g, int N, const EtAttnArgs& a, float* xagg, float* vagg, hipStream_t s);
+void launch_et_attn_bwd_g16(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
+                            float* g_vec, float* gd2, float* gr2, hipStream_t s);
 int et_sweep_waves(int F);  // waves per block of the attention sweeps = partial-sum slots per pair direction
 void launch_et_cat_norm(const float* xsrc, int Fx, const float* u, int ldu, int Fn, int N, float* hcat, hipStream_t s);
 void launch_et_norm_bwd(const float* g_n, int ldg, const float* u, int ldu, int Fn, int N, float* g_u, int ldgu, hipStream_t s);

@@ -95,7 +95,7 @@ struct EtEdge {  // what one lane needs for one edge (channel c of the row atom 
 // xagg[t,c] = sum_e sx * A_h ; vagg[t,a,c] = sum_e vec[s,a,c] * s1 + s2 * rhat_a      (torchmd_et.py:376-426)
 __global__ void k_et_attn_fwd(Graph g, EtAttnArgs a, float* __restrict__ xagg, float* __restrict__ vagg) {
   const int t = xcd_chunk(blockIdx.x, gridDim.x);
-  if (g.counts[2]) return;
+  if (g.counts[2] || (a.tile_open && *a.tile_open == 0)) return;  // (closed tiles: the tile sweeps run instead)
   const int F = a.F, hd = a.hd, c = threadIdx.x;
   const bool live = c < F;
   const int cc = live ? c : 0;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void et_fwd_load(const Graph& g, const EtAttnArgs& a,
 template <bool HAS_DK, bool HAS_DV, bool VCUT, int HD, bool BF>
 __global__ void k_et_attn_fwd_p(Graph g, EtAttnArgs a, float* __restrict__ xagg, float* __restrict__ vagg) {
   const int t = xcd_chunk(blockIdx.x, gridDim.x);
-  if (g.counts[2]) return;
+  if (g.counts[2] || (a.tile_open && *a.tile_open == 0)) return;  // (closed tiles: the tile sweeps run instead)
   const int F = a.F, hd = a.hd, c = threadIdx.x;  // blockDim.x == F
   const int e0 = g.rowptr[t], e1 = g.rowptr[t + 1];
   const float qt = a.qkv[(int64_t)t * 5 * F + c];
@@ -255,8 +255,14 @@ static bool et_pipelined_ok(const EtAttnArgs& a) {
   static const bool off = getenv("TMDNET_ET_GENERIC_SWEEPS") != nullptr;  // developer switch: the generic kernels
   return !off && a.F % 64 == 0 && a.F <= 1024 && a.hd <= 16;
 }
-void launch_et_attn_fwd(const Graph& g, int N, const EtAttnArgs& a, float* xagg, float* vagg, hipStream_t s) {
+void launch_et_attn_fwd(const Graph& g, int N, const EtAttnArgs& a_in, float* xagg, float* vagg, hipStream_t s) {
   if (N <= 0) return;
+  // tile sweeps (16-lane groups, two channels per lane, the tile's node rows in LDS: tn_et_g16.hip) when every tile is closed,
+  // the row sweeps below otherwise: the flag lives on the device (no read-back, same launches every step: capturable), the
+  // kernels of the generation that is not wanted return at once
+  EtAttnArgs a = a_in;
+  if (et_g16_ok(N, a.slot_stride / 2, a)) launch_et_attn_fwd_g16(g, N, a, xagg, vagg, s);
+  else a.tile_open = nullptr;
   if (et_pipelined_ok(a)) {
     const dim3 grid(N), block(a.F);
 #define ET_FWD2(DK, DV, VC, BF)                                                                                    \
@@ -374,7 +380,7 @@ __device__ __forceinline__ EtEdge et_edge(const EtAttnArgs& a, float tq, const f
 __global__ void k_et_attn_bwd(Graph g, EtAttnArgs a, const float* __restrict__ g_xagg, const float* __restrict__ g_vagg,
                               float* __restrict__ g_qkv, float* __restrict__ g_vec, float* __restrict__ gd2, float* __restrict__ gr2) {
   const int r = xcd_chunk(blockIdx.x, gridDim.x);
-  if (g.counts[2]) return;
+  if (g.counts[2] || (a.tile_open && *a.tile_open == 0)) return;  // (closed tiles: the tile sweeps run instead)
   const int F = a.F, c = threadIdx.x, lane = c & 63, wave = c >> 6;
   const bool live = c < F;
   const int cc = live ? c : 0;
@@ -525,7 +531,7 @@ __global__ void k_et_attn_bwd_p(Graph g, EtAttnArgs a, const float* __restrict__
                                 float* __restrict__ g_qkv, float* __restrict__ g_vec, float* __restrict__ gd2,
                                 float* __restrict__ gr2) {
   const int r = xcd_chunk(blockIdx.x, gridDim.x);
-  if (g.counts[2]) return;
+  if (g.counts[2] || (a.tile_open && *a.tile_open == 0)) return;  // (closed tiles: the tile sweeps run instead)
   const int F = a.F, c = threadIdx.x, lane = c & 63, wave = c >> 6, hd = a.hd;  // blockDim.x == F
   const int e0 = g.rowptr[r], e1 = g.rowptr[r + 1];
   const int64_t F5 = 5 * (int64_t)F;
@@ -601,9 +607,20 @@ __global__ void k_et_attn_bwd_p(Graph g, EtAttnArgs a, const float* __restrict__
   gv[F] += gvec1;
   gv[2 * F] += gvec2;
 }
-void launch_et_attn_bwd(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
+void launch_et_attn_bwd(const Graph& g, int N, const EtAttnArgs& a_in, const float* g_xagg, const float* g_vagg, float* g_qkv,
                         float* g_vec, float* gd2, float* gr2, hipStream_t s) {
   if (N <= 0) return;
+  EtAttnArgs a = a_in;
+  const bool tiles = et_g16_ok(N, a.slot_stride / 2, a);
+  if (!tiles) a.tile_open = nullptr;
+  {  // the kernels below write one slot array per 64 channels; the caller sums et_sweep_waves(F) of them: the rest are zero
+    const int nw_here = bthreads(a.F) / 64, nw_all = et_sweep_waves(a.F);
+    if (nw_all > nw_here) {
+      launch_fill(gd2 + nw_here * a.slot_stride, 0.f, (nw_all - nw_here) * a.slot_stride, s);
+      launch_fill(gr2 + 3 * nw_here * a.slot_stride, 0.f, 3 * (nw_all - nw_here) * a.slot_stride, s);
+    }
+  }
+  if (tiles) launch_et_attn_bwd_g16(g, N, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2, s);  // (see launch_et_attn_fwd)
   if (et_pipelined_ok(a)) {
     const dim3 grid(N), block(a.F);
 #define ET_BWD2(DK, DV, VC, BF)                                                                                                  \
@@ -761,7 +778,8 @@ void launch_et_add(const float* in, float* out, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_et_axpy, dim3(cdiv_(n, 256)), dim3(256), 0, s, in, out, n);
 }
 
-int et_sweep_waves(int F) { return bthreads(F) / 64; }
+// slot arrays per pair direction of the reverse sweep: one per 32-channel slice (tn_et_g16.hip) or per wave of 64 channels
+int et_sweep_waves(int F) { return F % 32 == 0 ? F / 32 : bthreads(F) / 64; }
 
 
 // ---------------------------------------------------------------------------------------------- parameter gradients

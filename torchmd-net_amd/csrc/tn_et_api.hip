@@ -53,6 +53,8 @@ struct EtBuffers {
   // reverse
   float *g_pre2, *g_h2, *g_w1, *g_vq, *g_y, *g_m1, *g_h1, *g_u12, *g_xf, *g_x, *g_vec, *g_o, *g_vp, *g_xagg, *g_qkv, *g_xt, *g_ln,
       *g_xcat, *gd2, *gr2, *gd, *g_rhat, *g_delta;
+  float* erec = nullptr;     // per-edge records of the tile sweeps
+  int* tile_open = nullptr;  // device flag: some row has a neighbour outside its tile of 64 rows (tn_et_g16.hip)
 };
 
 }  // namespace
@@ -193,6 +195,8 @@ EtBuffers et_carve(void* ws, const tmdnet_et_hparams& hp, int64_t N, int64_t B, 
   b.skeys_s = c.take<unsigned>(P1);
   b.svals_s = c.take<int>(P1);
   b.shist = c.take<int>(65536 + 2);
+  b.tile_open = c.take<int>(64);
+  b.erec = c.take<float>(8 * (2 * P1 + N));
   if (bwd) {
     b.g_pre2 = c.take<float>(N * F2);
     b.g_h2 = c.take<float>(N * F);
@@ -540,6 +544,8 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     KR(CAT_ELEMENTWISE, Nd * Fd * 4, launch_et_embed(z, W.emb, N, F, b.x[0], s));
   }
   KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_fill(b.vec[0], 0.f, (int64_t)N * 3 * F, s));
+  // which generation of the attention sweeps runs (decided on the device) + the per-edge records of the tile sweeps
+  KR(CAT_ELEMENTWISE, Ed * 64, launch_et_tile_prep(g, N, b.C, b.dC, 2 * (int64_t)P1 + N, b.tile_open, b.erec, s));
   std::vector<EtAttnArgs> aa(L);
   for (int l = 0; l < L; ++l) {
     const EtLayerP& q = W.layer[l];
@@ -556,7 +562,7 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     EtAttnArgs& a = aa[l];
     a = EtAttnArgs{b.qkv[l], b.vec[l], b.dkv[l], b.tkv[l], b.C, b.dC, F, hd, Wd,
                    (hp.distance_influence & 1) ? 0 : -1, (hp.distance_influence & 2) ? ((hp.distance_influence & 1) ? F : 0) : -1,
-                   hp.vector_cutoff, 2 * (int64_t)P1, pbf};
+                   hp.vector_cutoff, 2 * (int64_t)P1, pbf, b.tile_open, b.erec};
     // algorithmic bytes (every distinct tensor once): dkv [P+1, Wd], qkv [N,5F], vec [N,3F] in; xagg [N,F],
     // vagg [N,3F] out; edge indices
     float* const xagg_l = tc ? tc->Ch[l] : b.xagg;  // kept per layer when parameter gradients are wanted
