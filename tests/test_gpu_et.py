@@ -168,6 +168,45 @@ def test_et_shape_sweep_vs_oracle(hip_lib, F, H, K, di, ne, vc):
         assert rel_err(Fo[sel.cuda()].cpu(), Fr) < REL, (F, H, K, n_mol)
 
 
+@pytest.mark.parametrize("n_mol,n_atoms,rc,di,vc,H", [
+    (5, 64, 10.0, "both", True, 8),     # dense closed tiles: slot order, the pair rows exchanged through the LDS mailbox
+    (5, 64, 10.0, "keys", False, 4),    # ... one projection only (no exchange), attention cutoff, heads of 32 channels
+    (5, 64, 10.0, "values", True, 16),  # ... heads of 8 channels
+    (5, 64, 10.0, "none", False, 8),    # ... no filter rows at all
+    (7, 32, 5.0, "both", True, 8),      # two molecules per tile, sparse rows: list order; the last tile is half empty
+    (6, 64, 4.0, "both", False, 8),     # closed tiles with short rows (list order), attention cutoff
+    (4, 48, 10.0, "both", True, 8),     # molecules straddle the tiles: the flag sends the step to the row sweeps
+    (3, 100, 6.0, "both", True, 8),     # rows longer than a tile
+])
+def test_et_tile_sweeps_vs_oracle(hip_lib, n_mol, n_atoms, rc, di, vc, H):
+    """The tile generation of the attention sweeps (tn_et_g16.hip: a workgroup = 64 rows x 32 channels, node rows in LDS, slot or
+    list order, the pair rows fetched once and exchanged) and the device-side choice between it and the row sweeps, against
+    oracle/et_torch.py on the first, a middle and the last molecule; fp32 and bf16 pair rows; bit-identical repeats."""
+    from oracle import et_torch as ET
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.C4_ARGS, num_layers=2, num_heads=H, distance_influence=di, vector_cutoff=vc, cutoff_upper=rc)
+    torch.manual_seed(5)
+    model = create_model(dict(args)).to("cuda")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hp = ET.hparams_from_args(args)
+    z, pos, batch = W.synthetic_batch(n_mol=n_mol, n_atoms=n_atoms, first_seed=300)
+    zc, pc, bc = z.cuda(), pos.cuda(), batch.cuda()
+    E, F = model(zc, pc, bc)
+    E2, F2 = model(zc, pc.clone(), bc)
+    assert torch.equal(E, E2) and torch.equal(F, F2)
+    for m in sorted({0, n_mol // 2, n_mol - 1}):
+        sel = batch == m
+        Eo, Fo = ET.energy_and_forces(sd, hp, z[sel], pos[sel], torch.zeros(int(sel.sum()), dtype=torch.long))
+        assert rel_err(E[m].cpu().reshape(1, 1), Eo) < REL, (m, "E")
+        assert rel_err(F[sel.cuda()].cpu(), Fo) < REL, (m, "F")
+    if di != "none":  # bf16 storage of the pair rows: the same kernels with the other row type
+        model.pair_storage = "bf16"
+        Eb, Fb = model(zc, pc, bc)
+        assert rel_err(Eb.cpu(), E.cpu()) < 2e-2 and rel_err(Fb.cpu(), F.cpu()) < 2e-2
+        assert torch.isfinite(Fb).all()
+
+
 def test_et_randomised_small_systems_vs_oracle(hip_lib, golden_dir):
     """single atoms, isolated atoms (only the self loop: vec stays zero -> the norm's zero-row mask), ragged sizes, unsorted
     batch vectors, periodic boxes; oracle = oracle/et_torch.py."""

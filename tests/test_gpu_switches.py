@@ -47,6 +47,13 @@ e = torch.load(os.path.join(G, "et_tiny_ref.pt"))
 m = create_model(dict(e["args"])); m.load_state_dict(e["state_dict"]); m = m.to("cuda")
 E, F = m(e["z"].cuda(), e["pos"].cuda(), e["batch"].cuda())
 assert rel(E.cpu(), e["E"]) < 1e-4 and rel(F.cpu(), e["F"]) < 1e-4, "et"
+# Equivariant Transformer, ET-SPICE hyper-parameters on three 64-atom molecules (closed tiles: the tile sweeps and their switches)
+c4 = torch.load(os.path.join(G, "et_c4_ref.pt"))
+torch.manual_seed(0)
+m = create_model(dict(W.C4_ARGS)).to("cuda")
+z, pos, batch = W.synthetic_batch(n_mol=c4["n_mol"])
+E, F = m(z.cuda(), pos.cuda(), batch.cuda())
+assert rel(E.cpu(), c4["E"]) < 1e-4 and rel(F.cpu(), c4["F"]) < 1e-4, "et c4"
 print("SWITCHES_OK")
 """
 
@@ -66,7 +73,8 @@ SWITCHES = {"TMDNET_NO_MSG_ROWS8": "1", "TMDNET_NO_SPLIT_BF16": "1", "TMDNET_NO_
             "TMDNET_ET_GENERIC_SWEEPS": "1", "TMDNET_SIDE_STREAM": "1", "TMDNET_EI_RUN": "3", "TMDNET_EDGE_DIRECT_MAX": "0",
             "TMDNET_SPLIT_ROWS": "0", "TMDNET_GEMM_BPC": "2", "TMDNET_EDGE_TABLE_MIN_PAIRS": "100000000", "TMDNET_NO_TLIN9": "1",
             "TMDNET_MSG_NOBALANCE": "1", "TMDNET_SMALL_FUSED_MAX": "0", "TMDNET_MID_FUSED_MAX": "0",
-            "TMDNET_NO_ADJ_ROWS8": "1"}
+            "TMDNET_NO_ADJ_ROWS8": "1", "TMDNET_ET_NO_G16": "1", "TMDNET_ET_G16_SYNC": "0", "TMDNET_ET_G16_SLOT_MIN": "0",
+            "TMDNET_ET_G16_NO_MAILBOX": "1"}
 NOT_KERNEL_SWITCHES = {"TMDNET_DEBUG", "TMDNET_REFERENCE_ROOT"}  # error-message verbosity; location of the reference for CPU tests
 COMBOS.update({k.lower(): {k: v} for k, v in SWITCHES.items()})
 

@@ -30,4 +30,14 @@ for storage in ("fp32", "bf16"):
     table = bench.profile_collect(model, L, sp, ncat)
     out[storage] = {"ms_per_step": round(best, 4), "pair_bwd_ms": round(table["pair_bwd"]["ms"], 3), "message_ms": round(table["message"]["ms"], 3),
                     "forces_sha": hashlib.sha1(f.cpu().numpy().tobytes()).hexdigest()[:12], "energy_sha": hashlib.sha1(e.cpu().numpy().tobytes()).hexdigest()[:12]}
+# optional: compare with / leave behind the forces of another setting (REF_NPY: read when it exists, written otherwise)
+ref = os.environ.get("REF_NPY")
+if ref:
+    import numpy as np
+    fa = f.cpu().numpy()
+    if os.path.exists(ref):
+        fr = np.load(ref)
+        out["vs_ref"] = {"max_abs_diff": float(np.abs(fa - fr).max()), "max_abs": float(np.abs(fr).max()), "n_differ": int((fa != fr).sum()), "n": int(fa.size)}
+    else:
+        np.save(ref, fa)
 print(json.dumps(out))

@@ -22,6 +22,7 @@ struct EtAttnArgs {   // per-layer operands of the attention sweeps
   // tn_et_g16.hip run and the row sweeps return at once), else the other way round; null: row sweeps only
   const int* tile_open;
   const float* erec;  // [E][8] per-edge records of the tile sweeps (launch_et_tile_prep)
+  int mailbox;        // set by the launchers of tn_et_g16.hip: the rows of a pair are fetched once per tile and exchanged through LDS
 };
 
 // element `idx` of a per-pair row array kept in fp32 or, in the reduced-precision storage mode, bf16.  Branch-free on purpose:

@@ -16,6 +16,7 @@
 // A lane group owns its row's accumulators in registers (fixed order of edges: deterministic).  The distance / direction slots of
 // the reverse sweep are per 32-channel slice (et_sweep_waves = F / 32 arrays per pair direction).
 #include <cstdlib>
+#include <type_traits>
 
 #include "tn_common.h"
 #include "tn_et.h"
@@ -114,43 +115,52 @@ __device__ __forceinline__ float head_sum2(float v, int hl) {
 // read four atoms (consecutive in the symmetric order): two even, two odd -> the 512 bytes of a ds_read_b64 in two passes (optimal)
 constexpr int G16_ROWS = 64;
 constexpr int G16_V = G16_ROWS * 16;  // f2v elements per value plane
+constexpr int G16_RING = 8;           // steps whose (distance, direction) sums are kept in LDS before they are stored
 
 // the row's edge of step it, clamped to a valid edge when the row has none in that step (nothing is accumulated for it: act = 0).
 //   list order (sparse tiles): the row's list rotated to start at (row + column) mod 64 = 0, step it = its it-th edge;
 //   slot order (tiles at least 3/4 full, WG-uniform choice): step it = the column (it - row) mod 64 of the tile, whether the row has
-//   it or not - the two rows of a pair are then in the SAME step whatever the gaps in their lists, so their requests for the
-//   pair's filter rows meet in the CU's L1 / the XCD's L2 (with list order a missing column shifts the rest of the row by a step
-//   and the L2 holds about two steps of the XCD's traffic: the second request missed, 1.8 x the distinct bytes).
-struct G16Idx {  // the edge's record (k_et_tile_prep): one 32-byte request instead of eight 4-byte ones
+//   it or not - the two rows of a pair are then in the SAME step whatever the gaps in their lists (with list order a missing
+//   column shifts the rest of the row by a step, and the L2 holds about two steps of the XCD's traffic: the partner's request for
+//   the pair's filter rows missed, 1.8 x the distinct bytes).  The slot table lives in LDS: pair, edge number, sign of every tile
+//   column of every row, so nothing of a step's requests depends on another request.
+struct G16Idx {  // the edge's record (k_et_edge_records): one 32-byte request instead of eight 4-byte ones
   int j, p;
   float sg, C, dC, h0, h1, h2;
   int act;
 };
+constexpr int G16_NONE = -1;  // slot table: no such neighbour; else pair (24 bits) | edge number in the row << 24 | (sign < 0) << 30
 struct G16Walk {
   const float* erec;  // [E][8] col | pair | sign | C | dC | prhat
   int e0, e1, len, rot, rl;
-  const unsigned char* tbl;  // LDS: edge number within the row of every tile column, 255 = none (slot order), null: list order
+  const int* tbl;  // LDS slot table (slot order), null: list order
 };
+typedef float f4v_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ G16Idx g16_rec(const G16Walk& w, int e, int act) {
+  const f4v_* rp = reinterpret_cast<const f4v_*>(reinterpret_cast<const char*>(w.erec) + (size_t)((uint32_t)e * 32u));
+  const f4v_ r0 = rp[0], r1 = rp[1];
+  return G16Idx{__float_as_int(r0.x), __float_as_int(r0.y), r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, act};
+}
+__device__ __forceinline__ int g16_slot(const G16Walk& w, int it) {  // slot-table entry of step it
+  return it < G16_ROWS ? w.tbl[w.rl * G16_ROWS + ((it - w.rl) & (G16_ROWS - 1))] : G16_NONE;
+}
 __device__ __forceinline__ G16Idx g16_idx(const Graph& g, int it, const G16Walk& w) {
   int e, act;
   if (w.tbl) {
-    const int k = it < G16_ROWS ? w.tbl[w.rl * G16_ROWS + ((it - w.rl) & (G16_ROWS - 1))] : 255;
-    act = k != 255;
-    e = act ? w.e0 + k : (w.len ? w.e0 : 0);
+    const int t = g16_slot(w, it);
+    act = t != G16_NONE;
+    e = act ? w.e0 + ((t >> 24) & 63) : (w.len ? w.e0 : 0);
   } else {
     e = it + w.rot;
     if (e >= w.e1) e -= w.len;
     act = it < w.len;
     if (!act) e = w.len ? w.e0 : 0;
   }
-  typedef float f4v __attribute__((ext_vector_type(4)));
-  const f4v* rp = reinterpret_cast<const f4v*>(reinterpret_cast<const char*>(w.erec) + (size_t)((uint32_t)e * 32u));
-  const f4v r0 = rp[0], r1 = rp[1];
-  return G16Idx{__float_as_int(r0.x), __float_as_int(r0.y), r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, act};
+  return g16_rec(w, e, act);
 }
 // the walk of a lane group's row; fills the slot table when the tile is dense.  Every thread of the block calls (barriers inside).
-__device__ __forceinline__ G16Walk g16_walk(const Graph& g, const float* erec, int e0, int len, int rr, int rl, int gl, int tile0, int slot_min,
-                                            int* s_max, unsigned char* s_tbl, int& steps) {
+__device__ __forceinline__ G16Walk g16_walk(const Graph& g, const float* erec, int e0, int len, int rr, int rl, int gl, int tile0,
+                                            int slot_min, int* s_max, int* s_tbl, int& steps) {
   G16Walk w;
   w.erec = erec;
   w.e0 = e0;
@@ -160,9 +170,10 @@ __device__ __forceinline__ G16Walk g16_walk(const Graph& g, const float* erec, i
   const int longest = wg_max(len, s_max);
   const bool slot = slot_min > 0 && longest >= slot_min;  // WG-uniform
   if (slot) {
-    for (int k = threadIdx.x; k < G16_ROWS * G16_ROWS / 4; k += blockDim.x) reinterpret_cast<uint32_t*>(s_tbl)[k] = 0xFFFFFFFFu;
+    for (int k = threadIdx.x; k < G16_ROWS * G16_ROWS; k += blockDim.x) s_tbl[k] = G16_NONE;
     __syncthreads();
-    for (int k = gl; k < len; k += 16) s_tbl[rl * G16_ROWS + (g.col[e0 + k] - tile0)] = (unsigned char)k;
+    for (int k = gl; k < len; k += 16)
+      s_tbl[rl * G16_ROWS + (g.col[e0 + k] - tile0)] = g.epair[e0 + k] | (k << 24) | (g.esign[e0 + k] < 0.f ? 1 << 30 : 0);
     __syncthreads();
   }
   w.tbl = slot ? s_tbl : nullptr;
@@ -185,11 +196,17 @@ struct FwdPair {  // what arrives from memory for one edge: the pair's filter ro
 };
 
 template <bool HAS_DK, bool HAS_DV, bool VCUT, int HL, bool BF>
-__global__ __launch_bounds__(1024, 8) void k_et_attn_fwd_g16(Graph g, EtAttnArgs a, int N, int sync_every, int slot_min, float* __restrict__ xagg,
+__global__ __launch_bounds__(1024, BF ? 8 : 4) void k_et_attn_fwd_g16(Graph g, EtAttnArgs a, int N, int sync_every, int slot_min, float* __restrict__ xagg,
                                                           float* __restrict__ vagg) {
   __shared__ __attribute__((aligned(16))) f2v sN[7 * G16_V];  // k | vx | v1 | v2 | vec0 | vec1 | vec2 : 57 344 B
   __shared__ int s_max;
-  __shared__ __attribute__((aligned(16))) unsigned char s_tbl[G16_ROWS * G16_ROWS];
+  __shared__ __attribute__((aligned(16))) int s_tbl[G16_ROWS * G16_ROWS];  // slot table, 16 KB
+  // mailbox of the slot-order walk (see k_et_attn_bwd_g16): the pair's i requests dk | dvx, its j dv1 | dv2; two buffers taking turns.
+  // fp32 rows only: with bf16 rows the exchange measured slower than fetching twice (7.95 vs 8.19 ms per step), and without the
+  // mailbox two workgroups fit a CU (73 KB of LDS, 64 registers)
+  typedef typename std::conditional<BF, uint32_t, f2v>::type HalfT;
+  constexpr bool MB = !BF;
+  __shared__ __attribute__((aligned(16))) HalfT s_mb[MB ? 2 * 4 * G16_V : 4];
   if (g.counts[2] || *a.tile_open) return;
   const int F = a.F, nsl = F >> 5, hl = a.hd >> 1;
   const int tile = (int)blockIdx.x / nsl, sl = (int)blockIdx.x - tile * nsl, tile0 = tile * G16_ROWS;
@@ -252,7 +269,85 @@ __global__ __launch_bounds__(1024, 8) void k_et_attn_fwd_g16(Graph g, EtAttnArgs
     va2 += nb[6 * G16_V] * s1 + s2 * (m * u.h2);
   };
 
-  // two steps per trip, the edges' rows in two register sets that take turns (no copies): rows one step ahead, indices two
+  if (MB && w.tbl && a.mailbox) {
+    // ---- slot order with the exchange: a step's requests depend on the LDS slot table only, four steps ahead of their use (the
+    // sweep has little arithmetic per step: what hides the latency is the distance, not the other waves)
+    struct Step { HalfT h[2]; float C; f4v_ r1; int t; };
+    auto ldh = [&](const float* ubase, OffT off) __attribute__((always_inline)) -> HalfT {
+      if constexpr (BF) return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ubase) + (size_t)off);
+      else return *reinterpret_cast<const f2v*>(reinterpret_cast<const char*>(ubase) + (size_t)off);
+    };
+    auto widen = [&](HalfT x) __attribute__((always_inline)) -> f2v {
+      if constexpr (BF) return f2v{__uint_as_float(x << 16), __uint_as_float(x & 0xffff0000u)};
+      else return x;
+    };
+    {  // the self edge first, on its own (it needs all four rows: no branch around a request inside the loop), then out of the table
+      const int t = s_tbl[rl * G16_ROWS + rl];
+      if (t != G16_NONE) {
+        const G16Idx ix = g16_rec(w, e0 + ((t >> 24) & 63), 1);
+        FwdPair u;
+        rows(ix, u);
+        add(u);
+        s_tbl[rl * G16_ROWS + rl] = G16_NONE;  // (read by this lane group only)
+      }
+    }
+    // the pair's i requests dk | dvx, its j dv1 | dv2 = the same two requests 2 F elements further (the launcher takes this path
+    // only when both projections exist: dk at 0, dvx | dv1 | dv2 at F, 2 F, 3 F of the row)
+    const OffT j_delta = (OffT)(2 * F * esz);
+    auto request = [&](int it, Step& q) __attribute__((always_inline)) {
+      const int t = g16_slot(w, it);
+      q.t = t;
+      const bool act = t != G16_NONE;
+      const int e = act ? e0 + ((t >> 24) & 63) : (len ? e0 : 0);
+      const int p = act ? (t & 0xFFFFFF) : 0;
+      const char* rp = reinterpret_cast<const char*>(a.erec) + (size_t)((uint32_t)e * 32u);
+      q.C = *reinterpret_cast<const float*>(rp + 12);
+      q.r1 = *reinterpret_cast<const f4v_*>(rp + 16);
+      const OffT pr = (OffT)p * rowb + (OffT)(c * esz) + ((t >> 30) & 1 ? j_delta : (OffT)0);
+      q.h[0] = ldh(pdk, pr);
+      q.h[1] = ldh(pdx, pr);
+    };
+    auto finish = [&](int it, const Step& q) __attribute__((always_inline)) {
+      const bool act = q.t != G16_NONE;
+      const int cl = (it - rl) & (G16_ROWS - 1);
+      const bool neg = (q.t >> 30) & 1;
+      HalfT* mb = s_mb + (it & 1) * 4 * G16_V;
+      if (act) {
+        const int o = (neg ? 2 * G16_V : 0) + rl * 16 + gl;
+        mb[o] = q.h[0];
+        mb[G16_V + o] = q.h[1];
+      }
+      __syncthreads();
+      FwdPair u;
+      const int oi = (neg ? cl : rl) * 16 + gl, oj = (neg ? rl : cl) * 16 + gl;
+      u.dk = widen(mb[oi]);
+      u.dvx = widen(mb[1 * G16_V + oi]);
+      u.dv1 = widen(mb[2 * G16_V + oj]);
+      u.dv2 = widen(mb[3 * G16_V + oj]);
+      if (act) {
+        u.C = q.C; u.h0 = q.r1.y; u.h1 = q.r1.z; u.h2 = q.r1.w;
+        u.sg = neg ? -1.f : 1.f;
+        u.j = tile0 + cl; u.act = 1;
+        add(u);
+      }
+    };
+    Step qA, qB, qC, qD;
+    request(0, qA);
+    request(1, qB);
+    request(2, qC);
+    request(3, qD);
+    for (int it = 0; it < steps; it += 4) {  // (steps = 64 in slot order)
+      finish(it, qA);
+      request(it + 4, qA);
+      finish(it + 1, qB);
+      request(it + 5, qB);
+      finish(it + 2, qC);
+      request(it + 6, qC);
+      finish(it + 3, qD);
+      request(it + 7, qD);
+    }
+  } else {
+  // list order: two steps per trip, the edges' rows in two register sets that take turns (no copies): rows one step ahead, indices two
   FwdPair uA, uB;
   G16Idx i1 = {0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
   if (steps > 0) {
@@ -272,6 +367,7 @@ __global__ __launch_bounds__(1024, 8) void k_et_attn_fwd_g16(Graph g, EtAttnArgs
       until_sync = sync_every;
       __syncthreads();
     }
+  }
   }
   if (rowok) {
     *reinterpret_cast<f2v*>(xagg + (int64_t)r * F + c) = xa;
@@ -296,7 +392,17 @@ __global__ __launch_bounds__(1024) void k_et_attn_bwd_g16(Graph g, EtAttnArgs a,
   // q | k | vx | v1 | v2 | vec0..2 | g_xagg | g_vagg0..2 of the tile's 64 atoms: 98 304 B
   __shared__ __attribute__((aligned(16))) f2v sN[12 * G16_V];
   __shared__ int s_max;
-  __shared__ __attribute__((aligned(16))) unsigned char s_tbl[G16_ROWS * G16_ROWS];
+  __shared__ __attribute__((aligned(16))) int s_tbl[G16_ROWS * G16_ROWS];  // slot table, 16 KB
+  // the mailbox of the slot-order walk: the two rows of a pair are in the same step, each requests HALF of the pair's filter rows
+  // (the pair's i: dkv, its j: the tangents tkv) and leaves it here for the other: every row is fetched once per tile.  
+  // one buffer (32 KB: what the 160 KB leave) and two barriers per step.
+  typedef typename std::conditional<BF, uint32_t, f2v>::type HalfT;
+  constexpr int NBUF = 1;
+  constexpr bool MB = !BF;  // (bf16 rows: the exchange measured slower than fetching twice)
+  __shared__ __attribute__((aligned(16))) HalfT s_mb[MB ? NBUF * 4 * G16_V : 4];
+  // the (distance, direction) sums of the last G16_RING steps wait here and leave in one burst: a store between two requests makes
+  // the wait for the older request a wait for everything (loads and stores share one counter and retire out of order)
+  __shared__ float s_ring[MB ? G16_RING * G16_ROWS * 4 : 4];
   if (g.counts[2] || *a.tile_open) return;
   const int F = a.F, nsl = F >> 5, hl = a.hd >> 1;
   const int tile = (int)blockIdx.x / nsl, sl = (int)blockIdx.x - tile * nsl, tile0 = tile * G16_ROWS;
@@ -361,6 +467,7 @@ __global__ __launch_bounds__(1024) void k_et_attn_bwd_g16(Graph g, EtAttnArgs a,
   f2v gq = splat(0.f), gk = splat(0.f), gvx = splat(0.f), gv1 = splat(0.f), gv2 = splat(0.f);
   f2v gvec0 = splat(0.f), gvec1 = splat(0.f), gvec2 = splat(0.f);
   int own_off = rl * 16 + gl;
+  int ring_step = -1;  // >= 0: the step whose sums go to the ring (slot order), -1: stored at once
   auto add = [&](const BwdPair& u) __attribute__((always_inline)) {
     asm volatile("" : "+v"(own_off));  // the row's own values are re-read from LDS every step (22 registers otherwise)
     const f2v* own = sN + own_off;
@@ -388,7 +495,9 @@ __global__ __launch_bounds__(1024) void k_et_attn_bwd_g16(Graph g, EtAttnArgs a,
       if (VCUT) gd += hadd(g_sx * vxj * u.dvx + g_s1 * v1j * u.dv1 + g_s2 * v2j * u.dv2) * u.dC;
       else gd += (head0 ? g_A * sil : 0.f) * u.dC;
       const float tot = grp_sum4(gd, hadd(gr0 * s2), hadd(gr1 * s2), hadd(gr2_ * s2), gl);
-      if (u.sg != 0.f && (gl & 3) == 0) {
+      if (ring_step >= 0) {
+        if ((gl & 3) == 0) s_ring[((ring_step & (G16_RING - 1)) * G16_ROWS + rl) * 4 + (gl >> 2)] = tot;
+      } else if (u.sg != 0.f && (gl & 3) == 0) {
         const int64_t slot = (int64_t)sl * a.slot_stride + 2 * (int64_t)u.p + (u.sg > 0.f ? 0 : 1);
         const int comp = gl >> 2;
         if (comp == 0) gd2[slot] = tot;
@@ -414,6 +523,101 @@ __global__ __launch_bounds__(1024) void k_et_attn_bwd_g16(Graph g, EtAttnArgs a,
       gvec2 += gj2 * s1;
     }
   };
+  if (MB && w.tbl && a.mailbox) {
+    // ---- slot order with the exchange.  The half a lane group requests: the rows of dkv (sign >= 0, the self edge too) or of tkv
+    // (sign < 0), one offset register for both (tkv = dkv + a constant number of bytes, checked by the launcher); it lands in
+    // the group's mailbox row, and both halves are read back from the mailbox rows of the pair's i (dkv) and j (tkv) - no
+    // per-lane selects.  A self edge reads its own dkv rows in place of the tangents: they only feed slots that are not written.
+    const OffT tk_delta = (OffT)(tkvb - dkvb);
+    struct Half { HalfT v[4]; };
+    struct Step { f4v_ r0, r1; Half h; int t; };  // one step's requests: its record, its half rows, its slot-table entry
+    auto ldh = [&](const float* ubase, OffT off) __attribute__((always_inline)) -> HalfT {
+      if constexpr (BF) return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ubase) + (size_t)off);
+      else return *reinterpret_cast<const f2v*>(reinterpret_cast<const char*>(ubase) + (size_t)off);
+    };
+    auto widen = [&](HalfT x) __attribute__((always_inline)) -> f2v {
+      if constexpr (BF) return f2v{__uint_as_float(x << 16), __uint_as_float(x & 0xffff0000u)};
+      else return x;
+    };
+    auto request = [&](int it, Step& q) __attribute__((always_inline)) {
+      const int t = g16_slot(w, it);
+      q.t = t;
+      const bool act = t != G16_NONE;
+      const int e = act ? e0 + ((t >> 24) & 63) : (len ? e0 : 0);
+      const int p = act ? (t & 0xFFFFFF) : 0;
+      const f4v_* rp = reinterpret_cast<const f4v_*>(reinterpret_cast<const char*>(a.erec) + (size_t)((uint32_t)e * 32u));
+      q.r0 = rp[0];
+      q.r1 = rp[1];
+      const OffT pr = (OffT)p * rowb + (OffT)(c * esz) + ((t >> 30) & 1 ? tk_delta : (OffT)0);
+      if (HAS_DK) q.h.v[0] = ldh(pdk, pr);
+      if (HAS_DV) {
+        q.h.v[1] = ldh(pdx, pr);
+        q.h.v[2] = ldh(pd1, pr);
+        q.h.v[3] = ldh(pd2, pr);
+      }
+    };
+    int buf = 0;
+    auto finish = [&](int it, const Step& q) __attribute__((always_inline)) {
+      const bool act = q.t != G16_NONE;
+      const int cl = (it - rl) & (G16_ROWS - 1);  // the partner's row of the tile
+      const bool neg = (q.t >> 30) & 1;
+      HalfT* mb = s_mb + buf * 4 * G16_V;
+      if (act) {  // (a self edge too: its own row is the only one that reads it back)
+#pragma unroll
+        for (int k = HAS_DK ? 0 : 1; k < (HAS_DV ? 4 : 1); ++k) mb[k * G16_V + rl * 16 + gl] = q.h.v[k];
+      }
+      __syncthreads();
+      BwdPair u;
+      {
+        const int od = ((neg ? cl : rl) * 16 + gl), ot = ((neg ? rl : cl) * 16 + gl);
+        const f2v one = splat(1.f), zero = splat(0.f);
+        u.dk = HAS_DK ? widen(mb[od]) : one;
+        u.tk = HAS_DK ? widen(mb[ot]) : zero;
+        u.dvx = HAS_DV ? widen(mb[1 * G16_V + od]) : one;
+        u.dv1 = HAS_DV ? widen(mb[2 * G16_V + od]) : one;
+        u.dv2 = HAS_DV ? widen(mb[3 * G16_V + od]) : one;
+        u.tvx = HAS_DV ? widen(mb[1 * G16_V + ot]) : zero;
+        u.tv1 = HAS_DV ? widen(mb[2 * G16_V + ot]) : zero;
+        u.tv2 = HAS_DV ? widen(mb[3 * G16_V + ot]) : zero;
+      }
+      if (NBUF == 1) __syncthreads();
+      else buf ^= 1;
+      if (act) {
+        u.C = q.r0.w; u.dC = q.r1.x; u.h0 = q.r1.y; u.h1 = q.r1.z; u.h2 = q.r1.w;
+        u.sg = cl == rl ? 0.f : (neg ? -1.f : 1.f);
+        u.j = tile0 + cl; u.p = q.t & 0xFFFFFF; u.act = 1;
+        ring_step = it;
+        add(u);
+      }
+    };
+    auto flush = [&](int last) __attribute__((always_inline)) {  // the ring's steps last - 7 .. last (each lane reads back what it wrote)
+      if ((gl & 3) == 0) {
+        const int comp = gl >> 2;
+#pragma unroll
+        for (int k = 0; k < G16_RING; ++k) {
+          const int st = last - (G16_RING - 1) + k;
+          const int t = g16_slot(w, st);
+          if (t != G16_NONE && ((st - rl) & (G16_ROWS - 1)) != rl) {
+            const float v = s_ring[((st & (G16_RING - 1)) * G16_ROWS + rl) * 4 + comp];
+            const int64_t slot = (int64_t)sl * a.slot_stride + 2 * (int64_t)(t & 0xFFFFFF) + ((t >> 30) & 1);
+            if (comp == 0) gd2[slot] = v;
+            else gr2[slot * 3 + comp - 1] = v;
+          }
+        }
+      }
+    };
+    // two steps per trip, two request sets taking turns (no copies): everything of step it + 1 is requested before step it's
+    // exchange and arithmetic
+    Step qA, qB;
+    request(0, qA);
+    for (int it = 0; it < steps; it += 2) {
+      request(it + 1, qB);
+      finish(it, qA);
+      request(it + 2, qA);
+      finish(it + 1, qB);
+      if (((it + 2) & (G16_RING - 1)) == 0) flush(it + 1);
+    }
+  } else {
   BwdPair uA, uB;
   G16Idx i1 = {0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
   if (steps > 0) {
@@ -433,6 +637,7 @@ __global__ __launch_bounds__(1024) void k_et_attn_bwd_g16(Graph g, EtAttnArgs a,
       until_sync = sync_every;
       __syncthreads();
     }
+  }
   }
   if (rowok) {
     float* o = g_qkv + (int64_t)r * 5 * F + c;
@@ -473,6 +678,10 @@ __global__ void k_et_edge_records(Graph g, const float* __restrict__ C, const fl
 int g16_sync_every() {
   static const int v = getenv("TMDNET_ET_G16_SYNC") ? atoi(getenv("TMDNET_ET_G16_SYNC")) : 4;
   return v;
+}
+bool g16_mailbox() {  // developer switch: every lane group requests all rows of its pair (no exchange)
+  static const bool off = getenv("TMDNET_ET_G16_NO_MAILBOX") != nullptr;
+  return !off;
 }
 int g16_slot_min() {  // slot order from this row length on (0: list order always)
   static const int v = getenv("TMDNET_ET_G16_SLOT_MIN") ? atoi(getenv("TMDNET_ET_G16_SLOT_MIN")) : 48;
@@ -525,13 +734,21 @@ void launch_et_tile_prep(const Graph& g, int N, const float* C, const float* dC,
   hipLaunchKernelGGL(k_et_tile_open, dim3((N + 255) / 256), dim3(256), 0, s, g, N, flag);
   hipLaunchKernelGGL(k_et_edge_records, dim3((unsigned)((ecap + 255) / 256)), dim3(256), 0, s, g, C, dC, ecap, erec);
 }
-void launch_et_attn_fwd_g16(const Graph& g, int N, const EtAttnArgs& a, float* xagg, float* vagg, hipStream_t s) {
+void launch_et_attn_fwd_g16(const Graph& g, int N, const EtAttnArgs& a_in, float* xagg, float* vagg, hipStream_t s) {
   if (N <= 0) return;
+  EtAttnArgs a = a_in;
+  a.mailbox = (g16_mailbox() && !a.pair_bf16 && a.dk_off == 0 && a.dv_off == a.F) ? 1 : 0;
   G16_DISPATCH(k_et_attn_fwd_g16, xagg, vagg)
 }
-void launch_et_attn_bwd_g16(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
+void launch_et_attn_bwd_g16(const Graph& g, int N, const EtAttnArgs& a_in, const float* g_xagg, const float* g_vagg, float* g_qkv,
                             float* g_vec, float* gd2, float* gr2, hipStream_t s) {
   if (N <= 0) return;
+  EtAttnArgs a = a_in;
+  {  // the exchange addresses tkv as dkv + a 32-bit byte offset
+    const int64_t delta = reinterpret_cast<const char*>(a.tkv) - reinterpret_cast<const char*>(a.dkv);
+    const int64_t rows_b = (a.slot_stride / 2) * (int64_t)a.Wd * (a.pair_bf16 ? 2 : 4);
+    a.mailbox = (g16_mailbox() && !a.pair_bf16 && delta >= 0 && delta + rows_b < ((int64_t)1 << 32)) ? 1 : 0;  // (bf16 rows: see the forward kernel)
+  }
   G16_DISPATCH(k_et_attn_bwd_g16, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2)
 }
 
