@@ -334,7 +334,9 @@ def et_c4_leg(dev, L, steps=8, warmup=3, pair_storage="fp32"):
                      "f32 arithmetic, per-pair filter rows stored as bf16 (pair_storage='bf16': <= 2e-3 rel. vs the fp32 oracle, tests/test_gpu_et.py)",
             "pairs": model._engine.counts[0],
             "roofline": with_aux_traffic(roofline_of(rec, cls, label, note_kernel=ET_KERNEL_OF.get(cls)),
-                                         [(ET_KERNEL_OF.get(cls, "k_et_attn_bwd") + "_p<", "true>" if pair_storage == "bf16" else "false>")]),
+                                         # the tile sweeps (tn_et_g16.hip) run on this batch; the row sweeps' name for older summaries
+                                         [("g16::" + ET_KERNEL_OF.get(cls, "k_et_attn_bwd") + "_g16<", "true>" if pair_storage == "bf16" else "false>"),
+                                          (ET_KERNEL_OF.get(cls, "k_et_attn_bwd") + "_p<", "true>" if pair_storage == "bf16" else "false>")]),
             "classes_ms": {k: round(v["ms"], 3) for k, v in classes.items() if v["launches"]}}
 
 

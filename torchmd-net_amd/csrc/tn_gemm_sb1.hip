@@ -208,6 +208,130 @@ __global__ __launch_bounds__(256, 3) void k_gemm_sb1(GemmArgs a, int tiles_m, in
   }  // tile loop
 }
 
+
+// ---- half tiles (round 6): 64 x 64 outputs per block for launches with fewer 128 x 128 tiles than CUs (N <= 128 at M = 16 384:
+// 128 tiles on 256 CUs), so that every CU works.
+// Waves 0, 1 stage A (row, k-half: two 16-byte loads, split), waves 2, 3 stage W (three 16-byte loads of the fragment image,
+// copied): one instruction stream, the roles differ in pointers and in a branch around arithmetic only.
+constexpr int SBH_PLANE = 64 * 32;        // one bf16 plane of a [64 rows][16 k] chunk
+constexpr int SBH_STAGE = 6 * SBH_PLANE;  // 12 KB
+
+template <int EPI>
+__global__ __launch_bounds__(256, 6) void k_gemm_sb1h(GemmArgs a, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SBH_STAGE];  // 24 KB (the epilogue's 4 x 4 KB alias it)
+  const int total = tiles_m * tiles_n * a.groups;
+  int M = a.M;
+  if (a.m_dev) {
+    const int md = *a.m_dev + a.m_add;
+    M = md < M ? md : M;
+  }
+  const int N = a.N, K = a.K;
+  const int nk = K >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool role_a = wave_u < 2;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int st = tid & 127, srow = st >> 1, skh = st & 1;  // staging role: row (A) / column (W) of the tile, k-half
+  const int soff = (role_a ? 0 : 3 * SBH_PLANE) + sb_piece(srow, skh);
+  const int ra_ = wm * 32 + (lane & 31), rb_ = wn * 32 + (lane & 31), kh = lane >> 5;
+  const int foa = sb_piece(ra_, kh);
+  const int fob = 3 * SBH_PLANE + sb_piece(rb_, kh);
+
+  for (int vt = blockIdx.x; vt < total; vt += gridDim.x) {
+    const int t = xcd_chunk(vt, total);
+    const int tn_ = t % tiles_n, tg = t / tiles_n;
+    const int g = tg % a.groups, tm = tg / a.groups;
+    const int m0 = tm * 64, n0 = tn_ * 64;
+    if (m0 >= M || n0 >= N) continue;
+    __syncthreads();  // the previous tile's epilogue region / last chunk may still be in use by a slower wave
+    const int grow = (m0 + srow < M) ? m0 + srow : 0;  // rows past M: any valid row (their outputs are not stored)
+    // three 16-byte pieces per thread and chunk: A: 8 consecutive k of a row (two pieces, the third a repeat); W: the h / m / l
+    // pieces of (column, k-half) in the fragment image (768 uint4 per 128-column tile and chunk, plane stride 256)
+    const float4* p0;
+    int64_t step0, d1, d2;  // distance between chunks, and of pieces 1, 2 from piece 0 (in float4)
+    if (role_a) {
+      p0 = reinterpret_cast<const float4*>(a.A + a.a_off[g] + (int64_t)grow * a.lda + skh * 8);
+      step0 = 4; d1 = 1; d2 = 0;
+    } else {
+      p0 = reinterpret_cast<const float4*>(a.Wsbg[g]) + (int64_t)(n0 >> 7) * nk * 768 + ((n0 & 64) + srow) * 2 + skh;
+      step0 = 768; d1 = 256; d2 = 512;
+    }
+    float4 r0, r1, r2;
+#define SBH_FETCH(kt)           \
+  r0 = p0[(kt) * step0];        \
+  r1 = p0[(kt) * step0 + d1];   \
+  r2 = p0[(kt) * step0 + d2];
+#define SBH_PUT(buf)                                                                       \
+  {                                                                                        \
+    uint4 h, m, l;                                                                         \
+    if (role_a) split8(r0, r1, h, m, l);                                                   \
+    else {                                                                                 \
+      h = *reinterpret_cast<uint4*>(&r0); m = *reinterpret_cast<uint4*>(&r1); l = *reinterpret_cast<uint4*>(&r2); \
+    }                                                                                      \
+    *reinterpret_cast<uint4*>((buf) + 0 * SBH_PLANE + soff) = h;                           \
+    *reinterpret_cast<uint4*>((buf) + 1 * SBH_PLANE + soff) = m;                           \
+    *reinterpret_cast<uint4*>((buf) + 2 * SBH_PLANE + soff) = l;                           \
+  }
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    SBH_FETCH(0)
+    SBH_PUT(smem)
+    if (nk > 1) { SBH_FETCH(1) }
+    __syncthreads();
+#define SBH_MMA(cur)                                                                                       \
+  {                                                                                                        \
+    bf16x8 af[3], bf[3];                                                                                   \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                        \
+      af[p] = *reinterpret_cast<const bf16x8*>((cur) + foa + p * SBH_PLANE);                               \
+      bf[p] = *reinterpret_cast<const bf16x8*>((cur) + fob + p * SBH_PLANE);                               \
+    }                                                                                                      \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc, 0, 0, 0);                             \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc, 0, 0, 0);                             \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc, 0, 0, 0);                             \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc, 0, 0, 0);                             \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc, 0, 0, 0);                             \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc, 0, 0, 0);                             \
+  }
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      const unsigned char* cur = smem + (kt & 1) * SBH_STAGE;
+      unsigned char* nxt = smem + ((kt + 1) & 1) * SBH_STAGE;
+      const int kf = (kt + 2 < nk) ? kt + 2 : nk - 1;
+      SBH_PUT(nxt)       // chunk kt + 1 (registers) -> the other buffer
+      SBH_FETCH(kf)      // chunk kt + 2 on its way
+      SBH_MMA(cur)
+      __syncthreads();
+    }
+    SBH_MMA(smem + ((nk - 1) & 1) * SBH_STAGE)
+#undef SBH_MMA
+#undef SBH_PUT
+#undef SBH_FETCH
+
+    // epilogue through wave-private LDS (4 KB per wave): 16 bytes per lane, 8 rows x 128 contiguous bytes per access
+    __syncthreads();  // every wave is done reading the last chunk
+    float* xv = reinterpret_cast<float*>(smem) + wave * 1024;
+    float* Cg = a.C + a.c_off[g];
+    float* preg = a.pre ? a.pre + a.pre_off[g] : nullptr;
+    const float* auxg = a.aux ? a.aux + a.aux_off[g] : nullptr;
+    const int cb = n0 + wn * 32, rb = m0 + wm * 32;
+    const int col = cb + (lane & 31);
+    const float bv = (a.bias[g] && col < N) ? a.bias[g][col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      xv[rl * 32 + (lane & 31)] = acc[e] + bv;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int rl = rr * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(xv + rl * 32 + c4);
+      const int row = rb + rl;
+      if (row < M && cb + c4 < N)  // N % 4 == 0 (gemm_sb1_ok)
+        *reinterpret_cast<float4*>(Cg + (int64_t)row * a.ldc + cb + c4) = epi4<EPI>(a, Cg, preg, auxg, row, cb + c4, v);
+    }
+  }  // tile loop
+}
+
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 bool gemm_sb1_ok(const GemmArgs& a) {
@@ -232,6 +356,23 @@ int launch_gemm_sb1(const GemmArgs& a, hipStream_t stream) {
   }();
   const int total = tiles_m * tiles_n * a.groups;
   static const int bpc = getenv("TMDNET_GEMM_BPC") ? atoi(getenv("TMDNET_GEMM_BPC")) : 3;  // developer switch
+  // fewer 128 x 128 tiles than CUs (N <= 128 at M = 16 384): 64 x 64 tiles, every CU busy (22.9 -> 19.1 us for 16384 x 128 x 384;
+  // from one tile per CU on the two kernels measure the same: these launches are at their streaming floor, ~3.8 TB/s of operands
+  // and both outputs behind a 3 - 4 us launch).  Developer switch TMDNET_GEMM_HALF_BELOW: tiles per CU below which it is taken, 0 = never.
+  static const int half_below = getenv("TMDNET_GEMM_HALF_BELOW") ? atoi(getenv("TMDNET_GEMM_HALF_BELOW")) : 1;
+  if (total < half_below * n_cu) {
+    const int hm = (a.M + 63) / 64, hn = (a.N + 63) / 64;
+    const int htotal = hm * hn * a.groups;
+    const dim3 hgrid(htotal < 6 * n_cu ? htotal : 6 * n_cu), block(256);
+    switch (epi_kind(a)) {
+      case EPI_PLAIN: hipLaunchKernelGGL((k_gemm_sb1h<EPI_PLAIN>), hgrid, block, 0, stream, a, hm, hn); break;
+      case EPI_SILU_PRE: hipLaunchKernelGGL((k_gemm_sb1h<EPI_SILU_PRE>), hgrid, block, 0, stream, a, hm, hn); break;
+      case EPI_MULAUX_PRE: hipLaunchKernelGGL((k_gemm_sb1h<EPI_MULAUX_PRE>), hgrid, block, 0, stream, a, hm, hn); break;
+      case EPI_MULDSILU: hipLaunchKernelGGL((k_gemm_sb1h<EPI_MULDSILU>), hgrid, block, 0, stream, a, hm, hn); break;
+      default: hipLaunchKernelGGL((k_gemm_sb1h<EPI_GENERIC>), hgrid, block, 0, stream, a, hm, hn); break;
+    }
+    return (int)hipGetLastError();
+  }
   const dim3 grid(total < bpc * n_cu ? total : bpc * n_cu), block(256);  // persistent: 3 blocks per CU
   switch (epi_kind(a)) {
     case EPI_PLAIN: hipLaunchKernelGGL((k_gemm_sb1<EPI_PLAIN>), grid, block, 0, stream, a, tiles_m, tiles_n); break;
