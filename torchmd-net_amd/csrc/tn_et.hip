@@ -446,6 +446,16 @@ __global__ void k_et_attn_bwd(Graph g, EtAttnArgs a, const float* __restrict__ g
         const int comp = lane >> 4;
         if (comp == 0) gd2[slot] = tot;
         else gr2[slot * 3 + comp - 1] = tot;
+        // the caller sums et_sweep_waves(F) slot arrays per pair direction (one per 32 channels: the tile sweeps' count); this
+        // sweep fills one per 64 channels - the last wave of the row zeroes the others' entries of this (pair, direction)
+        if (wave == (int)(blockDim.x >> 6) - 1) {
+          const int nw_all = (F % 32 == 0) ? F / 32 : (int)(blockDim.x >> 6);
+          for (int ws = (int)(blockDim.x >> 6); ws < nw_all; ++ws) {
+            const int64_t sz = slot + (int64_t)(ws - wave) * a.slot_stride;
+            if (comp == 0) gd2[sz] = 0.f;
+            else gr2[sz * 3 + comp - 1] = 0.f;
+          }
+        }
       }
     }
     // ---- role SOURCE: message r -> j
@@ -577,6 +587,16 @@ __global__ void k_et_attn_bwd_p(Graph g, EtAttnArgs a, const float* __restrict__
         const int comp = lane >> 4;
         if (comp == 0) gd2[slot] = tot;
         else gr2[slot * 3 + comp - 1] = tot;
+        // the caller sums et_sweep_waves(F) slot arrays per pair direction (one per 32 channels: the tile sweeps' count); this
+        // sweep fills one per 64 channels - the last wave of the row zeroes the others' entries of this (pair, direction)
+        if (wave == (int)(blockDim.x >> 6) - 1) {
+          const int nw_all = (F % 32 == 0) ? F / 32 : (int)(blockDim.x >> 6);
+          for (int ws = (int)(blockDim.x >> 6); ws < nw_all; ++ws) {
+            const int64_t sz = slot + (int64_t)(ws - wave) * a.slot_stride;
+            if (comp == 0) gd2[sz] = 0.f;
+            else gr2[sz * 3 + comp - 1] = 0.f;
+          }
+        }
       }
     }
     // ---- role SOURCE: message r -> j
@@ -613,13 +633,7 @@ void launch_et_attn_bwd(const Graph& g, int N, const EtAttnArgs& a_in, const flo
   EtAttnArgs a = a_in;
   const bool tiles = et_g16_ok(N, a.slot_stride / 2, a);
   if (!tiles) a.tile_open = nullptr;
-  {  // the kernels below write one slot array per 64 channels; the caller sums et_sweep_waves(F) of them: the rest are zero
-    const int nw_here = bthreads(a.F) / 64, nw_all = et_sweep_waves(a.F);
-    if (nw_all > nw_here) {
-      launch_fill(gd2 + nw_here * a.slot_stride, 0.f, (nw_all - nw_here) * a.slot_stride, s);
-      launch_fill(gr2 + 3 * nw_here * a.slot_stride, 0.f, 3 * (nw_all - nw_here) * a.slot_stride, s);
-    }
-  }
+  // (the row sweeps below write one slot array per 64 channels and zero the remaining et_sweep_waves(F) - F / 64 themselves)
   if (tiles) launch_et_attn_bwd_g16(g, N, a, g_xagg, g_vagg, g_qkv, g_vec, gd2, gr2, s);  // (see launch_et_attn_fwd)
   if (et_pipelined_ok(a)) {
     const dim3 grid(N), block(a.F);
