@@ -177,6 +177,8 @@ def test_et_shape_sweep_vs_oracle(hip_lib, F, H, K, di, ne, vc):
     (6, 64, 4.0, "both", False, 8),     # closed tiles with short rows (list order), attention cutoff
     (4, 48, 10.0, "both", True, 8),     # molecules straddle the tiles: the flag sends the step to the row sweeps
     (3, 100, 6.0, "both", True, 8),     # rows longer than a tile
+    (9, 40, 10.0, "both", True, 8),     # one 40-atom molecule per tile (tiles = runs of whole molecules <= 64 rows), slot order off
+    (11, 21, 10.0, "both", False, 8),   # three molecules per tile, dense inside a molecule, list order
 ])
 def test_et_tile_sweeps_vs_oracle(hip_lib, n_mol, n_atoms, rc, di, vc, H):
     """The tile generation of the attention sweeps (tn_et_g16.hip: a workgroup = 64 rows x 32 channels, node rows in LDS, slot or
@@ -205,6 +207,38 @@ def test_et_tile_sweeps_vs_oracle(hip_lib, n_mol, n_atoms, rc, di, vc, H):
         Eb, Fb = model(zc, pc, bc)
         assert rel_err(Eb.cpu(), E.cpu()) < 2e-2 and rel_err(Fb.cpu(), F.cpu()) < 2e-2
         assert torch.isfinite(Fb).all()
+
+
+def test_et_tile_sweeps_ragged_batch_vs_oracle(hip_lib):
+    """Molecules of different sizes (1 .. 64 atoms, two of 70: those open the tiles and send the step to the row sweeps) in one
+    batch: the tiles are packed from whole molecules on the device; every molecule against oracle/et_torch.py."""
+    import numpy as np
+    from oracle import et_torch as ET
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.C4_ARGS, num_layers=2)
+    torch.manual_seed(9)
+    model = create_model(dict(args)).to("cuda")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    hp = ET.hparams_from_args(args)
+    rng = np.random.default_rng(3)
+    # (sizes, what the device decides): dense closed tiles -> tile sweeps; closed but half empty -> row sweeps (the fill rule of
+    # k_et_tile_pack); molecules of more than 64 atoms -> open -> row sweeps
+    for sizes, want_tiles in (([64, 30, 34, 64, 20, 44, 64], True), ([64, 1, 17, 40, 33, 31, 2, 64, 5, 59, 64, 12], False),
+                              ([20, 70, 8, 70, 3], False)):
+        zs, ps, bs = [], [], []
+        for m, n in enumerate(sizes):
+            z, pos, _ = W.synthetic_batch(n_mol=1, n_atoms=n, first_seed=500 + m)
+            zs.append(z); ps.append(pos); bs.append(torch.full((n,), m, dtype=torch.long))
+        z, pos, batch = torch.cat(zs), torch.cat(ps), torch.cat(bs)
+        E, F = model(z.cuda(), pos.cuda(), batch.cuda())
+        meta = model.debug_tensor("tile_meta", (2,)).view(torch.int32).cpu().tolist()  # [tiles open?, number of tiles]
+        assert (meta[0] == 0) == want_tiles and (not want_tiles or 0 < meta[1] <= len(sizes)), (sizes, meta)
+        for m in range(len(sizes)):
+            sel = batch == m
+            Eo, Fo = ET.energy_and_forces(sd, hp, z[sel], pos[sel], torch.zeros(int(sel.sum()), dtype=torch.long))
+            assert abs(E[m].item() - Eo.item()) < 1e-4 * max(1.0, abs(Eo.item())), (sizes, m)
+            assert (F[sel.cuda()].cpu() - Fo).abs().max().item() < 1e-4 * max(1.0, Fo.abs().max().item()), (sizes, m)
 
 
 def test_et_randomised_small_systems_vs_oracle(hip_lib, golden_dir):

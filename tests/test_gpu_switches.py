@@ -74,7 +74,8 @@ SWITCHES = {"TMDNET_NO_MSG_ROWS8": "1", "TMDNET_NO_SPLIT_BF16": "1", "TMDNET_NO_
             "TMDNET_SPLIT_ROWS": "0", "TMDNET_GEMM_BPC": "2", "TMDNET_EDGE_TABLE_MIN_PAIRS": "100000000", "TMDNET_NO_TLIN9": "1",
             "TMDNET_MSG_NOBALANCE": "1", "TMDNET_SMALL_FUSED_MAX": "0", "TMDNET_MID_FUSED_MAX": "0",
             "TMDNET_NO_ADJ_ROWS8": "1", "TMDNET_ET_NO_G16": "1", "TMDNET_ET_G16_SYNC": "0", "TMDNET_ET_G16_SLOT_MIN": "0",
-            "TMDNET_ET_G16_NO_MAILBOX": "1", "TMDNET_GEMM_HALF_BELOW": "0"}
+            "TMDNET_ET_G16_NO_MAILBOX": "1", "TMDNET_GEMM_HALF_BELOW": "0",
+            "TMDNET_ET_G16_MIN_FILL": "0"}
 NOT_KERNEL_SWITCHES = {"TMDNET_DEBUG", "TMDNET_REFERENCE_ROOT"}  # error-message verbosity; location of the reference for CPU tests
 COMBOS.update({k.lower(): {k: v} for k, v in SWITCHES.items()})
 

@@ -9,13 +9,26 @@ from torchmdnet_amd import _C, workloads as W
 from torchmdnet_amd.models.model import create_model
 import bench
 out = {"env": {k: v for k, v in os.environ.items() if k.startswith("TMDNET_ET_")}}
-z, pos, batch = (t.cuda() for t in W.synthetic_batch(n_mol=256))
+if os.environ.get("RAGGED"):  # molecules of 10 .. 64 atoms (uniform), about 16 384 atoms in all: a SPICE-like batch
+    import numpy as np
+    rng = np.random.default_rng(0)
+    zs, ps, bs, tot, m = [], [], [], 0, 0
+    while tot < 16384:
+        n = int(rng.integers(10, 65))
+        zz, pp, _ = W.synthetic_batch(n_mol=1, n_atoms=n, first_seed=1000 + m)
+        zs.append(zz); ps.append(pp); bs.append(torch.full((n,), m, dtype=torch.long)); tot += n; m += 1
+    z, pos, batch = torch.cat(zs).cuda(), torch.cat(ps).cuda(), torch.cat(bs).cuda()
+    N_MOL = m
+    out["ragged"] = {"molecules": m, "atoms": tot}
+else:
+    z, pos, batch = (t.cuda() for t in W.synthetic_batch(n_mol=256))
+    N_MOL = 256
 L = _C.lib()
 for storage in ("fp32", "bf16"):
     torch.manual_seed(0)
     model = create_model(dict(W.C4_ARGS)).to("cuda")
     model.pair_storage = storage
-    step = lambda: model.energy_and_forces(z, pos, batch, None, None, 256)
+    step = lambda: model.energy_and_forces(z, pos, batch, None, None, N_MOL)
     for _ in range(3): step()
     torch.cuda.synchronize()
     best = 1e9

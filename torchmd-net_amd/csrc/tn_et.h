@@ -18,9 +18,12 @@ struct EtAttnArgs {   // per-layer operands of the attention sweeps
   int vector_cutoff;
   int64_t slot_stride;  // reverse target sweep: distance between the per-wave slot arrays of gd2 / gr2 (= 2 (P + 1))
   int pair_bf16;        // 1: dkv / tkv rows are stored as bf16 (option "pair_rows_bf16"): the sweeps read half the bytes
-  // device flag written by launch_et_tile_open: 0 = every row's neighbours lie inside its tile of 64 rows (the tile sweeps of
-  // tn_et_g16.hip run and the row sweeps return at once), else the other way round; null: row sweeps only
+  // written on the device by launch_et_tile_prep: tile_open[0] = 0: every row's neighbours lie inside its tile (the tile sweeps of
+  // tn_et_g16.hip run and the row sweeps return at once), else the other way round; tile_open[1] = number of tiles; null: row
+  // sweeps only.  Tiles = runs of whole molecules of at most 64 rows: rows tile_start[t] .. tile_start[t + 1]
   const int* tile_open;
+  const int* tile_start;
+  int max_tiles;      // the tile sweeps' grids cover this many tiles (et_g16_max_tiles)
   const float* erec;  // [E][8] per-edge records of the tile sweeps (launch_et_tile_prep)
   int mailbox;        // set by the launchers of tn_et_g16.hip: the rows of a pair are fetched once per tile and exchanged through LDS
 };
@@ -59,7 +62,9 @@ void launch_et_train_nbr(const Graph& g, int N, int F, const int64_t* z, const f
 // third generation of the two attention sweeps (tn_et_g16.hip); et_g16_ok: the layout and the 32-bit offsets apply (P1 = pair rows)
 bool et_g16_ok(int N, int64_t P1, const EtAttnArgs& a);
 // once per step before the first sweep: the closed-tiles flag and the per-edge records (ecap = rows of erec)
-void launch_et_tile_prep(const Graph& g, int N, const float* C, const float* dC, int64_t ecap, int* flag, float* erec, hipStream_t s);
+void launch_et_tile_prep(const Graph& g, int N, int B, const int64_t* batch, const float* C, const float* dC, int64_t ecap, int pair_bf16,
+                         int* meta, int* tile_start, float* erec, hipStream_t s);
+int et_g16_max_tiles(int N, int B);
 void launch_et_attn_fwd_g16(const Graph& g, int N, const EtAttnArgs& a, float* xagg, float* vagg, hipStream_t s);
 void launch_et_attn_bwd_g16(const Graph& g, int N, const EtAttnArgs& a, const float* g_xagg, const float* g_vagg, float* g_qkv,
                             float* g_vec, float* gd2, float* gr2, hipStream_t s);

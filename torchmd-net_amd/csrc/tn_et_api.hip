@@ -54,6 +54,7 @@ struct EtBuffers {
   float *g_pre2, *g_h2, *g_w1, *g_vq, *g_y, *g_m1, *g_h1, *g_u12, *g_xf, *g_x, *g_vec, *g_o, *g_vp, *g_xagg, *g_qkv, *g_xt, *g_ln,
       *g_xcat, *gd2, *gr2, *gd, *g_rhat, *g_delta;
   float* erec = nullptr;     // per-edge records of the tile sweeps
+  int* tile_start = nullptr;  // [tiles + 1] first row of every tile of the tile sweeps
   int* tile_open = nullptr;  // device flag: some row has a neighbour outside its tile of 64 rows (tn_et_g16.hip)
 };
 
@@ -196,6 +197,7 @@ EtBuffers et_carve(void* ws, const tmdnet_et_hparams& hp, int64_t N, int64_t B, 
   b.svals_s = c.take<int>(P1);
   b.shist = c.take<int>(65536 + 2);
   b.tile_open = c.take<int>(64);
+  b.tile_start = c.take<int>(N + 8);
   b.erec = c.take<float>(8 * (2 * P1 + N));
   if (bwd) {
     b.g_pre2 = c.take<float>(N * F2);
@@ -545,7 +547,7 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
   }
   KR(CAT_ELEMENTWISE, Nd * Fd * 12, launch_fill(b.vec[0], 0.f, (int64_t)N * 3 * F, s));
   // which generation of the attention sweeps runs (decided on the device) + the per-edge records of the tile sweeps
-  KR(CAT_ELEMENTWISE, Ed * 64, launch_et_tile_prep(g, N, b.C, b.dC, 2 * (int64_t)P1 + N, b.tile_open, b.erec, s));
+  KR(CAT_ELEMENTWISE, Ed * 64, launch_et_tile_prep(g, N, B, batch, b.C, b.dC, 2 * (int64_t)P1 + N, pbf, b.tile_open, b.tile_start, b.erec, s));
   std::vector<EtAttnArgs> aa(L);
   for (int l = 0; l < L; ++l) {
     const EtLayerP& q = W.layer[l];
@@ -562,7 +564,7 @@ int et_energy_forces(tmdnet_model* m, hipStream_t s, const Graph& g, void* ws, s
     EtAttnArgs& a = aa[l];
     a = EtAttnArgs{b.qkv[l], b.vec[l], b.dkv[l], b.tkv[l], b.C, b.dC, F, hd, Wd,
                    (hp.distance_influence & 1) ? 0 : -1, (hp.distance_influence & 2) ? ((hp.distance_influence & 1) ? F : 0) : -1,
-                   hp.vector_cutoff, 2 * (int64_t)P1, pbf, b.tile_open, b.erec};
+                   hp.vector_cutoff, 2 * (int64_t)P1, pbf, b.tile_open, b.tile_start, et_g16_max_tiles(N, B), b.erec};
     // algorithmic bytes (every distinct tensor once): dkv [P+1, Wd], qkv [N,5F], vec [N,3F] in; xagg [N,F],
     // vagg [N,3F] out; edge indices
     float* const xagg_l = tc ? tc->Ch[l] : b.xagg;  // kept per layer when parameter gradients are wanted
@@ -727,6 +729,7 @@ int et_debug_tensor(tmdnet_model* m, hipStream_t s, const char* name, float* out
   else if (nm == "x_out") src = b.xf, n = N * F;
   else if (nm == "g_x") src = b.g_x, n = N * F;
   else if (nm == "g_vec") src = b.g_vec, n = N * 3 * F;
+  else if (nm == "tile_meta") src = reinterpret_cast<const float*>(b.tile_open), n = 2;  // int bits: [0] open flag, [1] number of tiles (tn_et_g16.hip)
   else if (nm.rfind("x_layer", 0) == 0 || nm.rfind("vec_layer", 0) == 0) {
     const bool isx = nm[0] == 'x';
     const int l = std::atoi(nm.c_str() + (isx ? 7 : 9));

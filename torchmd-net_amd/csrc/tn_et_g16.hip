@@ -181,12 +181,6 @@ __device__ __forceinline__ G16Walk g16_walk(const Graph& g, const float* erec, i
   steps = slot ? G16_ROWS : longest;
   return w;
 }
-// every row of the tile has all its neighbours inside the tile?  (columns ascend within a row)
-__device__ __forceinline__ bool g16_row_closed(const Graph& g, int e0, int len, int tile0) {
-  if (len <= 0) return true;
-  return g.col[e0] >= tile0 && g.col[e0 + len - 1] < tile0 + G16_ROWS;
-}
-
 // ================================================================================================= forward
 // xagg[t,c] = sum_e sx * A_h ; vagg[t,a,c] = sum_e vec[s,a,c] * s1 + s2 * rhat_a
 struct FwdPair {  // what arrives from memory for one edge: the pair's filter rows and scalars (node rows come from LDS)
@@ -207,12 +201,14 @@ __global__ __launch_bounds__(1024, BF ? 8 : 4) void k_et_attn_fwd_g16(Graph g, E
   typedef typename std::conditional<BF, uint32_t, f2v>::type HalfT;
   constexpr bool MB = !BF;
   __shared__ __attribute__((aligned(16))) HalfT s_mb[MB ? 2 * 4 * G16_V : 4];
-  if (g.counts[2] || *a.tile_open) return;
+  if (g.counts[2] || a.tile_open[0]) return;
   const int F = a.F, nsl = F >> 5, hl = a.hd >> 1;
-  const int tile = (int)blockIdx.x / nsl, sl = (int)blockIdx.x - tile * nsl, tile0 = tile * G16_ROWS;
+  const int tile = (int)blockIdx.x / nsl, sl = (int)blockIdx.x - tile * nsl;
+  if (tile >= a.tile_open[1]) return;  // (the grid covers the largest possible number of tiles)
+  const int tile0 = a.tile_start[tile], nrows = a.tile_start[tile + 1] - tile0;  // whole molecules, at most 64 rows
   const int gl = threadIdx.x & 15, rl = (int)threadIdx.x >> 4;
   const int r = tile0 + rl;
-  const bool rowok = r < N;
+  const bool rowok = rl < nrows && r < N;
   const int rr = rowok ? r : N - 1;
   const int c = sl * 32 + gl * 2;
   const int e0 = g.rowptr[rr], len = rowok ? g.rowptr[rr + 1] - e0 : 0, e1 = e0 + len;
@@ -403,12 +399,14 @@ __global__ __launch_bounds__(1024) void k_et_attn_bwd_g16(Graph g, EtAttnArgs a,
   // the (distance, direction) sums of the last G16_RING steps wait here and leave in one burst: a store between two requests makes
   // the wait for the older request a wait for everything (loads and stores share one counter and retire out of order)
   __shared__ float s_ring[MB ? G16_RING * G16_ROWS * 4 : 4];
-  if (g.counts[2] || *a.tile_open) return;
+  if (g.counts[2] || a.tile_open[0]) return;
   const int F = a.F, nsl = F >> 5, hl = a.hd >> 1;
-  const int tile = (int)blockIdx.x / nsl, sl = (int)blockIdx.x - tile * nsl, tile0 = tile * G16_ROWS;
+  const int tile = (int)blockIdx.x / nsl, sl = (int)blockIdx.x - tile * nsl;
+  if (tile >= a.tile_open[1]) return;  // (the grid covers the largest possible number of tiles)
+  const int tile0 = a.tile_start[tile], nrows = a.tile_start[tile + 1] - tile0;  // whole molecules, at most 64 rows
   const int gl = threadIdx.x & 15, rl = (int)threadIdx.x >> 4;
   const int r = tile0 + rl;
-  const bool rowok = r < N;
+  const bool rowok = rl < nrows && r < N;
   const int rr = rowok ? r : N - 1;
   const int c = sl * 32 + gl * 2;
   const int e0 = g.rowptr[rr], len = rowok ? g.rowptr[rr + 1] - e0 : 0, e1 = e0 + len;
@@ -653,12 +651,68 @@ __global__ __launch_bounds__(1024) void k_et_attn_bwd_g16(Graph g, EtAttnArgs a,
   }
 }
 
-// *flag |= 1 when a row has a neighbour outside its tile of 64 rows (flag zeroed by the caller)
-__global__ void k_et_tile_open(Graph g, int N, int* __restrict__ flag) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= N || g.counts[2]) return;
-  const int e0 = g.rowptr[r], len = g.rowptr[r + 1] - e0;
-  if (!g16_row_closed(g, e0, len, (r / G16_ROWS) * G16_ROWS)) atomicOr(flag, 1);
+// ---- tiles = runs of WHOLE molecules of at most 64 rows (round 6, second step: a batch of molecules of any sizes <= 64 has closed
+// tiles, not only 64-atom molecules aligned to 64 rows).  One block: the rows at which a tile may start (first atom of a
+// molecule; row N) as a bitmap in LDS, then one wave packs greedily - tile after tile, the last allowed start within 64 rows.
+// meta[0] = 1 (open: the row sweeps run) when a molecule has more than 64 atoms, meta[1] = number of tiles, tile_start[0 .. n].
+constexpr int G16_BITMAP_WORDS = 8192;  // rows up to 64 * 8192 - 64
+__global__ __launch_bounds__(1024) void k_et_tile_pack(Graph g, const int64_t* __restrict__ batch, int N, int max_tiles, float min_fill,
+                                                      int* __restrict__ tile_start, int* __restrict__ meta) {
+  __shared__ unsigned long long s_b[G16_BITMAP_WORDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (g.counts[2] || g.counts[3] || N > 64 * G16_BITMAP_WORDS - 128) {  // (overflow / unsorted batch: the step fails anyway)
+    if (tid == 0) {
+      meta[0] = 1;
+      meta[1] = 0;
+    }
+    return;
+  }
+  const int nw = (N >> 6) + 2;
+  for (int wd = wave; wd < nw; wd += 16) {
+    const int r = wd * 64 + lane;
+    const bool ok = r == N || r == 0 || (r < N && batch && batch[r] != batch[r - 1]);  // (no batch vector: one molecule)
+    const unsigned long long bits = __ballot(ok);
+    if (lane == 0) s_b[wd] = bits;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  int s0 = 0, n = 0;
+  bool open = false;
+  while (s0 < N) {
+    const int lo = s0 + 1, wd = lo >> 6, sh = lo & 63;  // candidates lo .. lo + 63: bit k of the window = row lo + k
+    const unsigned long long win = (s_b[wd] >> sh) | (sh ? (s_b[wd + 1] << (64 - sh)) : 0ull);
+    int nxt;
+    if (win) {
+      nxt = lo + 63 - __clzll(win);
+    } else {  // a molecule of more than 64 atoms: not closed; keep a valid partition
+      nxt = s0 + G16_ROWS < N ? s0 + G16_ROWS : N;
+      open = true;
+    }
+    if (lane == 0) tile_start[n] = s0;
+    ++n;
+    s0 = nxt;
+  }
+  if (lane == 0) {
+    tile_start[n] = N;
+    meta[1] = n;
+    if (open || n > max_tiles) meta[0] = 1;  // (more tiles than the sweeps' grids cover cannot happen with closed tiles: n <= molecules)
+    // sparse tiles (small molecules, short cutoffs): the row sweeps are the faster generation - a ragged batch of 10 .. 64-atom
+    // molecules at half-full tiles measured 8.87 (rows) against 9.44 ms (tiles) with fp32 pair rows, 8.18 against 7.36 with bf16
+    if ((float)g.counts[1] < min_fill * (float)n * (float)(G16_ROWS * G16_ROWS)) meta[0] = 1;
+  }
+}
+// meta[0] |= 1 when a row has a neighbour outside its tile (one wave per tile; after k_et_tile_pack)
+__global__ __launch_bounds__(256) void k_et_tile_open(Graph g, int N, const int* __restrict__ tile_start, int* __restrict__ meta) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (g.counts[2] || meta[0] || t >= meta[1]) return;
+  const int t0 = tile_start[t], t1 = tile_start[t + 1];
+  const int r = t0 + lane;
+  bool bad = t1 - t0 > G16_ROWS;
+  if (!bad && r < t1) {
+    const int e0 = g.rowptr[r], len = g.rowptr[r + 1] - e0;
+    if (len > 0) bad = g.col[e0] < t0 || g.col[e0 + len - 1] >= t1;  // (columns ascend within a row)
+  }
+  if (bad) atomicOr(meta, 1);
 }
 // the per-edge records of the tile sweeps: everything an edge needs besides rows, in one 32-byte piece
 __global__ void k_et_edge_records(Graph g, const float* __restrict__ C, const float* __restrict__ dC, int64_t cap,
@@ -697,7 +751,7 @@ bool et_g16_ok(int N, int64_t P1, const EtAttnArgs& a) {
   static const bool off = getenv("TMDNET_ET_NO_G16") != nullptr;  // developer switch: the one-channel-per-lane kernels
   const int64_t lim = (int64_t)1 << 31;
   const int hd = a.hd;
-  return !off && a.tile_open && a.erec && a.F % 32 == 0 && a.F <= 1024 && (hd == 2 || hd == 4 || hd == 8 || hd == 16 || hd == 32) &&
+  return !off && a.tile_open && a.tile_start && a.max_tiles > 0 && a.erec && a.F % 32 == 0 && a.F <= 1024 && (hd == 2 || hd == 4 || hd == 8 || hd == 16 || hd == 32) &&
          (int64_t)N * 5 * a.F * 4 < lim && P1 * a.Wd * 4 < lim && (2 * P1 + N) * 32 < lim;
 }
 
@@ -717,7 +771,7 @@ bool et_g16_ok(int N, int64_t P1, const EtAttnArgs& a) {
   }
 #define G16_DISPATCH(KERNEL, ...)                                                                  \
   {                                                                                                \
-    const dim3 grid(((N + 63) / 64) * (a.F / 32)), block(1024);                                    \
+    const dim3 grid(a.max_tiles * (a.F / 32)), block(1024);                                    \
     const int key = (a.dk_off >= 0 ? 4 : 0) | (a.dv_off >= 0 ? 2 : 0) | (a.vector_cutoff ? 1 : 0); \
     const int se = g16_sync_every(), sm = g16_slot_min();                                          \
     if (a.hd == 16) {                                                                              \
@@ -727,11 +781,21 @@ bool et_g16_ok(int N, int64_t P1, const EtAttnArgs& a) {
     }                                                                                              \
   }
 
-void launch_et_tile_prep(const Graph& g, int N, const float* C, const float* dC, int64_t ecap, int* flag, float* erec,
-                         hipStream_t s) {
+int et_g16_max_tiles(int N, int B) {  // closed tiles hold whole molecules, and two consecutive tiles more than 64 rows
+  const int by_rows = 2 * ((N + G16_ROWS - 1) / G16_ROWS) + 1;
+  const int t = B < by_rows ? B : by_rows;
+  return t < 1 ? 1 : t;
+}
+void launch_et_tile_prep(const Graph& g, int N, int B, const int64_t* batch, const float* C, const float* dC, int64_t ecap, int pair_bf16,
+                         int* meta, int* tile_start, float* erec, hipStream_t s) {
   if (N <= 0) return;
-  launch_fill(reinterpret_cast<float*>(flag), 0.f, 1, s);
-  hipLaunchKernelGGL(k_et_tile_open, dim3((N + 255) / 256), dim3(256), 0, s, g, N, flag);
+  const int max_tiles = et_g16_max_tiles(N, B);
+  // directed edges per tile slot (64 x 64) below which the step takes the row sweeps (developer switch, in percent)
+  static const int fill_env = getenv("TMDNET_ET_G16_MIN_FILL") ? atoi(getenv("TMDNET_ET_G16_MIN_FILL")) : -1;
+  const float min_fill = fill_env >= 0 ? 0.01f * (float)fill_env : (pair_bf16 ? 0.25f : 0.70f);
+  launch_fill(reinterpret_cast<float*>(meta), 0.f, 2, s);
+  hipLaunchKernelGGL(k_et_tile_pack, dim3(1), dim3(1024), 0, s, g, batch, N, max_tiles, min_fill, tile_start, meta);
+  hipLaunchKernelGGL(k_et_tile_open, dim3((max_tiles + 3) / 4), dim3(256), 0, s, g, N, tile_start, meta);
   hipLaunchKernelGGL(k_et_edge_records, dim3((unsigned)((ecap + 255) / 256)), dim3(256), 0, s, g, C, dC, ecap, erec);
 }
 void launch_et_attn_fwd_g16(const Graph& g, int N, const EtAttnArgs& a_in, float* xagg, float* vagg, hipStream_t s) {
