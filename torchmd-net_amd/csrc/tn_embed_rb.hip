@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_embed_moments(Graph g, int N, RadialPar
       const float cc0 = c * c0;
       float psi[KS];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) psi[s] = cc0 * expf(-beta[s] * (u - mu[s]) * (u - mu[s]));
+      for (int s = 0; s < KS; ++s) psi[s] = cc0 * __expf(-beta[s] * (u - mu[s]) * (u - mu[s]));
       // the neighbour's species is wave-uniform (an SGPR): a scalar branch per species instead of NTP compare-and-adds
 #pragma unroll
       for (int tt = 0; tt < NTP; ++tt)

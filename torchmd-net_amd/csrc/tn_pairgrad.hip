@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_embed_pair_rb8(Graph g, RadialParams rp
   for (int q = 0; q < 8; ++q) {
     const int k = 8 * c8 + q;
     const float mu = rp.means[k], beta = rp.betas[k];
-    const float gk = expf(-beta * (u - mu) * (u - mu));
+    const float gk = __expf(-beta * (u - mu) * (u - mu));
     const float phi = c0 * gk, dphi = dc0 * gk + c0 * gk * (-2.0f * beta * (u - mu)) * (-alpha * u);
     add(c * phi, dc * phi + c * dphi, b[0][q], b[1][q], b[2][q], b[3][q], b[4][q], b[5][q], b[6][q], b[7][q], b[8][q], b[9][q]);
   }
