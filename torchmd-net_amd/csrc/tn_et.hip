@@ -47,7 +47,25 @@ __global__ void k_et_nbr_embed(Graph g, int N, int F, const int64_t* __restrict_
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   for (int c = threadIdx.x; c < F; c += blockDim.x) {
     float acc = 0.f;
-    for (int e = e0; e < e1; ++e) {
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) {  // four edges' rows in flight (the same sum in the same order; self edges contribute zero)
+      int j[4], p[4];
+      float w[4], m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        j[u] = g.col[e + u];
+        p[u] = g.epair[e + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        w[u] = Wn[(int64_t)p[u] * F + c];
+        m[u] = embN[z[j[u]] * F + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j[u] != i) acc += w[u] * m[u];
+    }
+    for (; e < e1; ++e) {
       const int j = g.col[e];
       if (j == i) continue;
       acc += Wn[(int64_t)g.epair[e] * F + c] * embN[z[j] * F + c];

@@ -179,7 +179,29 @@ __global__ void k_tn2_edge_pre1(Graph g, int N, int F, const float* __restrict__
   const int e0 = g.rowptr[i], e1 = g.rowptr[i + 1];
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
     const float bt = Bt[(int64_t)i * F + f];
-    for (int e = e0; e < e1; ++e) {
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) {  // four edges' rows in flight
+      int j[4], p[4];
+      float ap[4], cs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        j[u] = g.col[e + u];
+        p[u] = g.epair[e + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ap[u] = Ap[(int64_t)p[u] * F + f];
+        cs[u] = Cs[(int64_t)j[u] * F + f];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v = ap[u] + bt + cs[u];
+        pre1[(int64_t)(e + u) * F + f] = v;
+        he1[(int64_t)(e + u) * F + f] = silu(v);
+        if (f == 0) Ce[e + u] = C[p[u]];
+      }
+    }
+    for (; e < e1; ++e) {
       const int j = g.col[e], p = g.epair[e];
       const float v = Ap[(int64_t)p * F + f] + bt + Cs[(int64_t)j * F + f];
       pre1[(int64_t)e * F + f] = v;
