@@ -195,15 +195,23 @@ __global__ __launch_bounds__(BK_THREADS) void k_pair_cutoff_hist(Graph g, int Pc
 }
 // exclusive scan of the T + 1 bucket counts in place (one block), total -> hist[T + 1]
 __global__ __launch_bounds__(1024) void k_bucket_scan(int* __restrict__ hist, int nb) {
+  // tiles of 8192 counts: a thread scans 8 consecutive ones, one block scan of the 1024 thread sums, a carry links the tiles
+  // (one trip for the 8193 buckets of the default tables instead of nine trips of 1024: 11.5 -> about 5 us)
+  constexpr int PER = 8, TILE = 1024 * PER;
   __shared__ int wsum[16];
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry = 0;
   __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
-    const int i = base + tid;
-    const int v = i < nb ? hist[i] : 0;
-    int inc = v;
+  for (int base = 0; base < nb; base += TILE) {
+    int v[PER], sum = 0;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int i = base + tid * PER + r;
+      v[r] = i < nb ? hist[i] : 0;
+      sum += v[r];
+    }
+    int inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const int t = __shfl_up(inc, off, 64);
@@ -211,11 +219,16 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(int* __restrict__ hist, in
     }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    int pre = carry;
+    int pre = carry + inc - sum;
     for (int w = 0; w < wave; ++w) pre += wsum[w];
-    if (i < nb) hist[i] = pre + inc - v;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int i = base + tid * PER + r;
+      if (i < nb) hist[i] = pre;
+      pre += v[r];
+    }
     __syncthreads();
-    if (tid == 1023) carry = pre + inc;
+    if (tid == 1023) carry = pre;
     __syncthreads();
   }
   if (tid == 0) hist[nb] = carry;
