@@ -1,20 +1,22 @@
-// Attention sweeps of the Equivariant Transformer, third generation (round 6): a 16-lane group per (row atom, 32 channels), two
-// channels per lane, a workgroup = 64 consecutive rows x one 32-channel slice (reference torchmd_et.py:376-426 and its adjoint,
-// SURVEY Appendix D; same arithmetic per edge as k_et_attn_fwd_p / k_et_attn_bwd_p of tn_et.hip).
+// Attention sweeps of the Equivariant Transformer, third generation (round 6): TILE sweeps.  A workgroup = one tile (a run of whole
+// molecules of at most 64 rows, packed on the device every step: k_et_tile_pack) x one 32-channel slice; a 16-lane group per
+// (row atom, slice), two channels per lane (reference torchmd_et.py:376-426 and its adjoint; the arithmetic per
+// edge is that of the row sweeps k_et_attn_fwd_p / k_et_attn_bwd_p of tn_et.hip, which stay for systems whose tiles are not closed).
 //
-// Why (profiles/r06_notes.md, counters of the one-channel-per-lane kernels on ET-SPICE 256 x 64 atoms):
-//   * the reverse sweep was VALU-bound, not byte-bound: 203 vector instructions per edge and wave, the vector pipe busy 94 % of
-//     the kernel (SQ_ACTIVE_INST_VALU), which is why storing the pair rows as bf16 bought 8 % only.  A third of the stream was
-//     not arithmetic: 64-bit address pairs per load (34), register copies of the prefetched edge (26), full-precision divides in
-//     the two sigmoids (20), one head sum per CHANNEL lane (4 x 4 DPP steps).  With two channels per lane the products are
-//     v_pk_mul / v_pk_fma (two channels per instruction), a head of 16 channels is 8 lanes (one in-lane add + 3 DPP steps), the
-//     sigmoids are once per lane pair of channels, loads are 8 bytes per lane from a wave-uniform base + one 32-bit offset.
-//   * both directed edges of a pair fetched the pair's filter rows from memory (1.87 x the distinct bytes): the rows of a molecule
-//     ran as independent blocks that drift apart.  Here the 64 rows of a tile are ONE workgroup and walk their lists in the
-//     symmetric order (row + column) mod 64: the two rows of a pair reach it in the same step, on the same CU; a barrier every
-//     few steps bounds the drift, so the second request is served by the CU's L1 / the XCD's L2.
+// Why (profiles/r06_notes.md, counters of the row sweeps on ET-SPICE 256 x 64 atoms):
+//   * the reverse row sweep was VALU-bound, not byte-bound: 203 vector instructions per edge and wave, the vector pipe busy 94 % of
+//     the kernel, which is why storing the pair rows as bf16 had bought 8 % only.  A third of the stream was not arithmetic: 64-bit
+//     address pairs per load (34), register copies of the prefetched edge (26), IEEE divides in the two sigmoids (20), one head sum
+//     per CHANNEL lane (4 x 4 DPP steps).  Here the products are v_pk_mul / v_pk_fma (two channels per instruction), a head of 16
+//     channels is 8 lanes, the sigmoids are once per lane, loads come from a wave-uniform base + one 32-bit offset register;
+//   * two dependent request latencies per step (index -> row) at four waves per SIMD: the tile's node rows (12 values x 32 channels
+//     x 64 atoms = 98 KB; forward: 7 values) are staged in LDS once, and everything else an edge needs is one 32-byte record;
+//   * both directed edges of a pair fetched the pair's filter rows (1.87 x the distinct bytes): in tiles that are at least 3/4 full
+//     the rows walk in SLOT order - step `it` of row r is tile column (it - r) mod 64 - so the two rows of a pair are in the same
+//     step; with fp32 rows each requests half of the pair's rows and they swap through an LDS mailbox (1.10 x the distinct bytes).
 // A lane group owns its row's accumulators in registers (fixed order of edges: deterministic).  The distance / direction slots of
-// the reverse sweep are per 32-channel slice (et_sweep_waves = F / 32 arrays per pair direction).
+// the reverse sweep are per 32-channel slice (et_sweep_waves = F / 32 arrays per pair direction).  Which generation runs is a flag
+// on the device (k_et_tile_open: closed tiles; k_et_tile_pack: full enough to pay), both are enqueued, one returns at once.
 #include <cstdlib>
 #include <type_traits>
 
