@@ -241,6 +241,31 @@ def test_et_tile_sweeps_ragged_batch_vs_oracle(hip_lib):
             assert (F[sel.cuda()].cpu() - Fo).abs().max().item() < 1e-4 * max(1.0, Fo.abs().max().item()), (sizes, m)
 
 
+def test_et_tile_sweeps_replay_from_a_captured_graph(hip_lib):
+    """The tile generation is chosen on the device (no read-back), so a captured step keeps working when the positions - and with
+    them the neighbour lists inside the closed tiles - change between replays: three 64-atom molecules, static shapes."""
+    from torchmdnet_amd.models.model import create_model
+
+    args = dict(W.C4_ARGS, num_layers=2)
+    torch.manual_seed(4)
+    dyn = create_model(dict(args)).to("cuda")
+    sta = create_model(dict(args, static_shapes=True)).to("cuda")
+    sta.load_state_dict(dyn.state_dict())
+    z, pos, batch = (t.cuda() for t in W.synthetic_batch(n_mol=3, n_atoms=64, first_seed=40))
+    replay = sta.capture(z, pos, batch)
+    E0, F0 = replay()
+    Ed, Fd = dyn(z, pos, batch)
+    assert rel_err(E0, Ed) < 1e-5 and rel_err(F0, Fd) < 1e-5
+    assert dyn.debug_tensor("tile_meta", (2,)).view(torch.int32).cpu().tolist() == [0, 3]  # closed, three tiles
+    torch.manual_seed(1)
+    for scale in (0.05, 0.3):
+        pos2 = pos + scale * torch.randn_like(pos)
+        E2, F2 = replay(pos2)
+        E2, F2 = E2.clone(), F2.clone()
+        Er, Fr = dyn(z, pos2, batch)
+        assert rel_err(E2, Er) < 1e-5 and rel_err(F2, Fr) < 1e-5, scale
+
+
 def test_et_randomised_small_systems_vs_oracle(hip_lib, golden_dir):
     """single atoms, isolated atoms (only the self loop: vec stays zero -> the norm's zero-row mask), ragged sizes, unsorted
     batch vectors, periodic boxes; oracle = oracle/et_torch.py."""
